@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- pair-end 2x150 bp reads aligned/sec through the MI355X batched Smith-Waterman path.
+
+One step = one pass of the hot path over one synthetic batch of PAIRS_PER_STEP read pairs (BASELINE.json
+configs[2] shape: 2x150 bp, 1 % substitutions, 0.1 % indels, 10 % of pairs need mate rescue):
+  * boundary 2: the extension wire batches of those reads (<= 32768 reads per batch, as the reference's
+    run_test.sh uses -bSWExtSize 32768), device-resident, through bpsw_extend_batch_device;
+  * boundary 1: the SWAlign2 rescue jobs of those pairs, device-resident, through bpsw_swalign2_batch_device.
+Inputs are already in HBM when the timed region starts.  N>1: one process per GPU (torch.distributed over
+RCCL for the barrier and the max-over-ranks only; the path has no data-path collective), each rank
+aligns its own shard of pairs ("weak" scaling: Spark partition -> device).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "cloud-scale-bwamem_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+READ_LEN = 150
+READS_PER_EXT_BATCH = 32768       # reference: -bSWExtSize 32768 (run_test.sh:7); idx travels as int16
+EXT_BATCHES_PER_STEP = 4
+PAIRS_PER_STEP = READS_PER_EXT_BATCH * EXT_BATCHES_PER_STEP // 2   # 65536 pairs = 131072 reads
+RESCUE_JOBS_PER_PAIR = 0.11       # p_resc = 10 % (+ multi-anchor pairs), SURVEY.md 8(d) config 3
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_inputs(rank: int):
+    from bpsw_hip import synth, wire_pack
+    seed0 = synth.CONFIG_SEED_BASE + 3 + 1000 * rank
+    wires, ntasks = [], []
+    for b in range(EXT_BATCHES_PER_STEP):
+        soa = synth.ext_tasks(READS_PER_EXT_BATCH, read_len=READ_LEN, sub_rate=0.01, indel_rate=0.001, n_rate=0.001,
+                              seed=seed0 + b)
+        wires.append(wire_pack(soa))
+        ntasks.append(soa.n)
+    n_jobs = int(PAIRS_PER_STEP * RESCUE_JOBS_PER_PAIR)
+    jobs = synth.sw_jobs(n_jobs, read_len=READ_LEN, win_min=400, win_max=400, sub_rate=0.02, indel_rate=0.002,
+                         unrelated_frac=0.05, decoy_frac=0.1, rev_frac=1.0, seed=seed0 + 100)
+    return wires, ntasks, jobs
+
+
+def cpu_baseline(wires, ntasks, jobs, xtra):
+    """The oracle (scalar C restatement of the Scala SW path) on this box's host cores, one thread, on a
+    bounded sample of the same step: the first extension batch and the first 1500 rescue jobs."""
+    import pyoracle as po
+    orc = po.Oracle()
+    t0 = time.perf_counter()
+    _, cells_ext = orc.wire_extend(wires[0])
+    t_ext = time.perf_counter() - t0
+    ns = min(1500, len(jobs["q_len"]))
+    sub = dict(jobs)
+    for k in ("q_len", "t_len", "q_off", "t_off", "q_rev"):
+        sub[k] = jobs[k][:ns]
+    t0 = time.perf_counter()
+    _, cells_sw = orc.sw_align2_jobs(orc.default_opt(), xtra, **sub)
+    t_sw = time.perf_counter() - t0
+    # seconds of CPU per read of the step = extension share + rescue share
+    sec_per_read = t_ext / READS_PER_EXT_BATCH + (t_sw / ns) * len(jobs["q_len"]) / (2.0 * PAIRS_PER_STEP)
+    return {
+        "value": round(1.0 / sec_per_read, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+        "sample": f"{ntasks[0]} extension tasks ({READS_PER_EXT_BATCH} reads) in {t_ext:.2f}s + {ns} SWAlign2 jobs in {t_sw:.2f}s, "
+                  f"oracle/bpsw_oracle.c single thread; {cells_ext / t_ext / 1e9:.3f} / {cells_sw / t_sw / 1e9:.3f} GCUPS",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import bpsw_hip
+    import ctypes as C
+    ctx = bpsw_hip.Context(local_rank)  # no fallback: raises without a gfx950 device
+    opt = bpsw_hip.default_opt()
+    xtra = bpsw_hip.KSW_XSUBO | bpsw_hip.KSW_XSTART | bpsw_hip.KSW_XBYTE | 19   # MemSamPe.scala:1187-1189
+
+    wires, ntasks, jobs = build_inputs(rank)
+    # ---- make everything resident in HBM before the timed region ---------------------------------
+    d_wires = [torch.from_numpy(w).to(dev) for w in wires]
+    d_outs = [torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks]
+    d_jobs = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in jobs.items()}
+    n_jobs = int(jobs["q_len"].shape[0])
+    d_sw_out = torch.zeros((n_jobs, 7), dtype=torch.int32, device=dev)
+    sj = bpsw_hip.SwJobs()
+    sj.n, sj.xtra = n_jobs, xtra
+    for k in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool"):
+        setattr(sj, k, d_jobs[k].data_ptr())
+    sj.q_pool_bytes, sj.t_pool_bytes = d_jobs["q_pool"].numel(), d_jobs["t_pool"].numel()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    ext_ms_sum, sw_ms_sum, ext_launches, sw_launches = 0.0, 0.0, 0, 0
+
+    def step(timed: bool):
+        nonlocal ext_ms_sum, sw_ms_sum, ext_launches, sw_launches
+        for w, n, dw, do in zip(wires, ntasks, d_wires, d_outs):
+            ctx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), stream)
+            e, _ = ctx.last_kernel_ms()     # HIP events on the launch stream, recorded inside the library
+            if timed:
+                ext_ms_sum += e
+                ext_launches += 1
+        ctx.swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), stream)
+        _, s = ctx.last_kernel_ms()
+        if timed:
+            sw_ms_sum += s
+            sw_launches += 1
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    reads_total = 2 * PAIRS_PER_STEP * args.steps * world
+    value = reads_total / elapsed
+
+    # ---- roofline of the dominant kernel (algorithmic bytes: DESIGN.md) -------------
+    ext_bytes = sum(int(w.size) + 20 * n for w, n in zip(wires, ntasks)) / len(wires)          # per launch
+    sw_bytes = float(jobs["q_len"].sum() + jobs["t_len"].sum() + 28 * n_jobs)                  # per launch
+    ext_avg_ms = ext_ms_sum / max(ext_launches, 1)
+    sw_avg_ms = sw_ms_sum / max(sw_launches, 1)
+    dominant = "extend" if ext_ms_sum >= sw_ms_sum else "swalign2"
+    dom_bytes, dom_ms = (ext_bytes, ext_avg_ms) if dominant == "extend" else (sw_bytes, sw_avg_ms)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(dominant)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "pair-end 2x150bp reads aligned/sec",
+        "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "configs[2]: pair-end 2x150bp synthetic reads (1% sub, 0.1% indel), batched seed "
+                               "extension + batched pair-end SW rescue (10% of pairs), 1 MI355X per rank",
+                   "pairs_per_step_per_gpu": PAIRS_PER_STEP, "ext_tasks_per_step": int(sum(ntasks)),
+                   "rescue_jobs_per_step": n_jobs, "parallelism": f"partition->device x{world} (no collective)"},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
+        "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes)},
+                    "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes)}},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wires, ntasks, jobs, xtra)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

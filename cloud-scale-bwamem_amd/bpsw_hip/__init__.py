@@ -1,0 +1,343 @@
+"""ctypes harness over the C ABI of libbPSW_hip.so (include/bpsw.h).
+
+The product is the shared library; this package only lets the JVM-free tests and bench.py drive the
+same entry points the JNI shim calls.  It never computes alignments itself and has no fallback: if the
+HIP library is missing or no gfx950 device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libbPSW_hip.so")
+SYNTH_PATH = os.path.join(PKG_ROOT, "lib", "libbpsw_synth.so")
+
+BPSW_OK = 0
+ZDROP_SCALA, ZDROP_BWA = 0, 1
+RESCUE_C, RESCUE_SCALA = 0, 1
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+
+# every symbol include/bpsw.h declares (tests check the built library exports all of them)
+ABI_SYMBOLS = [
+    "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_last_error", "bpsw_version",
+    "bpsw_set_ext_scoring", "bpsw_extend_batch", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
+    "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group",
+    "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
+]
+JNI_SYMBOLS = [
+    "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI",
+    "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI",
+    "Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld",
+]
+
+
+class BpswError(RuntimeError):
+    pass
+
+
+class AlnReg(C.Structure):  # bpsw_alnreg_t
+    _fields_ = [("rb", C.c_int64), ("re", C.c_int64), ("qb", C.c_int32), ("qe", C.c_int32), ("score", C.c_int32),
+                ("truesc", C.c_int32), ("sub", C.c_int32), ("csub", C.c_int32), ("sub_n", C.c_int32), ("w", C.c_int32),
+                ("seedcov", C.c_int32), ("secondary", C.c_int32), ("hash", C.c_uint64)]
+
+
+ALNREG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"),
+                         ("truesc", "<i4"), ("sub", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"), ("w", "<i4"),
+                         ("seedcov", "<i4"), ("secondary", "<i4"), ("hash", "<u8")])
+assert ALNREG_DTYPE.itemsize == 64 and C.sizeof(AlnReg) == 64
+
+
+class PeStat(C.Structure):  # bpsw_pestat_t
+    _fields_ = [("low", C.c_int32), ("high", C.c_int32), ("failed", C.c_int32), ("pad_", C.c_int32),
+                ("avg", C.c_double), ("std", C.c_double)]
+
+
+class Opt(C.Structure):  # bpsw_opt_t
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_unpaired", "pen_clip5",
+                                         "pen_clip3", "w", "zdrop", "T", "flag", "min_seed_len", "max_ins",
+                                         "max_matesw")] + [("mask_level_redun", C.c_float), ("mat", C.c_int8 * 25),
+                                                           ("pad_", C.c_int8 * 3)]
+
+
+class ExtTasks(C.Structure):  # bpsw_ext_tasks_t
+    _fields_ = [("n", C.c_int32)] + [(n, C.c_int32) for n in ("o_del", "e_del", "o_ins", "e_ins", "pen_clip5",
+                                                                "pen_clip3", "w", "mat_max")] + \
+               [(n, C.c_void_p) for n in ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "left_q_off",
+                                          "left_r_off", "right_q_off", "right_r_off", "reg_score", "q_beg", "h0", "idx",
+                                          "pool")]
+
+
+class SwJobs(C.Structure):  # bpsw_sw_jobs_t
+    _fields_ = [("n", C.c_int32), ("xtra", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool")] + \
+               [("q_pool_bytes", C.c_size_t), ("t_pool_bytes", C.c_size_t)]
+
+
+class RescueGroup(C.Structure):  # bpsw_rescue_group_t
+    _fields_ = [("group_size", C.c_int32), ("l_pac", C.c_int64), ("pes", PeStat * 4), ("seq_len", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq_pool", C.c_void_p), ("seq_pool_bytes", C.c_size_t),
+                ("reg_cnt", C.c_void_p), ("regs", C.c_void_p), ("ref_cnt", C.c_void_p), ("ref_rb", C.c_void_p),
+                ("ref_re", C.c_void_p), ("ref_len", C.c_void_p), ("ref_off", C.c_void_p), ("ref_pool", C.c_void_p),
+                ("ref_pool_bytes", C.c_size_t)]
+
+
+class Stats(C.Structure):  # bpsw_stats_t
+    _fields_ = [(n, C.c_uint64) for n in ("ext_calls", "ext_tasks", "ext_wire_bytes", "sw_calls", "sw_jobs",
+                                          "sw_speculated", "sw_replayed_rounds", "sw_wasted")] + \
+               [(n, C.c_double) for n in ("ext_h2d_ms", "ext_kernel_ms", "ext_d2h_ms", "sw_h2d_ms", "sw_kernel_ms",
+                                          "sw_d2h_ms", "sw_host_ms")]
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Load libbPSW_hip.so; fails loudly when it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise BpswError(f"{p} not found: build it with `make -C {PKG_ROOT}` (or __graft_entry__.build())")
+    if os.environ.get("BPSW_NO_TORCH") != "1":
+        # The PyTorch wheel bundles its own libamdhip64.so.7 / libhsa-runtime64; a process must initialise only
+        # one HIP runtime.  Loading torch first makes this library bind to the runtime torch uses, so device
+        # pointers and streams can be shared (bench.py, device-resident tests).  Under the JVM there is no
+        # torch and the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(p)
+    lib.bpsw_last_error.restype = C.c_char_p
+    lib.bpsw_version.restype = C.c_char_p
+    lib.bpsw_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.bpsw_destroy.argtypes = [C.c_void_p]
+    lib.bpsw_destroy.restype = None
+    lib.bpsw_device_of.argtypes = [C.c_void_p]
+    lib.bpsw_set_ext_scoring.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.bpsw_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.bpsw_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bpsw_wire_size.argtypes = [C.POINTER(ExtTasks)]
+    lib.bpsw_wire_size.restype = C.c_size_t
+    lib.bpsw_wire_pack.argtypes = [C.POINTER(ExtTasks), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.bpsw_opt_default.argtypes = [C.POINTER(Opt)]
+    lib.bpsw_opt_default.restype = None
+    lib.bpsw_swalign2_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(SwJobs), C.c_void_p]
+    lib.bpsw_swalign2_batch_device.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(SwJobs), C.c_void_p, C.c_void_p]
+    lib.bpsw_matesw_group.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(RescueGroup), C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.bpsw_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    lib.bpsw_reset_stats.argtypes = [C.c_void_p]
+    lib.bpsw_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(lib, rc, what):
+    if rc != BPSW_OK:
+        raise BpswError(f"{what} failed ({rc}): {lib.bpsw_last_error().decode()}")
+
+
+def default_opt() -> Opt:
+    o = Opt()
+    load_library().bpsw_opt_default(C.byref(o))
+    return o
+
+
+@dataclass
+class ExtTaskSoA:
+    """ExtParam fields (datatype/ExtensionParameters.scala:21-45) in struct-of-arrays form."""
+    left_qlen: np.ndarray
+    left_rlen: np.ndarray
+    right_qlen: np.ndarray
+    right_rlen: np.ndarray
+    left_q_off: np.ndarray
+    left_r_off: np.ndarray
+    right_q_off: np.ndarray
+    right_r_off: np.ndarray
+    reg_score: np.ndarray
+    q_beg: np.ndarray
+    h0: np.ndarray
+    idx: np.ndarray
+    pool: np.ndarray
+    o_del: int = 6
+    e_del: int = 1
+    o_ins: int = 6
+    e_ins: int = 1
+    pen_clip5: int = 5
+    pen_clip3: int = 5
+    w: int = 100
+    mat_max: int = 1
+
+    @property
+    def n(self) -> int:
+        return int(self.left_qlen.shape[0])
+
+    def subset(self, sel) -> "ExtTaskSoA":
+        kw = {k: getattr(self, k)[sel] for k in ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "left_q_off",
+                                                  "left_r_off", "right_q_off", "right_r_off", "reg_score", "q_beg",
+                                                  "h0", "idx")}
+        return ExtTaskSoA(pool=self.pool, o_del=self.o_del, e_del=self.e_del, o_ins=self.o_ins, e_ins=self.e_ins,
+                          pen_clip5=self.pen_clip5, pen_clip3=self.pen_clip3, w=self.w, mat_max=self.mat_max,
+                          **{k: np.ascontiguousarray(v) for k, v in kw.items()})
+
+    def as_struct(self) -> ExtTasks:
+        t = ExtTasks()
+        t.n = self.n
+        for f in ("o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "w", "mat_max"):
+            setattr(t, f, int(getattr(self, f)))
+        for f in ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "reg_score", "q_beg", "h0", "idx"):
+            a = getattr(self, f)
+            assert a.dtype == np.int32 and a.flags.c_contiguous
+            setattr(t, f, a.ctypes.data)
+        for f in ("left_q_off", "left_r_off", "right_q_off", "right_r_off"):
+            a = getattr(self, f)
+            assert a.dtype == np.int64 and a.flags.c_contiguous
+            setattr(t, f, a.ctypes.data)
+        assert self.pool.dtype == np.uint8
+        t.pool = self.pool.ctypes.data
+        return t
+
+
+def wire_pack(tasks: ExtTaskSoA) -> np.ndarray:
+    """Mirror of runOnFPGAJNI's packing (MemChainToAlignBatched.scala:76-172) -> the JNI byte[]."""
+    lib = load_library()
+    st = tasks.as_struct()
+    size = lib.bpsw_wire_size(C.byref(st))
+    buf = np.zeros(size, dtype=np.uint8)
+    used = C.c_size_t(0)
+    _chk(lib, lib.bpsw_wire_pack(C.byref(st), _ptr(buf), size, C.byref(used)), "bpsw_wire_pack")
+    return buf[: used.value]
+
+
+class Context:
+    """One bpsw_ctx_t: a device, a stream and its arenas."""
+
+    def __init__(self, device: int = -1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _chk(self.lib, self.lib.bpsw_create(device, C.byref(h)), "bpsw_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.bpsw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device(self) -> int:
+        return self.lib.bpsw_device_of(self.h)
+
+    def set_ext_scoring(self, mat=None, zdrop: int = 100, zdrop_mode: int = ZDROP_SCALA):
+        m = None if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
+        _chk(self.lib, self.lib.bpsw_set_ext_scoring(self.h, _ptr(m), zdrop, zdrop_mode), "bpsw_set_ext_scoring")
+
+    # boundary 2 ------------------------------------------------------------------------------
+    def extend_batch(self, wire: np.ndarray) -> np.ndarray:
+        """swExtendFPGAJNI(n*10, wire) -> int16[10*n]"""
+        wire = np.ascontiguousarray(wire, dtype=np.uint8)
+        n = int(np.frombuffer(wire[8:12].tobytes(), dtype="<i4")[0]) if wire.size >= 12 else 0
+        out = np.zeros(max(10 * n, 1), dtype=np.int16)
+        _chk(self.lib, self.lib.bpsw_extend_batch(self.h, _ptr(wire), wire.size, _ptr(out), out.size), "bpsw_extend_batch")
+        return out[: 10 * n]
+
+    def extend_batch_device(self, d_wire_ptr: int, wire_bytes: int, n_tasks: int, d_out_ptr: int, stream: int = 0):
+        _chk(self.lib, self.lib.bpsw_extend_batch_device(self.h, C.c_void_p(d_wire_ptr), wire_bytes, n_tasks,
+                                                        C.c_void_p(d_out_ptr), C.c_void_p(stream)),
+             "bpsw_extend_batch_device")
+
+    # boundary 1 ------------------------------------------------------------------------------
+    def swalign2_batch(self, opt: Opt, xtra: int, q_len, t_len, q_off, t_off, q_rev, q_pool, t_pool) -> np.ndarray:
+        j = SwJobs()
+        arrs = dict(q_len=np.ascontiguousarray(q_len, np.int32), t_len=np.ascontiguousarray(t_len, np.int32),
+                    q_off=np.ascontiguousarray(q_off, np.int64), t_off=np.ascontiguousarray(t_off, np.int64),
+                    q_rev=np.ascontiguousarray(q_rev, np.uint8), q_pool=np.ascontiguousarray(q_pool, np.uint8),
+                    t_pool=np.ascontiguousarray(t_pool, np.uint8))
+        j.n = int(arrs["q_len"].shape[0])
+        j.xtra = int(xtra)
+        for k, a in arrs.items():
+            setattr(j, k, a.ctypes.data)
+        j.q_pool_bytes = arrs["q_pool"].size
+        j.t_pool_bytes = arrs["t_pool"].size
+        out = np.zeros((max(j.n, 1), 7), dtype=np.int32)
+        _chk(self.lib, self.lib.bpsw_swalign2_batch(self.h, C.byref(opt), C.byref(j), _ptr(out)), "bpsw_swalign2_batch")
+        return out[: j.n]
+
+    def swalign2_batch_device(self, opt: Opt, jobs: SwJobs, d_out_ptr: int, stream: int = 0):
+        _chk(self.lib, self.lib.bpsw_swalign2_batch_device(self.h, C.byref(opt), C.byref(jobs), C.c_void_p(d_out_ptr),
+                                                          C.c_void_p(stream)), "bpsw_swalign2_batch_device")
+
+    def matesw_group(self, opt: Opt, g: "RescueGroupSoA", mode: int = RESCUE_C):
+        st = g.as_struct()
+        out_cnt = np.zeros(2 * g.group_size, dtype=np.int32)
+        cap = int(g.regs.shape[0] + 4 * g.ref_rb.shape[0] + 16)
+        out = np.zeros(cap, dtype=ALNREG_DTYPE)
+        total = C.c_int64(0)
+        _chk(self.lib, self.lib.bpsw_matesw_group(self.h, C.byref(opt), C.byref(st), mode, _ptr(out_cnt), _ptr(out), cap,
+                                                 C.byref(total)), "bpsw_matesw_group")
+        return out_cnt, out[: total.value]
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _chk(self.lib, self.lib.bpsw_get_stats(self.h, C.byref(s)), "bpsw_get_stats")
+        return s
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _chk(self.lib, self.lib.bpsw_last_kernel_ms(self.h, C.byref(a), C.byref(b)), "bpsw_last_kernel_ms")
+        return a.value, b.value
+
+
+@dataclass
+class RescueGroupSoA:
+    """The arguments of MateSWJNI.mateSWJNI (MemSamPe.scala:2091-2092) flattened; see include/bpsw.h."""
+    group_size: int
+    l_pac: int
+    pes: list  # 4 x (low, high, failed, avg, std)
+    seq_len: np.ndarray
+    seq_off: np.ndarray
+    seq_pool: np.ndarray
+    reg_cnt: np.ndarray
+    regs: np.ndarray  # ALNREG_DTYPE
+    ref_cnt: np.ndarray
+    ref_rb: np.ndarray
+    ref_re: np.ndarray
+    ref_len: np.ndarray
+    ref_off: np.ndarray
+    ref_pool: np.ndarray
+
+    def as_struct(self) -> RescueGroup:
+        g = RescueGroup()
+        g.group_size = self.group_size
+        g.l_pac = self.l_pac
+        for r in range(4):
+            lo, hi, failed, avg, std = self.pes[r]
+            g.pes[r].low, g.pes[r].high, g.pes[r].failed, g.pes[r].avg, g.pes[r].std = int(lo), int(hi), int(failed), float(avg), float(std)
+        for f, dt in (("seq_len", np.int32), ("seq_off", np.int64), ("seq_pool", np.uint8), ("reg_cnt", np.int32),
+                      ("ref_cnt", np.int32), ("ref_rb", np.int64), ("ref_re", np.int64), ("ref_len", np.int64),
+                      ("ref_off", np.int64), ("ref_pool", np.uint8)):
+            a = getattr(self, f)
+            assert a.dtype == dt and a.flags.c_contiguous, f
+            setattr(g, f, a.ctypes.data)
+        assert self.regs.dtype == ALNREG_DTYPE
+        g.regs = self.regs.ctypes.data
+        g.seq_pool_bytes = self.seq_pool.size
+        g.ref_pool_bytes = self.ref_pool.size
+        return g

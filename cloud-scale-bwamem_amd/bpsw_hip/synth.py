@@ -1,0 +1,233 @@
+"""Seeded synthetic workloads (ctypes over libbpsw_synth.so, csrc/bpsw_synth.cpp).
+
+Concretises the BASELINE.json configs the way SURVEY.md 8(d) lays out; inputs only, never measured.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import SYNTH_PATH, ExtTaskSoA, BpswError
+
+CONFIG_SEED_BASE = 0xB5A30000  # seed = 0xB5A3_0000 + config#
+
+
+class _ExtCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_int32), ("read_len", C.c_int32), ("sub_rate", C.c_double),
+                ("indel_rate", C.c_double), ("n_rate", C.c_double), ("tail_frac", C.c_double),
+                ("tail_sub_rate", C.c_double), ("tail_indel_rate", C.c_double)] + \
+               [(n, C.c_int32) for n in ("a", "o_del", "e_del", "o_ins", "e_ins", "w", "min_seed_len", "second_seed")]
+
+
+class _SwCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_jobs", C.c_int32), ("read_len", C.c_int32), ("win_min", C.c_int32),
+                ("win_max", C.c_int32), ("sub_rate", C.c_double), ("indel_rate", C.c_double), ("n_rate", C.c_double),
+                ("unrelated_frac", C.c_double), ("decoy_frac", C.c_double), ("rev_frac", C.c_double)]
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SYNTH_PATH):
+            raise BpswError(f"{SYNTH_PATH} not found: run `make -C {os.path.dirname(os.path.dirname(SYNTH_PATH))}`")
+        _lib = C.CDLL(SYNTH_PATH)
+        _lib.bpsw_synth_ext_tasks.restype = C.c_int
+        _lib.bpsw_synth_sw_jobs.restype = C.c_int
+    return _lib
+
+
+def ext_tasks(n_reads: int, read_len: int = 150, sub_rate: float = 0.01, indel_rate: float = 0.001,
+              n_rate: float = 0.001, tail_frac: float = 0.0, tail_sub_rate: float = 0.2, tail_indel_rate: float = 0.02,
+              seed: int = CONFIG_SEED_BASE + 3, second_seed: bool = True) -> ExtTaskSoA:
+    """Extension tasks for `n_reads` synthetic reads (default = config-3 error model, 2x150 bp)."""
+    lib = _load()
+    cfg = _ExtCfg(seed=seed, n_reads=n_reads, read_len=read_len, sub_rate=sub_rate, indel_rate=indel_rate,
+                  n_rate=n_rate, tail_frac=tail_frac, tail_sub_rate=tail_sub_rate, tail_indel_rate=tail_indel_rate,
+                  a=1, o_del=6, e_del=1, o_ins=6, e_ins=1, w=100, min_seed_len=19, second_seed=int(second_seed))
+    cap = 2 * n_reads + 1
+    i32 = lambda: np.zeros(cap, dtype=np.int32)
+    i64 = lambda: np.zeros(cap, dtype=np.int64)
+    f = dict(left_qlen=i32(), left_rlen=i32(), right_qlen=i32(), right_rlen=i32(), left_q_off=i64(), left_r_off=i64(),
+             right_q_off=i64(), right_r_off=i64(), reg_score=i32(), q_beg=i32(), h0=i32(), idx=i32())
+    pool_cap = int(cap) * (4 * read_len + 16)
+    pool = np.zeros(pool_cap, dtype=np.uint8)
+    used = C.c_size_t(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = lib.bpsw_synth_ext_tasks(C.byref(cfg), vp(f["left_qlen"]), vp(f["left_rlen"]), vp(f["right_qlen"]),
+                                 vp(f["right_rlen"]), vp(f["left_q_off"]), vp(f["left_r_off"]), vp(f["right_q_off"]),
+                                 vp(f["right_r_off"]), vp(f["reg_score"]), vp(f["q_beg"]), vp(f["h0"]), vp(f["idx"]),
+                                 vp(pool), C.c_size_t(pool_cap), C.byref(used))
+    if n < 0:
+        raise BpswError("synthetic pool too small")
+    return ExtTaskSoA(pool=pool[: max(used.value, 1)].copy(), **{k: v[:n].copy() for k, v in f.items()})
+
+
+def sw_jobs(n_jobs: int, read_len: int = 150, win_min: int = 450, win_max: int = 750, sub_rate: float = 0.02,
+            indel_rate: float = 0.002, n_rate: float = 0.001, unrelated_frac: float = 0.25, decoy_frac: float = 0.5,
+            rev_frac: float = 0.5, seed: int = CONFIG_SEED_BASE + 3):
+    """SWAlign2 jobs (mate vs rescue window).  Returns dict of arrays for Context.swalign2_batch."""
+    lib = _load()
+    cfg = _SwCfg(seed=seed, n_jobs=n_jobs, read_len=read_len, win_min=win_min, win_max=win_max, sub_rate=sub_rate,
+                 indel_rate=indel_rate, n_rate=n_rate, unrelated_frac=unrelated_frac, decoy_frac=decoy_frac,
+                 rev_frac=rev_frac)
+    q_len = np.zeros(n_jobs, np.int32)
+    t_len = np.zeros(n_jobs, np.int32)
+    q_off = np.zeros(n_jobs, np.int64)
+    t_off = np.zeros(n_jobs, np.int64)
+    q_rev = np.zeros(n_jobs, np.uint8)
+    q_cap = n_jobs * (read_len + 16) + 16
+    t_cap = n_jobs * (read_len + win_max + 16) + 16
+    q_pool = np.zeros(q_cap, np.uint8)
+    t_pool = np.zeros(t_cap, np.uint8)
+    qu, tu = C.c_size_t(0), C.c_size_t(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = lib.bpsw_synth_sw_jobs(C.byref(cfg), vp(q_len), vp(t_len), vp(q_off), vp(t_off), vp(q_rev), vp(q_pool),
+                               C.c_size_t(q_cap), vp(t_pool), C.c_size_t(t_cap), C.byref(qu), C.byref(tu))
+    if n < 0:
+        raise BpswError("synthetic pool too small")
+    return dict(q_len=q_len, t_len=t_len, q_off=q_off, t_off=t_off, q_rev=q_rev, q_pool=q_pool[: max(qu.value, 16)].copy(),
+                t_pool=t_pool[: max(tu.value, 16)].copy())
+
+
+# ---------------------------------------------------------------------------------------------------
+# Boundary-1 groups: what memSamPeGroupJNIPrepare (MemSamPe.scala:1895-2000) hands to MateSWJNI.mateSWJNI
+# ---------------------------------------------------------------------------------------------------
+def _revcomp(a: np.ndarray) -> np.ndarray:
+    r = a[::-1]
+    return np.where(r < 4, 3 - r, 4).astype(np.uint8)
+
+
+def _mutate(rng, seq: np.ndarray, sub: float, indel: float) -> np.ndarray:
+    out = []
+    i = 0
+    L = len(seq)
+    while len(out) < L and i < L:
+        u = rng.random()
+        if u < indel / 2:
+            out.append(int(rng.integers(0, 4)))
+        elif u < indel:
+            i += 1
+        elif u < indel + sub:
+            out.append(int((seq[i] + 1 + rng.integers(0, 3)) & 3))
+            i += 1
+        else:
+            out.append(int(seq[i]))
+            i += 1
+    while len(out) < L:
+        out.append(int(rng.integers(0, 4)))
+    return np.array(out[:L], dtype=np.uint8)
+
+
+def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE + 3, l_pac: int = 46_709_983,
+                 p_resc: float = 0.10, all_orientations: bool = False, sub_rate: float = 0.02, indel_rate: float = 0.002,
+                 p_multi_anchor: float = 0.10, p_wrong_mate: float = 0.05, max_matesw: int = 100, pen_unpaired: int = 17):
+    """Synthetic pair-end group (FR library, insert ~ N(400, 50^2)) in the flat layout of include/bpsw.h.
+
+    Each pair has an anchor on one end; with probability p_resc the mate has no consistent hit, so the
+    reference's mem_matesw would run SWAlign2 on the rescue window (which contains the mutated mate).
+    """
+    from . import RescueGroupSoA, ALNREG_DTYPE
+    rng = np.random.default_rng(seed)
+    L = read_len
+    avg, std = 400.0, 50.0
+    low, high = int(avg - 4 * std), int(avg + 4 * std)  # 200 .. 600
+    if all_orientations:  # exercise the non-reversed orientations too (never the case for Illumina FR data)
+        pes = [(low, high, 0, avg, std), (low, high, 0, avg, std), (low - 50, high - 50, 0, avg, std), (low, high + 40, 0, avg, std)]
+    else:
+        pes = [(0, 0, 1, 0.0, 0.0), (low, high, 0, avg, std), (0, 0, 1, 0.0, 0.0), (0, 0, 1, 0.0, 0.0)]
+
+    seq_len, seq_off, seq_chunks = [], [], []
+    reg_cnt, regs, ref_cnt = [], [], []
+    ref_rb, ref_re, ref_len, ref_off, ref_chunks = [], [], [], [], []
+    seq_at = 0
+    ref_at = 0
+
+    def add_seq(s):
+        nonlocal seq_at
+        seq_len.append(len(s)); seq_off.append(seq_at); seq_chunks.append(s)
+        pad = (-len(s)) % 16
+        if pad:
+            seq_chunks.append(np.zeros(pad, np.uint8))
+        seq_at += len(s) + pad
+
+    def mk_reg(rb, score, qb=0, qe=None):
+        qe = L if qe is None else qe
+        return (rb, rb + (qe - qb), qb, qe, score, score, 0, 0, 0, 100, (qe - qb) // 2, -1, int(rng.integers(0, 2 ** 62)))
+
+    def window_for(anchor_rb, r, mate_len):  # getAlnRegRefJNI, MemSamPe.scala:1810-1878
+        lo, hi, failed = pes[r][0], pes[r][1], pes[r][2]
+        if failed:
+            return -1, -1
+        is_rev = (r >> 1) != (r & 1)
+        is_larger = (r >> 1) == 0
+        if not is_rev:
+            rb = anchor_rb + lo if is_larger else anchor_rb - hi
+            re = (anchor_rb + hi if is_larger else anchor_rb - lo) + mate_len
+        else:
+            rb = (anchor_rb + lo if is_larger else anchor_rb - hi) - mate_len
+            re = anchor_rb + hi if is_larger else anchor_rb - lo
+        return max(rb, 0), min(re, 2 * l_pac)
+
+    for k in range(n_pairs):
+        P = int(rng.integers(2000, l_pac - 3000))
+        ins = int(np.clip(rng.normal(avg, std), low + 20, high - 20))
+        clean = [rng.integers(0, 4, L).astype(np.uint8), rng.integers(0, 4, L).astype(np.uint8)]  # forward-strand loci
+        reads = [_mutate(rng, clean[0], sub_rate, indel_rate), _revcomp(_mutate(rng, clean[1], sub_rate, indel_rate))]
+        true_rb = [P, 2 * l_pac - (P + ins)]  # end 0 forward at P; end 1 on the reverse strand
+        u = rng.random()
+        have = [True, True]
+        if u < p_resc:
+            have[int(rng.integers(0, 2))] = False
+        ends_regs = [[], []]
+        for i in range(2):
+            if have[i]:
+                ends_regs[i].append(mk_reg(true_rb[i], L - int(rng.integers(0, 8))))
+                if rng.random() < p_multi_anchor:  # a near-duplicate anchor a few bases away (overlapping hit)
+                    ends_regs[i].append(mk_reg(true_rb[i] + int(rng.integers(1, 4)), ends_regs[i][0][4] - int(rng.integers(0, pen_unpaired))))
+                if rng.random() < 0.15:  # a weak, far-away secondary hit below the anchor threshold
+                    ends_regs[i].append(mk_reg(int(rng.integers(0, 2 * l_pac - L)), ends_regs[i][0][4] - pen_unpaired - 5, 10, L - 20))
+            elif rng.random() < p_wrong_mate:
+                ends_regs[i].append(mk_reg(int(rng.integers(0, 2 * l_pac - L)), L // 2, 0, L // 2 + 10))
+            ends_regs[i].sort(key=lambda t: -t[4])
+        for i in range(2):
+            add_seq(reads[i])
+        for i in range(2):
+            rl = ends_regs[i]
+            reg_cnt.append(len(rl)); regs.extend(rl)
+            anchors = [t for t in rl if t[4] >= rl[0][4] - pen_unpaired][:max_matesw] if rl else []
+            ref_cnt.append(len(anchors))
+            mate = 1 - i
+            for a in anchors:
+                for r in range(4):
+                    rb, re = window_for(a[0], r, L)
+                    if rb < 0 and re < 0:
+                        ref_rb.append(-1); ref_re.append(-1); ref_len.append(0); ref_off.append(0)
+                        continue
+                    n = max(re - rb, 0)
+                    w = rng.integers(0, 4, n).astype(np.uint8)
+                    # where the mate truly lies in this window (only for the FR orientation of a true anchor)
+                    if r == 1 and abs(a[0] - true_rb[i]) < 8 and n >= L:
+                        off = (true_rb[i] + ins - L) - rb if i == 0 else (true_rb[i] + ins - L) - rb
+                        # window is on the anchor's strand; the mate lies `ins - L` past the anchor start
+                        off = (a[0] - rb) + (ins - L) + (true_rb[i] - a[0])
+                        if 0 <= off <= n - L:
+                            w[off:off + L] = clean[mate] if i == 0 else _revcomp(clean[mate])
+                    ref_rb.append(rb); ref_re.append(re); ref_len.append(n); ref_off.append(ref_at)
+                    ref_chunks.append(w)
+                    pad = (-n) % 16
+                    if pad:
+                        ref_chunks.append(np.zeros(pad, np.uint8))
+                    ref_at += n + pad
+
+    regs_arr = np.array(regs, dtype=ALNREG_DTYPE) if regs else np.zeros(0, ALNREG_DTYPE)
+    cat = lambda ch: np.concatenate(ch) if ch else np.zeros(16, np.uint8)
+    return RescueGroupSoA(group_size=n_pairs, l_pac=l_pac, pes=pes, seq_len=np.array(seq_len, np.int32),
+                          seq_off=np.array(seq_off, np.int64), seq_pool=cat(seq_chunks), reg_cnt=np.array(reg_cnt, np.int32),
+                          regs=regs_arr, ref_cnt=np.array(ref_cnt, np.int32), ref_rb=np.array(ref_rb, np.int64),
+                          ref_re=np.array(ref_re, np.int64), ref_len=np.array(ref_len, np.int64),
+                          ref_off=np.array(ref_off, np.int64), ref_pool=cat(ref_chunks))

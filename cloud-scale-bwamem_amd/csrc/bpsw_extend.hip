@@ -1,0 +1,305 @@
+// bpsw_extend.hip -- banded affine-gap seed extension for gfx950 (boundary 2).
+//
+// What it computes: for every task of a wire batch (MemChainToAlignBatched.scala:76-172) the result
+// of the Scala extension() (MemChainToAlignBatched.scala:789-883): left then right SWExtend
+// (SWUtil.scala:61-230) with up to MAX_BAND_TRY=2 band widths, bit-exact.
+//
+// How: one task per 64-lane wavefront, four independent waves per workgroup, no workgroup barrier.
+// The DP is row-synchronous because the band [beg,end) of row i+1 is derived from the finished row i
+// (SWUtil.scala:201-214).  A row is swept in 64-column chunks:
+//   a(j)   = max(H(i-1,j-1) + S(i,j), E(i,j))                      per lane
+//   F(i,j) = max(0, max_{k<j}(a(k) - oeIns - (j-1-k)*eIns))        wave max-plus prefix scan (DPP)
+//   H(i,j) = max(a(j), F(i,j)),  E(i+1,j) = max(E(i,j)-eDel, H(i,j)-oeDel, 0)
+// (valid because oIns >= 0, checked on the host).  The (H,E) row lives in LDS as int2 per column, the
+// 5 x qLen query profile as int8, the unpacked target as bytes.  Row maximum + LAST arg-max
+// (SWUtil.scala:158-161) come from a wave max-reduce + ballot; the band trimming loops
+// (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
+#include "bpsw_internal.h"
+#include "bpsw_wave.h"
+
+namespace bpsw {
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+// base k (0-based) of a task's nibble stream: 8 nibbles per word, first base in the top nibble
+__device__ __forceinline__ int nibble_at(const uint32_t* __restrict__ words, int k) {
+  const uint32_t w = words[k >> 3];
+  const int c = (int)((w >> (28 - 4 * (k & 7))) & 0xFu);
+  return c > 4 ? 4 : c;  // codes are 0..4 (LocusEncode); never index the matrix out of bounds
+}
+
+struct ExtRes {
+  int max, qle, tle, gtle, gscore, max_off;
+};
+
+// One SWExtend call (SWUtil.scala:61-230) executed by a whole wave.  All scalar state is wave-uniform.
+__device__ ExtRes sw_extend_wave(const int lane, const int qLen, const int tLen, int2* __restrict__ eh,
+                                 const int8_t* __restrict__ qp, const uint8_t* __restrict__ ts, const int oDel,
+                                 const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
+                                 const int zmode, const int h0) {
+  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
+  // row -1 (SWUtil.scala:75-78, 97-104): eh[0].h = h0, eh[j].h = max(0, h0 - oeIns - (j-1)*eIns), e = 0
+  for (int j = lane; j <= qLen; j += 64) {
+    const int h = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);
+    eh[j] = make_int2(h, 0);
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;  // SWUtil.scala:118-125
+  int beg = 0, end = qLen;
+  int t_next = tLen > 0 ? uni((int)ts[0]) : 0;
+
+  for (int i = 0; i < tLen; ++i) {
+    const int t = t_next;
+    if (i + 1 < tLen) t_next = uni((int)ts[i + 1]);  // prefetch the next row's target base
+    const int h1 = max(0, h0 - (oDel + eDel * (i + 1)));  // SWUtil.scala:137-138
+    beg = max(beg, i - w);                                // SWUtil.scala:140-142
+    end = min(min(end, i + w + 1), qLen);
+    const int8_t* __restrict__ q = qp + t * qLen;
+
+    int carry = NEG;   // running max of g(k) = a(k) - oeIns + k*eIns over the columns already swept
+    int hleft = h1;    // H(i, j0-1); for the first chunk the "first column" value of SWUtil.scala:137
+    int m = 0, mj = -1;
+    int lz_all = -1;   // last column with H == 0 among the columns already swept
+    int lz_best = -1;  // last column < mj with H == 0
+    int fz_after = -1; // first column > mj with H == 0
+
+    for (int j0 = beg; j0 < end; j0 += 64) {
+      const int j = j0 + lane;
+      const bool act = j < end;
+      int2 he = make_int2(0, 0);
+      int s = 0;
+      if (act) {
+        he = eh[j];
+        s = q[j];
+      }
+      const int a = act ? max(he.x + s, he.y) : NEG;
+      const int jE = j * eIns - oeIns;
+      const int P = max(wave_scan_max(a + jE), carry);
+      const int Pex = wave_shr1(carry, P);  // exclusive prefix; lane 0 takes the carry
+      const int H = max3i(a, Pex - (jE + oeIns - eIns), 0);     // F(i,j) = max(0, Pex - (j-1)*eIns)
+      carry = __builtin_amdgcn_readlane(P, 63);
+      const int E = max3i(he.y - eDel, H - oeDel, 0);           // E(i+1,j)
+      const int Hprev = wave_shr1(hleft, H);  // H(i,j-1), stored at eh[j].h
+      if (act) eh[j] = make_int2(Hprev, E);
+
+      const int nact = min(64, end - j0);
+      hleft = __builtin_amdgcn_readlane(H, nact - 1);
+      const unsigned long long actmask = nact == 64 ? ~0ull : ((1ull << nact) - 1ull);
+      const unsigned long long zmask = __builtin_amdgcn_ballot_w64(H == 0) & actmask;
+      const int Hm = act ? H : -1;
+      const int cm = __builtin_amdgcn_readlane(wave_scan_max(Hm), 63);
+      if (cm >= m) {  // "m <= h": a later chunk with an equal maximum takes over (last arg-max)
+        const unsigned long long eq = __builtin_amdgcn_ballot_w64(Hm == cm);
+        const int b = 63 - __builtin_clzll(eq);
+        m = cm;
+        mj = j0 + b;
+        const unsigned long long below = zmask & ((1ull << b) - 1ull);
+        lz_best = below ? j0 + 63 - __builtin_clzll(below) : lz_all;
+        const unsigned long long above = b == 63 ? 0ull : (zmask >> (b + 1));
+        fz_after = above ? j0 + b + 1 + __builtin_ctzll(above) : -1;
+      } else if (fz_after < 0 && zmask) {
+        fz_after = j0 + __builtin_ctzll(zmask);
+      }
+      if (zmask) lz_all = j0 + 63 - __builtin_clzll(zmask);
+    }
+    if (lane == 0) eh[end] = make_int2(hleft, 0);  // SWUtil.scala:174-175
+    __builtin_amdgcn_wave_barrier();
+
+    const int jfin = beg < end ? end : beg;  // value of j after the column loop
+    if (jfin == qLen && gscore <= hleft) {   // SWUtil.scala:177-182
+      max_ie = i;
+      gscore = hleft;
+    }
+    if (m == 0) break;  // SWUtil.scala:184-185
+    if (m > mx) {       // SWUtil.scala:187-193
+      mx = m;
+      max_i = i;
+      max_j = mj;
+      max_off = max(max_off, abs(mj - i));
+    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      const bool A = (i - max_i) > (mj - max_j);
+      const bool B = mx - m - ((i - max_i) - (mj - max_j)) * eDel > zdrop;
+      const bool C = mx - m - ((mj - max_j) - (i - max_i)) * eIns > zdrop;
+      const bool stop = zmode == BPSW_ZDROP_SCALA ? (A && (B || C)) : (A ? B : C);
+      if (stop) break;
+    }
+    // SWUtil.scala:202-214 on V(p) = eh[p].h: V(beg) = h1, V(j+1) = H(i,j)
+    beg = lz_best >= 0 ? lz_best + 2 : (h1 == 0 ? beg + 1 : beg);
+    end = fz_after >= 0 ? fz_after + 1 : end + 1;
+  }
+  ExtRes r;
+  r.max = mx; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+  return r;
+}
+
+// Unpack one side of a task into LDS: the 5 x qLen query profile and the target bytes.
+__device__ void load_side(const int lane, const uint32_t* __restrict__ words, const int qStart, const int qLen,
+                          const int rStart, const int rLen, const MatRows& mat, int8_t* __restrict__ qp,
+                          uint8_t* __restrict__ ts) {
+  for (int j = lane; j < qLen; j += 64) {
+    const int c = nibble_at(words, qStart + j);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) qp[k * qLen + j] = (int8_t)((mat.row[k] >> (8 * c)) & 0xff);
+  }
+  for (int i = lane; i < rLen; i += 64) ts[i] = (uint8_t)nibble_at(words, rStart + i);
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
+__device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
+                                                                     int16_t* __restrict__ out, const ExtScoring sc,
+                                                                     const int qcap, const int rcap,
+                                                                     const int lds_per_wave) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  unsigned char* base = smem + (size_t)wave * lds_per_wave;
+  int2* eh = reinterpret_cast<int2*>(base);
+  int8_t* qp = reinterpret_cast<int8_t*>(base + 8 * (size_t)(qcap + 2));
+  uint8_t* ts = reinterpret_cast<uint8_t*>(qp + 5 * (size_t)qcap);
+
+  // header, MemChainToAlignBatched.scala:78-84 (signed bytes)
+  const uint32_t hdr0 = wire[0], hdr1 = wire[1];
+  const int oDel = (int8_t)(hdr0 & 0xff), eDel = (int8_t)((hdr0 >> 8) & 0xff);
+  const int oIns = (int8_t)((hdr0 >> 16) & 0xff), eIns = (int8_t)((hdr0 >> 24) & 0xff);
+  const int penClip5 = (int8_t)(hdr1 & 0xff), penClip3 = (int8_t)((hdr1 >> 8) & 0xff);
+  const int wBand = (int8_t)((hdr1 >> 16) & 0xff);
+
+  const int stride = gridDim.x * WAVES_PER_BLOCK;
+  for (int task = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave); task < n_tasks; task += stride) {
+    const uint32_t* rec = wire + 8 + 8 * (size_t)task;  // MemChainToAlignBatched.scala:95-117
+    const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
+    const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
+    const uint32_t* words = wire + (size_t)uni((int)rec[2]);
+    const int regScore0 = uni(lo16(r3)), qBeg = uni(hi16(r3)), h0 = uni(lo16(r4));
+    const int lMaxIns = max(1, uni(lo16(r5))), lMaxDel = max(1, uni(hi16(r5)));  // SWUtil.scala:110-115
+    const int rMaxIns = max(1, uni(lo16(r6))), rMaxDel = max(1, uni(hi16(r6)));
+    const int idx = uni((int)rec[7]);
+
+    // extension(), MemChainToAlignBatched.scala:789-883
+    int aw0 = wBand, aw1 = wBand;
+    int regScore = regScore0;
+    int outQBeg = 0, outRBeg = 0, outQEnd = rq, outREnd = 0, trueScore = regScore0, score = -1;
+
+    if (lq > 0) {
+      load_side(lane, words, 0, lq, lq + rq, lr, sc.mat, qp, ts);
+      ExtRes r = {0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 2; ++i) {  // MAX_BAND_TRY
+        const int prev = regScore;
+        aw0 = wBand << i;
+        const int w = min(min(aw0, lMaxIns), lMaxDel);
+        r = sw_extend_wave(lane, lq, lr, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, h0);
+        regScore = r.max;
+        if (regScore == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+      }
+      score = regScore;
+      if (r.gscore <= 0 || r.gscore <= regScore - penClip5) {
+        outQBeg = qBeg - r.qle; outRBeg = -r.tle; trueScore = regScore;
+      } else {
+        outQBeg = 0; outRBeg = -r.gtle; trueScore = r.gscore;
+      }
+    }
+    if (rq > 0) {
+      load_side(lane, words, lq, rq, lq + rq + lr, rr, sc.mat, qp, ts);
+      const int sc0 = regScore;
+      ExtRes r = {0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 2; ++i) {
+        const int prev = regScore;
+        aw1 = wBand << i;
+        const int w = min(min(aw1, rMaxIns), rMaxDel);
+        r = sw_extend_wave(lane, rq, rr, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, sc0);
+        regScore = r.max;
+        if (regScore == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+      }
+      score = regScore;
+      if (r.gscore <= 0 || r.gscore <= regScore - penClip3) {
+        outQEnd = r.qle; outREnd = r.tle; trueScore += regScore - sc0;
+      } else {
+        outQEnd = rq; outREnd = r.gtle; trueScore += r.gscore - sc0;
+      }
+    }
+    const int width = aw0 > aw1 ? aw0 : aw1;
+    if (lane == 0) {  // MemChainToAlignBatched.scala:181-188: 10 int16 per task
+      uint32_t* o = reinterpret_cast<uint32_t*>(out + 10 * (size_t)task);
+      o[0] = (uint32_t)idx;
+      o[1] = ((uint32_t)outQBeg & 0xffffu) | ((uint32_t)outQEnd << 16);
+      o[2] = ((uint32_t)outRBeg & 0xffffu) | ((uint32_t)outREnd << 16);
+      o[3] = ((uint32_t)score & 0xffffu) | ((uint32_t)trueScore << 16);
+      o[4] = (uint32_t)width & 0xffffu;
+    }
+  }
+}
+
+// ---- table scan: validates the batch and finds the LDS capacities the main launch needs --------
+__global__ void ext_prepass_kernel(const uint32_t* __restrict__ wire, const unsigned long long wire_words,
+                                   const int n_tasks, ExtPrepass* __restrict__ pre) {
+  int mq = 0, mr = 0, err = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((int)wire[2] != n_tasks) err = 1;
+    const uint32_t hdr0 = wire[0];
+    const int oIns = (int8_t)((hdr0 >> 16) & 0xff), eIns = (int8_t)((hdr0 >> 24) & 0xff);
+    const int oDel = (int8_t)(hdr0 & 0xff), eDel = (int8_t)((hdr0 >> 8) & 0xff);
+    if (oIns < 0 || eIns < 0 || oDel < 0 || eDel < 0) err = 2;  // the prefix-scan form of F needs oIns >= 0
+  }
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {
+    const uint32_t* rec = wire + 8 + 8 * (size_t)t;
+    const int lq = lo16(rec[0]), lr = hi16(rec[0]), rq = lo16(rec[1]), rr = hi16(rec[1]);
+    const long long pos = (int)rec[2];
+    if (lq < 0 || lr < 0 || rq < 0 || rr < 0) { err = 3; continue; }
+    const long long words = ((long long)lq + lr + rq + rr + 7) / 8;
+    if (pos < 8 + 8ll * n_tasks || (unsigned long long)(pos + words) > wire_words) err = 4;
+    mq = max(mq, max(lq, rq));
+    mr = max(mr, max(lr, rr));
+  }
+  if (mq) atomicMax(&pre->max_qlen, mq);
+  if (mr) atomicMax(&pre->max_rlen, mr);
+  if (err) atomicMax(&pre->error, err);
+}
+
+}  // namespace
+
+size_t ext_lds_per_wave(int qcap, int rcap) {
+  size_t b = 8 * (size_t)(qcap + 2) + 5 * (size_t)qcap + (size_t)rcap;
+  return (b + 15) & ~(size_t)15;
+}
+
+void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, ExtPrepass* d_pre, hipStream_t s) {
+  const int threads = 256;
+  int blocks = (n_tasks + threads - 1) / threads;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(ext_prepass_kernel, dim3(blocks), dim3(threads), 0, s, d_wire, (unsigned long long)wire_words,
+                     n_tasks, d_pre);
+}
+
+hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
+                             int rcap, int num_cu, hipStream_t s) {
+  if (n_tasks <= 0) return hipSuccess;
+  // round the capacities so that a handful of LDS configurations cover all batches
+  qcap = (qcap + 31) & ~31;
+  rcap = (rcap + 63) & ~63;
+  const size_t per_wave = ext_lds_per_wave(qcap, rcap);
+  const size_t lds = per_wave * WAVES_PER_BLOCK;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static thread_local size_t attr_set = 0;
+  if (lds > 64 * 1024 && lds > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ext_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = lds;
+  }
+  // resident workgroups per CU: 8 waves/SIMD = 8 blocks of 4 waves, capped by LDS
+  int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+  per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+  int blocks = (n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  const int max_blocks = num_cu * per_cu;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(ext_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
+                     rcap, (int)per_wave);
+  return hipGetLastError();
+}
+
+}  // namespace bpsw

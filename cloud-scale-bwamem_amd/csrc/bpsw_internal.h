@@ -1,0 +1,118 @@
+// bpsw_internal.h -- declarations shared by the translation units of libbPSW_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bpsw.h"
+
+struct bpsw_ctx;
+
+namespace bpsw {
+
+// ---- scoring block handed to the kernels by value -------------------------------------------
+struct MatRows {
+  // row k of the 5x5 matrix packed little-endian: byte c = mat[k*5 + c]
+  unsigned long long row[5];
+};
+MatRows pack_mat(const int8_t mat[25]);
+
+struct ExtScoring {
+  MatRows mat;
+  int zdrop;
+  int zdrop_mode;
+};
+
+// ---- extension (boundary 2) -------------------------------------------------------------------
+// Result of the device-side table scan that validates a wire batch before the main launch.
+struct ExtPrepass {
+  int max_qlen;   // max over tasks of max(leftQlen, rightQlen)
+  int max_rlen;   // max over tasks of max(leftRlen, rightRlen)
+  int error;      // != 0: malformed table (negative length, sequence outside the buffer, n mismatch)
+  int reserved;
+};
+
+// Launch the table scan; `d_pre` is a device ExtPrepass that must be zeroed by the caller (stream-ordered).
+void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, ExtPrepass* d_pre, hipStream_t s);
+
+// LDS bytes one wave needs for tasks up to (qcap, rcap).
+size_t ext_lds_per_wave(int qcap, int rcap);
+
+// Launch the extension kernel over a validated batch.
+hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
+                             int rcap, int num_cu, hipStream_t s);
+
+// ---- local SW (boundary 1) ---------------------------------------------------------------------
+struct SwScoring {
+  MatRows mat;
+  int a, b, o_del, e_del, o_ins, e_ins;
+  int xtra;
+};
+
+struct SwJobsDev {  // all device pointers
+  int n;
+  const int32_t* q_len;
+  const int32_t* t_len;
+  const int64_t* q_off;
+  const int64_t* t_off;
+  const uint8_t* q_rev;
+  const uint8_t* q_pool;
+  const uint8_t* t_pool;
+};
+
+struct SwPrepass {
+  int max_qlen;
+  int max_tlen;
+  int error;
+  int reserved;
+};
+void launch_sw_prepass(const SwJobsDev& jobs, size_t q_pool_bytes, size_t t_pool_bytes, SwPrepass* d_pre, hipStream_t s);
+size_t sw_scratch_bytes_per_wave(int max_tlen);
+int sw_resident_waves(int num_cu);
+hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
+                            uint32_t* d_scratch, int num_cu, hipStream_t s);
+
+// ---- error text -----------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+// ---- context ----------------------------------------------------------------------------------------
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes);  // grow-only
+  void release();
+};
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes);
+  void release();
+};
+
+// runs SWAlign2 jobs whose arrays live in host memory; used by bpsw_swalign2_batch and the rescue layer.
+// Caller holds ctx->mu and has set the device.
+int run_sw_jobs_host(bpsw_ctx* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* jobs, int32_t* out);
+
+}  // namespace bpsw
+
+struct bpsw_ctx {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::mutex mu;
+  bpsw::ExtScoring ext_sc;
+  int8_t ext_mat[25];
+  // persistent arenas (grow-only; no hipMalloc on the steady-state path)
+  bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch;
+  bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
+  bpsw_stats_t stats;
+  float last_ext_ms = 0.f, last_sw_ms = 0.f;
+  bool have_ext_ev = false, have_sw_ev = false;
+};

@@ -1,0 +1,342 @@
+// bpsw_jni.cpp -- the JNI symbols the unmodified CS-BWAMEM Scala driver binds, as thin marshalling
+// shims over the C ABI (include/bpsw.h).
+//
+//   Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI  replaces jni_fpga/sw_extend_fpga.c:116-193
+//   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI              replaces native/jni_mate_sw.c:58-662
+//   Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld            replaces native/jni_hello_world.c:23-26
+//
+// Differences from the reference glue that a JVM can observe: nothing is printed, the JVM is never
+// exit()ed or assert()ed, a device failure surfaces as a java.lang.RuntimeException (Spark retries the
+// task), local references are bounded with Push/PopLocalFrame so -sbatch can be thousands of pairs, and
+// arrays are read with Get*ArrayRegion (no pinning).  No JVM exists in the build image, so this file
+// is compile- and link-checked, and exercised through a fake JNIEnv table in tests/test_jni_shim.py.
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <string>
+#include <vector>
+
+#include "bpsw.h"
+#include "jni_min.h"
+
+namespace {
+
+// One context per (thread, device): Spark runs several task threads per executor JVM and the reference
+// native code is re-entrant, so calls from different threads must not serialise on one stream.
+struct ThreadCtx {
+  bpsw_ctx_t* ctx = nullptr;
+  int device = -1;
+  ~ThreadCtx() {
+    if (ctx) bpsw_destroy(ctx);
+  }
+};
+thread_local ThreadCtx t_ctx;
+
+void clear_pending(JNIEnv* env) {
+  if (jni::ExceptionCheck(env)) jni::ExceptionClear(env);
+}
+
+// Spark partition -> device (north_star: "Spark-partition -> device index").  The partition id is not in
+// either JNI signature; org.apache.spark.TaskContext.get().partitionId() is reachable through JNIEnv.
+int spark_partition_id(JNIEnv* env) {
+  jclass cls = jni::FindClass(env, "org/apache/spark/TaskContext");
+  if (!cls || jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
+  jmethodID get = jni::GetStaticMethodID(env, cls, "get", "()Lorg/apache/spark/TaskContext;");
+  if (!get || jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
+  jobject tc = jni::CallStaticObjectMethod(env, cls, get);
+  if (!tc || jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
+  jmethodID pid = jni::GetMethodID(env, cls, "partitionId", "()I");
+  if (!pid || jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
+  const jint id = jni::CallIntMethod(env, tc, pid);
+  if (jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
+  return (int)id;
+}
+
+bpsw_ctx_t* thread_context(JNIEnv* env) {
+  const int ndev = bpsw_device_count();
+  if (ndev <= 0) return nullptr;
+  int want = -1;
+  const int part = spark_partition_id(env);
+  if (part >= 0) want = part % ndev;
+  if (t_ctx.ctx && (want < 0 || want == t_ctx.device)) return t_ctx.ctx;
+  if (t_ctx.ctx) { bpsw_destroy(t_ctx.ctx); t_ctx.ctx = nullptr; }
+  // want < 0: no TaskContext (harness) -> bpsw_create spreads threads round-robin over BPSW_DEVICES
+  if (bpsw_create(want, &t_ctx.ctx) != BPSW_OK) return nullptr;
+  t_ctx.device = bpsw_device_of(t_ctx.ctx);
+  return t_ctx.ctx;
+}
+
+void throw_runtime(JNIEnv* env, const std::string& msg) {
+  clear_pending(env);
+  jclass rte = jni::FindClass(env, "java/lang/RuntimeException");
+  if (rte) jni::ThrowNew(env, rte, msg.c_str());
+}
+
+struct OptIds {
+  jfieldID a, b, oDel, eDel, oIns, eIns, penUnpaired, penClip5, penClip3, w, zdrop, T, flag, minSeedLen, maxIns,
+      maxMatesw, maskLevelRedun, mat;
+};
+struct RegIds {
+  jfieldID rBeg, rEnd, qBeg, qEnd, score, trueScore, sub, csub, subNum, width, seedCov, secondary, hash;
+};
+
+bool load_reg_ids(JNIEnv* env, jclass c, RegIds* r) {  // MemAlnRegType.scala:26-38, native/jni_mate_sw.c:131-143
+  r->rBeg = jni::GetFieldID(env, c, "rBeg", "J"); r->rEnd = jni::GetFieldID(env, c, "rEnd", "J");
+  r->qBeg = jni::GetFieldID(env, c, "qBeg", "I"); r->qEnd = jni::GetFieldID(env, c, "qEnd", "I");
+  r->score = jni::GetFieldID(env, c, "score", "I"); r->trueScore = jni::GetFieldID(env, c, "trueScore", "I");
+  r->sub = jni::GetFieldID(env, c, "sub", "I"); r->csub = jni::GetFieldID(env, c, "csub", "I");
+  r->subNum = jni::GetFieldID(env, c, "subNum", "I"); r->width = jni::GetFieldID(env, c, "width", "I");
+  r->seedCov = jni::GetFieldID(env, c, "seedCov", "I"); r->secondary = jni::GetFieldID(env, c, "secondary", "I");
+  r->hash = jni::GetFieldID(env, c, "hash", "J");
+  return r->rBeg && r->rEnd && r->qBeg && r->qEnd && r->score && r->trueScore && r->sub && r->csub && r->subNum &&
+         r->width && r->seedCov && r->secondary && r->hash && !jni::ExceptionCheck(env);
+}
+
+void read_bytes(JNIEnv* env, jbyteArray arr, std::vector<uint8_t>& pool, int64_t* off, int32_t* len) {
+  *off = (int64_t)pool.size();
+  *len = 0;
+  if (!arr) return;
+  const jsize n = jni::GetArrayLength(env, arr);
+  pool.resize(pool.size() + (size_t)n);
+  if (n > 0) jni::GetByteArrayRegion(env, arr, 0, n, reinterpret_cast<jbyte*>(pool.data() + *off));
+  *len = n;
+  pool.resize((pool.size() + 15) & ~(size_t)15);  // keep every sequence 16-byte aligned for the device
+}
+
+}  // namespace
+
+extern "C" {
+
+JNIEXPORT void JNICALL Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld(JNIEnv*, jobject) {
+  printf("Hello World from %s (%d HIP device(s))\n", bpsw_version(), bpsw_device_count());
+}
+
+// ---- boundary 2 ------------------------------------------------------------------------------------
+JNIEXPORT jshortArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI(JNIEnv* env, jobject,
+                                                                                            jint retTaskNum,
+                                                                                            jbyteArray arrayIn) {
+  if (!arrayIn || retTaskNum < 0) { throw_runtime(env, "bPSW: swExtendFPGAJNI: bad arguments"); return nullptr; }
+  const jsize bytes = jni::GetArrayLength(env, arrayIn);
+  std::vector<uint8_t> wire((size_t)bytes);
+  if (bytes > 0) jni::GetByteArrayRegion(env, arrayIn, 0, bytes, reinterpret_cast<jbyte*>(wire.data()));
+  std::vector<int16_t> out((size_t)retTaskNum > 0 ? (size_t)retTaskNum : 1, 0);
+  bpsw_ctx_t* ctx = thread_context(env);
+  if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
+  const int rc = bpsw_extend_batch(ctx, wire.data(), wire.size(), out.data(), (size_t)retTaskNum);
+  if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: swExtendFPGAJNI: ") + bpsw_last_error()); return nullptr; }
+  jshortArray ret = jni::NewShortArray(env, retTaskNum);
+  if (!ret) return nullptr;  // OutOfMemoryError already pending
+  if (retTaskNum > 0) jni::SetShortArrayRegion(env, ret, 0, retTaskNum, out.data());
+  return ret;
+}
+
+// ---- boundary 1 ------------------------------------------------------------------------------------
+JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI(
+    JNIEnv* env, jobject, jobject optObj, jlong pacLen, jobjectArray pesArr, jint groupSize, jobjectArray seqArr,
+    jobjectArray mateArr, jobjectArray refArr, jintArray refSizeArr) {
+  if (!optObj || !pesArr || !seqArr || !mateArr || !refArr || !refSizeArr || groupSize < 0) {
+    throw_runtime(env, "bPSW: mateSWJNI: bad arguments");
+    return nullptr;
+  }
+  // classes are resolved inside the native call so that the executor's class loader is the one consulted
+  jclass regCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemAlnRegType");
+  jclass optCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemOptType");
+  jclass pesCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemPeStat");
+  jclass mateCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/MateSWType");
+  jclass seqCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/SeqSWType");
+  jclass refCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/RefSWType");
+  if (!regCls || !optCls || !pesCls || !mateCls || !seqCls || !refCls) return nullptr;  // NoClassDefFoundError pending
+
+  // ---- MemOptType (native/jni_mate_sw.c:102-128, 177-221) ----
+  bpsw_opt_t opt;
+  bpsw_opt_default(&opt);
+  {
+    struct { const char* name; int32_t* dst; } ints[] = {
+        {"a", &opt.a}, {"b", &opt.b}, {"oDel", &opt.o_del}, {"eDel", &opt.e_del}, {"oIns", &opt.o_ins},
+        {"eIns", &opt.e_ins}, {"penUnpaired", &opt.pen_unpaired}, {"penClip5", &opt.pen_clip5},
+        {"penClip3", &opt.pen_clip3}, {"w", &opt.w}, {"zdrop", &opt.zdrop}, {"T", &opt.T}, {"flag", &opt.flag},
+        {"minSeedLen", &opt.min_seed_len}, {"maxIns", &opt.max_ins}, {"maxMatesw", &opt.max_matesw}};
+    for (auto& f : ints) {
+      jfieldID id = jni::GetFieldID(env, optCls, f.name, "I");
+      if (!id) return nullptr;
+      *f.dst = jni::GetIntField(env, optObj, id);
+    }
+    jfieldID mlr = jni::GetFieldID(env, optCls, "maskLevelRedun", "F");
+    jfieldID matId = jni::GetFieldID(env, optCls, "mat", "[B");
+    if (!mlr || !matId) return nullptr;
+    opt.mask_level_redun = jni::GetFloatField(env, optObj, mlr);
+    jbyteArray matArr = (jbyteArray)jni::GetObjectField(env, optObj, matId);
+    if (!matArr || jni::GetArrayLength(env, matArr) < 25) { throw_runtime(env, "bPSW: mateSWJNI: opt.mat must hold 25 bytes"); return nullptr; }
+    jni::GetByteArrayRegion(env, matArr, 0, 25, reinterpret_cast<jbyte*>(opt.mat));
+    jni::DeleteLocalRef(env, matArr);
+  }
+
+  bpsw_rescue_group_t g;
+  memset(&g, 0, sizeof g);
+  g.group_size = groupSize;
+  g.l_pac = pacLen;
+  {  // ---- MemPeStat[4] (native/jni_mate_sw.c:225-236) ----
+    jfieldID low = jni::GetFieldID(env, pesCls, "low", "I"), high = jni::GetFieldID(env, pesCls, "high", "I");
+    jfieldID failed = jni::GetFieldID(env, pesCls, "failed", "I");
+    jfieldID avg = jni::GetFieldID(env, pesCls, "avg", "D"), sd = jni::GetFieldID(env, pesCls, "std", "D");
+    if (!low || !high || !failed || !avg || !sd) return nullptr;
+    for (int r = 0; r < 4; ++r) {
+      jobject o = jni::GetObjectArrayElement(env, pesArr, r);
+      if (!o) { throw_runtime(env, "bPSW: mateSWJNI: pes must hold 4 MemPeStat"); return nullptr; }
+      g.pes[r].low = jni::GetIntField(env, o, low); g.pes[r].high = jni::GetIntField(env, o, high);
+      g.pes[r].failed = jni::GetIntField(env, o, failed);
+      g.pes[r].avg = jni::GetDoubleField(env, o, avg); g.pes[r].std = jni::GetDoubleField(env, o, sd);
+      jni::DeleteLocalRef(env, o);
+    }
+  }
+  const size_t ends = 2 * (size_t)groupSize;
+  std::vector<int32_t> seq_len(ends, 0), reg_cnt(ends, 0), ref_cnt(ends, 0);
+  std::vector<int64_t> seq_off(ends, 0);
+  std::vector<uint8_t> seq_pool, ref_pool;
+  auto end_index = [&](jint k, jint i) -> long { return (k < 0 || k >= groupSize || i < 0 || i > 1) ? -1 : 2l * k + i; };
+
+  {  // ---- SeqSWType[] (native/jni_mate_sw.c:258-278) ----
+    jfieldID rid = jni::GetFieldID(env, seqCls, "readIdx", "I"), pid = jni::GetFieldID(env, seqCls, "pairIdx", "I");
+    jfieldID slen = jni::GetFieldID(env, seqCls, "seqLength", "I"), strans = jni::GetFieldID(env, seqCls, "seqTrans", "[B");
+    if (!rid || !pid || !slen || !strans) return nullptr;
+    const jsize n = jni::GetArrayLength(env, seqArr);
+    for (jsize s = 0; s < n; ++s) {
+      jobject o = jni::GetObjectArrayElement(env, seqArr, s);
+      const long e = o ? end_index(jni::GetIntField(env, o, rid), jni::GetIntField(env, o, pid)) : -1;
+      if (e < 0) { throw_runtime(env, "bPSW: mateSWJNI: SeqSWType index outside the group"); return nullptr; }
+      jbyteArray bytes = (jbyteArray)jni::GetObjectField(env, o, strans);
+      int32_t got = 0;
+      read_bytes(env, bytes, seq_pool, &seq_off[(size_t)e], &got);
+      const jint declared = jni::GetIntField(env, o, slen);
+      seq_len[(size_t)e] = declared < got ? declared : got;
+      if (bytes) jni::DeleteLocalRef(env, bytes);
+      jni::DeleteLocalRef(env, o);
+    }
+  }
+  RegIds rf;
+  if (!load_reg_ids(env, regCls, &rf)) return nullptr;
+  jfieldID mRid = jni::GetFieldID(env, mateCls, "readIdx", "I"), mPid = jni::GetFieldID(env, mateCls, "pairIdx", "I");
+  jfieldID mReg = jni::GetFieldID(env, mateCls, "regIdx", "I");
+  jfieldID mAln = jni::GetFieldID(env, mateCls, "alnReg", "Lcs/ucla/edu/bwaspark/datatype/MemAlnRegType;");
+  if (!mRid || !mPid || !mReg || !mAln) return nullptr;
+
+  std::vector<bpsw_alnreg_t> regs;
+  {  // ---- MateSWType[] -> regions grouped by (k,i) in arrival order (native/jni_mate_sw.c:300-345) ----
+    const jsize n = jni::GetArrayLength(env, mateArr);
+    std::vector<bpsw_alnreg_t> tmp((size_t)n);
+    std::vector<long> where((size_t)n);
+    for (jsize s = 0; s < n; ++s) {
+      jobject o = jni::GetObjectArrayElement(env, mateArr, s);
+      const long e = o ? end_index(jni::GetIntField(env, o, mRid), jni::GetIntField(env, o, mPid)) : -1;
+      jobject a = e >= 0 ? jni::GetObjectField(env, o, mAln) : nullptr;
+      if (!a) { throw_runtime(env, "bPSW: mateSWJNI: malformed MateSWType"); return nullptr; }
+      bpsw_alnreg_t& r = tmp[(size_t)s];
+      r.rb = jni::GetLongField(env, a, rf.rBeg); r.re = jni::GetLongField(env, a, rf.rEnd);
+      r.qb = jni::GetIntField(env, a, rf.qBeg); r.qe = jni::GetIntField(env, a, rf.qEnd);
+      r.score = jni::GetIntField(env, a, rf.score); r.truesc = jni::GetIntField(env, a, rf.trueScore);
+      r.sub = jni::GetIntField(env, a, rf.sub); r.csub = jni::GetIntField(env, a, rf.csub);
+      r.sub_n = jni::GetIntField(env, a, rf.subNum); r.w = jni::GetIntField(env, a, rf.width);
+      r.seedcov = jni::GetIntField(env, a, rf.seedCov); r.secondary = jni::GetIntField(env, a, rf.secondary);
+      r.hash = (uint64_t)jni::GetLongField(env, a, rf.hash);
+      where[(size_t)s] = e;
+      ++reg_cnt[(size_t)e];
+      jni::DeleteLocalRef(env, a);
+      jni::DeleteLocalRef(env, o);
+    }
+    std::vector<int64_t> at(ends + 1, 0);
+    for (size_t e = 0; e < ends; ++e) at[e + 1] = at[e] + reg_cnt[e];
+    regs.resize((size_t)n);
+    for (jsize s = 0; s < n; ++s) regs[(size_t)at[(size_t)where[(size_t)s]]++] = tmp[(size_t)s];
+  }
+  std::vector<int64_t> ref_rb, ref_re, ref_len, ref_off;
+  {  // ---- refSizeArray + RefSWType[] (native/jni_mate_sw.c:352-518) ----
+    if (jni::GetArrayLength(env, refSizeArr) < (jsize)ends) { throw_runtime(env, "bPSW: mateSWJNI: refSizeArray too short"); return nullptr; }
+    if (ends) jni::GetIntArrayRegion(env, refSizeArr, 0, (jsize)ends, ref_cnt.data());
+    std::vector<int64_t> base(ends + 1, 0);
+    for (size_t e = 0; e < ends; ++e) {
+      if (ref_cnt[e] < 0) { throw_runtime(env, "bPSW: mateSWJNI: negative refSizeArray entry"); return nullptr; }
+      base[e + 1] = base[e] + ref_cnt[e];
+    }
+    const size_t rows = (size_t)base[ends];
+    ref_rb.assign(4 * rows, -1); ref_re.assign(4 * rows, -1); ref_len.assign(4 * rows, 0); ref_off.assign(4 * rows, 0);
+    jfieldID rRid = jni::GetFieldID(env, refCls, "readIdx", "I"), rPid = jni::GetFieldID(env, refCls, "pairIdx", "I");
+    jfieldID rReg = jni::GetFieldID(env, refCls, "regIdx", "I");
+    jfieldID rB = jni::GetFieldID(env, refCls, "rBegArray", "[J"), rE = jni::GetFieldID(env, refCls, "rEndArray", "[J");
+    jfieldID rL = jni::GetFieldID(env, refCls, "lenArray", "[J");
+    jfieldID rRef[4] = {jni::GetFieldID(env, refCls, "ref0", "[B"), jni::GetFieldID(env, refCls, "ref1", "[B"),
+                        jni::GetFieldID(env, refCls, "ref2", "[B"), jni::GetFieldID(env, refCls, "ref3", "[B")};
+    if (!rRid || !rPid || !rReg || !rB || !rE || !rL || !rRef[0] || !rRef[1] || !rRef[2] || !rRef[3]) return nullptr;
+    const jsize n = jni::GetArrayLength(env, refArr);
+    for (jsize s = 0; s < n; ++s) {
+      if (jni::PushLocalFrame(env, 16) != JNI_OK) return nullptr;
+      jobject o = jni::GetObjectArrayElement(env, refArr, s);
+      const long e = o ? end_index(jni::GetIntField(env, o, rRid), jni::GetIntField(env, o, rPid)) : -1;
+      const jint j = o ? jni::GetIntField(env, o, rReg) : -1;
+      if (e < 0 || j < 0 || j >= ref_cnt[(size_t)e]) { jni::PopLocalFrame(env, nullptr); throw_runtime(env, "bPSW: mateSWJNI: RefSWType index outside refSizeArray"); return nullptr; }
+      const size_t x = 4 * (size_t)(base[(size_t)e] + j);
+      jlongArray ab = (jlongArray)jni::GetObjectField(env, o, rB), ae = (jlongArray)jni::GetObjectField(env, o, rE);
+      jlongArray al = (jlongArray)jni::GetObjectField(env, o, rL);
+      if (!ab || !ae || !al || jni::GetArrayLength(env, ab) < 4 || jni::GetArrayLength(env, ae) < 4 || jni::GetArrayLength(env, al) < 4) {
+        jni::PopLocalFrame(env, nullptr); throw_runtime(env, "bPSW: mateSWJNI: RefSWType arrays must hold 4 longs"); return nullptr;
+      }
+      jni::GetLongArrayRegion(env, ab, 0, 4, (jlong*)&ref_rb[x]);
+      jni::GetLongArrayRegion(env, ae, 0, 4, (jlong*)&ref_re[x]);
+      jni::GetLongArrayRegion(env, al, 0, 4, (jlong*)&ref_len[x]);
+      for (int r = 0; r < 4; ++r) {
+        if (ref_len[x + r] <= 0) continue;  // failed orientation: len=0, ref=null (MemSamPe.scala:1863-1868)
+        jbyteArray bytes = (jbyteArray)jni::GetObjectField(env, o, rRef[r]);
+        int32_t got = 0;
+        read_bytes(env, bytes, ref_pool, &ref_off[x + r], &got);
+        if (got < ref_len[x + r]) { jni::PopLocalFrame(env, nullptr); throw_runtime(env, "bPSW: mateSWJNI: reference window shorter than lenArray"); return nullptr; }
+      }
+      jni::PopLocalFrame(env, nullptr);
+    }
+  }
+  if (seq_pool.empty()) seq_pool.resize(16);
+  if (ref_pool.empty()) ref_pool.resize(16);
+  g.seq_len = seq_len.data(); g.seq_off = seq_off.data(); g.seq_pool = seq_pool.data(); g.seq_pool_bytes = seq_pool.size();
+  g.reg_cnt = reg_cnt.data(); g.regs = regs.data(); g.ref_cnt = ref_cnt.data();
+  g.ref_rb = ref_rb.data(); g.ref_re = ref_re.data(); g.ref_len = ref_len.data(); g.ref_off = ref_off.data();
+  g.ref_pool = ref_pool.data(); g.ref_pool_bytes = ref_pool.size();
+
+  bpsw_ctx_t* ctx = thread_context(env);
+  if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
+  std::vector<int32_t> out_cnt(ends ? ends : 1);
+  std::vector<bpsw_alnreg_t> out(regs.size() + 4 * ref_rb.size() / 4 + 16);
+  int64_t total = 0;
+  const char* compat = getenv("BPSW_MATESW_COMPAT");
+  const int mode = (compat && strcmp(compat, "scala") == 0) ? BPSW_RESCUE_SCALA : BPSW_RESCUE_C;
+  int rc = bpsw_matesw_group(ctx, &opt, &g, mode, out_cnt.data(), out.data(), (int64_t)out.size(), &total);
+  if (rc == BPSW_ERR_CAPACITY) {
+    out.resize((size_t)total);
+    rc = bpsw_matesw_group(ctx, &opt, &g, mode, out_cnt.data(), out.data(), (int64_t)out.size(), &total);
+  }
+  if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: mateSWJNI: ") + bpsw_last_error()); return nullptr; }
+
+  // ---- result: MateSWType[] in (k, i, rank) order (native/jni_mate_sw.c:548-591) ----
+  jobjectArray ret = jni::NewObjectArray(env, (jsize)total, mateCls, nullptr);
+  if (!ret) return nullptr;
+  int64_t at = 0;
+  for (size_t e = 0; e < ends; ++e)
+    for (int32_t rank = 0; rank < out_cnt[e]; ++rank, ++at) {
+      if (jni::PushLocalFrame(env, 8) != JNI_OK) return nullptr;
+      const bpsw_alnreg_t& r = out[(size_t)at];
+      jobject m = jni::AllocObject(env, mateCls), a = jni::AllocObject(env, regCls);
+      if (!m || !a) { jni::PopLocalFrame(env, nullptr); return nullptr; }
+      jni::SetIntField(env, m, mRid, (jint)(e >> 1)); jni::SetIntField(env, m, mPid, (jint)(e & 1)); jni::SetIntField(env, m, mReg, rank);
+      jni::SetLongField(env, a, rf.rBeg, r.rb); jni::SetLongField(env, a, rf.rEnd, r.re);
+      jni::SetIntField(env, a, rf.qBeg, r.qb); jni::SetIntField(env, a, rf.qEnd, r.qe);
+      jni::SetIntField(env, a, rf.score, r.score); jni::SetIntField(env, a, rf.trueScore, r.truesc);
+      jni::SetIntField(env, a, rf.sub, r.sub); jni::SetIntField(env, a, rf.csub, r.csub);
+      jni::SetIntField(env, a, rf.subNum, r.sub_n); jni::SetIntField(env, a, rf.width, r.w);
+      jni::SetIntField(env, a, rf.seedCov, r.seedcov); jni::SetIntField(env, a, rf.secondary, r.secondary);
+      jni::SetLongField(env, a, rf.hash, (jlong)r.hash);
+      jni::SetObjectField(env, m, mAln, a);
+      jni::SetObjectArrayElement(env, ret, (jsize)at, m);
+      jni::PopLocalFrame(env, nullptr);
+    }
+  return ret;
+}
+
+}  // extern "C"

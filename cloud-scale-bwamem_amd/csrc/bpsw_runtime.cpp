@@ -1,0 +1,302 @@
+// bpsw_runtime.cpp -- context, arenas and the C ABI of libbPSW_hip.so (include/bpsw.h).
+//
+// Replaces the reference's accelerator host side: the SysV-shm + TCP hop of
+// src/main/jni_fpga/sw_extend_fpga.c:116-193 and the OpenCL daemon src/main/alphadata/shm_host.c
+// become an in-process HIP stream with persistent device arenas and pinned staging buffers.
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+
+#include "bpsw_internal.h"
+
+namespace bpsw {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+static int hip_fail(hipError_t e, const char* what) {
+  return fail(BPSW_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
+  } while (0)
+
+hipError_t DeviceBuffer::reserve(size_t bytes) {
+  if (bytes <= cap) return hipSuccess;
+  size_t want = cap ? cap : 1 << 20;
+  while (want < bytes) want <<= 1;
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+  hipError_t e = hipMalloc(&ptr, want);
+  if (e == hipSuccess) cap = want;
+  return e;
+}
+void DeviceBuffer::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+}
+hipError_t PinnedBuffer::reserve(size_t bytes) {
+  if (bytes <= cap) return hipSuccess;
+  size_t want = cap ? cap : 1 << 20;
+  while (want < bytes) want <<= 1;
+  if (ptr) (void)hipHostFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+  hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+  if (e == hipSuccess) cap = want;
+  return e;
+}
+void PinnedBuffer::release() {
+  if (ptr) (void)hipHostFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+}
+
+MatRows pack_mat(const int8_t mat[25]) {
+  MatRows m;
+  for (int k = 0; k < 5; ++k) {
+    unsigned long long r = 0;
+    for (int c = 0; c < 5; ++c) r |= (unsigned long long)(uint8_t)mat[k * 5 + c] << (8 * c);
+    m.row[k] = r;
+  }
+  return m;
+}
+
+static void default_mat(int8_t mat[25], int a, int b) {  // bwaFillScmat, datatype/MemOptType.scala:58-73
+  int k = 0;
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) mat[k++] = (int8_t)(i == j ? a : -b);
+    mat[k++] = -1;
+  }
+  for (int j = 0; j < 5; ++j) mat[k++] = -1;
+}
+
+// BPSW_DEVICES="0,2,3" restricts and orders the devices contexts are spread over.
+static std::vector<int> allowed_devices() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return {};
+  std::vector<int> all;
+  const char* env = getenv("BPSW_DEVICES");
+  if (env && *env) {
+    const char* p = env;
+    while (*p) {
+      char* q = nullptr;
+      long v = strtol(p, &q, 10);
+      if (q == p) break;
+      if (v >= 0 && v < n) all.push_back((int)v);
+      p = (*q == ',') ? q + 1 : q;
+      if (*q != ',' && *q != 0) break;
+    }
+  }
+  if (all.empty())
+    for (int i = 0; i < n; ++i) all.push_back(i);
+  return all;
+}
+
+}  // namespace bpsw
+
+using namespace bpsw;
+
+extern "C" {
+
+const char* bpsw_last_error(void) { return g_err.c_str(); }
+const char* bpsw_version(void) { return "bPSW-hip 0.1 (gfx950)"; }
+
+int bpsw_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void bpsw_opt_default(bpsw_opt_t* o) {  // datatype/MemOptType.scala:28-73
+  memset(o, 0, sizeof *o);
+  o->a = 1; o->b = 4; o->o_del = 6; o->e_del = 1; o->o_ins = 6; o->e_ins = 1;
+  o->pen_unpaired = 17; o->pen_clip5 = 5; o->pen_clip3 = 5; o->w = 100; o->zdrop = 100;
+  o->T = 30; o->flag = 0; o->min_seed_len = 19; o->max_ins = 10000; o->max_matesw = 100;
+  o->mask_level_redun = 0.95f;
+  default_mat(o->mat, o->a, o->b);
+}
+
+int bpsw_create(int device, bpsw_ctx_t** out) {
+  if (!out) return fail(BPSW_ERR_ARG, "bpsw_create: null out");
+  *out = nullptr;
+  std::vector<int> devs = allowed_devices();
+  if (devs.empty()) return fail(BPSW_ERR_DEVICE, "bpsw_create: no HIP device visible (there is no CPU fallback)");
+  if (device < 0) {
+    static std::atomic<unsigned> rr{0};
+    device = devs[rr.fetch_add(1) % devs.size()];
+  } else {
+    int n = bpsw_device_count();
+    if (device >= n) return fail(BPSW_ERR_ARG, "bpsw_create: device index out of range");
+  }
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(BPSW_ERR_DEVICE, std::string("bpsw_create: kernels are built for gfx950, device is ") + prop.gcnArchName);
+  bpsw_ctx* c = new bpsw_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  memset(&c->stats, 0, sizeof c->stats);
+  default_mat(c->ext_mat, 1, 4);
+  c->ext_sc.mat = pack_mat(c->ext_mat);
+  c->ext_sc.zdrop = 100;
+  c->ext_sc.zdrop_mode = BPSW_ZDROP_SCALA;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
+  if (e == hipSuccess) e = c->d_pre.reserve(256);
+  if (e == hipSuccess) e = c->h_pre.reserve(256);
+  if (e != hipSuccess) {
+    bpsw_destroy(c);
+    return hip_fail(e, "bpsw_create");
+  }
+  *out = c;
+  return BPSW_OK;
+}
+
+void bpsw_destroy(bpsw_ctx_t* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->d_wire.release(); c->d_out.release(); c->d_pre.release();
+  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release();
+  c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();
+  for (int i = 0; i < 8; ++i)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int bpsw_device_of(const bpsw_ctx_t* c) { return c ? c->device : -1; }
+
+int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdrop_mode) {
+  if (!c) return fail(BPSW_ERR_ARG, "null context");
+  if (zdrop_mode != BPSW_ZDROP_SCALA && zdrop_mode != BPSW_ZDROP_BWA) return fail(BPSW_ERR_ARG, "bad zdrop_mode");
+  std::lock_guard<std::mutex> g(c->mu);
+  if (mat) memcpy(c->ext_mat, mat, 25);
+  c->ext_sc.mat = pack_mat(c->ext_mat);
+  c->ext_sc.zdrop = zdrop;
+  c->ext_sc.zdrop_mode = zdrop_mode;
+  return BPSW_OK;
+}
+
+// ------------------------------------------------------------------------------------- boundary 2
+static inline int rd16(const uint8_t* b, size_t at) { return (int16_t)(b[at] | (b[at + 1] << 8)); }
+static inline int rd32(const uint8_t* b, size_t at) {
+  return (int32_t)((uint32_t)b[at] | ((uint32_t)b[at + 1] << 8) | ((uint32_t)b[at + 2] << 16) | ((uint32_t)b[at + 3] << 24));
+}
+
+// Host-side twin of ext_prepass_kernel: validates the table, returns the LDS capacities.
+static int scan_wire(const uint8_t* wire, size_t bytes, int* n_out, int* maxq, int* maxr) {
+  if (!wire || bytes < 32 || (bytes & 3)) return fail(BPSW_ERR_ARG, "extend: wire batch shorter than its header or not word sized");
+  const int n = rd32(wire, 8);
+  if (n < 0 || 32 + 32 * (size_t)n > bytes) return fail(BPSW_ERR_ARG, "extend: task table exceeds the buffer");
+  if ((int8_t)wire[0] < 0 || (int8_t)wire[1] < 0 || (int8_t)wire[2] < 0 || (int8_t)wire[3] < 0)
+    return fail(BPSW_ERR_ARG, "extend: negative gap penalties are not supported");
+  int mq = 0, mr = 0;
+  const size_t words = bytes >> 2;
+  for (int t = 0; t < n; ++t) {
+    const size_t at = 32 + 32 * (size_t)t;
+    const int lq = rd16(wire, at), lr = rd16(wire, at + 2), rq = rd16(wire, at + 4), rr = rd16(wire, at + 6);
+    if (lq < 0 || lr < 0 || rq < 0 || rr < 0) return fail(BPSW_ERR_ARG, "extend: negative sequence length in task table");
+    const long long pos = rd32(wire, at + 8);
+    const long long w = ((long long)lq + lr + rq + rr + 7) / 8;
+    if (pos < 8 + 8ll * n || (unsigned long long)(pos + w) > words)
+      return fail(BPSW_ERR_ARG, "extend: task sequence offset outside the buffer");
+    if (lq > mq) mq = lq;
+    if (rq > mq) mq = rq;
+    if (lr > mr) mr = lr;
+    if (rr > mr) mr = rr;
+  }
+  if (mq > BPSW_EXT_MAX_QLEN || mr > BPSW_EXT_MAX_RLEN) return fail(BPSW_ERR_LIMIT, "extend: sequence longer than the kernel limit");
+  *n_out = n; *maxq = mq; *maxr = mr;
+  return BPSW_OK;
+}
+
+int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len) {
+  if (!c) return fail(BPSW_ERR_ARG, "null context");
+  int n = 0, mq = 0, mr = 0;
+  int rc = scan_wire(wire, wire_bytes, &n, &mq, &mr);
+  if (rc != BPSW_OK) return rc;
+  if (!out || out_len < 10 * (size_t)n) return fail(BPSW_ERR_CAPACITY, "extend: result buffer smaller than 10*n int16");
+  if (n == 0) return BPSW_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t out_bytes = 20 * (size_t)n;
+  HIP_TRY(c->d_wire.reserve(wire_bytes));
+  HIP_TRY(c->d_out.reserve(out_bytes));
+  HIP_TRY(c->h_stage_in.reserve(wire_bytes));
+  HIP_TRY(c->h_stage_out.reserve(out_bytes));
+  memcpy(c->h_stage_in.ptr, wire, wire_bytes);
+  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, (int16_t*)c->d_out.ptr, c->ext_sc, mq, mr, c->num_cu, c->stream));
+  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_stage_out.ptr, out_bytes);
+  float a = 0, b = 0, d = 0;
+  (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
+  c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n; c->stats.ext_wire_bytes += wire_bytes;
+  c->stats.ext_h2d_ms += a; c->stats.ext_kernel_ms += b; c->stats.ext_d2h_ms += d;
+  c->last_ext_ms = b;
+  c->have_ext_ev = false;
+  return BPSW_OK;
+}
+
+int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_bytes, int n_tasks, void* d_out,
+                             void* hip_stream) {
+  if (!c) return fail(BPSW_ERR_ARG, "null context");
+  if (!d_wire || !d_out || n_tasks < 0 || wire_bytes < 32 + 32 * (size_t)n_tasks || (wire_bytes & 3) ||
+      ((uintptr_t)d_wire & 15) || ((uintptr_t)d_out & 3))
+    return fail(BPSW_ERR_ARG, "extend_device: bad buffer arguments");
+  if (n_tasks == 0) return BPSW_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  // device-side table scan, then a tiny read-back: the launch geometry depends on the longest task
+  ExtPrepass* d_pre = (ExtPrepass*)c->d_pre.ptr;
+  ExtPrepass* h_pre = (ExtPrepass*)c->h_pre.ptr;
+  HIP_TRY(hipMemsetAsync(d_pre, 0, sizeof(ExtPrepass), s));
+  launch_ext_prepass((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, d_pre, s);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h_pre, d_pre, sizeof(ExtPrepass), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_pre->error) return fail(BPSW_ERR_ARG, "extend_device: malformed wire batch (code " + std::to_string(h_pre->error) + ")");
+  if (h_pre->max_qlen > BPSW_EXT_MAX_QLEN || h_pre->max_rlen > BPSW_EXT_MAX_RLEN)
+    return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
+  HIP_TRY(hipEventRecord(c->ev[4], s));
+  HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen, h_pre->max_rlen,
+                            c->num_cu, s));
+  HIP_TRY(hipEventRecord(c->ev[5], s));
+  c->have_ext_ev = true;
+  c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
+  return BPSW_OK;
+}
+
+int bpsw_get_stats(bpsw_ctx_t* c, bpsw_stats_t* out) {
+  if (!c || !out) return fail(BPSW_ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  *out = c->stats;
+  return BPSW_OK;
+}
+int bpsw_reset_stats(bpsw_ctx_t* c) {
+  if (!c) return fail(BPSW_ERR_ARG, "null context");
+  std::lock_guard<std::mutex> g(c->mu);
+  memset(&c->stats, 0, sizeof c->stats);
+  return BPSW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// bpsw_swalign.hip -- unbanded local affine-gap SW for the pair-end mate rescue (boundary 1), gfx950.
+//
+// What it computes: SWUtil.SWAlign2 (SWUtil.scala:583-601) = SWAlign (SWUtil.scala:417-570) forward
+// pass -> (score, tEnd, qEnd, second best outside +-ceil(score/a) rows) and, when asked for (KSW_XSTART),
+// a reverse pass over the reversed prefixes that yields (tBeg, qBeg).  Bit-exact with the Scala text,
+// including the true-DP second best (the SSE2 C differs there).
+//
+// How: one job per 64-lane wavefront, DP state entirely in registers.  The band is static, so the
+// row dependency can be skewed: lane l owns the C consecutive query columns [l*C, l*C+C) and at
+// step t works on target row t-l (a systolic anti-diagonal).  Everything a cell needs from its left
+// neighbour -- F(i,j), the diagonal H(i-1,j-1), the running row maximum and the row's target base --
+// arrives with one DPP wave_shr:1 from the previous step, so there is no in-row scan and no LDS
+// traffic in the inner loop (LDS only holds a 2 KB window of target bases).  Row i leaves the pipe at
+// lane (qLen-1)/C as key = H_max<<10 | (1023 - first argmax); the sequential per-row bookkeeping of
+// SWUtil.scala:517-538 runs on the scalar unit.
+#include "bpsw_internal.h"
+#include "bpsw_wave.h"
+
+namespace bpsw {
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int TBUF = 2048;           // target bases staged in LDS per wave
+constexpr int MINUS_INF = -0x40000000;  // SWUtil.scala:28
+
+struct PassRes {
+  int max, max_i, max_j, nb;
+};
+
+__device__ __forceinline__ int shr1_zero(int src) {  // lane l <- lane l-1 ; lane 0 <- 0
+  return __builtin_amdgcn_update_dpp(0, src, DPP_WAVE_SHR1, 0xf, 0xf, true);
+}
+
+// One SWAlign pass (SWUtil.scala:417-570) by a whole wave.
+//   pass2 == false: columns 0..qCols-1 are the mate (reverse-complemented on the fly when qrev);
+//                   rows are target[0..tLen)
+//   pass2 == true : the reversed prefixes of SWUtil.scala:588-590: column j is forward column qEnd-j,
+//                   row r is target[tEnd-r] for r <= tEnd and target[r] beyond
+template <int C>
+__device__ PassRes sw_pass(const int lane, const uint8_t* __restrict__ q, const int qLenRaw, const bool qrev,
+                           const int qCols, const bool pass2, const int qEnd, const uint8_t* __restrict__ tg,
+                           const int tLen, const int tEnd, const SwScoring& sc, const int minScore,
+                           const int endScore, const int maxScore, uint8_t* __restrict__ tbuf,
+                           uint32_t* __restrict__ list) {
+  const int eDel = sc.e_del, eIns = sc.e_ins, oeDel = sc.o_del + sc.e_del, oeIns = sc.o_ins + sc.e_ins;
+  int prof_lo[C], prof_hi[C], cmask[C], ckey[C], Hp[C], E[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = lane * C + c;
+    const bool valid = j < qCols;
+    int code = 4;
+    if (valid) {
+      const int fc = pass2 ? qEnd - j : j;
+      const int raw = qrev ? qLenRaw - 1 - fc : fc;
+      code = q[raw];
+      if (qrev) code = code < 4 ? 3 - code : 4;  // MemSamPe.scala:1178-1181
+      if (code > 4) code = 4;
+    }
+    const int sh = 8 * code;
+    prof_lo[c] = (int)(((sc.mat.row[0] >> sh) & 0xff) | (((sc.mat.row[1] >> sh) & 0xff) << 8) |
+                       (((sc.mat.row[2] >> sh) & 0xff) << 16) | (((sc.mat.row[3] >> sh) & 0xff) << 24));
+    prof_hi[c] = (int)(((sc.mat.row[4] >> sh) & 0xff) | 0x80808000u);  // row 4 = N, codes 5..7 = "no row": -128
+    cmask[c] = valid ? -1 : 0;
+    ckey[c] = 1023 - j;
+    Hp[c] = 0;
+    E[c] = 0;
+  }
+  int hlast_cur = 0, hlast_old = 0, fout = 0, keyout = 0;
+  int tcode = 5;
+  const int Lq = (qCols - 1) / C;  // lane that holds the last real column
+  const int nsteps = tLen + Lq;
+  int mx = MINUS_INF, max_i = -1, max_j = -1, nb = 0, lastScore = 0, lastT = -2;
+
+  for (int t = 0; t < nsteps; ++t) {
+    if ((t & (TBUF - 1)) == 0) {  // stage the next window of target bases
+      __builtin_amdgcn_wave_barrier();
+      for (int k = lane; k < TBUF; k += 64) {
+        const int r = t + k;
+        int code = 5;
+        if (r < tLen) {
+          const int src = (pass2 && r <= tEnd) ? tEnd - r : r;
+          code = tg[src];
+          if (code > 4) code = 4;
+        }
+        tbuf[k] = (uint8_t)code;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const int ch = tbuf[t & (TBUF - 1)];
+    tcode = wave_shr1(ch, tcode);                 // lane 0 starts row t, lane l continues row t-l
+    const int din = shr1_zero(hlast_old);         // H(i-1, l*C-1)
+    const int fin = shr1_zero(fout);              // F(i, l*C)
+    const int kin = shr1_zero(keyout);            // row maximum so far
+    hlast_old = hlast_cur;
+    const bool lo_sel = tcode < 4;
+    const unsigned sh = (unsigned)(tcode & 3) * 8u;
+    int diag = din, f = fin, key = kin;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {  // SWUtil.scala:484-505
+      const int pw = lo_sel ? prof_lo[c] : prof_hi[c];
+      const int s = __builtin_amdgcn_sbfe(pw, sh, 8u);
+      const int h = max3i(diag + s, E[c], f) & cmask[c];
+      diag = Hp[c];
+      Hp[c] = h;
+      key = max(key, (h << 10) | ckey[c]);  // first arg-max wins ties (SWUtil.scala:493)
+      E[c] = max3i(E[c] - eDel, h - oeDel, 0);
+      f = max3i(f - eIns, h - oeIns, 0);
+    }
+    hlast_cur = Hp[C - 1];
+    fout = f;
+    keyout = key;
+
+    const int i = t - Lq;  // the row that has just left the pipe
+    if (i >= 0) {
+      const int skey = __builtin_amdgcn_readlane(keyout, Lq);
+      const int m = skey >> 10;
+      if (m >= minScore) {  // SWUtil.scala:517-529
+        if (nb == 0 || lastT + 1 != i) {
+          if (lane == 0) list[nb] = ((uint32_t)m << 16) | (uint32_t)i;
+          ++nb; lastScore = m; lastT = i;
+        } else if (lastScore < m) {
+          if (lane == 0) list[nb - 1] = ((uint32_t)m << 16) | (uint32_t)i;
+          lastScore = m; lastT = i;
+        }
+      }
+      if (m > mx) {  // SWUtil.scala:532-538
+        mx = m; max_i = i;
+        max_j = m ? 1023 - (skey & 1023) : -1;
+        if (mx >= endScore || mx >= maxScore) break;
+      }
+    }
+  }
+  PassRes r;
+  r.max = mx; r.max_i = max_i; r.max_j = max_j; r.nb = nb;
+  return r;
+}
+
+template <int C>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(const SwJobsDev jobs, const SwScoring sc,
+                                                                    int32_t* __restrict__ out,
+                                                                    uint32_t* __restrict__ scratch,
+                                                                    const int scratch_per_wave) {
+  __shared__ uint8_t tbuf_all[WAVES_PER_BLOCK][TBUF];
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int slot = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  uint8_t* tbuf = tbuf_all[wave];
+  uint32_t* list = scratch + (size_t)slot * scratch_per_wave;
+  const int maxScore = 255 - abs(sc.b);  // SWUtil.scala:423
+  const int xtra = sc.xtra;
+  const int stride = gridDim.x * WAVES_PER_BLOCK;
+
+  for (int job = slot; job < jobs.n; job += stride) {
+    const int qLen = uni(jobs.q_len[job]), tLen = uni(jobs.t_len[job]);
+    const uint8_t* q = jobs.q_pool + jobs.q_off[job];
+    const uint8_t* tg = jobs.t_pool + jobs.t_off[job];
+    const bool qrev = uni((int)jobs.q_rev[job]) != 0;
+
+    const int minScore = (xtra & BPSW_KSW_XSUBO) ? (xtra & 0xffff) : 0x10000;  // SWUtil.scala:434-437
+    const int endScore = (xtra & BPSW_KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
+    const PassRes f = sw_pass<C>(lane, q, qLen, qrev, qLen, false, 0, tg, tLen, 0, sc, minScore, endScore, maxScore,
+                                 tbuf, list);
+    int score = f.max >= maxScore ? 255 : f.max;  // SWUtil.scala:544
+    const int te = f.max_i;
+    int qe = -1, score2 = -1, te2 = -1, tb = -1, qb = -1;
+    if (score != 255) {  // SWUtil.scala:549-567
+      qe = f.max_j;
+      if (f.nb > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // lane 0's list writes -> all lanes
+        const int tmp = (score + sc.a - 1) / sc.a;
+        const int low = te - tmp, high = te + tmp;
+        int best = -1;
+        for (int k = lane; k < f.nb; k += 64) {
+          const uint32_t e = list[k];
+          const int tE = (int)(e & 0xffffu);
+          if (tE < low || tE > high) best = max(best, (int)((e >> 16) << 16) | (0xffff - k));  // first wins ties
+        }
+        best = wave_max(best);
+        if (best >= 0) {
+          const int idx = 0xffff - (best & 0xffff);
+          score2 = best >> 16;
+          te2 = uni((int)(list[idx] & 0xffffu));
+        }
+      }
+    }
+    // SWUtil.scala:586-598
+    const bool want_start = (xtra & BPSW_KSW_XSTART) && !((xtra & BPSW_KSW_XSUBO) && score < (xtra & 0xffff));
+    if (want_start && qe >= 0 && te >= 0) {
+      const PassRes r = sw_pass<C>(lane, q, qLen, qrev, qe + 1, true, qe, tg, tLen, te, sc, 0x10000, score & 0xffff,
+                                   maxScore, tbuf, list);
+      const int rscore = r.max >= maxScore ? 255 : r.max;
+      if (score == rscore) {
+        tb = te - r.max_i;
+        qb = qe - r.max_j;
+      }
+    }
+    if (lane == 0) {
+      int32_t* o = out + 7 * (size_t)job;
+      o[0] = score; o[1] = te; o[2] = qe; o[3] = score2; o[4] = te2; o[5] = tb; o[6] = qb;
+    }
+  }
+}
+
+// validates the job table and finds the longest mate / window
+__global__ void sw_prepass_kernel(const SwJobsDev jobs, const unsigned long long q_pool_bytes,
+                                  const unsigned long long t_pool_bytes, SwPrepass* __restrict__ pre) {
+  int mq = 0, mt = 0, err = 0;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < jobs.n; j += gridDim.x * blockDim.x) {
+    const int ql = jobs.q_len[j], tl = jobs.t_len[j];
+    const long long qo = jobs.q_off[j], to = jobs.t_off[j];
+    if (ql < 1 || tl < 0 || qo < 0 || to < 0 || (unsigned long long)(qo + ql) > q_pool_bytes ||
+        (unsigned long long)(to + tl) > t_pool_bytes) {
+      err = 1;
+      continue;
+    }
+    mq = max(mq, ql);
+    mt = max(mt, tl);
+  }
+  if (mq) atomicMax(&pre->max_qlen, mq);
+  if (mt) atomicMax(&pre->max_tlen, mt);
+  if (err) atomicMax(&pre->error, err);
+}
+
+template <int C>
+hipError_t launch_c(const SwJobsDev& jobs, const SwScoring& sc, int32_t* d_out, uint32_t* d_scratch, int per_wave,
+                    int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(sw_kernel<C>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_wave);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+void launch_sw_prepass(const SwJobsDev& jobs, size_t q_pool_bytes, size_t t_pool_bytes, SwPrepass* d_pre, hipStream_t s) {
+  const int threads = 256;
+  int blocks = (jobs.n + threads - 1) / threads;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(sw_prepass_kernel, dim3(blocks), dim3(threads), 0, s, jobs, (unsigned long long)q_pool_bytes,
+                     (unsigned long long)t_pool_bytes, d_pre);
+}
+
+// one uint32 list entry per target row, per resident wave
+size_t sw_scratch_bytes_per_wave(int max_tlen) { return 4 * (((size_t)max_tlen + 63) & ~(size_t)63); }
+int sw_resident_waves(int num_cu) { return num_cu * 8 * WAVES_PER_BLOCK; }
+
+hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
+                            uint32_t* d_scratch, int num_cu, hipStream_t s) {
+  if (jobs.n <= 0) return hipSuccess;
+  int blocks = (jobs.n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  const int max_blocks = num_cu * 8;
+  if (blocks > max_blocks) blocks = max_blocks;
+  const int per_wave = (int)(sw_scratch_bytes_per_wave(max_tlen) / 4);
+  const int c = (max_qlen + 63) / 64;
+  if (c <= 1) return launch_c<1>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
+  if (c == 2) return launch_c<2>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
+  if (c == 3) return launch_c<3>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
+  if (c == 4) return launch_c<4>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
+  if (c <= 6) return launch_c<6>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
+  if (c <= 8) return launch_c<8>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace bpsw

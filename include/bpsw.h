@@ -1,0 +1,187 @@
+/*
+ * bpsw.h -- C ABI of libbPSW_hip.so, the MI355X (gfx950) batched Smith-Waterman plug-in for
+ * CS-BWAMEM (ytchen0323/cloud-scale-bwamem).
+ *
+ * The library is a drop-in for the reference's two native plug-in points; the JNI symbols the
+ * Scala driver binds are exported by the same .so (csrc/bpsw_jni.cpp) and are thin marshalling
+ * shims over the functions declared here:
+ *
+ *   boundary 2  SWExtendFPGAJNI.swExtendFPGAJNI(n, bytes)          -> bpsw_extend_batch
+ *               replaces src/main/jni_fpga/sw_extend_fpga.c:116-193 + src/main/alphadata/shm_host.c
+ *               (declared at src/main/scala/cs/ucla/edu/bwaspark/jni/SWExtendFPGAJNI.scala:22,
+ *                called at  .../worker1/MemChainToAlignBatched.scala:175-176)
+ *   boundary 1  MateSWJNI.mateSWJNI(opt,pacLen,pes,n,seqs,regs,refs,refSizes) -> bpsw_matesw_group
+ *               replaces src/main/native/jni_mate_sw.c:58-662 + native/bwamem_pair.c:115-228
+ *               (declared at .../jni/MateSWJNI.scala:24-25, called at .../worker2/MemSamPe.scala:2091-2092)
+ *
+ * All pointers are plain host (or, for the *_device entry points, device) pointers with explicit
+ * sizes; no C++/torch types cross this boundary.  Every function returns BPSW_OK (0) or a negative
+ * error code; bpsw_last_error() gives the text.  There is NO CPU fallback: if no HIP device is
+ * usable the calls fail with BPSW_ERR_DEVICE.
+ *
+ * Thread safety: a bpsw_ctx_t serialises its own calls with an internal mutex; use one context
+ * per host thread (the JNI shim keeps one per thread per device) for concurrency.
+ */
+#ifndef BPSW_H
+#define BPSW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPSW_OK 0
+#define BPSW_ERR_ARG (-1)      /* malformed argument / wire batch */
+#define BPSW_ERR_DEVICE (-2)   /* HIP runtime failure or no gfx950 device */
+#define BPSW_ERR_CAPACITY (-3) /* caller's output buffer too small */
+#define BPSW_ERR_LIMIT (-4)    /* sequence longer than the kernels support */
+
+#define BPSW_ZDROP_SCALA 0 /* SWUtil.scala:194-199 (default: bit-exact vs the Scala extension()) */
+#define BPSW_ZDROP_BWA 1   /* native/ksw.c:455-461 */
+
+#define BPSW_RESCUE_C 0     /* bookkeeping of native/bwamem_pair.c + bwamem.c (what -bPSWJNI 1 does today) */
+#define BPSW_RESCUE_SCALA 1 /* bookkeeping of MemSamPe.scala:1111-1238 (what -bPSWJNI 0 does) */
+
+#define BPSW_KSW_XBYTE 0x10000
+#define BPSW_KSW_XSTOP 0x20000
+#define BPSW_KSW_XSUBO 0x40000
+#define BPSW_KSW_XSTART 0x80000
+
+/* kernel limits (checked on the host before every launch) */
+#define BPSW_EXT_MAX_QLEN 1023  /* per-side query length of an extension task */
+#define BPSW_EXT_MAX_RLEN 4095  /* per-side reference length of an extension task */
+#define BPSW_SW_MAX_QLEN 512    /* mate length of a rescue job */
+#define BPSW_SW_MAX_TLEN 65535  /* window length of a rescue job */
+
+typedef struct bpsw_ctx bpsw_ctx_t;
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+int bpsw_device_count(void);
+/* device < 0: pick from BPSW_DEVICES / round robin (INTEGRATION.md "device selection") */
+int bpsw_create(int device, bpsw_ctx_t **out);
+void bpsw_destroy(bpsw_ctx_t *ctx);
+int bpsw_device_of(const bpsw_ctx_t *ctx);
+const char *bpsw_last_error(void); /* thread-local text of the last failing call */
+const char *bpsw_version(void);
+
+/* ---- scoring that boundary 2 does not transmit (zdrop, mat) ------------------ */
+/* defaults: MemOptType (datatype/MemOptType.scala:28-73): a=1 b=4 N=-1, zdrop=100, Scala z-drop parse */
+int bpsw_set_ext_scoring(bpsw_ctx_t *ctx, const int8_t mat[25], int zdrop, int zdrop_mode);
+
+/* ---- boundary 2: batched seed extension -------------------------------------------------- */
+/*
+ * wire = header(32 B) | task table (32 B x n) | nibble-packed sequences, exactly the byte[] built
+ * by runOnFPGAJNI (MemChainToAlignBatched.scala:76-172).  out receives 10 int16 per task
+ * (MemChainToAlignBatched.scala:181-188): idx lo, idx hi, qBeg, qEnd, rBeg, rEnd, score,
+ * trueScore, width, 0.  out_len is the capacity of out in int16 units (>= 10*n).
+ */
+int bpsw_extend_batch(bpsw_ctx_t *ctx, const uint8_t *wire, size_t wire_bytes, int16_t *out, size_t out_len);
+
+/* Same computation with the wire batch and the result already resident in device memory
+ * (used by bench.py; d_wire must be 16-byte aligned).  hip_stream is a hipStream_t or NULL for the context's stream.
+ * The call is asynchronous with respect to the host when a stream is given. */
+int bpsw_extend_batch_device(bpsw_ctx_t *ctx, const void *d_wire, size_t wire_bytes, int n_tasks,
+                             void *d_out, void *hip_stream);
+
+/* Host-side mirror of the Scala packer (MemChainToAlignBatched.scala:76-172) for non-JVM callers.
+ * SoA task description; sequences are byte-per-base codes 0..4 in `pool` (left_* already reversed). */
+typedef struct {
+  int32_t n;
+  int32_t o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w; /* header fields */
+  int32_t mat_max;                                             /* max(mat), feeds the maxIns/maxDel shorts */
+  const int32_t *left_qlen, *left_rlen, *right_qlen, *right_rlen;
+  const int64_t *left_q_off, *left_r_off, *right_q_off, *right_r_off; /* into pool */
+  const int32_t *reg_score, *q_beg, *h0, *idx;
+  const uint8_t *pool;
+} bpsw_ext_tasks_t;
+size_t bpsw_wire_size(const bpsw_ext_tasks_t *t);
+int bpsw_wire_pack(const bpsw_ext_tasks_t *t, uint8_t *buf, size_t cap, size_t *bytes);
+
+/* ---- boundary 1: pair-end mate-SW rescue -------------------------------------------------- */
+typedef struct { /* == mem_alnreg_t native/bwamem.h:49-61 == MemAlnRegType.scala:26-38 */
+  int64_t rb, re;
+  int32_t qb, qe, score, truesc, sub, csub, sub_n, w, seedcov, secondary;
+  uint64_t hash;
+} bpsw_alnreg_t; /* 64 bytes */
+
+typedef struct { /* == mem_pestat_t native/bwamem.h:65-69 == MemPeStat.scala:27-31 */
+  int32_t low, high, failed, pad_;
+  double avg, std;
+} bpsw_pestat_t;
+
+typedef struct { /* the MemOptType fields the rescue reads (native/jni_mate_sw.c:177-221) */
+  int32_t a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, pen_clip5, pen_clip3, w, zdrop, T, flag,
+      min_seed_len, max_ins, max_matesw;
+  float mask_level_redun;
+  int8_t mat[25];
+  int8_t pad_[3];
+} bpsw_opt_t;
+void bpsw_opt_default(bpsw_opt_t *opt);
+
+/*
+ * Raw local-SW jobs (SWUtil.SWAlign2, SWUtil.scala:583-601), one per (anchor, orientation).
+ * Job t aligns query bytes q_pool[q_off[t] .. +q_len[t]) -- reverse-complemented on the fly when
+ * q_rev[t] != 0 (MemSamPe.scala:1175-1184) -- against t_pool[t_off[t] .. +t_len[t]).
+ * out receives 7 int32 per job: score, tEnd, qEnd, score2, tEnd2, tBeg, qBeg.
+ */
+typedef struct {
+  int32_t n;
+  int32_t xtra; /* KSW_X* flags | min score, same for all jobs (MemSamPe.scala:1187-1189) */
+  const int32_t *q_len, *t_len;
+  const int64_t *q_off, *t_off;
+  const uint8_t *q_rev;
+  const uint8_t *q_pool, *t_pool;
+  size_t q_pool_bytes, t_pool_bytes;
+} bpsw_sw_jobs_t;
+int bpsw_swalign2_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_sw_jobs_t *jobs, int32_t *out);
+
+/* Device-resident form: every array pointer in `jobs` is a device pointer (pools 16-byte aligned). */
+int bpsw_swalign2_batch_device(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_sw_jobs_t *jobs,
+                               void *d_out, void *hip_stream);
+
+/*
+ * The whole boundary-1 call in flat SoA form (what the JNI shim builds from the object arrays):
+ *   seq_len/seq_off[2G]   mate sequences (codes 0..4) in seq_pool, index 2k+i
+ *   reg_cnt[2G], regs     existing regions concatenated in (k,i,j) order (MemSamPe.scala:1963-1990)
+ *   ref_cnt[2G]           refSizeArray (MemSamPe.scala:1944-1947)
+ *   ref_rb/re/len/off[4R] per (k,i,j<ref_cnt) x 4 orientations; window bytes at ref_pool+ref_off
+ *   out_cnt[2G], out_regs regions after rescue in (k,i,rank) order; *out_total = sum(out_cnt)
+ * Returns BPSW_ERR_CAPACITY (with *out_total set to the needed size) if out_cap is too small.
+ */
+typedef struct {
+  int32_t group_size;
+  int64_t l_pac;
+  bpsw_pestat_t pes[4];
+  const int32_t *seq_len;
+  const int64_t *seq_off;
+  const uint8_t *seq_pool;
+  size_t seq_pool_bytes;
+  const int32_t *reg_cnt;
+  const bpsw_alnreg_t *regs;
+  const int32_t *ref_cnt;
+  const int64_t *ref_rb, *ref_re, *ref_len, *ref_off;
+  const uint8_t *ref_pool;
+  size_t ref_pool_bytes;
+} bpsw_rescue_group_t;
+int bpsw_matesw_group(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_rescue_group_t *g, int mode,
+                      int32_t *out_cnt, bpsw_alnreg_t *out_regs, int64_t out_cap, int64_t *out_total);
+
+/* ---- statistics (the buckets of profiling/SWBatchTimeBreakdown.scala:25-39, device flavoured) -- */
+typedef struct {
+  uint64_t ext_calls, ext_tasks, ext_wire_bytes;
+  uint64_t sw_calls, sw_jobs, sw_speculated, sw_replayed_rounds, sw_wasted;
+  double ext_h2d_ms, ext_kernel_ms, ext_d2h_ms;
+  double sw_h2d_ms, sw_kernel_ms, sw_d2h_ms, sw_host_ms;
+} bpsw_stats_t;
+int bpsw_get_stats(bpsw_ctx_t *ctx, bpsw_stats_t *out);
+int bpsw_reset_stats(bpsw_ctx_t *ctx);
+/* duration in ms of the most recent extend / swalign kernel launch on this context, measured with
+ * hipEvents on the launch stream (synchronises the stream). */
+int bpsw_last_kernel_ms(bpsw_ctx_t *ctx, float *ext_ms, float *sw_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

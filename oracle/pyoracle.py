@@ -1,0 +1,259 @@
+"""ctypes bindings for the parity oracle -- TEST INFRASTRUCTURE ONLY.
+
+`Oracle`  : oracle/_build/libbpsw_oracle.so, our C restatement of the Scala SW path (bpsw_oracle.c).
+`Ref`     : oracle/_ref/libbwaref.so, the reference's own C sources compiled in place (oracle/Makefile
+            `make ref`); present only where /root/reference was available at build time or the prebuilt
+            .so travelled with the snapshot.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "_build", "libbpsw_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libbwaref.so")
+
+ZDROP_SCALA, ZDROP_BWA = 0, 1
+RESCUE_C, RESCUE_SCALA = 0, 1
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+
+ALNREG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"),
+                         ("truesc", "<i4"), ("sub", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"), ("w", "<i4"),
+                         ("seedcov", "<i4"), ("secondary", "<i4"), ("hash", "<u8")])
+
+
+def build(ref: bool = True):
+    subprocess.run(["make", "-C", HERE, "-s"], check=True)
+    if ref:
+        subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
+
+
+class ExtParam(C.Structure):
+    _fields_ = [("left_qlen", C.c_int32), ("left_rlen", C.c_int32), ("right_qlen", C.c_int32), ("right_rlen", C.c_int32),
+                ("left_qs", C.c_void_p), ("left_rs", C.c_void_p), ("right_qs", C.c_void_p), ("right_rs", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("w", "o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "zdrop", "h0",
+                                         "reg_score", "q_beg", "idx")] + [("mat", C.c_void_p)]
+
+
+class ExtRet(C.Structure):
+    _fields_ = [("q_beg", C.c_int32), ("q_end", C.c_int32), ("r_beg", C.c_int64), ("r_end", C.c_int64),
+                ("score", C.c_int32), ("true_score", C.c_int32), ("width", C.c_int32), ("idx", C.c_int32)]
+
+
+class PeStat(C.Structure):
+    _fields_ = [("low", C.c_int32), ("high", C.c_int32), ("failed", C.c_int32), ("pad_", C.c_int32),
+                ("avg", C.c_double), ("std", C.c_double)]
+
+
+class Opt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_unpaired", "pen_clip5",
+                                         "pen_clip3", "w", "zdrop", "T", "flag", "min_seed_len", "max_ins",
+                                         "max_matesw")] + [("mask_level_redun", C.c_float), ("mat", C.c_int8 * 25),
+                                                           ("pad_", C.c_int8 * 3)]
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_mat(a: int = 1, b: int = 4) -> np.ndarray:
+    m = np.full((5, 5), -1, dtype=np.int8)
+    for i in range(4):
+        for j in range(4):
+            m[i, j] = a if i == j else -b
+    return m.reshape(25)
+
+
+class Oracle:
+    def __init__(self, path: str = ORACLE_SO):
+        if not os.path.exists(path):
+            build(ref=False)
+        self.lib = C.CDLL(path)
+        self.lib.orc_wire_size.restype = C.c_size_t
+        self.lib.orc_wire_pack.restype = C.c_size_t
+        self.lib.orc_matesw_group.restype = C.c_int64
+        self.lib.orc_sw_global.restype = C.c_int
+
+    def default_opt(self) -> Opt:
+        o = Opt()
+        self.lib.orc_opt_default(C.byref(o))
+        return o
+
+    def sw_extend(self, query, target, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0, zdrop_mode=ZDROP_SCALA):
+        q = np.ascontiguousarray(query, np.uint8)
+        t = np.ascontiguousarray(target, np.uint8)
+        m = np.ascontiguousarray(mat, np.int8)
+        out = np.zeros(6, np.int32)
+        cells = C.c_int64(0)
+        self.lib.orc_sw_extend(C.c_int(q.size), _vp(q), C.c_int(t.size), _vp(t), 5, _vp(m), o_del, e_del, o_ins, e_ins,
+                               w, end_bonus, zdrop, h0, zdrop_mode, _vp(out), C.byref(cells))
+        return out, cells.value
+
+    def wire_extend(self, wire, mat=None, zdrop=100, zdrop_mode=ZDROP_SCALA):
+        """decode a boundary-2 batch and run extension() per task -> (int16[10n], cells)"""
+        wire = np.ascontiguousarray(wire, np.uint8)
+        m = np.ascontiguousarray(default_mat() if mat is None else mat, np.int8)
+        n = int(np.frombuffer(wire[8:12].tobytes(), "<i4")[0])
+        out = np.zeros(max(10 * n, 1), np.int16)
+        cells = C.c_int64(0)
+        rc = self.lib.orc_wire_extend(_vp(wire), C.c_size_t(wire.size), _vp(m), zdrop, zdrop_mode, _vp(out), C.byref(cells))
+        if rc < 0:
+            raise ValueError("malformed wire batch")
+        return out[: 10 * n], cells.value
+
+    def wire_pack_soa(self, soa, mat=None):
+        """pack an ExtTaskSoA through the ORACLE's packer (MemChainToAlignBatched.scala:76-172)"""
+        m = np.ascontiguousarray(default_mat() if mat is None else mat, np.int8)
+        n = soa.n
+        arr = (ExtParam * n)()
+        base = soa.pool.ctypes.data
+        for i in range(n):
+            p = arr[i]
+            p.left_qlen, p.left_rlen = int(soa.left_qlen[i]), int(soa.left_rlen[i])
+            p.right_qlen, p.right_rlen = int(soa.right_qlen[i]), int(soa.right_rlen[i])
+            p.left_qs, p.left_rs = base + int(soa.left_q_off[i]), base + int(soa.left_r_off[i])
+            p.right_qs, p.right_rs = base + int(soa.right_q_off[i]), base + int(soa.right_r_off[i])
+            p.w, p.o_del, p.e_del, p.o_ins, p.e_ins = soa.w, soa.o_del, soa.e_del, soa.o_ins, soa.e_ins
+            p.pen_clip5, p.pen_clip3, p.zdrop = soa.pen_clip5, soa.pen_clip3, 100
+            p.h0, p.reg_score, p.q_beg, p.idx = int(soa.h0[i]), int(soa.reg_score[i]), int(soa.q_beg[i]), int(soa.idx[i])
+            p.mat = m.ctypes.data
+        size = self.lib.orc_wire_size(n, arr)
+        buf = np.zeros(size, np.uint8)
+        got = self.lib.orc_wire_pack(n, arr, _vp(buf), C.c_size_t(size))
+        assert got == size
+        return buf
+
+    def sw_align2(self, query, target, opt: Opt, xtra, two_pass=True):
+        q = np.ascontiguousarray(query, np.uint8)
+        t = np.ascontiguousarray(target, np.uint8)
+        out = np.zeros(7, np.int32)
+        cells = C.c_int64(0)
+        fn = self.lib.orc_sw_align2 if two_pass else self.lib.orc_sw_align
+        fn(C.c_int(q.size), _vp(q), C.c_int(t.size), _vp(t), 5, C.byref(opt, Opt.mat.offset), opt.a, opt.b, opt.o_del,
+           opt.e_del, opt.o_ins, opt.e_ins, C.c_int(xtra), _vp(out), C.byref(cells))
+        return out, cells.value
+
+    def sw_align2_jobs(self, opt: Opt, xtra, q_len, t_len, q_off, t_off, q_rev, q_pool, t_pool):
+        n = len(q_len)
+        out = np.zeros((n, 7), np.int32)
+        cells = 0
+        for i in range(n):
+            q = q_pool[q_off[i]: q_off[i] + q_len[i]]
+            if q_rev[i]:
+                q = np.where(q[::-1] < 4, 3 - q[::-1], 4).astype(np.uint8)  # MemSamPe.scala:1175-1184
+            o, c = self.sw_align2(q, t_pool[t_off[i]: t_off[i] + t_len[i]], opt, xtra)
+            out[i] = o
+            cells += c
+        return out, cells
+
+    def sw_global(self, query, target, mat, o_del, e_del, o_ins, e_ins, w):
+        q = np.ascontiguousarray(query, np.uint8)
+        t = np.ascontiguousarray(target, np.uint8)
+        m = np.ascontiguousarray(mat, np.int8)
+        cap = q.size + t.size + 4
+        cig = np.zeros(cap, np.uint32)
+        nc = C.c_int(0)
+        score = self.lib.orc_sw_global(C.c_int(q.size), _vp(q), C.c_int(t.size), _vp(t), 5, _vp(m), o_del, e_del, o_ins,
+                                       e_ins, w, C.byref(nc), _vp(cig), cap)
+        return score, cig[: nc.value].copy()
+
+    def sort_dedup(self, regs: np.ndarray, mask_level_redun=0.95, mode=RESCUE_C) -> np.ndarray:
+        a = np.ascontiguousarray(regs.copy())
+        n = self.lib.orc_sort_dedup(C.c_int(a.shape[0]), _vp(a), C.c_float(mask_level_redun), mode)
+        return a[:n]
+
+    def matesw_group(self, opt: Opt, g, mode=RESCUE_C):
+        """g: bpsw_hip.RescueGroupSoA (same flat layout)."""
+        pes = (PeStat * 4)()
+        for r in range(4):
+            pes[r].low, pes[r].high, pes[r].failed, pes[r].avg, pes[r].std = g.pes[r]
+        out_cnt = np.zeros(2 * g.group_size, np.int32)
+        cap = int(g.regs.shape[0] + 4 * g.ref_rb.shape[0] + 16)
+        out = np.zeros(cap, ALNREG_DTYPE)
+        n_sw, cells = C.c_int64(0), C.c_int64(0)
+        total = self.lib.orc_matesw_group(C.byref(opt), C.c_int64(g.l_pac), pes, g.group_size, _vp(g.seq_len), _vp(g.seq_off),
+                                          _vp(g.seq_pool), _vp(g.reg_cnt), _vp(g.regs), _vp(g.ref_cnt), _vp(g.ref_rb),
+                                          _vp(g.ref_re), _vp(g.ref_len), _vp(g.ref_off), _vp(g.ref_pool), mode,
+                                          _vp(out_cnt), _vp(out), C.c_int64(cap), C.byref(n_sw), C.byref(cells))
+        assert total >= 0
+        return out_cnt, out[:total], n_sw.value, cells.value
+
+
+class KswrT(C.Structure):  # kswr_t, native/ksw.h
+    _fields_ = [("score", C.c_int), ("te", C.c_int), ("qe", C.c_int), ("score2", C.c_int), ("te2", C.c_int),
+                ("tb", C.c_int), ("qb", C.c_int)]
+
+
+class Ref:
+    """The reference's own C (bwa-0.7.8 as vendored under src/main/native), compiled in place."""
+
+    def __init__(self, path: str = REF_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.lib.ksw_align2.restype = KswrT
+        self.lib.ref_group_matesw_flat.restype = C.c_int64
+        self.libc = C.CDLL(None)
+        self.libc.free.argtypes = [C.c_void_p]
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_SO)
+
+    def ksw_extend2(self, query, target, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0):
+        q = np.ascontiguousarray(query, np.uint8)
+        t = np.ascontiguousarray(target, np.uint8)
+        m = np.ascontiguousarray(mat, np.int8)
+        qle, tle, gtle, gscore, max_off = (C.c_int(0) for _ in range(5))
+        score = self.lib.ksw_extend2(C.c_int(q.size), _vp(q), C.c_int(t.size), _vp(t), 5, _vp(m), o_del, e_del, o_ins,
+                                     e_ins, w, end_bonus, zdrop, h0, C.byref(qle), C.byref(tle), C.byref(gtle),
+                                     C.byref(gscore), C.byref(max_off))
+        return np.array([score, qle.value, tle.value, gtle.value, gscore.value, max_off.value], np.int32)
+
+    def ksw_align2(self, query, target, mat, o_del, e_del, o_ins, e_ins, xtra):
+        q = np.ascontiguousarray(query, np.uint8).copy()  # reversed in place and restored
+        t = np.ascontiguousarray(target, np.uint8).copy()
+        m = np.ascontiguousarray(mat, np.int8)
+        r = self.lib.ksw_align2(C.c_int(q.size), _vp(q), C.c_int(t.size), _vp(t), 5, _vp(m), o_del, e_del, o_ins, e_ins,
+                                C.c_int(xtra), None)
+        return np.array([r.score, r.te, r.qe, r.score2, r.te2, r.tb, r.qb], np.int32)
+
+    def ksw_global2(self, query, target, mat, o_del, e_del, o_ins, e_ins, w):
+        q = np.ascontiguousarray(query, np.uint8)
+        t = np.ascontiguousarray(target, np.uint8)
+        m = np.ascontiguousarray(mat, np.int8)
+        nc = C.c_int(0)
+        cig = C.POINTER(C.c_uint32)()
+        score = self.lib.ksw_global2(C.c_int(q.size), _vp(q), C.c_int(t.size), _vp(t), 5, _vp(m), o_del, e_del, o_ins,
+                                     e_ins, w, C.byref(nc), C.byref(cig))
+        out = np.array([cig[i] for i in range(nc.value)], np.uint32)
+        self.libc.free(C.cast(cig, C.c_void_p))
+        return score, out
+
+    def sort_dedup(self, regs: np.ndarray, mask_level_redun=0.95) -> np.ndarray:
+        a = np.ascontiguousarray(regs.copy())
+        n = self.lib.mem_sort_and_dedup(C.c_int(a.shape[0]), _vp(a), C.c_float(mask_level_redun))
+        return a[:n]
+
+    def matesw_group(self, opt: Opt, g):
+        ints = np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_unpaired, opt.pen_clip5,
+                         opt.pen_clip3, opt.w, opt.zdrop, opt.T, opt.flag, opt.min_seed_len, opt.max_ins,
+                         opt.max_matesw], np.int32)
+        mat = np.array(list(opt.mat), np.int8)
+        pes = (PeStat * 4)()
+        for r in range(4):
+            pes[r].low, pes[r].high, pes[r].failed, pes[r].avg, pes[r].std = g.pes[r]
+        out_cnt = np.zeros(2 * g.group_size, np.int32)
+        cap = int(g.regs.shape[0] + 4 * g.ref_rb.shape[0] + 16)
+        out = np.zeros(cap, ALNREG_DTYPE)
+        total = self.lib.ref_group_matesw_flat(_vp(ints), C.c_float(opt.mask_level_redun), _vp(mat), C.c_int64(g.l_pac), pes,
+                                               g.group_size, _vp(g.seq_len), _vp(g.seq_off), _vp(g.seq_pool), _vp(g.reg_cnt),
+                                               _vp(g.regs), _vp(g.ref_cnt), _vp(g.ref_rb), _vp(g.ref_re), _vp(g.ref_len),
+                                               _vp(g.ref_off), _vp(g.ref_pool), _vp(out_cnt), _vp(out), C.c_int64(cap))
+        assert total >= 0
+        return out_cnt, out[:total]

@@ -1,0 +1,113 @@
+/*
+ * ref_shim.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin adapter compiled INTO oracle/_ref/libbwaref.so together with the reference's own C
+ * sources (taken where they lie under /root/reference/src/main/native, never copied).  It only
+ * re-shapes the nested pointer arguments of mem_group_matesw (native/bwamem.h:108) into the flat
+ * SoA form the tests use; every computation is the reference's.  ksw_extend2, ksw_align2,
+ * ksw_global2 and mem_sort_and_dedup are called directly through ctypes and need no adapter.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bwamem.h" /* from the reference include path, see oracle/Makefile */
+#include "kvec.h"
+
+typedef struct {
+  int64_t rb, re;
+  int32_t qb, qe, score, truesc, sub, csub, sub_n, w, seedcov, secondary;
+  uint64_t hash;
+} flat_alnreg_t;
+
+typedef struct {
+  int32_t low, high, failed, pad_;
+  double avg, std;
+} flat_pestat_t;
+
+void ref_opt_default(int32_t ints[16], float *mask_level_redun, int8_t mat[25]) {
+  mem_opt_t *o = mem_opt_init();
+  ints[0] = o->a; ints[1] = o->b; ints[2] = o->o_del; ints[3] = o->e_del; ints[4] = o->o_ins; ints[5] = o->e_ins;
+  ints[6] = o->pen_unpaired; ints[7] = o->pen_clip5; ints[8] = o->pen_clip3; ints[9] = o->w; ints[10] = o->zdrop;
+  ints[11] = o->T; ints[12] = o->flag; ints[13] = o->min_seed_len; ints[14] = o->max_ins; ints[15] = o->max_matesw;
+  *mask_level_redun = o->mask_level_redun;
+  memcpy(mat, o->mat, 25);
+  free(o);
+}
+
+int64_t ref_group_matesw_flat(const int32_t ints[16], float mask_level_redun, const int8_t mat[25], int64_t l_pac,
+                              const flat_pestat_t pes_in[4], int group_size, const int32_t *seq_len,
+                              const int64_t *seq_off, const uint8_t *seq_pool, const int32_t *reg_cnt,
+                              const flat_alnreg_t *regs, const int32_t *ref_cnt, const int64_t *ref_rb,
+                              const int64_t *ref_re, const int64_t *ref_len, const int64_t *ref_off,
+                              const uint8_t *ref_pool, int32_t *out_cnt, flat_alnreg_t *out_regs, int64_t out_cap) {
+  mem_opt_t *o = mem_opt_init();
+  o->a = ints[0]; o->b = ints[1]; o->o_del = ints[2]; o->e_del = ints[3]; o->o_ins = ints[4]; o->e_ins = ints[5];
+  o->pen_unpaired = ints[6]; o->pen_clip5 = ints[7]; o->pen_clip3 = ints[8]; o->w = ints[9]; o->zdrop = ints[10];
+  o->T = ints[11]; o->flag = ints[12]; o->min_seed_len = ints[13]; o->max_ins = ints[14]; o->max_matesw = ints[15];
+  o->mask_level_redun = mask_level_redun;
+  memcpy(o->mat, mat, 25);
+  mem_pestat_t pes[4];
+  for (int r = 0; r < 4; ++r) {
+    pes[r].low = pes_in[r].low; pes[r].high = pes_in[r].high; pes[r].failed = pes_in[r].failed;
+    pes[r].avg = pes_in[r].avg; pes[r].std = pes_in[r].std;
+  }
+  int **seq_len_pairs = (int **)malloc(sizeof(int *) * group_size);
+  uint8_t ***seqs = (uint8_t ***)malloc(sizeof(uint8_t **) * group_size);
+  mem_alnreg_v **vec = (mem_alnreg_v **)malloc(sizeof(mem_alnreg_v *) * group_size);
+  ref_t ****refs = (ref_t ****)malloc(sizeof(ref_t ***) * group_size);
+  int64_t reg_base = 0, ref_base = 0;
+  for (int k = 0; k < group_size; ++k) {
+    seq_len_pairs[k] = (int *)malloc(sizeof(int) * 2);
+    seqs[k] = (uint8_t **)malloc(sizeof(uint8_t *) * 2);
+    vec[k] = (mem_alnreg_v *)malloc(sizeof(mem_alnreg_v) * 2);
+    refs[k] = (ref_t ***)malloc(sizeof(ref_t **) * 2);
+    for (int i = 0; i < 2; ++i) {
+      seq_len_pairs[k][i] = seq_len[2 * k + i];
+      seqs[k][i] = (uint8_t *)malloc((size_t)seq_len[2 * k + i] + 1);
+      memcpy(seqs[k][i], seq_pool + seq_off[2 * k + i], (size_t)seq_len[2 * k + i]);
+      kv_init(vec[k][i]);
+      for (int j = 0; j < reg_cnt[2 * k + i]; ++j) {
+        mem_alnreg_t a;
+        memcpy(&a, &regs[reg_base + j], sizeof a); /* identical layout: native/bwamem.h:49-61 */
+        kv_push(mem_alnreg_t, vec[k][i], a);
+      }
+      reg_base += reg_cnt[2 * k + i];
+      const int nr = ref_cnt[2 * k + i];
+      refs[k][i] = (ref_t **)malloc(sizeof(ref_t *) * (nr > 0 ? nr : 1));
+      for (int j = 0; j < nr; ++j) {
+        refs[k][i][j] = (ref_t *)malloc(sizeof(ref_t) * 4);
+        for (int r = 0; r < 4; ++r) {
+          const int64_t x = (ref_base + j) * 4 + r;
+          refs[k][i][j][r].rBeg = ref_rb[x]; refs[k][i][j][r].rEnd = ref_re[x]; refs[k][i][j][r].len = ref_len[x];
+          refs[k][i][j][r].ref = 0;
+          if (ref_len[x] > 0) { /* ksw_align2 reverses the target in place: give it a private copy */
+            refs[k][i][j][r].ref = (uint8_t *)malloc((size_t)ref_len[x]);
+            memcpy(refs[k][i][j][r].ref, ref_pool + ref_off[x], (size_t)ref_len[x]);
+          }
+        }
+      }
+      ref_base += nr;
+    }
+  }
+  mem_group_matesw(o, l_pac, pes, group_size, seq_len_pairs, seqs, refs, &vec);
+  int64_t total = 0;
+  int overflow = 0;
+  for (int k = 0; k < group_size; ++k) {
+    for (int i = 0; i < 2; ++i) {
+      out_cnt[2 * k + i] = (int32_t)vec[k][i].n;
+      for (size_t j = 0; j < vec[k][i].n; ++j) {
+        if (total < out_cap) memcpy(&out_regs[total], &vec[k][i].a[j], sizeof(flat_alnreg_t)); else overflow = 1;
+        ++total;
+      }
+      for (int j = 0; j < ref_cnt[2 * k + i]; ++j) {
+        for (int r = 0; r < 4; ++r) free(refs[k][i][j][r].ref);
+        free(refs[k][i][j]);
+      }
+      free(refs[k][i]); free(vec[k][i].a); free(seqs[k][i]);
+    }
+    free(refs[k]); free(vec[k]); free(seqs[k]); free(seq_len_pairs[k]);
+  }
+  free(refs); free(vec); free(seqs); free(seq_len_pairs); free(o);
+  return overflow ? -total : total;
+}

@@ -1,0 +1,64 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cloud-scale-bwamem_amd")
+for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have(path):
+    return os.path.exists(path)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build what can be built here: the oracle always, oracle/_ref and the HIP library when missing."""
+    import pyoracle
+    if not _have(pyoracle.ORACLE_SO):
+        pyoracle.build(ref=False)
+    if not _have(pyoracle.REF_SO) and os.path.isdir("/root/reference/src/main/native"):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "ref"], check=False)
+    import bpsw_hip
+    if not (_have(bpsw_hip.LIB_PATH) and _have(bpsw_hip.SYNTH_PATH)):
+        subprocess.run(["make", "-C", PKG, "-s", "-j4"], check=True)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import pyoracle
+    return pyoracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    import pyoracle
+    if not pyoracle.Ref.available():
+        pytest.skip("oracle/_ref/libbwaref.so not built (reference tree absent)")
+    return pyoracle.Ref()
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """A device context; only -m gpu tests ask for it.  No fallback: failure to create one is an error."""
+    import bpsw_hip
+    c = bpsw_hip.Context(0)
+    yield c
+    c.close()
+
+
+def region_fields_equal(a: np.ndarray, b: np.ndarray, skip=()):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    for f in a.dtype.names:
+        if f in skip:
+            continue
+        assert np.array_equal(a[f], b[f]), f"field {f}: {int((a[f] != b[f]).sum())} of {a.shape[0]} differ"

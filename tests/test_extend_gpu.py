@@ -1,0 +1,123 @@
+"""Parity of the HIP extension kernel (boundary 2) with the oracle's restatement of the Scala extension()
+(MemChainToAlignBatched.scala:789-883 over SWUtil.scala:61-230).  Bit-exact: int16 results compared with ==."""
+import numpy as np
+import pytest
+
+import bpsw_hip
+from bpsw_hip import synth
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, orc, soa, zmode=po.ZDROP_SCALA, zdrop=100, mat=None):
+    wire = bpsw_hip.wire_pack(soa)
+    mat = po.default_mat() if mat is None else mat
+    ctx.set_ext_scoring(mat, zdrop, zmode)
+    try:
+        got = ctx.extend_batch(wire)
+    finally:
+        ctx.set_ext_scoring(po.default_mat(), 100, bpsw_hip.ZDROP_SCALA)
+    want, cells = orc.wire_extend(wire, mat, zdrop, zmode)
+    assert got.shape == want.shape
+    bad = np.nonzero((got != want).reshape(-1, 10).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size}/{soa.n} tasks differ, first {bad[:5]}: got {got.reshape(-1,10)[bad[:3]]} want {want.reshape(-1,10)[bad[:3]]}"
+    return cells
+
+
+@pytest.mark.parametrize("read_len,sub,indel,tail,n", [
+    (100, 0.01, 0.001, 0.0, 1000),   # config 1 shape (phiX-like SE 100 bp)
+    (150, 0.01, 0.001, 0.0, 4000),   # configs 2-4 (2x150 bp)
+    (150, 0.05, 0.005, 0.0, 2000),
+    (250, 0.08, 0.02, 0.05, 2000),   # config 5 (2x250 bp, high error, band doubling)
+])
+def test_extension_matches_oracle(ctx, orc, read_len, sub, indel, tail, n):
+    soa = synth.ext_tasks(n, read_len=read_len, sub_rate=sub, indel_rate=indel, tail_frac=tail, seed=42 + read_len)
+    cells = _check(ctx, orc, soa)
+    assert cells > 0
+
+
+def test_bwa_zdrop_mode_matches_oracle(ctx, orc):
+    soa = synth.ext_tasks(1500, read_len=250, sub_rate=0.1, indel_rate=0.03, tail_frac=0.3, seed=7)
+    _check(ctx, orc, soa, zmode=po.ZDROP_BWA)
+    _check(ctx, orc, soa, zmode=po.ZDROP_SCALA, zdrop=20)  # small zdrop forces the z-drop branch
+    _check(ctx, orc, soa, zmode=po.ZDROP_BWA, zdrop=20)
+
+
+def _manual_tasks(tasks):
+    """tasks: list of (leftQ, leftR, rightQ, rightR, h0, qBeg) as python lists of codes"""
+    pool, f = [], {k: [] for k in ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "left_q_off", "left_r_off",
+                                     "right_q_off", "right_r_off", "reg_score", "q_beg", "h0", "idx")}
+    for i, (lq, lr, rq, rr, h0, qb) in enumerate(tasks):
+        for name, seq in (("left_q", lq), ("left_r", lr), ("right_q", rq), ("right_r", rr)):
+            f[name + "_off"].append(len(pool))
+            f[name.replace("_q", "_qlen").replace("_r", "_rlen")].append(len(seq))
+            pool.extend(seq)
+        f["reg_score"].append(h0); f["h0"].append(h0); f["q_beg"].append(qb); f["idx"].append(i)
+    kw = {k: np.array(v, np.int64 if k.endswith("_off") else np.int32) for k, v in f.items()}
+    return bpsw_hip.ExtTaskSoA(pool=np.array(pool + [0], np.uint8), **kw)
+
+
+def test_edge_cases(ctx, orc):
+    rng = np.random.default_rng(3)
+    r = lambda n: rng.integers(0, 4, n).tolist()
+    q60 = r(60)
+    tasks = [
+        ([], [], q60, q60 + r(50), 30, 0),                 # right side only, perfect match
+        (q60, q60 + r(50), [], [], 30, 60),                # left side only
+        (r(1), r(3), r(1), r(2), 19, 1),                   # one-base sides
+        (r(40), r(80), r(40), r(80), 25, 40),              # unrelated flanks: m == 0 / early stop
+        ([4] * 30, r(60), [4] * 30, r(60), 50, 30),        # all-N query
+        (q60, [4] * 100, q60, [4] * 100, 50, 60),          # all-N reference
+        (q60[:30], q60[:30], q60[30:], q60[30:], 100, 30), # reference exactly as long as the query
+        (q60, q60[:20], q60, q60[:10], 40, 60),            # reference shorter than the query
+        (r(131), r(262), r(131), r(262), 19, 131),         # longest 150-bp sides (> 2 chunks)
+        (q60 + r(71), q60 + r(140), [], [], 200, 131),     # high h0: wide band of positive H
+    ]
+    # a long seed followed by unrelated sequence after a good stretch: the z-drop region
+    good = r(100)
+    tasks.append((good + r(120), good + r(200), good + r(120), good + r(200), 150, 220))
+    soa = _manual_tasks(tasks)
+    for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
+        _check(ctx, orc, soa, zmode=zmode)
+        _check(ctx, orc, soa, zmode=zmode, zdrop=10)
+
+
+def test_single_task_and_ragged_batch_sizes(ctx, orc):
+    soa = synth.ext_tasks(700, read_len=150, seed=99)
+    for n in (1, 2, 3, 5, 63, 64, 65, 257):
+        _check(ctx, orc, soa.subset(np.arange(n)))
+
+
+def test_custom_scoring_matrix(ctx, orc):
+    soa = synth.ext_tasks(800, read_len=150, sub_rate=0.04, indel_rate=0.01, seed=123)
+    mat = po.default_mat(2, 3)
+    soa.mat_max = 2
+    _check(ctx, orc, soa, mat=mat)
+
+
+def test_rejects_malformed_batches(ctx):
+    soa = synth.ext_tasks(50, seed=1)
+    wire = bpsw_hip.wire_pack(soa)
+    with pytest.raises(bpsw_hip.BpswError):
+        ctx.extend_batch(wire[: 32 + 32 * soa.n - 4])       # table truncated
+    bad = wire.copy(); bad[32 + 8: 32 + 12] = np.frombuffer(np.int32(10 ** 8).tobytes(), np.uint8)  # sequence offset outside
+    with pytest.raises(bpsw_hip.BpswError):
+        ctx.extend_batch(bad)
+    empty = wire[:32].copy(); empty[8:12] = 0
+    assert ctx.extend_batch(empty).size == 0                # empty batch is fine
+
+
+def test_device_resident_entry_matches_host_entry(ctx, orc):
+    import torch
+    soa = synth.ext_tasks(3000, read_len=150, seed=2024)
+    wire = bpsw_hip.wire_pack(soa)
+    want = ctx.extend_batch(wire)
+    d_wire = torch.from_numpy(wire.copy()).to("cuda:0")
+    d_out = torch.zeros(10 * soa.n, dtype=torch.int16, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.extend_batch_device(d_wire.data_ptr(), wire.size, soa.n, d_out.data_ptr())
+    ext_ms, _ = ctx.last_kernel_ms()
+    torch.cuda.synchronize()
+    assert ext_ms > 0
+    assert np.array_equal(d_out.cpu().numpy(), want)

@@ -1,0 +1,42 @@
+"""Parity of the whole boundary-1 call (speculate -> GPU SW -> replay) with the oracle's sequential walk
+(native/bwamem_pair.c:115-228 semantics, and the pure-Scala MemSamPe.scala:1111-1369 flavour)."""
+import numpy as np
+import pytest
+
+import bpsw_hip
+from bpsw_hip import synth
+import pyoracle as po
+from conftest import region_fields_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", [po.RESCUE_C, po.RESCUE_SCALA])
+@pytest.mark.parametrize("allo,n,p", [(False, 400, 0.3), (True, 150, 0.5), (False, 64, 0.0)])
+def test_group_rescue_matches_oracle(ctx, orc, mode, allo, n, p):
+    g = synth.rescue_group(n, seed=900 + n, p_resc=p, all_orientations=allo)
+    want_cnt, want, n_sw, _ = orc.matesw_group(orc.default_opt(), g, mode)
+    got_cnt, got = ctx.matesw_group(bpsw_hip.default_opt(), g, mode)
+    assert np.array_equal(got_cnt, want_cnt)
+    region_fields_equal(got, want)
+    if p > 0:
+        assert n_sw > 0 and got.shape[0] > g.regs.shape[0]   # something was rescued
+
+
+def test_no_rescue_flag_and_empty_group(ctx, orc):
+    g = synth.rescue_group(50, seed=1, p_resc=0.5)
+    opt = bpsw_hip.default_opt(); opt.flag = 0x20  # MEM_F_NO_RESCUE
+    cnt, regs = ctx.matesw_group(opt, g)
+    assert np.array_equal(cnt, g.reg_cnt) and np.array_equal(regs, g.regs)
+    g0 = synth.rescue_group(0, seed=1)
+    cnt, regs = ctx.matesw_group(bpsw_hip.default_opt(), g0)
+    assert cnt.size == 0 and regs.size == 0
+
+
+def test_speculation_stats(ctx):
+    g = synth.rescue_group(300, seed=31, p_resc=0.3, p_multi_anchor=0.5)
+    before = ctx.stats()
+    ctx.matesw_group(bpsw_hip.default_opt(), g)
+    after = ctx.stats()
+    assert after.sw_speculated > before.sw_speculated
+    assert after.sw_jobs - before.sw_jobs >= after.sw_speculated - before.sw_speculated
