@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors from the REFERENCE'S OWN C (oracle/_ref/libbwaref.so = the files
+under /root/reference/src/main/native compiled in place by oracle/Makefile).  Run in the build container:
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+Each .npz holds inputs and the reference's outputs; nothing here is produced by our oracle or kernels.
+Known caveat recorded per file: ksw_align2's score2/te2 come from the SSE2 striped kernel and are NOT the
+true-DP values the Scala text computes; tests compare them only where `b8_safe` is set.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "cloud-scale-bwamem_amd"))
+import pyoracle as po  # noqa: E402
+from bpsw_hip import synth  # noqa: E402
+
+ref = po.Ref()
+mat = po.default_mat()
+rng = np.random.default_rng(20261003)
+
+
+def mutate(seq, sub, indel):
+    out, i = [], 0
+    while i < len(seq):
+        u = rng.random()
+        if u < indel / 2:
+            out.append(int(rng.integers(0, 4)))
+        elif u < indel:
+            i += 1
+        elif u < indel + sub:
+            out.append(int((seq[i] + 1 + rng.integers(0, 3)) & 3)); i += 1
+        else:
+            out.append(int(seq[i])); i += 1
+    return np.array(out, np.uint8)
+
+
+def pack(seqs):
+    off = np.zeros(len(seqs) + 1, np.int64)
+    for i, s in enumerate(seqs):
+        off[i + 1] = off[i] + len(s)
+    return off, (np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)).astype(np.uint8)
+
+
+# ---- ksw_extend2 (== SWExtend under the BWA z-drop parse) ---------------------------------------
+qs, ts, par, outs = [], [], [], []
+for n in range(600):
+    ql = int(rng.integers(1, 232))
+    err = [0.01, 0.05, 0.10, 0.20][n % 4]
+    tl = ql + int(rng.integers(0, max(ql, 2)))
+    t = rng.integers(0, 4, tl).astype(np.uint8)
+    q = mutate(t, err, err / 5)[:ql]
+    if len(q) < ql:
+        q = np.concatenate([q, rng.integers(0, 4, ql - len(q)).astype(np.uint8)])
+    if n % 7 == 0:  # a good prefix followed by unrelated sequence: the z-drop / early-stop regime
+        cut = ql // 2
+        q[cut:] = rng.integers(0, 4, ql - cut)
+    if n % 50 == 0:
+        q[rng.integers(0, ql)] = 4
+    w = [100, 200, 5, 30][n % 4]
+    h0 = int(rng.integers(19, 120))
+    zdrop = [100, 100, 20, 0][(n // 4) % 4]
+    bonus = 5
+    qs.append(q); ts.append(t); par.append((w, bonus, zdrop, h0))
+    outs.append(ref.ksw_extend2(q, t, mat, 6, 1, 6, 1, w, bonus, zdrop, h0))
+qo, qp = pack(qs); to, tp = pack(ts)
+np.savez_compressed(os.path.join(HERE, "ksw_extend2.npz"), q_off=qo, q_pool=qp, t_off=to, t_pool=tp,
+                    params=np.array(par, np.int32), out=np.array(outs, np.int32),
+                    note="ksw_extend2(native/ksw.c:379-476), scoring 1/-4/6/1/6/1, mat N=-1; out=[score,qle,tle,gtle,gscore,max_off]")
+
+# ---- ksw_align2 (== SWAlign2 for score,te,qe,tb,qb) -----------------------------------------------
+qs, ts, outs, safe = [], [], [], []
+XTRA = po.KSW_XSUBO | po.KSW_XSTART | po.KSW_XBYTE | 19
+for n in range(160):
+    L = [100, 150, 150, 250][n % 4]
+    wl = L + int(rng.integers(300, 700))
+    t = rng.integers(0, 4, wl).astype(np.uint8)
+    pos = int(rng.integers(0, wl - L - 20))
+    q = mutate(t[pos:pos + L + 20], [0.02, 0.10][n % 2], 0.004)[:L]
+    if len(q) < L:
+        q = np.concatenate([q, rng.integers(0, 4, L - len(q)).astype(np.uint8)])
+    if n % 5 == 0:
+        q = rng.integers(0, 4, L).astype(np.uint8)  # unrelated
+    if n % 3 == 0:  # decoy partial copy
+        dl = int(rng.integers(25, 80)); dp = int(rng.integers(0, wl - dl))
+        t[dp:dp + dl] = q[:dl]
+    xtra = XTRA if L * 1 < 250 else (XTRA & ~po.KSW_XBYTE)
+    qs.append(q); ts.append(t)
+    outs.append(ref.ksw_align2(q, t, mat, 6, 1, 6, 1, xtra))
+qo, qp = pack(qs); to, tp = pack(ts)
+np.savez_compressed(os.path.join(HERE, "ksw_align2.npz"), q_off=qo, q_pool=qp, t_off=to, t_pool=tp,
+                    out=np.array(outs, np.int32),
+                    note="ksw_align2(native/ksw.c:342-364) xtra=XSUBO|XSTART|XBYTE(if L<250)|19; out=[score,te,qe,score2,te2,tb,qb]; "
+                         "score2/te2 are SSE2-padded values (SURVEY B8), compare only score,te,qe,tb,qb")
+
+# ---- ksw_global2 (== SWGlobal) -----------------------------------------------------------------------
+qs, ts, ws, scores, cigs = [], [], [], [], []
+for n in range(200):
+    ql = int(rng.integers(20, 251))
+    q = rng.integers(0, 4, ql).astype(np.uint8)
+    t = mutate(q, [0.0, 0.05, 0.12, 0.19][n % 4], [0.0, 0.01, 0.03, 0.05][n % 4])
+    if len(t) == 0:
+        t = q[:1].copy()
+    w = abs(len(t) - ql) + 3 + int(rng.integers(0, 40))
+    sc, cg = ref.ksw_global2(q, t, mat, 6, 1, 6, 1, w)
+    qs.append(q); ts.append(t); ws.append(w); scores.append(sc); cigs.append(cg)
+qo, qp = pack(qs); to, tp = pack(ts)
+co = np.zeros(len(cigs) + 1, np.int64)
+for i, c in enumerate(cigs):
+    co[i + 1] = co[i] + len(c)
+np.savez_compressed(os.path.join(HERE, "ksw_global2.npz"), q_off=qo, q_pool=qp, t_off=to, t_pool=tp, w=np.array(ws, np.int32),
+                    score=np.array(scores, np.int32), cig_off=co, cig_pool=np.concatenate(cigs).astype(np.uint32),
+                    note="ksw_global2(native/ksw.c:501-584); cigar = len<<4|op, op 0=M 1=I 2=D")
+
+# ---- mem_sort_and_dedup ---------------------------------------------------------------------------------
+ins, outs_, in_off, out_off = [], [], [0], [0]
+for n in range(150):
+    k = int(rng.integers(0, 40)) if n % 10 else int(rng.integers(17, 80))
+    regs = np.zeros(k, po.ALNREG_DTYPE)
+    base = int(rng.integers(1000, 5000))
+    for i in range(k):
+        rb = base + int(rng.integers(0, 400)) if rng.random() < 0.8 else int(rng.integers(0, 10 ** 6))
+        ln = int(rng.integers(30, 151))
+        qb = int(rng.integers(0, 20))
+        regs[i] = (rb, rb + ln + int(rng.integers(-3, 4)), qb, qb + ln, int(rng.integers(19, 151)), 0, 0, 0, 0, 100, ln // 2, -1, int(rng.integers(0, 2 ** 62)))
+    if k > 3 and n % 3 == 0:  # exact duplicates and equal-re ties
+        regs[1] = regs[0]
+        regs[2]["re"] = regs[0]["re"]
+    out = ref.sort_dedup(regs, 0.95)
+    ins.append(regs); outs_.append(out); in_off.append(in_off[-1] + k); out_off.append(out_off[-1] + len(out))
+np.savez_compressed(os.path.join(HERE, "mem_sort_and_dedup.npz"), in_off=np.array(in_off, np.int64), out_off=np.array(out_off, np.int64),
+                    regs_in=np.concatenate(ins), regs_out=np.concatenate(outs_),
+                    note="mem_sort_and_dedup(native/bwamem.c:394-435), mask_level_redun=0.95")
+
+# ---- mem_group_matesw (the whole boundary-1 computation of jniNative.so) ------------------------------
+import ctypes as C  # noqa: E402
+orc_opt = po.Opt()
+ints = np.zeros(16, np.int32); mlr = C.c_float(0); m25 = np.zeros(25, np.int8)
+ref.lib.ref_opt_default(ints.ctypes.data_as(C.c_void_p), C.byref(mlr), m25.ctypes.data_as(C.c_void_p))
+for i, name in enumerate(["a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_unpaired", "pen_clip5", "pen_clip3", "w", "zdrop", "T",
+                          "flag", "min_seed_len", "max_ins", "max_matesw"]):
+    setattr(orc_opt, name, int(ints[i]))
+orc_opt.mask_level_redun = mlr.value
+for k in range(25):
+    orc_opt.mat[k] = int(m25[k])
+for tag, allo, n, p in (("fr", False, 48, 0.4), ("all4", True, 24, 0.5)):
+    g = synth.rescue_group(n, seed=4242 + n, p_resc=p, all_orientations=allo)
+    cnt, regs = ref.matesw_group(orc_opt, g)
+    np.savez_compressed(os.path.join(HERE, f"mem_group_matesw_{tag}.npz"), group_size=g.group_size, l_pac=g.l_pac,
+                        pes=np.array(g.pes, np.float64), seq_len=g.seq_len, seq_off=g.seq_off, seq_pool=g.seq_pool, reg_cnt=g.reg_cnt,
+                        regs=g.regs, ref_cnt=g.ref_cnt, ref_rb=g.ref_rb, ref_re=g.ref_re, ref_len=g.ref_len, ref_off=g.ref_off,
+                        ref_pool=g.ref_pool, out_cnt=cnt, out_regs=regs, opt_ints=ints, opt_mat=m25, opt_mask=np.float32(mlr.value),
+                        note="mem_group_matesw(native/bwamem_pair.c:115-156) with mem_opt_init() defaults; csub inherits B8")
+print("golden vectors written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
