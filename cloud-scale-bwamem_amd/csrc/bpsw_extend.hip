@@ -134,6 +134,209 @@ __device__ ExtRes sw_extend_wave(const int lane, const int qLen, const int tLen,
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Register-resident form of the same SWExtend for qLen <= 255 (every 2x150 / 2x250 bp task).
+// Column j lives in lane j&63 of slot j>>6, so the (H,E) row never leaves VGPRs and the diagonal
+// H(i-1,j-1) is one DPP wave_shr:1.  Two interleaved fused-DPP max-scans per slot give
+//   prefix max of g(k) = a(k) - oeIns + k*eIns   -> F(i,j)
+//   wave max of a(k)                             -> the row maximum m
+// With oeIns > 0, H(i,j) == m > 0 iff a(j) == m (F stays strictly below the maximum), so the row
+// maximum and its LAST arg-max (SWUtil.scala:158-161) are read off `a` with one ballot.
+// The kernel is bound by the CU's single scalar unit, not by VALU, so the per-row control below is
+// written to need as few SALU instructions as possible (s_bfm/s_flbit/s_ff1 on the 64-bit zero mask).
+// ---------------------------------------------------------------------------------------------------
+
+// Two independent inclusive max-scans over the 64 lanes, interleaved so each DPP read sees its operand
+// two wait states after the write (the hazard hipcc does not handle inside asm statements).
+__device__ __forceinline__ void dual_scan_max(int& g, int& a) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(g), "+v"(a));
+}
+__device__ __forceinline__ unsigned long long s_below_mask(int width) {  // (1 << width) - 1, width 0..63
+  unsigned long long r;
+  asm("s_bfm_b64 %0, %1, 0" : "=s"(r) : "s"(width));
+  return r;
+}
+__device__ __forceinline__ int s_lead_zeros(unsigned long long v) {  // -1 when v == 0
+  int r;
+  asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(v));
+  return r;
+}
+__device__ __forceinline__ int s_first_one(unsigned long long v) {  // -1 when v == 0
+  int r;
+  asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(v));
+  return r;
+}
+
+template <int S>
+__device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, const uint32_t* __restrict__ words,
+                                const int qStart, const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
+                                const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
+                                const int zmode, const int h0) {
+  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
+  int Hs[S], Es[S], As[S], plo[S], phi[S], jE[S], c2[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int j = 64 * s + lane;
+    const int code = j < qLen ? nibble_at(words, qStart + j) : 4;
+    const int sh = 8 * code;
+    plo[s] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
+                   (((mat.row[3] >> sh) & 0xff) << 24));
+    phi[s] = (int)(int8_t)((mat.row[4] >> sh) & 0xff);
+    Hs[s] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
+    Es[s] = 0;
+    As[s] = NEG;
+    jE[s] = j * eIns - oeIns;
+    c2[s] = (j - 1) * eIns;
+  }
+
+  int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;  // SWUtil.scala:118-125
+  int beg = 0, end = qLen;
+  int h1raw = h0 - oDel;  // h0 - (oDel + eDel*(i+1)) after the decrement below
+
+  for (int i = 0; i < tLen; ++i) {
+    const int tsv = ts[i];  // 8 * target base, same in every lane
+    const bool isN = tsv == 32;
+    h1raw -= eDel;
+    const int h1 = max(0, h1raw);            // SWUtil.scala:137-138
+    beg = max(beg, i - w);                   // SWUtil.scala:140-142
+    end = min(min(end, i + w + 1), qLen);
+    const unsigned span = (unsigned)(end - beg);  // wraps to "huge" when beg > end, which no column satisfies below
+
+    int carry_g = NEG, carry_a = NEG;  // running maxima over the slots already swept (S > 1)
+    int hl_prev = h1;                  // H(i, 64*s - 1) for the next slot's lane 0
+    int scan_a = NEG;
+    unsigned long long zm[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      zm[s] = 0;
+      if (S > 1 && (64 * s + 63 < beg || 64 * s > end)) {  // slot entirely outside [beg, end]
+        As[s] = NEG;
+        continue;
+      }
+      const unsigned rel = (unsigned)(64 * s + lane - beg);
+      const bool act = beg < end && rel < span;            // beg <= j < end
+      const bool upd = beg <= end && rel <= span;          // beg <= j <= end: eh[end] is written too
+      const int sc = isN ? phi[s] : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
+      const int a = act ? max(Hs[s] + sc, Es[s]) : NEG;
+      As[s] = a;
+      int Pg = a + jE[s];
+      scan_a = a;
+      dual_scan_max(Pg, scan_a);
+      if (S > 1) {
+        Pg = max(Pg, carry_g);
+        scan_a = max(scan_a, carry_a);
+      }
+      const int Pex = wave_shr1(carry_g, Pg);  // exclusive prefix; lane 0 takes the carry of the earlier slots
+      if (S > 1) {
+        carry_g = __builtin_amdgcn_readlane(Pg, 63);
+        carry_a = __builtin_amdgcn_readlane(scan_a, 63);
+      }
+      const int H = max3i(a, Pex - c2[s], 0);  // F(i,j) = max(0, Pex - (j-1)*eIns)
+      zm[s] = __builtin_amdgcn_ballot_w64((act ? H : -1) == 0);
+      const int En = act ? max3i(Es[s] - eDel, H - oeDel, 0) : 0;  // E(i+1,j); eh[end].e = 0
+      int hsh = wave_shr1(hl_prev, H);                             // H(i,j-1)
+      if (S > 1) hl_prev = __builtin_amdgcn_readlane(H, 63);
+      hsh = rel == 0u ? h1 : hsh;                                  // eh[beg].h = h1, SWUtil.scala:153
+      Hs[s] = upd ? hsh : Hs[s];
+      Es[s] = upd ? En : Es[s];
+    }
+    const int m = max(0, S > 1 ? carry_a : __builtin_amdgcn_readlane(scan_a, 63));
+
+    if ((beg < end ? end : beg) == qLen) {  // SWUtil.scala:177-182 with h1 = eh[end].h
+      int hlast = h1;
+      if (beg < end) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+          if (S == 1 || (end >> 6) == s) hlast = __builtin_amdgcn_readlane(Hs[s], end & 63);
+      }
+      if (gscore <= hlast) {
+        max_ie = i;
+        gscore = hlast;
+      }
+    }
+    if (m == 0) break;  // SWUtil.scala:184-185
+
+    int sm = 0, bm;  // slot and lane of the LAST column whose a == m  (SWUtil.scala:158-161)
+    if (S == 1) {
+      bm = 63 - s_lead_zeros(__builtin_amdgcn_ballot_w64(As[0] == m));
+    } else {
+      bm = -1;
+#pragma unroll
+      for (int s = S - 1; s >= 0; --s) {
+        const int lzc = s_lead_zeros(__builtin_amdgcn_ballot_w64(As[s] == m));
+        if (bm < 0 && lzc >= 0) { bm = 63 - lzc; sm = s; }
+      }
+    }
+    const int mj = 64 * sm + bm;
+    if (m > mx) {  // SWUtil.scala:187-193
+      mx = m;
+      max_i = i;
+      max_j = mj;
+      max_off = max(max_off, abs(mj - i));
+    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      const int di = i - max_i, dj = mj - max_j;
+      if (di > dj) {
+        if (mx - m - (di - dj) * eDel > zdrop) break;
+        if (zmode == BPSW_ZDROP_SCALA && mx - m - (dj - di) * eIns > zdrop) break;
+      } else if (zmode != BPSW_ZDROP_SCALA) {
+        if (mx - m - (dj - di) * eIns > zdrop) break;
+      }
+    }
+    // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj
+    int nb = beg + (h1 == 0 ? 1 : 0), ne = end + 1;
+    if (S == 1) {
+      const int lzc = s_lead_zeros(zm[0] & s_below_mask(bm));
+      if (lzc >= 0) nb = 65 - lzc;
+      const int fo = s_first_one((zm[0] >> bm) >> 1);
+      if (fo >= 0) ne = bm + fo + 2;
+    } else {
+      bool found = false;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const unsigned long long below = s == sm ? (zm[s] & s_below_mask(bm)) : zm[s];
+        const unsigned long long above = s == sm ? (((zm[s] >> bm) >> 1) << bm) << 1 : zm[s];
+        const int lzc = s_lead_zeros(below);
+        if (s <= sm && lzc >= 0) nb = 64 * s + 65 - lzc;
+        const int fo = s_first_one(above);
+        if (s >= sm && !found && fo >= 0) { ne = 64 * s + fo + 1; found = true; }
+      }
+    }
+    beg = nb;
+    end = ne;
+  }
+  ExtRes r;
+  r.max = mx; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+  return r;
+}
+
+// stage the target of one side in LDS as 8*code bytes (the shift the register path feeds to v_bfe)
+__device__ void load_target_shifts(const int lane, const uint32_t* __restrict__ words, const int rStart, const int rLen,
+                                   uint8_t* __restrict__ ts) {
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < rLen; i += 64) ts[i] = (uint8_t)(8 * nibble_at(words, rStart + i));
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Unpack one side of a task into LDS: the 5 x qLen query profile and the target bytes.
 __device__ void load_side(const int lane, const uint32_t* __restrict__ words, const int qStart, const int qLen,
                           const int rStart, const int rLen, const MatRows& mat, int8_t* __restrict__ qp,
@@ -147,13 +350,34 @@ __device__ void load_side(const int lane, const uint32_t* __restrict__ words, co
   __builtin_amdgcn_wave_barrier();
 }
 
+// Wave-level dequeue: lane 0 alone performs one returning atomic add, the result is broadcast.  Written as
+// a single asm statement so that the compiler sees no lane-dependent branch here: with a C-level
+// `if (lane == 0) atomicAdd(...)` hipcc threaded that branch together with the lane-0 result store at the end
+// of the previous iteration and peeled the other 63 lanes out of the loop, which breaks every cross-lane
+// operation of the row sweep.
+__device__ __forceinline__ int dequeue_task(int* counter) {
+  int v = 1;
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %1, exec\n\t"
+      "s_mov_b64 exec, 1\n\t"
+      "global_atomic_add %0, %2, %0, off sc0\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_mov_b64 exec, %1"
+      : "+v"(v), "=&s"(saved)
+      : "v"(counter)
+      : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
 
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
-                                                                     const int lds_per_wave) {
+                                                                     const int lds_per_wave,
+                                                                     int* __restrict__ next_task) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
@@ -169,8 +393,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
   const int penClip5 = (int8_t)(hdr1 & 0xff), penClip3 = (int8_t)((hdr1 >> 8) & 0xff);
   const int wBand = (int8_t)((hdr1 >> 16) & 0xff);
 
-  const int stride = gridDim.x * WAVES_PER_BLOCK;
-  for (int task = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave); task < n_tasks; task += stride) {
+  // Tasks differ in cost by an order of magnitude, so waves pull them from a shared counter instead of
+  // striding: a wave takes the next task when it finishes one and leaves when the counter passes n_tasks.
+  for (;;) {
+    const int task = dequeue_task(next_task);
+    if (task >= n_tasks) break;
     const uint32_t* rec = wire + 8 + 8 * (size_t)task;  // MemChainToAlignBatched.scala:95-117
     const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
     const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
@@ -180,48 +407,53 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
     const int rMaxIns = max(1, uni(lo16(r6))), rMaxDel = max(1, uni(hi16(r6)));
     const int idx = uni((int)rec[7]);
 
-    // extension(), MemChainToAlignBatched.scala:789-883
-    int aw0 = wBand, aw1 = wBand;
+    // extension(), MemChainToAlignBatched.scala:789-883: side 0 = left (penClip5), side 1 = right (penClip3)
+    int aw[2] = {wBand, wBand};
     int regScore = regScore0;
     int outQBeg = 0, outRBeg = 0, outQEnd = rq, outREnd = 0, trueScore = regScore0, score = -1;
-
-    if (lq > 0) {
-      load_side(lane, words, 0, lq, lq + rq, lr, sc.mat, qp, ts);
+    for (int side = 0; side < 2; ++side) {
+      const int qLen = side ? rq : lq, rLen = side ? rr : lr;
+      if (qLen <= 0) continue;
+      const int qStart = side ? lq : 0, rStart = side ? lq + rq + lr : lq + rq;
+      const int maxIns = side ? rMaxIns : lMaxIns, maxDel = side ? rMaxDel : lMaxDel;
+      const int penClip = side ? penClip3 : penClip5;
+      const int hInit = side ? regScore : h0;  // the right extension starts from the score after the left one
+      const int sc0 = regScore;
+      // register path: needs one lane per column 0..qLen and oeIns > 0 (see sw_extend_reg)
+      const bool reg_path = qLen <= 255 && oIns + eIns > 0;
+      if (reg_path) load_target_shifts(lane, words, rStart, rLen, ts);
+      else load_side(lane, words, qStart, qLen, rStart, rLen, sc.mat, qp, ts);
       ExtRes r = {0, 0, 0, 0, 0, 0};
       for (int i = 0; i < 2; ++i) {  // MAX_BAND_TRY
         const int prev = regScore;
-        aw0 = wBand << i;
-        const int w = min(min(aw0, lMaxIns), lMaxDel);
-        r = sw_extend_wave(lane, lq, lr, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, h0);
+        aw[side] = wBand << i;
+        const int w = min(min(aw[side], maxIns), maxDel);
+        if (reg_path) {
+          switch ((qLen + 64) >> 6) {
+            case 1: r = sw_extend_reg<1>(lane, qLen, rLen, words, qStart, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit); break;
+            case 2: r = sw_extend_reg<2>(lane, qLen, rLen, words, qStart, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit); break;
+            case 3: r = sw_extend_reg<3>(lane, qLen, rLen, words, qStart, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit); break;
+            default: r = sw_extend_reg<4>(lane, qLen, rLen, words, qStart, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit); break;
+          }
+        } else {
+          r = sw_extend_wave(lane, qLen, rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit);
+        }
         regScore = r.max;
-        if (regScore == prev || r.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+        if (regScore == prev || r.max_off < (aw[side] >> 1) + (aw[side] >> 2)) break;
       }
       score = regScore;
-      if (r.gscore <= 0 || r.gscore <= regScore - penClip5) {
-        outQBeg = qBeg - r.qle; outRBeg = -r.tle; trueScore = regScore;
+      const bool local = r.gscore <= 0 || r.gscore <= regScore - penClip;  // local extension vs reaching the query end
+      if (side == 0) {
+        outQBeg = local ? qBeg - r.qle : 0;
+        outRBeg = local ? -r.tle : -r.gtle;
+        trueScore = local ? regScore : r.gscore;
       } else {
-        outQBeg = 0; outRBeg = -r.gtle; trueScore = r.gscore;
+        outQEnd = local ? r.qle : rq;
+        outREnd = local ? r.tle : r.gtle;
+        trueScore += (local ? regScore : r.gscore) - sc0;
       }
     }
-    if (rq > 0) {
-      load_side(lane, words, lq, rq, lq + rq + lr, rr, sc.mat, qp, ts);
-      const int sc0 = regScore;
-      ExtRes r = {0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < 2; ++i) {
-        const int prev = regScore;
-        aw1 = wBand << i;
-        const int w = min(min(aw1, rMaxIns), rMaxDel);
-        r = sw_extend_wave(lane, rq, rr, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, sc0);
-        regScore = r.max;
-        if (regScore == prev || r.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-      }
-      score = regScore;
-      if (r.gscore <= 0 || r.gscore <= regScore - penClip3) {
-        outQEnd = r.qle; outREnd = r.tle; trueScore += regScore - sc0;
-      } else {
-        outQEnd = rq; outREnd = r.gtle; trueScore += r.gscore - sc0;
-      }
-    }
+    const int aw0 = aw[0], aw1 = aw[1];
     const int width = aw0 > aw1 ? aw0 : aw1;
     if (lane == 0) {  // MemChainToAlignBatched.scala:181-188: 10 int16 per task
       uint32_t* o = reinterpret_cast<uint32_t*>(out + 10 * (size_t)task);
@@ -276,7 +508,7 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 }
 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
-                             int rcap, int num_cu, hipStream_t s) {
+                             int rcap, int num_cu, int* d_counter, hipStream_t s) {
   if (n_tasks <= 0) return hipSuccess;
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
@@ -297,8 +529,10 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   int blocks = (n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int max_blocks = num_cu * per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
+  hipError_t me = hipMemsetAsync(d_counter, 0, sizeof(int), s);
+  if (me != hipSuccess) return me;
   hipLaunchKernelGGL(ext_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
-                     rcap, (int)per_wave);
+                     rcap, (int)per_wave, d_counter);
   return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@ struct ExtScoring {
   MatRows mat;
   int zdrop;
   int zdrop_mode;
+  int mat_max;  // max(mat): bounds the scores a task can reach (selects the int16 register path)
 };
 
 // ---- extension (boundary 2) -------------------------------------------------------------------
@@ -44,8 +45,9 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 size_t ext_lds_per_wave(int qcap, int rcap);
 
 // Launch the extension kernel over a validated batch.
+// d_counter: one device int used as the kernel's task queue head (zeroed on the stream before the launch).
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
-                             int rcap, int num_cu, hipStream_t s);
+                             int rcap, int num_cu, int* d_counter, hipStream_t s);
 
 // ---- local SW (boundary 1) ---------------------------------------------------------------------
 struct SwScoring {

@@ -150,6 +150,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.mat = pack_mat(c->ext_mat);
   c->ext_sc.zdrop = 100;
   c->ext_sc.zdrop_mode = BPSW_ZDROP_SCALA;
+  c->ext_sc.mat_max = 1;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
   if (e == hipSuccess) e = c->d_pre.reserve(256);
@@ -183,6 +184,8 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
   std::lock_guard<std::mutex> g(c->mu);
   if (mat) memcpy(c->ext_mat, mat, 25);
   c->ext_sc.mat = pack_mat(c->ext_mat);
+  c->ext_sc.mat_max = c->ext_mat[0];
+  for (int k = 1; k < 25; ++k) c->ext_sc.mat_max = c->ext_mat[k] > c->ext_sc.mat_max ? c->ext_mat[k] : c->ext_sc.mat_max;
   c->ext_sc.zdrop = zdrop;
   c->ext_sc.zdrop_mode = zdrop_mode;
   return BPSW_OK;
@@ -239,7 +242,8 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, (int16_t*)c->d_out.ptr, c->ext_sc, mq, mr, c->num_cu, c->stream));
+  HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, (int16_t*)c->d_out.ptr, c->ext_sc, mq, mr, c->num_cu,
+                            (int*)((char*)c->d_pre.ptr + 128), c->stream));
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->ev[3], c->stream));
@@ -279,7 +283,7 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
     return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
   HIP_TRY(hipEventRecord(c->ev[4], s));
   HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen, h_pre->max_rlen,
-                            c->num_cu, s));
+                            c->num_cu, (int*)((char*)c->d_pre.ptr + 128), s));
   HIP_TRY(hipEventRecord(c->ev[5], s));
   c->have_ext_ev = true;
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
