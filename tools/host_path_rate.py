@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rates of the host-buffer entry points (what the JNI shim calls): never the bench `value`,
+reported in DESIGN.md.  Usage on a GPU box:  python tools/host_path_rate.py"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cloud-scale-bwamem_amd"))
+import bpsw_hip  # noqa: E402
+from bpsw_hip import synth  # noqa: E402
+
+ctx = bpsw_hip.Context(0)
+out = {}
+soa = synth.ext_tasks(32768, read_len=150, seed=synth.CONFIG_SEED_BASE + 3)
+wire = bpsw_hip.wire_pack(soa)
+for _ in range(3):
+    ctx.extend_batch(wire)
+s0 = ctx.stats()
+t0 = time.perf_counter()
+R = 20
+for _ in range(R):
+    ctx.extend_batch(wire)
+dt = time.perf_counter() - t0
+s1 = ctx.stats()
+out["extend_host_entry"] = {"reads_per_s": 32768 * R / dt, "tasks": soa.n, "wire_bytes": int(wire.size), "ms_per_call": 1e3 * dt / R,
+                            "h2d_ms": (s1.ext_h2d_ms - s0.ext_h2d_ms) / R, "kernel_ms": (s1.ext_kernel_ms - s0.ext_kernel_ms) / R,
+                            "d2h_ms": (s1.ext_d2h_ms - s0.ext_d2h_ms) / R}
+for pairs in (4096, 16384):
+    g = synth.rescue_group(pairs, seed=synth.CONFIG_SEED_BASE + 3, p_resc=0.10)
+    opt = bpsw_hip.default_opt()
+    ctx.matesw_group(opt, g)
+    s0 = ctx.stats()
+    t0 = time.perf_counter()
+    R = 5
+    for _ in range(R):
+        ctx.matesw_group(opt, g)
+    dt = time.perf_counter() - t0
+    s1 = ctx.stats()
+    out[f"matesw_group_{pairs}_pairs"] = {"pairs_per_s": pairs * R / dt, "ms_per_call": 1e3 * dt / R,
+                                          "sw_jobs_per_call": (s1.sw_jobs - s0.sw_jobs) / R, "kernel_ms": (s1.sw_kernel_ms - s0.sw_kernel_ms) / R,
+                                          "h2d_ms": (s1.sw_h2d_ms - s0.sw_h2d_ms) / R, "replay_rounds": int(s1.sw_replayed_rounds - s0.sw_replayed_rounds),
+                                          "wasted_jobs": int(s1.sw_wasted - s0.sw_wasted)}
+print(json.dumps(out, indent=1))
