@@ -187,6 +187,15 @@ __device__ __forceinline__ int s_first_one(unsigned long long v) {  // -1 when v
   return r;
 }
 
+// A wave-uniform value deliberately kept in a VGPR: arithmetic on it then runs on the SIMD's vector ALU (2x the
+// issue rate of the one scalar ALU a CU's four SIMDs share).  The asm hides the uniformity from the compiler.
+__device__ __forceinline__ int vu(int s) {
+  int v;
+  asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 template <int S>
 __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, const uint32_t* __restrict__ words,
                                 const int qStart, const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
@@ -208,34 +217,37 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
     jE[s] = j * eIns - oeIns;
     c2[s] = (j - 1) * eIns;
   }
+  // SWUtil.scala:118-125 -- wave-uniform state, held in VGPRs (see vu)
+  int mx = vu(h0), max_i = vu(-1), max_j = vu(-1), max_ie = vu(-1), gscore = vu(-1), max_off = vu(0);
+  int beg = vu(0), end = vu(qLen);
+  int h1raw = vu(h0 - oDel);  // h0 - (oDel + eDel*(i+1)) after the decrement below
+  int iv = vu(0);             // vector copy of the row index
 
-  int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;  // SWUtil.scala:118-125
-  int beg = 0, end = qLen;
-  int h1raw = h0 - oDel;  // h0 - (oDel + eDel*(i+1)) after the decrement below
-
-  for (int i = 0; i < tLen; ++i) {
+  for (int i = 0; i < tLen; ++i, iv += 1) {
     const int tsv = ts[i];  // 8 * target base, same in every lane
     const bool isN = tsv == 32;
     h1raw -= eDel;
-    const int h1 = max(0, h1raw);            // SWUtil.scala:137-138
-    beg = max(beg, i - w);                   // SWUtil.scala:140-142
-    end = min(min(end, i + w + 1), qLen);
-    const unsigned span = (unsigned)(end - beg);  // wraps to "huge" when beg > end, which no column satisfies below
+    const int h1 = max(0, h1raw);      // SWUtil.scala:137-138
+    beg = max(beg, iv - w);            // SWUtil.scala:140-142
+    end = min(min(end, iv + (w + 1)), qLen);
+    const int span = end - beg;
+    const unsigned spanA = (unsigned)max(span, 0);      // columns beg <= j <  end
+    const unsigned spanU = (unsigned)max(span + 1, 0);  // columns beg <= j <= end (eh[end] is written too)
 
-    int carry_g = NEG, carry_a = NEG;  // running maxima over the slots already swept (S > 1)
+    int carry_g = NEG, carry_a = NEG;  // running maxima over the slots already swept (scalars, S > 1)
     int hl_prev = h1;                  // H(i, 64*s - 1) for the next slot's lane 0
     int scan_a = NEG;
     unsigned long long zm[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       zm[s] = 0;
-      if (S > 1 && (64 * s + 63 < beg || 64 * s > end)) {  // slot entirely outside [beg, end]
+      const unsigned rel = (unsigned)(64 * s + lane - beg);
+      const bool upd = rel < spanU;
+      if (S > 1 && !any_lane(upd)) {  // slot entirely outside [beg, end]
         As[s] = NEG;
         continue;
       }
-      const unsigned rel = (unsigned)(64 * s + lane - beg);
-      const bool act = beg < end && rel < span;            // beg <= j < end
-      const bool upd = beg <= end && rel <= span;          // beg <= j <= end: eh[end] is written too
+      const bool act = rel < spanA;
       const int sc = isN ? phi[s] : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
       const int a = act ? max(Hs[s] + sc, Es[s]) : NEG;
       As[s] = a;
@@ -260,19 +272,20 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
       Hs[s] = upd ? hsh : Hs[s];
       Es[s] = upd ? En : Es[s];
     }
-    const int m = max(0, S > 1 ? carry_a : __builtin_amdgcn_readlane(scan_a, 63));
+    const int m = max(0, S > 1 ? carry_a : __builtin_amdgcn_readlane(scan_a, 63));  // scalar
 
-    if ((beg < end ? end : beg) == qLen) {  // SWUtil.scala:177-182 with h1 = eh[end].h
+    // SWUtil.scala:177-182: j after the column loop is end (or beg for an empty band); h1 there is eh[end].h
+    if (any_lane((span > 0 ? end : beg) == qLen)) {
       int hlast = h1;
-      if (beg < end) {
+      if (any_lane(span > 0)) {
+        const int e = __builtin_amdgcn_readfirstlane(end);
 #pragma unroll
         for (int s = 0; s < S; ++s)
-          if (S == 1 || (end >> 6) == s) hlast = __builtin_amdgcn_readlane(Hs[s], end & 63);
+          if (S == 1 || (e >> 6) == s) hlast = __builtin_amdgcn_readlane(Hs[s], e & 63);
       }
-      if (gscore <= hlast) {
-        max_ie = i;
-        gscore = hlast;
-      }
+      const bool better = gscore <= hlast;
+      max_ie = better ? iv : max_ie;
+      gscore = better ? hlast : gscore;
     }
     if (m == 0) break;  // SWUtil.scala:184-185
 
@@ -287,45 +300,53 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
         if (bm < 0 && lzc >= 0) { bm = 63 - lzc; sm = s; }
       }
     }
-    const int mj = 64 * sm + bm;
-    if (m > mx) {  // SWUtil.scala:187-193
-      mx = m;
-      max_i = i;
-      max_j = mj;
-      max_off = max(max_off, abs(mj - i));
-    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
-      const int di = i - max_i, dj = mj - max_j;
-      if (di > dj) {
-        if (mx - m - (di - dj) * eDel > zdrop) break;
-        if (zmode == BPSW_ZDROP_SCALA && mx - m - (dj - di) * eIns > zdrop) break;
-      } else if (zmode != BPSW_ZDROP_SCALA) {
-        if (mx - m - (dj - di) * eIns > zdrop) break;
-      }
+    const int mj = 64 * sm + bm;  // scalar
+    const bool improved = m > mx;
+    if (!any_lane(improved) && zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      const int di = iv - max_i, dj = mj - max_j;
+      const bool A = di > dj;
+      const bool B = mx - m - (di - dj) * eDel > zdrop;
+      const bool C = mx - m - (dj - di) * eIns > zdrop;
+      const bool stop = zmode == BPSW_ZDROP_SCALA ? (A && (B || C)) : (A ? B : C);
+      if (any_lane(stop)) break;
+    }
+    {  // SWUtil.scala:187-193
+      const int d = mj - iv;
+      const int off = max3i(max_off, d, -d);
+      mx = improved ? m : mx;
+      max_i = improved ? iv : max_i;
+      max_j = improved ? mj : max_j;
+      max_off = improved ? off : max_off;
     }
     // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj
-    int nb = beg + (h1 == 0 ? 1 : 0), ne = end + 1;
+    int lzc, fo, lbase = 65, fbase = bm + 2;
     if (S == 1) {
-      const int lzc = s_lead_zeros(zm[0] & s_below_mask(bm));
-      if (lzc >= 0) nb = 65 - lzc;
-      const int fo = s_first_one((zm[0] >> bm) >> 1);
-      if (fo >= 0) ne = bm + fo + 2;
+      lzc = s_lead_zeros(zm[0] & s_below_mask(bm));
+      fo = s_first_one((zm[0] >> bm) >> 1);
     } else {
-      bool found = false;
+      lzc = -1;
+      fo = -1;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const unsigned long long below = s == sm ? (zm[s] & s_below_mask(bm)) : zm[s];
-        const unsigned long long above = s == sm ? (((zm[s] >> bm) >> 1) << bm) << 1 : zm[s];
-        const int lzc = s_lead_zeros(below);
-        if (s <= sm && lzc >= 0) nb = 64 * s + 65 - lzc;
-        const int fo = s_first_one(above);
-        if (s >= sm && !found && fo >= 0) { ne = 64 * s + fo + 1; found = true; }
+        const unsigned long long above = s == sm ? (zm[s] >> bm) >> 1 : zm[s];
+        const int l = s_lead_zeros(below);
+        if (s <= sm && l >= 0) { lzc = l; lbase = 64 * s + 65; }
+        const int f = s_first_one(above);
+        if (s >= sm && fo < 0 && f >= 0) { fo = f; fbase = s == sm ? 64 * s + bm + 2 : 64 * s + 1; }
       }
     }
-    beg = nb;
-    end = ne;
+    const int nb0 = beg + (h1 == 0 ? 1 : 0);
+    beg = lzc >= 0 ? vu(lbase - lzc) : nb0;
+    end = fo >= 0 ? vu(fbase + fo) : end + 1;
   }
   ExtRes r;
-  r.max = mx; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+  r.max = __builtin_amdgcn_readfirstlane(mx);
+  r.qle = __builtin_amdgcn_readfirstlane(max_j) + 1;
+  r.tle = __builtin_amdgcn_readfirstlane(max_i) + 1;
+  r.gtle = __builtin_amdgcn_readfirstlane(max_ie) + 1;
+  r.gscore = __builtin_amdgcn_readfirstlane(gscore);
+  r.max_off = __builtin_amdgcn_readfirstlane(max_off);
   return r;
 }
 

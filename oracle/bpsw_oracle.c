@@ -13,6 +13,11 @@
 
 #define ORC_MINUS_INF (-0x40000000) /* SW:28 */
 
+/* diagnostic: DP rows swept by orc_sw_extend since the last reset (used to size per-row costs in DESIGN.md) */
+static int64_t g_ext_rows = 0, g_ext_calls = 0;
+int64_t orc_diag_ext_rows(int reset) { int64_t r = g_ext_rows; if (reset) g_ext_rows = 0; return r; }
+int64_t orc_diag_ext_calls(int reset) { int64_t r = g_ext_calls; if (reset) g_ext_calls = 0; return r; }
+
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int iabs(int a) { return a < 0 ? -a : a; }
 
@@ -56,7 +61,9 @@ void orc_sw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
   int beg = 0, end = qlen;
   int stop = 0;
 
+  ++g_ext_calls;
   for (i = 0; i < tlen && !stop; ++i) { /* SW:129-220 */
+    ++g_ext_rows;
     int t, f = 0, h1, mm = 0, mj = -1;
     const int8_t *q = qp + (size_t)target[i] * qlen;
     h1 = h0 - (o_del + e_del * (i + 1)); /* SW:137-138 */
