@@ -1,0 +1,291 @@
+// fake_jni.cpp -- TEST INFRASTRUCTURE: a miniature JVM object model behind a real JNIEnv function table, so the
+// JNI shim of libbPSW_hip.so (csrc/bpsw_jni.cpp) can be driven end to end without a JVM (none exists in the image).
+// Only the table slots the shim uses are populated; any other slot aborts loudly.  Objects carry their fields by name,
+// exactly what GetFieldID/Get*Field need.  The two drivers at the bottom build the Scala-side argument graphs
+// (SeqSWType / MateSWType / RefSWType / MemOptType / MemPeStat, jni/*.scala, datatype/*.scala) from flat arrays,
+// call the exported Java_* symbol, and flatten what comes back.
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "jni_min.h"
+
+namespace {
+
+struct FObj {
+  std::string cls;  // class name, or "[B" "[S" "[I" "[J" "[L" for arrays, or "class" for a jclass handle
+  std::map<std::string, int64_t> ints;
+  std::map<std::string, double> dbls;
+  std::map<std::string, FObj*> objs;
+  std::vector<int8_t> bytes;
+  std::vector<int16_t> shorts;
+  std::vector<int32_t> ia;
+  std::vector<int64_t> la;
+  std::vector<FObj*> elems;
+};
+struct FField { std::string name, sig; };
+
+struct Jvm {
+  std::vector<std::unique_ptr<FObj>> heap;
+  std::vector<std::unique_ptr<FField>> fields;
+  std::map<std::string, FObj*> classes;
+  bool pending = false;
+  std::string pending_msg;
+  int partition = -1;  // >= 0: org.apache.spark.TaskContext.get().partitionId() answers this
+  long calls[JNI_SLOT_COUNT] = {0};
+  FObj* alloc(const std::string& cls) { heap.emplace_back(new FObj()); heap.back()->cls = cls; return heap.back().get(); }
+};
+Jvm* g_vm = nullptr;
+
+const char* kKnown[] = {"cs/ucla/edu/bwaspark/datatype/MemAlnRegType", "cs/ucla/edu/bwaspark/datatype/MemOptType",
+                        "cs/ucla/edu/bwaspark/datatype/MemPeStat", "cs/ucla/edu/bwaspark/jni/MateSWType",
+                        "cs/ucla/edu/bwaspark/jni/SeqSWType", "cs/ucla/edu/bwaspark/jni/RefSWType",
+                        "java/lang/RuntimeException"};
+
+FObj* O(jobject o) { return reinterpret_cast<FObj*>(o); }
+jobject J(FObj* o) { return reinterpret_cast<jobject>(o); }
+
+jclass f_FindClass(JNIEnv*, const char* name) {
+  g_vm->calls[JNI_SLOT_FindClass]++;
+  bool ok = false;
+  for (const char* k : kKnown) ok |= strcmp(k, name) == 0;
+  if (strcmp(name, "org/apache/spark/TaskContext") == 0) ok = g_vm->partition >= 0;
+  if (!ok) { g_vm->pending = true; g_vm->pending_msg = std::string("NoClassDefFoundError: ") + name; return nullptr; }
+  auto it = g_vm->classes.find(name);
+  if (it != g_vm->classes.end()) return J(it->second);
+  FObj* c = g_vm->alloc("class");
+  c->objs["name"] = nullptr;
+  c->cls = std::string("class:") + name;
+  g_vm->classes[name] = c;
+  return J(c);
+}
+jint f_ThrowNew(JNIEnv*, jclass c, const char* msg) {
+  g_vm->pending = true;
+  g_vm->pending_msg = O(c)->cls.substr(6) + ": " + msg;
+  return 0;
+}
+void f_ExceptionClear(JNIEnv*) { g_vm->pending = false; }
+jboolean f_ExceptionCheck(JNIEnv*) { return g_vm->pending ? 1 : 0; }
+jint f_PushLocalFrame(JNIEnv*, jint) { g_vm->calls[JNI_SLOT_PushLocalFrame]++; return JNI_OK; }
+jobject f_PopLocalFrame(JNIEnv*, jobject r) { g_vm->calls[JNI_SLOT_PopLocalFrame]++; return r; }
+void f_DeleteLocalRef(JNIEnv*, jobject) {}
+jobject f_AllocObject(JNIEnv*, jclass c) { return J(g_vm->alloc(O(c)->cls.substr(6))); }
+jfieldID f_GetFieldID(JNIEnv*, jclass, const char* name, const char* sig) {
+  g_vm->calls[JNI_SLOT_GetFieldID]++;
+  g_vm->fields.emplace_back(new FField{name, sig});
+  return reinterpret_cast<jfieldID>(g_vm->fields.back().get());
+}
+const FField* F(jfieldID f) { return reinterpret_cast<const FField*>(f); }
+jobject f_GetObjectField(JNIEnv*, jobject o, jfieldID f) {
+  auto it = O(o)->objs.find(F(f)->name);
+  return it == O(o)->objs.end() ? nullptr : J(it->second);
+}
+jint f_GetIntField(JNIEnv*, jobject o, jfieldID f) { return (jint)O(o)->ints[F(f)->name]; }
+jlong f_GetLongField(JNIEnv*, jobject o, jfieldID f) { return (jlong)O(o)->ints[F(f)->name]; }
+jfloat f_GetFloatField(JNIEnv*, jobject o, jfieldID f) { return (jfloat)O(o)->dbls[F(f)->name]; }
+jdouble f_GetDoubleField(JNIEnv*, jobject o, jfieldID f) { return O(o)->dbls[F(f)->name]; }
+void f_SetObjectField(JNIEnv*, jobject o, jfieldID f, jobject v) { O(o)->objs[F(f)->name] = O(v); }
+void f_SetIntField(JNIEnv*, jobject o, jfieldID f, jint v) { O(o)->ints[F(f)->name] = v; }
+void f_SetLongField(JNIEnv*, jobject o, jfieldID f, jlong v) { O(o)->ints[F(f)->name] = v; }
+jmethodID f_GetMethodID(JNIEnv*, jclass, const char* name, const char*) {
+  g_vm->fields.emplace_back(new FField{name, "()"});
+  return reinterpret_cast<jmethodID>(g_vm->fields.back().get());
+}
+jmethodID f_GetStaticMethodID(JNIEnv* e, jclass c, const char* name, const char* sig) { return f_GetMethodID(e, c, name, sig); }
+jobject f_CallStaticObjectMethod(JNIEnv*, jclass, jmethodID, ...) { return J(g_vm->alloc("org/apache/spark/TaskContext")); }
+jint f_CallIntMethod(JNIEnv*, jobject, jmethodID, ...) { return g_vm->partition; }
+jsize f_GetArrayLength(JNIEnv*, jarray a) {
+  FObj* o = O(a);
+  if (o->cls == "[B") return (jsize)o->bytes.size();
+  if (o->cls == "[S") return (jsize)o->shorts.size();
+  if (o->cls == "[I") return (jsize)o->ia.size();
+  if (o->cls == "[J") return (jsize)o->la.size();
+  return (jsize)o->elems.size();
+}
+jobjectArray f_NewObjectArray(JNIEnv*, jsize n, jclass, jobject) {
+  FObj* a = g_vm->alloc("[L");
+  a->elems.assign((size_t)n, nullptr);
+  return J(a);
+}
+jobject f_GetObjectArrayElement(JNIEnv*, jobjectArray a, jsize i) {
+  return (i < 0 || (size_t)i >= O(a)->elems.size()) ? nullptr : J(O(a)->elems[(size_t)i]);
+}
+void f_SetObjectArrayElement(JNIEnv*, jobjectArray a, jsize i, jobject v) { O(a)->elems[(size_t)i] = O(v); }
+jshortArray f_NewShortArray(JNIEnv*, jsize n) {
+  FObj* a = g_vm->alloc("[S");
+  a->shorts.assign((size_t)n, 0);
+  return J(a);
+}
+void f_GetByteArrayRegion(JNIEnv*, jbyteArray a, jsize s, jsize l, jbyte* b) { memcpy(b, O(a)->bytes.data() + s, (size_t)l); }
+void f_GetIntArrayRegion(JNIEnv*, jintArray a, jsize s, jsize l, jint* b) { memcpy(b, O(a)->ia.data() + s, 4 * (size_t)l); }
+void f_GetLongArrayRegion(JNIEnv*, jlongArray a, jsize s, jsize l, jlong* b) { memcpy(b, O(a)->la.data() + s, 8 * (size_t)l); }
+void f_SetShortArrayRegion(JNIEnv*, jshortArray a, jsize s, jsize l, const jshort* b) { memcpy(O(a)->shorts.data() + s, b, 2 * (size_t)l); }
+
+void unpopulated() {
+  fprintf(stderr, "fake_jni: the shim called a JNI slot this fake does not implement\n");
+  abort();
+}
+
+struct Env {
+  JNINativeInterface_ table;
+  const JNINativeInterface_* env;  // JNIEnv = pointer to the table
+  Env() {
+    for (auto& s : table.slot) s = reinterpret_cast<void*>(&unpopulated);
+#define SET(name) table.slot[JNI_SLOT_##name] = reinterpret_cast<void*>(&f_##name)
+    SET(FindClass); SET(ThrowNew); SET(ExceptionClear); SET(ExceptionCheck); SET(PushLocalFrame); SET(PopLocalFrame);
+    SET(DeleteLocalRef); SET(AllocObject); SET(GetFieldID); SET(GetObjectField); SET(GetIntField); SET(GetLongField);
+    SET(GetFloatField); SET(GetDoubleField); SET(SetObjectField); SET(SetIntField); SET(SetLongField); SET(GetMethodID);
+    SET(GetStaticMethodID); SET(CallStaticObjectMethod); SET(CallIntMethod); SET(GetArrayLength); SET(NewObjectArray);
+    SET(GetObjectArrayElement); SET(SetObjectArrayElement); SET(NewShortArray); SET(GetByteArrayRegion);
+    SET(GetIntArrayRegion); SET(GetLongArrayRegion); SET(SetShortArrayRegion);
+#undef SET
+    env = &table;
+  }
+};
+
+FObj* byte_array(const uint8_t* p, size_t n) {
+  FObj* a = g_vm->alloc("[B");
+  a->bytes.assign(reinterpret_cast<const int8_t*>(p), reinterpret_cast<const int8_t*>(p) + n);
+  return a;
+}
+
+struct FlatReg {
+  int64_t rb, re;
+  int32_t qb, qe, score, truesc, sub, csub, sub_n, w, seedcov, secondary;
+  uint64_t hash;
+};
+FObj* reg_object(const FlatReg& r) {  // MemAlnRegType.scala:26-38
+  FObj* a = g_vm->alloc("cs/ucla/edu/bwaspark/datatype/MemAlnRegType");
+  a->ints["rBeg"] = r.rb; a->ints["rEnd"] = r.re; a->ints["qBeg"] = r.qb; a->ints["qEnd"] = r.qe;
+  a->ints["score"] = r.score; a->ints["trueScore"] = r.truesc; a->ints["sub"] = r.sub; a->ints["csub"] = r.csub;
+  a->ints["subNum"] = r.sub_n; a->ints["width"] = r.w; a->ints["seedCov"] = r.seedcov; a->ints["secondary"] = r.secondary;
+  a->ints["hash"] = (int64_t)r.hash;
+  return a;
+}
+
+void* load_symbol(const char* lib, const char* sym, char* err, size_t errcap) {
+  void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { snprintf(err, errcap, "dlopen: %s", dlerror()); return nullptr; }
+  void* f = dlsym(h, sym);
+  if (!f) snprintf(err, errcap, "dlsym: %s", dlerror());
+  return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+// returns 0 on success, 1 if the shim left a Java exception pending (text in err), -1 on harness failure
+int fake_jvm_extend(const char* lib, int partition, const uint8_t* wire, int wire_bytes, int ret_task_num, int16_t* out,
+                    char* err, int errcap) {
+  Jvm vm;
+  g_vm = &vm;
+  vm.partition = partition;
+  Env e;
+  typedef jshortArray (*Fn)(JNIEnv*, jobject, jint, jbyteArray);
+  Fn fn = (Fn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI", err, (size_t)errcap);
+  if (!fn) return -1;
+  FObj* self = vm.alloc("cs/ucla/edu/bwaspark/jni/SWExtendFPGAJNI");
+  jshortArray r = fn(&e.env, J(self), ret_task_num, J(byte_array(wire, (size_t)wire_bytes)));
+  if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+  if (!r || (int)O(r)->shorts.size() != ret_task_num) { snprintf(err, (size_t)errcap, "bad result array"); return -1; }
+  memcpy(out, O(r)->shorts.data(), 2 * (size_t)ret_task_num);
+  return 0;
+}
+
+int fake_jvm_matesw(const char* lib, int partition, const int32_t opt_ints[16], float mask_level_redun, const int8_t mat[25],
+                    int64_t l_pac, const double* pes /*4x5: low high failed avg std*/, int group_size, const int32_t* seq_len,
+                    const int64_t* seq_off, const uint8_t* seq_pool, const int32_t* reg_cnt, const FlatReg* regs,
+                    const int32_t* ref_cnt, const int64_t* ref_rb, const int64_t* ref_re, const int64_t* ref_len,
+                    const int64_t* ref_off, const uint8_t* ref_pool, int32_t* out_cnt, FlatReg* out_regs, int64_t out_cap,
+                    int64_t* out_total, long* local_frames, char* err, int errcap) {
+  Jvm vm;
+  g_vm = &vm;
+  vm.partition = partition;
+  Env e;
+  typedef jobjectArray (*Fn)(JNIEnv*, jobject, jobject, jlong, jobjectArray, jint, jobjectArray, jobjectArray, jobjectArray, jintArray);
+  Fn fn = (Fn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI", err, (size_t)errcap);
+  if (!fn) return -1;
+  // MemOptType (datatype/MemOptType.scala:28-56)
+  static const char* names[16] = {"a", "b", "oDel", "eDel", "oIns", "eIns", "penUnpaired", "penClip5", "penClip3", "w", "zdrop",
+                                  "T", "flag", "minSeedLen", "maxIns", "maxMatesw"};
+  FObj* opt = vm.alloc("cs/ucla/edu/bwaspark/datatype/MemOptType");
+  for (int i = 0; i < 16; ++i) opt->ints[names[i]] = opt_ints[i];
+  opt->dbls["maskLevelRedun"] = mask_level_redun;
+  opt->objs["mat"] = byte_array(reinterpret_cast<const uint8_t*>(mat), 25);
+  FObj* pes_arr = vm.alloc("[L");
+  for (int r = 0; r < 4; ++r) {
+    FObj* p = vm.alloc("cs/ucla/edu/bwaspark/datatype/MemPeStat");
+    p->ints["low"] = (int64_t)pes[5 * r]; p->ints["high"] = (int64_t)pes[5 * r + 1]; p->ints["failed"] = (int64_t)pes[5 * r + 2];
+    p->dbls["avg"] = pes[5 * r + 3]; p->dbls["std"] = pes[5 * r + 4];
+    pes_arr->elems.push_back(p);
+  }
+  FObj *seqs = vm.alloc("[L"), *mates = vm.alloc("[L"), *refs = vm.alloc("[L"), *ref_sizes = vm.alloc("[I");
+  int64_t reg_at = 0, row = 0;
+  for (int k = 0; k < group_size; ++k)  // memSamPeGroupJNIPrepare emits all refs first (MemSamPe.scala:1931-1950)
+    for (int i = 0; i < 2; ++i) {
+      const int e2 = 2 * k + i;
+      ref_sizes->ia.push_back(ref_cnt[e2]);
+      for (int j = 0; j < ref_cnt[e2]; ++j, ++row) {
+        FObj* r = vm.alloc("cs/ucla/edu/bwaspark/jni/RefSWType");
+        r->ints["readIdx"] = k; r->ints["pairIdx"] = i; r->ints["regIdx"] = j;
+        FObj *rb = vm.alloc("[J"), *re = vm.alloc("[J"), *ln = vm.alloc("[J");
+        for (int o = 0; o < 4; ++o) {
+          rb->la.push_back(ref_rb[4 * row + o]); re->la.push_back(ref_re[4 * row + o]); ln->la.push_back(ref_len[4 * row + o]);
+          static const char* rn[4] = {"ref0", "ref1", "ref2", "ref3"};
+          r->objs[rn[o]] = ref_len[4 * row + o] > 0 ? byte_array(ref_pool + ref_off[4 * row + o], (size_t)ref_len[4 * row + o]) : nullptr;
+        }
+        r->objs["rBegArray"] = rb; r->objs["rEndArray"] = re; r->objs["lenArray"] = ln;
+        refs->elems.push_back(r);
+      }
+    }
+  for (int k = 0; k < group_size; ++k)  // then seqs and regions in (k,i,j) order (MemSamPe.scala:1962-1990)
+    for (int i = 0; i < 2; ++i) {
+      const int e2 = 2 * k + i;
+      FObj* s = vm.alloc("cs/ucla/edu/bwaspark/jni/SeqSWType");
+      s->ints["readIdx"] = k; s->ints["pairIdx"] = i; s->ints["seqLength"] = seq_len[e2];
+      s->objs["seqTrans"] = byte_array(seq_pool + seq_off[e2], (size_t)seq_len[e2]);
+      seqs->elems.push_back(s);
+      for (int j = 0; j < reg_cnt[e2]; ++j, ++reg_at) {
+        FObj* m = vm.alloc("cs/ucla/edu/bwaspark/jni/MateSWType");
+        m->ints["readIdx"] = k; m->ints["pairIdx"] = i; m->ints["regIdx"] = j;
+        m->objs["alnReg"] = reg_object(regs[reg_at]);
+        mates->elems.push_back(m);
+      }
+    }
+  FObj* self = vm.alloc("cs/ucla/edu/bwaspark/jni/MateSWJNI");
+  jobjectArray r = fn(&e.env, J(self), J(opt), (jlong)l_pac, J(pes_arr), group_size, J(seqs), J(mates), J(refs), J(ref_sizes));
+  if (local_frames) *local_frames = vm.calls[JNI_SLOT_PushLocalFrame] - vm.calls[JNI_SLOT_PopLocalFrame];
+  if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+  if (!r) { snprintf(err, (size_t)errcap, "null result"); return -1; }
+  // mateSWArrayToAlnRegPairArray (MemSamPe.scala:2010-2044): group by (readIdx, pairIdx) in arrival order
+  memset(out_cnt, 0, sizeof(int32_t) * 2 * (size_t)group_size);
+  *out_total = (int64_t)O(r)->elems.size();
+  if (*out_total > out_cap) { snprintf(err, (size_t)errcap, "out_cap too small"); return -1; }
+  int64_t at = 0;
+  int last_e = -1, last_rank = -1;
+  for (FObj* m : O(r)->elems) {
+    if (!m || m->cls != "cs/ucla/edu/bwaspark/jni/MateSWType" || !m->objs["alnReg"]) { snprintf(err, (size_t)errcap, "malformed MateSWType"); return -1; }
+    const int e2 = 2 * (int)m->ints["readIdx"] + (int)m->ints["pairIdx"];
+    if (e2 < last_e || (e2 == last_e && (int)m->ints["regIdx"] != last_rank + 1) || (e2 != last_e && m->ints["regIdx"] != 0)) {
+      snprintf(err, (size_t)errcap, "result not in (k,i,rank) order"); return -1;
+    }
+    last_rank = (int)m->ints["regIdx"]; last_e = e2;
+    out_cnt[e2]++;
+    FObj* a = m->objs["alnReg"];
+    FlatReg& o = out_regs[at++];
+    o.rb = a->ints["rBeg"]; o.re = a->ints["rEnd"]; o.qb = (int32_t)a->ints["qBeg"]; o.qe = (int32_t)a->ints["qEnd"];
+    o.score = (int32_t)a->ints["score"]; o.truesc = (int32_t)a->ints["trueScore"]; o.sub = (int32_t)a->ints["sub"];
+    o.csub = (int32_t)a->ints["csub"]; o.sub_n = (int32_t)a->ints["subNum"]; o.w = (int32_t)a->ints["width"];
+    o.seedcov = (int32_t)a->ints["seedCov"]; o.secondary = (int32_t)a->ints["secondary"]; o.hash = (uint64_t)a->ints["hash"];
+  }
+  return 0;
+}
+
+}  // extern "C"

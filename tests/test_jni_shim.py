@@ -1,0 +1,96 @@
+"""Drives the exported Java_* symbols of libbPSW_hip.so through a fake JNIEnv (tests/fake_jvm/fake_jni.cpp): the
+argument graphs are built the way memSamPeGroupJNIPrepare / runOnFPGAJNI build them, the result is flattened the way
+mateSWArrayToAlnRegPairArray reads it.  No JVM exists in the image, so this is the closest available check of the
+marshalling code; the JNI function-table slot numbers are taken from the JNI specification (csrc/jni_min.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bpsw_hip
+from bpsw_hip import synth
+from conftest import region_fields_equal
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FAKE_SO = os.path.join(HERE, "fake_jvm", "libfakejvm.so")
+
+
+@pytest.fixture(scope="module")
+def fake():
+    src = os.path.join(HERE, "fake_jvm", "fake_jni.cpp")
+    if not os.path.exists(FAKE_SO) or os.path.getmtime(FAKE_SO) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "cloud-scale-bwamem_amd", "csrc"),
+                        "-o", FAKE_SO, src, "-ldl"], check=True)
+    bpsw_hip.load_library()   # torch first (one HIP runtime per process), then the product library
+    lib = C.CDLL(FAKE_SO)
+    lib.fake_jvm_extend.restype = C.c_int
+    lib.fake_jvm_matesw.restype = C.c_int
+    return lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _extend(fake, wire, n, partition=-1):
+    out = np.zeros(max(10 * n, 1), np.int16)
+    err = C.create_string_buffer(512)
+    rc = fake.fake_jvm_extend(bpsw_hip.LIB_PATH.encode(), partition, _vp(wire), int(wire.size), 10 * n, _vp(out), err, 512)
+    return rc, out[: 10 * n], err.value.decode()
+
+
+def _matesw(fake, g, partition=-1):
+    opt = bpsw_hip.default_opt()
+    ints = np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_unpaired, opt.pen_clip5, opt.pen_clip3,
+                     opt.w, opt.zdrop, opt.T, opt.flag, opt.min_seed_len, opt.max_ins, opt.max_matesw], np.int32)
+    mat = np.array(list(opt.mat), np.int8)
+    pes = np.array([[p[0], p[1], p[2], p[3], p[4]] for p in g.pes], np.float64)
+    out_cnt = np.zeros(2 * g.group_size + 1, np.int32)
+    cap = int(g.regs.shape[0] + g.ref_rb.shape[0] + 16)
+    out = np.zeros(cap, bpsw_hip.ALNREG_DTYPE)
+    total, frames = C.c_int64(0), C.c_long(0)
+    err = C.create_string_buffer(512)
+    rc = fake.fake_jvm_matesw(bpsw_hip.LIB_PATH.encode(), partition, _vp(ints), C.c_float(opt.mask_level_redun), _vp(mat),
+                              C.c_int64(g.l_pac), _vp(pes), g.group_size, _vp(g.seq_len), _vp(g.seq_off), _vp(g.seq_pool),
+                              _vp(g.reg_cnt), _vp(g.regs), _vp(g.ref_cnt), _vp(g.ref_rb), _vp(g.ref_re), _vp(g.ref_len),
+                              _vp(g.ref_off), _vp(g.ref_pool), _vp(out_cnt), _vp(out), C.c_int64(cap), C.byref(total),
+                              C.byref(frames), err, 512)
+    return rc, out_cnt[: 2 * g.group_size], out[: total.value], frames.value, err.value.decode()
+
+
+def test_without_a_device_the_shim_raises_a_java_exception(fake):
+    if bpsw_hip.load_library().bpsw_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    soa = synth.ext_tasks(16, seed=3)
+    rc, _, msg = _extend(fake, bpsw_hip.wire_pack(soa), soa.n)
+    assert rc == 1 and msg.startswith("java/lang/RuntimeException: bPSW: no usable HIP device")
+    rc, _, _, frames, msg = _matesw(fake, synth.rescue_group(4, seed=3, p_resc=0.5))
+    assert rc == 1 and "RuntimeException" in msg and frames == 0       # every PushLocalFrame was popped
+
+
+@pytest.mark.gpu
+def test_extend_through_jni_matches_c_abi(fake, ctx):
+    soa = synth.ext_tasks(2000, seed=77)
+    wire = bpsw_hip.wire_pack(soa)
+    want = ctx.extend_batch(wire)
+    for partition in (-1, 5):          # no TaskContext / TaskContext.get().partitionId() == 5
+        rc, got, msg = _extend(fake, wire, soa.n, partition)
+        assert rc == 0, msg
+        assert np.array_equal(got, want)
+    rc, _, msg = _extend(fake, wire[: 32 + 32 * soa.n - 8], soa.n)
+    assert rc == 1 and "RuntimeException" in msg                        # malformed batch -> exception, not a crash
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("allo", [False, True])
+def test_matesw_through_jni_matches_c_abi(fake, ctx, allo):
+    g = synth.rescue_group(120, seed=404, p_resc=0.4, all_orientations=allo)
+    want_cnt, want = ctx.matesw_group(bpsw_hip.default_opt(), g)
+    rc, cnt, regs, frames, msg = _matesw(fake, g, partition=3)
+    assert rc == 0, msg
+    assert frames == 0
+    assert np.array_equal(cnt, want_cnt)
+    region_fields_equal(regs, want)
