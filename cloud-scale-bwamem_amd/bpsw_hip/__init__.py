@@ -26,7 +26,7 @@ KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
 ABI_SYMBOLS = [
     "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_last_error", "bpsw_version",
     "bpsw_set_ext_scoring", "bpsw_extend_batch", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
-    "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group",
+    "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
 ]
 JNI_SYMBOLS = [
@@ -75,6 +75,12 @@ class ExtTasks(C.Structure):  # bpsw_ext_tasks_t
 class SwJobs(C.Structure):  # bpsw_sw_jobs_t
     _fields_ = [("n", C.c_int32), ("xtra", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool")] + \
+               [("q_pool_bytes", C.c_size_t), ("t_pool_bytes", C.c_size_t)]
+
+
+class GlobalJobs(C.Structure):  # bpsw_global_jobs_t
+    _fields_ = [("n", C.c_int32), ("max_cigar", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("q_len", "t_len", "w", "q_off", "t_off", "q_pool", "t_pool")] + \
                [("q_pool_bytes", C.c_size_t), ("t_pool_bytes", C.c_size_t)]
 
 
@@ -132,6 +138,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_swalign2_batch_device.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(SwJobs), C.c_void_p, C.c_void_p]
     lib.bpsw_matesw_group.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(RescueGroup), C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.bpsw_global_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(GlobalJobs), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bpsw_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.bpsw_reset_stats.argtypes = [C.c_void_p]
     lib.bpsw_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -283,6 +290,24 @@ class Context:
     def swalign2_batch_device(self, opt: Opt, jobs: SwJobs, d_out_ptr: int, stream: int = 0):
         _chk(self.lib, self.lib.bpsw_swalign2_batch_device(self.h, C.byref(opt), C.byref(jobs), C.c_void_p(d_out_ptr),
                                                           C.c_void_p(stream)), "bpsw_swalign2_batch_device")
+
+    def global_batch(self, opt: Opt, q_len, t_len, w, q_off, t_off, q_pool, t_pool, max_cigar: int = 64):
+        """SWGlobal (SWUtil.scala:233-397) for a batch of jobs -> (score[n], list of cigar arrays len<<4|op)"""
+        j = GlobalJobs()
+        arrs = dict(q_len=np.ascontiguousarray(q_len, np.int32), t_len=np.ascontiguousarray(t_len, np.int32),
+                    w=np.ascontiguousarray(w, np.int32), q_off=np.ascontiguousarray(q_off, np.int64),
+                    t_off=np.ascontiguousarray(t_off, np.int64), q_pool=np.ascontiguousarray(q_pool, np.uint8),
+                    t_pool=np.ascontiguousarray(t_pool, np.uint8))
+        j.n, j.max_cigar = int(arrs["q_len"].shape[0]), int(max_cigar)
+        for k, a in arrs.items():
+            setattr(j, k, a.ctypes.data)
+        j.q_pool_bytes, j.t_pool_bytes = arrs["q_pool"].size, arrs["t_pool"].size
+        score = np.zeros(max(j.n, 1), np.int32)
+        ncig = np.zeros(max(j.n, 1), np.int32)
+        cig = np.zeros((max(j.n, 1), max_cigar), np.uint32)
+        _chk(self.lib, self.lib.bpsw_global_batch(self.h, C.byref(opt), C.byref(j), _ptr(score), _ptr(ncig), _ptr(cig)),
+             "bpsw_global_batch")
+        return score[: j.n], ncig[: j.n], cig[: j.n]
 
     def matesw_group(self, opt: Opt, g: "RescueGroupSoA", mode: int = RESCUE_C):
         st = g.as_struct()

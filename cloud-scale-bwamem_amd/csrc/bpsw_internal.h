@@ -79,6 +79,29 @@ int sw_resident_waves(int num_cu);
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
                             uint32_t* d_scratch, int num_cu, hipStream_t s);
 
+// ---- global alignment + CIGAR -------------------------------------------------
+struct GlobalJobsDev {  // all device pointers
+  int n;
+  int max_cigar;
+  const int32_t* q_len;
+  const int32_t* t_len;
+  const int32_t* w;
+  const int64_t* q_off;
+  const int64_t* t_off;
+  const uint8_t* q_pool;
+  const uint8_t* t_pool;
+};
+struct GlobalPrepass {
+  int max_qlen;
+  int error;
+  unsigned long long max_z;  // max over jobs of nCol * tLen (bytes of backtrack matrix)
+};
+void launch_global_prepass(const GlobalJobsDev& jobs, size_t q_pool_bytes, size_t t_pool_bytes, GlobalPrepass* d_pre, hipStream_t s);
+int global_resident_waves(int num_cu, int qcap);
+hipError_t launch_global_kernel(const GlobalJobsDev& jobs, const SwScoring& sc, int max_qlen, size_t z_per_wave,
+                                int32_t* d_score, int32_t* d_ncigar, uint32_t* d_cigar, uint8_t* d_z, int num_cu,
+                                hipStream_t s);
+
 // ---- error text -----------------------------------------------------------------------------------
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
@@ -112,7 +135,7 @@ struct bpsw_ctx {
   bpsw::ExtScoring ext_sc;
   int8_t ext_mat[25];
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
-  bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch;
+  bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z;
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
   bpsw_stats_t stats;
   float last_ext_ms = 0.f, last_sw_ms = 0.f;

@@ -168,7 +168,7 @@ void bpsw_destroy(bpsw_ctx_t* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
-  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release();
+  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release();
   c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();
   for (int i = 0; i < 8; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

@@ -147,6 +147,68 @@ int bpsw_swalign2_batch_device(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_
   return BPSW_OK;
 }
 
+int bpsw_global_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_global_jobs_t* j, int32_t* out_score,
+                      int32_t* out_ncigar, uint32_t* out_cigar) {
+  if (!c || !j || !out_score || !out_ncigar || !out_cigar) return fail(BPSW_ERR_ARG, "global: null argument");
+  SwScoring sc;
+  int rc = make_scoring(opt, 0, &sc);
+  if (rc != BPSW_OK) return rc;
+  const int n = j->n;
+  if (n == 0) return BPSW_OK;
+  if (n < 0 || !j->q_len || !j->t_len || !j->w || !j->q_off || !j->t_off || !j->q_pool || !j->t_pool)
+    return fail(BPSW_ERR_ARG, "global: null job arrays");
+  if (j->max_cigar < 1 || j->max_cigar > BPSW_GLOBAL_MAX_CIGAR) return fail(BPSW_ERR_ARG, "global: max_cigar must be 1..512");
+  int mq = 0;
+  size_t mz = 0;
+  for (int i = 0; i < n; ++i) {  // host twin of global_prepass_kernel
+    const int ql = j->q_len[i], tl = j->t_len[i], w = j->w[i];
+    const long long qo = j->q_off[i], to = j->t_off[i];
+    if (ql < 1 || tl < 1 || w < 0 || qo < 0 || to < 0 || (unsigned long long)(qo + ql) > j->q_pool_bytes ||
+        (unsigned long long)(to + tl) > j->t_pool_bytes)
+      return fail(BPSW_ERR_ARG, "global: job sequence outside its pool (or empty)");
+    if (ql > BPSW_GLOBAL_MAX_QLEN || tl > BPSW_GLOBAL_MAX_TLEN) return fail(BPSW_ERR_LIMIT, "global: sequence longer than the kernel limit");
+    const long long ncol = ql < 2ll * w + 1 ? ql : 2ll * w + 1;
+    if ((size_t)(ncol * tl) > mz) mz = (size_t)(ncol * tl);
+    if (ql > mq) mq = ql;
+  }
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t o_qlen = 0, o_tlen = align16(4 * (size_t)n), o_w = align16(o_tlen + 4 * (size_t)n);
+  const size_t o_qoff = align16(o_w + 4 * (size_t)n), o_toff = align16(o_qoff + 8 * (size_t)n);
+  const size_t o_qpool = align16(o_toff + 8 * (size_t)n), o_tpool = align16(o_qpool + j->q_pool_bytes);
+  const size_t total = align16(o_tpool + j->t_pool_bytes);
+  const size_t o_score = 0, o_nc = align16(4 * (size_t)n), o_cig = align16(o_nc + 4 * (size_t)n);
+  const size_t out_bytes = o_cig + 4 * (size_t)n * (size_t)j->max_cigar;
+  const size_t z_per_wave = (mz + 255) & ~(size_t)255;
+  const int qcap = (mq + 31) & ~31;
+  HIP_TRY(c->h_stage_in.reserve(total));
+  HIP_TRY(c->d_sw_in.reserve(total));
+  HIP_TRY(c->h_stage_out.reserve(out_bytes));
+  HIP_TRY(c->d_sw_out.reserve(out_bytes));
+  HIP_TRY(c->d_gl_z.reserve(z_per_wave * (size_t)global_resident_waves(c->num_cu, qcap)));
+  uint8_t* h = (uint8_t*)c->h_stage_in.ptr;
+  memcpy(h + o_qlen, j->q_len, 4 * (size_t)n); memcpy(h + o_tlen, j->t_len, 4 * (size_t)n); memcpy(h + o_w, j->w, 4 * (size_t)n);
+  memcpy(h + o_qoff, j->q_off, 8 * (size_t)n); memcpy(h + o_toff, j->t_off, 8 * (size_t)n);
+  memcpy(h + o_qpool, j->q_pool, j->q_pool_bytes); memcpy(h + o_tpool, j->t_pool, j->t_pool_bytes);
+  uint8_t* d = (uint8_t*)c->d_sw_in.ptr;
+  GlobalJobsDev dev;
+  dev.n = n; dev.max_cigar = j->max_cigar;
+  dev.q_len = (const int32_t*)(d + o_qlen); dev.t_len = (const int32_t*)(d + o_tlen); dev.w = (const int32_t*)(d + o_w);
+  dev.q_off = (const int64_t*)(d + o_qoff); dev.t_off = (const int64_t*)(d + o_toff);
+  dev.q_pool = d + o_qpool; dev.t_pool = d + o_tpool;
+  uint8_t* dout = (uint8_t*)c->d_sw_out.ptr;
+  HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(launch_global_kernel(dev, sc, mq, z_per_wave, (int32_t*)(dout + o_score), (int32_t*)(dout + o_nc),
+                               (uint32_t*)(dout + o_cig), (uint8_t*)c->d_gl_z.ptr, c->num_cu, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const uint8_t* ho = (const uint8_t*)c->h_stage_out.ptr;
+  memcpy(out_score, ho + o_score, 4 * (size_t)n);
+  memcpy(out_ncigar, ho + o_nc, 4 * (size_t)n);
+  memcpy(out_cigar, ho + o_cig, 4 * (size_t)n * (size_t)j->max_cigar);
+  return BPSW_OK;
+}
+
 int bpsw_last_kernel_ms(bpsw_ctx_t* c, float* ext_ms, float* sw_ms) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   std::lock_guard<std::mutex> g(c->mu);

@@ -168,6 +168,30 @@ typedef struct {
 int bpsw_matesw_group(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_rescue_group_t *g, int mode,
                       int32_t *out_cnt, bpsw_alnreg_t *out_regs, int64_t out_cap, int64_t *out_total);
 
+/* ---- "next" row: banded global alignment -> score + CIGAR ------------------------------ */
+/*
+ * SWUtil.SWGlobal (SWUtil.scala:233-397 == ksw_global2, native/ksw.c:501-584), the DP behind bwaGenCigar2
+ * (MemRegToADAMSAM.scala:738-891).  It is NOT behind either JNI of the reference (the Scala driver calls it
+ * directly), so this is an additional export for callers that want CIGARs from the device.
+ * Job t aligns q_pool[q_off[t]..+q_len[t]) to t_pool[t_off[t]..+t_len[t]) globally inside the band w[t]
+ * (the caller applies the band rule of MemRegToADAMSAM.scala:794-804 and the strand reversal of :764-781).
+ * out_score[t]; out_ncigar[t] = number of operations; out_cigar[t*max_cigar ..] = len<<4|op (0=M 1=I 2=D).
+ * If out_ncigar[t] > max_cigar that job's operations were not written: resubmit it with a larger max_cigar (<= 512).
+ */
+#define BPSW_GLOBAL_MAX_QLEN 1023
+#define BPSW_GLOBAL_MAX_TLEN 65535
+#define BPSW_GLOBAL_MAX_CIGAR 512
+typedef struct {
+  int32_t n;
+  int32_t max_cigar;
+  const int32_t *q_len, *t_len, *w;
+  const int64_t *q_off, *t_off;
+  const uint8_t *q_pool, *t_pool;
+  size_t q_pool_bytes, t_pool_bytes;
+} bpsw_global_jobs_t;
+int bpsw_global_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_global_jobs_t *jobs, int32_t *out_score,
+                      int32_t *out_ncigar, uint32_t *out_cigar);
+
 /* ---- statistics (the buckets of profiling/SWBatchTimeBreakdown.scala:25-39, device flavoured) -- */
 typedef struct {
   uint64_t ext_calls, ext_tasks, ext_wire_bytes;
