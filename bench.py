@@ -97,7 +97,11 @@ def main():
 
     import bpsw_hip
     import ctypes as C
-    ctx = bpsw_hip.Context(local_rank)  # no fallback: raises without a gfx950 device
+    # One context per extension batch of the step plus one for the rescue jobs, all on this rank's GPU: each context
+    # owns a stream, so the independent batches of a step overlap on the device the way concurrent Spark task
+    # threads of one executor overlap their JNI calls (the reference native code is re-entrant for that reason).
+    ctxs = [bpsw_hip.Context(local_rank) for _ in range(EXT_BATCHES_PER_STEP + 1)]  # no fallback: raises without a gfx950 device
+    ctx = ctxs[-1]
     opt = bpsw_hip.default_opt()
     xtra = bpsw_hip.KSW_XSUBO | bpsw_hip.KSW_XSTART | bpsw_hip.KSW_XBYTE | 19   # MemSamPe.scala:1187-1189
 
@@ -113,19 +117,20 @@ def main():
     for k in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool"):
         setattr(sj, k, d_jobs[k].data_ptr())
     sj.q_pool_bytes, sj.t_pool_bytes = d_jobs["q_pool"].numel(), d_jobs["t_pool"].numel()
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    torch.cuda.synchronize(dev)
 
     ext_ms_sum, sw_ms_sum, ext_launches, sw_launches = 0.0, 0.0, 0, 0
 
     def step(timed: bool):
         nonlocal ext_ms_sum, sw_ms_sum, ext_launches, sw_launches
-        for w, n, dw, do in zip(wires, ntasks, d_wires, d_outs):
-            ctx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), stream)
-            e, _ = ctx.last_kernel_ms()     # HIP events on the launch stream, recorded inside the library
+        for cx, w, n, dw, do in zip(ctxs, wires, ntasks, d_wires, d_outs):
+            cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)   # asynchronous, context's own stream
+        ctx.swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
+        for cx in ctxs[:-1]:
+            e, _ = cx.last_kernel_ms()      # HIP events on the launch stream, recorded inside the library; waits for the batch
             if timed:
                 ext_ms_sum += e
                 ext_launches += 1
-        ctx.swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), stream)
         _, s = ctx.last_kernel_ms()
         if timed:
             sw_ms_sum += s
@@ -189,7 +194,8 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for cx in ctxs:
+        cx.close()
     if distributed:
         dist.destroy_process_group()
 

@@ -21,6 +21,7 @@ namespace bpsw {
 namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
+constexpr int EXT_CHUNK = 1;  // tasks per dequeue (larger chunks measured slower: the tail grows faster than the atomic traffic shrinks)
 
 // base k (0-based) of a task's nibble stream: 8 nibbles per word, first base in the top nibble
 __device__ __forceinline__ int nibble_at(const uint32_t* __restrict__ words, int k) {
@@ -398,7 +399,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
                                                                      const int lds_per_wave,
-                                                                     int* __restrict__ next_task) {
+                                                                     int* __restrict__ next_task,
+                                                                     const int* __restrict__ task_list) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
@@ -416,9 +418,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
 
   // Tasks differ in cost by an order of magnitude, so waves pull them from a shared counter instead of
   // striding: a wave takes the next task when it finishes one and leaves when the counter passes n_tasks.
+  // One counter word sustains only ~90 returning atomics per microsecond chip-wide (MI355X_MICROARCH.md, row
+  // "dequeue"), which at one atomic per task would cap a 30 k-task batch near 0.4 ms; waves therefore take tickets
+  // in chunks of EXT_CHUNK consecutive tasks.
+  int ticket = 0, ticket_end = 0;
   for (;;) {
-    const int task = dequeue_task(next_task);
-    if (task >= n_tasks) break;
+    if (ticket == ticket_end) {
+      ticket = dequeue_task(next_task) * EXT_CHUNK;
+      ticket_end = min(ticket + EXT_CHUNK, n_tasks);
+      if (ticket >= n_tasks) break;
+    }
+    const int task = task_list ? uni(task_list[ticket]) : ticket;  // n_tasks counts the entries of task_list when given
+    ++ticket;
     const uint32_t* rec = wire + 8 + 8 * (size_t)task;  // MemChainToAlignBatched.scala:95-117
     const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
     const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
@@ -497,6 +508,7 @@ __global__ void ext_prepass_kernel(const uint32_t* __restrict__ wire, const unsi
     const int oIns = (int8_t)((hdr0 >> 16) & 0xff), eIns = (int8_t)((hdr0 >> 24) & 0xff);
     const int oDel = (int8_t)(hdr0 & 0xff), eDel = (int8_t)((hdr0 >> 8) & 0xff);
     if (oIns < 0 || eIns < 0 || oDel < 0 || eDel < 0) err = 2;  // the prefix-scan form of F needs oIns >= 0
+    pre->reserved = oIns + eIns > 0 ? 1 : 0;                    // quad-task kernels are usable
   }
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {
     const uint32_t* rec = wire + 8 + 8 * (size_t)t;
@@ -529,7 +541,7 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 }
 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
-                             int rcap, int num_cu, int* d_counter, hipStream_t s) {
+                             int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s) {
   if (n_tasks <= 0) return hipSuccess;
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
@@ -553,7 +565,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   hipError_t me = hipMemsetAsync(d_counter, 0, sizeof(int), s);
   if (me != hipSuccess) return me;
   hipLaunchKernelGGL(ext_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
-                     rcap, (int)per_wave, d_counter);
+                     rcap, (int)per_wave, d_counter, d_task_list);
   return hipGetLastError();
 }
 

@@ -46,8 +46,24 @@ size_t ext_lds_per_wave(int qcap, int rcap);
 
 // Launch the extension kernel over a validated batch.
 // d_counter: one device int used as the kernel's task queue head (zeroed on the stream before the launch).
+// d_task_list (optional): the n_tasks task indices this launch handles (else tasks 0..n_tasks-1).
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
-                             int rcap, int num_cu, int* d_counter, hipStream_t s);
+                             int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s);
+// Quad-task kernel (bpsw_extend_qt.hip): s_cols = 4 (sides <= 63 bp) or 9 (<= 143 bp).
+hipError_t launch_ext_qt_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, const int* d_list, int n_list,
+                                int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter, hipStream_t s);
+struct ExtStreams {  // two auxiliary streams + events so the independent launches of one batch overlap
+  hipStream_t stream[2];
+  hipEvent_t fork, join[2];
+};
+// Splits the tasks of a validated batch into three lists (d_lists[bin * n_tasks + k]) and counts (d_counts[3], zeroed
+// by the caller): bin 0 -> quad-task S=4, bin 1 -> quad-task S=9, bin 2 -> one task per wave (ext_kernel).
+void launch_ext_bin(const uint32_t* d_wire, int n_tasks, int* d_lists, int* d_counts, hipStream_t s);
+// All launches of one extension batch; h_counts are the three bin sizes read back by the caller.
+// d_counters: three device ints (one queue head per launch).
+hipError_t launch_ext_all(const uint32_t* d_wire, size_t wire_words, int n_tasks, int16_t* d_out, const ExtScoring& sc,
+                          int qcap, int rcap, int num_cu, int* d_counters, const int* d_lists, const int h_counts[3],
+                          bool use_qt, const ExtStreams& aux, hipStream_t s);
 
 // ---- local SW (boundary 1) ---------------------------------------------------------------------
 struct SwScoring {
@@ -131,11 +147,12 @@ struct bpsw_ctx {
   int num_cu = 256;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bpsw::ExtStreams aux = {{nullptr, nullptr}, nullptr, {nullptr, nullptr}};
   std::mutex mu;
   bpsw::ExtScoring ext_sc;
   int8_t ext_mat[25];
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
-  bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z;
+  bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
   bpsw_stats_t stats;
   float last_ext_ms = 0.f, last_sw_ms = 0.f;

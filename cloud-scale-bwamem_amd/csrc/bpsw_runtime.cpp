@@ -153,6 +153,11 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.mat_max = 1;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
+  for (int k = 0; e == hipSuccess && k < 2; ++k) {
+    e = hipStreamCreateWithFlags(&c->aux.stream[k], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux.join[k], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux.fork, hipEventDisableTiming);
   if (e == hipSuccess) e = c->d_pre.reserve(256);
   if (e == hipSuccess) e = c->h_pre.reserve(256);
   if (e != hipSuccess) {
@@ -168,10 +173,15 @@ void bpsw_destroy(bpsw_ctx_t* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
-  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release();
+  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release();
   c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();
   for (int i = 0; i < 8; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int k = 0; k < 2; ++k) {
+    if (c->aux.stream[k]) (void)hipStreamDestroy(c->aux.stream[k]);
+    if (c->aux.join[k]) (void)hipEventDestroy(c->aux.join[k]);
+  }
+  if (c->aux.fork) (void)hipEventDestroy(c->aux.fork);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -189,6 +199,13 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
   c->ext_sc.zdrop = zdrop;
   c->ext_sc.zdrop_mode = zdrop_mode;
   return BPSW_OK;
+}
+
+// The quad-task kernels (bpsw_extend_qt.hip) execute 1.8x fewer instructions than ext_kernel but are not faster at
+// 32 k-read batches on MI355X, so they are opt-in: BPSW_EXT_QT=1.
+static bool ext_qt_enabled() {
+  static const bool on = getenv("BPSW_EXT_QT") && atoi(getenv("BPSW_EXT_QT")) != 0;
+  return on;
 }
 
 // ------------------------------------------------------------------------------------- boundary 2
@@ -236,14 +253,28 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
   const size_t out_bytes = 20 * (size_t)n;
   HIP_TRY(c->d_wire.reserve(wire_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
+  HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n + 16));
   HIP_TRY(c->h_stage_in.reserve(wire_bytes));
   HIP_TRY(c->h_stage_out.reserve(out_bytes));
   memcpy(c->h_stage_in.ptr, wire, wire_bytes);
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, (int16_t*)c->d_out.ptr, c->ext_sc, mq, mr, c->num_cu,
-                            (int*)((char*)c->d_pre.ptr + 128), c->stream));
+  // bin the tasks on the device (which kernel handles which), read the three counts back, launch
+  int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
+  int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
+  const bool use_qt = (int8_t)wire[2] + (int8_t)wire[3] > 0 && ext_qt_enabled();
+  h_counts[0] = h_counts[1] = 0; h_counts[2] = n;
+  if (use_qt) {
+    HIP_TRY(hipMemsetAsync(d_counts, 0, 16, c->stream));
+    launch_ext_bin((const uint32_t*)c->d_wire.ptr, n, (int*)c->d_ext_lists.ptr, d_counts, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+  }
+  HIP_TRY(launch_ext_all((const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, n, (int16_t*)c->d_out.ptr, c->ext_sc, mq, mr, c->num_cu,
+                         (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts, use_qt, c->aux, c->stream));
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->ev[3], c->stream));
@@ -276,14 +307,27 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   HIP_TRY(hipMemsetAsync(d_pre, 0, sizeof(ExtPrepass), s));
   launch_ext_prepass((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, d_pre, s);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h_pre, d_pre, sizeof(ExtPrepass), hipMemcpyDeviceToHost, s));
+  // bin the tasks in the same pass (the lists are only used if the scan finds the batch well formed)
+  int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
+  int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
+  if (12 * (size_t)n_tasks + 16 > c->d_ext_lists.cap) {
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n_tasks + 16));
+  }
+  HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
+  launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (h_pre->error) return fail(BPSW_ERR_ARG, "extend_device: malformed wire batch (code " + std::to_string(h_pre->error) + ")");
   if (h_pre->max_qlen > BPSW_EXT_MAX_QLEN || h_pre->max_rlen > BPSW_EXT_MAX_RLEN)
     return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
   HIP_TRY(hipEventRecord(c->ev[4], s));
-  HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen, h_pre->max_rlen,
-                            c->num_cu, (int*)((char*)c->d_pre.ptr + 128), s));
+  const bool use_qt = h_pre->reserved != 0 && ext_qt_enabled();  // reserved: set by the scan when oIns + eIns > 0
+  if (!use_qt) { h_counts[0] = h_counts[1] = 0; h_counts[2] = n_tasks; }
+  HIP_TRY(launch_ext_all((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen,
+                         h_pre->max_rlen, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts,
+                         use_qt, c->aux, s));
   HIP_TRY(hipEventRecord(c->ev[5], s));
   c->have_ext_ev = true;
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
