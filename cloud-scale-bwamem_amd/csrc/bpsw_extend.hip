@@ -14,6 +14,8 @@
 // 5 x qLen query profile as int8, the unpacked target as bytes.  Row maximum + LAST arg-max
 // (SWUtil.scala:158-161) come from a wave max-reduce + ballot; the band trimming loops
 // (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
+#include <stdlib.h>
+
 #include "bpsw_internal.h"
 #include "bpsw_wave.h"
 
@@ -188,12 +190,25 @@ __device__ __forceinline__ int s_first_one(unsigned long long v) {  // -1 when v
   return r;
 }
 
-// A wave-uniform value deliberately kept in a VGPR: arithmetic on it then runs on the SIMD's vector ALU (2x the
-// issue rate of the one scalar ALU a CU's four SIMDs share).  The asm hides the uniformity from the compiler.
+// Where the wave-uniform row control runs.  Measured on MI355X (tools/microbench_issue.hip, profiles/): a SIMD issues
+// one integer VALU / DPP / v_cmp / v_readlane wave-instruction per ~3.7 cycles and one SALU instruction per ~3.7
+// cycles; mixed streams from several waves reach about one instruction per 2.4 cycles, and once the GPU is saturated
+// the kernel time follows the TOTAL instruction count (1.15 ns x (VALU + SALU) / SIMD), not the split.  Two builds:
+//   BPSW_EXT_VECTOR_CONTROL 1 (default): uniform values kept in VGPRs through an opaque asm -> 355 M VALU + 200 M SALU
+//                                        per 30 k-task batch, 0.713 ms stand-alone
+//   BPSW_EXT_VECTOR_CONTROL 0          : control on the scalar pipe -> 239 M VALU + 323 M SALU, 0.748 ms stand-alone
+// Both give 2.95 ms per bench step when the step's batches overlap on the device.
+#ifndef BPSW_EXT_VECTOR_CONTROL
+#define BPSW_EXT_VECTOR_CONTROL 1
+#endif
 __device__ __forceinline__ int vu(int s) {
+#if BPSW_EXT_VECTOR_CONTROL
   int v;
   asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
   return v;
+#else
+  return s;
+#endif
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
@@ -558,7 +573,8 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   }
   // resident workgroups per CU: 8 waves/SIMD = 8 blocks of 4 waves, capped by LDS
   int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
-  per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+  static const int cap_per_cu = getenv("BPSW_EXT_BLOCKS_PER_CU") ? atoi(getenv("BPSW_EXT_BLOCKS_PER_CU")) : 8;
+  per_cu = per_cu > cap_per_cu ? cap_per_cu : (per_cu < 1 ? 1 : per_cu);
   int blocks = (n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int max_blocks = num_cu * per_cu;
   if (blocks > max_blocks) blocks = max_blocks;

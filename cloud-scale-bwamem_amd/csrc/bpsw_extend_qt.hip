@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_qt_kernel(const uint
 
 // ---- binning: which kernel handles which task ------------------------------------------------------------------
 __global__ void ext_bin_kernel(const uint32_t* __restrict__ wire, const int n_tasks, int* __restrict__ lists,
-                               int* __restrict__ counts) {
+                               int* __restrict__ counts, const int max_qt_side) {
   const int lane = threadIdx.x & 63;
   const int nround = (n_tasks + 63) & ~63;  // every lane of a wave runs the same number of iterations (ballots below)
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nround; t += gridDim.x * blockDim.x) {
@@ -410,7 +410,7 @@ __global__ void ext_bin_kernel(const uint32_t* __restrict__ wire, const int n_ta
       const int lq = lo16(rec[0]), lr = hi16(rec[0]), rq = lo16(rec[1]), rr = hi16(rec[1]);
       const int mq = max(lq, rq), mr = max(lr, rr);
       bin = 2;
-      if (mr <= QT_TS_CAP) bin = mq <= 16 * 4 - 1 ? 0 : (mq <= 16 * 9 - 1 ? 1 : 2);
+      if (mr <= QT_TS_CAP && mq <= max_qt_side) bin = mq <= 16 * 4 - 1 ? 0 : (mq <= 16 * 9 - 1 ? 1 : 2);
     }
 #pragma unroll
     for (int b = 0; b < 3; ++b) {  // one atomic per wave and bin instead of one per task
@@ -430,7 +430,9 @@ void launch_ext_bin(const uint32_t* d_wire, int n_tasks, int* d_lists, int* d_co
   const int threads = 256;
   int blocks = (n_tasks + threads - 1) / threads;
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-  hipLaunchKernelGGL(ext_bin_kernel, dim3(blocks), dim3(threads), 0, s, d_wire, n_tasks, d_lists, d_counts);
+  // BPSW_EXT_QT=2: only sides <= 63 bp go to the quad-task kernel (S = 4); =1: also S = 9
+  static const int max_side = (getenv("BPSW_EXT_QT") && atoi(getenv("BPSW_EXT_QT")) == 2) ? 63 : 143;
+  hipLaunchKernelGGL(ext_bin_kernel, dim3(blocks), dim3(threads), 0, s, d_wire, n_tasks, d_lists, d_counts, max_side);
 }
 
 hipError_t launch_ext_qt_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, const int* d_list, int n_list,
