@@ -36,27 +36,58 @@ HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def build_inputs(rank: int):
     from bpsw_hip import synth, wire_pack
     seed0 = synth.CONFIG_SEED_BASE + 3 + 1000 * rank
-    wires, ntasks = [], []
+    wires, ntasks, soas = [], [], []
     for b in range(EXT_BATCHES_PER_STEP):
         soa = synth.ext_tasks(READS_PER_EXT_BATCH, read_len=READ_LEN, sub_rate=0.01, indel_rate=0.001, n_rate=0.001,
                               seed=seed0 + b)
         wires.append(wire_pack(soa))
+        soas.append(soa)
         ntasks.append(soa.n)
     n_jobs = int(PAIRS_PER_STEP * RESCUE_JOBS_PER_PAIR)
     jobs = synth.sw_jobs(n_jobs, read_len=READ_LEN, win_min=400, win_max=400, sub_rate=0.02, indel_rate=0.002,
                          unrelated_frac=0.05, decoy_frac=0.1, rev_frac=1.0, seed=seed0 + 100)
-    return wires, ntasks, jobs
+    return soas, wires, ntasks, jobs
 
 
-def cpu_baseline(wires, ntasks, jobs, xtra):
-    """The oracle (scalar C restatement of the Scala SW path) on this box's host cores, one thread, on a
-    bounded sample of the same step: the first extension batch and the first 1500 rescue jobs."""
+def cpu_baseline(soas, wires, ntasks, jobs, xtra):
+    """The reference's CPU path timed on this box's host cores, on a bounded sample of the same step.
+
+    kind "reference": oracle/_ref/libbwaref.so (the reference's own C built in place by oracle/Makefile): ksw_extend2 under
+    the extension() control for boundary 2 and the SSE2 ksw_align2 that jniNative.so runs for boundary 1, one whole step
+    per thread on every host core (the reference is one Spark task thread per core).  kind "port": the scalar oracle
+    (oracle/bpsw_oracle.c), one thread, when the reference build did not travel with the snapshot."""
     import pyoracle as po
+    n_jobs = len(jobs["q_len"])
+    if os.path.exists(po.REF_SO):
+        from concurrent.futures import ThreadPoolExecutor
+        ref = po.Ref()
+        mat = po.default_mat()
+        cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+
+        def one_step(_):
+            for soa in soas:
+                ref.extend_batch(soa, mat)
+            ref.align2_batch(mat, 6, 1, 6, 1, xtra, **jobs)
+
+        one = time.perf_counter()
+        one_step(0)
+        one = time.perf_counter() - one
+        reps = max(1, int(round(3.0 / max(one, 1e-3))))          # ~3 s of wall per thread, ~3 s x cores of CPU work
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:                     # ctypes releases the GIL inside the C loops
+            list(ex.map(one_step, range(cores * reps)))
+        dt = time.perf_counter() - t0
+        return {
+            "value": round(cores * reps * 2 * PAIRS_PER_STEP / dt, 1), "unit": "reads/s", "cores": cores, "kind": "reference",
+            "sample": f"{cores * reps} whole steps ({sum(ntasks)} extension tasks + {n_jobs} rescue jobs each) in {dt:.2f}s on "
+                      f"{cores} threads; reference ksw_extend2 (scalar) + ksw_align2 (SSE2) from oracle/_ref; "
+                      f"1 thread alone: {2 * PAIRS_PER_STEP / one:.0f} reads/s",
+        }
     orc = po.Oracle()
     t0 = time.perf_counter()
     _, cells_ext = orc.wire_extend(wires[0])
     t_ext = time.perf_counter() - t0
-    ns = min(1500, len(jobs["q_len"]))
+    ns = min(1500, n_jobs)
     sub = dict(jobs)
     for k in ("q_len", "t_len", "q_off", "t_off", "q_rev"):
         sub[k] = jobs[k][:ns]
@@ -64,7 +95,7 @@ def cpu_baseline(wires, ntasks, jobs, xtra):
     _, cells_sw = orc.sw_align2_jobs(orc.default_opt(), xtra, **sub)
     t_sw = time.perf_counter() - t0
     # seconds of CPU per read of the step = extension share + rescue share
-    sec_per_read = t_ext / READS_PER_EXT_BATCH + (t_sw / ns) * len(jobs["q_len"]) / (2.0 * PAIRS_PER_STEP)
+    sec_per_read = t_ext / READS_PER_EXT_BATCH + (t_sw / ns) * n_jobs / (2.0 * PAIRS_PER_STEP)
     return {
         "value": round(1.0 / sec_per_read, 1), "unit": "reads/s", "cores": 1, "kind": "port",
         "sample": f"{ntasks[0]} extension tasks ({READS_PER_EXT_BATCH} reads) in {t_ext:.2f}s + {ns} SWAlign2 jobs in {t_sw:.2f}s, "
@@ -105,7 +136,7 @@ def main():
     opt = bpsw_hip.default_opt()
     xtra = bpsw_hip.KSW_XSUBO | bpsw_hip.KSW_XSTART | bpsw_hip.KSW_XBYTE | 19   # MemSamPe.scala:1187-1189
 
-    wires, ntasks, jobs = build_inputs(rank)
+    soas, wires, ntasks, jobs = build_inputs(rank)
     # ---- make everything resident in HBM before the timed region ---------------------------------
     d_wires = [torch.from_numpy(w).to(dev) for w in wires]
     d_outs = [torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks]
@@ -189,7 +220,7 @@ def main():
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes)}},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wires, ntasks, jobs, xtra)
+        out["cpu_baseline"] = cpu_baseline(soas, wires, ntasks, jobs, xtra)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -240,6 +240,26 @@ class Ref:
         n = self.lib.mem_sort_and_dedup(C.c_int(a.shape[0]), _vp(a), C.c_float(mask_level_redun))
         return a[:n]
 
+    def extend_batch(self, soa, mat, zdrop=100):
+        """extension() control (MemChainToAlignBatched.scala:789-883) around the reference ksw_extend2, looped in C"""
+        m = np.ascontiguousarray(mat, np.int8)
+        out = np.zeros((soa.n, 7), np.int32)
+        self.lib.ref_extend_batch(C.c_int(soa.n), _vp(soa.left_qlen), _vp(soa.left_rlen), _vp(soa.right_qlen), _vp(soa.right_rlen),
+                                  _vp(soa.left_q_off), _vp(soa.left_r_off), _vp(soa.right_q_off), _vp(soa.right_r_off),
+                                  _vp(soa.reg_score), _vp(soa.q_beg), _vp(soa.h0), _vp(soa.pool), _vp(m), soa.o_del, soa.e_del,
+                                  soa.o_ins, soa.e_ins, soa.w, soa.pen_clip5, soa.pen_clip3, zdrop, _vp(out))
+        return out
+
+    def align2_batch(self, mat, o_del, e_del, o_ins, e_ins, xtra, q_len, t_len, q_off, t_off, q_rev, q_pool, t_pool):
+        """ksw_align2 (the SSE2 kernels jniNative.so runs) over SoA jobs, looped in C"""
+        m = np.ascontiguousarray(mat, np.int8)
+        n = len(q_len)
+        out = np.zeros((n, 7), np.int32)
+        a = [np.ascontiguousarray(x, dt) for x, dt in ((q_len, np.int32), (t_len, np.int32), (q_off, np.int64), (t_off, np.int64),
+                                                      (q_rev, np.uint8), (q_pool, np.uint8), (t_pool, np.uint8))]
+        self.lib.ref_align2_batch(C.c_int(n), *[_vp(x) for x in a], _vp(m), o_del, e_del, o_ins, e_ins, C.c_int(xtra), _vp(out))
+        return out
+
     def matesw_group(self, opt: Opt, g):
         ints = np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_unpaired, opt.pen_clip5,
                          opt.pen_clip3, opt.w, opt.zdrop, opt.T, opt.flag, opt.min_seed_len, opt.max_ins,

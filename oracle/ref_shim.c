@@ -111,3 +111,62 @@ int64_t ref_group_matesw_flat(const int32_t ints[16], float mask_level_redun, co
   free(refs); free(vec); free(seqs); free(seq_len_pairs); free(o);
   return overflow ? -total : total;
 }
+
+/* ---- batch drivers for the CPU baseline (bench.py): loops in C so the timing is the reference kernels', not ctypes ---- */
+#include "ksw.h"
+
+/* The extension() control of MemChainToAlignBatched.scala:789-883 around the reference's ksw_extend2
+ * (native/ksw.c:379-476), over SoA tasks (bytes per base).  out: 7 ints per task (qBeg,qEnd,rBeg,rEnd,score,trueScore,width). */
+void ref_extend_batch(int n, const int32_t *lq, const int32_t *lr, const int32_t *rq, const int32_t *rr, const int64_t *lq_off,
+                      const int64_t *lr_off, const int64_t *rq_off, const int64_t *rr_off, const int32_t *reg_score,
+                      const int32_t *q_beg, const int32_t *h0, const uint8_t *pool, const int8_t mat[25], int o_del, int e_del,
+                      int o_ins, int e_ins, int w, int pen_clip5, int pen_clip3, int zdrop, int32_t *out) {
+  for (int t = 0; t < n; ++t) {
+    int aw0 = w, aw1 = w, score = reg_score[t], qle = -1, tle = -1, gtle = -1, gscore = -1, maxoff = -1, prev;
+    int32_t *o = out + 7 * (size_t)t;
+    o[0] = 0; o[1] = rq[t]; o[2] = 0; o[3] = 0; o[4] = -1; o[5] = reg_score[t]; o[6] = w;
+    if (lq[t] > 0) {
+      for (int i = 0; i < 2; ++i) {
+        prev = score; aw0 = w << i;
+        score = ksw_extend2(lq[t], pool + lq_off[t], lr[t], pool + lr_off[t], 5, mat, o_del, e_del, o_ins, e_ins, aw0, pen_clip5,
+                            zdrop, h0[t], &qle, &tle, &gtle, &gscore, &maxoff);
+        if (score == prev || maxoff < (aw0 >> 1) + (aw0 >> 2)) break;
+      }
+      o[4] = score;
+      if (gscore <= 0 || gscore <= score - pen_clip5) { o[0] = q_beg[t] - qle; o[2] = -tle; o[5] = score; }
+      else { o[0] = 0; o[2] = -gtle; o[5] = gscore; }
+    }
+    if (rq[t] > 0) {
+      const int sc0 = score;
+      for (int i = 0; i < 2; ++i) {
+        prev = score; aw1 = w << i;
+        score = ksw_extend2(rq[t], pool + rq_off[t], rr[t], pool + rr_off[t], 5, mat, o_del, e_del, o_ins, e_ins, aw1, pen_clip3,
+                            zdrop, sc0, &qle, &tle, &gtle, &gscore, &maxoff);
+        if (score == prev || maxoff < (aw1 >> 1) + (aw1 >> 2)) break;
+      }
+      o[4] = score;
+      if (gscore <= 0 || gscore <= score - pen_clip3) { o[1] = qle; o[3] = tle; o[5] += score - sc0; }
+      else { o[1] = rq[t]; o[3] = gtle; o[5] += gscore - sc0; }
+    }
+    o[6] = aw0 > aw1 ? aw0 : aw1;
+  }
+}
+
+/* ksw_align2 (native/ksw.c:342-364; the SSE2 u8/i16 kernels jniNative.so runs) over SoA jobs.  out: 7 ints per job. */
+void ref_align2_batch(int n, const int32_t *q_len, const int32_t *t_len, const int64_t *q_off, const int64_t *t_off,
+                      const uint8_t *q_rev, const uint8_t *q_pool, const uint8_t *t_pool, const int8_t mat[25], int o_del,
+                      int e_del, int o_ins, int e_ins, int xtra, int32_t *out) {
+  uint8_t *q = (uint8_t *)malloc(65536), *t = (uint8_t *)malloc(1 << 20);
+  for (int j = 0; j < n; ++j) {
+    const int ql = q_len[j], tl = t_len[j];
+    for (int i = 0; i < ql; ++i) {
+      const uint8_t c = q_pool[q_off[j] + (q_rev[j] ? ql - 1 - i : i)];
+      q[i] = q_rev[j] ? (c < 4 ? 3 - c : 4) : c;
+    }
+    memcpy(t, t_pool + t_off[j], (size_t)tl); /* ksw_align2 reverses its inputs in place */
+    kswr_t r = ksw_align2(ql, q, tl, t, 5, mat, o_del, e_del, o_ins, e_ins, xtra, 0);
+    int32_t *o = out + 7 * (size_t)j;
+    o[0] = r.score; o[1] = r.te; o[2] = r.qe; o[3] = r.score2; o[4] = r.te2; o[5] = r.tb; o[6] = r.qb;
+  }
+  free(q); free(t);
+}
