@@ -152,11 +152,23 @@ def main():
 
     ext_ms_sum, sw_ms_sum, ext_launches, sw_launches = 0.0, 0.0, 0, 0
 
+    pool = None
+    if os.environ.get("BENCH_THREADS"):
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(EXT_BATCHES_PER_STEP + 1)
+
     def step(timed: bool):
         nonlocal ext_ms_sum, sw_ms_sum, ext_launches, sw_launches
-        for cx, w, n, dw, do in zip(ctxs, wires, ntasks, d_wires, d_outs):
-            cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)   # asynchronous, context's own stream
-        ctx.swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
+        if pool is not None:
+            futs = [pool.submit(cx.extend_batch_device, dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)
+                    for cx, w, n, dw, do in zip(ctxs, wires, ntasks, d_wires, d_outs)]
+            futs.append(pool.submit(ctx.swalign2_batch_device, opt, sj, d_sw_out.data_ptr(), 0))
+            for f in futs:
+                f.result()
+        else:
+            for cx, w, n, dw, do in zip(ctxs, wires, ntasks, d_wires, d_outs):
+                cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)   # asynchronous, context's own stream
+            ctx.swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
         for cx in ctxs[:-1]:
             e, _ = cx.last_kernel_ms()      # HIP events on the launch stream, recorded inside the library; waits for the batch
             if timed:
@@ -188,6 +200,26 @@ def main():
     reads_total = 2 * PAIRS_PER_STEP * args.steps * world
     value = reads_total / elapsed
 
+    # ---- the two boundaries on their own (outside the timed region of `value`) ------
+    def time_only(fn, reps):
+        fn()
+        barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        return (time.perf_counter() - t) / reps
+
+    def ext_only():
+        for cx, w, n, dw, do in zip(ctxs, wires, ntasks, d_wires, d_outs):
+            cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)
+
+    def sw_only():
+        ctx.swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
+
+    reps = max(3, min(args.steps, 10))
+    t_ext_only, t_sw_only = time_only(ext_only, reps), time_only(sw_only, reps)
+
     # ---- roofline of the dominant kernel (algorithmic bytes: DESIGN.md) -------------
     ext_bytes = sum(int(w.size) + 20 * n for w, n in zip(wires, ntasks)) / len(wires)          # per launch
     sw_bytes = float(jobs["q_len"].sum() + jobs["t_len"].sum() + 28 * n_jobs)                  # per launch
@@ -218,6 +250,9 @@ def main():
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
         "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes)},
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes)}},
+        "breakdown": {"extend_only_reads_per_s": round(2 * PAIRS_PER_STEP / t_ext_only, 1), "extend_only_ms_per_step": round(1e3 * t_ext_only, 3),
+                      "rescue_only_jobs_per_s": round(n_jobs / t_sw_only, 1), "rescue_only_ms_per_step": round(1e3 * t_sw_only, 3),
+                      "note": "this rank only; same resident inputs, each boundary alone (SURVEY.md 8d i/ii); `value` is (iii) combined"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(soas, wires, ntasks, jobs, xtra)

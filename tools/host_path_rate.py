@@ -27,19 +27,25 @@ s1 = ctx.stats()
 out["extend_host_entry"] = {"reads_per_s": 32768 * R / dt, "tasks": soa.n, "wire_bytes": int(wire.size), "ms_per_call": 1e3 * dt / R,
                             "h2d_ms": (s1.ext_h2d_ms - s0.ext_h2d_ms) / R, "kernel_ms": (s1.ext_kernel_ms - s0.ext_kernel_ms) / R,
                             "d2h_ms": (s1.ext_d2h_ms - s0.ext_d2h_ms) / R}
-for pairs in (4096, 16384):
-    g = synth.rescue_group(pairs, seed=synth.CONFIG_SEED_BASE + 3, p_resc=0.10)
+for pairs in (10, 256, 4096, 16384):
+    # -sbatch 10 is the reference default (commandline/BWAMEMCommand.scala:28): most calls then carry 0-2 SW jobs,
+    # so average over many different groups
+    ngroups = 40 if pairs <= 256 else 1
+    groups = [synth.rescue_group(pairs, seed=synth.CONFIG_SEED_BASE + 3 + 17 * k, p_resc=0.10) for k in range(ngroups)]
     opt = bpsw_hip.default_opt()
-    ctx.matesw_group(opt, g)
-    s0 = ctx.stats()
-    t0 = time.perf_counter()
-    R = 5
-    for _ in range(R):
+    for g in groups:
         ctx.matesw_group(opt, g)
+    s0 = ctx.stats()
+    R = 5
+    t0 = time.perf_counter()
+    for _ in range(R):
+        for g in groups:
+            ctx.matesw_group(opt, g)
     dt = time.perf_counter() - t0
     s1 = ctx.stats()
-    out[f"matesw_group_{pairs}_pairs"] = {"pairs_per_s": pairs * R / dt, "ms_per_call": 1e3 * dt / R,
-                                          "sw_jobs_per_call": (s1.sw_jobs - s0.sw_jobs) / R, "kernel_ms": (s1.sw_kernel_ms - s0.sw_kernel_ms) / R,
-                                          "h2d_ms": (s1.sw_h2d_ms - s0.sw_h2d_ms) / R, "replay_rounds": int(s1.sw_replayed_rounds - s0.sw_replayed_rounds),
+    calls = R * ngroups
+    out[f"matesw_group_{pairs}_pairs"] = {"pairs_per_s": pairs * calls / dt, "ms_per_call": 1e3 * dt / calls,
+                                          "sw_jobs_per_call": (s1.sw_jobs - s0.sw_jobs) / calls, "kernel_ms": (s1.sw_kernel_ms - s0.sw_kernel_ms) / calls,
+                                          "h2d_ms": (s1.sw_h2d_ms - s0.sw_h2d_ms) / calls, "replay_rounds": int(s1.sw_replayed_rounds - s0.sw_replayed_rounds),
                                           "wasted_jobs": int(s1.sw_wasted - s0.sw_wasted)}
 print(json.dumps(out, indent=1))
