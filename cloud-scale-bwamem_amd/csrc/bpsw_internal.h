@@ -65,6 +65,15 @@ hipError_t launch_ext_all(const uint32_t* d_wire, size_t wire_words, int n_tasks
                           int qcap, int rcap, int num_cu, int* d_counters, const int* d_lists, const int h_counts[3],
                           bool use_qt, const ExtStreams& aux, hipStream_t s);
 
+// Lane-per-task kernel (bpsw_extend_lane.hip): 64 tasks per wavefront.
+// Sort: d_counts[0] = tasks in d_lane_list (ordered by left query length), [1] = tasks in d_fb_list (for ext_kernel),
+// [2] = longest side among lane tasks, [3] = largest leftQlen + rightQlen.  One workgroup; d_counts need not be zeroed.
+void launch_ext_lane_sort(const uint32_t* d_wire, int n_tasks, int mat_max, int* d_lane_list, int* d_fb_list, int* d_counts,
+                          hipStream_t s);
+size_t ext_lane_lds_bytes(int max_side, int max_qsum);
+hipError_t launch_ext_lane_kernel(const uint32_t* d_wire, const int* d_list, int n_list, int16_t* d_out, const ExtScoring& sc,
+                                  int max_side, int max_qsum, hipStream_t s);
+
 // ---- local SW (boundary 1) ---------------------------------------------------------------------
 struct SwScoring {
   MatRows mat;

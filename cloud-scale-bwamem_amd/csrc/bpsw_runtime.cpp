@@ -208,6 +208,28 @@ static bool ext_qt_enabled() {
   return on;
 }
 
+// BPSW_EXT_MODE=lane: the lane-per-task kernel (bpsw_extend_lane.hip) takes every task that fits it.
+static bool ext_lane_enabled() {
+  static const bool on = getenv("BPSW_EXT_MODE") && std::string(getenv("BPSW_EXT_MODE")) == "lane";
+  return on;
+}
+
+// Lane-per-task path: enqueue the sort (its four counts land in d_pre + 64), and, once the caller has read them back,
+// the launches.
+static void lane_sort_enqueue(bpsw_ctx_t* c, const uint32_t* d_wire, int n, hipStream_t s) {
+  int* lane_list = (int*)c->d_ext_lists.ptr;
+  launch_ext_lane_sort(d_wire, n, c->ext_sc.mat_max, lane_list, lane_list + n, (int*)((char*)c->d_pre.ptr + 64), s);
+}
+static int lane_launch(bpsw_ctx_t* c, const uint32_t* d_wire, int n, int16_t* d_out, int mq, int mr, const int h_counts[4],
+                       hipStream_t s) {
+  const int* lane_list = (const int*)c->d_ext_lists.ptr;
+  HIP_TRY(launch_ext_lane_kernel(d_wire, lane_list, h_counts[0], d_out, c->ext_sc, h_counts[2], h_counts[3], s));
+  if (h_counts[1] > 0)
+    HIP_TRY(launch_ext_kernel(d_wire, h_counts[1], d_out, c->ext_sc, mq, mr, c->num_cu, (int*)((char*)c->d_pre.ptr + 128),
+                              lane_list + n, s));
+  return BPSW_OK;
+}
+
 // ------------------------------------------------------------------------------------- boundary 2
 static inline int rd16(const uint8_t* b, size_t at) { return (int16_t)(b[at] | (b[at + 1] << 8)); }
 static inline int rd32(const uint8_t* b, size_t at) {
@@ -263,8 +285,18 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
   // bin the tasks on the device (which kernel handles which), read the three counts back, launch
   int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
   int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
-  const bool use_qt = (int8_t)wire[2] + (int8_t)wire[3] > 0 && ext_qt_enabled();
+  const bool use_lane = ext_lane_enabled();
+  const bool use_qt = !use_lane && (int8_t)wire[2] + (int8_t)wire[3] > 0 && ext_qt_enabled();
   h_counts[0] = h_counts[1] = 0; h_counts[2] = n;
+  if (use_lane) {
+    lane_sort_enqueue(c, (const uint32_t*)c->d_wire.ptr, n, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    rc = lane_launch(c, (const uint32_t*)c->d_wire.ptr, n, (int16_t*)c->d_out.ptr, mq, mr, h_counts, c->stream);
+    if (rc != BPSW_OK) return rc;
+  }
   if (use_qt) {
     HIP_TRY(hipMemsetAsync(d_counts, 0, 16, c->stream));
     launch_ext_bin((const uint32_t*)c->d_wire.ptr, n, (int*)c->d_ext_lists.ptr, d_counts, c->stream);
@@ -273,8 +305,9 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
   }
-  HIP_TRY(launch_ext_all((const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, n, (int16_t*)c->d_out.ptr, c->ext_sc, mq, mr, c->num_cu,
-                         (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts, use_qt, c->aux, c->stream));
+  if (!use_lane)
+    HIP_TRY(launch_ext_all((const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, n, (int16_t*)c->d_out.ptr, c->ext_sc, mq, mr, c->num_cu,
+                           (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts, use_qt, c->aux, c->stream));
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->ev[3], c->stream));
@@ -315,7 +348,8 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
     HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n_tasks + 16));
   }
   HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
-  launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
+  if (ext_lane_enabled()) lane_sort_enqueue(c, (const uint32_t*)d_wire, n_tasks, s);
+  else launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -323,6 +357,14 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   if (h_pre->max_qlen > BPSW_EXT_MAX_QLEN || h_pre->max_rlen > BPSW_EXT_MAX_RLEN)
     return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
   HIP_TRY(hipEventRecord(c->ev[4], s));
+  if (ext_lane_enabled()) {
+    int rc = lane_launch(c, (const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, h_pre->max_qlen, h_pre->max_rlen, h_counts, s);
+    if (rc != BPSW_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev[5], s));
+    c->have_ext_ev = true;
+    c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
+    return BPSW_OK;
+  }
   const bool use_qt = h_pre->reserved != 0 && ext_qt_enabled();  // reserved: set by the scan when oIns + eIns > 0
   if (!use_qt) { h_counts[0] = h_counts[1] = 0; h_counts[2] = n_tasks; }
   HIP_TRY(launch_ext_all((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen,

@@ -1,0 +1,23 @@
+"""The opt-in lane-per-task extension kernel (BPSW_EXT_MODE=lane, csrc/bpsw_extend_lane.hip: 64 tasks per wavefront,
+tasks sorted on the device, misfits routed to ext_kernel) must stay bit-exact too: the extension and golden parity
+tests are re-run in a subprocess with the switch on (the switch is read once per process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_extension_parity_with_lane_per_task_kernel():
+    if os.environ.get("BPSW_EXT_MODE") == "lane":
+        pytest.skip("already running with BPSW_EXT_MODE=lane")
+    env = dict(os.environ, BPSW_EXT_MODE="lane")
+    env.pop("BPSW_EXT_QT", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(HERE, "test_extend_gpu.py"),
+                        os.path.join(HERE, "test_golden_gpu.py"), os.path.join(HERE, "test_jni_shim.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
