@@ -28,11 +28,13 @@ ABI_SYMBOLS = [
     "bpsw_set_ext_scoring", "bpsw_extend_batch", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
+    "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch",
 ]
 JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI",
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI",
     "Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld",
+    "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI",   # new entry for SURVEY.md 8f.2
 ]
 
 
@@ -142,6 +144,11 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.bpsw_reset_stats.argtypes = [C.c_void_p]
     lib.bpsw_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.bpsw_ref_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.bpsw_ref_unload.argtypes = [C.c_void_p]
+    lib.bpsw_ref_length.argtypes = [C.c_void_p]
+    lib.bpsw_ref_length.restype = C.c_int64
+    lib.bpsw_ref_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -272,17 +279,19 @@ class Context:
 
     # boundary 1 ------------------------------------------------------------------------------
     def swalign2_batch(self, opt: Opt, xtra: int, q_len, t_len, q_off, t_off, q_rev, q_pool, t_pool) -> np.ndarray:
+        """t_pool=None: t_off/t_len name windows of the reference loaded with ref_load (doubled coordinates)"""
         j = SwJobs()
         arrs = dict(q_len=np.ascontiguousarray(q_len, np.int32), t_len=np.ascontiguousarray(t_len, np.int32),
                     q_off=np.ascontiguousarray(q_off, np.int64), t_off=np.ascontiguousarray(t_off, np.int64),
-                    q_rev=np.ascontiguousarray(q_rev, np.uint8), q_pool=np.ascontiguousarray(q_pool, np.uint8),
-                    t_pool=np.ascontiguousarray(t_pool, np.uint8))
+                    q_rev=np.ascontiguousarray(q_rev, np.uint8), q_pool=np.ascontiguousarray(q_pool, np.uint8))
+        if t_pool is not None:
+            arrs["t_pool"] = np.ascontiguousarray(t_pool, np.uint8)
         j.n = int(arrs["q_len"].shape[0])
         j.xtra = int(xtra)
         for k, a in arrs.items():
             setattr(j, k, a.ctypes.data)
         j.q_pool_bytes = arrs["q_pool"].size
-        j.t_pool_bytes = arrs["t_pool"].size
+        j.t_pool_bytes = arrs["t_pool"].size if t_pool is not None else 0
         out = np.zeros((max(j.n, 1), 7), dtype=np.int32)
         _chk(self.lib, self.lib.bpsw_swalign2_batch(self.h, C.byref(opt), C.byref(j), _ptr(out)), "bpsw_swalign2_batch")
         return out[: j.n]
@@ -319,6 +328,35 @@ class Context:
                                                  C.byref(total)), "bpsw_matesw_group")
         return out_cnt, out[: total.value]
 
+    # reference resident on the device --------------------------------------------
+    def ref_load(self, pac: np.ndarray, l_pac: int):
+        pac = np.ascontiguousarray(pac, np.uint8)
+        if pac.size < (int(l_pac) + 3) // 4:
+            raise BpswError("pac shorter than (l_pac+3)/4 bytes")
+        _chk(self.lib, self.lib.bpsw_ref_load(self.h, _ptr(pac), int(l_pac)), "bpsw_ref_load")
+
+    def ref_unload(self):
+        _chk(self.lib, self.lib.bpsw_ref_unload(self.h), "bpsw_ref_unload")
+
+    def ref_length(self) -> int:
+        return int(self.lib.bpsw_ref_length(self.h))
+
+    def ref_fetch(self, beg, end):
+        """bnsGetSeq for n windows -> (list of uint8 arrays, lengths)"""
+        beg = np.ascontiguousarray(beg, np.int64)
+        end = np.ascontiguousarray(end, np.int64)
+        n = int(beg.shape[0])
+        span = np.abs(end - beg) + 16
+        off = np.zeros(n, np.int64)
+        if n > 1:
+            off[1:] = np.cumsum((span[:-1] + 15) & ~15)
+        total = int(off[-1] + span[-1]) if n else 0
+        pool = np.zeros(max(total, 16), np.uint8)
+        lens = np.zeros(max(n, 1), np.int64)
+        _chk(self.lib, self.lib.bpsw_ref_fetch(self.h, n, _ptr(beg), _ptr(end), _ptr(pool), pool.size, _ptr(off), _ptr(lens)),
+             "bpsw_ref_fetch")
+        return [pool[off[i]: off[i] + lens[i]].copy() for i in range(n)], lens[:n]
+
     def stats(self) -> Stats:
         s = Stats()
         _chk(self.lib, self.lib.bpsw_get_stats(self.h, C.byref(s)), "bpsw_get_stats")
@@ -346,7 +384,7 @@ class RescueGroupSoA:
     ref_re: np.ndarray
     ref_len: np.ndarray
     ref_off: np.ndarray
-    ref_pool: np.ndarray
+    ref_pool: np.ndarray | None  # None: windows are (ref_rb, ref_re) coordinates of the reference loaded with ref_load
 
     def as_struct(self) -> RescueGroup:
         g = RescueGroup()
@@ -359,10 +397,12 @@ class RescueGroupSoA:
                       ("ref_cnt", np.int32), ("ref_rb", np.int64), ("ref_re", np.int64), ("ref_len", np.int64),
                       ("ref_off", np.int64), ("ref_pool", np.uint8)):
             a = getattr(self, f)
+            if a is None and f in ("ref_pool", "ref_len", "ref_off"):
+                continue  # coordinate mode
             assert a.dtype == dt and a.flags.c_contiguous, f
             setattr(g, f, a.ctypes.data)
         assert self.regs.dtype == ALNREG_DTYPE
         g.regs = self.regs.ctypes.data
         g.seq_pool_bytes = self.seq_pool.size
-        g.ref_pool_bytes = self.ref_pool.size
+        g.ref_pool_bytes = self.ref_pool.size if self.ref_pool is not None else 0
         return g

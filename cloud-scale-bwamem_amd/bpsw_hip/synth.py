@@ -123,13 +123,37 @@ def _mutate(rng, seq: np.ndarray, sub: float, indel: float) -> np.ndarray:
     return np.array(out[:L], dtype=np.uint8)
 
 
+def random_pac(l_pac: int, seed: int = CONFIG_SEED_BASE + 77):
+    """A 2-bit packed i.i.d. reference in BWA's .pac layout: base k = pac[k>>2] >> ((~k&3)<<1) & 3"""
+    rng = np.random.default_rng(seed)
+    bases = rng.integers(0, 4, l_pac).astype(np.uint8)
+    padded = np.zeros(((l_pac + 3) // 4) * 4, np.uint8)
+    padded[:l_pac] = bases
+    q = padded.reshape(-1, 4)
+    pac = ((q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]).astype(np.uint8)
+    return pac, bases
+
+
+def window_bases(bases: np.ndarray, l_pac: int, rb: int, re: int) -> np.ndarray:
+    """bnsGetSeq on unpacked forward bases (data generation only): empty when the window bridges the strands"""
+    rb, re = max(rb, 0), min(re, 2 * l_pac)
+    if re <= rb or not (rb >= l_pac or re <= l_pac):
+        return np.zeros(0, np.uint8)
+    if rb >= l_pac:
+        return (3 - bases[2 * l_pac - re: 2 * l_pac - rb])[::-1].astype(np.uint8)
+    return bases[rb:re].copy()
+
+
 def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE + 3, l_pac: int = 46_709_983,
                  p_resc: float = 0.10, all_orientations: bool = False, sub_rate: float = 0.02, indel_rate: float = 0.002,
-                 p_multi_anchor: float = 0.10, p_wrong_mate: float = 0.05, max_matesw: int = 100, pen_unpaired: int = 17):
+                 p_multi_anchor: float = 0.10, p_wrong_mate: float = 0.05, max_matesw: int = 100, pen_unpaired: int = 17,
+                 ref_bases: np.ndarray | None = None):
     """Synthetic pair-end group (FR library, insert ~ N(400, 50^2)) in the flat layout of include/bpsw.h.
 
     Each pair has an anchor on one end; with probability p_resc the mate has no consistent hit, so the
     reference's mem_matesw would run SWAlign2 on the rescue window (which contains the mutated mate).
+    With ref_bases (the unpacked forward strand of a reference of length l_pac) reads and windows are cut from that
+    reference, so the same group can be submitted with bytes or, after ref_load, with coordinates only.
     """
     from . import RescueGroupSoA, ALNREG_DTYPE
     rng = np.random.default_rng(seed)
@@ -177,6 +201,8 @@ def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE
         P = int(rng.integers(2000, l_pac - 3000))
         ins = int(np.clip(rng.normal(avg, std), low + 20, high - 20))
         clean = [rng.integers(0, 4, L).astype(np.uint8), rng.integers(0, 4, L).astype(np.uint8)]  # forward-strand loci
+        if ref_bases is not None:
+            clean = [ref_bases[P:P + L].copy(), ref_bases[P + ins - L:P + ins].copy()]
         reads = [_mutate(rng, clean[0], sub_rate, indel_rate), _revcomp(_mutate(rng, clean[1], sub_rate, indel_rate))]
         true_rb = [P, 2 * l_pac - (P + ins)]  # end 0 forward at P; end 1 on the reverse strand
         u = rng.random()
@@ -209,9 +235,13 @@ def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE
                         ref_rb.append(-1); ref_re.append(-1); ref_len.append(0); ref_off.append(0)
                         continue
                     n = max(re - rb, 0)
-                    w = rng.integers(0, 4, n).astype(np.uint8)
+                    if ref_bases is not None:
+                        w = window_bases(ref_bases, l_pac, rb, re)
+                        n = len(w)  # 0 when the window bridges the strands (then len != re - rb: the window is skipped)
+                    else:
+                        w = rng.integers(0, 4, n).astype(np.uint8)
                     # where the mate truly lies in this window (only for the FR orientation of a true anchor)
-                    if r == 1 and abs(a[0] - true_rb[i]) < 8 and n >= L:
+                    if ref_bases is None and r == 1 and abs(a[0] - true_rb[i]) < 8 and n >= L:
                         off = (true_rb[i] + ins - L) - rb if i == 0 else (true_rb[i] + ins - L) - rb
                         # window is on the anchor's strand; the mate lies `ins - L` past the anchor start
                         off = (a[0] - rb) + (ins - L) + (true_rb[i] - a[0])

@@ -89,7 +89,9 @@ struct SwJobsDev {  // all device pointers
   const int64_t* t_off;
   const uint8_t* q_rev;
   const uint8_t* q_pool;
-  const uint8_t* t_pool;
+  const uint8_t* t_pool;          // nullptr: windows are coordinates (t_off) into the 2-bit reference below
+  const uint8_t* pac = nullptr;
+  long long l_pac = 0;
 };
 
 struct SwPrepass {
@@ -99,6 +101,9 @@ struct SwPrepass {
   int reserved;
 };
 void launch_sw_prepass(const SwJobsDev& jobs, size_t q_pool_bytes, size_t t_pool_bytes, SwPrepass* d_pre, hipStream_t s);
+void launch_ref_fetch(const uint8_t* d_pac, long long l_pac, int n, const long long* d_beg, const long long* d_end,
+                      uint8_t* d_out_pool, size_t out_pool_bytes, const long long* d_out_off, long long* d_out_len,
+                      int* d_error, hipStream_t s);
 size_t sw_scratch_bytes_per_wave(int max_tlen);
 int sw_resident_waves(int num_cu);
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
@@ -145,6 +150,17 @@ struct PinnedBuffer {
   void release();
 };
 
+// The 2-bit reference (bpsw_ref_load) is shared by every context of a device: the JNI shim keeps one context per
+// Spark task thread, and 20 copies of a 0.8 GB genome would be pointless.
+struct DeviceRef {
+  std::mutex mu;
+  DeviceBuffer buf;
+  long long l_pac = 0;
+};
+DeviceRef& device_ref(int device);
+// snapshot of the reference loaded on c's device (l_pac == 0: none)
+void ref_snapshot(const bpsw_ctx* c, const uint8_t** pac, long long* l_pac);
+
 // runs SWAlign2 jobs whose arrays live in host memory; used by bpsw_swalign2_batch and the rescue layer.
 // Caller holds ctx->mu and has set the device.
 int run_sw_jobs_host(bpsw_ctx* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* jobs, int32_t* out);
@@ -162,6 +178,7 @@ struct bpsw_ctx {
   int8_t ext_mat[25];
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
   bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
+
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
   bpsw_stats_t stats;
   float last_ext_ms = 0.f, last_sw_ms = 0.f;

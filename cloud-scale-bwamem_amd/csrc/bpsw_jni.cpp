@@ -4,6 +4,10 @@
 //   Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI  replaces jni_fpga/sw_extend_fpga.c:116-193
 //   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI              replaces native/jni_mate_sw.c:58-662
 //   Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld            replaces native/jni_hello_world.c:23-26
+//   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI             NEW (needs one line of Scala, see
+//                                                                  INTEGRATION.md): puts the 2-bit reference on every
+//                                                                  visible device; mateSWJNI then accepts RefSWType
+//                                                                  objects whose ref0..ref3 are null (coordinates only)
 //
 // Differences from the reference glue that a JVM can observe: nothing is printed, the JVM is never
 // exit()ed or assert()ed, a device failure surfaces as a java.lang.RuntimeException (Spark retries the
@@ -250,6 +254,7 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
     for (jsize s = 0; s < n; ++s) regs[(size_t)at[(size_t)where[(size_t)s]]++] = tmp[(size_t)s];
   }
   std::vector<int64_t> ref_rb, ref_re, ref_len, ref_off;
+  size_t coord_windows = 0, byte_windows = 0;
   {  // ---- refSizeArray + RefSWType[] (native/jni_mate_sw.c:352-518) ----
     if (jni::GetArrayLength(env, refSizeArr) < (jsize)ends) { throw_runtime(env, "bPSW: mateSWJNI: refSizeArray too short"); return nullptr; }
     if (ends) jni::GetIntArrayRegion(env, refSizeArr, 0, (jsize)ends, ref_cnt.data());
@@ -284,8 +289,11 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       jni::GetLongArrayRegion(env, ae, 0, 4, (jlong*)&ref_re[x]);
       jni::GetLongArrayRegion(env, al, 0, 4, (jlong*)&ref_len[x]);
       for (int r = 0; r < 4; ++r) {
-        if (ref_len[x + r] <= 0) continue;  // failed orientation: len=0, ref=null (MemSamPe.scala:1863-1868)
+        if (ref_rb[x + r] < 0 && ref_re[x + r] < 0) continue;  // failed orientation: rBeg=rEnd=-1, ref=null (MemSamPe.scala:1863-1868)
         jbyteArray bytes = (jbyteArray)jni::GetObjectField(env, o, rRef[r]);
+        if (!bytes && ref_len[x + r] != 0) { ++coord_windows; continue; }  // named by (rBeg, rEnd) only: read from the device-resident reference
+        ++byte_windows;
+        if (ref_len[x + r] <= 0) continue;          // bnsGetSeq returned nothing (window bridging the strands)
         int32_t got = 0;
         read_bytes(env, bytes, ref_pool, &ref_off[x + r], &got);
         if (got < ref_len[x + r]) { jni::PopLocalFrame(env, nullptr); throw_runtime(env, "bPSW: mateSWJNI: reference window shorter than lenArray"); return nullptr; }
@@ -299,6 +307,10 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
   g.reg_cnt = reg_cnt.data(); g.regs = regs.data(); g.ref_cnt = ref_cnt.data();
   g.ref_rb = ref_rb.data(); g.ref_re = ref_re.data(); g.ref_len = ref_len.data(); g.ref_off = ref_off.data();
   g.ref_pool = ref_pool.data(); g.ref_pool_bytes = ref_pool.size();
+  if (coord_windows > 0) {
+    if (byte_windows > 0) { throw_runtime(env, "bPSW: mateSWJNI: RefSWType windows must all carry bytes or all be coordinates"); return nullptr; }
+    g.ref_pool = nullptr; g.ref_pool_bytes = 0; g.ref_len = nullptr; g.ref_off = nullptr;
+  }
 
   bpsw_ctx_t* ctx = thread_context(env);
   if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
@@ -337,6 +349,29 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       jni::PopLocalFrame(env, nullptr);
     }
   return ret;
+}
+
+// ---- reference on the device -------------------------------------------------------------
+// Scala side (one line in jni/MateSWJNI.scala):  @native def loadPacJNI(pac: Array[Byte], pacLen: Long): Int
+// Call once per executor JVM before the first mateSWJNI; returns the number of devices that now hold the reference.
+JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI(JNIEnv* env, jobject, jbyteArray pacArr, jlong pacLen) {
+  if (!pacArr || pacLen < 1) { throw_runtime(env, "bPSW: loadPacJNI: bad arguments"); return 0; }
+  const jsize bytes = jni::GetArrayLength(env, pacArr);
+  if ((int64_t)bytes < (pacLen + 3) / 4) { throw_runtime(env, "bPSW: loadPacJNI: pac shorter than (pacLen+3)/4 bytes"); return 0; }
+  std::vector<uint8_t> pac((size_t)bytes);
+  jni::GetByteArrayRegion(env, pacArr, 0, bytes, reinterpret_cast<jbyte*>(pac.data()));
+  const int ndev = bpsw_device_count();
+  if (ndev <= 0) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return 0; }
+  int loaded = 0;
+  for (int d = 0; d < ndev; ++d) {  // any task thread may land on any device (partition -> device)
+    bpsw_ctx_t* c = nullptr;
+    int rc = bpsw_create(d, &c);
+    if (rc == BPSW_OK) rc = bpsw_ref_load(c, pac.data(), pacLen);
+    if (c) bpsw_destroy(c);
+    if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: loadPacJNI: ") + bpsw_last_error()); return loaded; }
+    ++loaded;
+  }
+  return loaded;
 }
 
 }  // extern "C"

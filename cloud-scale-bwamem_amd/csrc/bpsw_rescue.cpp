@@ -165,6 +165,7 @@ struct Group {
   std::vector<int32_t> job_of;              // per window x: job index, -1 = not launched
   std::vector<int32_t> results;             // 7 ints per launched job
   std::vector<uint8_t> used;                // per job: consumed by the replay
+  const int64_t* ref_len;                   // per window x: g->ref_len, or derived from (rb, re) in coordinate mode
 };
 
 void skip_flags(const Group& G, const Reg& a, const std::vector<Reg>& mates, int skip[4]) {
@@ -177,7 +178,7 @@ void skip_flags(const Group& G, const Reg& a, const std::vector<Reg>& mates, int
   }
 }
 
-inline bool window_ok(const bpsw_rescue_group_t* g, int64_t x) { return g->ref_len[x] == g->ref_re[x] - g->ref_rb[x]; }
+inline bool window_ok(const Group& G, int64_t x) { return G.ref_len[x] == G.g->ref_re[x] - G.g->ref_rb[x]; }
 
 // region built from an SWAlign2 result: native/bwamem_pair.c:203-212 / MemSamPe.scala:1192-1212
 bool make_region(const Group& G, const int32_t aln[7], int r, int l_ms, int64_t x, Reg* out) {
@@ -210,7 +211,7 @@ bool precompute(Group& G, const Reg& a, int l_ms, std::vector<Reg>& ma, int64_t 
     for (int r = 0; r < 4; ++r) {
       if (skip[r]) continue;
       const int64_t x = xrow * 4 + r;
-      if (window_ok(G.g, x)) {
+      if (window_ok(G, x)) {
         const int job = G.job_of[(size_t)x];
         if (job < 0) { missing.push_back(x); return false; }
         G.used[(size_t)job] = 1;
@@ -234,7 +235,7 @@ bool precompute(Group& G, const Reg& a, int l_ms, std::vector<Reg>& ma, int64_t 
   for (int r = 0; r < 4; ++r) {
     if (skip[r]) continue;
     const int64_t x = xrow * 4 + r;
-    if (window_ok(G.g, x)) {
+    if (window_ok(G, x)) {
       const int job = G.job_of[(size_t)x];
       if (job < 0) { missing.push_back(x); return false; }
       G.used[(size_t)job] = 1;
@@ -301,9 +302,35 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
     S.reg_base[(size_t)e] = nreg; S.ref_base[(size_t)e] = nref;
     nreg += g->reg_cnt[e]; nref += g->ref_cnt[e];
   }
-  for (int64_t x = 0; x < 4 * nref; ++x)
-    if (g->ref_len[x] > 0 && (g->ref_off[x] < 0 || (uint64_t)(g->ref_off[x] + g->ref_len[x]) > g->ref_pool_bytes))
-      return fail(BPSW_ERR_ARG, "matesw_group: window outside ref_pool");
+  // with ref_pool == NULL the windows are named by (rb, re) only and read from the 2-bit reference
+  // loaded on the context; their lengths follow bnsGetSeq (util/BNTSeqUtil.scala:37-59)
+  const bool pac_mode = g->ref_pool == nullptr && nref > 0;
+  std::vector<int64_t> derived_len;
+  if (pac_mode) {
+    const uint8_t* d_pac = nullptr;
+    long long loaded = 0;
+    ref_snapshot(c, &d_pac, &loaded);
+    if (loaded <= 0) return fail(BPSW_ERR_ARG, "matesw_group: ref_pool is null and no reference is loaded (bpsw_ref_load)");
+    if (loaded != g->l_pac) return fail(BPSW_ERR_ARG, "matesw_group: l_pac differs from the loaded reference");
+    derived_len.resize((size_t)(4 * nref));
+    for (int64_t x = 0; x < 4 * nref; ++x) {
+      int64_t b = g->ref_rb[x], e = g->ref_re[x], len = 0;
+      if (!(b < 0 && e < 0)) {  // (-1,-1): failed orientation, MemSamPe.scala:1863-1868
+        if (e < b) std::swap(b, e);
+        if (e > (g->l_pac << 1)) e = g->l_pac << 1;
+        if (b < 0) b = 0;
+        len = e - b > 0 ? e - b : 0;
+        if (!(b >= g->l_pac || e <= g->l_pac)) len = 0;  // bridging the strands: bnsGetSeq returns nothing
+      }
+      derived_len[(size_t)x] = len;
+    }
+    S.ref_len = derived_len.data();
+  } else {
+    for (int64_t x = 0; x < 4 * nref; ++x)
+      if (g->ref_len[x] > 0 && (g->ref_off[x] < 0 || (uint64_t)(g->ref_off[x] + g->ref_len[x]) > g->ref_pool_bytes))
+        return fail(BPSW_ERR_ARG, "matesw_group: window outside ref_pool");
+    S.ref_len = g->ref_len;
+  }
   S.job_of.assign((size_t)(4 * nref), -1);
 
   const bool rescue_on = (opt->flag & 0x20) == 0;  // MEM_F_NO_RESCUE, native/bwamem.h:18
@@ -326,7 +353,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
           skip_flags(S, a, init[!i], skip);
           const int64_t xrow = S.ref_base[(size_t)(2 * k + i)] + j;
           for (int r = 0; r < 4; ++r)
-            if (!skip[r] && window_ok(g, xrow * 4 + r)) want.push_back(xrow * 4 + r);
+            if (!skip[r] && window_ok(S, xrow * 4 + r)) want.push_back(xrow * 4 + r);
           ++j;
         }
       }
@@ -352,7 +379,8 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       std::vector<uint8_t> q_rev(nj);
       std::vector<uint8_t> tpool;
       size_t tbytes = 0;
-      for (size_t t = 0; t < nj; ++t) tbytes += ((size_t)g->ref_len[want[t]] + 15) & ~(size_t)15;
+      if (!pac_mode)
+        for (size_t t = 0; t < nj; ++t) tbytes += ((size_t)g->ref_len[want[t]] + 15) & ~(size_t)15;
       tpool.resize(tbytes ? tbytes : 16);
       size_t at = 0;
       for (size_t t = 0; t < nj; ++t) {
@@ -360,7 +388,12 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
         const int e = end_of_row[(size_t)(x >> 2)], mate = e ^ 1, r = (int)(x & 3);
         q_len[t] = g->seq_len[mate]; q_off[t] = g->seq_off[mate];
         q_rev[t] = ((r >> 1) != (r & 1)) ? 1 : 0;  // native/bwamem_pair.c:177
-        t_len[t] = (int32_t)g->ref_len[x]; t_off[t] = (int64_t)at;
+        t_len[t] = (int32_t)S.ref_len[x];
+        if (pac_mode) {  // window_ok held, so the window starts at ref_rb[x] unclamped
+          t_off[t] = g->ref_rb[x];
+          continue;
+        }
+        t_off[t] = (int64_t)at;
         memcpy(tpool.data() + at, g->ref_pool + g->ref_off[x], (size_t)g->ref_len[x]);
         at += ((size_t)g->ref_len[x] + 15) & ~(size_t)15;
       }
@@ -368,8 +401,8 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       memset(&jobs, 0, sizeof jobs);
       jobs.n = (int32_t)nj; jobs.xtra = xtra_base;  // KSW_XBYTE is ignored by SWAlign
       jobs.q_len = q_len.data(); jobs.t_len = t_len.data(); jobs.q_off = q_off.data(); jobs.t_off = t_off.data();
-      jobs.q_rev = q_rev.data(); jobs.q_pool = g->seq_pool; jobs.t_pool = tpool.data();
-      jobs.q_pool_bytes = g->seq_pool_bytes; jobs.t_pool_bytes = tpool.size();
+      jobs.q_rev = q_rev.data(); jobs.q_pool = g->seq_pool; jobs.t_pool = pac_mode ? nullptr : tpool.data();
+      jobs.q_pool_bytes = g->seq_pool_bytes; jobs.t_pool_bytes = pac_mode ? 0 : tpool.size();
       const size_t first = S.results.size() / 7;
       S.results.resize(7 * (first + nj));
       S.used.resize(first + nj, 0);

@@ -27,6 +27,22 @@ struct PassRes {
   int max, max_i, max_j, nb;
 };
 
+// Where the target rows of a job come from: a byte-per-base window, or the 2-bit reference resident in HBM
+// (bnsGetSeq, util/BNTSeqUtil.scala:37-79: coordinates >= l_pac read the reverse-complement strand).
+struct TgSrc {
+  const uint8_t* bytes;
+  const uint8_t* pac;
+  long long l_pac, rb;
+  __device__ __forceinline__ int at(int src) const {
+    if (bytes) return bytes[src];
+    const long long pos = rb + src;
+    const bool rev = rb >= l_pac;
+    const long long k = rev ? (l_pac << 1) - 1 - pos : pos;
+    const int b = (pac[k >> 2] >> ((~k & 3) << 1)) & 3;
+    return rev ? 3 - b : b;
+  }
+};
+
 __device__ __forceinline__ int shr1_zero(int src) {  // lane l <- lane l-1 ; lane 0 <- 0
   return __builtin_amdgcn_update_dpp(0, src, DPP_WAVE_SHR1, 0xf, 0xf, true);
 }
@@ -38,7 +54,7 @@ __device__ __forceinline__ int shr1_zero(int src) {  // lane l <- lane l-1 ; lan
 //                   row r is target[tEnd-r] for r <= tEnd and target[r] beyond
 template <int C>
 __device__ PassRes sw_pass(const int lane, const uint8_t* __restrict__ q, const int qLenRaw, const bool qrev,
-                           const int qCols, const bool pass2, const int qEnd, const uint8_t* __restrict__ tg,
+                           const int qCols, const bool pass2, const int qEnd, const TgSrc tg,
                            const int tLen, const int tEnd, const SwScoring& sc, const int minScore,
                            const int endScore, const int maxScore, uint8_t* __restrict__ tbuf,
                            uint32_t* __restrict__ list) {
@@ -79,7 +95,7 @@ __device__ PassRes sw_pass(const int lane, const uint8_t* __restrict__ q, const 
         int code = 5;
         if (r < tLen) {
           const int src = (pass2 && r <= tEnd) ? tEnd - r : r;
-          code = tg[src];
+          code = tg.at(src);
           if (code > 4) code = 4;
         }
         tbuf[k] = (uint8_t)code;
@@ -153,7 +169,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(const SwJobsDe
   for (int job = slot; job < jobs.n; job += stride) {
     const int qLen = uni(jobs.q_len[job]), tLen = uni(jobs.t_len[job]);
     const uint8_t* q = jobs.q_pool + jobs.q_off[job];
-    const uint8_t* tg = jobs.t_pool + jobs.t_off[job];
+    const long long toff = jobs.t_off[job];
+    const TgSrc tg = {jobs.t_pool ? jobs.t_pool + toff : nullptr, jobs.pac, jobs.l_pac, toff};
     const bool qrev = uni((int)jobs.q_rev[job]) != 0;
 
     const int minScore = (xtra & BPSW_KSW_XSUBO) ? (xtra & 0xffff) : 0x10000;  // SWUtil.scala:434-437
@@ -208,8 +225,10 @@ __global__ void sw_prepass_kernel(const SwJobsDev jobs, const unsigned long long
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < jobs.n; j += gridDim.x * blockDim.x) {
     const int ql = jobs.q_len[j], tl = jobs.t_len[j];
     const long long qo = jobs.q_off[j], to = jobs.t_off[j];
-    if (ql < 1 || tl < 0 || qo < 0 || to < 0 || (unsigned long long)(qo + ql) > q_pool_bytes ||
-        (unsigned long long)(to + tl) > t_pool_bytes) {
+    // a window named by coordinates must lie inside one strand of the loaded reference
+    const bool t_ok = jobs.t_pool ? (unsigned long long)(to + tl) <= t_pool_bytes
+                                  : (to + tl <= (jobs.l_pac << 1) && (to >= jobs.l_pac || to + tl <= jobs.l_pac));
+    if (ql < 1 || tl < 0 || qo < 0 || to < 0 || (unsigned long long)(qo + ql) > q_pool_bytes || !t_ok) {
       err = 1;
       continue;
     }
@@ -219,6 +238,31 @@ __global__ void sw_prepass_kernel(const SwJobsDev jobs, const unsigned long long
   if (mq) atomicMax(&pre->max_qlen, mq);
   if (mt) atomicMax(&pre->max_tlen, mt);
   if (err) atomicMax(&pre->error, err);
+}
+
+// bnsGetSeq for n windows: swap / clamp / strand rules of util/BNTSeqUtil.scala:37-59, bases by TgSrc::at
+__global__ void ref_fetch_kernel(const uint8_t* __restrict__ pac, const long long l_pac, const int n,
+                                 const long long* __restrict__ beg, const long long* __restrict__ end,
+                                 uint8_t* __restrict__ out_pool, const unsigned long long out_pool_bytes,
+                                 const long long* __restrict__ out_off, long long* __restrict__ out_len,
+                                 int* __restrict__ error) {
+  for (int t = blockIdx.x; t < n; t += gridDim.x) {
+    long long b = beg[t], e = end[t];
+    if (e < b) { const long long x = b; b = e; e = x; }
+    if (e > (l_pac << 1)) e = l_pac << 1;
+    if (b < 0) b = 0;
+    long long len = e - b;
+    if (len < 0) len = 0;                        // both ends beyond 2*l_pac
+    if (!(b >= l_pac || e <= l_pac)) len = 0;    // bridging the forward-reverse boundary: nothing
+    const long long off = out_off[t];
+    if (off < 0 || (unsigned long long)(off + len) > out_pool_bytes) {
+      if (threadIdx.x == 0) { out_len[t] = len; atomicMax(error, 1); }
+      continue;
+    }
+    if (threadIdx.x == 0) out_len[t] = len;
+    const TgSrc src = {nullptr, pac, l_pac, b};
+    for (long long k = threadIdx.x; k < len; k += blockDim.x) out_pool[off + k] = (uint8_t)src.at((int)k);
+  }
 }
 
 template <int C>
@@ -236,6 +280,14 @@ void launch_sw_prepass(const SwJobsDev& jobs, size_t q_pool_bytes, size_t t_pool
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   hipLaunchKernelGGL(sw_prepass_kernel, dim3(blocks), dim3(threads), 0, s, jobs, (unsigned long long)q_pool_bytes,
                      (unsigned long long)t_pool_bytes, d_pre);
+}
+
+void launch_ref_fetch(const uint8_t* d_pac, long long l_pac, int n, const long long* d_beg, const long long* d_end,
+                      uint8_t* d_out_pool, size_t out_pool_bytes, const long long* d_out_off, long long* d_out_len,
+                      int* d_error, hipStream_t s) {
+  int blocks = n < 1 ? 1 : (n > 8192 ? 8192 : n);
+  hipLaunchKernelGGL(ref_fetch_kernel, dim3(blocks), dim3(256), 0, s, d_pac, l_pac, n, d_beg, d_end, d_out_pool,
+                     (unsigned long long)out_pool_bytes, d_out_off, d_out_len, d_error);
 }
 
 // one uint32 list entry per target row, per resident wave

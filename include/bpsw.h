@@ -192,6 +192,30 @@ typedef struct {
 int bpsw_global_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_global_jobs_t *jobs, int32_t *out_score,
                       int32_t *out_ncigar, uint32_t *out_cigar);
 
+/* ---- "next" row: reference-window extraction on the device ------------------------------ */
+/*
+ * bnsGetSeq (util/BNTSeqUtil.scala:37-79 == bns_get_seq, native/bntseq.c) with the 2-bit .pac resident in HBM
+ * (base k = pac[k>>2] >> ((~k & 3) << 1) & 3; coordinates >= l_pac address the reverse-complement strand).  The
+ * reference belongs to the DEVICE of the context it was loaded through and is seen by every context of that device
+ * (the JNI shim keeps one context per Spark task thread); loading or unloading must not race with calls in flight on
+ * that device.  Once loaded, the callers of bnsGetSeq on the hot path (MemSamPe.scala:1852 for the rescue windows)
+ * can send only (rBeg, rEnd) instead of the bytes:
+ *   bpsw_sw_jobs_t      with t_pool == NULL : t_off[t] is the window start in the doubled coordinate space,
+ *                                             t_len[t] its length; a window may not bridge l_pac.
+ *   bpsw_rescue_group_t with ref_pool == NULL: ref_rb/ref_re name the windows (-1,-1 = failed orientation,
+ *                                             MemSamPe.scala:1863-1868); ref_len/ref_off are ignored, the length is
+ *                                             derived with bnsGetSeq's own rules (clamp to [0, 2*l_pac), 0 when the
+ *                                             window bridges the strands) and g->l_pac must equal the loaded length.
+ * bpsw_ref_fetch is bnsGetSeq itself (n windows -> bytes), for callers that still want the bases on the host and
+ * for the parity tests: out_len[t] = window length after the reference's swap/clamp (0 when bridging); the bases go
+ * to out_pool[out_off[t] ..]; returns BPSW_ERR_CAPACITY if a window does not fit before out_pool_bytes.
+ */
+int bpsw_ref_load(bpsw_ctx_t *ctx, const uint8_t *pac, int64_t l_pac); /* copies (l_pac+3)/4 bytes to the device */
+int bpsw_ref_unload(bpsw_ctx_t *ctx);
+int64_t bpsw_ref_length(const bpsw_ctx_t *ctx); /* l_pac of the loaded reference, 0 if none */
+int bpsw_ref_fetch(bpsw_ctx_t *ctx, int32_t n, const int64_t *beg, const int64_t *end, uint8_t *out_pool,
+                   size_t out_pool_bytes, const int64_t *out_off, int64_t *out_len);
+
 /* ---- statistics (the buckets of profiling/SWBatchTimeBreakdown.scala:25-39, device flavoured) -- */
 typedef struct {
   uint64_t ext_calls, ext_tasks, ext_wire_bytes;

@@ -745,3 +745,24 @@ int64_t orc_matesw_group(const orc_opt_t *opt, int64_t l_pac, const orc_pestat_t
   }
   return overflow ? -total : total;
 }
+
+/* ------------------------------------------------------------------ bnsGetSeq */
+/* util/BNTSeqUtil.scala:37-79 */
+int64_t orc_bns_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t end, uint8_t *out, int64_t cap) {
+  int64_t b = beg, e = end; /* BNTSeqUtil.scala:38-47: swap if end < beg */
+  if (end < beg) { e = beg; b = end; }
+  if (e > (l_pac << 1)) e = l_pac << 1; /* :48-49 */
+  if (b < 0) b = 0;
+  int64_t rlen = e - b; /* :50 */
+  if (rlen < 0) rlen = 0; /* both ends past 2*l_pac: the Scala would throw on a negative array size; never reached */
+  if (!(b >= l_pac || e <= l_pac)) return 0; /* :75-76 bridging the forward-reverse boundary */
+  if (rlen > cap) return -rlen;
+  int64_t l = 0, k;
+  if (b >= l_pac) { /* reverse strand, :56-65 */
+    const int64_t beg_f = (l_pac << 1) - 1 - e, end_f = (l_pac << 1) - 1 - b;
+    for (k = end_f; k >= beg_f + 1; --k) out[l++] = (uint8_t)((3 - (pac[k >> 2] >> ((~k & 3) << 1))) & 3);
+  } else { /* :66-73 */
+    for (k = b; k < e; ++k) out[l++] = (uint8_t)((pac[k >> 2] >> ((~k & 3) << 1)) & 3);
+  }
+  return rlen;
+}

@@ -118,6 +118,11 @@ void orc_opt_default(orc_opt_t *opt); /* MemOptType defaults + bwaFillScmat, Mem
 /* infer_dir, native/bwamem_pair.c:27-34 (inlined at PE:1128-1146) */
 int orc_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist);
 
+/* bnsGetSeq, util/BNTSeqUtil.scala:37-79 (== bns_get_seq, native/bntseq.c:355-376): the window [beg,end) of the 2-bit
+ * reference in the doubled coordinate space; returns its length (0 when it bridges the strands) and writes at most
+ * `cap` bases to out (a longer window returns -length and writes nothing). */
+int64_t orc_bns_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t end, uint8_t *out, int64_t cap);
+
 /*
  * Batched rescue (boundary 1), flat SoA form of the JNI call's arguments.
  *   seq_len/seq_off[2G]     : mate sequences (codes 0..4) in seq_pool, index 2k+i

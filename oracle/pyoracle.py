@@ -61,6 +61,15 @@ def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _get_seq(fn, l_pac, pac, beg, end):
+    pac = np.ascontiguousarray(pac, np.uint8)
+    cap = int(abs(int(end) - int(beg))) + 8
+    out = np.zeros(cap, np.uint8)
+    n = fn(C.c_int64(l_pac), _vp(pac), C.c_int64(beg), C.c_int64(end), _vp(out), C.c_int64(cap))
+    assert n >= 0
+    return out[:n].copy()
+
+
 def default_mat(a: int = 1, b: int = 4) -> np.ndarray:
     m = np.full((5, 5), -1, dtype=np.int8)
     for i in range(4):
@@ -78,6 +87,7 @@ class Oracle:
         self.lib.orc_wire_pack.restype = C.c_size_t
         self.lib.orc_matesw_group.restype = C.c_int64
         self.lib.orc_sw_global.restype = C.c_int
+        self.lib.orc_bns_get_seq.restype = C.c_int64
 
     def default_opt(self) -> Opt:
         o = Opt()
@@ -151,6 +161,10 @@ class Oracle:
             cells += c
         return out, cells
 
+    def bns_get_seq(self, l_pac, pac, beg, end):
+        """bnsGetSeq (util/BNTSeqUtil.scala:37-79) -> uint8 bases (empty when the window bridges the strands)"""
+        return _get_seq(self.lib.orc_bns_get_seq, l_pac, pac, beg, end)
+
     def sw_global(self, query, target, mat, o_del, e_del, o_ins, e_ins, w):
         q = np.ascontiguousarray(query, np.uint8)
         t = np.ascontiguousarray(target, np.uint8)
@@ -198,12 +212,18 @@ class Ref:
         self.lib = C.CDLL(path)
         self.lib.ksw_align2.restype = KswrT
         self.lib.ref_group_matesw_flat.restype = C.c_int64
+        if hasattr(self.lib, "ref_bns_get_seq"):
+            self.lib.ref_bns_get_seq.restype = C.c_int64
         self.libc = C.CDLL(None)
         self.libc.free.argtypes = [C.c_void_p]
 
     @staticmethod
     def available() -> bool:
         return os.path.exists(REF_SO)
+
+    def bns_get_seq(self, l_pac, pac, beg, end):
+        """bns_get_seq (native/bntseq.c:355-376)"""
+        return _get_seq(self.lib.ref_bns_get_seq, l_pac, pac, beg, end)
 
     def ksw_extend2(self, query, target, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0):
         q = np.ascontiguousarray(query, np.uint8)

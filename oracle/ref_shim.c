@@ -170,3 +170,14 @@ void ref_align2_batch(int n, const int32_t *q_len, const int32_t *t_len, const i
   }
   free(q); free(t);
 }
+
+/* bns_get_seq (native/bntseq.c:355-376) into a caller buffer: returns the length, or -length if it exceeds cap */
+#include "bntseq.h"
+int64_t ref_bns_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t end, uint8_t *out, int64_t cap) {
+  int64_t len = 0;
+  uint8_t *seq = bns_get_seq(l_pac, pac, beg, end, &len);
+  if (len > cap) { free(seq); return -len; }
+  if (seq && len > 0) memcpy(out, seq, (size_t)len);
+  free(seq);
+  return len;
+}

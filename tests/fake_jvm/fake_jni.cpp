@@ -204,11 +204,20 @@ int fake_jvm_matesw(const char* lib, int partition, const int32_t opt_ints[16], 
                     const int64_t* seq_off, const uint8_t* seq_pool, const int32_t* reg_cnt, const FlatReg* regs,
                     const int32_t* ref_cnt, const int64_t* ref_rb, const int64_t* ref_re, const int64_t* ref_len,
                     const int64_t* ref_off, const uint8_t* ref_pool, int32_t* out_cnt, FlatReg* out_regs, int64_t out_cap,
-                    int64_t* out_total, long* local_frames, char* err, int errcap) {
+                    int64_t* out_total, long* local_frames, char* err, int errcap, const uint8_t* pac /* may be null */) {
   Jvm vm;
   g_vm = &vm;
   vm.partition = partition;
   Env e;
+  if (pac) {  // the driver loads the reference once, then sends coordinates only
+    typedef jint (*LoadFn)(JNIEnv*, jobject, jbyteArray, jlong);
+    LoadFn load = (LoadFn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI", err, (size_t)errcap);
+    if (!load) return -1;
+    FObj* self0 = vm.alloc("cs/ucla/edu/bwaspark/jni/MateSWJNI");
+    const jint nd = load(&e.env, J(self0), (jbyteArray)J(byte_array(pac, (size_t)((l_pac + 3) / 4))), (jlong)l_pac);
+    if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+    if (nd < 1) { snprintf(err, (size_t)errcap, "loadPacJNI loaded no device"); return -1; }
+  }
   typedef jobjectArray (*Fn)(JNIEnv*, jobject, jobject, jlong, jobjectArray, jint, jobjectArray, jobjectArray, jobjectArray, jintArray);
   Fn fn = (Fn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI", err, (size_t)errcap);
   if (!fn) return -1;
@@ -237,8 +246,14 @@ int fake_jvm_matesw(const char* lib, int partition, const int32_t opt_ints[16], 
         r->ints["readIdx"] = k; r->ints["pairIdx"] = i; r->ints["regIdx"] = j;
         FObj *rb = vm.alloc("[J"), *re = vm.alloc("[J"), *ln = vm.alloc("[J");
         for (int o = 0; o < 4; ++o) {
-          rb->la.push_back(ref_rb[4 * row + o]); re->la.push_back(ref_re[4 * row + o]); ln->la.push_back(ref_len[4 * row + o]);
           static const char* rn[4] = {"ref0", "ref1", "ref2", "ref3"};
+          rb->la.push_back(ref_rb[4 * row + o]); re->la.push_back(ref_re[4 * row + o]);
+          if (pac) {  // coordinates only: lenArray = rEnd - rBeg, no bytes
+            ln->la.push_back(ref_rb[4 * row + o] < 0 ? 0 : ref_re[4 * row + o] - ref_rb[4 * row + o]);
+            r->objs[rn[o]] = nullptr;
+            continue;
+          }
+          ln->la.push_back(ref_len[4 * row + o]);
           r->objs[rn[o]] = ref_len[4 * row + o] > 0 ? byte_array(ref_pool + ref_off[4 * row + o], (size_t)ref_len[4 * row + o]) : nullptr;
         }
         r->objs["rBegArray"] = rb; r->objs["rEndArray"] = re; r->objs["lenArray"] = ln;

@@ -23,6 +23,19 @@ from bpsw_hip import synth  # noqa: E402
 ref = po.Ref()
 mat = po.default_mat()
 rng = np.random.default_rng(20261003)
+ONLY = set(sys.argv[1:])  # optional: file stems to (re)write, e.g. `make_golden.py bns_get_seq`; default all
+_savez = np.savez_compressed
+
+
+def _filtered_savez(path, **kw):
+    stem = os.path.splitext(os.path.basename(path))[0]
+    if ONLY and stem not in ONLY:
+        return
+    _savez(path, **kw)
+    print("wrote", os.path.basename(path))
+
+
+np.savez_compressed = _filtered_savez
 
 
 def mutate(seq, sub, indel):
@@ -157,3 +170,33 @@ for tag, allo, n, p in (("fr", False, 48, 0.4), ("all4", True, 24, 0.5)):
                         ref_pool=g.ref_pool, out_cnt=cnt, out_regs=regs, opt_ints=ints, opt_mat=m25, opt_mask=np.float32(mlr.value),
                         note="mem_group_matesw(native/bwamem_pair.c:115-156) with mem_opt_init() defaults; csub inherits B8")
 print("golden vectors written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
+
+
+# ---- bns_get_seq (== bnsGetSeq, util/BNTSeqUtil.scala:37-79): windows of a 2-bit reference -------------------------
+rng2 = np.random.default_rng(20261004)
+l_pac = 50_021
+pac = rng2.integers(0, 256, (l_pac + 3) // 4, dtype=np.uint8)
+begs, ends, seqs = [], [], []
+for t in range(400):
+    kind = t % 8
+    L = int(rng2.integers(0, 900))
+    if kind == 0:    # forward strand
+        b = int(rng2.integers(0, l_pac - L)); e = b + L
+    elif kind == 1:  # reverse strand
+        b = int(rng2.integers(l_pac, 2 * l_pac - L)); e = b + L
+    elif kind == 2:  # bridging the strands -> nothing
+        b = l_pac - 1 - int(rng2.integers(0, 300)); e = l_pac + 1 + int(rng2.integers(0, 300))
+    elif kind == 3:  # swapped ends
+        e = int(rng2.integers(0, l_pac - L)); b = e + L
+    elif kind == 4:  # clamped at 0
+        b = -int(rng2.integers(1, 200)); e = int(rng2.integers(0, 600))
+    elif kind == 5:  # clamped at 2*l_pac
+        b = 2 * l_pac - int(rng2.integers(0, 600)); e = 2 * l_pac + int(rng2.integers(1, 200))
+    elif kind == 6:  # touching the strand boundary from either side
+        b = l_pac - L if t % 16 == 6 else l_pac; e = b + L
+    else:            # anywhere
+        b = int(rng2.integers(0, 2 * l_pac - L)); e = b + L
+    begs.append(b); ends.append(e); seqs.append(ref.bns_get_seq(l_pac, pac, b, e))
+so, sp = pack(seqs)
+np.savez_compressed(os.path.join(HERE, "bns_get_seq.npz"), l_pac=l_pac, pac=pac, beg=np.array(begs, np.int64),
+                    end=np.array(ends, np.int64), seq_off=so, seq_pool=sp)

@@ -131,3 +131,16 @@ def test_oracle_vs_python_transliteration_sw_align2(orc):
         want = scala_text.sw_align2(q.tolist(), t.tolist(), MAT.tolist(), 1, 4, 6, 1, 6, 1, xtra)
         got, _ = orc.sw_align2(q, t, opt, xtra)
         assert got.tolist() == want
+
+
+def test_bns_get_seq_vs_reference_golden(orc):
+    """bnsGetSeq restatement (util/BNTSeqUtil.scala:37-79) against bns_get_seq outputs of the reference C"""
+    z = np.load(os.path.join(G, "bns_get_seq.npz"))
+    l_pac, pac = int(z["l_pac"]), z["pac"]
+    want = _seqs(z, "seq")
+    n_empty = 0
+    for b, e, w in zip(z["beg"], z["end"], want):
+        got = orc.bns_get_seq(l_pac, pac, int(b), int(e))
+        assert np.array_equal(got, w)
+        n_empty += int(len(w) == 0)
+    assert 0 < n_empty < len(want) // 3   # the bridging windows (and a few empty ones) return nothing

@@ -42,7 +42,7 @@ def _extend(fake, wire, n, partition=-1):
     return rc, out[: 10 * n], err.value.decode()
 
 
-def _matesw(fake, g, partition=-1):
+def _matesw(fake, g, partition=-1, pac=None):
     opt = bpsw_hip.default_opt()
     ints = np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_unpaired, opt.pen_clip5, opt.pen_clip3,
                      opt.w, opt.zdrop, opt.T, opt.flag, opt.min_seed_len, opt.max_ins, opt.max_matesw], np.int32)
@@ -57,7 +57,7 @@ def _matesw(fake, g, partition=-1):
                               C.c_int64(g.l_pac), _vp(pes), g.group_size, _vp(g.seq_len), _vp(g.seq_off), _vp(g.seq_pool),
                               _vp(g.reg_cnt), _vp(g.regs), _vp(g.ref_cnt), _vp(g.ref_rb), _vp(g.ref_re), _vp(g.ref_len),
                               _vp(g.ref_off), _vp(g.ref_pool), _vp(out_cnt), _vp(out), C.c_int64(cap), C.byref(total),
-                              C.byref(frames), err, 512)
+                              C.byref(frames), err, 512, _vp(pac) if pac is not None else None)
     return rc, out_cnt[: 2 * g.group_size], out[: total.value], frames.value, err.value.decode()
 
 
@@ -94,3 +94,18 @@ def test_matesw_through_jni_matches_c_abi(fake, ctx, allo):
     assert frames == 0
     assert np.array_equal(cnt, want_cnt)
     region_fields_equal(regs, want)
+
+
+@pytest.mark.gpu
+def test_matesw_through_jni_with_reference_on_device(fake, ctx):
+    """SURVEY.md 8f.2 through the JNI surface: loadPacJNI, then RefSWType objects that carry (rBeg, rEnd) only"""
+    l_pac = 300_007
+    pac, bases = synth.random_pac(l_pac, seed=51)
+    g = synth.rescue_group(150, seed=52, l_pac=l_pac, p_resc=0.4, ref_bases=bases)
+    want_cnt, want = ctx.matesw_group(bpsw_hip.default_opt(), g)          # windows shipped as bytes
+    rc, cnt, regs, frames, msg = _matesw(fake, g, partition=1, pac=pac)  # windows named by coordinates
+    assert rc == 0, msg
+    assert frames == 0
+    assert np.array_equal(cnt, want_cnt)
+    region_fields_equal(regs, want)
+    assert regs.shape[0] > g.regs.shape[0]

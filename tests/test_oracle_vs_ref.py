@@ -49,3 +49,17 @@ def test_group_rescue_c_mode(orc, ref):
         rcnt, rregs = ref.matesw_group(opt, g)
         assert n_sw > 0 and np.array_equal(cnt, rcnt)
         region_fields_equal(regs, rregs, skip=("csub",))
+
+
+def test_bns_get_seq_live(orc, ref):
+    rng = np.random.default_rng(5)
+    l_pac = 200_003
+    pac = rng.integers(0, 256, (l_pac + 3) // 4, dtype=np.uint8)
+    for t in range(2000):
+        b = int(rng.integers(-100, 2 * l_pac))
+        e = b + int(rng.integers(0, 1200))
+        if t % 5 == 0:
+            b = l_pac - int(rng.integers(0, 600)); e = b + int(rng.integers(0, 1200))
+        if t % 9 == 0:
+            b, e = e, b
+        assert np.array_equal(orc.bns_get_seq(l_pac, pac, b, e), ref.bns_get_seq(l_pac, pac, b, e))
