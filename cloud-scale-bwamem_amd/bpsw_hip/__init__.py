@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "bpsw_set_ext_scoring", "bpsw_extend_batch", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
-    "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch",
+    "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
 ]
 JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI",
@@ -84,6 +84,15 @@ class GlobalJobs(C.Structure):  # bpsw_global_jobs_t
     _fields_ = [("n", C.c_int32), ("max_cigar", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("q_len", "t_len", "w", "q_off", "t_off", "q_pool", "t_pool")] + \
                [("q_pool_bytes", C.c_size_t), ("t_pool_bytes", C.c_size_t)]
+
+
+class Chains(C.Structure):  # bpsw_chains_t
+    _fields_ = [("n_reads", C.c_int32), ("read_len", C.c_void_p), ("read_off", C.c_void_p), ("read_pool", C.c_void_p),
+                ("read_pool_bytes", C.c_size_t), ("chain_cnt", C.c_void_p), ("seed_cnt", C.c_void_p), ("seed_rbeg", C.c_void_p),
+                ("seed_qbeg", C.c_void_p), ("seed_len", C.c_void_p)]
+
+
+C2A_SORT_DEDUP, C2A_DEDUP_SCALA = 1, 2
 
 
 class RescueGroup(C.Structure):  # bpsw_rescue_group_t
@@ -144,6 +153,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.bpsw_reset_stats.argtypes = [C.c_void_p]
     lib.bpsw_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.bpsw_chain2aln_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(Chains), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.POINTER(C.c_int64)]
     lib.bpsw_ref_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.bpsw_ref_unload.argtypes = [C.c_void_p]
     lib.bpsw_ref_length.argtypes = [C.c_void_p]
@@ -357,6 +368,24 @@ class Context:
              "bpsw_ref_fetch")
         return [pool[off[i]: off[i] + lens[i]].copy() for i in range(n)], lens[:n]
 
+    # memChainToAlnBatched on the device ------------------------------------------
+    def chain2aln_batch(self, opt: Opt, b: "ChainBatchSoA", zdrop_mode: int = ZDROP_SCALA, flags: int = 0):
+        st = Chains()
+        st.n_reads = b.n_reads
+        for f, dt in (("read_len", np.int32), ("read_off", np.int64), ("read_pool", np.uint8), ("chain_cnt", np.int32),
+                      ("seed_cnt", np.int32), ("seed_rbeg", np.int64), ("seed_qbeg", np.int32), ("seed_len", np.int32)):
+            a = getattr(b, f)
+            assert a.dtype == dt and a.flags.c_contiguous, f
+            setattr(st, f, a.ctypes.data)
+        st.read_pool_bytes = b.read_pool.size
+        cap = int(b.seed_len.shape[0]) + 8
+        out_cnt = np.zeros(max(b.n_reads, 1), np.int32)
+        out = np.zeros(cap, dtype=ALNREG_DTYPE)
+        total = C.c_int64(0)
+        _chk(self.lib, self.lib.bpsw_chain2aln_batch(self.h, C.byref(opt), C.byref(st), zdrop_mode, flags, _ptr(out_cnt), _ptr(out), cap,
+                                                    C.byref(total)), "bpsw_chain2aln_batch")
+        return out_cnt[: b.n_reads], out[: total.value]
+
     def stats(self) -> Stats:
         s = Stats()
         _chk(self.lib, self.lib.bpsw_get_stats(self.h, C.byref(s)), "bpsw_get_stats")
@@ -366,6 +395,24 @@ class Context:
         a, b = C.c_float(0), C.c_float(0)
         _chk(self.lib, self.lib.bpsw_last_kernel_ms(self.h, C.byref(a), C.byref(b)), "bpsw_last_kernel_ms")
         return a.value, b.value
+
+
+@dataclass
+class ChainBatchSoA:
+    """Reads and their seed chains, the arguments of memChainToAlnBatched (MemChainToAlignBatched.scala:380-391), flat."""
+    l_pac: int
+    read_len: np.ndarray   # int32 [n]
+    read_off: np.ndarray   # int64 [n]
+    read_pool: np.ndarray  # uint8, codes 0..4
+    chain_cnt: np.ndarray  # int32 [n]
+    seed_cnt: np.ndarray   # int32 [sum chain_cnt]
+    seed_rbeg: np.ndarray  # int64 [sum seed_cnt]
+    seed_qbeg: np.ndarray  # int32
+    seed_len: np.ndarray   # int32
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.read_len.shape[0])
 
 
 @dataclass

@@ -261,3 +261,96 @@ def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE
                           regs=regs_arr, ref_cnt=np.array(ref_cnt, np.int32), ref_rb=np.array(ref_rb, np.int64),
                           ref_re=np.array(ref_re, np.int64), ref_len=np.array(ref_len, np.int64),
                           ref_off=np.array(ref_off, np.int64), ref_pool=cat(ref_chunks))
+
+
+def read_chains(n_reads: int, ref_bases: np.ndarray, l_pac: int, read_len: int = 150, sub_rate: float = 0.01,
+                indel_rate: float = 0.001, tail_frac: float = 0.0, min_seed: int = 19, p_subseed: float = 0.3,
+                p_shifted: float = 0.15, p_decoy: float = 0.3, seed: int = CONFIG_SEED_BASE + 9):
+    """Reads with their seed chains, as memChainToAlnBatched (MemChainToAlignBatched.scala:380-616) receives them.
+
+    A read is a mutated substring of either strand of the reference; its chain holds the exact-match runs >= min_seed
+    (a surrogate for the SMEM seeds), sometimes a contained sub-seed (skipped by testExtension), sometimes a
+    seed on a neighbouring diagonal (kept alive by checkOverlapping), and sometimes a second chain at an unrelated locus.
+    """
+    from . import ChainBatchSoA
+    rng = np.random.default_rng(seed)
+    L = read_len
+    read_len_a, read_off, pools = [], [], []
+    chain_cnt, seed_cnt, s_rb, s_qb, s_len = [], [], [], [], []
+    at = 0
+    for r in range(n_reads):
+        rev = rng.random() < 0.5
+        lo, hi = (l_pac + 600, 2 * l_pac - L - 600) if rev else (600, l_pac - L - 600)
+        rb0 = int(rng.integers(lo, hi))
+        seg = window_bases(ref_bases, l_pac, rb0, rb0 + L + 60)
+        es, ei = sub_rate, indel_rate
+        if tail_frac > 0 and rng.random() < tail_frac:
+            es, ei = 0.2, 0.05
+        read, pos = [], []          # pos[i] = index in seg the read base was copied from, -1 otherwise
+        i = 0
+        while len(read) < L and i < len(seg):
+            u = rng.random()
+            if u < ei / 2:          # insertion
+                read.append(int(rng.integers(0, 4))); pos.append(-1)
+            elif u < ei:            # deletion
+                i += 1
+            elif u < ei + es:       # substitution
+                read.append(int((seg[i] + 1 + rng.integers(0, 3)) & 3)); pos.append(-1); i += 1
+            else:
+                read.append(int(seg[i])); pos.append(i); i += 1
+        while len(read) < L:
+            read.append(int(rng.integers(0, 4))); pos.append(-1)
+        read = np.array(read, np.uint8)
+        if rng.random() < 0.02:
+            read[int(rng.integers(0, L))] = 4   # an N
+            pos[int(np.argmax(read == 4))] = -1
+        seeds = []
+        q = 0
+        while q < L:
+            if pos[q] < 0:
+                q += 1
+                continue
+            e = q
+            while e + 1 < L and pos[e + 1] == pos[e] + 1:
+                e += 1
+            if e + 1 - q >= min_seed:
+                seeds.append((rb0 + pos[q], q, e + 1 - q))
+            q = e + 1
+        chains = []
+        if seeds:
+            ch = list(seeds)
+            if rng.random() < p_subseed:
+                rb, qb, ln = ch[int(rng.integers(0, len(ch)))]
+                if ln >= min_seed + 8:
+                    d = int(rng.integers(1, ln - min_seed))
+                    ch.append((rb + d, qb + d, int(rng.integers(min_seed, ln - d + 1))))
+            if rng.random() < p_shifted:
+                rb, qb, ln = ch[int(rng.integers(0, len(ch)))]
+                sh = int(rng.integers(1, 6)) * (1 if rng.random() < 0.5 else -1)
+                cut = int(rng.integers(0, max(1, ln // 3)))
+                if ln - cut >= min_seed:
+                    ch.append((rb + sh + cut, qb + cut, ln - cut))
+            ch.sort(key=lambda t: (t[1], t[0]))
+            chains.append(ch)
+        if rng.random() < p_decoy:
+            lo2, hi2 = (l_pac + 600, 2 * l_pac - L - 600) if rng.random() < 0.5 else (600, l_pac - L - 600)
+            rbd = int(rng.integers(lo2, hi2))
+            qb = int(rng.integers(0, L - 30))
+            ch = [(rbd + qb, qb, int(rng.integers(min_seed, 30)))]
+            if rng.random() < 0.3 and qb + 60 < L:
+                ch.append((rbd + qb + 40 + int(rng.integers(-2, 3)), qb + 40, int(rng.integers(min_seed, 20 + 1))))
+            chains.append(ch)
+        read_len_a.append(L); read_off.append(at); pools.append(read)
+        pad = (-L) % 16
+        if pad:
+            pools.append(np.zeros(pad, np.uint8))
+        at += L + pad
+        chain_cnt.append(len(chains))
+        for ch in chains:
+            seed_cnt.append(len(ch))
+            for rb, qb, ln in ch:
+                s_rb.append(rb); s_qb.append(qb); s_len.append(ln)
+    return ChainBatchSoA(l_pac=l_pac, read_len=np.array(read_len_a, np.int32), read_off=np.array(read_off, np.int64),
+                         read_pool=np.concatenate(pools) if pools else np.zeros(16, np.uint8),
+                         chain_cnt=np.array(chain_cnt, np.int32), seed_cnt=np.array(seed_cnt, np.int32),
+                         seed_rbeg=np.array(s_rb, np.int64), seed_qbeg=np.array(s_qb, np.int32), seed_len=np.array(s_len, np.int32))

@@ -16,355 +16,13 @@
 // (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
 #include <stdlib.h>
 
-#include "bpsw_internal.h"
-#include "bpsw_wave.h"
+#include "bpsw_extend_core.h"
 
 namespace bpsw {
 namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int EXT_CHUNK = 1;  // tasks per dequeue (larger chunks measured slower: the tail grows faster than the atomic traffic shrinks)
-
-// base k (0-based) of a task's nibble stream: 8 nibbles per word, first base in the top nibble
-__device__ __forceinline__ int nibble_at(const uint32_t* __restrict__ words, int k) {
-  const uint32_t w = words[k >> 3];
-  const int c = (int)((w >> (28 - 4 * (k & 7))) & 0xFu);
-  return c > 4 ? 4 : c;  // codes are 0..4 (LocusEncode); never index the matrix out of bounds
-}
-
-struct ExtRes {
-  int max, qle, tle, gtle, gscore, max_off;
-};
-
-// One SWExtend call (SWUtil.scala:61-230) executed by a whole wave.  All scalar state is wave-uniform.
-__device__ ExtRes sw_extend_wave(const int lane, const int qLen, const int tLen, int2* __restrict__ eh,
-                                 const int8_t* __restrict__ qp, const uint8_t* __restrict__ ts, const int oDel,
-                                 const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
-                                 const int zmode, const int h0) {
-  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
-  // row -1 (SWUtil.scala:75-78, 97-104): eh[0].h = h0, eh[j].h = max(0, h0 - oeIns - (j-1)*eIns), e = 0
-  for (int j = lane; j <= qLen; j += 64) {
-    const int h = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);
-    eh[j] = make_int2(h, 0);
-  }
-  __builtin_amdgcn_wave_barrier();
-
-  int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;  // SWUtil.scala:118-125
-  int beg = 0, end = qLen;
-  int t_next = tLen > 0 ? uni((int)ts[0]) : 0;
-
-  for (int i = 0; i < tLen; ++i) {
-    const int t = t_next;
-    if (i + 1 < tLen) t_next = uni((int)ts[i + 1]);  // prefetch the next row's target base
-    const int h1 = max(0, h0 - (oDel + eDel * (i + 1)));  // SWUtil.scala:137-138
-    beg = max(beg, i - w);                                // SWUtil.scala:140-142
-    end = min(min(end, i + w + 1), qLen);
-    const int8_t* __restrict__ q = qp + t * qLen;
-
-    int carry = NEG;   // running max of g(k) = a(k) - oeIns + k*eIns over the columns already swept
-    int hleft = h1;    // H(i, j0-1); for the first chunk the "first column" value of SWUtil.scala:137
-    int m = 0, mj = -1;
-    int lz_all = -1;   // last column with H == 0 among the columns already swept
-    int lz_best = -1;  // last column < mj with H == 0
-    int fz_after = -1; // first column > mj with H == 0
-
-    for (int j0 = beg; j0 < end; j0 += 64) {
-      const int j = j0 + lane;
-      const bool act = j < end;
-      int2 he = make_int2(0, 0);
-      int s = 0;
-      if (act) {
-        he = eh[j];
-        s = q[j];
-      }
-      const int a = act ? max(he.x + s, he.y) : NEG;
-      const int jE = j * eIns - oeIns;
-      const int P = max(wave_scan_max(a + jE), carry);
-      const int Pex = wave_shr1(carry, P);  // exclusive prefix; lane 0 takes the carry
-      const int H = max3i(a, Pex - (jE + oeIns - eIns), 0);     // F(i,j) = max(0, Pex - (j-1)*eIns)
-      carry = __builtin_amdgcn_readlane(P, 63);
-      const int E = max3i(he.y - eDel, H - oeDel, 0);           // E(i+1,j)
-      const int Hprev = wave_shr1(hleft, H);  // H(i,j-1), stored at eh[j].h
-      if (act) eh[j] = make_int2(Hprev, E);
-
-      const int nact = min(64, end - j0);
-      hleft = __builtin_amdgcn_readlane(H, nact - 1);
-      const unsigned long long actmask = nact == 64 ? ~0ull : ((1ull << nact) - 1ull);
-      const unsigned long long zmask = __builtin_amdgcn_ballot_w64(H == 0) & actmask;
-      const int Hm = act ? H : -1;
-      const int cm = __builtin_amdgcn_readlane(wave_scan_max(Hm), 63);
-      if (cm >= m) {  // "m <= h": a later chunk with an equal maximum takes over (last arg-max)
-        const unsigned long long eq = __builtin_amdgcn_ballot_w64(Hm == cm);
-        const int b = 63 - __builtin_clzll(eq);
-        m = cm;
-        mj = j0 + b;
-        const unsigned long long below = zmask & ((1ull << b) - 1ull);
-        lz_best = below ? j0 + 63 - __builtin_clzll(below) : lz_all;
-        const unsigned long long above = b == 63 ? 0ull : (zmask >> (b + 1));
-        fz_after = above ? j0 + b + 1 + __builtin_ctzll(above) : -1;
-      } else if (fz_after < 0 && zmask) {
-        fz_after = j0 + __builtin_ctzll(zmask);
-      }
-      if (zmask) lz_all = j0 + 63 - __builtin_clzll(zmask);
-    }
-    if (lane == 0) eh[end] = make_int2(hleft, 0);  // SWUtil.scala:174-175
-    __builtin_amdgcn_wave_barrier();
-
-    const int jfin = beg < end ? end : beg;  // value of j after the column loop
-    if (jfin == qLen && gscore <= hleft) {   // SWUtil.scala:177-182
-      max_ie = i;
-      gscore = hleft;
-    }
-    if (m == 0) break;  // SWUtil.scala:184-185
-    if (m > mx) {       // SWUtil.scala:187-193
-      mx = m;
-      max_i = i;
-      max_j = mj;
-      max_off = max(max_off, abs(mj - i));
-    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
-      const bool A = (i - max_i) > (mj - max_j);
-      const bool B = mx - m - ((i - max_i) - (mj - max_j)) * eDel > zdrop;
-      const bool C = mx - m - ((mj - max_j) - (i - max_i)) * eIns > zdrop;
-      const bool stop = zmode == BPSW_ZDROP_SCALA ? (A && (B || C)) : (A ? B : C);
-      if (stop) break;
-    }
-    // SWUtil.scala:202-214 on V(p) = eh[p].h: V(beg) = h1, V(j+1) = H(i,j)
-    beg = lz_best >= 0 ? lz_best + 2 : (h1 == 0 ? beg + 1 : beg);
-    end = fz_after >= 0 ? fz_after + 1 : end + 1;
-  }
-  ExtRes r;
-  r.max = mx; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
-  return r;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Register-resident form of the same SWExtend for qLen <= 255 (every 2x150 / 2x250 bp task).
-// Column j lives in lane j&63 of slot j>>6, so the (H,E) row never leaves VGPRs and the diagonal
-// H(i-1,j-1) is one DPP wave_shr:1.  Two interleaved fused-DPP max-scans per slot give
-//   prefix max of g(k) = a(k) - oeIns + k*eIns   -> F(i,j)
-//   wave max of a(k)                             -> the row maximum m
-// With oeIns > 0, H(i,j) == m > 0 iff a(j) == m (F stays strictly below the maximum), so the row
-// maximum and its LAST arg-max (SWUtil.scala:158-161) are read off `a` with one ballot.
-// The kernel is bound by the CU's single scalar unit, not by VALU, so the per-row control below is
-// written to need as few SALU instructions as possible (s_bfm/s_flbit/s_ff1 on the 64-bit zero mask).
-// ---------------------------------------------------------------------------------------------------
-
-// Two independent inclusive max-scans over the 64 lanes, interleaved so each DPP read sees its operand
-// two wait states after the write (the hazard hipcc does not handle inside asm statements).
-__device__ __forceinline__ void dual_scan_max(int& g, int& a) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1"
-      : "+v"(g), "+v"(a));
-}
-__device__ __forceinline__ unsigned long long s_below_mask(int width) {  // (1 << width) - 1, width 0..63
-  unsigned long long r;
-  asm("s_bfm_b64 %0, %1, 0" : "=s"(r) : "s"(width));
-  return r;
-}
-__device__ __forceinline__ int s_lead_zeros(unsigned long long v) {  // -1 when v == 0
-  int r;
-  asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(v));
-  return r;
-}
-__device__ __forceinline__ int s_first_one(unsigned long long v) {  // -1 when v == 0
-  int r;
-  asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(v));
-  return r;
-}
-
-// Where the wave-uniform row control runs.  Measured on MI355X (tools/microbench_issue.hip, profiles/): a SIMD issues
-// one integer VALU / DPP / v_cmp / v_readlane wave-instruction per ~3.7 cycles and one SALU instruction per ~3.7
-// cycles; mixed streams from several waves reach about one instruction per 2.4 cycles, and once the GPU is saturated
-// the kernel time follows the TOTAL instruction count (1.15 ns x (VALU + SALU) / SIMD), not the split.  Two builds:
-//   BPSW_EXT_VECTOR_CONTROL 1 (default): uniform values kept in VGPRs through an opaque asm -> 355 M VALU + 200 M SALU
-//                                        per 30 k-task batch, 0.713 ms stand-alone
-//   BPSW_EXT_VECTOR_CONTROL 0          : control on the scalar pipe -> 239 M VALU + 323 M SALU, 0.748 ms stand-alone
-// Both give 2.95 ms per bench step when the step's batches overlap on the device.
-#ifndef BPSW_EXT_VECTOR_CONTROL
-#define BPSW_EXT_VECTOR_CONTROL 1
-#endif
-__device__ __forceinline__ int vu(int s) {
-#if BPSW_EXT_VECTOR_CONTROL
-  int v;
-  asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
-  return v;
-#else
-  return s;
-#endif
-}
-__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-
-template <int S>
-__device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, const uint32_t* __restrict__ words,
-                                const int qStart, const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
-                                const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
-                                const int zmode, const int h0) {
-  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
-  int Hs[S], Es[S], As[S], plo[S], phi[S], jE[S], c2[S];
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const int j = 64 * s + lane;
-    const int code = j < qLen ? nibble_at(words, qStart + j) : 4;
-    const int sh = 8 * code;
-    plo[s] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
-                   (((mat.row[3] >> sh) & 0xff) << 24));
-    phi[s] = (int)(int8_t)((mat.row[4] >> sh) & 0xff);
-    Hs[s] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
-    Es[s] = 0;
-    As[s] = NEG;
-    jE[s] = j * eIns - oeIns;
-    c2[s] = (j - 1) * eIns;
-  }
-  // SWUtil.scala:118-125 -- wave-uniform state, held in VGPRs (see vu)
-  int mx = vu(h0), max_i = vu(-1), max_j = vu(-1), max_ie = vu(-1), gscore = vu(-1), max_off = vu(0);
-  int beg = vu(0), end = vu(qLen);
-  int h1raw = vu(h0 - oDel);  // h0 - (oDel + eDel*(i+1)) after the decrement below
-  int iv = vu(0);             // vector copy of the row index
-
-  for (int i = 0; i < tLen; ++i, iv += 1) {
-    const int tsv = ts[i];  // 8 * target base, same in every lane
-    const bool isN = tsv == 32;
-    h1raw -= eDel;
-    const int h1 = max(0, h1raw);      // SWUtil.scala:137-138
-    beg = max(beg, iv - w);            // SWUtil.scala:140-142
-    end = min(min(end, iv + (w + 1)), qLen);
-    const int span = end - beg;
-    const unsigned spanA = (unsigned)max(span, 0);      // columns beg <= j <  end
-    const unsigned spanU = (unsigned)max(span + 1, 0);  // columns beg <= j <= end (eh[end] is written too)
-
-    int carry_g = NEG, carry_a = NEG;  // running maxima over the slots already swept (scalars, S > 1)
-    int hl_prev = h1;                  // H(i, 64*s - 1) for the next slot's lane 0
-    int scan_a = NEG;
-    unsigned long long zm[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      zm[s] = 0;
-      const unsigned rel = (unsigned)(64 * s + lane - beg);
-      const bool upd = rel < spanU;
-      if (S > 1 && !any_lane(upd)) {  // slot entirely outside [beg, end]
-        As[s] = NEG;
-        continue;
-      }
-      const bool act = rel < spanA;
-      const int sc = isN ? phi[s] : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
-      const int a = act ? max(Hs[s] + sc, Es[s]) : NEG;
-      As[s] = a;
-      int Pg = a + jE[s];
-      scan_a = a;
-      dual_scan_max(Pg, scan_a);
-      if (S > 1) {
-        Pg = max(Pg, carry_g);
-        scan_a = max(scan_a, carry_a);
-      }
-      const int Pex = wave_shr1(carry_g, Pg);  // exclusive prefix; lane 0 takes the carry of the earlier slots
-      if (S > 1) {
-        carry_g = __builtin_amdgcn_readlane(Pg, 63);
-        carry_a = __builtin_amdgcn_readlane(scan_a, 63);
-      }
-      const int H = max3i(a, Pex - c2[s], 0);  // F(i,j) = max(0, Pex - (j-1)*eIns)
-      zm[s] = __builtin_amdgcn_ballot_w64((act ? H : -1) == 0);
-      const int En = act ? max3i(Es[s] - eDel, H - oeDel, 0) : 0;  // E(i+1,j); eh[end].e = 0
-      int hsh = wave_shr1(hl_prev, H);                             // H(i,j-1)
-      if (S > 1) hl_prev = __builtin_amdgcn_readlane(H, 63);
-      hsh = rel == 0u ? h1 : hsh;                                  // eh[beg].h = h1, SWUtil.scala:153
-      Hs[s] = upd ? hsh : Hs[s];
-      Es[s] = upd ? En : Es[s];
-    }
-    const int m = max(0, S > 1 ? carry_a : __builtin_amdgcn_readlane(scan_a, 63));  // scalar
-
-    // SWUtil.scala:177-182: j after the column loop is end (or beg for an empty band); h1 there is eh[end].h
-    if (any_lane((span > 0 ? end : beg) == qLen)) {
-      int hlast = h1;
-      if (any_lane(span > 0)) {
-        const int e = __builtin_amdgcn_readfirstlane(end);
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-          if (S == 1 || (e >> 6) == s) hlast = __builtin_amdgcn_readlane(Hs[s], e & 63);
-      }
-      const bool better = gscore <= hlast;
-      max_ie = better ? iv : max_ie;
-      gscore = better ? hlast : gscore;
-    }
-    if (m == 0) break;  // SWUtil.scala:184-185
-
-    int sm = 0, bm;  // slot and lane of the LAST column whose a == m  (SWUtil.scala:158-161)
-    if (S == 1) {
-      bm = 63 - s_lead_zeros(__builtin_amdgcn_ballot_w64(As[0] == m));
-    } else {
-      bm = -1;
-#pragma unroll
-      for (int s = S - 1; s >= 0; --s) {
-        const int lzc = s_lead_zeros(__builtin_amdgcn_ballot_w64(As[s] == m));
-        if (bm < 0 && lzc >= 0) { bm = 63 - lzc; sm = s; }
-      }
-    }
-    const int mj = 64 * sm + bm;  // scalar
-    const bool improved = m > mx;
-    if (!any_lane(improved) && zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
-      const int di = iv - max_i, dj = mj - max_j;
-      const bool A = di > dj;
-      const bool B = mx - m - (di - dj) * eDel > zdrop;
-      const bool C = mx - m - (dj - di) * eIns > zdrop;
-      const bool stop = zmode == BPSW_ZDROP_SCALA ? (A && (B || C)) : (A ? B : C);
-      if (any_lane(stop)) break;
-    }
-    {  // SWUtil.scala:187-193
-      const int d = mj - iv;
-      const int off = max3i(max_off, d, -d);
-      mx = improved ? m : mx;
-      max_i = improved ? iv : max_i;
-      max_j = improved ? mj : max_j;
-      max_off = improved ? off : max_off;
-    }
-    // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj
-    int lzc, fo, lbase = 65, fbase = bm + 2;
-    if (S == 1) {
-      lzc = s_lead_zeros(zm[0] & s_below_mask(bm));
-      fo = s_first_one((zm[0] >> bm) >> 1);
-    } else {
-      lzc = -1;
-      fo = -1;
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const unsigned long long below = s == sm ? (zm[s] & s_below_mask(bm)) : zm[s];
-        const unsigned long long above = s == sm ? (zm[s] >> bm) >> 1 : zm[s];
-        const int l = s_lead_zeros(below);
-        if (s <= sm && l >= 0) { lzc = l; lbase = 64 * s + 65; }
-        const int f = s_first_one(above);
-        if (s >= sm && fo < 0 && f >= 0) { fo = f; fbase = s == sm ? 64 * s + bm + 2 : 64 * s + 1; }
-      }
-    }
-    const int nb0 = beg + (h1 == 0 ? 1 : 0);
-    beg = lzc >= 0 ? vu(lbase - lzc) : nb0;
-    end = fo >= 0 ? vu(fbase + fo) : end + 1;
-  }
-  ExtRes r;
-  r.max = __builtin_amdgcn_readfirstlane(mx);
-  r.qle = __builtin_amdgcn_readfirstlane(max_j) + 1;
-  r.tle = __builtin_amdgcn_readfirstlane(max_i) + 1;
-  r.gtle = __builtin_amdgcn_readfirstlane(max_ie) + 1;
-  r.gscore = __builtin_amdgcn_readfirstlane(gscore);
-  r.max_off = __builtin_amdgcn_readfirstlane(max_off);
-  return r;
-}
 
 // stage the target of one side in LDS as 8*code bytes (the shift the register path feeds to v_bfe)
 __device__ void load_target_shifts(const int lane, const uint32_t* __restrict__ words, const int rStart, const int rLen,
@@ -385,26 +43,6 @@ __device__ void load_side(const int lane, const uint32_t* __restrict__ words, co
   }
   for (int i = lane; i < rLen; i += 64) ts[i] = (uint8_t)nibble_at(words, rStart + i);
   __builtin_amdgcn_wave_barrier();
-}
-
-// Wave-level dequeue: lane 0 alone performs one returning atomic add, the result is broadcast.  Written as
-// a single asm statement so that the compiler sees no lane-dependent branch here: with a C-level
-// `if (lane == 0) atomicAdd(...)` hipcc threaded that branch together with the lane-0 result store at the end
-// of the previous iteration and peeled the other 63 lanes out of the loop, which breaks every cross-lane
-// operation of the row sweep.
-__device__ __forceinline__ int dequeue_task(int* counter) {
-  int v = 1;
-  unsigned long long saved;
-  asm volatile(
-      "s_mov_b64 %1, exec\n\t"
-      "s_mov_b64 exec, 1\n\t"
-      "global_atomic_add %0, %2, %0, off sc0\n\t"
-      "s_waitcnt vmcnt(0)\n\t"
-      "s_mov_b64 exec, %1"
-      : "+v"(v), "=&s"(saved)
-      : "v"(counter)
-      : "memory");
-  return __builtin_amdgcn_readfirstlane(v);
 }
 
 __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
@@ -476,12 +114,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
         aw[side] = wBand << i;
         const int w = min(min(aw[side], maxIns), maxDel);
         if (reg_path) {
-          switch ((qLen + 64) >> 6) {
-            case 1: r = sw_extend_reg<1>(lane, qLen, rLen, words, qStart, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit); break;
-            case 2: r = sw_extend_reg<2>(lane, qLen, rLen, words, qStart, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit); break;
-            case 3: r = sw_extend_reg<3>(lane, qLen, rLen, words, qStart, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit); break;
-            default: r = sw_extend_reg<4>(lane, qLen, rLen, words, qStart, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit); break;
-          }
+          r = sw_extend_reg_any(lane, qLen, rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit);
         } else {
           r = sw_extend_wave(lane, qLen, rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit);
         }

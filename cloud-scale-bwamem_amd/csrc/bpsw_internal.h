@@ -132,6 +132,33 @@ hipError_t launch_global_kernel(const GlobalJobsDev& jobs, const SwScoring& sc, 
                                 int32_t* d_score, int32_t* d_ncigar, uint32_t* d_cigar, uint8_t* d_z, int num_cu,
                                 hipStream_t s);
 
+// ---- memChainToAlnBatched on the device ----------------------------------------------
+struct ChainParams {
+  MatRows mat;
+  int mat_max, a, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop, zmode;
+};
+struct ChainBatchDev {  // all device pointers
+  int n_reads;
+  const int32_t* read_len;
+  const long long* read_off;
+  const uint8_t* read_pool;
+  const int32_t* chain_cnt;
+  const int32_t* chain_base;   // first chain of read r
+  const int32_t* seed_cnt;     // per chain
+  const long long* seed_base;  // first seed of chain c
+  const long long* seed_rbeg;
+  const int32_t* seed_qbeg;
+  const int32_t* seed_len;
+  const long long* reg_base;   // first output slot of read r (= seeds before it)
+  const uint8_t* pac;
+  long long l_pac;
+};
+int chain2aln_resident_waves(int num_cu);
+hipError_t launch_chain2aln_kernel(const ChainBatchDev& B, const ChainParams& P, bpsw_alnreg_t* d_out_regs, int32_t* d_out_cnt,
+                                   int32_t* d_srt_scratch, int srt_per_wave, int num_cu, int* d_counter, hipStream_t s);
+// memSortAndDedup on a host vector (bpsw_rescue.cpp): mode BPSW_RESCUE_C or BPSW_RESCUE_SCALA; returns the new size
+int sort_dedup_regs(std::vector<bpsw_alnreg_t>& v, float mask_level_redun, int mode);
+
 // ---- error text -----------------------------------------------------------------------------------
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);

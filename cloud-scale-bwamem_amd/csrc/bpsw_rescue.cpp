@@ -282,6 +282,10 @@ bool replay_pair(Group& G, int k, std::vector<Reg> v[2], std::vector<int64_t>& m
 
 }  // namespace
 
+namespace bpsw {
+int sort_dedup_regs(std::vector<bpsw_alnreg_t>& v, float mask_level_redun, int mode) { return sort_dedup(v, mask_level_redun, mode); }
+}  // namespace bpsw
+
 extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_rescue_group_t* g, int mode,
                                  int32_t* out_cnt, bpsw_alnreg_t* out_regs, int64_t out_cap, int64_t* out_total) {
   if (!c || !opt || !g || !out_cnt || !out_total) return fail(BPSW_ERR_ARG, "matesw_group: null argument");

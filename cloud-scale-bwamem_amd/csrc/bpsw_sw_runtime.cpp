@@ -247,6 +247,144 @@ int bpsw_ref_fetch(bpsw_ctx_t* c, int32_t n, const int64_t* beg, const int64_t* 
   return BPSW_OK;
 }
 
+// ---- memChainToAlnBatched on the device ------------------------------------------------------------
+int bpsw_chain2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_chains_t* b, int zdrop_mode, int flags, int32_t* out_cnt,
+                         bpsw_alnreg_t* out_regs, int64_t out_cap, int64_t* out_total) {
+  if (!c || !opt || !b || !out_cnt || !out_total) return fail(BPSW_ERR_ARG, "chain2aln: null argument");
+  if (zdrop_mode != BPSW_ZDROP_SCALA && zdrop_mode != BPSW_ZDROP_BWA) return fail(BPSW_ERR_ARG, "chain2aln: bad zdrop_mode");
+  const int n = b->n_reads;
+  *out_total = 0;
+  if (n == 0) return BPSW_OK;
+  if (n < 0 || !b->read_len || !b->read_off || !b->read_pool || !b->chain_cnt) return fail(BPSW_ERR_ARG, "chain2aln: null read arrays");
+  if (opt->a < 1 || opt->o_del < 0 || opt->o_ins < 0 || opt->e_del < 1 || opt->e_ins < 1)
+    return fail(BPSW_ERR_ARG, "chain2aln: scoring must have a >= 1, gap opens >= 0 and gap extensions >= 1");
+  if (opt->w < 1 || opt->w > 254) return fail(BPSW_ERR_LIMIT, "chain2aln: band width must be 1..254");
+  std::lock_guard<std::mutex> g(c->mu);
+  const uint8_t* d_pac = nullptr;
+  long long l_pac = 0;
+  ref_snapshot(c, &d_pac, &l_pac);
+  if (l_pac <= 0) return fail(BPSW_ERR_ARG, "chain2aln: no reference is loaded (bpsw_ref_load)");
+  HIP_TRY(hipSetDevice(c->device));
+
+  // ---- host twin of a table scan: validate, build the prefix arrays the kernel indexes with ----
+  std::vector<int32_t> chain_base((size_t)n);
+  std::vector<long long> reg_base((size_t)n);
+  long long nchains = 0, nseeds = 0;
+  int max_seeds = 1;
+  for (int r = 0; r < n; ++r) {
+    const int ql = b->read_len[r];
+    const long long qo = b->read_off[r];
+    if (ql < 1 || qo < 0 || (unsigned long long)(qo + ql) > b->read_pool_bytes) return fail(BPSW_ERR_ARG, "chain2aln: read outside read_pool");
+    if (ql > 256) return fail(BPSW_ERR_LIMIT, "chain2aln: read longer than 256 bases");
+    if (b->chain_cnt[r] < 0) return fail(BPSW_ERR_ARG, "chain2aln: negative chain count");
+    chain_base[(size_t)r] = (int32_t)nchains;
+    nchains += b->chain_cnt[r];
+    if (nchains > 0x7fffffffll) return fail(BPSW_ERR_LIMIT, "chain2aln: too many chains in one batch");
+  }
+  if (nchains > 0 && (!b->seed_cnt || !b->seed_rbeg || !b->seed_qbeg || !b->seed_len)) return fail(BPSW_ERR_ARG, "chain2aln: null seed arrays");
+  std::vector<long long> seed_base((size_t)(nchains > 0 ? nchains : 1));
+  {
+    long long ch = 0;
+    for (int r = 0; r < n; ++r) {
+      reg_base[(size_t)r] = nseeds;
+      const int ql = b->read_len[r];
+      for (int k = 0; k < b->chain_cnt[r]; ++k, ++ch) {
+        const int ns = b->seed_cnt[ch];
+        if (ns < 0) return fail(BPSW_ERR_ARG, "chain2aln: negative seed count");
+        seed_base[(size_t)ch] = nseeds;
+        const bool fwd = ns > 0 && b->seed_rbeg[nseeds] < l_pac;
+        for (int i = 0; i < ns; ++i) {
+          const long long rb = b->seed_rbeg[nseeds + i];
+          const int qb = b->seed_qbeg[nseeds + i], ln = b->seed_len[nseeds + i];
+          if (ln < 1 || qb < 0 || qb + ln > ql) return fail(BPSW_ERR_ARG, "chain2aln: seed outside its read");
+          if (rb < 0 || rb + ln > (l_pac << 1) || (rb < l_pac) != fwd || (fwd && rb + ln > l_pac))
+            return fail(BPSW_ERR_ARG, "chain2aln: seed outside the reference or chain across both strands");
+        }
+        if (ns > max_seeds) max_seeds = ns;
+        nseeds += ns;
+      }
+    }
+  }
+  *out_total = nseeds;  // upper bound until the kernel has run: one region per seed at most
+  if (nseeds > out_cap || (nseeds > 0 && !out_regs)) return fail(BPSW_ERR_CAPACITY, "chain2aln: out_regs must hold one region per seed");
+
+  // ---- one staging block, one H2D copy ----
+  const size_t o_rlen = 0, o_roff = align16(4 * (size_t)n), o_ccnt = align16(o_roff + 8 * (size_t)n);
+  const size_t o_cbase = align16(o_ccnt + 4 * (size_t)n), o_rbase = align16(o_cbase + 4 * (size_t)n);
+  const size_t o_scnt = align16(o_rbase + 8 * (size_t)n), o_sbase = align16(o_scnt + 4 * (size_t)nchains);
+  const size_t o_srb = align16(o_sbase + 8 * (size_t)nchains), o_sqb = align16(o_srb + 8 * (size_t)nseeds);
+  const size_t o_sln = align16(o_sqb + 4 * (size_t)nseeds), o_pool = align16(o_sln + 4 * (size_t)nseeds);
+  const size_t total = align16(o_pool + b->read_pool_bytes);
+  const size_t o_cnt = 0, o_regs = align16(4 * (size_t)n);
+  const size_t out_bytes = o_regs + sizeof(bpsw_alnreg_t) * (size_t)(nseeds > 0 ? nseeds : 1);
+  const int srt_per_wave = (max_seeds + 15) & ~15;
+  HIP_TRY(c->h_stage_in.reserve(total));
+  HIP_TRY(c->d_sw_in.reserve(total));
+  HIP_TRY(c->h_stage_out.reserve(out_bytes));
+  HIP_TRY(c->d_sw_out.reserve(out_bytes));
+  HIP_TRY(c->d_sw_scratch.reserve(4 * (size_t)srt_per_wave * (size_t)chain2aln_resident_waves(c->num_cu)));
+  uint8_t* h = (uint8_t*)c->h_stage_in.ptr;
+  memcpy(h + o_rlen, b->read_len, 4 * (size_t)n); memcpy(h + o_roff, b->read_off, 8 * (size_t)n);
+  memcpy(h + o_ccnt, b->chain_cnt, 4 * (size_t)n); memcpy(h + o_cbase, chain_base.data(), 4 * (size_t)n);
+  memcpy(h + o_rbase, reg_base.data(), 8 * (size_t)n);
+  if (nchains) { memcpy(h + o_scnt, b->seed_cnt, 4 * (size_t)nchains); memcpy(h + o_sbase, seed_base.data(), 8 * (size_t)nchains); }
+  if (nseeds) {
+    memcpy(h + o_srb, b->seed_rbeg, 8 * (size_t)nseeds); memcpy(h + o_sqb, b->seed_qbeg, 4 * (size_t)nseeds);
+    memcpy(h + o_sln, b->seed_len, 4 * (size_t)nseeds);
+  }
+  memcpy(h + o_pool, b->read_pool, b->read_pool_bytes);
+  uint8_t* d = (uint8_t*)c->d_sw_in.ptr;
+  uint8_t* dout = (uint8_t*)c->d_sw_out.ptr;
+  ChainBatchDev B;
+  B.n_reads = n;
+  B.read_len = (const int32_t*)(d + o_rlen); B.read_off = (const long long*)(d + o_roff); B.read_pool = d + o_pool;
+  B.chain_cnt = (const int32_t*)(d + o_ccnt); B.chain_base = (const int32_t*)(d + o_cbase);
+  B.seed_cnt = (const int32_t*)(d + o_scnt); B.seed_base = (const long long*)(d + o_sbase);
+  B.seed_rbeg = (const long long*)(d + o_srb); B.seed_qbeg = (const int32_t*)(d + o_sqb); B.seed_len = (const int32_t*)(d + o_sln);
+  B.reg_base = (const long long*)(d + o_rbase);
+  B.pac = d_pac; B.l_pac = l_pac;
+  ChainParams P;
+  P.mat = pack_mat(opt->mat);
+  P.mat_max = opt->mat[0];
+  for (int k = 1; k < 25; ++k) P.mat_max = opt->mat[k] > P.mat_max ? opt->mat[k] : P.mat_max;
+  P.a = opt->a; P.o_del = opt->o_del; P.e_del = opt->e_del; P.o_ins = opt->o_ins; P.e_ins = opt->e_ins;
+  P.pen_clip5 = opt->pen_clip5; P.pen_clip3 = opt->pen_clip3; P.w = opt->w; P.zdrop = opt->zdrop; P.zmode = zdrop_mode;
+
+  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(launch_chain2aln_kernel(B, P, (bpsw_alnreg_t*)(dout + o_regs), (int32_t*)(dout + o_cnt), (int32_t*)c->d_sw_scratch.ptr,
+                                  srt_per_wave, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), c->stream));
+  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
+  c->stats.ext_kernel_ms += ms;
+  c->last_ext_ms = ms;
+  c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)nseeds;
+
+  // ---- compact (and optionally memSortAndDedup, as bwaMemWorker1Batched does right after, BWAMemWorker1Batched.scala:128-133) ----
+  const uint8_t* ho = (const uint8_t*)c->h_stage_out.ptr;
+  const int32_t* cnt = (const int32_t*)(ho + o_cnt);
+  const bpsw_alnreg_t* regs = (const bpsw_alnreg_t*)(ho + o_regs);
+  int64_t at = 0;
+  std::vector<bpsw_alnreg_t> v;
+  for (int r = 0; r < n; ++r) {
+    const bpsw_alnreg_t* first = regs + reg_base[(size_t)r];
+    int m = cnt[r];
+    if (flags & BPSW_C2A_SORT_DEDUP) {
+      v.assign(first, first + m);
+      m = sort_dedup_regs(v, opt->mask_level_redun, (flags & BPSW_C2A_DEDUP_SCALA) ? BPSW_RESCUE_SCALA : BPSW_RESCUE_C);
+      first = v.data();
+    }
+    out_cnt[r] = m;
+    for (int k = 0; k < m; ++k) out_regs[at++] = first[k];
+  }
+  *out_total = at;
+  return BPSW_OK;
+}
+
 int bpsw_global_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_global_jobs_t* j, int32_t* out_score,
                       int32_t* out_ncigar, uint32_t* out_cigar) {
   if (!c || !j || !out_score || !out_ncigar || !out_cigar) return fail(BPSW_ERR_ARG, "global: null argument");

@@ -216,6 +216,40 @@ int64_t bpsw_ref_length(const bpsw_ctx_t *ctx); /* l_pac of the loaded reference
 int bpsw_ref_fetch(bpsw_ctx_t *ctx, int32_t n, const int64_t *beg, const int64_t *end, uint8_t *out_pool,
                    size_t out_pool_bytes, const int64_t *out_off, int64_t *out_len);
 
+/* ---- "next" row: the memChainToAlnBatched round loop on the device ----------------------------- */
+/*
+ * memChainToAlnBatched (worker1/MemChainToAlignBatched.scala:380-616; per chain == mem_chain2aln, native/bwamem.c:552-672):
+ * the caller hands over the reads of a batch with their filtered seed chains and gets back, per read, the regions the
+ * Scala leaves in regArrays -- all rounds (testExtension, checkOverlapping, extension with band retries, seed coverage)
+ * run on the device, one wavefront per read, with the reference windows read from the 2-bit reference loaded by
+ * bpsw_ref_load.  One call per batch replaces one swExtendFPGAJNI call per round plus the Scala-side task packing.
+ *   read_len/read_off[n]  : reads (codes 0..4, <= 256 bases) in read_pool
+ *   chain_cnt[n]          : chains per read (0 == chainsFilteredArray(i) null)
+ *   seed_cnt[sum chains]  : seeds per chain, (read, chain) order
+ *   seed_rbeg/qbeg/len[]  : MemSeedType fields in (read, chain, seedsRefArray) order; a chain lies on one strand
+ *   out_cnt[n], out_regs  : regions per read in creation order (sub, csub, sub_n, secondary, hash = 0 as in the Scala);
+ *                           out_cap must be >= the total number of seeds.  With BPSW_C2A_SORT_DEDUP the lists are
+ *                           passed through memSortAndDedup (what bwaMemWorker1Batched returns,
+ *                           BWAMemWorker1Batched.scala:128-133), C flavour by default, Scala flavour with
+ *                           BPSW_C2A_DEDUP_SCALA.
+ * zdrop_mode selects the z-drop parse as in bpsw_set_ext_scoring.  Needs e_del, e_ins >= 1 and 1 <= w <= 254.
+ */
+#define BPSW_C2A_SORT_DEDUP 1
+#define BPSW_C2A_DEDUP_SCALA 2
+typedef struct {
+  int32_t n_reads;
+  const int32_t *read_len;
+  const int64_t *read_off;
+  const uint8_t *read_pool;
+  size_t read_pool_bytes;
+  const int32_t *chain_cnt;
+  const int32_t *seed_cnt;
+  const int64_t *seed_rbeg;
+  const int32_t *seed_qbeg, *seed_len;
+} bpsw_chains_t;
+int bpsw_chain2aln_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_chains_t *batch, int zdrop_mode, int flags,
+                         int32_t *out_cnt, bpsw_alnreg_t *out_regs, int64_t out_cap, int64_t *out_total);
+
 /* ---- statistics (the buckets of profiling/SWBatchTimeBreakdown.scala:25-39, device flavoured) -- */
 typedef struct {
   uint64_t ext_calls, ext_tasks, ext_wire_bytes;

@@ -766,3 +766,157 @@ int64_t orc_bns_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t 
   }
   return rlen;
 }
+
+/* ------------------------------------------------------------------ memChainToAlnBatched */
+static int cal_max_gap(const orc_opt_t *o, int qlen) { /* C2AB:625-643 */
+  const int len_del = dtoi((double)(qlen * o->a - o->o_del) / (double)o->e_del + 1.0);
+  const int len_ins = dtoi((double)(qlen * o->a - o->o_ins) / (double)o->e_ins + 1.0);
+  int len = len_del > len_ins ? len_del : len_ins;
+  if (len <= 1) len = 1;
+  const int tmp = o->w << 1;
+  return len < tmp ? len : tmp;
+}
+
+typedef struct { int32_t len, index; } srt_t;
+static int srt_cmp(const void *a, const void *b) { /* sortBy(s => (s.len, s.index)), C2AB:372 */
+  const srt_t *x = (const srt_t *)a, *y = (const srt_t *)b;
+  if (x->len != y->len) return x->len < y->len ? -1 : 1;
+  return x->index < y->index ? -1 : (x->index > y->index);
+}
+#define SRT_MARKED (-2) /* C2AB:51 */
+
+/* one chain of one read; regs[0..*n_regs) are the regions the read already has (all its earlier chains included) */
+static void chain2aln(const orc_opt_t *o, int zdrop_mode, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query,
+                      int n_seeds, const int64_t *s_rbeg, const int32_t *s_qbeg, const int32_t *s_len, orc_alnreg_t *regs,
+                      int *n_regs, int64_t *n_ext, int64_t *cells) {
+  if (n_seeds == 0) return;
+  int i, k;
+  /* getMaxSpan, C2AB:648-676 */
+  int64_t rmax0 = l_pac << 1, rmax1 = 0;
+  for (i = 0; i < n_seeds; ++i) {
+    const int64_t b = s_rbeg[i] - (s_qbeg[i] + cal_max_gap(o, s_qbeg[i]));
+    const int64_t e = s_rbeg[i] + s_len[i] + (l_query - s_qbeg[i] - s_len[i]) + cal_max_gap(o, l_query - s_qbeg[i] - s_len[i]);
+    if (rmax0 > b) rmax0 = b;
+    if (rmax1 < e) rmax1 = e;
+  }
+  if (rmax0 <= 0) rmax0 = 0;
+  if (rmax1 >= (l_pac << 1)) rmax1 = l_pac << 1;
+  if (rmax0 < l_pac && l_pac < rmax1) { /* crossing the forward-reverse boundary: choose the side of seed 0 */
+    if (s_rbeg[0] < l_pac) rmax1 = l_pac; else rmax0 = l_pac;
+  }
+  /* calPreResultsOfSW, C2AB:344-375 */
+  const int64_t span = rmax1 - rmax0;
+  uint8_t *rseq = (uint8_t *)malloc((size_t)(span > 0 ? span : 1));
+  const int64_t rlen = orc_bns_get_seq(l_pac, pac, rmax0, rmax1, rseq, span > 0 ? span : 0);
+  (void)rlen; /* the Scala asserts rlen == rmax(1) - rmax(0) */
+  srt_t *srt = (srt_t *)malloc(sizeof(srt_t) * (size_t)n_seeds);
+  for (i = 0; i < n_seeds; ++i) { srt[i].len = s_len[i]; srt[i].index = i; }
+  qsort(srt, (size_t)n_seeds, sizeof(srt_t), srt_cmp);
+  uint8_t *lq = (uint8_t *)malloc((size_t)l_query + 1), *lr = (uint8_t *)malloc((size_t)(span > 0 ? span : 1));
+
+  for (k = n_seeds - 1; k >= 0; --k) { /* one round per seed, longest first (C2AB:405-409, 420-455) */
+    const int si = srt[k].index;
+    const int64_t srb = s_rbeg[si];
+    const int sqb = s_qbeg[si], sl = s_len[si];
+    /* testExtension, C2AB:680-741 */
+    int ext = *n_regs;
+    for (i = 0; i < *n_regs; ++i) {
+      const orc_alnreg_t *p = &regs[i];
+      if (srb >= p->rb && srb + sl <= p->re && sqb >= p->qb && sqb + sl <= p->qe) {
+        int qd = sqb - p->qb;
+        int64_t rd = srb - p->rb;
+        int mind = qd < rd ? qd : (int)rd;
+        int mg = cal_max_gap(o, mind);
+        int w = mg < o->w ? mg : o->w;
+        if (qd - rd < w && rd - qd < w) { ext = i; break; }
+        qd = p->qe - (sqb + sl);
+        rd = p->re - (srb + sl);
+        mind = qd < rd ? qd : (int)rd;
+        mg = cal_max_gap(o, mind);
+        w = mg < o->w ? mg : o->w;
+        if (qd - rd < w && rd - qd < w) { ext = i; break; }
+      }
+    }
+    if (ext < *n_regs) { /* checkOverlapping, C2AB:753-787 */
+      int ovl = n_seeds;
+      for (i = k + 1; i < n_seeds; ++i) {
+        if (srt[i].index == SRT_MARKED) continue;
+        const int ti = srt[i].index;
+        if ((double)s_len[ti] >= (double)sl * 0.95) {
+          if (sqb <= s_qbeg[ti] && sqb + sl - s_qbeg[ti] >= (sl >> 2) && (int64_t)(s_qbeg[ti] - sqb) != s_rbeg[ti] - srb) { ovl = i; break; }
+          if (s_qbeg[ti] <= sqb && s_qbeg[ti] + s_len[ti] - sqb >= (sl >> 2) && (int64_t)(sqb - s_qbeg[ti]) != srb - s_rbeg[ti]) { ovl = i; break; }
+        }
+      }
+      if (ovl == n_seeds) { srt[k].index = SRT_MARKED; continue; } /* C2AB:482-484 */
+    }
+    orc_alnreg_t reg; /* C2AB:486-499 */
+    memset(&reg, 0, sizeof reg);
+    reg.w = o->w;
+    reg.score = sl * o->a; reg.truesc = sl * o->a;
+    reg.qb = 0; reg.rb = srb; reg.qe = l_query; reg.re = srb + sl;
+    if (sqb > 0 || sqb + sl != l_query) { /* C2AB:500-562 */
+      orc_ext_param_t p;
+      memset(&p, 0, sizeof p);
+      p.left_qlen = sqb;
+      if (p.left_qlen > 0) {
+        for (i = 0; i < p.left_qlen; ++i) lq[i] = query[p.left_qlen - 1 - i];
+        p.left_rlen = (int32_t)(srb - rmax0);
+        for (i = 0; i < p.left_rlen; ++i) lr[i] = rseq[p.left_rlen - 1 - i];
+        p.left_qs = lq; p.left_rs = lr;
+      }
+      const int qe = sqb + sl;
+      p.right_qlen = l_query - qe;
+      if (p.right_qlen > 0) {
+        const int64_t re = srb + sl - rmax0;
+        p.right_rlen = (int32_t)(rmax1 - rmax0 - re);
+        p.right_qs = query + qe; p.right_rs = rseq + re;
+      }
+      p.w = o->w; p.mat = o->mat; p.o_del = o->o_del; p.o_ins = o->o_ins; p.e_del = o->e_del; p.e_ins = o->e_ins;
+      p.pen_clip5 = o->pen_clip5; p.pen_clip3 = o->pen_clip3; p.zdrop = o->zdrop;
+      p.h0 = sl * o->a; p.reg_score = reg.score; p.q_beg = sqb; p.idx = 0;
+      orc_ext_ret_t r;
+      orc_extension(&p, zdrop_mode, &r, cells);
+      if (n_ext) ++*n_ext;
+      reg.qb = r.q_beg; /* C2AB:590-599 */
+      reg.rb = r.r_beg + srb;
+      reg.qe = r.q_end + sqb + sl;
+      reg.re = r.r_end + srb + sl;
+      reg.score = r.score; reg.truesc = r.true_score; reg.w = r.width;
+    }
+    int cov = 0; /* computeSeedCoverage, C2AB:891-907 */
+    for (i = 0; i < n_seeds; ++i)
+      if (s_qbeg[i] >= reg.qb && s_qbeg[i] + s_len[i] <= reg.qe && s_rbeg[i] >= reg.rb && s_rbeg[i] + s_len[i] <= reg.re) cov += s_len[i];
+    reg.seedcov = cov;
+    regs[(*n_regs)++] = reg;
+  }
+  free(lq); free(lr); free(srt); free(rseq);
+}
+
+int64_t orc_chain2aln_batch(const orc_opt_t *opt, int zdrop_mode, int64_t l_pac, const uint8_t *pac, int n_reads,
+                            const int32_t *read_len, const int64_t *read_off, const uint8_t *read_pool,
+                            const int32_t *chain_cnt, const int32_t *seed_cnt, const int64_t *seed_rbeg,
+                            const int32_t *seed_qbeg, const int32_t *seed_len, int32_t *out_cnt, orc_alnreg_t *out_regs,
+                            int64_t out_cap, int64_t *n_ext, int64_t *cells) {
+  int64_t total = 0, chain_at = 0, seed_at = 0;
+  int overflow = 0;
+  for (int r = 0; r < n_reads; ++r) {
+    int64_t nseeds = 0;
+    for (int c = 0; c < chain_cnt[r]; ++c) nseeds += seed_cnt[chain_at + c];
+    orc_alnreg_t *regs = (orc_alnreg_t *)malloc(sizeof(orc_alnreg_t) * (size_t)(nseeds > 0 ? nseeds : 1)); /* maxLength, W1B:117 */
+    int n_regs = 0;
+    for (int c = 0; c < chain_cnt[r]; ++c) {
+      const int ns = seed_cnt[chain_at + c];
+      chain2aln(opt, zdrop_mode, l_pac, pac, read_len[r], read_pool + read_off[r], ns, seed_rbeg + seed_at, seed_qbeg + seed_at,
+                seed_len + seed_at, regs, &n_regs, n_ext, cells);
+      seed_at += ns;
+    }
+    chain_at += chain_cnt[r];
+    out_cnt[r] = n_regs;
+    for (int j = 0; j < n_regs; ++j) {
+      if (total < out_cap) out_regs[total] = regs[j]; else overflow = 1;
+      ++total;
+    }
+    free(regs);
+  }
+  return overflow ? -total : total;
+}

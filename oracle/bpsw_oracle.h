@@ -124,6 +124,23 @@ int orc_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist);
 int64_t orc_bns_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t end, uint8_t *out, int64_t cap);
 
 /*
+ * memChainToAlnBatched, C2AB:380-616 (== mem_chain2aln per chain, native/bwamem.c:552-672), for a batch of reads in flat
+ * SoA form.  The Scala walks "one seed per read per round"; per read that is exactly: chains in order, seeds of a chain
+ * from the longest down (srt, C2AB:366-373), testExtension (C2AB:680-741) against every region the read has so far,
+ * checkOverlapping (C2AB:753-787), extension() (C2AB:789-883) on windows cut from bnsGetSeq(rmax) (C2AB:344-364,
+ * getMaxSpan C2AB:648-676), computeSeedCoverage (C2AB:891-907).
+ *   read_len/read_off[n]   : reads (codes 0..4) in read_pool
+ *   chain_cnt[n]           : chains per read;  seed_cnt[sum chain_cnt] : seeds per chain, (read, chain) order
+ *   seed_rbeg/qbeg/len[]   : seeds in (read, chain, seedsRefArray) order
+ *   out_cnt[n], out_regs[] : regions in creation order (regArrays before memSortAndDedup); returns total, or -needed
+ */
+int64_t orc_chain2aln_batch(const orc_opt_t *opt, int zdrop_mode, int64_t l_pac, const uint8_t *pac, int n_reads,
+                            const int32_t *read_len, const int64_t *read_off, const uint8_t *read_pool,
+                            const int32_t *chain_cnt, const int32_t *seed_cnt, const int64_t *seed_rbeg,
+                            const int32_t *seed_qbeg, const int32_t *seed_len, int32_t *out_cnt, orc_alnreg_t *out_regs,
+                            int64_t out_cap, int64_t *n_ext, int64_t *cells);
+
+/*
  * Batched rescue (boundary 1), flat SoA form of the JNI call's arguments.
  *   seq_len/seq_off[2G]     : mate sequences (codes 0..4) in seq_pool, index 2k+i
  *   reg_cnt[2G], regs[]     : existing regions, concatenated in (k,i,j) order

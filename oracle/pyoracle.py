@@ -165,6 +165,22 @@ class Oracle:
         """bnsGetSeq (util/BNTSeqUtil.scala:37-79) -> uint8 bases (empty when the window bridges the strands)"""
         return _get_seq(self.lib.orc_bns_get_seq, l_pac, pac, beg, end)
 
+    def chain2aln_batch(self, opt: Opt, pac, b, zdrop_mode=ZDROP_SCALA):
+        """memChainToAlnBatched (MemChainToAlignBatched.scala:380-616) per read -> (cnt[n], regs, n_ext, cells)"""
+        pac = np.ascontiguousarray(pac, np.uint8)
+        n = int(b.read_len.shape[0])
+        cap = int(b.seed_len.shape[0]) + 8
+        out_cnt = np.zeros(max(n, 1), np.int32)
+        out = np.zeros(cap, ALNREG_DTYPE)
+        n_ext, cells = C.c_int64(0), C.c_int64(0)
+        self.lib.orc_chain2aln_batch.restype = C.c_int64
+        tot = self.lib.orc_chain2aln_batch(C.byref(opt), C.c_int(zdrop_mode), C.c_int64(b.l_pac), _vp(pac), C.c_int(n), _vp(b.read_len),
+                                           _vp(b.read_off), _vp(b.read_pool), _vp(b.chain_cnt), _vp(b.seed_cnt), _vp(b.seed_rbeg),
+                                           _vp(b.seed_qbeg), _vp(b.seed_len), _vp(out_cnt), _vp(out), C.c_int64(cap),
+                                           C.byref(n_ext), C.byref(cells))
+        assert tot >= 0
+        return out_cnt[:n], out[:tot], n_ext.value, cells.value
+
     def sw_global(self, query, target, mat, o_del, e_del, o_ins, e_ins, w):
         q = np.ascontiguousarray(query, np.uint8)
         t = np.ascontiguousarray(target, np.uint8)
@@ -224,6 +240,23 @@ class Ref:
     def bns_get_seq(self, l_pac, pac, beg, end):
         """bns_get_seq (native/bntseq.c:355-376)"""
         return _get_seq(self.lib.ref_bns_get_seq, l_pac, pac, beg, end)
+
+    def chain2aln_batch(self, opt: Opt, pac, b):
+        """mem_chain2aln (native/bwamem.c:552-672) per chain of every read -> (cnt[n], regs)"""
+        ints = np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_unpaired, opt.pen_clip5, opt.pen_clip3,
+                         opt.w, opt.zdrop, opt.T, opt.flag, opt.min_seed_len, opt.max_ins, opt.max_matesw], np.int32)
+        mat = np.array(list(opt.mat), np.int8)
+        pac = np.ascontiguousarray(pac, np.uint8)
+        n = int(b.read_len.shape[0])
+        cap = int(b.seed_len.shape[0]) + 8
+        out_cnt = np.zeros(max(n, 1), np.int32)
+        out = np.zeros(cap, ALNREG_DTYPE)
+        self.lib.ref_chain2aln_batch.restype = C.c_int64
+        tot = self.lib.ref_chain2aln_batch(_vp(ints), _vp(mat), C.c_int64(b.l_pac), _vp(pac), C.c_int(n), _vp(b.read_len),
+                                           _vp(b.read_off), _vp(b.read_pool), _vp(b.chain_cnt), _vp(b.seed_cnt), _vp(b.seed_rbeg),
+                                           _vp(b.seed_qbeg), _vp(b.seed_len), _vp(out_cnt), _vp(out), C.c_int64(cap))
+        assert tot >= 0
+        return out_cnt[:n], out[:tot]
 
     def ksw_extend2(self, query, target, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0):
         q = np.ascontiguousarray(query, np.uint8)

@@ -181,3 +181,48 @@ int64_t ref_bns_get_seq(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t 
   free(seq);
   return len;
 }
+
+/* mem_chain2aln (native/bwamem.c:552-672) over the flat batch layout of orc_chain2aln_batch.  mem_seed_t / mem_chain_t are
+ * private to bwamem.c (lines 167-176); the declarations below restate their layout for the call. */
+typedef struct { int64_t rbeg; int32_t qbeg, len; } shim_seed_t;
+typedef struct { int n, m; int64_t pos; shim_seed_t *seeds; } shim_chain_t;
+void mem_chain2aln(const mem_opt_t *opt, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query, const void *c,
+                   mem_alnreg_v *av);
+int64_t ref_chain2aln_batch(const int32_t ints[16], const int8_t mat[25], int64_t l_pac, const uint8_t *pac, int n_reads,
+                            const int32_t *read_len, const int64_t *read_off, const uint8_t *read_pool,
+                            const int32_t *chain_cnt, const int32_t *seed_cnt, const int64_t *seed_rbeg,
+                            const int32_t *seed_qbeg, const int32_t *seed_len, int32_t *out_cnt, flat_alnreg_t *out_regs,
+                            int64_t out_cap) {
+  mem_opt_t *o = mem_opt_init();
+  o->a = ints[0]; o->b = ints[1]; o->o_del = ints[2]; o->e_del = ints[3]; o->o_ins = ints[4]; o->e_ins = ints[5];
+  o->pen_unpaired = ints[6]; o->pen_clip5 = ints[7]; o->pen_clip3 = ints[8]; o->w = ints[9]; o->zdrop = ints[10];
+  o->T = ints[11]; o->flag = ints[12]; o->min_seed_len = ints[13]; o->max_ins = ints[14]; o->max_matesw = ints[15];
+  memcpy(o->mat, mat, 25);
+  int64_t total = 0, chain_at = 0, seed_at = 0;
+  int overflow = 0;
+  for (int r = 0; r < n_reads; ++r) {
+    mem_alnreg_v av;
+    kv_init(av);
+    for (int c = 0; c < chain_cnt[r]; ++c) {
+      shim_chain_t ch;
+      ch.n = ch.m = seed_cnt[chain_at + c];
+      ch.pos = ch.n > 0 ? seed_rbeg[seed_at] : 0;
+      ch.seeds = (shim_seed_t *)malloc(sizeof(shim_seed_t) * (size_t)(ch.n > 0 ? ch.n : 1));
+      for (int i = 0; i < ch.n; ++i) {
+        ch.seeds[i].rbeg = seed_rbeg[seed_at + i]; ch.seeds[i].qbeg = seed_qbeg[seed_at + i]; ch.seeds[i].len = seed_len[seed_at + i];
+      }
+      mem_chain2aln(o, l_pac, pac, read_len[r], read_pool + read_off[r], &ch, &av);
+      free(ch.seeds);
+      seed_at += ch.n;
+    }
+    chain_at += chain_cnt[r];
+    out_cnt[r] = (int32_t)av.n;
+    for (size_t j = 0; j < av.n; ++j) {
+      if (total < out_cap) memcpy(&out_regs[total], &av.a[j], sizeof(flat_alnreg_t)); else overflow = 1;
+      ++total;
+    }
+    free(av.a);
+  }
+  free(o);
+  return overflow ? -total : total;
+}

@@ -200,3 +200,14 @@ for t in range(400):
 so, sp = pack(seqs)
 np.savez_compressed(os.path.join(HERE, "bns_get_seq.npz"), l_pac=l_pac, pac=pac, beg=np.array(begs, np.int64),
                     end=np.array(ends, np.int64), seq_off=so, seq_pool=sp)
+
+
+# ---- mem_chain2aln (== memChainToAlnBatched per read, MemChainToAlignBatched.scala:380-616; BWA z-drop parse) -------
+l_pac3 = 60_013
+pac3, bases3 = synth.random_pac(l_pac3, seed=20261005)
+cb = synth.read_chains(400, bases3, l_pac3, read_len=150, sub_rate=0.03, indel_rate=0.006, tail_frac=0.08, seed=20261006)
+opt3 = po.Oracle().default_opt()
+cnt3, regs3 = ref.chain2aln_batch(opt3, pac3, cb)
+np.savez_compressed(os.path.join(HERE, "mem_chain2aln.npz"), l_pac=l_pac3, pac=pac3, read_len=cb.read_len, read_off=cb.read_off,
+                    read_pool=cb.read_pool, chain_cnt=cb.chain_cnt, seed_cnt=cb.seed_cnt, seed_rbeg=cb.seed_rbeg,
+                    seed_qbeg=cb.seed_qbeg, seed_len=cb.seed_len, out_cnt=cnt3, out_regs=regs3)

@@ -144,3 +144,21 @@ def test_bns_get_seq_vs_reference_golden(orc):
         assert np.array_equal(got, w)
         n_empty += int(len(w) == 0)
     assert 0 < n_empty < len(want) // 3   # the bridging windows (and a few empty ones) return nothing
+
+
+def _chain_batch(z):
+    from bpsw_hip import ChainBatchSoA
+    return ChainBatchSoA(l_pac=int(z["l_pac"]), read_len=z["read_len"], read_off=z["read_off"], read_pool=z["read_pool"],
+                         chain_cnt=z["chain_cnt"], seed_cnt=z["seed_cnt"], seed_rbeg=z["seed_rbeg"], seed_qbeg=z["seed_qbeg"],
+                         seed_len=z["seed_len"])
+
+
+def test_chain2aln_vs_mem_chain2aln_golden(orc):
+    """memChainToAlnBatched restatement against mem_chain2aln outputs of the reference C (BWA z-drop parse)"""
+    z = np.load(os.path.join(G, "mem_chain2aln.npz"))
+    b = _chain_batch(z)
+    cnt, regs, n_ext, _ = orc.chain2aln_batch(orc.default_opt(), z["pac"], b, po.ZDROP_BWA)
+    assert np.array_equal(cnt, z["out_cnt"])
+    for f in regs.dtype.names:
+        assert np.array_equal(regs[f], z["out_regs"][f]), f
+    assert n_ext > 300 and len(regs) < len(b.seed_len)       # extensions ran; contained seeds were skipped

@@ -63,3 +63,16 @@ def test_bns_get_seq_live(orc, ref):
         if t % 9 == 0:
             b, e = e, b
         assert np.array_equal(orc.bns_get_seq(l_pac, pac, b, e), ref.bns_get_seq(l_pac, pac, b, e))
+
+
+def test_chain2aln_live(orc, ref):
+    l_pac = 400_009
+    pac, bases = synth.random_pac(l_pac, seed=61)
+    for L, es, ei, tail in ((150, 0.01, 0.001, 0.0), (250, 0.08, 0.02, 0.05), (100, 0.04, 0.01, 0.2)):
+        b = synth.read_chains(1500, bases, l_pac, read_len=L, sub_rate=es, indel_rate=ei, tail_frac=tail, seed=62 + L)
+        cnt, regs, n_ext, _ = orc.chain2aln_batch(orc.default_opt(), pac, b, po.ZDROP_BWA)
+        rcnt, rregs = ref.chain2aln_batch(orc.default_opt(), pac, b)
+        assert np.array_equal(cnt, rcnt)
+        for f in regs.dtype.names:
+            assert np.array_equal(regs[f], rregs[f]), (L, f)
+        assert n_ext > 1000
