@@ -35,6 +35,7 @@ JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI",
     "Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld",
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI",   # new entry for SURVEY.md 8f.2
+    "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI",   # new entry for SURVEY.md 8f.3
 ]
 
 

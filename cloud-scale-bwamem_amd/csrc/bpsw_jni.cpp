@@ -4,6 +4,8 @@
 //   Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI  replaces jni_fpga/sw_extend_fpga.c:116-193
 //   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI              replaces native/jni_mate_sw.c:58-662
 //   Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld            replaces native/jni_hello_world.c:23-26
+//   Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI    NEW: the whole round loop of
+//                                                                  memChainToAlnBatched in one call, primitive arrays only
 //   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI             NEW (needs one line of Scala, see
 //                                                                  INTEGRATION.md): puts the 2-bit reference on every
 //                                                                  visible device; mateSWJNI then accepts RefSWType
@@ -372,6 +374,88 @@ JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI(JNIEnv
     ++loaded;
   }
   return loaded;
+}
+
+// ---- the whole memChainToAlnBatched round loop in one call -------------------------------------
+// Scala side (jni/SWExtendFPGAJNI.scala, next to swExtendFPGAJNI):
+//   @native def chainToAlnJNI(optInts: Array[Int], mat: Array[Byte], readLen: Array[Int], reads: Array[Byte],
+//                             chainCnt: Array[Int], seedCnt: Array[Int], seedRBeg: Array[Long], seedQBeg: Array[Int],
+//                             seedLen: Array[Int]): Array[Long]
+// optInts = (a, b, oDel, eDel, oIns, eIns, penClip5, penClip3, w, zdrop); reads = the reads back to back (codes 0..4).
+// Result: n longs (regions per read) followed by 8 longs per region in (read, creation) order:
+//   rBeg, rEnd, qBeg, qEnd, score, trueScore, width, seedCov     (what memChainToAlnBatched leaves in regArrays).
+// Needs loadPacJNI first.  BPSW_ZDROP=bwa selects the BWA z-drop parse, default is the Scala one (SWUtil.scala:194-199).
+JNIEXPORT jlongArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI(
+    JNIEnv* env, jobject, jintArray optInts, jbyteArray matArr, jintArray readLenArr, jbyteArray readsArr, jintArray chainCntArr,
+    jintArray seedCntArr, jlongArray seedRBegArr, jintArray seedQBegArr, jintArray seedLenArr) {
+  if (!optInts || !matArr || !readLenArr || !readsArr || !chainCntArr || !seedCntArr || !seedRBegArr || !seedQBegArr || !seedLenArr ||
+      jni::GetArrayLength(env, optInts) < 10 || jni::GetArrayLength(env, matArr) < 25) {
+    throw_runtime(env, "bPSW: chainToAlnJNI: bad arguments");
+    return nullptr;
+  }
+  bpsw_opt_t opt;
+  bpsw_opt_default(&opt);
+  jint oi[10];
+  jni::GetIntArrayRegion(env, optInts, 0, 10, oi);
+  opt.a = oi[0]; opt.b = oi[1]; opt.o_del = oi[2]; opt.e_del = oi[3]; opt.o_ins = oi[4]; opt.e_ins = oi[5];
+  opt.pen_clip5 = oi[6]; opt.pen_clip3 = oi[7]; opt.w = oi[8]; opt.zdrop = oi[9];
+  jni::GetByteArrayRegion(env, matArr, 0, 25, reinterpret_cast<jbyte*>(opt.mat));
+  const jsize n = jni::GetArrayLength(env, readLenArr);
+  if (jni::GetArrayLength(env, chainCntArr) < n) { throw_runtime(env, "bPSW: chainToAlnJNI: chainCnt shorter than readLen"); return nullptr; }
+  std::vector<int32_t> read_len((size_t)n), chain_cnt((size_t)n);
+  if (n) { jni::GetIntArrayRegion(env, readLenArr, 0, n, read_len.data()); jni::GetIntArrayRegion(env, chainCntArr, 0, n, chain_cnt.data()); }
+  std::vector<int64_t> read_off((size_t)n);
+  int64_t at = 0, nchains = 0;
+  for (jsize r = 0; r < n; ++r) {
+    if (read_len[(size_t)r] < 0 || chain_cnt[(size_t)r] < 0) { throw_runtime(env, "bPSW: chainToAlnJNI: negative length or count"); return nullptr; }
+    read_off[(size_t)r] = at; at += read_len[(size_t)r]; nchains += chain_cnt[(size_t)r];
+  }
+  const jsize pool_bytes = jni::GetArrayLength(env, readsArr);
+  if ((int64_t)pool_bytes < at || (int64_t)jni::GetArrayLength(env, seedCntArr) < nchains) { throw_runtime(env, "bPSW: chainToAlnJNI: reads or seedCnt too short"); return nullptr; }
+  std::vector<uint8_t> pool((size_t)pool_bytes + 16);
+  if (pool_bytes) jni::GetByteArrayRegion(env, readsArr, 0, pool_bytes, reinterpret_cast<jbyte*>(pool.data()));
+  std::vector<int32_t> seed_cnt((size_t)nchains + 1);
+  if (nchains) jni::GetIntArrayRegion(env, seedCntArr, 0, (jsize)nchains, seed_cnt.data());
+  int64_t nseeds = 0;
+  for (int64_t k = 0; k < nchains; ++k) {
+    if (seed_cnt[(size_t)k] < 0) { throw_runtime(env, "bPSW: chainToAlnJNI: negative seed count"); return nullptr; }
+    nseeds += seed_cnt[(size_t)k];
+  }
+  if ((int64_t)jni::GetArrayLength(env, seedRBegArr) < nseeds || (int64_t)jni::GetArrayLength(env, seedQBegArr) < nseeds ||
+      (int64_t)jni::GetArrayLength(env, seedLenArr) < nseeds) { throw_runtime(env, "bPSW: chainToAlnJNI: seed arrays too short"); return nullptr; }
+  std::vector<int64_t> seed_rbeg((size_t)nseeds + 1);
+  std::vector<int32_t> seed_qbeg((size_t)nseeds + 1), seed_len((size_t)nseeds + 1);
+  if (nseeds) {
+    jni::GetLongArrayRegion(env, seedRBegArr, 0, (jsize)nseeds, (jlong*)seed_rbeg.data());
+    jni::GetIntArrayRegion(env, seedQBegArr, 0, (jsize)nseeds, seed_qbeg.data());
+    jni::GetIntArrayRegion(env, seedLenArr, 0, (jsize)nseeds, seed_len.data());
+  }
+  bpsw_chains_t b;
+  memset(&b, 0, sizeof b);
+  b.n_reads = n; b.read_len = read_len.data(); b.read_off = read_off.data(); b.read_pool = pool.data(); b.read_pool_bytes = (size_t)pool_bytes;
+  b.chain_cnt = chain_cnt.data(); b.seed_cnt = seed_cnt.data(); b.seed_rbeg = seed_rbeg.data(); b.seed_qbeg = seed_qbeg.data(); b.seed_len = seed_len.data();
+  bpsw_ctx_t* ctx = thread_context(env);
+  if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
+  std::vector<int32_t> out_cnt((size_t)n + 1);
+  std::vector<bpsw_alnreg_t> out((size_t)nseeds + 1);
+  int64_t total = 0;
+  const char* zd = getenv("BPSW_ZDROP");
+  const int zmode = (zd && strcmp(zd, "bwa") == 0) ? BPSW_ZDROP_BWA : BPSW_ZDROP_SCALA;
+  if (bpsw_chain2aln_batch(ctx, &opt, &b, zmode, 0, out_cnt.data(), out.data(), (int64_t)out.size(), &total) != BPSW_OK) {
+    throw_runtime(env, std::string("bPSW: chainToAlnJNI: ") + bpsw_last_error());
+    return nullptr;
+  }
+  std::vector<jlong> flat((size_t)n + 8 * (size_t)total);
+  for (jsize r = 0; r < n; ++r) flat[(size_t)r] = out_cnt[(size_t)r];
+  for (int64_t k = 0; k < total; ++k) {
+    jlong* o = flat.data() + (size_t)n + 8 * (size_t)k;
+    const bpsw_alnreg_t& g = out[(size_t)k];
+    o[0] = g.rb; o[1] = g.re; o[2] = g.qb; o[3] = g.qe; o[4] = g.score; o[5] = g.truesc; o[6] = g.w; o[7] = g.seedcov;
+  }
+  jlongArray ret = jni::NewLongArray(env, (jsize)flat.size());
+  if (!ret) return nullptr;  // OutOfMemoryError already pending
+  if (!flat.empty()) jni::SetLongArrayRegion(env, ret, 0, (jsize)flat.size(), flat.data());
+  return ret;
 }
 
 }  // extern "C"

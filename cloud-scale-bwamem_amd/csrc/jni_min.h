@@ -70,10 +70,12 @@ enum {
   JNI_SLOT_GetObjectArrayElement = 173,
   JNI_SLOT_SetObjectArrayElement = 174,
   JNI_SLOT_NewShortArray = 178,
+  JNI_SLOT_NewLongArray = 180,
   JNI_SLOT_GetByteArrayRegion = 200,
   JNI_SLOT_GetIntArrayRegion = 203,
   JNI_SLOT_GetLongArrayRegion = 204,
   JNI_SLOT_SetShortArrayRegion = 210,
+  JNI_SLOT_SetLongArrayRegion = 212,
   JNI_SLOT_ExceptionCheck = 228,
   JNI_SLOT_COUNT = 233
 };
@@ -115,6 +117,8 @@ inline jobjectArray NewObjectArray(JNIEnv* e, jsize n, jclass c, jobject init) {
 inline jobject GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { return fn<jobject (*)(JNIEnv*, jobjectArray, jsize)>(e, JNI_SLOT_GetObjectArrayElement)(e, a, i); }
 inline void SetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i, jobject v) { fn<void (*)(JNIEnv*, jobjectArray, jsize, jobject)>(e, JNI_SLOT_SetObjectArrayElement)(e, a, i, v); }
 inline jshortArray NewShortArray(JNIEnv* e, jsize n) { return fn<jshortArray (*)(JNIEnv*, jsize)>(e, JNI_SLOT_NewShortArray)(e, n); }
+inline jlongArray NewLongArray(JNIEnv* e, jsize n) { return fn<jlongArray (*)(JNIEnv*, jsize)>(e, JNI_SLOT_NewLongArray)(e, n); }
+inline void SetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, const jlong* b) { fn<void (*)(JNIEnv*, jlongArray, jsize, jsize, const jlong*)>(e, JNI_SLOT_SetLongArrayRegion)(e, a, s, l, b); }
 inline void GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, jbyte* b) { fn<void (*)(JNIEnv*, jbyteArray, jsize, jsize, jbyte*)>(e, JNI_SLOT_GetByteArrayRegion)(e, a, s, l, b); }
 inline void GetIntArrayRegion(JNIEnv* e, jintArray a, jsize s, jsize l, jint* b) { fn<void (*)(JNIEnv*, jintArray, jsize, jsize, jint*)>(e, JNI_SLOT_GetIntArrayRegion)(e, a, s, l, b); }
 inline void GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, jlong* b) { fn<void (*)(JNIEnv*, jlongArray, jsize, jsize, jlong*)>(e, JNI_SLOT_GetLongArrayRegion)(e, a, s, l, b); }

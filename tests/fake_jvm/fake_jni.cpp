@@ -122,6 +122,12 @@ jshortArray f_NewShortArray(JNIEnv*, jsize n) {
   a->shorts.assign((size_t)n, 0);
   return J(a);
 }
+jlongArray f_NewLongArray(JNIEnv*, jsize n) {
+  FObj* a = g_vm->alloc("[J");
+  a->la.assign((size_t)n, 0);
+  return (jlongArray)J(a);
+}
+void f_SetLongArrayRegion(JNIEnv*, jlongArray a, jsize s, jsize l, const jlong* b) { memcpy(O(a)->la.data() + s, b, 8 * (size_t)l); }
 void f_GetByteArrayRegion(JNIEnv*, jbyteArray a, jsize s, jsize l, jbyte* b) { memcpy(b, O(a)->bytes.data() + s, (size_t)l); }
 void f_GetIntArrayRegion(JNIEnv*, jintArray a, jsize s, jsize l, jint* b) { memcpy(b, O(a)->ia.data() + s, 4 * (size_t)l); }
 void f_GetLongArrayRegion(JNIEnv*, jlongArray a, jsize s, jsize l, jlong* b) { memcpy(b, O(a)->la.data() + s, 8 * (size_t)l); }
@@ -143,7 +149,7 @@ struct Env {
     SET(GetFloatField); SET(GetDoubleField); SET(SetObjectField); SET(SetIntField); SET(SetLongField); SET(GetMethodID);
     SET(GetStaticMethodID); SET(CallStaticObjectMethod); SET(CallIntMethod); SET(GetArrayLength); SET(NewObjectArray);
     SET(GetObjectArrayElement); SET(SetObjectArrayElement); SET(NewShortArray); SET(GetByteArrayRegion);
-    SET(GetIntArrayRegion); SET(GetLongArrayRegion); SET(SetShortArrayRegion);
+    SET(GetIntArrayRegion); SET(GetLongArrayRegion); SET(SetShortArrayRegion); SET(NewLongArray); SET(SetLongArrayRegion);
 #undef SET
     env = &table;
   }
@@ -152,6 +158,17 @@ struct Env {
 FObj* byte_array(const uint8_t* p, size_t n) {
   FObj* a = g_vm->alloc("[B");
   a->bytes.assign(reinterpret_cast<const int8_t*>(p), reinterpret_cast<const int8_t*>(p) + n);
+  return a;
+}
+
+FObj* int_array(const int32_t* p, size_t n) {
+  FObj* a = g_vm->alloc("[I");
+  a->ia.assign(p, p + n);
+  return a;
+}
+FObj* long_array(const int64_t* p, size_t n) {
+  FObj* a = g_vm->alloc("[J");
+  a->la.assign(p, p + n);
   return a;
 }
 
@@ -300,6 +317,39 @@ int fake_jvm_matesw(const char* lib, int partition, const int32_t opt_ints[16], 
     o.csub = (int32_t)a->ints["csub"]; o.sub_n = (int32_t)a->ints["subNum"]; o.w = (int32_t)a->ints["width"];
     o.seedcov = (int32_t)a->ints["seedCov"]; o.secondary = (int32_t)a->ints["secondary"]; o.hash = (uint64_t)a->ints["hash"];
   }
+  return 0;
+}
+
+// loadPacJNI, then chainToAlnJNI with primitive arrays (reads back to back).  out receives the returned
+// long[] (n counts, then 8 longs per region); *out_n its length.
+int fake_jvm_chain2aln(const char* lib, int partition, const uint8_t* pac, int64_t l_pac, const int32_t opt_ints[10],
+                       const int8_t mat[25], int n_reads, const int32_t* read_len, const uint8_t* reads, int64_t reads_bytes,
+                       const int32_t* chain_cnt, int64_t n_chains, const int32_t* seed_cnt, int64_t n_seeds, const int64_t* seed_rbeg,
+                       const int32_t* seed_qbeg, const int32_t* seed_len, int64_t* out, int64_t out_cap, int64_t* out_n, char* err,
+                       int errcap) {
+  Jvm vm;
+  g_vm = &vm;
+  vm.partition = partition;
+  Env e;
+  typedef jint (*LoadFn)(JNIEnv*, jobject, jbyteArray, jlong);
+  LoadFn load = (LoadFn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI", err, (size_t)errcap);
+  if (!load) return -1;
+  load(&e.env, J(vm.alloc("cs/ucla/edu/bwaspark/jni/MateSWJNI")), (jbyteArray)J(byte_array(pac, (size_t)((l_pac + 3) / 4))), (jlong)l_pac);
+  if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+  typedef jlongArray (*Fn)(JNIEnv*, jobject, jintArray, jbyteArray, jintArray, jbyteArray, jintArray, jintArray, jlongArray, jintArray, jintArray);
+  Fn fn = (Fn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI", err, (size_t)errcap);
+  if (!fn) return -1;
+  FObj* self = vm.alloc("cs/ucla/edu/bwaspark/jni/SWExtendFPGAJNI");
+  jlongArray r = fn(&e.env, J(self), (jintArray)J(int_array(opt_ints, 10)), (jbyteArray)J(byte_array(reinterpret_cast<const uint8_t*>(mat), 25)),
+                    (jintArray)J(int_array(read_len, (size_t)n_reads)), (jbyteArray)J(byte_array(reads, (size_t)reads_bytes)),
+                    (jintArray)J(int_array(chain_cnt, (size_t)n_reads)), (jintArray)J(int_array(seed_cnt, (size_t)n_chains)),
+                    (jlongArray)J(long_array(seed_rbeg, (size_t)n_seeds)), (jintArray)J(int_array(seed_qbeg, (size_t)n_seeds)),
+                    (jintArray)J(int_array(seed_len, (size_t)n_seeds)));
+  if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+  if (!r) { snprintf(err, (size_t)errcap, "null result"); return -1; }
+  *out_n = (int64_t)O(r)->la.size();
+  if (*out_n > out_cap) { snprintf(err, (size_t)errcap, "out_cap too small"); return -1; }
+  memcpy(out, O(r)->la.data(), 8 * (size_t)*out_n);
   return 0;
 }
 

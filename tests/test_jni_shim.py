@@ -109,3 +109,32 @@ def test_matesw_through_jni_with_reference_on_device(fake, ctx):
     assert np.array_equal(cnt, want_cnt)
     region_fields_equal(regs, want)
     assert regs.shape[0] > g.regs.shape[0]
+
+
+@pytest.mark.gpu
+def test_chain2aln_through_jni_matches_c_abi(fake, ctx):
+    """SURVEY.md 8f.3 through the JNI surface: loadPacJNI + chainToAlnJNI (primitive arrays only)"""
+    l_pac = 300_007
+    pac, bases = synth.random_pac(l_pac, seed=81)
+    b = synth.read_chains(600, bases, l_pac, read_len=150, sub_rate=0.02, indel_rate=0.004, seed=82)
+    ctx.ref_load(pac, l_pac)
+    opt = bpsw_hip.default_opt()
+    want_cnt, want = ctx.chain2aln_batch(opt, b)
+    reads = np.concatenate([b.read_pool[o:o + n] for o, n in zip(b.read_off, b.read_len)])   # back to back, as the Scala side sends them
+    ints = np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_clip5, opt.pen_clip3, opt.w, opt.zdrop], np.int32)
+    mat = np.array(list(opt.mat), np.int8)
+    out = np.zeros(b.n_reads + 8 * len(b.seed_len) + 8, np.int64)
+    out_n = C.c_int64(0)
+    err = C.create_string_buffer(512)
+    fake.fake_jvm_chain2aln.restype = C.c_int
+    rc = fake.fake_jvm_chain2aln(bpsw_hip.LIB_PATH.encode(), 2, _vp(pac), C.c_int64(l_pac), _vp(ints), _vp(mat), b.n_reads, _vp(b.read_len),
+                                 _vp(reads), C.c_int64(reads.size), _vp(b.chain_cnt), C.c_int64(len(b.seed_cnt)), _vp(b.seed_cnt),
+                                 C.c_int64(len(b.seed_len)), _vp(b.seed_rbeg), _vp(b.seed_qbeg), _vp(b.seed_len), _vp(out),
+                                 C.c_int64(out.size), C.byref(out_n), err, 512)
+    assert rc == 0, err.value.decode()
+    n = b.n_reads
+    assert out_n.value == n + 8 * len(want)
+    assert np.array_equal(out[:n], want_cnt)
+    flat = out[n:out_n.value].reshape(-1, 8)
+    for k, f in enumerate(("rb", "re", "qb", "qe", "score", "truesc", "w", "seedcov")):
+        assert np.array_equal(flat[:, k], want[f].astype(np.int64)), f
