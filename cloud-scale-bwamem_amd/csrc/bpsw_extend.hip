@@ -16,6 +16,8 @@
 // (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "bpsw_extend_core.h"
 
 namespace bpsw {
@@ -197,12 +199,16 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   const size_t per_wave = ext_lds_per_wave(qcap, rcap);
   const size_t lds = per_wave * WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static thread_local size_t attr_set = 0;
-  if (lds > 64 * 1024 && lds > attr_set) {
+  // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device
+  static std::atomic<size_t> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (lds > 64 * 1024 && lds > attr_set[dev].load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ext_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = lds;
+    size_t seen = attr_set[dev].load(std::memory_order_relaxed);
+    while (seen < lds && !attr_set[dev].compare_exchange_weak(seen, lds, std::memory_order_relaxed)) {}
   }
   // resident workgroups per CU: 8 waves/SIMD = 8 blocks of 4 waves, capped by LDS
   int per_cu = (int)((160 * 1024) / (lds ? lds : 1));

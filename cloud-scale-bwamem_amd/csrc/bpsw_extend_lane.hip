@@ -18,6 +18,8 @@
 // ext_kernel through the fallback list.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "bpsw_internal.h"
 
 namespace bpsw {
@@ -289,12 +291,16 @@ hipError_t launch_ext_lane_kernel(const uint32_t* d_wire, const int* d_list, int
   max_qsum = (max_qsum + 15) & ~15;
   const size_t lds = ext_lane_lds_bytes(max_side - 1, max_qsum);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static thread_local size_t attr_set = 0;
-  if (lds > 64 * 1024 && lds > attr_set) {
+  // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device
+  static std::atomic<size_t> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (lds > 64 * 1024 && lds > attr_set[dev].load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ext_lane_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = lds;
+    size_t seen = attr_set[dev].load(std::memory_order_relaxed);
+    while (seen < lds && !attr_set[dev].compare_exchange_weak(seen, lds, std::memory_order_relaxed)) {}
   }
   const int blocks = (n_list + 63) / 64;
   hipLaunchKernelGGL(ext_lane_kernel, dim3(blocks), dim3(64), lds, s, d_wire, d_list, n_list, d_out, sc, max_side);

@@ -349,7 +349,7 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   }
   HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
   if (ext_lane_enabled()) lane_sort_enqueue(c, (const uint32_t*)d_wire, n_tasks, s);
-  else launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
+  else if (ext_qt_enabled()) launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
