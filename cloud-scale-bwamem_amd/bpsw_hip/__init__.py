@@ -415,6 +415,15 @@ class ChainBatchSoA:
     def n_reads(self) -> int:
         return int(self.read_len.shape[0])
 
+    def slice(self, lo: int, hi: int) -> "ChainBatchSoA":
+        """reads lo..hi-1 with their chains and seeds (the read pool is shared, offsets stay valid)"""
+        c0, c1 = int(self.chain_cnt[:lo].sum()), int(self.chain_cnt[:hi].sum())
+        s0, s1 = int(self.seed_cnt[:c0].sum()), int(self.seed_cnt[:c1].sum())
+        cp = np.ascontiguousarray
+        return ChainBatchSoA(l_pac=self.l_pac, read_len=cp(self.read_len[lo:hi]), read_off=cp(self.read_off[lo:hi]),
+                             read_pool=self.read_pool, chain_cnt=cp(self.chain_cnt[lo:hi]), seed_cnt=cp(self.seed_cnt[c0:c1]),
+                             seed_rbeg=cp(self.seed_rbeg[s0:s1]), seed_qbeg=cp(self.seed_qbeg[s0:s1]), seed_len=cp(self.seed_len[s0:s1]))
+
 
 @dataclass
 class RescueGroupSoA:

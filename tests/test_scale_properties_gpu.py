@@ -80,3 +80,34 @@ def test_swalign_full_size_properties(ctx, orc):
         sub[k] = jobs[k][pick]
     want, _ = orc.sw_align2_jobs(orc.default_opt(), xtra, **sub)
     assert np.array_equal(want, a[pick])
+
+
+def test_chain2aln_full_size_properties(ctx, orc):
+    """The on-device round loop at 100 k reads: independence of how the reads are batched, determinism,
+    structural invariants of every region, and oracle parity on a sample."""
+    l_pac = 4_000_037
+    pac, bases = synth.random_pac(l_pac, seed=101)
+    ctx.ref_load(pac, l_pac)
+    n = 100_000
+    b = synth.read_chains(n, bases, l_pac, read_len=150, sub_rate=0.01, indel_rate=0.001, seed=102)
+    opt = bpsw_hip.default_opt()
+    cnt, regs = ctx.chain2aln_batch(opt, b)
+    cnt2, regs2 = ctx.chain2aln_batch(opt, b)
+    assert np.array_equal(cnt, cnt2) and np.array_equal(regs, regs2)                     # deterministic
+    parts = [ctx.chain2aln_batch(opt, b.slice(lo, min(lo + 32768, n))) for lo in range(0, n, 32768)]
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), cnt)                    # batching does not matter
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), regs)
+    assert int(cnt.sum()) == regs.shape[0] <= b.seed_len.shape[0]
+    assert (regs["qb"] >= 0).all() and (regs["qe"] <= 150).all() and (regs["qb"] < regs["qe"]).all()
+    assert (regs["rb"] < regs["re"]).all() and (regs["rb"] >= 0).all() and (regs["re"] <= 2 * l_pac).all()
+    assert ((regs["rb"] < l_pac) == (regs["re"] <= l_pac)).all()                          # a region stays on one strand
+    assert (regs["score"] >= 19).all() and (regs["truesc"] <= regs["score"] + 5).all()    # seed score; to-end bonus pen_clip
+    assert (regs["seedcov"] >= 19).all()
+    lo = 41_000
+    sub = b.slice(lo, lo + 3000)
+    want_cnt, want, _, _ = orc.chain2aln_batch(orc.default_opt(), pac, sub)
+    at = int(cnt[:lo].sum())
+    assert np.array_equal(cnt[lo:lo + 3000], want_cnt)
+    got = regs[at:at + int(want_cnt.sum())]
+    for f in want.dtype.names:
+        assert np.array_equal(got[f], want[f]), f
