@@ -14,7 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libbPSW_hip.so")
+# BPSW_LIB: load another build of the same library (kernel experiments: tools/build_variant.sh)
+LIB_PATH = os.environ.get("BPSW_LIB") or os.path.join(PKG_ROOT, "lib", "libbPSW_hip.so")
 SYNTH_PATH = os.path.join(PKG_ROOT, "lib", "libbpsw_synth.so")
 
 BPSW_OK = 0
