@@ -464,3 +464,45 @@ class RescueGroupSoA:
         g.seq_pool_bytes = self.seq_pool.size
         g.ref_pool_bytes = self.ref_pool.size if self.ref_pool is not None else 0
         return g
+
+
+@dataclass
+class TailGroupSoA:
+    """What worker2's tail (memSamPeGroupRest, MemSamPe.scala:1390-1612) works on, flat: a group of pairs with the region
+    lists of both ends after the rescue, the reads with names and qualities, and the contig table of the reference."""
+    group_size: int
+    l_pac: int
+    id0: int               # pair id of the first pair (the reference hashes id + k)
+    pes: list              # 4 x (low, high, failed, avg, std)
+    read_len: np.ndarray   # int32 [2G], (pair, end) order
+    read_off: np.ndarray   # int64 [2G]
+    read_pool: np.ndarray  # uint8 codes 0..4
+    qual_pool: np.ndarray | None  # uint8 ASCII, same offsets as read_pool
+    name_off: np.ndarray   # int64 [G+1]
+    name_pool: np.ndarray  # uint8
+    reg_cnt: np.ndarray    # int32 [2G]
+    regs: np.ndarray       # ALNREG_DTYPE, (pair, end, j) order
+    ann_off: np.ndarray    # int64 [n_seqs]   bntann1_t.offset
+    ann_len: np.ndarray    # int32 [n_seqs]   bntann1_t.len
+    ann_name_off: np.ndarray  # int64 [n_seqs+1]
+    ann_name_pool: np.ndarray  # uint8
+
+
+def make_tail_group(chain_batch, names, qual_pool, pes, reg_cnt, regs, ann_off, ann_len, ann_names, id0=0) -> TailGroupSoA:
+    n = chain_batch.n_reads
+    assert n % 2 == 0 and len(names) == n // 2
+
+    def pool(strs):
+        off = np.zeros(len(strs) + 1, np.int64)
+        bs = [s.encode() for s in strs]
+        off[1:] = np.cumsum([len(b) for b in bs])
+        return off, np.frombuffer(b"".join(bs) + b"\0", np.uint8).copy()
+
+    name_off, name_pool = pool(names)
+    a_off, a_pool = pool(ann_names)
+    cp = np.ascontiguousarray
+    return TailGroupSoA(group_size=n // 2, l_pac=int(chain_batch.l_pac), id0=int(id0), pes=list(pes), read_len=cp(chain_batch.read_len),
+                        read_off=cp(chain_batch.read_off), read_pool=cp(chain_batch.read_pool),
+                        qual_pool=None if qual_pool is None else cp(qual_pool, np.uint8), name_off=name_off, name_pool=name_pool,
+                        reg_cnt=cp(reg_cnt, np.int32), regs=cp(regs), ann_off=cp(ann_off, np.int64), ann_len=cp(ann_len, np.int32),
+                        ann_name_off=a_off, ann_name_pool=a_pool)

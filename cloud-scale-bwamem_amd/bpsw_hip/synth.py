@@ -354,3 +354,163 @@ def read_chains(n_reads: int, ref_bases: np.ndarray, l_pac: int, read_len: int =
                          read_pool=np.concatenate(pools) if pools else np.zeros(16, np.uint8),
                          chain_cnt=np.array(chain_cnt, np.int32), seed_cnt=np.array(seed_cnt, np.int32),
                          seed_rbeg=np.array(s_rb, np.int64), seed_qbeg=np.array(s_qb, np.int32), seed_len=np.array(s_len, np.int32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# worker2's tail: pairs with their seed chains over a multi-contig reference
+def contig_reference(contig_lens, seed: int = CONFIG_SEED_BASE + 78, dup_len: int = 1500):
+    """A multi-contig 2-bit reference: (pac, bases, ann_off, ann_len, ann_names, dups).  Each contig but the first also
+    carries a near-copy (0.5 % substitutions) of a `dup_len` stretch of contig 0, so reads drawn from those stretches have
+    more than one hit (sub / sub_n / secondary / the pairing choice of memPair all come alive)."""
+    l_pac = int(sum(contig_lens))
+    pac, bases = random_pac(l_pac, seed)
+    rng = np.random.default_rng(seed + 1)
+    off = np.concatenate([[0], np.cumsum(contig_lens)[:-1]]).astype(np.int64)
+    dups = []  # (src, dst, len)
+    for c in range(1, len(contig_lens)):
+        if contig_lens[0] < 4 * dup_len or contig_lens[c] < 4 * dup_len:
+            continue
+        src = int(rng.integers(dup_len, contig_lens[0] - 2 * dup_len))
+        dst = int(off[c] + rng.integers(dup_len, contig_lens[c] - 2 * dup_len))
+        seg = bases[src:src + dup_len].copy()
+        mut = rng.random(dup_len) < 0.005
+        seg[mut] = (seg[mut] + 1 + rng.integers(0, 3, int(mut.sum()))) & 3
+        bases[dst:dst + dup_len] = seg
+        dups.append((src, dst, dup_len))
+    padded = np.zeros(((l_pac + 3) // 4) * 4, np.uint8)
+    padded[:l_pac] = bases
+    q = padded.reshape(-1, 4)
+    pac = ((q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]).astype(np.uint8)
+    names = [f"ctg{c + 1}" for c in range(len(contig_lens))]
+    return pac, bases, off, np.array(contig_lens, np.int32), names, dups
+
+
+def _seeded_read(rng, ref_bases, l_pac, rb0, L, es, ei, min_seed):
+    """A read copied from doubled-coordinate position rb0 with errors; returns (read, exact-match seeds, pos map)"""
+    seg = window_bases(ref_bases, l_pac, rb0, rb0 + L + 60)
+    read, pos = [], []
+    i = 0
+    while len(read) < L and i < len(seg):
+        u = rng.random()
+        if u < ei / 2:
+            read.append(int(rng.integers(0, 4))); pos.append(-1)
+        elif u < ei:
+            i += 1
+        elif u < ei + es:
+            read.append(int((seg[i] + 1 + rng.integers(0, 3)) & 3)); pos.append(-1); i += 1
+        else:
+            read.append(int(seg[i])); pos.append(i); i += 1
+    while len(read) < L:
+        read.append(int(rng.integers(0, 4))); pos.append(-1)
+    read = np.array(read, np.uint8)
+    seeds = []
+    q = 0
+    while q < L:
+        if pos[q] < 0:
+            q += 1
+            continue
+        e = q
+        while e + 1 < L and pos[e + 1] == pos[e] + 1:
+            e += 1
+        if e + 1 - q >= min_seed:
+            seeds.append((rb0 + pos[q], q, e + 1 - q))
+        q = e + 1
+    return read, seeds
+
+
+def tail_pairs(n_pairs: int, ref_bases: np.ndarray, ann_off, ann_len, dups=(), read_len: int = 150, sub_rate: float = 0.01,
+               indel_rate: float = 0.002, p_unmappable: float = 0.04, p_far: float = 0.05, p_span: float = 0.03,
+               p_dup: float = 0.15, p_decoy: float = 0.15, p_clip: float = 0.1, min_seed: int = 19,
+               seed: int = CONFIG_SEED_BASE + 11):
+    """FR pairs (insert ~ N(400, 50^2)) with the seed chains of both ends, plus names and qualities: what worker2's tail
+    needs once chains have been turned into regions (memChainToAln + memSortAndDedup) and the rescue has run.
+    Returns (ChainBatchSoA over the 2n reads in (pair, end) order, names list, qual_pool aligned with read_pool, pes)."""
+    from . import ChainBatchSoA
+    rng = np.random.default_rng(seed)
+    L = read_len
+    l_pac = int(ann_off[-1] + ann_len[-1])
+    avg, std = 400.0, 50.0
+    low, high = int(avg - 4 * std), int(avg + 4 * std)
+    pes = [(0, 0, 1, 0.0, 0.0), (low, high, 0, avg, std), (0, 0, 1, 0.0, 0.0), (0, 0, 1, 0.0, 0.0)]
+    read_len_a, read_off, pools, quals = [], [], [], []
+    chain_cnt, seed_cnt, s_rb, s_qb, s_len = [], [], [], [], []
+    names = []
+    at = 0
+
+    def add_read(read, chains):
+        nonlocal at
+        read_len_a.append(L); read_off.append(at); pools.append(read)
+        quals.append((33 + rng.integers(2, 41, L)).astype(np.uint8))
+        pad = (-L) % 16
+        if pad:
+            pools.append(np.zeros(pad, np.uint8)); quals.append(np.full(pad, 33, np.uint8))
+        at += L + pad
+        chain_cnt.append(len(chains))
+        for ch in chains:
+            seed_cnt.append(len(ch))
+            for rb, qb, ln in ch:
+                s_rb.append(rb); s_qb.append(qb); s_len.append(ln)
+
+    for k in range(n_pairs):
+        names.append(f"pair{seed & 0xffff}_{k}")
+        ins = int(np.clip(rng.normal(avg, std), low + 20, high - 20))
+        u = rng.random()
+        if u < p_span and len(ann_off) > 1:      # the fragment straddles a contig boundary (bwaFixXref2)
+            c = int(rng.integers(1, len(ann_off)))
+            P = int(ann_off[c]) - int(rng.integers(10, ins - 10))
+        elif u < p_span + p_dup and dups:        # inside a duplicated stretch: two candidate loci
+            src, dst, dl = dups[int(rng.integers(0, len(dups)))]
+            P = (src if rng.random() < 0.5 else dst) + int(rng.integers(0, max(1, dl - ins)))
+        else:
+            c = int(rng.integers(0, len(ann_off)))
+            P = int(ann_off[c]) + int(rng.integers(0, max(1, int(ann_len[c]) - ins)))
+        P = max(0, min(P, l_pac - ins - 70))
+        P2 = P
+        if rng.random() < p_far:                 # improper pair: the mate comes from somewhere else
+            P2 = int(rng.integers(0, l_pac - ins - 70))
+        fwd_rb = P                               # forward-strand end starts at P
+        rev_rb = 2 * l_pac - (P2 + ins)          # reverse-strand end, doubled coordinates
+        ends = [fwd_rb, rev_rb] if rng.random() < 0.5 else [rev_rb, fwd_rb]
+        for i in range(2):
+            if rng.random() < p_unmappable:
+                add_read(rng.integers(0, 4, L).astype(np.uint8), [])
+                continue
+            read, seeds = _seeded_read(rng, ref_bases, l_pac, ends[i], L, sub_rate, indel_rate, min_seed)
+            if rng.random() < p_clip:            # an unrelated tail: soft clipping on one side
+                cut = int(rng.integers(15, 50))
+                if rng.random() < 0.5:
+                    read[:cut] = rng.integers(0, 4, cut)
+                    seeds = [(rb + max(0, cut - qb), max(qb, cut), ln - max(0, cut - qb)) for rb, qb, ln in seeds if qb + ln - cut >= min_seed]
+                else:
+                    read[L - cut:] = rng.integers(0, 4, cut)
+                    seeds = [(rb, qb, min(ln, L - cut - qb)) for rb, qb, ln in seeds if min(ln, L - cut - qb) >= min_seed]
+            if rng.random() < 0.02:              # an N: no seed may cover it
+                pn = int(rng.integers(0, L))
+                read[pn] = 4
+                seeds = [(rb, qb, ln) for rb, qb, ln in seeds if not (qb <= pn < qb + ln)]
+            chains = [sorted(seeds, key=lambda t: (t[1], t[0]))] if seeds else []
+            # the other copy of a duplicated stretch: seeds that are exact there too
+            for src, dst, dl in dups:
+                for a, b in ((src, dst), (dst, src)):
+                    fpos = ends[i] if ends[i] < l_pac else 2 * l_pac - ends[i] - L
+                    if a <= fpos and fpos + L <= a + dl and seeds:
+                        shift = b - a
+                        alt = []
+                        for rb, qb, ln in seeds:
+                            rb2 = rb + shift if rb < l_pac else rb - shift
+                            w1 = window_bases(ref_bases, l_pac, rb2, rb2 + ln)
+                            if len(w1) == ln and np.array_equal(w1, read[qb:qb + ln]):
+                                alt.append((rb2, qb, ln))
+                        if alt:
+                            chains.append(alt)
+            if rng.random() < p_decoy:
+                lo2, hi2 = (l_pac + 600, 2 * l_pac - L - 600) if rng.random() < 0.5 else (600, l_pac - L - 600)
+                rbd = int(rng.integers(lo2, hi2))
+                qb = int(rng.integers(0, L - 30))
+                chains.append([(rbd + qb, qb, int(rng.integers(min_seed, 30)))])
+            add_read(read, chains)
+    b = ChainBatchSoA(l_pac=l_pac, read_len=np.array(read_len_a, np.int32), read_off=np.array(read_off, np.int64),
+                      read_pool=np.concatenate(pools), chain_cnt=np.array(chain_cnt, np.int32),
+                      seed_cnt=np.array(seed_cnt, np.int32), seed_rbeg=np.array(s_rb, np.int64),
+                      seed_qbeg=np.array(s_qb, np.int32), seed_len=np.array(s_len, np.int32))
+    return b, names, np.concatenate(quals), pes

@@ -158,6 +158,40 @@ int64_t orc_matesw_group(const orc_opt_t *opt, int64_t l_pac, const orc_pestat_t
                          const int64_t *ref_off, const uint8_t *ref_pool, int mode, int32_t *out_cnt,
                          orc_alnreg_t *out_regs, int64_t out_cap, int64_t *n_sw, int64_t *cells);
 
+/* ---- worker2's tail (bpsw_oracle_tail.c): mark-primary, pairing, mapQ, memRegToAln, SAM text ------------------------ */
+#define ORC_TAIL_SCALA 0 /* the Scala text: MemMarkPrimarySe.scala, MemSamPe.scala:462-572,1390-1612, MemRegToADAMSAM.scala */
+#define ORC_TAIL_C 1     /* the BWA C it was transcribed from: native/bwamem.c, native/bwamem_pair.c, native/bwa.c */
+
+typedef struct {
+  float mask_level, mapq_coef_len; /* MemOptType.scala:47,51 */
+  int32_t mapq_coef_fac;           /* :52 */
+  int32_t pad_;
+} orc_tail_opt_t;
+void orc_tail_opt_default(orc_tail_opt_t *t);
+
+typedef struct { /* datatype/MemAlnType.scala == mem_aln_t native/bwamem.h:71-80, CIGAR and MD kept beside it */
+  int64_t pos;
+  int32_t rid, flag, is_rev, mapq, NM, n_cigar, score, sub, md_len, status;
+} orc_aln_t; /* 48 bytes */
+
+void orc_mark_primary_se(const orc_opt_t *o, const orc_tail_opt_t *t, int n, orc_alnreg_t *a, int64_t id, int flavour);
+int orc_approx_mapq_se(const orc_opt_t *o, const orc_tail_opt_t *t, const orc_alnreg_t *a, int flavour);
+int orc_mem_pair(const orc_opt_t *o, int64_t l_pac, const orc_pestat_t pes[4], int n0, const orc_alnreg_t *a0, int n1,
+                 const orc_alnreg_t *a1, int64_t id, int flavour, int *sub, int *n_sub, int z[2]);
+int orc_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t *pac,
+                   int l_query, const uint8_t *query_in, int64_t rb, int64_t re, int flavour, int *score, int *n_cigar, int *NM,
+                   uint32_t *cigar, int cigar_cap, char *md, int md_cap, int *md_len);
+int orc_bns_pos2rid(int n_seqs, const int64_t *ann_off, int64_t l_pac, int64_t pos_f);
+void orc_reg2aln(const orc_opt_t *o, const orc_tail_opt_t *t, int n_seqs, const int64_t *ann_off, const int32_t *ann_len,
+                 int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query, const orc_alnreg_t *ar, int flavour,
+                 orc_aln_t *a, uint32_t *cigar, int cigar_cap, char *md, int md_cap);
+int64_t orc_sam_pe_batch(const orc_opt_t *o, const orc_tail_opt_t *t, int n_seqs, const int64_t *ann_off, const int32_t *ann_len,
+                         const int64_t *ann_name_off, const char *ann_name_pool, int64_t l_pac, const uint8_t *pac,
+                         const orc_pestat_t pes[4], int group_size, int64_t id0, const int32_t *read_len, const int64_t *read_off,
+                         const uint8_t *read_pool, const char *qual_pool, const int64_t *name_off, const char *name_pool,
+                         const int32_t *reg_cnt, orc_alnreg_t *regs, int flavour, char *out_text, int64_t cap, int64_t *out_off,
+                         int64_t *n_reg2aln);
+
 #ifdef __cplusplus
 }
 #endif

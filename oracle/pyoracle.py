@@ -330,3 +330,180 @@ class Ref:
                                                _vp(g.ref_off), _vp(g.ref_pool), _vp(out_cnt), _vp(out), C.c_int64(cap))
         assert total >= 0
         return out_cnt, out[:total]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# worker2's tail (bpsw_oracle_tail.c / the tail shims of ref_shim.c)
+TAIL_SCALA, TAIL_C = 0, 1
+MEM_F_NOPAIRING, MEM_F_ALL, MEM_F_NO_MULTI, MEM_F_NO_RESCUE = 0x4, 0x8, 0x10, 0x20
+
+ALN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("flag", "<i4"), ("is_rev", "<i4"), ("mapq", "<i4"), ("NM", "<i4"),
+                      ("n_cigar", "<i4"), ("score", "<i4"), ("sub", "<i4"), ("md_len", "<i4"), ("status", "<i4")])
+
+
+class TailOpt(C.Structure):
+    _fields_ = [("mask_level", C.c_float), ("mapq_coef_len", C.c_float), ("mapq_coef_fac", C.c_int32), ("pad_", C.c_int32)]
+
+
+def _ints_of(opt: Opt):
+    return np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_unpaired, opt.pen_clip5, opt.pen_clip3,
+                     opt.w, opt.zdrop, opt.T, opt.flag, opt.min_seed_len, opt.max_ins, opt.max_matesw], np.int32)
+
+
+def _pes_of(pes_list):
+    pes = (PeStat * 4)()
+    for r in range(4):
+        pes[r].low, pes[r].high, pes[r].failed, pes[r].avg, pes[r].std = pes_list[r]
+    return pes
+
+
+def _split_text(text: bytes, off: np.ndarray):
+    return [text[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+
+
+def _orc_default_tail_opt(self) -> TailOpt:
+    t = TailOpt()
+    self.lib.orc_tail_opt_default(C.byref(t))
+    return t
+
+
+def _orc_mark_primary(self, opt, topt, regs, rid, flavour=TAIL_SCALA):
+    a = np.ascontiguousarray(regs.copy())
+    self.lib.orc_mark_primary_se(C.byref(opt), C.byref(topt), C.c_int(a.shape[0]), _vp(a), C.c_int64(rid), C.c_int(flavour))
+    return a
+
+
+def _orc_approx_mapq(self, opt, topt, reg, flavour=TAIL_SCALA):
+    a = np.ascontiguousarray(np.array([reg], ALNREG_DTYPE))
+    return int(self.lib.orc_approx_mapq_se(C.byref(opt), C.byref(topt), _vp(a), C.c_int(flavour)))
+
+
+def _orc_mem_pair(self, opt, l_pac, pes, a0, a1, pid, flavour=TAIL_SCALA):
+    a0 = np.ascontiguousarray(a0); a1 = np.ascontiguousarray(a1)
+    sub, n_sub = C.c_int(0), C.c_int(0)
+    z = (C.c_int * 2)(-1, -1)
+    ret = self.lib.orc_mem_pair(C.byref(opt), C.c_int64(l_pac), _pes_of(pes), C.c_int(a0.shape[0]), _vp(a0), C.c_int(a1.shape[0]),
+                                _vp(a1), C.c_int64(pid), C.c_int(flavour), C.byref(sub), C.byref(n_sub), z)
+    return int(ret), sub.value, n_sub.value, (z[0], z[1])
+
+
+def _orc_reg2aln_batch(self, opt, topt, pac, l_pac, ann_off, ann_len, read_len, read_off, read_pool, regs, flavour=TAIL_SCALA,
+                       cigar_cap=64, md_cap=256):
+    """memRegToAln (MemRegToADAMSAM.scala:172-313) for n (read, region) jobs -> (alns[n], cigar[n, cigar_cap], md[n, md_cap])"""
+    pac = np.ascontiguousarray(pac, np.uint8)
+    ann_off = np.ascontiguousarray(ann_off, np.int64); ann_len = np.ascontiguousarray(ann_len, np.int32)
+    regs = np.ascontiguousarray(regs)
+    n = int(regs.shape[0])
+    alns = np.zeros(n, ALN_DTYPE)
+    cig = np.zeros((n, cigar_cap), np.uint32)
+    md = np.zeros((n, md_cap), np.uint8)
+    for j in range(n):
+        q = np.ascontiguousarray(read_pool[int(read_off[j]):int(read_off[j]) + int(read_len[j])])
+        self.lib.orc_reg2aln(C.byref(opt), C.byref(topt), C.c_int(ann_off.shape[0]), _vp(ann_off), _vp(ann_len), C.c_int64(l_pac),
+                             _vp(pac), C.c_int(q.size), _vp(q), C.c_void_p(regs.ctypes.data + j * regs.itemsize), C.c_int(flavour),
+                             C.c_void_p(alns.ctypes.data + j * alns.itemsize), C.c_void_p(cig.ctypes.data + 4 * j * cigar_cap),
+                             C.c_int(cigar_cap), C.c_void_p(md.ctypes.data + j * md_cap), C.c_int(md_cap))
+    return alns, cig, md
+
+
+def _orc_sam_pe_batch(self, opt, topt, pac, g, flavour=TAIL_SCALA):
+    """memSamPeGroupRest (MemSamPe.scala:1390-1612) -> (list of 2G SAM texts, regs as the tail leaves them, n_reg2aln)"""
+    pac = np.ascontiguousarray(pac, np.uint8)
+    regs = np.ascontiguousarray(g.regs.copy())
+    cap = 4096 * max(1, 2 * g.group_size)
+    off = np.zeros(2 * g.group_size + 1, np.int64)
+    nra = C.c_int64(0)
+    self.lib.orc_sam_pe_batch.restype = C.c_int64
+    while True:
+        buf = np.zeros(cap, np.uint8)
+        regs = np.ascontiguousarray(g.regs.copy())
+        tot = self.lib.orc_sam_pe_batch(C.byref(opt), C.byref(topt), C.c_int(g.ann_off.shape[0]), _vp(g.ann_off), _vp(g.ann_len),
+                                        _vp(g.ann_name_off), _vp(g.ann_name_pool), C.c_int64(g.l_pac), _vp(pac), _pes_of(g.pes),
+                                        C.c_int(g.group_size), C.c_int64(g.id0), _vp(g.read_len), _vp(g.read_off), _vp(g.read_pool),
+                                        _vp(g.qual_pool), _vp(g.name_off), _vp(g.name_pool), _vp(g.reg_cnt), _vp(regs),
+                                        C.c_int(flavour), _vp(buf), C.c_int64(cap), _vp(off), C.byref(nra))
+        if tot >= 0:
+            break
+        cap = -tot + 64
+    return _split_text(buf[:tot].tobytes(), off), regs, nra.value
+
+
+Oracle.default_tail_opt = _orc_default_tail_opt
+Oracle.mark_primary = _orc_mark_primary
+Oracle.approx_mapq = _orc_approx_mapq
+Oracle.mem_pair = _orc_mem_pair
+Oracle.reg2aln_batch = _orc_reg2aln_batch
+Oracle.sam_pe_batch = _orc_sam_pe_batch
+
+
+def _tail3(topt: TailOpt):
+    return np.array([topt.mask_level, topt.mapq_coef_len, float(topt.mapq_coef_fac)], np.float32)
+
+
+def _ref_mark_primary(self, opt, topt, regs, rid):
+    a = np.ascontiguousarray(regs.copy())
+    self.lib.ref_mark_primary_se(_vp(_ints_of(opt)), _vp(np.array(list(opt.mat), np.int8)), _vp(_tail3(topt)), C.c_int(a.shape[0]),
+                                 _vp(a), C.c_int64(rid))
+    return a
+
+
+def _ref_approx_mapq(self, opt, topt, reg):
+    a = np.ascontiguousarray(np.array([reg], ALNREG_DTYPE))
+    return int(self.lib.ref_approx_mapq_se(_vp(_ints_of(opt)), _vp(np.array(list(opt.mat), np.int8)), _vp(_tail3(topt)), _vp(a)))
+
+
+def _ref_mem_pair(self, opt, l_pac, pes, a0, a1, pid):
+    a0 = np.ascontiguousarray(a0); a1 = np.ascontiguousarray(a1)
+    out = np.zeros(5, np.int32)
+    self.lib.ref_mem_pair(_vp(_ints_of(opt)), _vp(np.array(list(opt.mat), np.int8)), C.c_int64(l_pac), _pes_of(pes),
+                          C.c_int(a0.shape[0]), _vp(a0), C.c_int(a1.shape[0]), _vp(a1), C.c_int(pid), _vp(out))
+    return int(out[0]), int(out[1]), int(out[2]), (int(out[3]), int(out[4]))
+
+
+def _ref_reg2aln_batch(self, opt, topt, pac, l_pac, ann_off, ann_len, read_len, read_off, read_pool, regs, cigar_cap=64, md_cap=256):
+    """mem_reg2aln (native/bwamem.c:949-1021) -> (alns[n] as ALN_DTYPE with status 0, cigar, md)"""
+    pac = np.ascontiguousarray(pac, np.uint8)
+    ann_off = np.ascontiguousarray(ann_off, np.int64); ann_len = np.ascontiguousarray(ann_len, np.int32)
+    regs = np.ascontiguousarray(regs)
+    n = int(regs.shape[0])
+    raw = np.zeros((n, 10), np.int64)
+    cig = np.zeros((n, cigar_cap), np.uint32)
+    md = np.zeros((n, md_cap), np.uint8)
+    rl = np.ascontiguousarray(read_len, np.int32); ro = np.ascontiguousarray(read_off, np.int64)
+    rp = np.ascontiguousarray(read_pool, np.uint8)
+    self.lib.ref_reg2aln_batch(_vp(_ints_of(opt)), _vp(np.array(list(opt.mat), np.int8)), _vp(_tail3(topt)), C.c_int64(l_pac), _vp(pac),
+                               C.c_int(ann_off.shape[0]), _vp(ann_off), _vp(ann_len), C.c_int(n), _vp(rl), _vp(ro), _vp(rp), _vp(regs),
+                               _vp(raw), _vp(cig), C.c_int(cigar_cap), _vp(md), C.c_int(md_cap))
+    alns = np.zeros(n, ALN_DTYPE)
+    for k, f in enumerate(("pos", "rid", "flag", "is_rev", "mapq", "NM", "n_cigar", "score", "sub", "md_len")):
+        alns[f] = raw[:, k]
+    return alns, cig, md
+
+
+def _ref_sam_pe_batch(self, opt, topt, pac, g, no_rescue=True):
+    """mem_sam_pe (native/bwamem_pair.c:361-453) per pair -> list of 2G SAM texts"""
+    pac = np.ascontiguousarray(pac, np.uint8)
+    ints = _ints_of(opt)
+    if no_rescue:
+        ints[12] |= MEM_F_NO_RESCUE
+    cap = 4096 * max(1, 2 * g.group_size)
+    off = np.zeros(2 * g.group_size + 1, np.int64)
+    self.lib.ref_sam_pe_batch.restype = C.c_int64
+    while True:
+        buf = np.zeros(cap, np.uint8)
+        tot = self.lib.ref_sam_pe_batch(_vp(ints), _vp(np.array(list(opt.mat), np.int8)), _vp(_tail3(topt)), C.c_int64(g.l_pac), _vp(pac),
+                                        C.c_int(g.ann_off.shape[0]), _vp(g.ann_off), _vp(g.ann_len), _vp(g.ann_name_off),
+                                        _vp(g.ann_name_pool), _pes_of(g.pes), C.c_int(g.group_size), C.c_int64(g.id0), _vp(g.read_len),
+                                        _vp(g.read_off), _vp(g.read_pool), _vp(g.qual_pool), _vp(g.name_off), _vp(g.name_pool),
+                                        _vp(g.reg_cnt), _vp(np.ascontiguousarray(g.regs)), _vp(buf), C.c_int64(cap), _vp(off))
+        if tot >= 0:
+            break
+        cap = -tot + 64
+    return _split_text(buf[:tot].tobytes(), off)
+
+
+Ref.mark_primary = _ref_mark_primary
+Ref.approx_mapq = _ref_approx_mapq
+Ref.mem_pair = _ref_mem_pair
+Ref.reg2aln_batch = _ref_reg2aln_batch
+Ref.sam_pe_batch = _ref_sam_pe_batch

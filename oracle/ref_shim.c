@@ -226,3 +226,151 @@ int64_t ref_chain2aln_batch(const int32_t ints[16], const int8_t mat[25], int64_
   free(o);
   return overflow ? -total : total;
 }
+
+/* ---- worker2's tail: the reference's own mem_mark_primary_se / mem_approx_mapq_se / mem_pair / mem_reg2aln / mem_sam_pe
+ * over flat arrays.  ints[16] as above; tail = {mask_level, mapQ_coef_len, (float)mapQ_coef_fac}. ---- */
+#include "bwa.h"
+void mem_mark_primary_se(const mem_opt_t *opt, int n, mem_alnreg_t *a, int64_t id);
+int mem_approx_mapq_se(const mem_opt_t *opt, const mem_alnreg_t *a);
+int mem_pair(const mem_opt_t *opt, int64_t l_pac, const uint8_t *pac, const mem_pestat_t pes[4], bseq1_t s[2], mem_alnreg_v a[2],
+             int id, int *sub, int *n_sub, int z[2]);
+int mem_sam_pe(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2],
+               mem_alnreg_v a[2]);
+
+static mem_opt_t *shim_opt(const int32_t ints[16], float mask_level_redun, const int8_t mat[25], const float tail[3]) {
+  mem_opt_t *o = mem_opt_init();
+  o->a = ints[0]; o->b = ints[1]; o->o_del = ints[2]; o->e_del = ints[3]; o->o_ins = ints[4]; o->e_ins = ints[5];
+  o->pen_unpaired = ints[6]; o->pen_clip5 = ints[7]; o->pen_clip3 = ints[8]; o->w = ints[9]; o->zdrop = ints[10];
+  o->T = ints[11]; o->flag = ints[12]; o->min_seed_len = ints[13]; o->max_ins = ints[14]; o->max_matesw = ints[15];
+  o->mask_level_redun = mask_level_redun;
+  memcpy(o->mat, mat, 25);
+  if (tail) { o->mask_level = tail[0]; o->mapQ_coef_len = tail[1]; o->mapQ_coef_fac = (int)tail[2]; }
+  return o;
+}
+static void shim_pes(const flat_pestat_t in[4], mem_pestat_t pes[4]) {
+  for (int r = 0; r < 4; ++r) {
+    pes[r].low = in[r].low; pes[r].high = in[r].high; pes[r].failed = in[r].failed; pes[r].avg = in[r].avg; pes[r].std = in[r].std;
+  }
+}
+static bntseq_t *shim_bns(int64_t l_pac, int n_seqs, const int64_t *ann_off, const int32_t *ann_len, const int64_t *name_off,
+                          const char *name_pool) {
+  bntseq_t *b = (bntseq_t *)calloc(1, sizeof(bntseq_t));
+  b->l_pac = l_pac; b->n_seqs = n_seqs;
+  b->anns = (bntann1_t *)calloc((size_t)n_seqs, sizeof(bntann1_t));
+  for (int i = 0; i < n_seqs; ++i) {
+    b->anns[i].offset = ann_off[i]; b->anns[i].len = ann_len[i];
+    const size_t l = name_off ? (size_t)(name_off[i + 1] - name_off[i]) : 0;
+    b->anns[i].name = (char *)calloc(l + 1, 1);
+    if (l) memcpy(b->anns[i].name, name_pool + name_off[i], l);
+    b->anns[i].anno = b->anns[i].name + l; /* empty */
+  }
+  return b;
+}
+static void shim_bns_free(bntseq_t *b) {
+  for (int i = 0; i < b->n_seqs; ++i) free(b->anns[i].name);
+  free(b->anns); free(b);
+}
+
+void ref_mark_primary_se(const int32_t ints[16], const int8_t mat[25], const float tail[3], int n, flat_alnreg_t *regs, int64_t id) {
+  mem_opt_t *o = shim_opt(ints, 0.95f, mat, tail);
+  mem_mark_primary_se(o, n, (mem_alnreg_t *)regs, id); /* identical layout: native/bwamem.h:49-61 */
+  free(o);
+}
+int ref_approx_mapq_se(const int32_t ints[16], const int8_t mat[25], const float tail[3], const flat_alnreg_t *reg) {
+  mem_opt_t *o = shim_opt(ints, 0.95f, mat, tail);
+  const int q = mem_approx_mapq_se(o, (const mem_alnreg_t *)reg);
+  free(o);
+  return q;
+}
+/* out4 = {ret, sub, n_sub, z0, z1} */
+void ref_mem_pair(const int32_t ints[16], const int8_t mat[25], int64_t l_pac, const flat_pestat_t pes_in[4], int n0,
+                  const flat_alnreg_t *a0, int n1, const flat_alnreg_t *a1, int id, int32_t out5[5]) {
+  mem_opt_t *o = shim_opt(ints, 0.95f, mat, 0);
+  mem_pestat_t pes[4];
+  shim_pes(pes_in, pes);
+  mem_alnreg_v a[2];
+  a[0].n = a[0].m = (size_t)n0; a[0].a = (mem_alnreg_t *)a0;
+  a[1].n = a[1].m = (size_t)n1; a[1].a = (mem_alnreg_t *)a1;
+  bseq1_t s[2];
+  memset(s, 0, sizeof s);
+  int sub = 0, n_sub = 0, z[2] = {-1, -1};
+  out5[0] = mem_pair(o, l_pac, 0, pes, s, a, id, &sub, &n_sub, z);
+  out5[1] = sub; out5[2] = n_sub; out5[3] = z[0]; out5[4] = z[1];
+  free(o);
+}
+
+/* mem_reg2aln (native/bwamem.c:949-1021) for n (read, region) jobs.  out: 10 x int64 per job {pos, rid, flag, is_rev, mapq, NM,
+ * n_cigar, score, sub, md_len}; cigar: cigar_cap words per job; md: md_cap bytes per job (text without the NUL). */
+void ref_reg2aln_batch(const int32_t ints[16], const int8_t mat[25], const float tail[3], int64_t l_pac, const uint8_t *pac,
+                       int n_seqs, const int64_t *ann_off, const int32_t *ann_len, int n, const int32_t *read_len,
+                       const int64_t *read_off, const uint8_t *read_pool, const flat_alnreg_t *regs, int64_t *out, uint32_t *cigar,
+                       int cigar_cap, char *md, int md_cap) {
+  mem_opt_t *o = shim_opt(ints, 0.95f, mat, tail);
+  bntseq_t *bns = shim_bns(l_pac, n_seqs, ann_off, ann_len, 0, 0);
+  for (int j = 0; j < n; ++j) {
+    mem_aln_t a = mem_reg2aln(o, bns, pac, read_len[j], (const char *)(read_pool + read_off[j]), (const mem_alnreg_t *)&regs[j]);
+    int64_t *r = out + 10 * (size_t)j;
+    r[0] = a.pos; r[1] = a.rid; r[2] = a.flag; r[3] = a.is_rev; r[4] = a.mapq; r[5] = a.NM; r[6] = a.n_cigar; r[7] = a.score; r[8] = a.sub;
+    r[9] = 0;
+    if (a.cigar) {
+      for (int k = 0; k < a.n_cigar && k < cigar_cap; ++k) cigar[(size_t)j * cigar_cap + k] = a.cigar[k];
+      const char *m = (const char *)(a.cigar + a.n_cigar);
+      const size_t l = strlen(m);
+      r[9] = (int64_t)l;
+      memcpy(md + (size_t)j * md_cap, m, l < (size_t)md_cap ? l : (size_t)md_cap);
+      free(a.cigar);
+    }
+  }
+  shim_bns_free(bns); free(o);
+}
+
+/* mem_sam_pe (native/bwamem_pair.c:361-453) for a group of pairs; the caller sets MEM_F_NO_RESCUE (0x20) in ints[12] when the
+ * region lists are already rescued.  Text of read 2k+i in out_text[out_off[2k+i] .. out_off[2k+i+1]); out_cnt/out_regs (optional)
+ * receive the region lists as mem_sam_pe leaves them.  returns total text bytes or -(needed). */
+int64_t ref_sam_pe_batch(const int32_t ints[16], const int8_t mat[25], const float tail[3], int64_t l_pac, const uint8_t *pac,
+                         int n_seqs, const int64_t *ann_off, const int32_t *ann_len, const int64_t *ann_name_off,
+                         const char *ann_name_pool, const flat_pestat_t pes_in[4], int group_size, int64_t id0,
+                         const int32_t *read_len, const int64_t *read_off, const uint8_t *read_pool, const char *qual_pool,
+                         const int64_t *name_off, const char *name_pool, const int32_t *reg_cnt, const flat_alnreg_t *regs,
+                         char *out_text, int64_t cap, int64_t *out_off) {
+  mem_opt_t *o = shim_opt(ints, 0.95f, mat, tail);
+  bntseq_t *bns = shim_bns(l_pac, n_seqs, ann_off, ann_len, ann_name_off, ann_name_pool);
+  mem_pestat_t pes[4];
+  shim_pes(pes_in, pes);
+  int64_t total = 0, reg_at = 0;
+  int overflow = 0;
+  for (int k = 0; k < group_size; ++k) {
+    bseq1_t s[2];
+    mem_alnreg_v a[2];
+    memset(s, 0, sizeof s);
+    const size_t nl = (size_t)(name_off[k + 1] - name_off[k]);
+    char *name = (char *)calloc(nl + 1, 1);
+    memcpy(name, name_pool + name_off[k], nl);
+    for (int i = 0; i < 2; ++i) {
+      const int l = read_len[2 * k + i];
+      s[i].l_seq = l; s[i].name = name;
+      s[i].seq = (char *)malloc((size_t)l + 1);
+      memcpy(s[i].seq, read_pool + read_off[2 * k + i], (size_t)l);
+      if (qual_pool) { s[i].qual = (char *)calloc((size_t)l + 1, 1); memcpy(s[i].qual, qual_pool + read_off[2 * k + i], (size_t)l); }
+      kv_init(a[i]);
+      for (int j = 0; j < reg_cnt[2 * k + i]; ++j) {
+        mem_alnreg_t r;
+        memcpy(&r, &regs[reg_at + j], sizeof r);
+        kv_push(mem_alnreg_t, a[i], r);
+      }
+      reg_at += reg_cnt[2 * k + i];
+    }
+    mem_sam_pe(o, bns, pac, pes, (uint64_t)(id0 + k), s, a);
+    for (int i = 0; i < 2; ++i) {
+      const size_t l = s[i].sam ? strlen(s[i].sam) : 0;
+      out_off[2 * k + i] = total;
+      if (total + (int64_t)l <= cap) memcpy(out_text + total, s[i].sam, l); else overflow = 1;
+      total += (int64_t)l;
+      free(s[i].sam); free(s[i].seq); free(s[i].qual); free(a[i].a);
+    }
+    free(name);
+  }
+  out_off[2 * group_size] = total;
+  shim_bns_free(bns); free(o);
+  return overflow ? -total : total;
+}
