@@ -211,3 +211,64 @@ cnt3, regs3 = ref.chain2aln_batch(opt3, pac3, cb)
 np.savez_compressed(os.path.join(HERE, "mem_chain2aln.npz"), l_pac=l_pac3, pac=pac3, read_len=cb.read_len, read_off=cb.read_off,
                     read_pool=cb.read_pool, chain_cnt=cb.chain_cnt, seed_cnt=cb.seed_cnt, seed_rbeg=cb.seed_rbeg,
                     seed_qbeg=cb.seed_qbeg, seed_len=cb.seed_len, out_cnt=cnt3, out_regs=regs3)
+
+# ---- worker2's tail: mem_reg2aln and mem_sam_pe (== memRegToAln / memSamPeGroupRest, C flavour) --------------------
+# Regions come from the reference's own mem_chain2aln + mem_sort_and_dedup on synthetic FR pairs over a four-contig
+# reference with duplicated stretches; mem_sam_pe runs with MEM_F_NO_RESCUE (the rescue is boundary 1's business).
+import bpsw_hip  # noqa: E402
+
+contigs = [60_000, 40_000, 25_000, 35_000]
+pac4, bases4, ann_off4, ann_len4, ann_names4, dups4 = synth.contig_reference(contigs, seed=20261007)
+opt4 = po.Oracle().default_opt()
+topt4 = po.Oracle().default_tail_opt()
+
+
+def regions_of(batch, opt):
+    cnt, regs = ref.chain2aln_batch(opt, pac4, batch)
+    out_cnt, out, at = [], [], 0
+    for c in cnt:
+        r = ref.sort_dedup(regs[at:at + c]) if c else regs[0:0]
+        at += c
+        out_cnt.append(len(r)); out.append(r)
+    return np.array(out_cnt, np.int32), np.concatenate(out)
+
+
+for stem, n_pairs, es, ei, flag, seed in (("mem_sam_pe", 160, 0.02, 0.006, 0, 20261008),
+                                          ("mem_sam_pe_all", 60, 0.03, 0.01, po.MEM_F_ALL, 20261009)):
+    tb, names, quals, pes = synth.tail_pairs(n_pairs, bases4, ann_off4, ann_len4, dups4, sub_rate=es, indel_rate=ei, seed=seed)
+    rc, rg = regions_of(tb, opt4)
+    g4 = bpsw_hip.make_tail_group(tb, names, quals, pes, rc, rg, ann_off4, ann_len4, ann_names4, id0=4242)
+    o = po.Oracle().default_opt()
+    o.flag = flag
+    texts = ref.sam_pe_batch(o, topt4, pac4, g4)
+    t_off = np.zeros(len(texts) + 1, np.int64)
+    t_off[1:] = np.cumsum([len(t) for t in texts])
+    np.savez_compressed(os.path.join(HERE, stem + ".npz"), l_pac=g4.l_pac, pac=pac4, id0=g4.id0, flag=flag, pes=np.array(pes, np.float64),
+                        read_len=g4.read_len, read_off=g4.read_off, read_pool=g4.read_pool, qual_pool=g4.qual_pool,
+                        name_off=g4.name_off, name_pool=g4.name_pool, reg_cnt=g4.reg_cnt, regs=g4.regs, ann_off=g4.ann_off,
+                        ann_len=g4.ann_len, ann_name_off=g4.ann_name_off, ann_name_pool=g4.ann_name_pool,
+                        text=np.frombuffer(b"".join(texts), np.uint8), text_off=t_off)
+
+# mem_reg2aln on every region of 250 pairs (primary and secondary alike), plus the unmapped record
+tb, names, quals, pes = synth.tail_pairs(250, bases4, ann_off4, ann_len4, dups4, sub_rate=0.03, indel_rate=0.01, p_span=0.08, seed=20261010)
+rc, rg = regions_of(tb, opt4)
+rg = rg.copy()
+jl, jo = [], []
+for r in range(tb.n_reads):
+    for _ in range(int(rc[r])):
+        jl.append(int(tb.read_len[r])); jo.append(int(tb.read_off[r]))
+at = 0
+for r in range(tb.n_reads):        # what mem_mark_primary_se would leave: give some regions a parent and sub scores
+    c = int(rc[r])
+    rg[at:at + c] = ref.mark_primary(opt4, topt4, rg[at:at + c], 2 * r)
+    at += c
+jl.append(int(tb.read_len[0])); jo.append(int(tb.read_off[0]))
+unm = np.zeros(1, rg.dtype)
+unm["rb"] = -1; unm["re"] = -1
+rg = np.concatenate([rg, unm])
+alns, cig, md = ref.reg2aln_batch(opt4, topt4, pac4, int(sum(contigs)), ann_off4, ann_len4, np.array(jl, np.int32), np.array(jo, np.int64),
+                                  tb.read_pool, rg, cigar_cap=32, md_cap=160)
+assert int(alns["n_cigar"].max()) <= 32 and int(alns["md_len"].max()) <= 160
+np.savez_compressed(os.path.join(HERE, "mem_reg2aln.npz"), l_pac=int(sum(contigs)), pac=pac4, ann_off=ann_off4, ann_len=ann_len4,
+                    read_len=np.array(jl, np.int32), read_off=np.array(jo, np.int64), read_pool=tb.read_pool, regs=rg, alns=alns,
+                    cigar=cig, md=md)
