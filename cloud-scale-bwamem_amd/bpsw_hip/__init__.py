@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
+    "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_last_tail_kernel",
 ]
 JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI",
@@ -162,6 +163,13 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_ref_length.argtypes = [C.c_void_p]
     lib.bpsw_ref_length.restype = C.c_int64
     lib.bpsw_ref_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.bpsw_tail_opt_default.argtypes = [C.c_void_p]
+    lib.bpsw_tail_opt_default.restype = None
+    lib.bpsw_bns_load.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_char_p]
+    lib.bpsw_reg2aln_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bpsw_sam_pe_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.POINTER(C.c_size_t), C.c_void_p]
+    lib.bpsw_last_tail_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if path is None:
         _lib = lib
     return lib
@@ -506,3 +514,107 @@ def make_tail_group(chain_batch, names, qual_pool, pes, reg_cnt, regs, ann_off, 
                         qual_pool=None if qual_pool is None else cp(qual_pool, np.uint8), name_off=name_off, name_pool=name_pool,
                         reg_cnt=cp(reg_cnt, np.int32), regs=cp(regs), ann_off=cp(ann_off, np.int64), ann_len=cp(ann_len, np.int32),
                         ann_name_off=a_off, ann_name_pool=a_pool)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# worker2's tail: bpsw_bns_load, bpsw_reg2aln_batch, bpsw_sam_pe_batch
+TAIL_SCALA, TAIL_C = 0, 1
+MEM_F_NOPAIRING, MEM_F_ALL, MEM_F_NO_MULTI = 0x4, 0x8, 0x10
+ALN_OK, ALN_XREF, ALN_NOCIGAR, ALN_OVERFLOW = 0, 1, 2, 3
+ALN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("flag", "<i4"), ("is_rev", "<i4"), ("mapq", "<i4"), ("NM", "<i4"),
+                      ("n_cigar", "<i4"), ("score", "<i4"), ("sub", "<i4"), ("md_len", "<i4"), ("status", "<i4")])
+
+
+class TailOpt(C.Structure):  # bpsw_tail_opt_t
+    _fields_ = [("mask_level", C.c_float), ("mapq_coef_len", C.c_float), ("mapq_coef_fac", C.c_int32), ("flavour", C.c_int32)]
+
+
+class Reg2AlnJobs(C.Structure):  # bpsw_reg2aln_jobs_t
+    _fields_ = [("n", C.c_int32), ("max_cigar", C.c_int32), ("max_md", C.c_int32), ("read_len", C.c_void_p), ("read_off", C.c_void_p),
+                ("read_pool", C.c_void_p), ("read_pool_bytes", C.c_size_t), ("regs", C.c_void_p)]
+
+
+class Pairs(C.Structure):  # bpsw_pairs_t
+    _fields_ = [("group_size", C.c_int32), ("id0", C.c_int64), ("pes", PeStat * 4), ("read_len", C.c_void_p), ("read_off", C.c_void_p),
+                ("read_pool", C.c_void_p), ("qual_pool", C.c_void_p), ("read_pool_bytes", C.c_size_t), ("name_off", C.c_void_p),
+                ("name_pool", C.c_void_p), ("reg_cnt", C.c_void_p), ("regs", C.c_void_p)]
+
+
+def default_tail_opt(flavour: int = TAIL_SCALA) -> TailOpt:
+    t = TailOpt()
+    load_library().bpsw_tail_opt_default(C.byref(t))
+    t.flavour = flavour
+    return t
+
+
+def _ctx_bns_load(self, ann_off, ann_len, names=None):
+    off = np.ascontiguousarray(ann_off, np.int64)
+    ln = np.ascontiguousarray(ann_len, np.int32)
+    blob = None if names is None else b"".join(n.encode() + b"\0" for n in names)
+    _chk(self.lib, self.lib.bpsw_bns_load(self.h, int(off.shape[0]), _ptr(off), _ptr(ln), blob), "bpsw_bns_load")
+
+
+def _ctx_reg2aln_batch(self, opt: Opt, topt: TailOpt, read_len, read_off, read_pool, regs, max_cigar: int = 64, max_md: int = 256):
+    """memRegToAln for n (read, region) jobs -> (alns[n] ALN_DTYPE, cigar[n, max_cigar], md[n, max_md])"""
+    rl = np.ascontiguousarray(read_len, np.int32); ro = np.ascontiguousarray(read_off, np.int64)
+    rp = np.ascontiguousarray(read_pool, np.uint8); rg = np.ascontiguousarray(regs)
+    assert rg.dtype == ALNREG_DTYPE
+    j = Reg2AlnJobs()
+    j.n, j.max_cigar, j.max_md = int(rg.shape[0]), int(max_cigar), int(max_md)
+    j.read_len, j.read_off, j.read_pool, j.read_pool_bytes, j.regs = rl.ctypes.data, ro.ctypes.data, rp.ctypes.data, rp.size, rg.ctypes.data
+    alns = np.zeros(max(j.n, 1), ALN_DTYPE)
+    cig = np.zeros((max(j.n, 1), max_cigar), np.uint32)
+    md = np.zeros((max(j.n, 1), max_md), np.uint8)
+    _chk(self.lib, self.lib.bpsw_reg2aln_batch(self.h, C.byref(opt), C.byref(topt), C.byref(j), _ptr(alns), _ptr(cig), _ptr(md)),
+         "bpsw_reg2aln_batch")
+    return alns[: j.n], cig[: j.n], md[: j.n]
+
+
+def _ctx_sam_pe_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA"):
+    """memSamPeGroupRest -> (list of 2G SAM texts (bytes), regions as the tail leaves them)"""
+    st = Pairs()
+    st.group_size, st.id0 = g.group_size, g.id0
+    for r in range(4):
+        lo, hi, failed, avg, std = g.pes[r]
+        st.pes[r].low, st.pes[r].high, st.pes[r].failed, st.pes[r].avg, st.pes[r].std = int(lo), int(hi), int(failed), float(avg), float(std)
+    keep = []
+    for f, dt in (("read_len", np.int32), ("read_off", np.int64), ("read_pool", np.uint8), ("name_off", np.int64),
+                  ("name_pool", np.uint8), ("reg_cnt", np.int32)):
+        a = np.ascontiguousarray(getattr(g, f), dt)
+        keep.append(a)
+        setattr(st, f, a.ctypes.data)
+    if g.qual_pool is not None:
+        q = np.ascontiguousarray(g.qual_pool, np.uint8)
+        keep.append(q)
+        st.qual_pool = q.ctypes.data
+    st.read_pool_bytes = int(np.asarray(g.read_pool).size)
+    regs = np.ascontiguousarray(g.regs)
+    assert regs.dtype == ALNREG_DTYPE
+    st.regs = regs.ctypes.data
+    off = np.zeros(2 * g.group_size + 1, np.int64)
+    out_regs = np.zeros(max(regs.shape[0], 1), ALNREG_DTYPE)
+    need = C.c_size_t(0)
+    cap = 1024 * max(1, 2 * g.group_size)
+    while True:
+        buf = np.zeros(cap, np.uint8)
+        rc = self.lib.bpsw_sam_pe_batch(self.h, C.byref(opt), C.byref(topt), C.byref(st), _ptr(buf), cap, _ptr(off), C.byref(need),
+                                        _ptr(out_regs))
+        if rc == -3 and need.value > cap:   # BPSW_ERR_CAPACITY
+            cap = int(need.value) + 64
+            continue
+        _chk(self.lib, rc, "bpsw_sam_pe_batch")
+        break
+    text = buf[: int(off[-1])].tobytes()
+    return [text[int(off[i]):int(off[i + 1])] for i in range(2 * g.group_size)], out_regs[: regs.shape[0]]
+
+
+def _ctx_last_tail_kernel(self):
+    ms, n = C.c_float(0), C.c_int32(0)
+    _chk(self.lib, self.lib.bpsw_last_tail_kernel(self.h, C.byref(ms), C.byref(n)), "bpsw_last_tail_kernel")
+    return ms.value, n.value
+
+
+Context.bns_load = _ctx_bns_load
+Context.reg2aln_batch = _ctx_reg2aln_batch
+Context.sam_pe_batch = _ctx_sam_pe_batch
+Context.last_tail_kernel = _ctx_last_tail_kernel

@@ -132,6 +132,31 @@ hipError_t launch_global_kernel(const GlobalJobsDev& jobs, const SwScoring& sc, 
                                 int32_t* d_score, int32_t* d_ncigar, uint32_t* d_cigar, uint8_t* d_z, int num_cu,
                                 hipStream_t s);
 
+// ---- memRegToAln on the device (bpsw_reg2aln.hip) ----------------------------------------------------
+struct Reg2AlnDev {  // all device pointers
+  int n;
+  int max_cigar, max_md;
+  int flavour;  // BPSW_TAIL_SCALA / BPSW_TAIL_C: the band rule of bwaGenCigar2
+  int opt_w, a;
+  const int32_t* read_len;
+  const long long* read_off;
+  const uint8_t* read_pool;
+  const bpsw_alnreg_t* regs;
+  const uint8_t* pac;
+  long long l_pac;
+  int n_seqs;
+  const long long* ann_off;
+  const int32_t* ann_len;
+};
+struct Reg2AlnOut {  // what the kernel computes of a mem_aln_t; flag, mapq, score, sub are the host's (bpsw_tail.cpp)
+  long long pos;
+  int32_t rid, is_rev, NM, n_cigar, md_len, status, gscore, pad_;
+};
+size_t reg2aln_lds_per_wave(int qcap, int rcap, int md_cap);
+int reg2aln_resident_waves(int num_cu, int qcap, int rcap, int md_cap);
+hipError_t launch_reg2aln_kernel(const Reg2AlnDev& J, const SwScoring& sc, int qcap, int rcap, int md_cap, size_t z_per_wave,
+                                 Reg2AlnOut* d_out, uint32_t* d_cigar, uint8_t* d_md, uint8_t* d_z, int num_cu, hipStream_t s);
+
 // ---- memChainToAlnBatched on the device ----------------------------------------------
 struct ChainParams {
   MatRows mat;
@@ -183,6 +208,11 @@ struct DeviceRef {
   std::mutex mu;
   DeviceBuffer buf;
   long long l_pac = 0;
+  // the contig table (bntann1_t offset/len, bpsw_bns_load): device copy for the kernels, host copy for the tail
+  DeviceBuffer ann;  // n_seqs x int64 offsets, then n_seqs x int32 lengths
+  std::vector<long long> ann_off;
+  std::vector<int32_t> ann_len;
+  std::vector<std::string> ann_name;
 };
 DeviceRef& device_ref(int device);
 // snapshot of the reference loaded on c's device (l_pac == 0: none)
@@ -205,6 +235,9 @@ struct bpsw_ctx {
   int8_t ext_mat[25];
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
   bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
+  float last_tail_ms = 0.f;
+  int last_tail_jobs = 0;
+  bool have_tail_ev = false;
 
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
   bpsw_stats_t stats;

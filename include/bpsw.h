@@ -250,6 +250,89 @@ typedef struct {
 int bpsw_chain2aln_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_chains_t *batch, int zdrop_mode, int flags,
                          int32_t *out_cnt, bpsw_alnreg_t *out_regs, int64_t out_cap, int64_t *out_total);
 
+/* ---- worker2's tail: everything after the rescue ------------------------------------------
+ *
+ * memSamPeGroupRest (worker2/MemSamPe.scala:1390-1612 == mem_sam_pe after the rescue, native/bwamem_pair.c:385-452):
+ * memMarkPrimarySe, memPair, the mapQ arithmetic, memRegToAln (band inference, up to three banded global alignments,
+ * NM/MD, position, clipping) and the SAM text (memAlnToSAM, worker2/MemRegToADAMSAM.scala:328-560).  Not behind either
+ * JNI of the reference (the Scala calls them directly), so these are additional exports like bpsw_global_batch.
+ * The global alignments, NM/MD and the coordinates run on the GPU against the reference loaded with bpsw_ref_load
+ * (bpsw_reg2aln.hip); the per-pair bookkeeping and the text are host code (bpsw_tail.cpp).
+ *
+ * flavour: where the Scala text and the C it was transcribed from differ (band rule of bwaGenCigar2,
+ * mapQ at len == mapQCoefLen, hash ordering and parent index in memMarkPrimarySe, flag folding in memAlnToSAM) the
+ * Scala form is BPSW_TAIL_SCALA (default) and the C form BPSW_TAIL_C.
+ */
+#define BPSW_TAIL_SCALA 0
+#define BPSW_TAIL_C 1
+#define BPSW_MEM_F_NOPAIRING 0x4 /* bits of bpsw_opt_t.flag the tail reads (native/bwamem.h:14-19) */
+#define BPSW_MEM_F_ALL 0x8
+#define BPSW_MEM_F_NO_MULTI 0x10
+#define BPSW_R2A_MAX_QLEN 1024 /* read length */
+#define BPSW_R2A_MAX_RLEN 4096 /* re - rb of a region */
+
+typedef struct { /* the MemOptType fields only the tail reads (datatype/MemOptType.scala:47-52) */
+  float mask_level, mapq_coef_len;
+  int32_t mapq_coef_fac;
+  int32_t flavour;
+} bpsw_tail_opt_t;
+void bpsw_tail_opt_default(bpsw_tail_opt_t *t);
+
+/* The contig table of the reference loaded with bpsw_ref_load (bntann1_t offset / len / name, native/bntseq.h:40-46 ==
+ * datatype/BNTSeqType.scala); shared by every context of the device like the reference itself.  names: n_seqs
+ * NUL-terminated strings back to back, or NULL (then the SAM text uses "ctgN"). */
+int bpsw_bns_load(bpsw_ctx_t *ctx, int32_t n_seqs, const int64_t *offset, const int32_t *len, const char *names);
+
+#define BPSW_ALN_OK 0
+#define BPSW_ALN_XREF 1     /* bwaFixXref2 could not repair the hit (the Scala asserts, R2S:196-199; the C exits) */
+#define BPSW_ALN_NOCIGAR 2  /* bwaGenCigar2 returned null (window out of range / bridging the strands) */
+#define BPSW_ALN_OVERFLOW 3 /* more CIGAR operations / MD bytes than the kernel stages: not produced */
+typedef struct { /* MemAlnType (datatype/MemAlnType.scala) == mem_aln_t (native/bwamem.h:71-80); CIGAR and MD beside it */
+  int64_t pos;
+  int32_t rid, flag, is_rev, mapq, NM, n_cigar, score, sub, md_len, status;
+} bpsw_aln_t; /* 48 bytes */
+
+/* memRegToAln (worker2/MemRegToADAMSAM.scala:172-313 == mem_reg2aln, native/bwamem.c:949-1021) for n (read, region) jobs.
+ * regs[j].rb < 0 or .re < 0: the unmapped record.  out_cigar: max_cigar words per job (len<<4|op, op MIDS=0123);
+ * out_md: max_md bytes per job (text, no NUL).  A job whose n_cigar > max_cigar or md_len > max_md has to be resubmitted
+ * with more room (nothing is truncated silently: its status is BPSW_ALN_OVERFLOW only past the kernel's own staging). */
+typedef struct {
+  int32_t n;
+  int32_t max_cigar, max_md;
+  const int32_t *read_len;
+  const int64_t *read_off;
+  const uint8_t *read_pool; /* codes 0..4 */
+  size_t read_pool_bytes;
+  const bpsw_alnreg_t *regs;
+} bpsw_reg2aln_jobs_t;
+int bpsw_reg2aln_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_reg2aln_jobs_t *jobs,
+                       bpsw_aln_t *out, uint32_t *out_cigar, uint8_t *out_md);
+
+/* The tail over a group of pairs.  Arrays are indexed 2k+i (pair k, end i); regions in (k, i, j) order as
+ * bpsw_matesw_group leaves them.  id0: pair id of the first pair (the reference hashes id0 + k).
+ * Output: out_text receives the SAM lines (read 2k+i: out_text[out_off[2k+i] .. out_off[2k+i+1]); a read with
+ * supplementary hits has several lines); BPSW_ERR_CAPACITY with *out_needed set when text_cap is too small.
+ * out_regs (optional, same size as regs): the region lists as the tail leaves them (sorted, sub/sub_n/secondary/hash). */
+typedef struct {
+  int32_t group_size;
+  int64_t id0;
+  bpsw_pestat_t pes[4];
+  const int32_t *read_len;
+  const int64_t *read_off;
+  const uint8_t *read_pool;
+  const uint8_t *qual_pool; /* same offsets as read_pool, or NULL */
+  size_t read_pool_bytes;
+  const int64_t *name_off;  /* group_size + 1 offsets into name_pool */
+  const char *name_pool;
+  const int32_t *reg_cnt;
+  const bpsw_alnreg_t *regs;
+} bpsw_pairs_t;
+int bpsw_sam_pe_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_pairs_t *g, char *out_text,
+                      size_t text_cap, int64_t *out_off, size_t *out_needed, bpsw_alnreg_t *out_regs);
+/* duration in ms of the most recent reg2aln kernel launch on this context (hipEvents on the launch stream), and the
+ * number of jobs it carried */
+int bpsw_last_tail_kernel(bpsw_ctx_t *ctx, float *ms, int32_t *n_jobs);
+
 /* ---- statistics (the buckets of profiling/SWBatchTimeBreakdown.scala:25-39, device flavoured) -- */
 typedef struct {
   uint64_t ext_calls, ext_tasks, ext_wire_bytes;

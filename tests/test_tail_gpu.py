@@ -1,0 +1,90 @@
+"""worker2's tail on the GPU (bpsw_reg2aln_batch, bpsw_sam_pe_batch) against the reference's golden vectors and the oracle,
+in both flavours, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import bpsw_hip
+import pyoracle as po
+from tail_util import G, load_sam_pe_golden, synthetic_group
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_ref(ctx, pac, g):
+    ctx.ref_load(pac, g.l_pac)
+    n = g.ann_off.shape[0]
+    names = [bytes(g.ann_name_pool[int(g.ann_name_off[i]):int(g.ann_name_off[i + 1])]).decode() for i in range(n)]
+    ctx.bns_load(g.ann_off, g.ann_len, names)
+
+
+@pytest.mark.parametrize("stem", ["mem_sam_pe", "mem_sam_pe_all"])
+def test_sam_pe_vs_reference_golden_text(ctx, stem):
+    pac, g, flag, want = load_sam_pe_golden(stem)
+    _load_ref(ctx, pac, g)
+    opt = bpsw_hip.default_opt()
+    opt.flag = flag
+    got, _ = ctx.sam_pe_batch(opt, bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C), g)
+    assert got == want          # the reference's mem_sam_pe output, byte for byte
+    ms, n_jobs = ctx.last_tail_kernel()
+    assert n_jobs > 0 and ms > 0
+
+
+def test_reg2aln_vs_reference_golden(ctx):
+    z = np.load(os.path.join(G, "mem_reg2aln.npz"))
+    ctx.ref_load(z["pac"], int(z["l_pac"]))
+    ctx.bns_load(z["ann_off"], z["ann_len"])
+    regs = z["regs"].astype(bpsw_hip.ALNREG_DTYPE)
+    alns, cig, md = ctx.reg2aln_batch(bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C), z["read_len"], z["read_off"],
+                                      z["read_pool"], regs, max_cigar=32, max_md=160)
+    want = z["alns"]
+    assert int((alns["status"] != 0).sum()) == 0
+    for f in ("pos", "rid", "flag", "is_rev", "mapq", "NM", "n_cigar", "score", "sub", "md_len"):
+        assert np.array_equal(alns[f], want[f]), f
+    assert np.array_equal(cig, z["cigar"]) and np.array_equal(md, z["md"])
+
+
+@pytest.mark.parametrize("flavour", [bpsw_hip.TAIL_SCALA, bpsw_hip.TAIL_C])
+@pytest.mark.parametrize("L,es,ei,flag", [(150, 0.01, 0.002, 0), (150, 0.05, 0.02, bpsw_hip.MEM_F_ALL), (250, 0.08, 0.02, 0),
+                                          (100, 0.02, 0.005, bpsw_hip.MEM_F_NO_MULTI | bpsw_hip.MEM_F_ALL), (150, 0.02, 0.004, bpsw_hip.MEM_F_NOPAIRING)])
+def test_sam_pe_vs_oracle(ctx, orc, flavour, L, es, ei, flag):
+    pac, g = synthetic_group(orc, 400, 3000 + L + flavour, read_len=L, sub_rate=es, indel_rate=ei, p_span=0.05)
+    _load_ref(ctx, pac, g)
+    opt, oopt = bpsw_hip.default_opt(), orc.default_opt()
+    opt.flag = oopt.flag = flag
+    want, want_regs, n_jobs = orc.sam_pe_batch(oopt, orc.default_tail_opt(), pac, g, flavour=flavour)
+    got, got_regs = ctx.sam_pe_batch(opt, bpsw_hip.default_tail_opt(flavour), g)
+    bad = [i for i in range(len(want)) if want[i] != got[i]]
+    assert not bad, (len(bad), want[bad[0]], got[bad[0]])
+    assert want_regs.tobytes() == got_regs.tobytes()
+    assert 0 < ctx.last_tail_kernel()[1] <= n_jobs      # one job per distinct (read, region)
+
+
+def test_reg2aln_jobs_vs_oracle_and_edge_cases(ctx, orc):
+    pac, g = synthetic_group(orc, 300, 5151, sub_rate=0.04, indel_rate=0.02, p_span=0.1)
+    _load_ref(ctx, pac, g)
+    rl, ro = [], []
+    for r in range(2 * g.group_size):
+        rl += [int(g.read_len[r])] * int(g.reg_cnt[r]); ro += [int(g.read_off[r])] * int(g.reg_cnt[r])
+    regs = g.regs.copy()
+    unm = np.zeros(1, regs.dtype); unm["rb"] = -1; unm["re"] = -1
+    regs = np.concatenate([regs, unm]); rl.append(int(g.read_len[0])); ro.append(int(g.read_off[0]))
+    for flavour in (bpsw_hip.TAIL_SCALA, bpsw_hip.TAIL_C):
+        want, wc, wm = orc.reg2aln_batch(orc.default_opt(), orc.default_tail_opt(), pac, g.l_pac, g.ann_off, g.ann_len, rl, ro, g.read_pool,
+                                         regs, flavour=flavour, cigar_cap=48, md_cap=320)
+        got, gc, gm = ctx.reg2aln_batch(bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(flavour), rl, ro, g.read_pool, regs, max_cigar=48, max_md=320)
+        for f in want.dtype.names:
+            assert np.array_equal(want[f], got[f]), (flavour, f)
+        assert np.array_equal(wc, gc) and np.array_equal(wm, gm)
+    assert ctx.reg2aln_batch(bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(), [], [], g.read_pool, regs[:0])[0].shape[0] == 0
+    # a tiny room for the CIGAR: the job reports how many operations it needs and produces none of them
+    a, c, _ = ctx.reg2aln_batch(bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(), rl, ro, g.read_pool, regs, max_cigar=1, max_md=320)
+    big = want["n_cigar"] > 1
+    assert big.any() and np.array_equal(a["n_cigar"], want["n_cigar"]) and not c[big].any()
+    bad = regs[:1].copy(); bad["re"] = 2 * g.l_pac + 5
+    with pytest.raises(bpsw_hip.BpswError):
+        ctx.reg2aln_batch(bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(), rl[:1], ro[:1], g.read_pool, bad)
+    bad = regs[:1].copy(); bad["qe"] = 10_000
+    with pytest.raises(bpsw_hip.BpswError):
+        ctx.reg2aln_batch(bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(), rl[:1], ro[:1], g.read_pool, bad)
