@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
-    "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_last_tail_kernel",
+    "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_last_tail_times",
 ]
 JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI",
@@ -38,6 +38,8 @@ JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld",
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI",   # new entry for SURVEY.md 8f.2
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI",   # new entry for SURVEY.md 8f.3
+    "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI",            # new entries for SURVEY.md 8f.1 / 8f.4
+    "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI",
 ]
 
 
@@ -169,7 +171,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_reg2aln_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bpsw_sam_pe_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.POINTER(C.c_size_t), C.c_void_p]
-    lib.bpsw_last_tail_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    lib.bpsw_last_tail_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -609,12 +611,21 @@ def _ctx_sam_pe_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA"):
 
 
 def _ctx_last_tail_kernel(self):
+    """(kernel ms, jobs) of the most recent tail call"""
     ms, n = C.c_float(0), C.c_int32(0)
-    _chk(self.lib, self.lib.bpsw_last_tail_kernel(self.h, C.byref(ms), C.byref(n)), "bpsw_last_tail_kernel")
+    _chk(self.lib, self.lib.bpsw_last_tail_times(self.h, C.byref(ms), C.byref(n), None), "bpsw_last_tail_times")
     return ms.value, n.value
+
+
+def _ctx_last_tail_host_ms(self):
+    """(plan, device round trip, emit) ms of the most recent bpsw_sam_pe_batch"""
+    h = (C.c_double * 3)()
+    _chk(self.lib, self.lib.bpsw_last_tail_times(self.h, None, None, h), "bpsw_last_tail_times")
+    return h[0], h[1], h[2]
 
 
 Context.bns_load = _ctx_bns_load
 Context.reg2aln_batch = _ctx_reg2aln_batch
 Context.sam_pe_batch = _ctx_sam_pe_batch
 Context.last_tail_kernel = _ctx_last_tail_kernel
+Context.last_tail_host_ms = _ctx_last_tail_host_ms

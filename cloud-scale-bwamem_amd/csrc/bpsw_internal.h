@@ -236,7 +236,8 @@ struct bpsw_ctx {
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
   bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
   float last_tail_ms = 0.f;
-  int last_tail_jobs = 0;
+  int last_tail_jobs = 0, last_tail_resubmitted = 0;
+  double tail_host_ms[3] = {0., 0., 0.};  // plan, device round trip (staging + copies + kernel), emit
   bool have_tail_ev = false;
 
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;

@@ -10,6 +10,9 @@
 //                                                                  INTEGRATION.md): puts the 2-bit reference on every
 //                                                                  visible device; mateSWJNI then accepts RefSWType
 //                                                                  objects whose ref0..ref3 are null (coordinates only)
+//   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI             NEW: the contig table next to the reference
+//   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI           NEW: memSamPeGroupRest for a group of
+//                                                                  pairs in one call, primitive arrays in, SAM text out
 //
 // Differences from the reference glue that a JVM can observe: nothing is printed, the JVM is never
 // exit()ed or assert()ed, a device failure surfaces as a java.lang.RuntimeException (Spark retries the
@@ -17,6 +20,7 @@
 // arrays are read with Get*ArrayRegion (no pinning).  No JVM exists in the build image, so this file
 // is compile- and link-checked, and exercised through a fake JNIEnv table in tests/test_jni_shim.py.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -455,6 +459,145 @@ JNIEXPORT jlongArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chain
   jlongArray ret = jni::NewLongArray(env, (jsize)flat.size());
   if (!ret) return nullptr;  // OutOfMemoryError already pending
   if (!flat.empty()) jni::SetLongArrayRegion(env, ret, 0, (jsize)flat.size(), flat.data());
+  return ret;
+}
+
+// ---- worker2's tail -----------------------------------------------------------------------------
+// Scala side (jni/MateSWJNI.scala):
+//   @native def loadBnsJNI(offset: Array[Long], len: Array[Int], names: Array[Byte]): Int     // names NUL-terminated, back to back
+// Call once per executor JVM after loadPacJNI (bns.anns(i).offset / .len / .name); returns the number of devices loaded.
+JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI(JNIEnv* env, jobject, jlongArray offArr, jintArray lenArr,
+                                                                          jbyteArray namesArr) {
+  if (!offArr || !lenArr) { throw_runtime(env, "bPSW: loadBnsJNI: bad arguments"); return 0; }
+  const jsize n = jni::GetArrayLength(env, offArr);
+  if (n < 1 || jni::GetArrayLength(env, lenArr) != n) { throw_runtime(env, "bPSW: loadBnsJNI: offset and len must have one entry per contig"); return 0; }
+  std::vector<jlong> off((size_t)n);
+  std::vector<jint> len((size_t)n);
+  jni::GetLongArrayRegion(env, offArr, 0, n, off.data());
+  jni::GetIntArrayRegion(env, lenArr, 0, n, len.data());
+  std::vector<char> names;
+  if (namesArr) {
+    const jsize nb = jni::GetArrayLength(env, namesArr);
+    names.resize((size_t)nb + 1, 0);
+    if (nb > 0) jni::GetByteArrayRegion(env, namesArr, 0, nb, reinterpret_cast<jbyte*>(names.data()));
+    jsize zeros = 0;
+    for (jsize i = 0; i < nb; ++i) zeros += names[(size_t)i] == 0;
+    if (zeros < n) { throw_runtime(env, "bPSW: loadBnsJNI: fewer NUL-terminated names than contigs"); return 0; }
+  }
+  const int ndev = bpsw_device_count();
+  if (ndev <= 0) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return 0; }
+  int loaded = 0;
+  for (int d = 0; d < ndev; ++d) {
+    bpsw_ctx_t* c = nullptr;
+    int rc = bpsw_create(d, &c);
+    if (rc == BPSW_OK) rc = bpsw_bns_load(c, n, reinterpret_cast<const int64_t*>(off.data()), len.data(), namesArr ? names.data() : nullptr);
+    if (c) bpsw_destroy(c);
+    if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: loadBnsJNI: ") + bpsw_last_error()); return loaded; }
+    ++loaded;
+  }
+  return loaded;
+}
+
+// Scala side (jni/MateSWJNI.scala); replaces the body of memSamPeGroupRest (worker2/MemSamPe.scala:1390-1612):
+//   @native def samPeTailJNI(optInts: Array[Int], reals: Array[Double], mat: Array[Byte], id: Long, readLen: Array[Int],
+//                            reads: Array[Byte], quals: Array[Byte], nameLen: Array[Int], names: Array[Byte], regCnt: Array[Int],
+//                            regLongs: Array[Long], regInts: Array[Int], outOff: Array[Long]): Array[Byte]
+// optInts = (a, b, oDel, eDel, oIns, eIns, penUnpaired, w, T, flag, minSeedLen, mapQCoefFac);
+// reals   = (maskLevel, mapQCoefLen) then per orientation (low, high, failed, avg, std);
+// readLen / regCnt are indexed 2k+i; reads / quals / names back to back (quals may be null: '*');
+// regLongs = (rBeg, rEnd) and regInts = (qBeg, qEnd, score, trueScore, sub, csub, subNum, width, seedCov, secondary) per region,
+// in (k, i, j) order as mateSWJNI returns them.  Returns the SAM text of the group; the text of read 2k+i is
+// [outOff(2k+i), outOff(2k+i+1)) (outOff has 2*groupSize + 1 entries).  BPSW_TAIL_COMPAT=c selects the C flavour.
+JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI(
+    JNIEnv* env, jobject, jintArray optInts, jdoubleArray realsArr, jbyteArray matArr, jlong id0, jintArray readLenArr, jbyteArray readsArr,
+    jbyteArray qualsArr, jintArray nameLenArr, jbyteArray namesArr, jintArray regCntArr, jlongArray regLongsArr, jintArray regIntsArr,
+    jlongArray outOffArr) {
+  if (!optInts || !realsArr || !matArr || !readLenArr || !readsArr || !nameLenArr || !namesArr || !regCntArr || !regLongsArr || !regIntsArr ||
+      !outOffArr || jni::GetArrayLength(env, optInts) < 12 || jni::GetArrayLength(env, realsArr) < 22 || jni::GetArrayLength(env, matArr) < 25) {
+    throw_runtime(env, "bPSW: samPeTailJNI: bad arguments");
+    return nullptr;
+  }
+  bpsw_opt_t opt;
+  bpsw_opt_default(&opt);
+  bpsw_tail_opt_t topt;
+  bpsw_tail_opt_default(&topt);
+  jint oi[12];
+  jni::GetIntArrayRegion(env, optInts, 0, 12, oi);
+  opt.a = oi[0]; opt.b = oi[1]; opt.o_del = oi[2]; opt.e_del = oi[3]; opt.o_ins = oi[4]; opt.e_ins = oi[5]; opt.pen_unpaired = oi[6];
+  opt.w = oi[7]; opt.T = oi[8]; opt.flag = oi[9]; opt.min_seed_len = oi[10]; topt.mapq_coef_fac = oi[11];
+  jdouble re[22];
+  jni::GetDoubleArrayRegion(env, realsArr, 0, 22, re);
+  topt.mask_level = (float)re[0]; topt.mapq_coef_len = (float)re[1];
+  jni::GetByteArrayRegion(env, matArr, 0, 25, reinterpret_cast<jbyte*>(opt.mat));
+  const char* compat = getenv("BPSW_TAIL_COMPAT");
+  topt.flavour = (compat && (compat[0] == 'c' || compat[0] == 'C')) ? BPSW_TAIL_C : BPSW_TAIL_SCALA;
+  const jsize n2 = jni::GetArrayLength(env, readLenArr);
+  const jsize G = n2 / 2;
+  if ((n2 & 1) || jni::GetArrayLength(env, regCntArr) != n2 || jni::GetArrayLength(env, nameLenArr) != G ||
+      jni::GetArrayLength(env, outOffArr) < n2 + 1) {
+    throw_runtime(env, "bPSW: samPeTailJNI: array lengths do not describe groupSize pairs");
+    return nullptr;
+  }
+  std::vector<int32_t> read_len((size_t)n2), reg_cnt((size_t)n2), name_len((size_t)G);
+  if (n2) { jni::GetIntArrayRegion(env, readLenArr, 0, n2, read_len.data()); jni::GetIntArrayRegion(env, regCntArr, 0, n2, reg_cnt.data()); }
+  if (G) jni::GetIntArrayRegion(env, nameLenArr, 0, G, name_len.data());
+  std::vector<int64_t> read_off((size_t)n2), name_off((size_t)G + 1, 0);
+  int64_t at = 0, n_regs = 0;
+  for (jsize r = 0; r < n2; ++r) {
+    if (read_len[(size_t)r] < 0 || reg_cnt[(size_t)r] < 0) { throw_runtime(env, "bPSW: samPeTailJNI: negative length or count"); return nullptr; }
+    read_off[(size_t)r] = at; at += read_len[(size_t)r]; n_regs += reg_cnt[(size_t)r];
+  }
+  for (jsize k = 0; k < G; ++k) {
+    if (name_len[(size_t)k] < 0) { throw_runtime(env, "bPSW: samPeTailJNI: negative name length"); return nullptr; }
+    name_off[(size_t)k + 1] = name_off[(size_t)k] + name_len[(size_t)k];
+  }
+  if ((int64_t)jni::GetArrayLength(env, readsArr) < at || (qualsArr && (int64_t)jni::GetArrayLength(env, qualsArr) < at) ||
+      (int64_t)jni::GetArrayLength(env, namesArr) < name_off[(size_t)G] || (int64_t)jni::GetArrayLength(env, regLongsArr) < 2 * n_regs ||
+      (int64_t)jni::GetArrayLength(env, regIntsArr) < 10 * n_regs) {
+    throw_runtime(env, "bPSW: samPeTailJNI: a pool is shorter than its table says");
+    return nullptr;
+  }
+  std::vector<uint8_t> reads((size_t)at + 16), quals;
+  if (at) jni::GetByteArrayRegion(env, readsArr, 0, (jsize)at, reinterpret_cast<jbyte*>(reads.data()));
+  if (qualsArr) { quals.resize((size_t)at + 16); if (at) jni::GetByteArrayRegion(env, qualsArr, 0, (jsize)at, reinterpret_cast<jbyte*>(quals.data())); }
+  std::vector<char> names((size_t)name_off[(size_t)G] + 1);
+  if (name_off[(size_t)G]) jni::GetByteArrayRegion(env, namesArr, 0, (jsize)name_off[(size_t)G], reinterpret_cast<jbyte*>(names.data()));
+  std::vector<jlong> rl((size_t)(2 * n_regs) + 1);
+  std::vector<jint> ri((size_t)(10 * n_regs) + 1);
+  if (n_regs) { jni::GetLongArrayRegion(env, regLongsArr, 0, (jsize)(2 * n_regs), rl.data()); jni::GetIntArrayRegion(env, regIntsArr, 0, (jsize)(10 * n_regs), ri.data()); }
+  std::vector<bpsw_alnreg_t> regs((size_t)n_regs + 1);
+  for (int64_t j = 0; j < n_regs; ++j) {
+    bpsw_alnreg_t& a = regs[(size_t)j];
+    const jint* v = ri.data() + 10 * j;
+    a.rb = rl[(size_t)(2 * j)]; a.re = rl[(size_t)(2 * j + 1)];
+    a.qb = v[0]; a.qe = v[1]; a.score = v[2]; a.truesc = v[3]; a.sub = v[4]; a.csub = v[5]; a.sub_n = v[6]; a.w = v[7]; a.seedcov = v[8];
+    a.secondary = v[9]; a.hash = 0;
+  }
+  bpsw_pairs_t g;
+  memset(&g, 0, sizeof g);
+  g.group_size = G; g.id0 = id0;
+  for (int r = 0; r < 4; ++r) {
+    g.pes[r].low = (int32_t)re[2 + 5 * r]; g.pes[r].high = (int32_t)re[3 + 5 * r]; g.pes[r].failed = (int32_t)re[4 + 5 * r];
+    g.pes[r].avg = re[5 + 5 * r]; g.pes[r].std = re[6 + 5 * r];
+  }
+  g.read_len = read_len.data(); g.read_off = read_off.data(); g.read_pool = reads.data(); g.qual_pool = qualsArr ? quals.data() : nullptr;
+  g.read_pool_bytes = (size_t)at; g.name_off = name_off.data(); g.name_pool = names.data(); g.reg_cnt = reg_cnt.data(); g.regs = regs.data();
+  bpsw_ctx_t* ctx = thread_context(env);
+  if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
+  std::vector<int64_t> out_off((size_t)n2 + 1, 0);
+  std::vector<char> text((size_t)G * 1400 + 1024);
+  size_t need = 0;
+  int rc = bpsw_sam_pe_batch(ctx, &opt, &topt, &g, text.data(), text.size(), out_off.data(), &need, nullptr);
+  if (rc == BPSW_ERR_CAPACITY && need > text.size()) {
+    text.resize(need + 16);
+    rc = bpsw_sam_pe_batch(ctx, &opt, &topt, &g, text.data(), text.size(), out_off.data(), &need, nullptr);
+  }
+  if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: samPeTailJNI: ") + bpsw_last_error()); return nullptr; }
+  if (need > 0x7fffffffULL) { throw_runtime(env, "bPSW: samPeTailJNI: SAM text of the group exceeds 2 GiB; use a smaller group"); return nullptr; }
+  jbyteArray ret = jni::NewByteArray(env, (jsize)need);
+  if (!ret) return nullptr;  // OutOfMemoryError already pending
+  if (need) jni::SetByteArrayRegion(env, ret, 0, (jsize)need, reinterpret_cast<const jbyte*>(text.data()));
+  jni::SetLongArrayRegion(env, outOffArr, 0, n2 + 1, reinterpret_cast<const jlong*>(out_off.data()));
   return ret;
 }
 

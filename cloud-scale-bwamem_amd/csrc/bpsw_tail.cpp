@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <utility>
 #include <vector>
@@ -30,6 +31,9 @@ int hip_fail(hipError_t e, const char* what) { return fail(BPSW_ERR_DEVICE, std:
   } while (0)
 
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // the kernel stages at most this many CIGAR operations (CIG_LDS in bpsw_global_core.h)
 constexpr int KERNEL_CIG_CAP = 512;
@@ -136,8 +140,8 @@ int launch_jobs(bpsw_ctx* c, const SwScoring& sc, const bpsw_opt_t* opt, int fla
   HIP_TRY(hipStreamSynchronize(c->stream));
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]);
-  c->last_tail_ms = ms;
-  c->last_tail_jobs = n;
+  c->last_tail_ms += ms;  // a call may launch twice (jobs whose CIGAR / MD outgrew the first, small, room)
+  c->last_tail_jobs += n;  // distinct jobs = this minus last_tail_resubmitted
   c->have_tail_ev = true;
   const uint8_t* r = (const uint8_t*)c->h_stage_out.ptr;
   memcpy(out, r + r_out, sizeof(Reg2AlnOut) * (size_t)n);
@@ -180,6 +184,7 @@ int run_jobs(bpsw_ctx* c, const SwScoring& sc, const bpsw_opt_t* opt, int flavou
       }
     }
     todo.swap(again);
+    c->last_tail_resubmitted += (int)todo.size();
     max_cigar = std::min(max_cigar * 8, KERNEL_CIG_CAP + 2);
     max_md = std::min(max_md * 8, 4096 + 2 * BPSW_R2A_MAX_QLEN);
   }
@@ -525,6 +530,7 @@ int bpsw_reg2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt
   for (int t = 0; t < n; ++t)
     if (j->regs[t].rb >= 0 && j->regs[t].re >= 0) { mapped.push_back(t); rl.push_back(j->read_len[t]); ro.push_back(j->read_off[t]); rg.push_back(j->regs[t]); }
   const int m = (int)mapped.size();
+  c->last_tail_ms = 0.f; c->last_tail_jobs = 0; c->last_tail_resubmitted = 0; c->tail_host_ms[0] = c->tail_host_ms[1] = c->tail_host_ms[2] = 0.;
   std::vector<Reg2AlnOut> k((size_t)m);
   std::vector<uint32_t> cig((size_t)m * (size_t)j->max_cigar);
   std::vector<uint8_t> md((size_t)m * (size_t)j->max_md);
@@ -574,6 +580,8 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
   const bpsw_tail_opt_t& t = *topt;
 
   // ---- plan -----------------------------------------------------------------------------------------------------------
+  c->last_tail_ms = 0.f; c->last_tail_jobs = 0; c->last_tail_resubmitted = 0;
+  const double t_plan = now_ms();
   std::vector<std::vector<bpsw_alnreg_t> > regs((size_t)(2 * G));
   std::vector<PairPlan> plan((size_t)G);
   std::vector<int32_t> job_len;
@@ -640,6 +648,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
 
   // ---- device -----------------------------------------------------------------------------------------------------------
   std::vector<JobResult> res;
+  const double t_dev = now_ms();
   rc = run_jobs(c, sc, opt, t.flavour, bns, job_len, job_off, g->read_pool, g->read_pool_bytes, job_reg, &res);
   if (rc != BPSW_OK) return rc;
   for (size_t j = 0; j < res.size(); ++j)
@@ -648,6 +657,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
                                                                    : "sam_pe: an alignment has more CIGAR operations than the kernel stages");
 
   // ---- emit ---------------------------------------------------------------------------------------------------------------
+  const double t_emit = now_ms();
   std::string text;
   text.reserve((size_t)G * 700);
   for (int k = 0; k < G; ++k) {
@@ -712,16 +722,18 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
     size_t w = 0;
     for (int r = 0; r < 2 * G; ++r) { if (!regs[(size_t)r].empty()) memcpy(out_regs + w, regs[(size_t)r].data(), sizeof(bpsw_alnreg_t) * regs[(size_t)r].size()); w += regs[(size_t)r].size(); }
   }
+  c->tail_host_ms[0] = t_dev - t_plan; c->tail_host_ms[1] = t_emit - t_dev; c->tail_host_ms[2] = now_ms() - t_emit;
   if (out_needed) *out_needed = text.size();
   if (!out_text || text.size() > text_cap) return fail(BPSW_ERR_CAPACITY, "sam_pe: text buffer too small (see *out_needed)");
   memcpy(out_text, text.data(), text.size());
   return BPSW_OK;
 }
 
-int bpsw_last_tail_kernel(bpsw_ctx_t* c, float* ms, int32_t* n_jobs) {
+int bpsw_last_tail_times(bpsw_ctx_t* c, float* kernel_ms, int32_t* n_jobs, double host_ms[3]) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   std::lock_guard<std::mutex> g(c->mu);
-  if (ms) *ms = c->have_tail_ev ? c->last_tail_ms : 0.f;
-  if (n_jobs) *n_jobs = c->have_tail_ev ? c->last_tail_jobs : 0;
+  if (kernel_ms) *kernel_ms = c->have_tail_ev ? c->last_tail_ms : 0.f;
+  if (n_jobs) *n_jobs = c->have_tail_ev ? c->last_tail_jobs - c->last_tail_resubmitted : 0;  // distinct (read, region) jobs
+  if (host_ms) for (int i = 0; i < 3; ++i) host_ms[i] = c->tail_host_ms[i];
   return BPSW_OK;
 }

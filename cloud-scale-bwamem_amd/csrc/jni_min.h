@@ -30,6 +30,7 @@ typedef jarray jbyteArray;
 typedef jarray jshortArray;
 typedef jarray jintArray;
 typedef jarray jlongArray;
+typedef jarray jdoubleArray;
 struct _jfieldID;
 typedef _jfieldID* jfieldID;
 struct _jmethodID;
@@ -69,11 +70,14 @@ enum {
   JNI_SLOT_NewObjectArray = 172,
   JNI_SLOT_GetObjectArrayElement = 173,
   JNI_SLOT_SetObjectArrayElement = 174,
+  JNI_SLOT_NewByteArray = 176,
   JNI_SLOT_NewShortArray = 178,
   JNI_SLOT_NewLongArray = 180,
   JNI_SLOT_GetByteArrayRegion = 200,
   JNI_SLOT_GetIntArrayRegion = 203,
   JNI_SLOT_GetLongArrayRegion = 204,
+  JNI_SLOT_GetDoubleArrayRegion = 206,
+  JNI_SLOT_SetByteArrayRegion = 208,
   JNI_SLOT_SetShortArrayRegion = 210,
   JNI_SLOT_SetLongArrayRegion = 212,
   JNI_SLOT_ExceptionCheck = 228,
@@ -122,5 +126,8 @@ inline void SetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, const 
 inline void GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, jbyte* b) { fn<void (*)(JNIEnv*, jbyteArray, jsize, jsize, jbyte*)>(e, JNI_SLOT_GetByteArrayRegion)(e, a, s, l, b); }
 inline void GetIntArrayRegion(JNIEnv* e, jintArray a, jsize s, jsize l, jint* b) { fn<void (*)(JNIEnv*, jintArray, jsize, jsize, jint*)>(e, JNI_SLOT_GetIntArrayRegion)(e, a, s, l, b); }
 inline void GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, jlong* b) { fn<void (*)(JNIEnv*, jlongArray, jsize, jsize, jlong*)>(e, JNI_SLOT_GetLongArrayRegion)(e, a, s, l, b); }
+inline jbyteArray NewByteArray(JNIEnv* e, jsize n) { return fn<jbyteArray (*)(JNIEnv*, jsize)>(e, JNI_SLOT_NewByteArray)(e, n); }
+inline void SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, const jbyte* b) { fn<void (*)(JNIEnv*, jbyteArray, jsize, jsize, const jbyte*)>(e, JNI_SLOT_SetByteArrayRegion)(e, a, s, l, b); }
+inline void GetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize s, jsize l, jdouble* b) { fn<void (*)(JNIEnv*, jdoubleArray, jsize, jsize, jdouble*)>(e, JNI_SLOT_GetDoubleArrayRegion)(e, a, s, l, b); }
 inline void SetShortArrayRegion(JNIEnv* e, jshortArray a, jsize s, jsize l, const jshort* b) { fn<void (*)(JNIEnv*, jshortArray, jsize, jsize, const jshort*)>(e, JNI_SLOT_SetShortArrayRegion)(e, a, s, l, b); }
 }  // namespace jni

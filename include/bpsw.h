@@ -329,9 +329,9 @@ typedef struct {
 } bpsw_pairs_t;
 int bpsw_sam_pe_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_pairs_t *g, char *out_text,
                       size_t text_cap, int64_t *out_off, size_t *out_needed, bpsw_alnreg_t *out_regs);
-/* duration in ms of the most recent reg2aln kernel launch on this context (hipEvents on the launch stream), and the
- * number of jobs it carried */
-int bpsw_last_tail_kernel(bpsw_ctx_t *ctx, float *ms, int32_t *n_jobs);
+/* the most recent tail call on this context: kernel_ms = reg2aln_kernel launches (hipEvents on the launch stream), n_jobs =
+ * jobs they carried, host_ms = {plan, device round trip (staging, copies, kernel), emit} of bpsw_sam_pe_batch */
+int bpsw_last_tail_times(bpsw_ctx_t *ctx, float *kernel_ms, int32_t *n_jobs, double host_ms[3]);
 
 /* ---- statistics (the buckets of profiling/SWBatchTimeBreakdown.scala:25-39, device flavoured) -- */
 typedef struct {

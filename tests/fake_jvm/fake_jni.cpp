@@ -27,6 +27,7 @@ struct FObj {
   std::vector<int16_t> shorts;
   std::vector<int32_t> ia;
   std::vector<int64_t> la;
+  std::vector<double> da;
   std::vector<FObj*> elems;
 };
 struct FField { std::string name, sig; };
@@ -106,6 +107,7 @@ jsize f_GetArrayLength(JNIEnv*, jarray a) {
   if (o->cls == "[S") return (jsize)o->shorts.size();
   if (o->cls == "[I") return (jsize)o->ia.size();
   if (o->cls == "[J") return (jsize)o->la.size();
+  if (o->cls == "[D") return (jsize)o->da.size();
   return (jsize)o->elems.size();
 }
 jobjectArray f_NewObjectArray(JNIEnv*, jsize n, jclass, jobject) {
@@ -131,6 +133,13 @@ void f_SetLongArrayRegion(JNIEnv*, jlongArray a, jsize s, jsize l, const jlong* 
 void f_GetByteArrayRegion(JNIEnv*, jbyteArray a, jsize s, jsize l, jbyte* b) { memcpy(b, O(a)->bytes.data() + s, (size_t)l); }
 void f_GetIntArrayRegion(JNIEnv*, jintArray a, jsize s, jsize l, jint* b) { memcpy(b, O(a)->ia.data() + s, 4 * (size_t)l); }
 void f_GetLongArrayRegion(JNIEnv*, jlongArray a, jsize s, jsize l, jlong* b) { memcpy(b, O(a)->la.data() + s, 8 * (size_t)l); }
+jbyteArray f_NewByteArray(JNIEnv*, jsize n) {
+  FObj* a = g_vm->alloc("[B");
+  a->bytes.assign((size_t)n, 0);
+  return (jbyteArray)J(a);
+}
+void f_SetByteArrayRegion(JNIEnv*, jbyteArray a, jsize s, jsize l, const jbyte* b) { memcpy(O(a)->bytes.data() + s, b, (size_t)l); }
+void f_GetDoubleArrayRegion(JNIEnv*, jdoubleArray a, jsize s, jsize l, jdouble* b) { memcpy(b, O(a)->da.data() + s, 8 * (size_t)l); }
 void f_SetShortArrayRegion(JNIEnv*, jshortArray a, jsize s, jsize l, const jshort* b) { memcpy(O(a)->shorts.data() + s, b, 2 * (size_t)l); }
 
 void unpopulated() {
@@ -150,6 +159,7 @@ struct Env {
     SET(GetStaticMethodID); SET(CallStaticObjectMethod); SET(CallIntMethod); SET(GetArrayLength); SET(NewObjectArray);
     SET(GetObjectArrayElement); SET(SetObjectArrayElement); SET(NewShortArray); SET(GetByteArrayRegion);
     SET(GetIntArrayRegion); SET(GetLongArrayRegion); SET(SetShortArrayRegion); SET(NewLongArray); SET(SetLongArrayRegion);
+    SET(NewByteArray); SET(SetByteArrayRegion); SET(GetDoubleArrayRegion);
 #undef SET
     env = &table;
   }
@@ -169,6 +179,12 @@ FObj* int_array(const int32_t* p, size_t n) {
 FObj* long_array(const int64_t* p, size_t n) {
   FObj* a = g_vm->alloc("[J");
   a->la.assign(p, p + n);
+  return a;
+}
+
+FObj* double_array(const double* p, size_t n) {
+  FObj* a = g_vm->alloc("[D");
+  a->da.assign(p, p + n);
   return a;
 }
 
@@ -350,6 +366,51 @@ int fake_jvm_chain2aln(const char* lib, int partition, const uint8_t* pac, int64
   *out_n = (int64_t)O(r)->la.size();
   if (*out_n > out_cap) { snprintf(err, (size_t)errcap, "out_cap too small"); return -1; }
   memcpy(out, O(r)->la.data(), 8 * (size_t)*out_n);
+  return 0;
+}
+
+// loadPacJNI + loadBnsJNI, then samPeTailJNI with primitive arrays.  out_text receives the returned
+// byte[], out_off the offsets the native filled in.
+int fake_jvm_sam_pe_tail(const char* lib, int partition, const uint8_t* pac, int64_t l_pac, int n_seqs, const int64_t* ann_off,
+                         const int32_t* ann_len, const uint8_t* ann_names, int64_t ann_names_bytes, const int32_t opt_ints[12],
+                         const double reals[22], const int8_t mat[25], int64_t id0, int n2, const int32_t* read_len, const uint8_t* reads,
+                         const uint8_t* quals, int64_t reads_bytes, const int32_t* name_len, const uint8_t* names, int64_t names_bytes,
+                         const int32_t* reg_cnt, const int64_t* reg_longs, const int32_t* reg_ints, int64_t n_regs, uint8_t* out_text,
+                         int64_t out_cap, int64_t* out_bytes, int64_t* out_off, char* err, int errcap) {
+  Jvm vm;
+  g_vm = &vm;
+  vm.partition = partition;
+  Env e;
+  FObj* self = vm.alloc("cs/ucla/edu/bwaspark/jni/MateSWJNI");
+  typedef jint (*LoadFn)(JNIEnv*, jobject, jbyteArray, jlong);
+  LoadFn load = (LoadFn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI", err, (size_t)errcap);
+  if (!load) return -1;
+  load(&e.env, J(self), (jbyteArray)J(byte_array(pac, (size_t)((l_pac + 3) / 4))), (jlong)l_pac);
+  if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+  typedef jint (*BnsFn)(JNIEnv*, jobject, jlongArray, jintArray, jbyteArray);
+  BnsFn bns = (BnsFn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI", err, (size_t)errcap);
+  if (!bns) return -1;
+  bns(&e.env, J(self), (jlongArray)J(long_array(ann_off, (size_t)n_seqs)), (jintArray)J(int_array(ann_len, (size_t)n_seqs)),
+      (jbyteArray)J(byte_array(ann_names, (size_t)ann_names_bytes)));
+  if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+  typedef jbyteArray (*Fn)(JNIEnv*, jobject, jintArray, jdoubleArray, jbyteArray, jlong, jintArray, jbyteArray, jbyteArray, jintArray,
+                           jbyteArray, jintArray, jlongArray, jintArray, jlongArray);
+  Fn fn = (Fn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI", err, (size_t)errcap);
+  if (!fn) return -1;
+  std::vector<int64_t> zero((size_t)n2 + 1, 0);
+  FObj* off = long_array(zero.data(), zero.size());
+  jbyteArray r = fn(&e.env, J(self), (jintArray)J(int_array(opt_ints, 12)), (jdoubleArray)J(double_array(reals, 22)),
+                    (jbyteArray)J(byte_array(reinterpret_cast<const uint8_t*>(mat), 25)), (jlong)id0, (jintArray)J(int_array(read_len, (size_t)n2)),
+                    (jbyteArray)J(byte_array(reads, (size_t)reads_bytes)), quals ? (jbyteArray)J(byte_array(quals, (size_t)reads_bytes)) : nullptr,
+                    (jintArray)J(int_array(name_len, (size_t)(n2 / 2))), (jbyteArray)J(byte_array(names, (size_t)names_bytes)),
+                    (jintArray)J(int_array(reg_cnt, (size_t)n2)), (jlongArray)J(long_array(reg_longs, (size_t)(2 * n_regs))),
+                    (jintArray)J(int_array(reg_ints, (size_t)(10 * n_regs))), (jlongArray)J(off));
+  if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+  if (!r) { snprintf(err, (size_t)errcap, "null result"); return -1; }
+  *out_bytes = (int64_t)O(r)->bytes.size();
+  if (*out_bytes > out_cap) { snprintf(err, (size_t)errcap, "out_cap too small"); return -1; }
+  memcpy(out_text, O(r)->bytes.data(), (size_t)*out_bytes);
+  memcpy(out_off, off->la.data(), 8 * ((size_t)n2 + 1));
   return 0;
 }
 

@@ -138,3 +138,42 @@ def test_chain2aln_through_jni_matches_c_abi(fake, ctx):
     flat = out[n:out_n.value].reshape(-1, 8)
     for k, f in enumerate(("rb", "re", "qb", "qe", "score", "truesc", "w", "seedcov")):
         assert np.array_equal(flat[:, k], want[f].astype(np.int64)), f
+
+
+@pytest.mark.gpu
+def test_sam_pe_tail_through_jni_matches_c_abi(fake, ctx, orc):
+    """SURVEY.md 8f.1 / 8f.4 through the JNI surface: loadPacJNI + loadBnsJNI + samPeTailJNI (primitive arrays in, SAM text out)"""
+    from tail_util import synthetic_group
+    pac, g = synthetic_group(orc, 250, 7070, sub_rate=0.03, indel_rate=0.008, p_span=0.05)
+    names = [bytes(g.ann_name_pool[int(g.ann_name_off[i]):int(g.ann_name_off[i + 1])]).decode() for i in range(g.ann_off.shape[0])]
+    ctx.ref_load(pac, g.l_pac)
+    ctx.bns_load(g.ann_off, g.ann_len, names)
+    opt, topt = bpsw_hip.default_opt(), bpsw_hip.default_tail_opt()
+    want, _ = ctx.sam_pe_batch(opt, topt, g)
+    n2 = 2 * g.group_size
+    reads = np.concatenate([g.read_pool[o:o + n] for o, n in zip(g.read_off, g.read_len)])      # back to back, as the Scala side sends them
+    quals = np.concatenate([g.qual_pool[o:o + n] for o, n in zip(g.read_off, g.read_len)])
+    name_len = np.diff(g.name_off).astype(np.int32)
+    rnames = np.ascontiguousarray(g.name_pool[:int(g.name_off[-1])])
+    ann_names = np.frombuffer(b"".join(n.encode() + b"\0" for n in names), np.uint8).copy()
+    ints = np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_unpaired, opt.w, opt.T, opt.flag, opt.min_seed_len,
+                     topt.mapq_coef_fac], np.int32)
+    reals = np.array([topt.mask_level, topt.mapq_coef_len] + [float(v) for p in g.pes for v in p], np.float64)
+    mat = np.array(list(opt.mat), np.int8)
+    reg_longs = np.ascontiguousarray(np.stack([g.regs["rb"], g.regs["re"]], axis=1).reshape(-1), np.int64)
+    reg_ints = np.ascontiguousarray(np.stack([g.regs[f] for f in ("qb", "qe", "score", "truesc", "sub", "csub", "sub_n", "w", "seedcov", "secondary")],
+                                             axis=1).reshape(-1), np.int32)
+    out = np.zeros(sum(len(t) for t in want) + 64, np.uint8)
+    out_off = np.zeros(n2 + 1, np.int64)
+    nb = C.c_int64(0)
+    err = C.create_string_buffer(512)
+    fake.fake_jvm_sam_pe_tail.restype = C.c_int
+    rc = fake.fake_jvm_sam_pe_tail(bpsw_hip.LIB_PATH.encode(), 3, _vp(pac), C.c_int64(g.l_pac), C.c_int(len(names)), _vp(g.ann_off), _vp(g.ann_len),
+                                   _vp(ann_names), C.c_int64(ann_names.size), _vp(ints), _vp(reals), _vp(mat), C.c_int64(g.id0), C.c_int(n2),
+                                   _vp(np.ascontiguousarray(g.read_len)), _vp(reads), _vp(quals), C.c_int64(reads.size), _vp(name_len), _vp(rnames),
+                                   C.c_int64(rnames.size), _vp(np.ascontiguousarray(g.reg_cnt)), _vp(reg_longs), _vp(reg_ints),
+                                   C.c_int64(g.regs.shape[0]), _vp(out), C.c_int64(out.size), C.byref(nb), _vp(out_off), err, 512)
+    assert rc == 0, err.value.decode()
+    text = out[:nb.value].tobytes()
+    got = [text[int(out_off[i]):int(out_off[i + 1])] for i in range(n2)]
+    assert got == want
