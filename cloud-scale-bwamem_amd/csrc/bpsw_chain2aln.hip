@@ -207,7 +207,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void chain2aln_kernel(const C
             for (int i = lane; i < tstage; i += 64) ts[i] = (uint8_t)(8 * pac_base(B.pac, B.l_pac, tpos + (long long)tstep * i));
             __builtin_amdgcn_wave_barrier();
             ExtRes x = {0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < 2; ++i) {  // MAX_BAND_TRY
+            // near-exact flank: the DP result is known without running it (bpsw_extend_core.h, flank_closed_form)
+            const int oe_min = min(oIns + eIns, oDel + eDel);
+            const bool exact = P.exact_a > 0 && oe_min > 0 && w0 >= 2 && rLen >= qLen && tstage >= qLen &&
+                               flank_closed_form(lane, qLen, qsrc, [ts](int j) { return (int)(ts[j] >> 3); }, P.mat, hInit, P.exact_a,
+                                                 oe_min, P.zdrop, &x);
+            if (exact) {
+              aw[side] = w0;
+              regScore = x.max;
+            }
+            for (int i = 0; i < 2 && !exact; ++i) {  // MAX_BAND_TRY
               const int prev = regScore;
               aw[side] = w0 << i;
               const int w = min(min(aw[side], maxIns), maxDel);

@@ -70,6 +70,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
   const int oIns = (int8_t)((hdr0 >> 16) & 0xff), eIns = (int8_t)((hdr0 >> 24) & 0xff);
   const int penClip5 = (int8_t)(hdr1 & 0xff), penClip3 = (int8_t)((hdr1 >> 8) & 0xff);
   const int wBand = (int8_t)((hdr1 >> 16) & 0xff);
+  // closed form for near-exact flanks (bpsw_extend_core.h, flank_closed_form): usable with this batch's band?
+  const int oe_min = min(oIns + eIns, oDel + eDel);
+  const int exact_a = (oe_min > 0 && wBand >= 2) ? sc.exact_a : 0;
 
   // Tasks differ in cost by an order of magnitude, so waves pull them from a shared counter instead of
   // striding: a wave takes the next task when it finishes one and leaves when the counter passes n_tasks.
@@ -108,10 +111,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
       const int sc0 = regScore;
       // register path: needs one lane per column 0..qLen and oeIns > 0 (see sw_extend_reg)
       const bool reg_path = qLen <= 255 && oIns + eIns > 0;
-      if (reg_path) load_target_shifts(lane, words, rStart, rLen, ts);
-      else load_side(lane, words, qStart, qLen, rStart, rLen, sc.mat, qp, ts);
       ExtRes r = {0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < 2; ++i) {  // MAX_BAND_TRY
+      // near-exact flank: the DP result is known (flank_closed_form); the retry loop would stop after its first try
+      const bool exact = exact_a > 0 && rLen >= qLen &&
+                         flank_closed_form(lane, qLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat, hInit, exact_a, oe_min,
+                                           sc.zdrop, &r);
+      if (exact) {
+        aw[side] = wBand;
+        regScore = r.max;
+      } else if (reg_path) {
+        load_target_shifts(lane, words, rStart, rLen, ts);
+      } else {
+        load_side(lane, words, qStart, qLen, rStart, rLen, sc.mat, qp, ts);
+      }
+      for (int i = 0; i < 2 && !exact; ++i) {  // MAX_BAND_TRY
         const int prev = regScore;
         aw[side] = wBand << i;
         const int w = min(min(aw[side], maxIns), maxDel);

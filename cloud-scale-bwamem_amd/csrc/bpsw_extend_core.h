@@ -351,6 +351,59 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Closed form for near-exact flanks.  Let a = the match score (every other matrix entry < a), s_j = S(t_j, q_j) the score
+// on the main diagonal, D_i = sum_{j<=i} (a - s_j) the diagonal deficit, D = D_{qLen-1}.  If
+//        D < min(oeIns, oeDel),   h0 > D,   tLen >= qLen        (default scoring: at most ONE substitution, or <= 3 N)
+// then SWExtend's result is known without running the DP:
+//   * the gapless path gives H(i,i) >= h0 + a(i+1) - D_i; any path that leaves the main diagonal pays a gap open (the
+//     first column and row -1 are themselves gap-penalised, SWUtil.scala:97-104,137), a path restarted from a zero cell
+//     starts at 0 < h0 - D, and no path collects more than min(i,j)+1 diagonal steps of at most +a each; hence every
+//     off-diagonal cell of row i is <= h0 + a(min(i,j)+1) - min(oeIns,oeDel) < H(i,i), and H(i,i) equals the gapless value:
+//     the row maximum is m(i) = h0 + a(i+1) - D_i at mj = i for every i < qLen (never 0);
+//   * the trimming keeps column mj+1 (SWUtil.scala:202-214: beg <= mj+1, end >= mj+2) and the band keeps the diagonal
+//     (w >= 1), so the next diagonal cell is always computed; rows with m <= max reach the z-drop test with
+//     i - max_i == mj - max_j: the Scala parse does nothing, the BWA parse compares max - m <= D with zdrop (so D <= zdrop
+//     is required when zdrop > 0);
+//   * max / max_i follow from folding m(i) with the strict `m > max` (m rises by a between deficit columns, so the only
+//     candidates are the rows just before a deficit column and the last row); max_off stays 0;
+//   * at row qLen-1 the loop ends at j == qLen: gscore = H(qLen-1,qLen-1) = h0 + a*qLen - D, max_ie = qLen-1; every later
+//     row has H(i,qLen-1) <= h0 + a*qLen - oeDel < gscore, so nothing after row qLen-1 (z-drop, m == 0, tLen) matters.
+// The caller's band retry stops after its first try (max_off = 0 < 3/4 aw needs aw >= 2).  Seeds are maximal exact
+// matches, so a flank always STARTS with an error; at 1 % substitutions about half of all flanks have no second one.
+// Verified against the oracle on 45 894 random flanks (homopolymers, tandem repeats, N, five gap-cost sets, w 2..200,
+// z-drop 0/3/5/100, both parses: 0 differences) and by every parity test, whose batches take this path for ~half the sides.
+// ExtScoring::exact_a / ChainParams::exact_a carry a (0: matrix not of that form, or BPSW_EXT_EXACT=0).
+template <class QC, class TC>
+__device__ __forceinline__ bool flank_closed_form(const int lane, const int qLen, const QC& qcode, const TC& tcode,
+                                                  const MatRows& mat, const int h0, const int a, const int oe_min,
+                                                  const int zdrop, ExtRes* out) {
+  int D = 0, best = h0, best_i = -1;  // SWUtil.scala:118-121: max = h0, max_i = max_j = -1
+  for (int j0 = 0; j0 < qLen; j0 += 64) {
+    const int j = j0 + lane;
+    int d = 0;
+    if (j < qLen) {
+      const int q = qcode(j), t = tcode(j);
+      d = a - (int)(int8_t)((mat.row[t] >> (8 * q)) & 0xff);
+    }
+    unsigned long long m = __builtin_amdgcn_ballot_w64(d > 0);
+    while (m) {  // the (very few) diagonal cells that are not a match
+      const int b = (int)__builtin_ctzll(m);
+      m &= m - 1;
+      const int pos = j0 + b;
+      const int v = h0 + pos * a - D;  // m(pos-1): the last row before this deficit
+      if (pos >= 1 && v > best) { best = v; best_i = pos - 1; }
+      D += __builtin_amdgcn_readlane(d, b);
+      if (D >= oe_min) return false;
+    }
+  }
+  if (h0 <= D || (zdrop > 0 && D > zdrop)) return false;
+  const int g = h0 + qLen * a - D;
+  if (g > best) { best = g; best_i = qLen - 1; }
+  out->max = best; out->qle = best_i + 1; out->tle = best_i + 1; out->gtle = qLen; out->gscore = g; out->max_off = 0;
+  return true;
+}
+
 // query source of a wire-batch task: nibble stream `words`, first column at base qStart
 struct NibbleQ {
   const uint32_t* __restrict__ words;

@@ -27,7 +27,10 @@ struct ExtScoring {
   int zdrop;
   int zdrop_mode;
   int mat_max;  // max(mat): bounds the scores a task can reach (selects the int16 register path)
+  int exact_a;  // match score when the exact-flank shortcut is valid for this matrix (bpsw_extend_core.h), else 0
 };
+// a > 0 if mat[c][c] == a for the four bases and every other entry is < a; else 0.  BPSW_EXT_EXACT=0 disables.
+int exact_match_score(const int8_t mat[25]);
 
 // ---- extension (boundary 2) -------------------------------------------------------------------
 // Result of the device-side table scan that validates a wire batch before the main launch.
@@ -161,6 +164,7 @@ hipError_t launch_reg2aln_kernel(const Reg2AlnDev& J, const SwScoring& sc, int q
 struct ChainParams {
   MatRows mat;
   int mat_max, a, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop, zmode;
+  int exact_a;  // see ExtScoring
 };
 struct ChainBatchDev {  // all device pointers
   int n_reads;

@@ -70,6 +70,19 @@ MatRows pack_mat(const int8_t mat[25]) {
   return m;
 }
 
+int exact_match_score(const int8_t mat[25]) {
+  static const bool off = getenv("BPSW_EXT_EXACT") && atoi(getenv("BPSW_EXT_EXACT")) == 0;  // A/B switch for measurements
+  if (off) return 0;
+  const int a = mat[0];
+  if (a <= 0) return 0;
+  for (int r = 0; r < 5; ++r)
+    for (int c = 0; c < 5; ++c) {
+      const bool diag = r == c && r < 4;
+      if (diag ? mat[r * 5 + c] != a : mat[r * 5 + c] >= a) return 0;
+    }
+  return a;
+}
+
 static void default_mat(int8_t mat[25], int a, int b) {  // bwaFillScmat, datatype/MemOptType.scala:58-73
   int k = 0;
   for (int i = 0; i < 4; ++i) {
@@ -151,6 +164,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.zdrop = 100;
   c->ext_sc.zdrop_mode = BPSW_ZDROP_SCALA;
   c->ext_sc.mat_max = 1;
+  c->ext_sc.exact_a = exact_match_score(c->ext_mat);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
   for (int k = 0; e == hipSuccess && k < 2; ++k) {
@@ -198,6 +212,7 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
   for (int k = 1; k < 25; ++k) c->ext_sc.mat_max = c->ext_mat[k] > c->ext_sc.mat_max ? c->ext_mat[k] : c->ext_sc.mat_max;
   c->ext_sc.zdrop = zdrop;
   c->ext_sc.zdrop_mode = zdrop_mode;
+  c->ext_sc.exact_a = exact_match_score(c->ext_mat);
   return BPSW_OK;
 }
 
