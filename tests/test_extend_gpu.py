@@ -121,3 +121,54 @@ def test_device_resident_entry_matches_host_entry(ctx, orc):
     torch.cuda.synchronize()
     assert ext_ms > 0
     assert np.array_equal(d_out.cpu().numpy(), want)
+
+
+def test_near_exact_flanks_closed_form_boundaries(ctx, orc):
+    """The closed form for near-exact flanks (bpsw_extend_core.h, flank_closed_form): flanks built around its validity
+    boundary -- diagonal deficit just below / at / above a gap open, h0 <= deficit, repeats that offer gapped alternatives,
+    N on either strand, reference exactly as long as the query -- under several gap costs, bands, z-drops and both parses.
+    The kernel must agree with the oracle's full DP whichever path it takes."""
+    rng = np.random.default_rng(11)
+
+    def flank(kind, n):
+        if kind == 0:
+            return rng.integers(0, 4, n)
+        if kind == 1:
+            return np.full(n, rng.integers(0, 4))                      # homopolymer: every shifted diagonal matches too
+        return np.tile(rng.integers(0, 4, int(rng.integers(1, 4))), n)[:n]   # tandem repeat
+
+    tasks = []
+    for t in range(1500):
+        sides = []
+        for _ in range(2):
+            n = int(rng.integers(1, 132))
+            q = flank(t % 3, n).astype(np.int64)
+            r = q.copy()
+            for _ in range(int(rng.integers(0, 4))):                  # 0..3 defects, often on the first base (as after a maximal seed)
+                p = 0 if rng.random() < 0.5 else int(rng.integers(0, n))
+                u = rng.random()
+                if u < 0.2:
+                    r[p] = 4
+                elif u < 0.3:
+                    q[p] = 4
+                else:
+                    r[p] = (r[p] + 1 + rng.integers(0, 3)) & 3
+            extra = int(rng.integers(0, 80)) if rng.random() < 0.9 else 0
+            tail = rng.integers(0, 5, extra) if rng.random() < 0.5 else np.tile(q, 2)[:extra]
+            sides.append((q.tolist(), np.concatenate([r, tail]).astype(np.int64).tolist()))
+        h0 = int(rng.integers(1, 12)) if t % 7 == 0 else int(rng.integers(19, 140))     # h0 <= deficit now and then
+        if t % 11 == 0:
+            sides[0] = ([], [])
+        tasks.append((sides[0][0], sides[0][1], sides[1][0], sides[1][1], h0, len(sides[0][0])))
+    soa = _manual_tasks(tasks)
+    for (od, ed, oi, ei), w in (((6, 1, 6, 1), 100), ((0, 1, 0, 1), 100), ((3, 2, 7, 1), 2), ((1, 1, 1, 1), 1), ((4, 2, 2, 3), 5)):
+        soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w
+        for zmode, zdrop in ((po.ZDROP_SCALA, 100), (po.ZDROP_BWA, 100), (po.ZDROP_BWA, 3), (po.ZDROP_SCALA, 0)):
+            _check(ctx, orc, soa, zmode=zmode, zdrop=zdrop)
+    soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = 6, 1, 6, 1, 100
+    soa.mat_max = 3
+    _check(ctx, orc, soa, mat=po.default_mat(3, 2))                     # deficit of a substitution = 5 with a = 3
+    asym = po.default_mat(1, 4)
+    asym[1 * 5 + 1] = 2                                                 # unequal match scores: the closed form must switch itself off
+    soa.mat_max = 2
+    _check(ctx, orc, soa, mat=asym)
