@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void chain2aln_kernel(const C
               aw[side] = w0 << i;
               const int w = min(min(aw[side], maxIns), maxDel);
               const int tl = min(rLen, qLen + w + 2);
-              x = sw_extend_reg_any(lane, qLen, tl, qsrc, ts, P.mat, oDel, eDel, oIns, eIns, w, P.zdrop, P.zmode, hInit);
+              x = sw_extend_reg_any(lane, qLen, tl, qsrc, ts, P.mat, oDel, eDel, oIns, eIns, w, P.zdrop, P.zmode, hInit, P.tail_bound ? P.mat_max : 0);
               regScore = x.max;
               if (regScore == prev || x.max_off < (aw[side] >> 1) + (aw[side] >> 2)) break;
             }

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
   // closed form for near-exact flanks (bpsw_extend_core.h, flank_closed_form): usable with this batch's band?
   const int oe_min = min(oIns + eIns, oDel + eDel);
   const int exact_a = (oe_min > 0 && wBand >= 2) ? sc.exact_a : 0;
+  const int amax = sc.tail_bound ? sc.mat_max : 0;  // rows past the query end that cannot matter (tail_row_bound)
 
   // Tasks differ in cost by an order of magnitude, so waves pull them from a shared counter instead of
   // striding: a wave takes the next task when it finishes one and leaves when the counter passes n_tasks.
@@ -129,9 +130,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
         aw[side] = wBand << i;
         const int w = min(min(aw[side], maxIns), maxDel);
         if (reg_path) {
-          r = sw_extend_reg_any(lane, qLen, rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit);
+          r = sw_extend_reg_any(lane, qLen, rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
         } else {
-          r = sw_extend_wave(lane, qLen, rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit);
+          r = sw_extend_wave(lane, qLen, rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
         }
         regScore = r.max;
         if (regScore == prev || r.max_off < (aw[side] >> 1) + (aw[side] >> 2)) break;

@@ -28,7 +28,9 @@ struct ExtScoring {
   int zdrop_mode;
   int mat_max;  // max(mat): bounds the scores a task can reach (selects the int16 register path)
   int exact_a;  // match score when the exact-flank shortcut is valid for this matrix (bpsw_extend_core.h), else 0
+  int tail_bound;  // 1: stop a call once the rows past the query end cannot change its result (tail_row_bound)
 };
+bool tail_bound_enabled();  // BPSW_EXT_TAIL=0 disables (A/B runs)
 // a > 0 if mat[c][c] == a for the four bases and every other entry is < a; else 0.  BPSW_EXT_EXACT=0 disables.
 int exact_match_score(const int8_t mat[25]);
 
@@ -165,6 +167,7 @@ struct ChainParams {
   MatRows mat;
   int mat_max, a, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop, zmode;
   int exact_a;  // see ExtScoring
+  int tail_bound;
 };
 struct ChainBatchDev {  // all device pointers
   int n_reads;

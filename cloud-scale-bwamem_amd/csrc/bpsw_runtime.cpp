@@ -70,6 +70,11 @@ MatRows pack_mat(const int8_t mat[25]) {
   return m;
 }
 
+bool tail_bound_enabled() {
+  static const bool off = getenv("BPSW_EXT_TAIL") && atoi(getenv("BPSW_EXT_TAIL")) == 0;
+  return !off;
+}
+
 int exact_match_score(const int8_t mat[25]) {
   static const bool off = getenv("BPSW_EXT_EXACT") && atoi(getenv("BPSW_EXT_EXACT")) == 0;  // A/B switch for measurements
   if (off) return 0;
@@ -165,6 +170,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.zdrop_mode = BPSW_ZDROP_SCALA;
   c->ext_sc.mat_max = 1;
   c->ext_sc.exact_a = exact_match_score(c->ext_mat);
+  c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
   for (int k = 0; e == hipSuccess && k < 2; ++k) {
@@ -213,6 +219,7 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
   c->ext_sc.zdrop = zdrop;
   c->ext_sc.zdrop_mode = zdrop_mode;
   c->ext_sc.exact_a = exact_match_score(c->ext_mat);
+  c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
   return BPSW_OK;
 }
 

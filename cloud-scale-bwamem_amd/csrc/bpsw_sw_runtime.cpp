@@ -350,6 +350,7 @@ int bpsw_chain2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_chains
   P.a = opt->a; P.o_del = opt->o_del; P.e_del = opt->e_del; P.o_ins = opt->o_ins; P.e_ins = opt->e_ins;
   P.pen_clip5 = opt->pen_clip5; P.pen_clip3 = opt->pen_clip3; P.w = opt->w; P.zdrop = opt->zdrop; P.zmode = zdrop_mode;
   P.exact_a = exact_match_score(opt->mat);
+  P.tail_bound = tail_bound_enabled() ? 1 : 0;
 
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
