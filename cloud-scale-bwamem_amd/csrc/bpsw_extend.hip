@@ -171,7 +171,7 @@ __global__ void ext_prepass_kernel(const uint32_t* __restrict__ wire, const unsi
     const uint32_t hdr0 = wire[0];
     const int oIns = (int8_t)((hdr0 >> 16) & 0xff), eIns = (int8_t)((hdr0 >> 24) & 0xff);
     const int oDel = (int8_t)(hdr0 & 0xff), eDel = (int8_t)((hdr0 >> 8) & 0xff);
-    if (oIns < 0 || eIns < 0 || oDel < 0 || eDel < 0) err = 2;  // the prefix-scan form of F needs oIns >= 0
+    if (oIns < 0 || eIns < 1 || oDel < 0 || eDel < 1) err = 2;  // the prefix-scan form of F needs oIns >= 0; e = 0 divides by zero in SWUtil.scala:110-115
     pre->reserved = oIns + eIns > 0 ? 1 : 0;                    // quad-task kernels are usable
   }
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {

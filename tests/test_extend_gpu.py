@@ -106,6 +106,9 @@ def test_rejects_malformed_batches(ctx):
         ctx.extend_batch(bad)
     empty = wire[:32].copy(); empty[8:12] = 0
     assert ctx.extend_batch(empty).size == 0                # empty batch is fine
+    zero_ext = wire.copy(); zero_ext[1] = 0                 # eDel = 0: (qLen*max + bonus - oDel) / eDel is a division by zero in the Scala
+    with pytest.raises(bpsw_hip.BpswError):
+        ctx.extend_batch(zero_ext)
 
 
 def test_device_resident_entry_matches_host_entry(ctx, orc):
@@ -172,3 +175,63 @@ def test_near_exact_flanks_closed_form_boundaries(ctx, orc):
     asym[1 * 5 + 1] = 2                                                 # unequal match scores: the closed form must switch itself off
     soa.mat_max = 2
     _check(ctx, orc, soa, mat=asym)
+
+
+def test_tail_row_bound_cases(ctx, orc):
+    """Rows past the query end are skipped once they provably cannot change the result (bpsw_extend_core.h, tail_row_bound).
+    Flanks that stress the bound: the query occurs again later in the target (an alignment restarted from a zero cell can
+    out-score everything before it), long deletions (the best alignment ends far below row qLen), low h0, eDel = 0, repeats,
+    and scoring matrices with a larger or uneven maximum."""
+    rng = np.random.default_rng(23)
+
+    def mutate(seq, sub, indel):
+        out, i = [], 0
+        while i < len(seq):
+            u = rng.random()
+            if u < indel / 2:
+                out.append(int(rng.integers(0, 4)))
+            elif u < indel:
+                i += 1
+            elif u < indel + sub:
+                out.append(int((seq[i] + 1 + rng.integers(0, 3)) & 3)); i += 1
+            else:
+                out.append(int(seq[i])); i += 1
+        return out
+
+    tasks = []
+    for t in range(1200):
+        sides = []
+        for _ in range(2):
+            n = int(rng.integers(1, 125))
+            base = rng.integers(0, 4, n + 200)
+            if t % 6 == 1:
+                base = np.full(n + 200, rng.integers(0, 4))
+            if t % 6 == 2:
+                base = np.tile(rng.integers(0, 4, int(rng.integers(1, 5))), n + 200)[: n + 200]
+            err = (0.01, 0.05, 0.15, 0.3)[t % 4]
+            q = mutate(base[: n + 30].tolist(), err, err / 3)[:n]
+            if len(q) < n:
+                q = q + rng.integers(0, 4, n - len(q)).tolist()
+            tl = n + int(rng.integers(0, n + 60))
+            r = base[:tl].tolist()
+            if t % 6 == 3:      # unrelated sequence, then the query again: restart from zero
+                r = rng.integers(0, 4, int(rng.integers(5, 70))).tolist() + q + rng.integers(0, 4, 20).tolist()
+            if t % 6 == 4:      # a block the read does not have: long deletion
+                p = int(rng.integers(0, n))
+                r = base[:p].tolist() + rng.integers(0, 4, int(rng.integers(1, 45))).tolist() + base[p:tl].tolist()
+            if rng.random() < 0.1 and r:
+                r[int(rng.integers(0, len(r)))] = 4
+            sides.append((q, r))
+        h0 = int(rng.integers(1, 15)) if t % 5 == 0 else int(rng.integers(19, 140))
+        tasks.append((sides[0][0], sides[0][1], sides[1][0], sides[1][1], h0, len(sides[0][0])))
+    soa = _manual_tasks(tasks)
+    for (od, ed, oi, ei), w in (((6, 1, 6, 1), 100), ((0, 1, 0, 1), 100), ((3, 2, 7, 1), 30), ((4, 1, 2, 3), 100), ((1, 1, 1, 1), 5)):
+        soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w
+        for zmode, zdrop in ((po.ZDROP_SCALA, 100), (po.ZDROP_BWA, 100), (po.ZDROP_BWA, 20), (po.ZDROP_SCALA, 0)):
+            _check(ctx, orc, soa, zmode=zmode, zdrop=zdrop)
+    soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = 6, 1, 6, 1, 100
+    soa.mat_max = 3
+    _check(ctx, orc, soa, mat=po.default_mat(3, 2))
+    uneven = po.default_mat(1, 4)
+    uneven[2 * 5 + 2] = 3                                               # one base scores more: amax = 3 bounds all of them
+    _check(ctx, orc, soa, mat=uneven)
