@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
-    "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_last_tail_times",
+    "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_worker2_batch", "bpsw_last_tail_times",
 ]
 JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI",
@@ -171,6 +171,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_reg2aln_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bpsw_sam_pe_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.POINTER(C.c_size_t), C.c_void_p]
+    lib.bpsw_worker2_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     lib.bpsw_last_tail_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p]
     if path is None:
         _lib = lib
@@ -572,8 +574,7 @@ def _ctx_reg2aln_batch(self, opt: Opt, topt: TailOpt, read_len, read_off, read_p
     return alns[: j.n], cig[: j.n], md[: j.n]
 
 
-def _ctx_sam_pe_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA"):
-    """memSamPeGroupRest -> (list of 2G SAM texts (bytes), regions as the tail leaves them)"""
+def _pairs_struct(g):
     st = Pairs()
     st.group_size, st.id0 = g.group_size, g.id0
     for r in range(4):
@@ -593,6 +594,13 @@ def _ctx_sam_pe_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA"):
     regs = np.ascontiguousarray(g.regs)
     assert regs.dtype == ALNREG_DTYPE
     st.regs = regs.ctypes.data
+    keep.append(regs)
+    return st, keep, regs
+
+
+def _ctx_sam_pe_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA"):
+    """memSamPeGroupRest -> (list of 2G SAM texts (bytes), regions as the tail leaves them)"""
+    st, keep, regs = _pairs_struct(g)
     off = np.zeros(2 * g.group_size + 1, np.int64)
     out_regs = np.zeros(max(regs.shape[0], 1), ALNREG_DTYPE)
     need = C.c_size_t(0)
@@ -608,6 +616,27 @@ def _ctx_sam_pe_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA"):
         break
     text = buf[: int(off[-1])].tobytes()
     return [text[int(off[i]):int(off[i + 1])] for i in range(2 * g.group_size)], out_regs[: regs.shape[0]]
+
+
+def _ctx_worker2_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA", rescue_mode: int = RESCUE_C):
+    """rescue + tail for a group whose g.regs are the lists BEFORE the rescue -> (SAM texts, reg_cnt[2G], regs after)"""
+    st, keep, regs = _pairs_struct(g)
+    off = np.zeros(2 * g.group_size + 1, np.int64)
+    cnt = np.zeros(2 * g.group_size, np.int32)
+    need, total = C.c_size_t(0), C.c_int64(0)
+    cap, rcap = 1024 * max(1, 2 * g.group_size), int(regs.shape[0]) + 8 * g.group_size + 64
+    while True:
+        buf = np.zeros(cap, np.uint8)
+        out_regs = np.zeros(rcap, ALNREG_DTYPE)
+        rc = self.lib.bpsw_worker2_batch(self.h, C.byref(opt), C.byref(topt), C.byref(st), rescue_mode, _ptr(buf), cap, _ptr(off),
+                                         C.byref(need), _ptr(cnt), _ptr(out_regs), rcap, C.byref(total))
+        if rc == -3 and (need.value > cap or total.value > rcap):
+            cap, rcap = max(cap, int(need.value) + 64), max(rcap, int(total.value) + 16)
+            continue
+        _chk(self.lib, rc, "bpsw_worker2_batch")
+        break
+    text = buf[: int(off[-1])].tobytes()
+    return [text[int(off[i]):int(off[i + 1])] for i in range(2 * g.group_size)], cnt, out_regs[: total.value]
 
 
 def _ctx_last_tail_kernel(self):
@@ -627,5 +656,6 @@ def _ctx_last_tail_host_ms(self):
 Context.bns_load = _ctx_bns_load
 Context.reg2aln_batch = _ctx_reg2aln_batch
 Context.sam_pe_batch = _ctx_sam_pe_batch
+Context.worker2_batch = _ctx_worker2_batch
 Context.last_tail_kernel = _ctx_last_tail_kernel
 Context.last_tail_host_ms = _ctx_last_tail_host_ms

@@ -420,7 +420,7 @@ def _seeded_read(rng, ref_bases, l_pac, rb0, L, es, ei, min_seed):
 
 def tail_pairs(n_pairs: int, ref_bases: np.ndarray, ann_off, ann_len, dups=(), read_len: int = 150, sub_rate: float = 0.01,
                indel_rate: float = 0.002, p_unmappable: float = 0.04, p_far: float = 0.05, p_span: float = 0.03,
-               p_dup: float = 0.15, p_decoy: float = 0.15, p_clip: float = 0.1, min_seed: int = 19,
+               p_dup: float = 0.15, p_decoy: float = 0.15, p_clip: float = 0.1, p_hard: float = 0.0, min_seed: int = 19,
                seed: int = CONFIG_SEED_BASE + 11):
     """FR pairs (insert ~ N(400, 50^2)) with the seed chains of both ends, plus names and qualities: what worker2's tail
     needs once chains have been turned into regions (memChainToAln + memSortAndDedup) and the rescue has run.
@@ -475,7 +475,8 @@ def tail_pairs(n_pairs: int, ref_bases: np.ndarray, ann_off, ann_len, dups=(), r
             if rng.random() < p_unmappable:
                 add_read(rng.integers(0, 4, L).astype(np.uint8), [])
                 continue
-            read, seeds = _seeded_read(rng, ref_bases, l_pac, ends[i], L, sub_rate, indel_rate, min_seed)
+            es, ei = (0.09, 0.01) if rng.random() < p_hard else (sub_rate, indel_rate)   # p_hard: too many errors for a seed
+            read, seeds = _seeded_read(rng, ref_bases, l_pac, ends[i], L, es, ei, min_seed)
             if rng.random() < p_clip:            # an unrelated tail: soft clipping on one side
                 cut = int(rng.integers(15, 50))
                 if rng.random() < 0.5:

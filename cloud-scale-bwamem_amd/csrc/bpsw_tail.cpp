@@ -729,6 +729,85 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
   return BPSW_OK;
 }
 
+// ---- worker2 in one call: the rescue (boundary 1) followed by the tail -------------------------------------------------------
+// memSamPeGroupJNIPrepare (PE:1895-2000) with getAlnRegRefJNI (PE:1810-1878) in coordinate form: per end the regions within
+// penUnpaired of the best one (at most maxMatesw) are anchors, each with the four orientation windows of the mate; then
+// bpsw_matesw_group (windows read from the resident reference), then bpsw_sam_pe_batch on the rescued lists.
+int bpsw_worker2_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_t* topt, const bpsw_pairs_t* g, int rescue_mode,
+                       char* out_text, size_t text_cap, int64_t* out_off, size_t* out_needed, int32_t* out_reg_cnt,
+                       bpsw_alnreg_t* out_regs, int64_t out_regs_cap, int64_t* out_regs_total) {
+  if (!c || !opt || !topt || !g || !out_off) return fail(BPSW_ERR_ARG, "worker2: null argument");
+  const int G = g->group_size;
+  if (G < 0) return fail(BPSW_ERR_ARG, "worker2: negative group size");
+  if (G > 0 && (!g->read_len || !g->read_off || !g->read_pool || !g->reg_cnt)) return fail(BPSW_ERR_ARG, "worker2: null group arrays");
+  const long long l_pac = (long long)bpsw_ref_length(c);
+  if (l_pac <= 0) return fail(BPSW_ERR_ARG, "worker2: no reference loaded on this device (bpsw_ref_load)");
+  // ---- prepare: anchors and their windows ----------------------------------------------------------------------------------
+  std::vector<int32_t> ref_cnt((size_t)(2 * G), 0);
+  std::vector<int64_t> ref_rb, ref_re;
+  size_t at = 0, n_in = 0;
+  for (int e = 0; e < 2 * G; ++e) {
+    const int n = g->reg_cnt[e];
+    if (n < 0) return fail(BPSW_ERR_ARG, "worker2: negative region count");
+    const bpsw_alnreg_t* a = g->regs + at;
+    const int mate_len = g->read_len[e ^ 1];
+    int cnt = 0;
+    for (int j = 0; j < n && cnt < opt->max_matesw; ++j) {
+      if (!(a[j].score >= a[0].score - opt->pen_unpaired)) continue;  // PE:1944-1947
+      for (int r = 0; r < 4; ++r) {                                    // PE:1834-1868
+        long long rb = -1, re = -1;
+        if (!g->pes[r].failed) {
+          const bool is_rev = (r >> 1) != (r & 1), is_larger = !(r >> 1);
+          const long long lo = g->pes[r].low, hi = g->pes[r].high;
+          if (!is_rev) {
+            rb = is_larger ? a[j].rb + lo : a[j].rb - hi;
+            re = (is_larger ? a[j].rb + hi : a[j].rb - lo) + mate_len;
+          } else {
+            rb = (is_larger ? a[j].rb + lo : a[j].rb - hi) - mate_len;
+            re = is_larger ? a[j].rb + hi : a[j].rb - lo;
+          }
+          if (rb < 0) rb = 0;
+          if (re > (l_pac << 1)) re = l_pac << 1;
+        }
+        ref_rb.push_back(rb); ref_re.push_back(re);
+      }
+      ++cnt;
+    }
+    ref_cnt[(size_t)e] = cnt;
+    at += (size_t)n; n_in += (size_t)n;
+  }
+  // ---- rescue ----------------------------------------------------------------------------------------------------------------
+  bpsw_rescue_group_t rg;
+  memset(&rg, 0, sizeof rg);
+  rg.group_size = G; rg.l_pac = l_pac;
+  memcpy(rg.pes, g->pes, sizeof rg.pes);
+  rg.seq_len = g->read_len; rg.seq_off = g->read_off; rg.seq_pool = g->read_pool; rg.seq_pool_bytes = g->read_pool_bytes;
+  rg.reg_cnt = g->reg_cnt; rg.regs = g->regs; rg.ref_cnt = ref_cnt.data();
+  static const int64_t kNone = 0;
+  rg.ref_rb = ref_rb.empty() ? &kNone : ref_rb.data(); rg.ref_re = ref_re.empty() ? &kNone : ref_re.data();
+  rg.ref_len = nullptr; rg.ref_off = nullptr; rg.ref_pool = nullptr; rg.ref_pool_bytes = 0;  // coordinate windows
+  std::vector<int32_t> cnt2((size_t)(2 * G) + 1, 0);
+  std::vector<bpsw_alnreg_t> regs2(n_in + 4 * ref_rb.size() / 4 * 4 + 16);
+  int64_t total = 0;
+  int rc = bpsw_matesw_group(c, opt, &rg, rescue_mode, cnt2.data(), regs2.data(), (int64_t)regs2.size(), &total);
+  if (rc == BPSW_ERR_CAPACITY) {
+    regs2.resize((size_t)total + 16);
+    rc = bpsw_matesw_group(c, opt, &rg, rescue_mode, cnt2.data(), regs2.data(), (int64_t)regs2.size(), &total);
+  }
+  if (rc != BPSW_OK) return rc;
+  // ---- tail ------------------------------------------------------------------------------------------------------------------
+  bpsw_pairs_t t = *g;
+  t.reg_cnt = cnt2.data();
+  t.regs = regs2.data();
+  if (out_regs_total) *out_regs_total = total;
+  if (out_reg_cnt) memcpy(out_reg_cnt, cnt2.data(), sizeof(int32_t) * (size_t)(2 * G));
+  bpsw_alnreg_t* tail_regs = (out_regs && out_regs_cap >= total) ? out_regs : nullptr;
+  rc = bpsw_sam_pe_batch(c, opt, topt, &t, out_text, text_cap, out_off, out_needed, tail_regs);
+  if (rc != BPSW_OK) return rc;
+  if (out_regs && out_regs_cap < total) return fail(BPSW_ERR_CAPACITY, "worker2: out_regs too small (see *out_regs_total)");
+  return BPSW_OK;
+}
+
 int bpsw_last_tail_times(bpsw_ctx_t* c, float* kernel_ms, int32_t* n_jobs, double host_ms[3]) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   std::lock_guard<std::mutex> g(c->mu);

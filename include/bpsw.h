@@ -329,6 +329,13 @@ typedef struct {
 } bpsw_pairs_t;
 int bpsw_sam_pe_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_pairs_t *g, char *out_text,
                       size_t text_cap, int64_t *out_off, size_t *out_needed, bpsw_alnreg_t *out_regs);
+/* worker2 in one call: the rescue of boundary 1 (anchors and windows as memSamPeGroupJNIPrepare builds them,
+ * worker2/MemSamPe.scala:1895-2000, windows named by coordinates of the reference loaded with bpsw_ref_load; rescue_mode as in
+ * bpsw_matesw_group) followed by the tail above.  g->regs are the region lists BEFORE the rescue (what worker1 hands over).
+ * out_reg_cnt (2*group_size, optional) / out_regs (optional): the lists after the rescue and the tail's bookkeeping. */
+int bpsw_worker2_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_pairs_t *g, int rescue_mode,
+                       char *out_text, size_t text_cap, int64_t *out_off, size_t *out_needed, int32_t *out_reg_cnt,
+                       bpsw_alnreg_t *out_regs, int64_t out_regs_cap, int64_t *out_regs_total);
 /* the most recent tail call on this context: kernel_ms = reg2aln_kernel launches (hipEvents on the launch stream), n_jobs =
  * jobs they carried, host_ms = {plan, device round trip (staging, copies, kernel), emit} of bpsw_sam_pe_batch */
 int bpsw_last_tail_times(bpsw_ctx_t *ctx, float *kernel_ms, int32_t *n_jobs, double host_ms[3]);
