@@ -103,12 +103,39 @@ def cpu_baseline(soas, wires, ntasks, jobs, xtra):
     }
 
 
+def tail_breakdown(ctx, opt, n_pairs: int = 4096):
+    """bpsw_sam_pe_batch on a synthetic group (regions from the device's own memChainToAln + memSortAndDedup): reads/s of the
+    whole call for ONE calling thread (host passes + staging + kernel; host buffers in, SAM text out) and the kernel's rate."""
+    import bpsw_hip
+    from bpsw_hip import synth
+    pac, bases, off, ln, names, dups = synth.contig_reference([400_000, 300_000, 200_000, 100_000], seed=synth.CONFIG_SEED_BASE + 40)
+    tb, rn, quals, pes = synth.tail_pairs(n_pairs, bases, off, ln, dups, seed=synth.CONFIG_SEED_BASE + 41)
+    ctx.ref_load(pac, int(off[-1] + ln[-1]))
+    ctx.bns_load(off, ln, names)
+    cnt, regs = ctx.chain2aln_batch(opt, tb, flags=bpsw_hip.C2A_SORT_DEDUP)
+    g = bpsw_hip.make_tail_group(tb, rn, quals, pes, cnt, regs, off, ln, names, id0=0)
+    topt = bpsw_hip.default_tail_opt()
+    ctx.sam_pe_batch(opt, topt, g)
+    reps, k_ms, host = 3, 0.0, (0.0, 0.0, 0.0)
+    for _ in range(reps):
+        texts, _ = ctx.sam_pe_batch(opt, topt, g)
+        ms, jobs = ctx.last_tail_kernel()
+        k_ms += ms
+        host = tuple(a + b for a, b in zip(host, ctx.last_tail_host_ms()))
+    call_ms = sum(host) / reps
+    return {"pairs": n_pairs, "reg2aln_jobs": int(jobs), "call_ms": round(call_ms, 3), "kernel_ms": round(k_ms / reps, 4),
+            "reads_per_s_one_thread": round(2 * n_pairs / (call_ms * 1e-3), 1), "alignments_per_s_kernel": round(jobs / (k_ms / reps * 1e-3), 1),
+            "host_ms": {"plan": round(host[0] / reps, 3), "device_roundtrip": round(host[1] / reps, 3), "sam_text": round(host[2] / reps, 3)},
+            "sam_bytes": int(sum(len(t) for t in texts)), "note": "host buffers in, SAM text out; not part of `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tail", action="store_true", help="skip the worker2-tail breakdown entry")
     args = ap.parse_args()
 
     import torch
@@ -220,6 +247,14 @@ def main():
     reps = max(3, min(args.steps, 10))
     t_ext_only, t_sw_only = time_only(ext_only, reps), time_only(sw_only, reps)
 
+    # ---- worker2's tail, outside `value`: host-inclusive rate of one calling thread + kernel rate ----
+    tail = None
+    if rank == 0 and not args.no_tail:
+        try:
+            tail = tail_breakdown(ctx, opt)
+        except Exception as e:  # noqa: BLE001 -- a breakdown line must never cost the bench its JSON
+            tail = {"error": repr(e)}
+
     # ---- roofline of the dominant kernel (algorithmic bytes: DESIGN.md) -------------
     ext_bytes = sum(int(w.size) + 20 * n for w, n in zip(wires, ntasks)) / len(wires)          # per launch
     sw_bytes = float(jobs["q_len"].sum() + jobs["t_len"].sum() + 28 * n_jobs)                  # per launch
@@ -252,7 +287,8 @@ def main():
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes)}},
         "breakdown": {"extend_only_reads_per_s": round(2 * PAIRS_PER_STEP / t_ext_only, 1), "extend_only_ms_per_step": round(1e3 * t_ext_only, 3),
                       "rescue_only_jobs_per_s": round(n_jobs / t_sw_only, 1), "rescue_only_ms_per_step": round(1e3 * t_sw_only, 3),
-                      "note": "this rank only; same resident inputs, each boundary alone (SURVEY.md 8d i/ii); `value` is (iii) combined"},
+                      "note": "this rank only; same resident inputs, each boundary alone (SURVEY.md 8d i/ii); `value` is (iii) combined",
+                      "worker2_tail": tail},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(soas, wires, ntasks, jobs, xtra)
