@@ -249,7 +249,7 @@ def main():
 
     # ---- worker2's tail, outside `value`: host-inclusive rate of one calling thread + kernel rate ----
     tail = None
-    if rank == 0 and not args.no_tail:
+    if rank == 0 and world == 1 and not args.no_tail:   # single-GPU runs only: the scaling runs must not make the other ranks wait
         try:
             tail = tail_breakdown(ctx, opt)
         except Exception as e:  # noqa: BLE001 -- a breakdown line must never cost the bench its JSON

@@ -58,3 +58,40 @@ def test_concurrent_contexts_give_identical_results():
         t.join(300)
     assert not errors, errors
     main.close()
+
+
+def test_concurrent_tail_and_worker2_calls(orc):
+    """worker2's tail from several threads at once (one context each), all reading the same device-resident reference and
+    contig table: every thread must get the text a lone call gets."""
+    from tail_util import synthetic_group
+    pac, g = synthetic_group(orc, 300, 6060, sub_rate=0.03, indel_rate=0.008, p_hard=0.15, p_span=0.05)
+    names = [bytes(g.ann_name_pool[int(g.ann_name_off[i]):int(g.ann_name_off[i + 1])]).decode() for i in range(g.ann_off.shape[0])]
+    main = bpsw_hip.Context(0)
+    main.ref_load(pac, g.l_pac)
+    main.bns_load(g.ann_off, g.ann_len, names)
+    opt, topt = bpsw_hip.default_opt(), bpsw_hip.default_tail_opt()
+    want_tail, _ = main.sam_pe_batch(opt, topt, g)
+    want_w2, want_cnt, _ = main.worker2_batch(opt, topt, g)
+    errors = []
+
+    def worker(tid):
+        try:
+            c = bpsw_hip.Context(0)
+            for it in range(5):
+                if (tid + it) % 2:
+                    got, _ = c.sam_pe_batch(opt, topt, g)
+                    assert got == want_tail
+                else:
+                    got, cnt, _ = c.worker2_batch(opt, topt, g)
+                    assert got == want_w2 and np.array_equal(cnt, want_cnt)
+            c.close()
+        except BaseException as e:   # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    main.close()
