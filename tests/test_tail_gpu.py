@@ -134,3 +134,51 @@ def test_worker2_in_one_call_vs_reference_mem_sam_pe(ctx, orc, ref):
     for i in diff:
         wl, gl = want[i].splitlines(), got[i].splitlines()
         assert len(wl) == len(gl) and all(strip(a) == strip(b) for a, b in zip(wl, gl)), (want[i], got[i])
+
+
+def _slice_group(g, lo, hi):
+    """pairs lo..hi-1 of a TailGroupSoA as their own group (same pools; id0 moves so that every pair keeps its id)"""
+    r0, r1 = int(g.reg_cnt[:2 * lo].sum()), int(g.reg_cnt[:2 * hi].sum())
+    s = copy.copy(g)
+    s.group_size, s.id0 = hi - lo, g.id0 + lo
+    s.read_len, s.read_off = np.ascontiguousarray(g.read_len[2 * lo:2 * hi]), np.ascontiguousarray(g.read_off[2 * lo:2 * hi])
+    s.name_off = np.ascontiguousarray(g.name_off[lo:hi + 1])        # offsets stay absolute into the shared name pool
+    s.reg_cnt, s.regs = np.ascontiguousarray(g.reg_cnt[2 * lo:2 * hi]), np.ascontiguousarray(g.regs[r0:r1])
+    return s
+
+
+def test_tail_scale_properties(ctx, orc):
+    """16 384 pairs (regions from the device's own memChainToAln + memSortAndDedup): the text does not depend on how the pairs
+    are grouped into calls, repeated calls agree, every read gets at least one line with its own name and flag bits that are
+    consistent between mates, and a slice in the middle matches the oracle."""
+    from bpsw_hip import synth
+    n_pairs = 16384
+    pac, bases, off, ln, names, dups = synth.contig_reference([400_000, 300_000, 200_000, 100_000], seed=4242)
+    tb, rn, quals, pes = synth.tail_pairs(n_pairs, bases, off, ln, dups, seed=4243, p_hard=0.05)
+    ctx.ref_load(pac, int(off[-1] + ln[-1]))
+    ctx.bns_load(off, ln, names)
+    opt, topt = bpsw_hip.default_opt(), bpsw_hip.default_tail_opt()
+    cnt, regs = ctx.chain2aln_batch(opt, tb, flags=bpsw_hip.C2A_SORT_DEDUP)
+    g = bpsw_hip.make_tail_group(tb, rn, quals, pes, cnt, regs, off, ln, names, id0=1_000_000)
+    whole, _ = ctx.sam_pe_batch(opt, topt, g)
+    again, _ = ctx.sam_pe_batch(opt, topt, g)
+    assert whole == again
+    parts = []
+    for lo, hi in ((0, 1), (1, 4097), (4097, 12000), (12000, n_pairs)):
+        t, _ = ctx.sam_pe_batch(opt, topt, _slice_group(g, lo, hi))
+        parts += t
+    assert parts == whole
+    n_proper = 0
+    for k in range(n_pairs):
+        a, b = whole[2 * k].split(b"\n")[0].split(b"\t"), whole[2 * k + 1].split(b"\n")[0].split(b"\t")
+        assert a[0] == b[0] == rn[k].encode()
+        fa, fb = int(a[1]), int(b[1])
+        assert fa & 0x41 == 0x41 and fb & 0x81 == 0x81                      # paired, first / second in pair
+        assert bool(fa & 0x8) == bool(fb & 0x4) and bool(fb & 0x8) == bool(fa & 0x4)   # mate-unmapped mirrors unmapped
+        assert bool(fa & 0x2) == bool(fb & 0x2)
+        n_proper += bool(fa & 0x2)
+    assert n_proper > 0.7 * n_pairs
+    lo, hi = 7000, 7400
+    sub = _slice_group(g, lo, hi)
+    want, _, _ = orc.sam_pe_batch(orc.default_opt(), orc.default_tail_opt(), pac, sub)
+    assert whole[2 * lo:2 * hi] == want
