@@ -50,13 +50,17 @@ __device__ void load_side(const int lane, const uint32_t* __restrict__ words, co
 __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
 
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 5) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
                                                                      const int lds_per_wave,
                                                                      int* __restrict__ next_task,
-                                                                     const int* __restrict__ task_list) {
+                                                                     const int* __restrict__ task_list,
+                                                                     const ExtPrepass* __restrict__ pre) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // asynchronous entry (bpsw_extend_batch_device): the table scan ran just before on the same stream and nobody has read
+  // it back yet -- a malformed batch, or one whose tasks outgrow the LDS this launch was sized for, is left untouched
+  if (pre && (pre->error != 0 || pre->max_qlen > qcap || pre->max_rlen > rcap)) return;
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
   unsigned char* base = smem + (size_t)wave * lds_per_wave;
@@ -115,8 +119,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void ext_kernel(const uint32_
       ExtRes r = {0, 0, 0, 0, 0, 0};
       // near-exact flank: the DP result is known (flank_closed_form); the retry loop would stop after its first try
       const bool exact = exact_a > 0 && rLen >= qLen &&
-                         flank_closed_form(lane, qLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat, hInit, exact_a, oe_min,
-                                           sc.zdrop, &r);
+                         flank_closed_form(lane, qLen, rLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat, hInit, exact_a, oDel,
+                                           eDel, oIns, eIns, sc.zdrop, sc.certify != 0, &r);
       if (exact) {
         aw[side] = wBand;
         regScore = r.max;
@@ -205,7 +209,8 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 }
 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
-                             int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s) {
+                             int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
+                             const ExtPrepass* d_pre_check) {
   if (n_tasks <= 0) return hipSuccess;
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
@@ -234,7 +239,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   hipError_t me = hipMemsetAsync(d_counter, 0, sizeof(int), s);
   if (me != hipSuccess) return me;
   hipLaunchKernelGGL(ext_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
-                     rcap, (int)per_wave, d_counter, d_task_list);
+                     rcap, (int)per_wave, d_counter, d_task_list, d_pre_check);
   return hipGetLastError();
 }
 

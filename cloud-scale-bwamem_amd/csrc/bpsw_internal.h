@@ -29,7 +29,9 @@ struct ExtScoring {
   int mat_max;  // max(mat): bounds the scores a task can reach (selects the int16 register path)
   int exact_a;  // match score when the exact-flank shortcut is valid for this matrix (bpsw_extend_core.h), else 0
   int tail_bound;  // 1: stop a call once the rows past the query end cannot change its result (tail_row_bound)
+  int certify;     // 1: single-gap certificate for flanks with a deficit below two gap opens (BPSW_EXT_CERT=0 disables)
 };
+bool certify_enabled();
 bool tail_bound_enabled();  // BPSW_EXT_TAIL=0 disables (A/B runs)
 // a > 0 if mat[c][c] == a for the four bases and every other entry is < a; else 0.  BPSW_EXT_EXACT=0 disables.
 int exact_match_score(const int8_t mat[25]);
@@ -52,8 +54,11 @@ size_t ext_lds_per_wave(int qcap, int rcap);
 // Launch the extension kernel over a validated batch.
 // d_counter: one device int used as the kernel's task queue head (zeroed on the stream before the launch).
 // d_task_list (optional): the n_tasks task indices this launch handles (else tasks 0..n_tasks-1).
+// d_pre_check (optional): device ExtPrepass written earlier on the same stream; the kernel does nothing when it reports an
+// error or lengths beyond (qcap, rcap) -- the asynchronous device entry sizes the launch before anybody has read the scan back.
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
-                             int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s);
+                             int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
+                             const ExtPrepass* d_pre_check = nullptr);
 // Quad-task kernel (bpsw_extend_qt.hip): s_cols = 4 (sides <= 63 bp) or 9 (<= 143 bp).
 hipError_t launch_ext_qt_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, const int* d_list, int n_list,
                                 int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter, hipStream_t s);
@@ -111,8 +116,9 @@ void launch_ref_fetch(const uint8_t* d_pac, long long l_pac, int n, const long l
                       int* d_error, hipStream_t s);
 size_t sw_scratch_bytes_per_wave(int max_tlen);
 int sw_resident_waves(int num_cu);
+// d_pre_check: as for launch_ext_kernel (the launch is sized for max_qlen / max_tlen speculatively).
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
-                            uint32_t* d_scratch, int num_cu, hipStream_t s);
+                            uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check = nullptr);
 
 // ---- global alignment + CIGAR -------------------------------------------------
 struct GlobalJobsDev {  // all device pointers
@@ -167,7 +173,7 @@ struct ChainParams {
   MatRows mat;
   int mat_max, a, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop, zmode;
   int exact_a;  // see ExtScoring
-  int tail_bound;
+  int tail_bound, certify;
 };
 struct ChainBatchDev {  // all device pointers
   int n_reads;
@@ -225,6 +231,16 @@ DeviceRef& device_ref(int device);
 // snapshot of the reference loaded on c's device (l_pac == 0: none)
 void ref_snapshot(const bpsw_ctx* c, const uint8_t** pac, long long* l_pac);
 
+// Asynchronous device entries (bpsw_extend_batch_device, bpsw_swalign2_batch_device) leave a launch whose table scan has not
+// been read back; every entry point that reuses the context's scan buffers or stream resolves it first.  Caller holds c->mu
+// and has set the device.  Scan buffers: ExtPrepass at d_pre+0 (bin counts +64, queue heads +128), SwPrepass at d_pre+256.
+int finish_pending_ext(bpsw_ctx* c);
+int finish_pending_sw(bpsw_ctx* c);
+inline int finish_pending(bpsw_ctx* c) {
+  const int a = finish_pending_ext(c), b = finish_pending_sw(c);
+  return a != BPSW_OK ? a : b;
+}
+
 // runs SWAlign2 jobs whose arrays live in host memory; used by bpsw_swalign2_batch and the rescue layer.
 // Caller holds ctx->mu and has set the device.
 int run_sw_jobs_host(bpsw_ctx* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* jobs, int32_t* out);
@@ -242,6 +258,12 @@ struct bpsw_ctx {
   int8_t ext_mat[25];
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
   bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
+  // asynchronous device entries: a launch whose table scan has not been read back yet (resolved by finish_pending)
+  struct PendingExt { bool active = false; const void* d_wire = nullptr; size_t wire_bytes = 0; int n_tasks = 0; void* d_out = nullptr;
+                      hipStream_t s = nullptr; } pend_ext;
+  struct PendingSw { bool active = false; bpsw_sw_jobs_t jobs; bpsw_opt_t opt; void* d_out = nullptr; hipStream_t s = nullptr;
+                     int cap_qlen = 0, cap_tlen = 0; } pend_sw;
+  int sw_geom_qlen = 0, sw_geom_tlen = 0;  // geometry of the last verified SW launch on this context (speculation for the next)
   float last_tail_ms = 0.f;
   int last_tail_jobs = 0, last_tail_resubmitted = 0;
   double tail_host_ms[3] = {0., 0., 0.};  // plan, device round trip (staging + copies + kernel), emit

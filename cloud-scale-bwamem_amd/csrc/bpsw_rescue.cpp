@@ -295,6 +295,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
   std::lock_guard<std::mutex> lock(c->mu);
   hipError_t he = hipSetDevice(c->device);
   if (he != hipSuccess) return fail(BPSW_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
 
   Group S;
   S.opt = opt; S.g = g; S.mode = mode;

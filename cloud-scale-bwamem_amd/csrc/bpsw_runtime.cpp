@@ -75,6 +75,11 @@ bool tail_bound_enabled() {
   return !off;
 }
 
+bool certify_enabled() {
+  static const bool off = getenv("BPSW_EXT_CERT") && atoi(getenv("BPSW_EXT_CERT")) == 0;
+  return !off;
+}
+
 int exact_match_score(const int8_t mat[25]) {
   static const bool off = getenv("BPSW_EXT_EXACT") && atoi(getenv("BPSW_EXT_EXACT")) == 0;  // A/B switch for measurements
   if (off) return 0;
@@ -171,6 +176,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.mat_max = 1;
   c->ext_sc.exact_a = exact_match_score(c->ext_mat);
   c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
+  c->ext_sc.certify = certify_enabled() ? 1 : 0;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
   for (int k = 0; e == hipSuccess && k < 2; ++k) {
@@ -178,8 +184,8 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux.join[k], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux.fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = c->d_pre.reserve(256);
-  if (e == hipSuccess) e = c->h_pre.reserve(256);
+  if (e == hipSuccess) e = c->d_pre.reserve(512);
+  if (e == hipSuccess) e = c->h_pre.reserve(512);
   if (e != hipSuccess) {
     bpsw_destroy(c);
     return hip_fail(e, "bpsw_create");
@@ -191,6 +197,8 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
 void bpsw_destroy(bpsw_ctx_t* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->pend_ext.active && c->pend_ext.s) (void)hipStreamSynchronize(c->pend_ext.s);  // a caller-provided stream may still run
+  if (c->pend_sw.active && c->pend_sw.s) (void)hipStreamSynchronize(c->pend_sw.s);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
   c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release();
@@ -220,6 +228,7 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
   c->ext_sc.zdrop_mode = zdrop_mode;
   c->ext_sc.exact_a = exact_match_score(c->ext_mat);
   c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
+  c->ext_sc.certify = certify_enabled() ? 1 : 0;
   return BPSW_OK;
 }
 
@@ -294,6 +303,7 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
   if (n == 0) return BPSW_OK;
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
   const size_t out_bytes = 20 * (size_t)n;
   HIP_TRY(c->d_wire.reserve(wire_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
@@ -346,6 +356,58 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
   return BPSW_OK;
 }
 
+// Fixed LDS geometry of the asynchronous launch: covers every register-path task (sides <= 255 bases) and the longest
+// reference flank the kernels accept; 29.8 KB per workgroup, i.e. 5 workgroups per CU -- what the VGPR budget allows anyway.
+static const int ASYNC_QCAP = 256, ASYNC_RCAP = 4096;
+
+// the synchronous geometry-dependent launch (quad-task / lane experiments, and batches that outgrow the async geometry)
+static int ext_device_sync_launch(bpsw_ctx_t* c, const void* d_wire, size_t wire_bytes, int n_tasks, void* d_out, hipStream_t s,
+                                  const ExtPrepass* h_pre, const int* h_counts) {
+  HIP_TRY(hipEventRecord(c->ev[4], s));
+  if (ext_lane_enabled()) {
+    int rc = lane_launch(c, (const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, h_pre->max_qlen, h_pre->max_rlen, h_counts, s);
+    if (rc != BPSW_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev[5], s));
+    c->have_ext_ev = true;
+    return BPSW_OK;
+  }
+  const bool use_qt = h_pre->reserved != 0 && ext_qt_enabled();  // reserved: set by the scan when oIns + eIns > 0
+  int counts[3] = {h_counts[0], h_counts[1], h_counts[2]};
+  if (!use_qt) { counts[0] = counts[1] = 0; counts[2] = n_tasks; }
+  HIP_TRY(launch_ext_all((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen,
+                         h_pre->max_rlen, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, counts,
+                         use_qt, c->aux, s));
+  HIP_TRY(hipEventRecord(c->ev[5], s));
+  c->have_ext_ev = true;
+  return BPSW_OK;
+}
+
+extern "C++" {
+namespace bpsw {
+// Resolves an asynchronous extension launch of this context: waits for it, reads the table scan, reports a malformed
+// batch, and re-launches a batch that outgrew the speculative geometry.  Caller holds c->mu and has set the device.
+int finish_pending_ext(bpsw_ctx_t* c) {
+  if (!c->pend_ext.active) return BPSW_OK;
+  bpsw_ctx::PendingExt p = c->pend_ext;
+  c->pend_ext.active = false;
+  HIP_TRY(hipStreamSynchronize(p.s));
+  const ExtPrepass* h_pre = (const ExtPrepass*)c->h_pre.ptr;
+  if (h_pre->error) { c->have_ext_ev = false; return fail(BPSW_ERR_ARG, "extend_device: malformed wire batch (code " + std::to_string(h_pre->error) + ")"); }
+  if (h_pre->max_qlen > BPSW_EXT_MAX_QLEN || h_pre->max_rlen > BPSW_EXT_MAX_RLEN) {
+    c->have_ext_ev = false;
+    return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
+  }
+  if (h_pre->max_qlen > ASYNC_QCAP || h_pre->max_rlen > ASYNC_RCAP) {  // the kernel left the batch untouched: launch it for real
+    int counts[3] = {0, 0, p.n_tasks};
+    int rc = ext_device_sync_launch(c, p.d_wire, p.wire_bytes, p.n_tasks, p.d_out, p.s, h_pre, counts);
+    if (rc != BPSW_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(p.s));
+  }
+  return BPSW_OK;
+}
+}  // namespace bpsw
+}  // extern "C++"
+
 int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_bytes, int n_tasks, void* d_out,
                              void* hip_stream) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
@@ -355,14 +417,29 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   if (n_tasks == 0) return BPSW_OK;
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { int rc = finish_pending(c); if (rc != BPSW_OK) return rc; }  // the scan buffers of this context are about to be reused
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-  // device-side table scan, then a tiny read-back: the launch geometry depends on the longest task
   ExtPrepass* d_pre = (ExtPrepass*)c->d_pre.ptr;
   ExtPrepass* h_pre = (ExtPrepass*)c->h_pre.ptr;
   HIP_TRY(hipMemsetAsync(d_pre, 0, sizeof(ExtPrepass), s));
   launch_ext_prepass((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, d_pre, s);
   HIP_TRY(hipGetLastError());
-  // bin the tasks in the same pass (the lists are only used if the scan finds the batch well formed)
+  c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
+  if (!ext_lane_enabled() && !ext_qt_enabled()) {
+    // Asynchronous: scan, main launch (sized for ASYNC_QCAP / ASYNC_RCAP, checking the scan on the device) and the scan's
+    // read-back are enqueued back to back; nothing waits.  Errors surface at the next call on this context or at
+    // bpsw_last_kernel_ms, which is also where a batch that outgrew the geometry is re-launched.
+    HIP_TRY(hipEventRecord(c->ev[4], s));
+    HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, ASYNC_QCAP, ASYNC_RCAP, c->num_cu,
+                              (int*)((char*)c->d_pre.ptr + 128), nullptr, s, d_pre));
+    HIP_TRY(hipEventRecord(c->ev[5], s));
+    HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
+    c->have_ext_ev = true;
+    c->pend_ext.active = true; c->pend_ext.d_wire = d_wire; c->pend_ext.wire_bytes = wire_bytes; c->pend_ext.n_tasks = n_tasks;
+    c->pend_ext.d_out = d_out; c->pend_ext.s = s;
+    return BPSW_OK;
+  }
+  // experiments (quad-task / lane kernels): bin the tasks in the same pass, read the scan back, then launch
   int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
   int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
   if (12 * (size_t)n_tasks + 16 > c->d_ext_lists.cap) {
@@ -371,31 +448,14 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   }
   HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
   if (ext_lane_enabled()) lane_sort_enqueue(c, (const uint32_t*)d_wire, n_tasks, s);
-  else if (ext_qt_enabled()) launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
+  else launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (h_pre->error) return fail(BPSW_ERR_ARG, "extend_device: malformed wire batch (code " + std::to_string(h_pre->error) + ")");
   if (h_pre->max_qlen > BPSW_EXT_MAX_QLEN || h_pre->max_rlen > BPSW_EXT_MAX_RLEN)
     return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
-  HIP_TRY(hipEventRecord(c->ev[4], s));
-  if (ext_lane_enabled()) {
-    int rc = lane_launch(c, (const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, h_pre->max_qlen, h_pre->max_rlen, h_counts, s);
-    if (rc != BPSW_OK) return rc;
-    HIP_TRY(hipEventRecord(c->ev[5], s));
-    c->have_ext_ev = true;
-    c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
-    return BPSW_OK;
-  }
-  const bool use_qt = h_pre->reserved != 0 && ext_qt_enabled();  // reserved: set by the scan when oIns + eIns > 0
-  if (!use_qt) { h_counts[0] = h_counts[1] = 0; h_counts[2] = n_tasks; }
-  HIP_TRY(launch_ext_all((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen,
-                         h_pre->max_rlen, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts,
-                         use_qt, c->aux, s));
-  HIP_TRY(hipEventRecord(c->ev[5], s));
-  c->have_ext_ev = true;
-  c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
-  return BPSW_OK;
+  return ext_device_sync_launch(c, d_wire, wire_bytes, n_tasks, d_out, s, h_pre, h_counts);
 }
 
 int bpsw_get_stats(bpsw_ctx_t* c, bpsw_stats_t* out) {

@@ -127,8 +127,47 @@ int bpsw_swalign2_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_sw_jobs
   if (!c || !jobs) return fail(BPSW_ERR_ARG, "swalign: null argument");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   return run_sw_jobs_host(c, opt, jobs, out);
 }
+
+extern "C++" {
+namespace bpsw {
+// Resolves an asynchronous SW launch of this context (see finish_pending_ext).
+int finish_pending_sw(bpsw_ctx* c) {
+  if (!c->pend_sw.active) return BPSW_OK;
+  bpsw_ctx::PendingSw p = c->pend_sw;
+  c->pend_sw.active = false;
+  HIP_TRY(hipStreamSynchronize(p.s));
+  const SwPrepass* h_pre = (const SwPrepass*)((const char*)c->h_pre.ptr + 256);
+  if (h_pre->error) { c->have_sw_ev = false; return fail(BPSW_ERR_ARG, "swalign_device: job sequence outside its pool (or window outside / bridging the reference)"); }
+  if (h_pre->max_qlen > BPSW_SW_MAX_QLEN || h_pre->max_tlen > BPSW_SW_MAX_TLEN) {
+    c->have_sw_ev = false;
+    return fail(BPSW_ERR_LIMIT, "swalign_device: sequence longer than the kernel limit");
+  }
+  c->sw_geom_qlen = h_pre->max_qlen; c->sw_geom_tlen = h_pre->max_tlen;
+  if (h_pre->max_qlen > p.cap_qlen || h_pre->max_tlen > p.cap_tlen) {  // the kernel left the jobs untouched: launch for the real geometry
+    SwScoring sc;
+    int rc = make_scoring(&p.opt, p.jobs.xtra, &sc);
+    if (rc != BPSW_OK) return rc;
+    const uint8_t* d_pac = nullptr;
+    long long l_pac = 0;
+    ref_snapshot(c, &d_pac, &l_pac);
+    SwJobsDev dev;
+    dev.n = p.jobs.n; dev.q_len = p.jobs.q_len; dev.t_len = p.jobs.t_len; dev.q_off = p.jobs.q_off; dev.t_off = p.jobs.t_off;
+    dev.q_rev = p.jobs.q_rev; dev.q_pool = p.jobs.q_pool; dev.t_pool = p.jobs.t_pool; dev.pac = d_pac; dev.l_pac = l_pac;
+    const size_t scratch = sw_scratch_bytes_per_wave(h_pre->max_tlen) * (size_t)sw_resident_waves(c->num_cu);
+    HIP_TRY(c->d_sw_scratch.reserve(scratch));
+    HIP_TRY(hipEventRecord(c->ev[6], p.s));
+    HIP_TRY(launch_sw_kernel(dev, sc, h_pre->max_qlen, h_pre->max_tlen, (int32_t*)p.d_out, (uint32_t*)c->d_sw_scratch.ptr, c->num_cu, p.s));
+    HIP_TRY(hipEventRecord(c->ev[7], p.s));
+    HIP_TRY(hipStreamSynchronize(p.s));
+    c->have_sw_ev = true;
+  }
+  return BPSW_OK;
+}
+}  // namespace bpsw
+}  // extern "C++"
 
 int bpsw_swalign2_batch_device(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* j, void* d_out, void* hip_stream) {
   if (!c || !j || !d_out) return fail(BPSW_ERR_ARG, "swalign_device: null argument");
@@ -144,16 +183,36 @@ int bpsw_swalign2_batch_device(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_
   ref_snapshot(c, &d_pac, &l_pac);
   if (!j->t_pool && l_pac <= 0) return fail(BPSW_ERR_ARG, "swalign_device: t_pool is null and no reference is loaded (bpsw_ref_load)");
   HIP_TRY(hipSetDevice(c->device));
+  rc = finish_pending(c);
+  if (rc != BPSW_OK) return rc;
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
   SwJobsDev dev;
   dev.n = j->n; dev.q_len = j->q_len; dev.t_len = j->t_len; dev.q_off = j->q_off; dev.t_off = j->t_off;
   dev.q_rev = j->q_rev; dev.q_pool = j->q_pool; dev.t_pool = j->t_pool;
   dev.pac = d_pac; dev.l_pac = l_pac;
-  SwPrepass* d_pre = (SwPrepass*)c->d_pre.ptr;
-  SwPrepass* h_pre = (SwPrepass*)c->h_pre.ptr;
+  SwPrepass* d_pre = (SwPrepass*)((char*)c->d_pre.ptr + 256);
+  SwPrepass* h_pre = (SwPrepass*)((char*)c->h_pre.ptr + 256);
   HIP_TRY(hipMemsetAsync(d_pre, 0, sizeof(SwPrepass), s));
   launch_sw_prepass(dev, j->q_pool_bytes, j->t_pool_bytes, d_pre, s);
   HIP_TRY(hipGetLastError());
+  c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)j->n;
+  if (c->sw_geom_qlen > 0) {
+    // Asynchronous: the launch is sized for the geometry the previous call on this context was verified to have (the kernel
+    // template by mate length, the scratch rows by window length) and checks the scan on the device; the scan is read back
+    // at the next call on this context or at bpsw_last_kernel_ms, where a batch that outgrew the guess is launched again.
+    const int cap_q = 64 * ((c->sw_geom_qlen + 63) / 64);
+    const int cap_t = (int)(c->d_sw_scratch.cap / ((size_t)sw_resident_waves(c->num_cu) * 4)) & ~63;  // rows the scratch holds per wave
+    if (cap_t >= c->sw_geom_tlen) {
+      HIP_TRY(hipEventRecord(c->ev[6], s));
+      HIP_TRY(launch_sw_kernel(dev, sc, cap_q, cap_t, (int32_t*)d_out, (uint32_t*)c->d_sw_scratch.ptr, c->num_cu, s, d_pre));
+      HIP_TRY(hipEventRecord(c->ev[7], s));
+      HIP_TRY(hipMemcpyAsync(h_pre, d_pre, sizeof(SwPrepass), hipMemcpyDeviceToHost, s));
+      c->have_sw_ev = true;
+      c->pend_sw.active = true; c->pend_sw.jobs = *j; c->pend_sw.opt = *opt; c->pend_sw.d_out = d_out; c->pend_sw.s = s;
+      c->pend_sw.cap_qlen = cap_q; c->pend_sw.cap_tlen = cap_t;
+      return BPSW_OK;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(h_pre, d_pre, sizeof(SwPrepass), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (h_pre->error) return fail(BPSW_ERR_ARG, "swalign_device: job sequence outside its pool (or window outside / bridging the reference)");
@@ -169,7 +228,7 @@ int bpsw_swalign2_batch_device(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_
                            c->num_cu, s));
   HIP_TRY(hipEventRecord(c->ev[7], s));
   c->have_sw_ev = true;
-  c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)j->n;
+  c->sw_geom_qlen = h_pre->max_qlen; c->sw_geom_tlen = h_pre->max_tlen;
   return BPSW_OK;
 }
 
@@ -179,6 +238,7 @@ int bpsw_ref_load(bpsw_ctx_t* c, const uint8_t* pac, int64_t l_pac) {
   if (l_pac > (int64_t)1 << 40) return fail(BPSW_ERR_LIMIT, "ref_load: reference longer than 2^40 bases");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   DeviceRef& r = device_ref(c->device);
   std::lock_guard<std::mutex> gr(r.mu);
   const size_t bytes = (size_t)((l_pac + 3) >> 2);
@@ -193,6 +253,7 @@ int bpsw_ref_unload(bpsw_ctx_t* c) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   DeviceRef& r = device_ref(c->device);
   std::lock_guard<std::mutex> gr(r.mu);
   HIP_TRY(hipDeviceSynchronize());
@@ -220,6 +281,7 @@ int bpsw_ref_fetch(bpsw_ctx_t* c, int32_t n, const int64_t* beg, const int64_t* 
   ref_snapshot(c, &d_pac, &l_pac);
   if (l_pac <= 0) return fail(BPSW_ERR_ARG, "ref_fetch: no reference is loaded (bpsw_ref_load)");
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   const size_t o_beg = 0, o_end = align16(8 * (size_t)n), o_off = align16(o_end + 8 * (size_t)n);
   const size_t in_total = align16(o_off + 8 * (size_t)n);
   const size_t o_len = 0, o_err = align16(8 * (size_t)n), o_pool = align16(o_err + 16);
@@ -265,6 +327,7 @@ int bpsw_chain2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_chains
   ref_snapshot(c, &d_pac, &l_pac);
   if (l_pac <= 0) return fail(BPSW_ERR_ARG, "chain2aln: no reference is loaded (bpsw_ref_load)");
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
 
   // ---- host twin of a table scan: validate, build the prefix arrays the kernel indexes with ----
   std::vector<int32_t> chain_base((size_t)n);
@@ -351,6 +414,7 @@ int bpsw_chain2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_chains
   P.pen_clip5 = opt->pen_clip5; P.pen_clip3 = opt->pen_clip3; P.w = opt->w; P.zdrop = opt->zdrop; P.zmode = zdrop_mode;
   P.exact_a = exact_match_score(opt->mat);
   P.tail_bound = tail_bound_enabled() ? 1 : 0;
+  P.certify = certify_enabled() ? 1 : 0;
 
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
@@ -413,6 +477,7 @@ int bpsw_global_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_global_jo
   }
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   const size_t o_qlen = 0, o_tlen = align16(4 * (size_t)n), o_w = align16(o_tlen + 4 * (size_t)n);
   const size_t o_qoff = align16(o_w + 4 * (size_t)n), o_toff = align16(o_qoff + 8 * (size_t)n);
   const size_t o_qpool = align16(o_toff + 8 * (size_t)n), o_tpool = align16(o_qpool + j->q_pool_bytes);
@@ -453,6 +518,7 @@ int bpsw_last_kernel_ms(bpsw_ctx_t* c, float* ext_ms, float* sw_ms) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }  // deferred errors of the asynchronous device entries surface here
   if (c->have_ext_ev) {
     HIP_TRY(hipEventSynchronize(c->ev[5]));
     HIP_TRY(hipEventElapsedTime(&c->last_ext_ms, c->ev[4], c->ev[5]));

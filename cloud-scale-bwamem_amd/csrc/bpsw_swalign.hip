@@ -155,8 +155,11 @@ template <int C>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(const SwJobsDev jobs, const SwScoring sc,
                                                                     int32_t* __restrict__ out,
                                                                     uint32_t* __restrict__ scratch,
-                                                                    const int scratch_per_wave) {
+                                                                    const int scratch_per_wave,
+                                                                    const SwPrepass* __restrict__ pre) {
   __shared__ uint8_t tbuf_all[WAVES_PER_BLOCK][TBUF];
+  // asynchronous entry: launched for a speculated geometry before the table scan was read back (see launch_ext_kernel)
+  if (pre && (pre->error != 0 || pre->max_qlen > 64 * C || 4 * ((pre->max_tlen + 63) & ~63) > 4 * scratch_per_wave)) return;
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
   const int slot = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
@@ -267,8 +270,8 @@ __global__ void ref_fetch_kernel(const uint8_t* __restrict__ pac, const long lon
 
 template <int C>
 hipError_t launch_c(const SwJobsDev& jobs, const SwScoring& sc, int32_t* d_out, uint32_t* d_scratch, int per_wave,
-                    int blocks, hipStream_t s) {
-  hipLaunchKernelGGL(sw_kernel<C>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_wave);
+                    int blocks, hipStream_t s, const SwPrepass* pre) {
+  hipLaunchKernelGGL(sw_kernel<C>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_wave, pre);
   return hipGetLastError();
 }
 
@@ -295,19 +298,19 @@ size_t sw_scratch_bytes_per_wave(int max_tlen) { return 4 * (((size_t)max_tlen +
 int sw_resident_waves(int num_cu) { return num_cu * 8 * WAVES_PER_BLOCK; }
 
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
-                            uint32_t* d_scratch, int num_cu, hipStream_t s) {
+                            uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check) {
   if (jobs.n <= 0) return hipSuccess;
   int blocks = (jobs.n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int max_blocks = num_cu * 8;
   if (blocks > max_blocks) blocks = max_blocks;
   const int per_wave = (int)(sw_scratch_bytes_per_wave(max_tlen) / 4);
   const int c = (max_qlen + 63) / 64;
-  if (c <= 1) return launch_c<1>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
-  if (c == 2) return launch_c<2>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
-  if (c == 3) return launch_c<3>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
-  if (c == 4) return launch_c<4>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
-  if (c <= 6) return launch_c<6>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
-  if (c <= 8) return launch_c<8>(jobs, sc, d_out, d_scratch, per_wave, blocks, s);
+  if (c <= 1) return launch_c<1>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
+  if (c == 2) return launch_c<2>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
+  if (c == 3) return launch_c<3>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
+  if (c == 4) return launch_c<4>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
+  if (c <= 6) return launch_c<6>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
+  if (c <= 8) return launch_c<8>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
   return hipErrorInvalidValue;
 }
 

@@ -484,6 +484,7 @@ int bpsw_bns_load(bpsw_ctx_t* c, int32_t n_seqs, const int64_t* offset, const in
   if (!c || n_seqs < 1 || !offset || !len) return fail(BPSW_ERR_ARG, "bns_load: null or empty contig table");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   DeviceRef& r = device_ref(c->device);
   std::lock_guard<std::mutex> gr(r.mu);
   if (r.l_pac <= 0) return fail(BPSW_ERR_ARG, "bns_load: load the reference first (bpsw_ref_load)");
@@ -519,6 +520,7 @@ int bpsw_reg2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt
   if (j->max_cigar < 1 || j->max_md < 1) return fail(BPSW_ERR_ARG, "reg2aln: max_cigar and max_md must be positive");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   BnsView bns;
   rc = snapshot_bns(c, &bns);
   if (rc != BPSW_OK) return rc;
@@ -573,6 +575,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
   if (n_regs && !g->regs) return fail(BPSW_ERR_ARG, "sam_pe: null region array");
   std::lock_guard<std::mutex> lock(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   BnsView bns;
   rc = snapshot_bns(c, &bns);
   if (rc != BPSW_OK) return rc;

@@ -28,6 +28,26 @@ __device__ __forceinline__ int wave_scan_max(int v) {
   v = max(v, dpp_mov<DPP_ROW_BCAST31, 0xc>(NEG, v));
   return v;
 }
+// inclusive prefix sum / prefix minimum over the 64 lanes (same DPP ladder)
+__device__ __forceinline__ int wave_scan_add(int v) {
+  v += dpp_mov<DPP_ROW_SHR1, 0xf>(0, v);
+  v += dpp_mov<DPP_ROW_SHR2, 0xf>(0, v);
+  v += dpp_mov<DPP_ROW_SHR4, 0xf>(0, v);
+  v += dpp_mov<DPP_ROW_SHR8, 0xf>(0, v);
+  v += dpp_mov<DPP_ROW_BCAST15, 0xa>(0, v);
+  v += dpp_mov<DPP_ROW_BCAST31, 0xc>(0, v);
+  return v;
+}
+constexpr int POS = 1 << 29;
+__device__ __forceinline__ int wave_scan_min(int v) {
+  v = min(v, dpp_mov<DPP_ROW_SHR1, 0xf>(POS, v));
+  v = min(v, dpp_mov<DPP_ROW_SHR2, 0xf>(POS, v));
+  v = min(v, dpp_mov<DPP_ROW_SHR4, 0xf>(POS, v));
+  v = min(v, dpp_mov<DPP_ROW_SHR8, 0xf>(POS, v));
+  v = min(v, dpp_mov<DPP_ROW_BCAST15, 0xa>(POS, v));
+  v = min(v, dpp_mov<DPP_ROW_BCAST31, 0xc>(POS, v));
+  return v;
+}
 __device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_scan_max(v), 63); }
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }

@@ -81,7 +81,12 @@ int bpsw_extend_batch(bpsw_ctx_t *ctx, const uint8_t *wire, size_t wire_bytes, i
 
 /* Same computation with the wire batch and the result already resident in device memory
  * (used by bench.py; d_wire must be 16-byte aligned).  hip_stream is a hipStream_t or NULL for the context's stream.
- * The call is asynchronous with respect to the host when a stream is given. */
+ * ASYNCHRONOUS: the device-side table scan, the main launch and the scan's read-back are enqueued back to back and the call
+ * returns.  The launch is sized for a fixed geometry (sides <= 256 bases) and checks the scan on the device: a malformed batch,
+ * or one with longer sides, is left untouched.  The NEXT call on this context, or bpsw_last_kernel_ms, waits for the launch and
+ * (a) returns the deferred BPSW_ERR_ARG / BPSW_ERR_LIMIT of a malformed batch, (b) launches a longer-sided batch again with its
+ * real geometry.  d_wire / d_out must stay valid until then.  bpsw_swalign2_batch_device behaves the same way, sizing the
+ * launch for the geometry of the previous (verified) call on the context; the first call of a context is synchronous. */
 int bpsw_extend_batch_device(bpsw_ctx_t *ctx, const void *d_wire, size_t wire_bytes, int n_tasks,
                              void *d_out, void *hip_stream);
 
@@ -350,7 +355,8 @@ typedef struct {
 int bpsw_get_stats(bpsw_ctx_t *ctx, bpsw_stats_t *out);
 int bpsw_reset_stats(bpsw_ctx_t *ctx);
 /* duration in ms of the most recent extend / swalign kernel launch on this context, measured with
- * hipEvents on the launch stream (synchronises the stream). */
+ * hipEvents on the launch stream.  Synchronises the stream and resolves the asynchronous device entries: their deferred
+ * errors are returned here. */
 int bpsw_last_kernel_ms(bpsw_ctx_t *ctx, float *ext_ms, float *sw_ms);
 
 #ifdef __cplusplus
