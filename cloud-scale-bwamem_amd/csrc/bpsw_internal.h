@@ -115,6 +115,7 @@ void launch_ref_fetch(const uint8_t* d_pac, long long l_pac, int n, const long l
                       uint8_t* d_out_pool, size_t out_pool_bytes, const long long* d_out_off, long long* d_out_len,
                       int* d_error, hipStream_t s);
 size_t sw_scratch_bytes_per_wave(int max_tlen);
+bool sw_quad_enabled();  // four rescue jobs per wavefront for mates <= 160 bases (BPSW_SW_QUAD=0 disables)
 int sw_resident_waves(int num_cu);
 // d_pre_check: as for launch_ext_kernel (the launch is sized for max_qlen / max_tlen speculatively).
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,

@@ -200,8 +200,8 @@ int bpsw_swalign2_batch_device(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_
     // Asynchronous: the launch is sized for the geometry the previous call on this context was verified to have (the kernel
     // template by mate length, the scratch rows by window length) and checks the scan on the device; the scan is read back
     // at the next call on this context or at bpsw_last_kernel_ms, where a batch that outgrew the guess is launched again.
-    const int cap_q = 64 * ((c->sw_geom_qlen + 63) / 64);
-    const int cap_t = (int)(c->d_sw_scratch.cap / ((size_t)sw_resident_waves(c->num_cu) * 4)) & ~63;  // rows the scratch holds per wave
+    const int cap_q = (c->sw_geom_qlen <= 160 && sw_quad_enabled()) ? 160 : 64 * ((c->sw_geom_qlen + 63) / 64);  // quad-job / sw_kernel<C>
+    const int cap_t = (int)(c->d_sw_scratch.cap / ((size_t)sw_resident_waves(c->num_cu) * 16)) & ~63;  // rows the scratch holds per job
     if (cap_t >= c->sw_geom_tlen) {
       HIP_TRY(hipEventRecord(c->ev[6], s));
       HIP_TRY(launch_sw_kernel(dev, sc, cap_q, cap_t, (int32_t*)d_out, (uint32_t*)c->d_sw_scratch.ptr, c->num_cu, s, d_pre));
