@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
     "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_worker2_batch", "bpsw_last_tail_times",
+    "bpsw_mark_primary_se", "bpsw_approx_mapq_se", "bpsw_mem_pair", "bpsw_sort_dedup",
 ]
 JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI",
@@ -173,6 +174,11 @@ def load_library(path: str | None = None) -> C.CDLL:
                                       C.POINTER(C.c_size_t), C.c_void_p]
     lib.bpsw_worker2_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.bpsw_mark_primary_se.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    lib.bpsw_approx_mapq_se.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_void_p]
+    lib.bpsw_mem_pair.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                  C.c_void_p]
+    lib.bpsw_sort_dedup.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_int]
     lib.bpsw_last_tail_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p]
     if path is None:
         _lib = lib
@@ -659,3 +665,41 @@ Context.sam_pe_batch = _ctx_sam_pe_batch
 Context.worker2_batch = _ctx_worker2_batch
 Context.last_tail_kernel = _ctx_last_tail_kernel
 Context.last_tail_host_ms = _ctx_last_tail_host_ms
+
+
+# ---- host-only pieces (no device): usable and testable on a CPU-only box -------------------------------------------------
+def _pes_struct(pes):
+    a = (PeStat * 4)()
+    for r in range(4):
+        lo, hi, failed, avg, std = pes[r]
+        a[r].low, a[r].high, a[r].failed, a[r].avg, a[r].std = int(lo), int(hi), int(failed), float(avg), float(std)
+    return a
+
+
+def mark_primary_se(opt: Opt, topt: TailOpt, regs: np.ndarray, rid: int) -> np.ndarray:
+    a = np.ascontiguousarray(regs.copy())
+    lib = load_library()
+    _chk(lib, lib.bpsw_mark_primary_se(C.byref(opt), C.byref(topt), int(a.shape[0]), _ptr(a), int(rid)), "bpsw_mark_primary_se")
+    return a
+
+
+def approx_mapq_se(opt: Opt, topt: TailOpt, reg) -> int:
+    a = np.ascontiguousarray(np.array([reg], ALNREG_DTYPE))
+    return int(load_library().bpsw_approx_mapq_se(C.byref(opt), C.byref(topt), _ptr(a)))
+
+
+def mem_pair(opt: Opt, topt: TailOpt, l_pac: int, pes, regs0: np.ndarray, regs1: np.ndarray, pid: int):
+    a0, a1 = np.ascontiguousarray(regs0), np.ascontiguousarray(regs1)
+    out = np.zeros(5, np.int32)
+    lib = load_library()
+    _chk(lib, lib.bpsw_mem_pair(C.byref(opt), C.byref(topt), int(l_pac), _pes_struct(pes), int(a0.shape[0]), _ptr(a0), int(a1.shape[0]),
+                                _ptr(a1), int(pid), _ptr(out)), "bpsw_mem_pair")
+    return int(out[0]), int(out[1]), int(out[2]), (int(out[3]), int(out[4]))
+
+
+def sort_dedup(regs: np.ndarray, mask_level_redun: float = 0.95, mode: int = RESCUE_C) -> np.ndarray:
+    a = np.ascontiguousarray(regs.copy())
+    n = load_library().bpsw_sort_dedup(int(a.shape[0]), _ptr(a), mask_level_redun, mode)
+    if n < 0:
+        raise BpswError("bpsw_sort_dedup failed")
+    return a[:n]

@@ -732,6 +732,37 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
   return BPSW_OK;
 }
 
+// ---- host-only exports (no device) -------------------------------------------------------------------------------------------
+int bpsw_mark_primary_se(const bpsw_opt_t* opt, const bpsw_tail_opt_t* topt, int32_t n, bpsw_alnreg_t* regs, int64_t id) {
+  if (!opt || !topt || n < 0 || (n > 0 && !regs)) return fail(BPSW_ERR_ARG, "mark_primary_se: null argument");
+  std::vector<bpsw_alnreg_t> v(regs, regs + n);
+  mark_primary(*opt, *topt, v, id);
+  if (n) memcpy(regs, v.data(), sizeof(bpsw_alnreg_t) * (size_t)n);
+  return BPSW_OK;
+}
+int bpsw_approx_mapq_se(const bpsw_opt_t* opt, const bpsw_tail_opt_t* topt, const bpsw_alnreg_t* reg) {
+  if (!opt || !topt || !reg) return fail(BPSW_ERR_ARG, "approx_mapq_se: null argument");
+  return approx_mapq(*opt, *topt, *reg);
+}
+int bpsw_mem_pair(const bpsw_opt_t* opt, const bpsw_tail_opt_t* topt, int64_t l_pac, const bpsw_pestat_t pes[4], int32_t n0,
+                  const bpsw_alnreg_t* regs0, int32_t n1, const bpsw_alnreg_t* regs1, int64_t id, int32_t out5[5]) {
+  if (!opt || !topt || !pes || !out5 || n0 < 0 || n1 < 0 || (n0 > 0 && !regs0) || (n1 > 0 && !regs1))
+    return fail(BPSW_ERR_ARG, "mem_pair: null argument");
+  std::vector<bpsw_alnreg_t> a[2];
+  a[0].assign(regs0, regs0 + n0);
+  a[1].assign(regs1, regs1 + n1);
+  const PairScore p = mem_pair(*opt, *topt, (long long)l_pac, pes, a, id);
+  out5[0] = p.score; out5[1] = p.sub; out5[2] = p.n_sub; out5[3] = p.z[0]; out5[4] = p.z[1];
+  return BPSW_OK;
+}
+int bpsw_sort_dedup(int32_t n, bpsw_alnreg_t* regs, float mask_level_redun, int mode) {
+  if (n < 0 || (n > 0 && !regs) || (mode != BPSW_RESCUE_C && mode != BPSW_RESCUE_SCALA)) return fail(BPSW_ERR_ARG, "sort_dedup: bad argument");
+  std::vector<bpsw_alnreg_t> v(regs, regs + n);
+  const int m = sort_dedup_regs(v, mask_level_redun, mode);
+  if (m > 0) memcpy(regs, v.data(), sizeof(bpsw_alnreg_t) * (size_t)m);
+  return m;
+}
+
 // ---- worker2 in one call: the rescue (boundary 1) followed by the tail -------------------------------------------------------
 // memSamPeGroupJNIPrepare (PE:1895-2000) with getAlnRegRefJNI (PE:1810-1878) in coordinate form: per end the regions within
 // penUnpaired of the best one (at most maxMatesw) are anchors, each with the four orientation windows of the mate; then

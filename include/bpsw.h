@@ -334,6 +334,15 @@ typedef struct {
 } bpsw_pairs_t;
 int bpsw_sam_pe_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_pairs_t *g, char *out_text,
                       size_t text_cap, int64_t *out_off, size_t *out_needed, bpsw_alnreg_t *out_regs);
+/* Host-only pieces of the tail and of the rescue bookkeeping, exported so that they can be used and tested without a device
+ * (no context, no GPU): memMarkPrimarySe (sorts regs in place and fills sub / sub_n / secondary / hash), memApproxMapqSe,
+ * memPair (out5 = {score, sub, n_sub, z0, z1}) and memSortAndDedup (mode BPSW_RESCUE_C / _SCALA; returns the new count). */
+int bpsw_mark_primary_se(const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, int32_t n, bpsw_alnreg_t *regs, int64_t id);
+int bpsw_approx_mapq_se(const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_alnreg_t *reg);
+int bpsw_mem_pair(const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, int64_t l_pac, const bpsw_pestat_t pes[4], int32_t n0,
+                  const bpsw_alnreg_t *regs0, int32_t n1, const bpsw_alnreg_t *regs1, int64_t id, int32_t out5[5]);
+int bpsw_sort_dedup(int32_t n, bpsw_alnreg_t *regs, float mask_level_redun, int mode);
+
 /* worker2 in one call: the rescue of boundary 1 (anchors and windows as memSamPeGroupJNIPrepare builds them,
  * worker2/MemSamPe.scala:1895-2000, windows named by coordinates of the reference loaded with bpsw_ref_load; rescue_mode as in
  * bpsw_matesw_group) followed by the tail above.  g->regs are the region lists BEFORE the rescue (what worker1 hands over).

@@ -1,0 +1,85 @@
+"""The host-side logic of the product library against the oracle and, where oracle/_ref exists, the reference's own C -- on
+the CPU: memMarkPrimarySe, memPair, memApproxMapqSe (bpsw_tail.cpp) and memSortAndDedup (bpsw_rescue.cpp).  No device."""
+import numpy as np
+import pytest
+
+import bpsw_hip
+import pyoracle as po
+from tail_util import synthetic_group
+
+
+@pytest.mark.parametrize("flavour", [bpsw_hip.TAIL_SCALA, bpsw_hip.TAIL_C])
+def test_tail_host_pieces_vs_oracle(orc, flavour):
+    opt, oopt, otopt = bpsw_hip.default_opt(), orc.default_opt(), orc.default_tail_opt()
+    topt = bpsw_hip.default_tail_opt(flavour)
+    n_mp = n_pair = 0
+    for seed, kw in ((41, dict(sub_rate=0.02, indel_rate=0.005)), (42, dict(sub_rate=0.05, indel_rate=0.02, p_dup=0.4))):
+        pac, g = synthetic_group(orc, 400, 500 + seed, **kw)
+        at = 0
+        marked = []
+        for r in range(2 * g.group_size):
+            c = int(g.reg_cnt[r])
+            rid = 2 * (g.id0 + r // 2) | (r & 1)
+            got = bpsw_hip.mark_primary_se(opt, topt, g.regs[at:at + c], rid)
+            want = orc.mark_primary(oopt, otopt, g.regs[at:at + c], rid, flavour)
+            assert got.tobytes() == want.tobytes()
+            for reg in got[:3]:
+                assert bpsw_hip.approx_mapq_se(opt, topt, reg) == orc.approx_mapq(oopt, otopt, reg, flavour)
+            marked.append(got)
+            n_mp += c > 1
+            at += c
+        for p in range(g.group_size):
+            a0, a1 = marked[2 * p], marked[2 * p + 1]
+            if len(a0) and len(a1):
+                assert bpsw_hip.mem_pair(opt, topt, g.l_pac, g.pes, a0, a1, g.id0 + p) == orc.mem_pair(oopt, g.l_pac, g.pes, a0, a1, g.id0 + p, flavour)
+                n_pair += 1
+    assert n_mp > 50 and n_pair > 500
+
+
+def test_tail_host_pieces_vs_reference(orc, ref):
+    opt, oopt, otopt = bpsw_hip.default_opt(), orc.default_opt(), orc.default_tail_opt()
+    topt = bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C)
+    pac, g = synthetic_group(orc, 500, 777, zdrop_mode=po.ZDROP_BWA, sub_rate=0.03, indel_rate=0.01, p_dup=0.4)
+    at = 0
+    marked = []
+    for r in range(2 * g.group_size):
+        c = int(g.reg_cnt[r])
+        rid = 2 * (g.id0 + r // 2) | (r & 1)
+        got = bpsw_hip.mark_primary_se(opt, topt, g.regs[at:at + c], rid)
+        assert got.tobytes() == ref.mark_primary(oopt, otopt, g.regs[at:at + c], rid).tobytes()
+        for reg in got[:2]:
+            assert bpsw_hip.approx_mapq_se(opt, topt, reg) == ref.approx_mapq(oopt, otopt, reg)
+        marked.append(got)
+        at += c
+    for p in range(g.group_size):
+        a0, a1 = marked[2 * p], marked[2 * p + 1]
+        if len(a0) and len(a1):
+            assert bpsw_hip.mem_pair(opt, topt, g.l_pac, g.pes, a0, a1, g.id0 + p) == ref.mem_pair(oopt, g.l_pac, g.pes, a0, a1, g.id0 + p)
+
+
+def test_sort_dedup_vs_oracle_and_golden(orc):
+    import os
+    from tail_util import G
+    z = np.load(os.path.join(G, "mem_sort_and_dedup.npz"))
+    names = list(z.keys())
+    rng = np.random.default_rng(9)
+    for mode in (bpsw_hip.RESCUE_C, bpsw_hip.RESCUE_SCALA):
+        for _ in range(300):
+            n = int(rng.integers(0, 40))
+            regs = np.zeros(n, bpsw_hip.ALNREG_DTYPE)
+            base = int(rng.integers(1000, 5000))
+            regs["rb"] = base + rng.integers(0, 60, n) * rng.integers(1, 4)
+            regs["re"] = regs["rb"] + rng.integers(20, 150, n)
+            regs["qb"] = rng.integers(0, 60, n)
+            regs["qe"] = regs["qb"] + rng.integers(20, 90, n)
+            regs["score"] = rng.integers(20, 150, n)
+            got = bpsw_hip.sort_dedup(regs, 0.95, mode)
+            want = orc.sort_dedup(regs, 0.95, mode)
+            assert got.tobytes() == want.tobytes()
+    # the reference's own mem_sort_and_dedup (klib introsort order included), straight from the committed golden file
+    from conftest import region_fields_equal
+    io, oo = z["in_off"], z["out_off"]
+    for i in range(len(io) - 1):
+        got = bpsw_hip.sort_dedup(z["regs_in"][io[i]:io[i + 1]].astype(bpsw_hip.ALNREG_DTYPE), 0.95, bpsw_hip.RESCUE_C)
+        region_fields_equal(got, z["regs_out"][oo[i]:oo[i + 1]])
+    assert names
