@@ -92,3 +92,12 @@ def test_rejects_out_of_pool_job(ctx):
     jobs["t_off"] = jobs["t_off"].copy(); jobs["t_off"][3] = 10 ** 9
     with pytest.raises(bpsw_hip.BpswError):
         ctx.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs)
+
+
+def test_large_batch_takes_the_quad_job_kernel(ctx, orc):
+    """>= 24 576 jobs of <= 160-base mates: launch_sw_kernel picks sw4_kernel (four jobs per wavefront) by itself; ragged
+    windows (so the four jobs of a wavefront end at different steps), a quartet that is not full, and every job vs the oracle."""
+    jobs = synth.sw_jobs(26003, read_len=150, win_min=300, win_max=650, sub_rate=0.03, indel_rate=0.004, unrelated_frac=0.1,
+                         decoy_frac=0.15, rev_frac=0.5, seed=909)
+    want = _check(ctx, orc, jobs)
+    assert (want[:, 3] >= 0).sum() > 100 and (want[:, 0] < 19).sum() > 100
