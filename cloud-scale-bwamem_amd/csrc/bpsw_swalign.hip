@@ -91,9 +91,11 @@ __device__ PassRes sw_pass(const int lane, const uint8_t* __restrict__ q, const 
 
   for (int t = 0; t < nsteps; ++t) {
     if ((t & (TBUF - 1)) == 0) {  // stage the next window of target bases
+      int t0 = t;
+      asm volatile("" : "+s"(t0));  // opaque: keeps the staging addresses from becoming per-step 64-bit induction variables (3 of 52 VALU per step)
       __builtin_amdgcn_wave_barrier();
       for (int k = lane; k < TBUF; k += 64) {
-        const int r = t + k;
+        const int r = t0 + k;
         int code = 5;
         if (r < tLen) {
           const int src = (pass2 && r <= tEnd) ? tEnd - r : r;
