@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
     "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_worker2_batch", "bpsw_last_tail_times",
-    "bpsw_mark_primary_se", "bpsw_approx_mapq_se", "bpsw_mem_pair", "bpsw_sort_dedup",
+    "bpsw_mark_primary_se", "bpsw_approx_mapq_se", "bpsw_mem_pair", "bpsw_sort_dedup", "bpsw_pe_stat",
 ]
 JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI",
@@ -179,6 +179,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_mem_pair.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                   C.c_void_p]
     lib.bpsw_sort_dedup.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_int]
+    lib.bpsw_pe_stat.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bpsw_last_tail_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p]
     if path is None:
         _lib = lib
@@ -703,3 +704,12 @@ def sort_dedup(regs: np.ndarray, mask_level_redun: float = 0.95, mode: int = RES
     if n < 0:
         raise BpswError("bpsw_sort_dedup failed")
     return a[:n]
+
+
+def pe_stat(opt: Opt, topt: TailOpt, l_pac: int, reg_cnt: np.ndarray, regs: np.ndarray):
+    """memPeStat -> 4 x (low, high, failed, avg, std)"""
+    rc = np.ascontiguousarray(reg_cnt, np.int32); rg = np.ascontiguousarray(regs)
+    pes = (PeStat * 4)()
+    lib = load_library()
+    _chk(lib, lib.bpsw_pe_stat(C.byref(opt), C.byref(topt), int(l_pac), int(rc.shape[0] // 2), _ptr(rc), _ptr(rg), pes), "bpsw_pe_stat")
+    return [(int(pes[r].low), int(pes[r].high), int(pes[r].failed), float(pes[r].avg), float(pes[r].std)) for r in range(4)]

@@ -763,6 +763,65 @@ int bpsw_sort_dedup(int32_t n, bpsw_alnreg_t* regs, float mask_level_redun, int 
   return m;
 }
 
+int bpsw_pe_stat(const bpsw_opt_t* opt, const bpsw_tail_opt_t* topt, int64_t l_pac, int32_t n_pairs, const int32_t* reg_cnt,
+                 const bpsw_alnreg_t* regs, bpsw_pestat_t pes[4]) {
+  if (!opt || !topt || !pes || n_pairs < 0 || (n_pairs > 0 && !reg_cnt)) return fail(BPSW_ERR_ARG, "pe_stat: null argument");
+  auto cal_sub = [&](const bpsw_alnreg_t* a, int n) {  // PE:77-101
+    int j = 1;
+    for (; j < n; ++j) {
+      const int b_max = std::max(a[j].qb, a[0].qb), e_min = std::min(a[j].qe, a[0].qe);
+      if (e_min > b_max) {
+        const int min_l = std::min(a[j].qe - a[j].qb, a[0].qe - a[0].qb);
+        if ((float)(e_min - b_max) >= (float)min_l * topt->mask_level) break;
+      }
+    }
+    return j < n ? a[j].score : opt->min_seed_len * opt->a;
+  };
+  std::vector<int64_t> isize[4];
+  size_t at = 0;
+  for (int i = 0; i < n_pairs; ++i) {
+    const int n0 = reg_cnt[2 * i], n1 = reg_cnt[2 * i + 1];
+    if (n0 < 0 || n1 < 0 || ((n0 || n1) && !regs)) return fail(BPSW_ERR_ARG, "pe_stat: bad region counts");
+    const bpsw_alnreg_t* r0 = regs + at;
+    const bpsw_alnreg_t* r1 = r0 + n0;
+    at += (size_t)n0 + (size_t)n1;
+    if (n0 == 0 || n1 == 0) continue;
+    if (cal_sub(r0, n0) > 0.8 * r0[0].score || cal_sub(r1, n1) > 0.8 * r1[0].score) continue;  // MIN_RATIO
+    long long is;
+    const int dir = infer_dir((long long)l_pac, r0[0].rb, r1[0].rb, &is);
+    if (topt->flavour == BPSW_TAIL_SCALA) is = (long long)(int32_t)is;  // `var dist: Int`, PE:148
+    if (is > 0 && is <= opt->max_ins) isize[dir].push_back(is);
+  }
+  memset(pes, 0, 4 * sizeof(bpsw_pestat_t));
+  size_t most = 0;
+  for (int d = 0; d < 4; ++d) {
+    bpsw_pestat_t& r = pes[d];
+    std::vector<int64_t>& q = isize[d];
+    most = std::max(most, q.size());
+    if (q.size() < 10) { r.failed = 1; continue; }  // MIN_DIR_CNT
+    std::sort(q.begin(), q.end());
+    const int p25 = (int)q[(size_t)(int)(.25 * q.size() + .499)], p75 = (int)q[(size_t)(int)(.75 * q.size() + .499)];
+    r.low = std::max(1, (int)(p25 - 2.0 * (p75 - p25) + .499));  // OUTLIER_BOUND
+    r.high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+    int x = 0;
+    double avg = 0, var = 0;
+    for (int64_t v : q) if (v >= r.low && v <= r.high) { avg += (double)v; ++x; }
+    avg /= x;
+    for (int64_t v : q) if (v >= r.low && v <= r.high) var += ((double)v - avg) * ((double)v - avg);
+    r.avg = avg;
+    r.std = sqrt(var / x);
+    r.low = (int)(p25 - 3.0 * (p75 - p25) + .499);  // MAPPING_BOUND
+    r.high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+    if (r.low > r.avg - 4.0 * r.std) r.low = (int)(r.avg - 4.0 * r.std + .499);  // MAX_STDDEV
+    if (r.high < r.avg - 4.0 * r.std)  // PE:215 assigns avg - 4 sigma, native/bwamem_pair.c:99 avg + 4 sigma
+      r.high = topt->flavour == BPSW_TAIL_SCALA ? (int)(r.avg - 4.0 * r.std + .499) : (int)(r.avg + 4.0 * r.std + .499);
+    if (r.low < 1) r.low = 1;
+  }
+  for (int d = 0; d < 4; ++d)
+    if (pes[d].failed == 0 && (double)isize[d].size() < most * 0.05) pes[d].failed = 1;  // MIN_DIR_RATIO
+  return BPSW_OK;
+}
+
 // ---- worker2 in one call: the rescue (boundary 1) followed by the tail -------------------------------------------------------
 // memSamPeGroupJNIPrepare (PE:1895-2000) with getAlnRegRefJNI (PE:1810-1878) in coordinate form: per end the regions within
 // penUnpaired of the best one (at most maxMatesw) are anchors, each with the four orientation windows of the mate; then

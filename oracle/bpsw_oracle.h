@@ -176,6 +176,9 @@ typedef struct { /* datatype/MemAlnType.scala == mem_aln_t native/bwamem.h:71-80
 
 void orc_mark_primary_se(const orc_opt_t *o, const orc_tail_opt_t *t, int n, orc_alnreg_t *a, int64_t id, int flavour);
 int orc_approx_mapq_se(const orc_opt_t *o, const orc_tail_opt_t *t, const orc_alnreg_t *a, int flavour);
+/* memPeStat, PE:117-260 (== mem_pestat, native/bwamem_pair.c:50-112): the insert-size statistics between worker1 and worker2 */
+void orc_pe_stat(const orc_opt_t *o, const orc_tail_opt_t *t, int64_t l_pac, int n_pairs, const int32_t *reg_cnt,
+                 const orc_alnreg_t *regs, int flavour, orc_pestat_t pes[4]);
 int orc_mem_pair(const orc_opt_t *o, int64_t l_pac, const orc_pestat_t pes[4], int n0, const orc_alnreg_t *a0, int n1,
                  const orc_alnreg_t *a1, int64_t id, int flavour, int *sub, int *n_sub, int z[2]);
 int orc_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t *pac,

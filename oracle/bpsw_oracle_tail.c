@@ -316,6 +316,78 @@ void orc_reg2aln(const orc_opt_t *o, const orc_tail_opt_t *t, int n_seqs, const 
   free(cg);
 }
 
+/* ------------------------------------------------------------------ memPeStat, PE:77-260 (C: native/bwamem_pair.c:36-112) */
+static int cal_sub(const orc_opt_t *o, const orc_tail_opt_t *t, int n, const orc_alnreg_t *a) { /* PE:77-101 */
+  int j;
+  for (j = 1; j < n; ++j) {
+    const int b_max = a[j].qb > a[0].qb ? a[j].qb : a[0].qb;
+    const int e_min = a[j].qe < a[0].qe ? a[j].qe : a[0].qe;
+    if (e_min > b_max) {
+      const int min_l = a[j].qe - a[j].qb < a[0].qe - a[0].qb ? a[j].qe - a[j].qb : a[0].qe - a[0].qb;
+      if (e_min - b_max >= min_l * t->mask_level) break;
+    }
+  }
+  return j < n ? a[j].score : o->min_seed_len * o->a;
+}
+static int cmp_i64(const void *a, const void *b) {
+  const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+/* regs: the region lists of the 2*n_pairs reads in (pair, end, j) order (after memSortAndDedup, before the rescue) */
+void orc_pe_stat(const orc_opt_t *o, const orc_tail_opt_t *t, int64_t l_pac, int n_pairs, const int32_t *reg_cnt,
+                 const orc_alnreg_t *regs, int flavour, orc_pestat_t pes[4]) {
+  int64_t *isize[4];
+  size_t ni[4] = {0, 0, 0, 0};
+  int d;
+  memset(pes, 0, 4 * sizeof(orc_pestat_t));
+  for (d = 0; d < 4; ++d) isize[d] = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_pairs > 0 ? n_pairs : 1));
+  size_t at = 0;
+  for (int i = 0; i < n_pairs; ++i) {
+    const int n0 = reg_cnt[2 * i], n1 = reg_cnt[2 * i + 1];
+    const orc_alnreg_t *r0 = regs + at, *r1 = regs + at + n0;
+    at += (size_t)n0 + (size_t)n1;
+    if (n0 == 0 || n1 == 0) continue;
+    if (cal_sub(o, t, n0, r0) > 0.8 * r0[0].score) continue; /* MIN_RATIO */
+    if (cal_sub(o, t, n1, r1) > 0.8 * r1[0].score) continue;
+    int64_t is;
+    const int dir = orc_infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+    if (flavour == ORC_TAIL_SCALA) is = (int64_t)(int32_t)is; /* `var dist: Int`, PE:148 */
+    if (is > 0 && is <= o->max_ins) isize[dir][ni[dir]++] = is;
+  }
+  for (d = 0; d < 4; ++d) {
+    orc_pestat_t *r = &pes[d];
+    int64_t *q = isize[d];
+    const size_t n = ni[d];
+    if (n < 10) { r->failed = 1; continue; } /* MIN_DIR_CNT */
+    qsort(q, n, sizeof(int64_t), cmp_i64);
+    const int p25 = (int)q[(int)(.25 * n + .499)], p75 = (int)q[(int)(.75 * n + .499)];
+    r->low = (int)(p25 - 2.0 * (p75 - p25) + .499); /* OUTLIER_BOUND */
+    if (r->low < 1) r->low = 1;
+    r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+    size_t i;
+    int x = 0;
+    r->avg = 0;
+    for (i = 0; i < n; ++i)
+      if (q[i] >= r->low && q[i] <= r->high) { r->avg += (double)q[i]; ++x; }
+    r->avg /= x;
+    r->std = 0;
+    for (i = 0; i < n; ++i)
+      if (q[i] >= r->low && q[i] <= r->high) r->std += ((double)q[i] - r->avg) * ((double)q[i] - r->avg);
+    r->std = sqrt(r->std / x);
+    r->low = (int)(p25 - 3.0 * (p75 - p25) + .499); /* MAPPING_BOUND */
+    r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+    if (r->low > r->avg - 4.0 * r->std) r->low = (int)(r->avg - 4.0 * r->std + .499); /* MAX_STDDEV */
+    if (r->high < r->avg - 4.0 * r->std) /* B6: the Scala assigns avg - 4 sigma (PE:215), the C avg + 4 sigma (native/bwamem_pair.c:99) */
+      r->high = flavour == ORC_TAIL_SCALA ? (int)(r->avg - 4.0 * r->std + .499) : (int)(r->avg + 4.0 * r->std + .499);
+    if (r->low < 1) r->low = 1;
+  }
+  size_t max = 0;
+  for (d = 0; d < 4; ++d) max = max > ni[d] ? max : ni[d];
+  for (d = 0; d < 4; ++d)
+    if (pes[d].failed == 0 && ni[d] < max * 0.05) pes[d].failed = 1; /* MIN_DIR_RATIO */
+  for (d = 0; d < 4; ++d) free(isize[d]);
+}
+
 /* ------------------------------------------------------------------ memPair, PE:462-572 */
 typedef struct { uint64_t x, y; } pair64_t;
 static int cmp_pair64(const void *a_, const void *b_) { /* pair64_lt, native/utils.h: (x, y) ascending; keys are unique */

@@ -507,3 +507,28 @@ Ref.approx_mapq = _ref_approx_mapq
 Ref.mem_pair = _ref_mem_pair
 Ref.reg2aln_batch = _ref_reg2aln_batch
 Ref.sam_pe_batch = _ref_sam_pe_batch
+
+
+def _pes_list(pes):
+    return [(int(pes[r].low), int(pes[r].high), int(pes[r].failed), float(pes[r].avg), float(pes[r].std)) for r in range(4)]
+
+
+def _orc_pe_stat(self, opt, topt, l_pac, reg_cnt, regs, flavour=TAIL_SCALA):
+    """memPeStat (MemSamPe.scala:117-260) -> 4 x (low, high, failed, avg, std)"""
+    rc = np.ascontiguousarray(reg_cnt, np.int32); rg = np.ascontiguousarray(regs)
+    pes = (PeStat * 4)()
+    self.lib.orc_pe_stat(C.byref(opt), C.byref(topt), C.c_int64(l_pac), C.c_int(rc.shape[0] // 2), _vp(rc), _vp(rg), C.c_int(flavour), pes)
+    return _pes_list(pes)
+
+
+def _ref_pestat(self, opt, topt, l_pac, reg_cnt, regs):
+    """mem_pestat (native/bwamem_pair.c:50-112)"""
+    rc = np.ascontiguousarray(reg_cnt, np.int32); rg = np.ascontiguousarray(regs)
+    pes = (PeStat * 4)()
+    self.lib.ref_pestat(_vp(_ints_of(opt)), _vp(np.array(list(opt.mat), np.int8)), _vp(_tail3(topt)), C.c_int64(l_pac),
+                        C.c_int(rc.shape[0] // 2), _vp(rc), _vp(rg), pes)
+    return _pes_list(pes)
+
+
+Oracle.pe_stat = _orc_pe_stat
+Ref.pestat = _ref_pestat

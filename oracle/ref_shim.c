@@ -374,3 +374,24 @@ int64_t ref_sam_pe_batch(const int32_t ints[16], const int8_t mat[25], const flo
   shim_bns_free(bns); free(o);
   return overflow ? -total : total;
 }
+
+/* mem_pestat (native/bwamem_pair.c:50-112) over flat region lists; it reports on stderr (unconditional fprintf) */
+void mem_pestat(const mem_opt_t *opt, int64_t l_pac, int n, const mem_alnreg_v *regs, mem_pestat_t pes[4]);
+void ref_pestat(const int32_t ints[16], const int8_t mat[25], const float tail[3], int64_t l_pac, int n_pairs, const int32_t *reg_cnt,
+                const flat_alnreg_t *regs, flat_pestat_t out[4]) {
+  mem_opt_t *o = shim_opt(ints, 0.95f, mat, tail);
+  mem_alnreg_v *v = (mem_alnreg_v *)calloc((size_t)(2 * n_pairs > 0 ? 2 * n_pairs : 1), sizeof(mem_alnreg_v));
+  size_t at = 0;
+  for (int e = 0; e < 2 * n_pairs; ++e) {
+    v[e].n = v[e].m = (size_t)reg_cnt[e];
+    v[e].a = (mem_alnreg_t *)(regs + at);
+    at += (size_t)reg_cnt[e];
+  }
+  mem_pestat_t pes[4];
+  mem_pestat(o, l_pac, 2 * n_pairs, v, pes);
+  for (int r = 0; r < 4; ++r) {
+    out[r].low = pes[r].low; out[r].high = pes[r].high; out[r].failed = pes[r].failed; out[r].pad_ = 0;
+    out[r].avg = pes[r].avg; out[r].std = pes[r].std;
+  }
+  free(v); free(o);
+}

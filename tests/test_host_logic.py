@@ -83,3 +83,18 @@ def test_sort_dedup_vs_oracle_and_golden(orc):
         got = bpsw_hip.sort_dedup(z["regs_in"][io[i]:io[i + 1]].astype(bpsw_hip.ALNREG_DTYPE), 0.95, bpsw_hip.RESCUE_C)
         region_fields_equal(got, z["regs_out"][oo[i]:oo[i + 1]])
     assert names
+
+
+def test_pe_stat_vs_oracle_and_reference(orc, ref):
+    """memPeStat: product == oracle in both flavours (and == the reference's mem_pestat in the C flavour), on libraries with one
+    and with several supported orientations, and on a batch too small for any."""
+    opt, oopt, otopt = bpsw_hip.default_opt(), orc.default_opt(), orc.default_tail_opt()
+    for seed, n in ((61, 600), (62, 300), (63, 8)):
+        pac, g = synthetic_group(orc, n, 800 + seed, zdrop_mode=po.ZDROP_BWA, sub_rate=0.02, indel_rate=0.004, p_far=0.1)
+        for flavour in (bpsw_hip.TAIL_SCALA, bpsw_hip.TAIL_C):
+            got = bpsw_hip.pe_stat(opt, bpsw_hip.default_tail_opt(flavour), g.l_pac, g.reg_cnt, g.regs)
+            assert got == orc.pe_stat(oopt, otopt, g.l_pac, g.reg_cnt, g.regs, flavour)
+        got_c = bpsw_hip.pe_stat(opt, bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C), g.l_pac, g.reg_cnt, g.regs)
+        assert got_c == ref.pestat(oopt, otopt, g.l_pac, g.reg_cnt, g.regs)
+        if n >= 300:
+            assert got_c[1][2] == 0 and 350 < got_c[1][3] < 450 and got_c[0][2] == 1      # FR supported, mean ~ 400; FF not

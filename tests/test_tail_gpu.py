@@ -8,6 +8,7 @@ import pytest
 import bpsw_hip
 import pyoracle as po
 import copy
+from bpsw_hip import synth
 
 from tail_util import G, load_sam_pe_golden, rescue_group_of, synthetic_group, synthetic_group_with_bases
 
@@ -182,3 +183,44 @@ def test_tail_scale_properties(ctx, orc):
     sub = _slice_group(g, lo, hi)
     want, _, _ = orc.sam_pe_batch(orc.default_opt(), orc.default_tail_opt(), pac, sub)
     assert whole[2 * lo:2 * hi] == want
+
+
+def test_chains_to_sam_end_to_end_vs_reference(ctx, orc, ref):
+    """Everything the library offers, chained as the driver chains it -- chains -> bpsw_chain2aln_batch (round loop + sort/dedup)
+    -> bpsw_pe_stat -> bpsw_worker2_batch (rescue + tail) -> SAM text -- against the reference's own C pipeline on the same
+    chains: mem_chain2aln + mem_sort_and_dedup, mem_pestat, mem_sam_pe.  The region lists and the insert-size statistics must be
+    identical; the text may differ in MAPQ / XS only, and only for a few percent of the pairs."""
+    pac, bases, off, ln, names, dups = synth.contig_reference([70_000, 50_000, 30_000, 50_000], seed=9100)
+    tb, rn, quals, _ = synth.tail_pairs(600, bases, off, ln, dups, seed=9101, sub_rate=0.02, indel_rate=0.004, p_hard=0.15,
+                                        p_unmappable=0.03)
+    opt, oopt = bpsw_hip.default_opt(), orc.default_opt()
+    topt, otopt = bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C), orc.default_tail_opt()
+    l_pac = int(tb.l_pac)
+    ctx.ref_load(pac, l_pac)
+    # worker1's second half
+    cnt, regs = ctx.chain2aln_batch(opt, tb, po.ZDROP_BWA, bpsw_hip.C2A_SORT_DEDUP)
+    rcnt, rregs = ref.chain2aln_batch(oopt, pac, tb)
+    want_regs, at = [], 0
+    for c in rcnt:
+        want_regs.append(ref.sort_dedup(rregs[at:at + c]) if c else rregs[0:0])
+        at += c
+    assert np.array_equal(cnt, [len(r) for r in want_regs]) and regs.tobytes() == np.concatenate(want_regs).tobytes()
+    # the driver's statistics
+    pes = bpsw_hip.pe_stat(opt, topt, l_pac, cnt, regs)
+    assert pes == ref.pestat(oopt, otopt, l_pac, cnt, regs) and pes[1][2] == 0
+    # worker2
+    g = bpsw_hip.make_tail_group(tb, rn, quals, pes, cnt, regs, off, ln, names, id0=5)
+    _load_ref(ctx, pac, g)
+    want = ref.sam_pe_batch(oopt, otopt, pac, g, no_rescue=False)
+    got, cnt2, _ = ctx.worker2_batch(opt, topt, g, bpsw_hip.RESCUE_C)
+    assert int(cnt2.sum()) > int(cnt.sum())
+
+    def strip(line):
+        f = line.rstrip(b"\n").split(b"\t")
+        return [x for k, x in enumerate(f) if k != 4 and not x.startswith(b"XS:i:")]
+
+    diff = [i for i in range(len(want)) if want[i] != got[i]]
+    assert len(diff) <= 0.05 * len(want), len(diff)
+    for i in diff:
+        wl, gl = want[i].splitlines(), got[i].splitlines()
+        assert len(wl) == len(gl) and all(strip(a) == strip(b) for a, b in zip(wl, gl)), (want[i], got[i])
