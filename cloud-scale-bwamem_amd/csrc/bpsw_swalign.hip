@@ -479,6 +479,364 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw4_kernel(const SwJo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed form: TWO jobs per wavefront, one in each 16-bit half of every DP register, and no per-row scalar work.
+//
+// The kernel is bound by the number of instructions a SIMD can issue, vector or scalar.  Two things cut that count:
+//  (1) CDNA's packed 16-bit integer ALU ops (v_pk_add_u16, v_pk_sub_u16 with clamp, v_pk_max_u16) apply one cell update to
+//      both halves at once, so the same systolic pipe carries two independent jobs for the instruction count of one.  What
+//      makes 16 bits exact: a pass stops at the first row whose maximum reaches maxScore = 255 - |b| (SWUtil.scala:423,537),
+//      so every H that is ever consumed is <= 254 + max(mat) <= 255 (launch_sw_kernel checks max(mat) <= |b| + 1); E and F are
+//      below H, everything is >= 0, and the row key H<<8 | (255 - j) fits the half exactly for up to 256 columns.  The
+//      substitution score of both jobs comes from ONE v_perm_b32 per cell: per column each job keeps its four target-base
+//      scores as biased bytes (score + bias >= 0), and the per-row selector word (prepared when the target window is staged,
+//      handed down the pipe like the target base in sw_pass) picks job A's byte into the low half and job B's into the high
+//      half; `max(diag + s, 0)` is the clamped subtraction of the bias.  A window with an N in it (never the case for
+//      windows cut from the 2-bit reference) runs a variant of the step that patches the N rows from a fifth score.
+//  (2) The sequential per-row bookkeeping of SWUtil.scala:517-538 leaves the loop.  The query is RIGHT-aligned in the
+//      pipe: the unused columns sit at the left, where they compute zeros by themselves (no column mask), the last real
+//      column is the last column of lane 63 - PK_TAIL, and the PK_TAIL lanes behind it only hand the finished row keys on.
+//      So after every group of PK_TAIL + 1 steps the tail lanes hold the keys of PK_TAIL + 1 consecutive rows of both jobs:
+//      each tail lane folds its row into a running best (m, earliest row, column -- one unsigned max, frozen once m reaches
+//      the stop score) and stores the packed key; the loop body has no readlane and no branch.  The list of local maxima
+//      `b` (SWUtil.scala:517-529), which only feeds the second-best score, is rebuilt afterwards from the stored row maxima
+//      in closed form (second_best below).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk(int x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ int unpk(u16x2 x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ u16x2 pk_max(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ u16x2 pk_subs(u16x2 a, u16x2 b) { return __builtin_elementwise_sub_sat(a, b); }  // max(a - b, 0)
+
+constexpr int PK_TBUF = 256;   // selector words staged in LDS per wave at a time (1 KB)
+constexpr int PK_TAIL = 7;     // lanes behind the last query column; rows are booked PK_TAIL + 1 at a time
+constexpr int PK_G = PK_TAIL + 1;
+constexpr int PK_LAST = 63 - PK_TAIL;  // lane of the last query column
+constexpr int PK_SEL_OFF = 12, PK_SEL_N = 13;  // v_perm_b32 selectors: 12 -> 0x00 (row beyond the window), 13 -> 0xff (row is N)
+
+struct Duo {  // wave-uniform: the two jobs a wave works on
+  int qLenRaw[2], qrev[2], tLen[2];
+  const uint8_t* q[2];
+  const uint8_t* tbytes[2];
+  long long rb[2];
+};
+
+template <int C>
+struct PkCols {  // per lane: C columns of both jobs
+  int prof[2][C], pn[C], ckey[C], Hp[C], E[C];
+  int sel, hlast_cur, hlast_old, fout, keyout;
+};
+
+struct PkConst {
+  u16x2 eDel, eIns, oeDel, oeIns, biasv, k256;
+  bool tail;
+  bool same_oe;  // oDel + eDel == oIns + eIns (the default): E and F share `H - oe`
+};
+
+// one anti-diagonal of both jobs (SWUtil.scala:484-505)
+template <int C, bool HASN, bool SAME_OE>
+__device__ __forceinline__ void swp_step(PkCols<C>& S, const PkConst& K, const int ch) {
+  S.sel = wave_shr1(ch, S.sel);                    // lane 0 starts a row of each job, lane l continues the row lane l-1 had
+  const int din = shr1_zero(S.hlast_old);          // H(i-1, l*C-1)
+  const int fin = shr1_zero(S.fout);               // F(i, l*C)
+  const int kin = shr1_zero(S.keyout);             // row maxima so far
+  S.hlast_old = S.hlast_cur;
+  int s[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) s[c] = (int)__builtin_amdgcn_perm((unsigned)S.prof[1][c], (unsigned)S.prof[0][c], (unsigned)S.sel);
+  if (HASN) {
+    const int nm = ((S.sel & 0xff) == PK_SEL_N ? 0xffff : 0) | (((S.sel >> 16) & 0xff) == PK_SEL_N ? (int)0xffff0000 : 0);
+#pragma unroll
+    for (int c = 0; c < C; ++c) s[c] = (s[c] & ~nm) | (S.pn[c] & nm);
+  }
+  u16x2 diag = pk(din), f = pk(fin), key = pk(kin);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const u16x2 m = pk_subs(diag + pk(s[c]), K.biasv);                 // max(H(i-1,j-1) + s, 0)
+    const u16x2 h = pk_max(pk_max(m, pk(S.E[c])), f);
+    diag = pk(S.Hp[c]);
+    S.Hp[c] = unpk(h);
+    key = pk_max(key, h * K.k256 + pk(S.ckey[c]));                     // first arg-max wins ties (SWUtil.scala:493)
+    const u16x2 hd = pk_subs(h, K.oeDel);
+    const u16x2 hi = SAME_OE ? hd : pk_subs(h, K.oeIns);
+    S.E[c] = unpk(pk_max(pk_subs(pk(S.E[c]), K.eDel), hd));
+    f = pk_max(pk_subs(f, K.eIns), hi);
+  }
+  S.hlast_cur = S.Hp[C - 1];
+  S.fout = unpk(f);
+  S.keyout = K.tail ? kin : unpk(key);
+}
+
+// The second-best score of SWUtil.scala:549-567 from the row maxima m[0..n_rows) of one pass.  The list logic of :517-529
+// over the rows with m >= minScore ("hot"): a hot row is WRITTEN (appended, or replaces the last entry) iff the row before was
+// not written or m grew, w(r) = hot(r) & (!w(r-1) | m(r) > m(r-1)); an entry's final value is a written row that the next
+// row does not replace.  w is a parity chain between the rows where it is forced (not hot -> 0, hot and grown -> 1), so with
+// k(r) the last forced row at or before r:  w(r) = hot(r) & (w(k) ^ ((r - k) & 1)).  The best entry outside +-tmp rows of
+// te, the earliest on ties, is then one wave maximum.
+__device__ void second_best(const int lane, const uint32_t* __restrict__ keys, const int shift, const int base, const int n_rows,
+                            const int minScore, const int low, const int high, int& score2, int& te2) {
+  int best = -1, carry = -1;
+  for (int r0 = 0; r0 < n_rows; r0 += 64) {
+    const int r = r0 + lane;
+    const bool in = r < n_rows;
+    const int mc = in ? (int)((keys[base + r] >> shift) & 0xffffu) >> 8 : 0;
+    const int mp = (in && r > 0) ? (int)((keys[base + r - 1] >> shift) & 0xffffu) >> 8 : 0;
+    const int mn = (r + 1 < n_rows) ? (int)((keys[base + r + 1] >> shift) & 0xffffu) >> 8 : 0;
+    const bool hot = in && mc >= minScore;
+    const bool grown = r == 0 || mc > mp;
+    const bool forced = !hot || grown;
+    const int val = (hot && grown) ? 1 : 0;
+    int k = forced ? ((r << 1) | val) : -1;
+    k = max(wave_scan_max(k), carry);
+    carry = __builtin_amdgcn_readlane(k, 63);
+    const bool w = hot && (((k & 1) ^ ((r - (k >> 1)) & 1)) != 0);
+    const bool fin = w && !(r + 1 < n_rows && mn >= minScore && mn > mc);
+    if (fin && (r < low || r > high)) best = max(best, (mc << 16) | (0xffff - r));
+  }
+  best = wave_max(best);
+  if (best >= 0) { score2 = best >> 16; te2 = 0xffff - (best & 0xffff); }
+}
+
+struct PkRes {
+  int max, max_i, max_j, n_rows;
+};
+
+template <int C>
+__device__ void swp_pass(const int lane, const Duo& J, const int (&on)[2], const int (&qCols)[2], const bool pass2,
+                         const int (&qEnd)[2], const int (&tEnd)[2], const uint8_t* __restrict__ pac, const long long l_pac,
+                         const SwScoring& sc, const int bias, const int (&stopScore)[2], uint32_t* __restrict__ tbuf,
+                         uint32_t* __restrict__ keys, int (&D)[2], PkRes (&res)[2]) {
+  const auto sat16 = [](int v) { return v > 0xffff ? 0xffff : v; };
+  PkConst K;
+  K.eDel = pk(sat16(sc.e_del) * 0x10001); K.eIns = pk(sat16(sc.e_ins) * 0x10001);
+  K.oeDel = pk(sat16(sc.o_del + sc.e_del) * 0x10001); K.oeIns = pk(sat16(sc.o_ins + sc.e_ins) * 0x10001);
+  K.biasv = pk(bias * 0x10001);
+  int k256 = 256 * 0x10001;
+  asm volatile("" : "+v"(k256));  // opaque: a multiply-add (v_pk_mad_u16), not a shift and an add
+  K.k256 = pk(k256);
+  K.tail = lane > PK_LAST;
+  K.same_oe = sc.o_del + sc.e_del == sc.o_ins + sc.e_ins;
+  PkCols<C> S;
+  int L0[2], nsteps[2], maxsteps = 0;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int pad = (PK_LAST + 1) * C - qCols[g];   // unused columns, at the left
+    L0[g] = on[g] ? pad / C : 0;                    // first lane with a query column: where row t enters at step t
+    D[g] = PK_LAST - L0[g];                         // row i leaves lane PK_LAST at step i + D
+    nsteps[g] = on[g] ? J.tLen[g] + D[g] : 0;
+    maxsteps = max(maxsteps, nsteps[g]);
+  }
+  maxsteps = (maxsteps + PK_G - 1) / PK_G * PK_G;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    int nrow[2];
+    S.ckey[c] = 0;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int j = lane * C + c - ((PK_LAST + 1) * C - qCols[g]);
+      const bool valid = on[g] && j >= 0 && j < qCols[g];
+      int w = 0;
+      nrow[g] = 0;
+      if (valid) {
+        const int fc = pass2 ? qEnd[g] - j : j;
+        const int raw = J.qrev[g] ? J.qLenRaw[g] - 1 - fc : fc;
+        int code = J.q[g][raw];
+        if (J.qrev[g]) code = code < 4 ? 3 - code : 4;  // MemSamPe.scala:1178-1181
+        if (code > 4) code = 4;
+        const int sh = 8 * code;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w |= (((int)(int8_t)(sc.mat.row[r] >> sh) + bias) & 0xff) << (8 * r);
+        nrow[g] = ((int)(int8_t)(sc.mat.row[4] >> sh) + bias) & 0xff;
+        S.ckey[c] |= (255 - j) << (16 * g);
+      }
+      S.prof[g][c] = w;   // an unused column scores -bias against everything: it stays 0
+    }
+    S.pn[c] = nrow[0] | (nrow[1] << 16);
+    S.Hp[c] = 0;
+    S.E[c] = 0;
+  }
+  S.hlast_cur = S.hlast_old = S.fout = S.keyout = 0;
+  const TgSrc tgA = {J.tbytes[0], pac, l_pac, J.rb[0]}, tgB = {J.tbytes[1], pac, l_pac, J.rb[1]};
+  const auto selector = [&](const int ra, const int rb) {  // the v_perm_b32 selector word of row ra of job A and row rb of job B
+    int sa = PK_SEL_OFF, sb = PK_SEL_OFF;
+    if (on[0] && ra >= 0 && ra < J.tLen[0]) {
+      const int code = tgA.at((pass2 && ra <= tEnd[0]) ? tEnd[0] - ra : ra);
+      sa = code < 4 ? code : PK_SEL_N;
+    }
+    if (on[1] && rb >= 0 && rb < J.tLen[1]) {
+      const int code = tgB.at((pass2 && rb <= tEnd[1]) ? tEnd[1] - rb : rb);
+      sb = code < 4 ? 4 + code : PK_SEL_N;
+    }
+    return sa | (PK_SEL_OFF << 8) | (sb << 16) | (PK_SEL_OFF << 24);
+  };
+  const auto has_n = [](const int w) { return (w & 0xff) == PK_SEL_N || ((w >> 16) & 0xff) == PK_SEL_N; };
+  // Row t of a job enters its first query lane L0 at step t: lane 0 is fed row t + L0 at step t, and the L0 rows that would
+  // have had to be fed before step 0 start out in the lanes below L0, already on their way.
+  S.sel = selector(L0[0] - 1 - lane, L0[1] - 1 - lane);
+  bool nPrev = __builtin_amdgcn_ballot_w64(has_n(S.sel)) != 0;
+
+  // per tail lane: the row it will hold at the end of the first group, and its running best m<<24 | (0xffff - row)<<8 | (255 - j)
+  const int x = lane - PK_LAST;  // 0..PK_TAIL on the booking lanes
+  const bool booker = x >= 0;
+  int row[2] = {PK_TAIL - x - D[0], PK_TAIL - x - D[1]};
+  int idx = PK_TAIL - x;         // step at which the key this lane holds at a group end left lane PK_LAST: its slot in keys[]
+  unsigned best[2] = {0u, 0u};
+  const unsigned thr[2] = {(unsigned)min(stopScore[0], 255) << 24, (unsigned)min(stopScore[1], 255) << 24};
+  bool hasN = false;
+  int stop[2] = {on[0] ? 0 : 1, on[1] ? 0 : 1};
+
+  for (int t = 0; t < maxsteps; t += PK_G) {
+    if ((t & (PK_TBUF - 1)) == 0) {  // stage the selector words of the next window of target rows
+      int t0 = t;
+      asm volatile("" : "+s"(t0));
+      __builtin_amdgcn_wave_barrier();
+      bool anyN = false;
+      for (int k = lane; k < PK_TBUF; k += 64) {
+        const int w = selector(t0 + k + L0[0], t0 + k + L0[1]);
+        anyN |= has_n(w);
+        tbuf[k] = (uint32_t)w;
+      }
+      const bool nCur = __builtin_amdgcn_ballot_w64(anyN) != 0;
+      hasN = nCur || nPrev;  // rows of the previous window are still in the pipe for 63 steps
+      nPrev = nCur;
+      __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t* w8 = tbuf + (t & (PK_TBUF - 1));
+    int ch[PK_G];
+#pragma unroll
+    for (int u = 0; u < PK_G; ++u) ch[u] = (int)w8[u];
+    if (hasN) {
+#pragma unroll
+      for (int u = 0; u < PK_G; ++u) swp_step<C, true, false>(S, K, ch[u]);
+    } else if (K.same_oe) {
+#pragma unroll
+      for (int u = 0; u < PK_G; ++u) swp_step<C, false, true>(S, K, ch[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < PK_G; ++u) swp_step<C, false, false>(S, K, ch[u]);
+    }
+    // the rows that have just left the pipe: SWUtil.scala:532-538 per tail lane
+    if (booker) keys[idx] = (uint32_t)S.keyout;
+    idx += PK_G;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const unsigned k16 = g ? (unsigned)S.keyout >> 16 : (unsigned)S.keyout & 0xffffu;
+      const unsigned cand = ((k16 & 0xff00u) << 16) | ((unsigned)(0xffff - row[g]) << 8) | (k16 & 0xffu);
+      // a lane's best is frozen once it holds a row that reached the stop score (0: nothing held yet)
+      if (booker && row[g] >= 0 && row[g] < J.tLen[g] && (best[g] == 0u || best[g] < thr[g])) best[g] = max(best[g], cand);
+      row[g] += PK_G;
+      if (!stop[g] && (__builtin_amdgcn_ballot_w64(best[g] != 0u && best[g] >= thr[g]) != 0 || t + PK_G >= nsteps[g])) stop[g] = 1;
+    }
+    if (stop[0] & stop[1]) break;
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    // the first row that reached the stop score, if any; else the best row (SWUtil.scala:532-538)
+    const bool frozen = best[g] != 0u && best[g] >= thr[g];
+    const unsigned long long fz = __builtin_amdgcn_ballot_w64(frozen);
+    unsigned pick = fz ? (frozen ? ((best[g] >> 8) & 0xffffu) | 0x10000u : 0u) : 0u;   // (0xffff - row): the earliest row wins
+    int src;
+    if (fz) {
+      const int top = wave_max((int)pick);
+      src = __builtin_ctzll(__builtin_amdgcn_ballot_w64((int)pick == top));
+    } else {
+      const int hi = wave_max((int)(best[g] >> 1));   // unsigned order, without the lowest bit
+      const unsigned long long c1 = __builtin_amdgcn_ballot_w64((int)(best[g] >> 1) == hi);
+      // rows differ between lanes, so at most the lowest bit (of the column) cannot decide; candidates are the same row -> same lane
+      src = __builtin_ctzll(c1);
+    }
+    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)best[g], src);
+    const bool any = on[g] && J.tLen[g] > 0;
+    const int m = (int)(b >> 24);
+    res[g].max = any ? m : MINUS_INF;
+    res[g].max_i = any ? 0xffff - (int)((b >> 8) & 0xffffu) : -1;
+    res[g].max_j = (any && m) ? 255 - (int)(b & 0xffu) : -1;
+    res[g].n_rows = any ? (fz ? res[g].max_i + 1 : J.tLen[g]) : 0;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void swp_kernel(const SwJobsDev jobs, const SwScoring sc, const int bias,
+                                                                     int32_t* __restrict__ out,
+                                                                     uint32_t* __restrict__ scratch,
+                                                                     const int scratch_per_job,
+                                                                     const SwPrepass* __restrict__ pre) {
+  __shared__ uint32_t tbuf_all[WAVES_PER_BLOCK][PK_TBUF + PK_G];
+  if (pre && (pre->error != 0 || pre->max_qlen > (PK_LAST + 1) * C || ((pre->max_tlen + 63) & ~63) > scratch_per_job)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int slot = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
+  uint32_t* tbuf = tbuf_all[wave];
+  uint32_t* keys = scratch + (size_t)slot * 4 * (size_t)scratch_per_job;  // packed row keys, one word per step: <= max_tlen + 70 words
+  const int maxScore = 255 - abs(sc.b);  // SWUtil.scala:423
+  const int xtra = sc.xtra;
+  const int stride = gridDim.x * WAVES_PER_BLOCK;
+  const int minScore = (xtra & BPSW_KSW_XSUBO) ? (xtra & 0xffff) : 0x10000;  // SWUtil.scala:434-437
+  const int endScore0 = (xtra & BPSW_KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
+  const int nduo = (jobs.n + 1) >> 1;
+
+  for (int duo = slot; duo < nduo; duo += stride) {
+    Duo J;
+    int job[2], on[2], qCols[2], zero2[2] = {0, 0}, stop1[2], D[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      job[g] = 2 * duo + g;
+      on[g] = job[g] < jobs.n ? 1 : 0;
+      const int jj = on[g] ? job[g] : 0;
+      J.qLenRaw[g] = uni(jobs.q_len[jj]);
+      J.tLen[g] = uni(jobs.t_len[jj]);
+      J.qrev[g] = uni((int)jobs.q_rev[jj]);
+      J.q[g] = jobs.q_pool + jobs.q_off[jj];
+      const long long toff = jobs.t_off[jj];
+      J.tbytes[g] = jobs.t_pool ? jobs.t_pool + toff : nullptr;
+      J.rb[g] = toff;
+      qCols[g] = J.qLenRaw[g];
+      stop1[g] = min(endScore0, maxScore);  // SWUtil.scala:537
+    }
+    PkRes f[2];
+    swp_pass<C>(lane, J, on, qCols, false, zero2, zero2, jobs.pac, jobs.l_pac, sc, bias, stop1, tbuf, keys, D, f);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the keys written by the tail lanes -> all lanes
+    int score[2], te[2], qe[2], score2[2], te2[2], tb[2], qb[2], on2[2], qCols2[2], stop2[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      score[g] = f[g].max >= maxScore ? 255 : f[g].max;  // SWUtil.scala:544
+      te[g] = f[g].max_i;
+      qe[g] = -1; score2[g] = -1; te2[g] = -1; tb[g] = -1; qb[g] = -1;
+      if (on[g] && score[g] != 255) {  // SWUtil.scala:549-567
+        qe[g] = f[g].max_j;
+        const int tmp = (score[g] + sc.a - 1) / sc.a;
+        second_best(lane, keys, 16 * g, D[g], f[g].n_rows, minScore, te[g] - tmp, te[g] + tmp, score2[g], te2[g]);
+      }
+      // SWUtil.scala:586-598
+      const bool want_start = (xtra & BPSW_KSW_XSTART) && !((xtra & BPSW_KSW_XSUBO) && score[g] < (xtra & 0xffff));
+      on2[g] = (on[g] && want_start && qe[g] >= 0 && te[g] >= 0) ? 1 : 0;
+      qCols2[g] = on2[g] ? qe[g] + 1 : 0;
+      stop2[g] = min(score[g] & 0xffff, maxScore);
+    }
+    if (on2[0] | on2[1]) {
+      PkRes r[2];
+      __builtin_amdgcn_wave_barrier();
+      swp_pass<C>(lane, J, on2, qCols2, true, qe, te, jobs.pac, jobs.l_pac, sc, bias, stop2, tbuf, keys, D, r);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (on2[g]) {
+          const int rscore = r[g].max >= maxScore ? 255 : r[g].max;
+          if (score[g] == rscore) { tb[g] = te[g] - r[g].max_i; qb[g] = qe[g] - r[g].max_j; }
+        }
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (on[g]) {
+          int32_t* o = out + 7 * (size_t)job[g];
+          o[0] = score[g]; o[1] = te[g]; o[2] = qe[g]; o[3] = score2[g]; o[4] = te2[g]; o[5] = tb[g]; o[6] = qb[g];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // validates the job table and finds the longest mate / window
 __global__ void sw_prepass_kernel(const SwJobsDev jobs, const unsigned long long q_pool_bytes,
                                   const unsigned long long t_pool_bytes, SwPrepass* __restrict__ pre) {
@@ -527,6 +885,13 @@ __global__ void ref_fetch_kernel(const uint8_t* __restrict__ pac, const long lon
 }
 
 template <int C>
+hipError_t launch_pk(const SwJobsDev& jobs, const SwScoring& sc, int bias, int32_t* d_out, uint32_t* d_scratch, int per_job,
+                     int blocks, hipStream_t s, const SwPrepass* pre) {
+  hipLaunchKernelGGL(swp_kernel<C>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, bias, d_out, d_scratch, per_job, pre);
+  return hipGetLastError();
+}
+
+template <int C>
 hipError_t launch_c(const SwJobsDev& jobs, const SwScoring& sc, int32_t* d_out, uint32_t* d_scratch, int per_wave,
                     int blocks, hipStream_t s, const SwPrepass* pre) {
   hipLaunchKernelGGL(sw_kernel<C>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_wave, pre);
@@ -567,6 +932,25 @@ static bool sw_quad_for(int n_jobs, int num_cu) {
   if (m > 0) return true;
   return (long long)n_jobs >= 24ll * 4 * num_cu * 4 / 4 * 1;  // >= 6 waves x 4 jobs per SIMD (4 SIMDs per CU)
 }
+// BPSW_SW_PACK=0 turns the two-jobs-per-wave packed kernel off.  It needs what makes 16-bit halves exact (see swp_pass):
+// every H that is consumed <= 255, i.e. max(mat) <= |b| + 1; biased scores in a byte; gap penalties >= 0.  Returns the bias
+// or -1.
+static int sw_pack_bias(const SwScoring& sc) {
+  static const int off = getenv("BPSW_SW_PACK") ? atoi(getenv("BPSW_SW_PACK")) == 0 : 0;
+  if (off) return -1;
+  int lo = 0, hi = 0;
+  for (int r = 0; r < 5; ++r)
+    for (int c = 0; c < 5; ++c) {
+      const int v = (int)(int8_t)(sc.mat.row[r] >> (8 * c));
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
+    }
+  const int bias = -lo;
+  if (hi > abs(sc.b) + 1 || hi + bias > 254 || abs(sc.b) > 254 || sc.a < 1) return -1;
+  if (sc.e_del < 0 || sc.e_ins < 0 || sc.o_del < 0 || sc.o_ins < 0) return -1;
+  return bias;
+}
+bool sw_pack_enabled(const SwScoring& sc) { return sw_pack_bias(sc) >= 0; }
 int sw_resident_waves(int num_cu) { return num_cu * 8 * WAVES_PER_BLOCK; }
 
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
@@ -582,8 +966,19 @@ hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_
     hipLaunchKernelGGL(sw4_kernel, dim3(qblocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_job, d_pre_check);
     return hipGetLastError();
   }
-  const int per_wave = per_job;  // one job per wave: the first quarter of the wave's scratch
   const int c = (max_qlen + 63) / 64;
+  const int bias = sw_pack_bias(sc);
+  if (bias >= 0 && max_qlen <= 256 && max_tlen < 65536 && jobs.n > 1) {  // two jobs per wavefront, packed 16-bit
+    int pblocks = ((jobs.n + 1) / 2 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (pblocks > max_blocks) pblocks = max_blocks;
+    const int pc = (max_qlen + PK_LAST) / (PK_LAST + 1);  // columns per lane over the 64 - PK_TAIL lanes that hold the query
+    if (pc <= 1) return launch_pk<1>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
+    if (pc == 2) return launch_pk<2>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
+    if (pc == 3) return launch_pk<3>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
+    if (pc == 4) return launch_pk<4>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
+    return launch_pk<5>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
+  }
+  const int per_wave = per_job;  // one job per wave: the first quarter of the wave's scratch
   if (c <= 1) return launch_c<1>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
   if (c == 2) return launch_c<2>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
   if (c == 3) return launch_c<3>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);

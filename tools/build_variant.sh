@@ -6,7 +6,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../cloud-scale-bwamem_amd"
 mkdir -p build_$name lib_exp
-for f in csrc/*.hip csrc/bpsw_runtime.cpp csrc/bpsw_sw_runtime.cpp csrc/bpsw_pack.cpp csrc/bpsw_rescue.cpp csrc/bpsw_jni.cpp csrc/bpsw_finish.cpp; do
+for f in csrc/*.hip csrc/*.cpp; do
   [ -f "$f" ] || continue
   o=build_$name/$(basename ${f%.*}).o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../include -Icsrc -Wno-unused-function "$@" -c $f -o $o &
