@@ -918,8 +918,8 @@ void launch_ref_fetch(const uint8_t* d_pac, long long l_pac, int n, const long l
 
 // one uint32 list entry per target row and job: four jobs per resident wave in the quad-job kernel
 size_t sw_scratch_bytes_per_wave(int max_tlen) { return 16 * (((size_t)max_tlen + 63) & ~(size_t)63); }
-// BPSW_SW_QUAD: 0 never, 1 always (mates <= 160 bases), unset: for batches large enough to keep >= 6 four-job waves on
-// every SIMD.  Measured on MI355X (tools/sw_kernel_time.py): 57 664 jobs 16.6 vs 13.6 M jobs/s, 28 832 jobs 14.6 vs 13.6,
+// The quad-job kernel serves scorings the packed kernel cannot take (sw_pack_bias).  BPSW_SW_QUAD: 0 never, 1 always (mates
+// <= 160 bases), unset: for batches large enough to keep >= 6 four-job waves on every SIMD.  Measured on MI355X (tools/sw_kernel_time.py): 57 664 jobs 16.6 vs 13.6 M jobs/s, 28 832 jobs 14.6 vs 13.6,
 // 7 208 jobs (the bench step) 10.0 vs 11.5 -- with four times fewer, longer waves a small batch leaves the chip half empty.
 static int sw_quad_mode() {
   static const int m = getenv("BPSW_SW_QUAD") ? atoi(getenv("BPSW_SW_QUAD")) : -1;
@@ -960,12 +960,6 @@ hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_
   const int max_blocks = num_cu * 8;
   if (blocks > max_blocks) blocks = max_blocks;
   const int per_job = (int)(sw_scratch_bytes_per_wave(max_tlen) / 16);
-  if (max_qlen <= 16 * Q4C && sw_quad_for(jobs.n, num_cu)) {  // four jobs per wavefront
-    int qblocks = (jobs.n + 4 * WAVES_PER_BLOCK - 1) / (4 * WAVES_PER_BLOCK);
-    if (qblocks > max_blocks) qblocks = max_blocks;
-    hipLaunchKernelGGL(sw4_kernel, dim3(qblocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_job, d_pre_check);
-    return hipGetLastError();
-  }
   const int c = (max_qlen + 63) / 64;
   const int bias = sw_pack_bias(sc);
   if (bias >= 0 && max_qlen <= 256 && max_tlen < 65536 && jobs.n > 1) {  // two jobs per wavefront, packed 16-bit
@@ -977,6 +971,12 @@ hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_
     if (pc == 3) return launch_pk<3>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
     if (pc == 4) return launch_pk<4>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
     return launch_pk<5>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
+  }
+  if (max_qlen <= 16 * Q4C && sw_quad_for(jobs.n, num_cu)) {  // four jobs per wavefront
+    int qblocks = (jobs.n + 4 * WAVES_PER_BLOCK - 1) / (4 * WAVES_PER_BLOCK);
+    if (qblocks > max_blocks) qblocks = max_blocks;
+    hipLaunchKernelGGL(sw4_kernel, dim3(qblocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_job, d_pre_check);
+    return hipGetLastError();
   }
   const int per_wave = per_job;  // one job per wave: the first quarter of the wave's scratch
   if (c <= 1) return launch_c<1>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
