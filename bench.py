@@ -166,7 +166,15 @@ def main():
     # One context per extension batch of the step plus one for the rescue jobs, all on this rank's GPU: each context
     # owns a stream, so the independent batches of a step overlap on the device the way concurrent Spark task
     # threads of one executor overlap their JNI calls (the reference native code is re-entrant for that reason).
-    ctxs = [bpsw_hip.Context(local_rank) for _ in range(EXT_BATCHES_PER_STEP + 1)]  # no fallback: raises without a gfx950 device
+    # BENCH_STEPS_IN_FLIGHT=n (default 1) rotates n such sets over the steps: the entries are asynchronous, so the host can
+    # submit step k+1 while the device still works on step k; a set is reused only after its previous step has been waited
+    # for, and the timed region ends with every step complete.  Measured on MI355X: 1.451 / 1.430 / 1.420 ms per step for
+    # n = 1 / 2 / 3 -- the device is already busy throughout a step, so the default stays 1 and the per-launch durations
+    # the roofline entry uses are not stretched by overlap between steps.
+    STEPS_IN_FLIGHT = max(1, int(os.environ.get("BENCH_STEPS_IN_FLIGHT", "1")))
+    sets = [[bpsw_hip.Context(local_rank) for _ in range(EXT_BATCHES_PER_STEP + 1)]  # no fallback: raises without a gfx950 device
+            for _ in range(STEPS_IN_FLIGHT)]
+    ctxs = sets[0]
     ctx = ctxs[-1]
     opt = bpsw_hip.default_opt()
     xtra = bpsw_hip.KSW_XSUBO | bpsw_hip.KSW_XSTART | bpsw_hip.KSW_XBYTE | 19   # MemSamPe.scala:1187-1189
@@ -174,10 +182,12 @@ def main():
     soas, wires, ntasks, jobs = build_inputs(rank)
     # ---- make everything resident in HBM before the timed region ---------------------------------
     d_wires = [torch.from_numpy(w).to(dev) for w in wires]
-    d_outs = [torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks]
+    d_outs_all = [[torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks] for _ in sets]
+    d_outs = d_outs_all[0]
     d_jobs = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in jobs.items()}
     n_jobs = int(jobs["q_len"].shape[0])
-    d_sw_out = torch.zeros((n_jobs, 7), dtype=torch.int32, device=dev)
+    d_sw_out_all = [torch.zeros((n_jobs, 7), dtype=torch.int32, device=dev) for _ in sets]
+    d_sw_out = d_sw_out_all[0]
     sj = bpsw_hip.SwJobs()
     sj.n, sj.xtra = n_jobs, xtra
     for k in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool"):
@@ -186,33 +196,39 @@ def main():
     torch.cuda.synchronize(dev)
 
     ext_ms_sum, sw_ms_sum, ext_launches, sw_launches = 0.0, 0.0, 0, 0
+    busy = [False] * len(sets)      # set has a submitted step that has not been waited for
+    counted = [False] * len(sets)   # ... and that step belongs to the timed region
+    turn = 0
 
-    pool = None
-    if os.environ.get("BENCH_THREADS"):
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(EXT_BATCHES_PER_STEP + 1)
-
-    def step(timed: bool):
+    def collect(k: int):
+        """wait for the step submitted on set k; HIP events on the launch streams, recorded inside the library"""
         nonlocal ext_ms_sum, sw_ms_sum, ext_launches, sw_launches
-        if pool is not None:
-            futs = [pool.submit(cx.extend_batch_device, dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)
-                    for cx, w, n, dw, do in zip(ctxs, wires, ntasks, d_wires, d_outs)]
-            futs.append(pool.submit(ctx.swalign2_batch_device, opt, sj, d_sw_out.data_ptr(), 0))
-            for f in futs:
-                f.result()
-        else:
-            for cx, w, n, dw, do in zip(ctxs, wires, ntasks, d_wires, d_outs):
-                cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)   # asynchronous, context's own stream
-            ctx.swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
-        for cx in ctxs[:-1]:
-            e, _ = cx.last_kernel_ms()      # HIP events on the launch stream, recorded inside the library; waits for the batch
-            if timed:
+        if not busy[k]:
+            return
+        for cx in sets[k][:-1]:
+            e, _ = cx.last_kernel_ms()
+            if counted[k]:
                 ext_ms_sum += e
                 ext_launches += 1
-        _, s = ctx.last_kernel_ms()
-        if timed:
-            sw_ms_sum += s
+        _, s_ms = sets[k][-1].last_kernel_ms()
+        if counted[k]:
+            sw_ms_sum += s_ms
             sw_launches += 1
+        busy[k] = False
+
+    def step(timed: bool):
+        nonlocal turn
+        k = turn % len(sets)
+        turn += 1
+        collect(k)                  # the step this set ran STEPS_IN_FLIGHT steps ago
+        for cx, w, n, dw, do in zip(sets[k], wires, ntasks, d_wires, d_outs_all[k]):
+            cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)   # asynchronous, context's own stream
+        sets[k][-1].swalign2_batch_device(opt, sj, d_sw_out_all[k].data_ptr(), 0)
+        busy[k], counted[k] = True, timed
+
+    def drain():
+        for k in range(len(sets)):
+            collect(k)
 
     def barrier():
         if distributed:
@@ -221,10 +237,12 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    drain()                         # every one of the K steps complete, results in HBM
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -287,7 +305,8 @@ def main():
         "config": {"workload": "configs[2]: pair-end 2x150bp synthetic reads (1% sub, 0.1% indel), batched seed "
                                "extension + batched pair-end SW rescue (10% of pairs), 1 MI355X per rank",
                    "pairs_per_step_per_gpu": PAIRS_PER_STEP, "ext_tasks_per_step": int(sum(ntasks)),
-                   "rescue_jobs_per_step": n_jobs, "parallelism": f"partition->device x{world} (no collective)"},
+                   "rescue_jobs_per_step": n_jobs, "steps_in_flight": STEPS_IN_FLIGHT,
+                   "parallelism": f"partition->device x{world} (no collective)"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},

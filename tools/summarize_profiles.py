@@ -14,7 +14,7 @@ P = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    for k, v in (("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
+    for k, v in (("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("swp_kernel", "swalign2"), ("sw4_kernel", "swalign2"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
                  ("reg2aln", "reg2aln"), ("chain2aln", "chain2aln"), ("ext_qt", "extend_qt"), ("global_kernel", "global")):
         if k in name:
             return v
