@@ -166,11 +166,13 @@ struct Group {
   std::vector<int32_t> results;             // 7 ints per launched job
   std::vector<uint8_t> used;                // per job: consumed by the replay
   const int64_t* ref_len;                   // per window x: g->ref_len, or derived from (rb, re) in coordinate mode
+  std::vector<Reg> anchors[2];              // scratch of replay_pair, kept across pairs (no allocation per pair)
 };
 
-void skip_flags(const Group& G, const Reg& a, const std::vector<Reg>& mates, int skip[4]) {
+void skip_flags(const Group& G, const Reg& a, const Reg* mates, size_t n_mates, int skip[4]) {
   for (int r = 0; r < 4; ++r) skip[r] = G.g->pes[r].failed ? 1 : 0;
-  for (const Reg& m : mates) {
+  for (size_t mi = 0; mi < n_mates; ++mi) {
+    const Reg& m = mates[mi];
     int64_t dist;
     const int r = infer_dir(G.g->l_pac, a.rb, m.rb, &dist);
     if (G.mode == BPSW_RESCUE_SCALA) dist = (int64_t)(int32_t)dist;  // MemSamPe.scala:1137-1138 narrows to Int
@@ -204,7 +206,7 @@ bool make_region(const Group& G, const int32_t aln[7], int r, int l_ms, int64_t 
 // One anchor against the mate list.  Returns false when a needed SW result is missing (x appended to `missing`).
 bool precompute(Group& G, const Reg& a, int l_ms, std::vector<Reg>& ma, int64_t xrow, std::vector<int64_t>& missing) {
   int skip[4];
-  skip_flags(G, a, ma, skip);
+  skip_flags(G, a, ma.data(), ma.size(), skip);
   if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return true;
   int n = 0;
   if (G.mode == BPSW_RESCUE_C) {
@@ -264,10 +266,11 @@ bool precompute(Group& G, const Reg& a, int l_ms, std::vector<Reg>& ma, int64_t 
 // Replays pair k from its initial state.  Returns false (and fills `missing`) if a result is not available yet.
 bool replay_pair(Group& G, int k, std::vector<Reg> v[2], std::vector<int64_t>& missing) {
   const bpsw_rescue_group_t* g = G.g;
-  std::vector<Reg> tmp[2];
+  std::vector<Reg>* tmp = G.anchors;
   for (int i = 0; i < 2; ++i) {
     const Reg* first = g->regs + G.reg_base[(size_t)(2 * k + i)];
     v[i].assign(first, first + g->reg_cnt[2 * k + i]);
+    tmp[i].clear();
     for (const Reg& r : v[i])  // anchors: filtered copy taken before any rescue (native/bwamem_pair.c:126-131)
       if (r.score >= v[i][0].score - G.opt->pen_unpaired) tmp[i].push_back(r);
   }
@@ -340,25 +343,26 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
 
   const bool rescue_on = (opt->flag & 0x20) == 0;  // MEM_F_NO_RESCUE, native/bwamem.h:18
   std::vector<int64_t> want;  // windows whose SW result the next GPU round computes
+  // pairs with at least one window to align; the lists of the others come out exactly as they went in (every anchor of
+  // theirs is skipped or has no usable window, and only an SW result can change a list)
+  std::vector<uint8_t> touched((size_t)G_, 0);
   if (rescue_on) {
     // ---- 1. speculate against the initial lists --------------------------------------------
-    std::vector<Reg> init[2];
     for (int k = 0; k < G_; ++k) {
-      for (int i = 0; i < 2; ++i) {
-        const Reg* first = g->regs + S.reg_base[(size_t)(2 * k + i)];
-        init[i].assign(first, first + g->reg_cnt[2 * k + i]);
-      }
+      const Reg* init[2] = {g->regs + S.reg_base[(size_t)(2 * k)], g->regs + S.reg_base[(size_t)(2 * k + 1)]};
+      const int n_init[2] = {g->reg_cnt[2 * k], g->reg_cnt[2 * k + 1]};
       for (int i = 0; i < 2; ++i) {
         if (g->seq_len[2 * k + !i] < 1) continue;
         int j = 0;
-        for (const Reg& a : init[i]) {
+        for (int ai = 0; ai < n_init[i]; ++ai) {
+          const Reg& a = init[i][ai];
           if (!(a.score >= init[i][0].score - opt->pen_unpaired)) continue;
           if (j >= opt->max_matesw || j >= g->ref_cnt[2 * k + i]) break;
           int skip[4];
-          skip_flags(S, a, init[!i], skip);
+          skip_flags(S, a, init[!i], (size_t)n_init[!i], skip);
           const int64_t xrow = S.ref_base[(size_t)(2 * k + i)] + j;
           for (int r = 0; r < 4; ++r)
-            if (!skip[r] && window_ok(S, xrow * 4 + r)) want.push_back(xrow * 4 + r);
+            if (!skip[r] && window_ok(S, xrow * 4 + r)) { want.push_back(xrow * 4 + r); touched[(size_t)k] = 1; }
           ++j;
         }
       }
@@ -370,8 +374,12 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
     for (int64_t j = 0; j < g->ref_cnt[e]; ++j) end_of_row[(size_t)(S.ref_base[(size_t)e] + j)] = e;
 
   const int xtra_base = BPSW_KSW_XSUBO | BPSW_KSW_XSTART | (opt->min_seed_len * opt->a);
-  std::vector<std::vector<Reg>> final_regs(2 * (size_t)G_);
+  // final lists, in the order the pairs complete: one arena, (offset, count) per end
+  std::vector<Reg> arena;
+  std::vector<int64_t> fin_off(2 * (size_t)G_, -1);  // -1: the input list, untouched
+  std::vector<int32_t> fin_cnt(2 * (size_t)G_, 0);
   std::vector<uint8_t> done((size_t)G_, 0);
+  std::vector<Reg> v[2];
   uint64_t rounds = 0, speculated = want.size();
   for (;;) {
     // ---- 2. one flat GPU batch ----------------------------------------------------------------
@@ -420,18 +428,21 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
     bool all_done = true;
     for (int k = 0; k < G_; ++k) {
       if (done[(size_t)k]) continue;
-      std::vector<Reg> v[2];
-      if (!rescue_on) {
-        for (int i = 0; i < 2; ++i) {
-          const Reg* first = g->regs + S.reg_base[(size_t)(2 * k + i)];
-          v[i].assign(first, first + g->reg_cnt[2 * k + i]);
-        }
-      } else if (!replay_pair(S, k, v, want)) {
+      if (!rescue_on || !touched[(size_t)k]) {
+        fin_cnt[(size_t)(2 * k)] = g->reg_cnt[2 * k];
+        fin_cnt[(size_t)(2 * k + 1)] = g->reg_cnt[2 * k + 1];
+        done[(size_t)k] = 1;
+        continue;
+      }
+      if (!replay_pair(S, k, v, want)) {
         all_done = false;
         continue;
       }
-      final_regs[(size_t)(2 * k)].swap(v[0]);
-      final_regs[(size_t)(2 * k + 1)].swap(v[1]);
+      for (int i = 0; i < 2; ++i) {
+        fin_off[(size_t)(2 * k + i)] = (int64_t)arena.size();
+        fin_cnt[(size_t)(2 * k + i)] = (int32_t)v[i].size();
+        arena.insert(arena.end(), v[i].begin(), v[i].end());
+      }
       done[(size_t)k] = 1;
     }
     if (all_done) break;
@@ -444,13 +455,16 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
 
   int64_t total = 0;
   for (int e = 0; e < 2 * G_; ++e) {
-    out_cnt[e] = (int32_t)final_regs[(size_t)e].size();
+    out_cnt[e] = fin_cnt[(size_t)e];
     total += out_cnt[e];
   }
   *out_total = total;
   if (total > out_cap || (total > 0 && !out_regs)) return fail(BPSW_ERR_CAPACITY, "matesw_group: out_regs too small");
   int64_t at = 0;
-  for (int e = 0; e < 2 * G_; ++e)
-    for (const Reg& r : final_regs[(size_t)e]) out_regs[at++] = r;
+  for (int e = 0; e < 2 * G_; ++e) {
+    const Reg* src = fin_off[(size_t)e] < 0 ? g->regs + S.reg_base[(size_t)e] : arena.data() + fin_off[(size_t)e];
+    if (fin_cnt[(size_t)e]) memcpy(out_regs + at, src, sizeof(Reg) * (size_t)fin_cnt[(size_t)e]);
+    at += fin_cnt[(size_t)e];
+  }
   return BPSW_OK;
 }
