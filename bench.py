@@ -297,6 +297,23 @@ def main():
         except Exception:
             traffic = None
 
+    # What actually binds these kernels: instruction issue.  Wave-instructions per step from the committed
+    # PMC pass, over the live step time, against the measured issue rates of one SIMD (tools/ubench/valu_rate.hip).
+    issue = None
+    try:
+        pi = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        per_step = EXT_BATCHES_PER_STEP * (pi["extend"]["valu"] + pi["extend"]["salu"] + pi["ext_prepass"]["valu"] + pi["ext_prepass"]["salu"]) \
+            + pi["swalign2"]["valu"] + pi["swalign2"]["salu"] + pi["sw_prepass"]["valu"] + pi["sw_prepass"]["salu"]
+        ns = 1e9 * (elapsed / args.steps) / (per_step / (4.0 * n_cu))
+        issue = {"wave_insts_per_step": int(per_step), "simds": 4 * n_cu, "ns_per_inst_per_simd": round(ns, 3),
+                 "measured_issue_ns": {"one_kind_stream": 1.8, "mixed_valu_salu_streams": 1.15},
+                 "frac_of_mixed_issue_rate": round(1.15 / ns, 3),
+                 "note": "instruction counts: profiles/pmc_issue.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, same command); "
+                         "issue rates: profiles/r01g_valu_rate.txt, profiles/r01_microbench_issue.txt"}
+    except Exception:
+        issue = None
+
     out = {
         "metric": "pair-end 2x150bp reads aligned/sec",
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -310,6 +327,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
+        "issue": issue,
         "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes)},
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes)}},
         "breakdown": {"extend_only_reads_per_s": round(2 * PAIRS_PER_STEP / t_ext_only, 1), "extend_only_ms_per_step": round(1e3 * t_ext_only, 3),

@@ -359,7 +359,7 @@ void put_contig(std::string& s, const BnsView& bns, int rid) {
 
 // memAlnToSAM, R2S:328-560 (C: native/bwamem.c:726-838; the Scala leaves the comment field out, R2S:546-556)
 void aln_to_sam(const BnsView& bns, int flavour, std::string& s, const char* name, size_t name_len, int l_seq, const uint8_t* seq,
-                const uint8_t* qual, const std::vector<Aln>& list, int which, const Aln* mate_in) {
+                const uint8_t* qual, const Aln* list, const size_t n_list, int which, const Aln* mate_in) {
   Aln p = list[(size_t)which];
   Aln m;
   const bool has_m = mate_in != nullptr;
@@ -410,15 +410,21 @@ void aln_to_sam(const BnsView& bns, int flavour, std::string& s, const char* nam
     if (!p.a.is_rev) {
       if (which && clip_first) qb += (int)((*p.cigar)[0] >> 4);
       if (which && clip_last) qe -= (int)((*p.cigar)[(size_t)nc - 1] >> 4);
-      for (int i = qb; i < qe; ++i) s.push_back("ACGTN"[seq[i] > 4 ? 4 : seq[i]]);
-      s.push_back('\t');
-      if (qual) s.append((const char*)qual + qb, (size_t)std::max(0, qe - qb)); else s.push_back('*');
+      const size_t n = (size_t)std::max(0, qe - qb), at = s.size();
+      s.resize(at + n + 1 + (qual ? n : 1));  // bases, tab, qualities: written in place
+      char* d = &s[at];
+      for (size_t i = 0; i < n; ++i) d[i] = "ACGTN"[seq[(size_t)qb + i] > 4 ? 4 : seq[(size_t)qb + i]];
+      d[n] = '\t';
+      if (qual) memcpy(d + n + 1, qual + qb, n); else d[n + 1] = '*';
     } else {
       if (which && clip_first) qe -= (int)((*p.cigar)[0] >> 4);
       if (which && clip_last) qb += (int)((*p.cigar)[(size_t)nc - 1] >> 4);
-      for (int i = qe - 1; i >= qb; --i) s.push_back("TGCAN"[seq[i] > 4 ? 4 : seq[i]]);
-      s.push_back('\t');
-      if (qual) for (int i = qe - 1; i >= qb; --i) s.push_back((char)qual[i]); else s.push_back('*');
+      const size_t n = (size_t)std::max(0, qe - qb), at = s.size();
+      s.resize(at + n + 1 + (qual ? n : 1));
+      char* d = &s[at];
+      for (size_t i = 0; i < n; ++i) d[i] = "TGCAN"[seq[(size_t)qe - 1 - i] > 4 ? 4 : seq[(size_t)qe - 1 - i]];
+      d[n] = '\t';
+      if (qual) for (size_t i = 0; i < n; ++i) d[n + 1 + i] = (char)qual[(size_t)qe - 1 - i]; else d[n + 1] = '*';
     }
   }
   if (p.a.n_cigar > 0) {
@@ -429,10 +435,10 @@ void aln_to_sam(const BnsView& bns, int flavour, std::string& s, const char* nam
   if (p.a.sub >= 0) { s += "\tXS:i:"; put_num(s, p.a.sub); }
   if (!(p.a.flag & 0x100)) {
     bool others = false;
-    for (size_t i = 0; i < list.size(); ++i) if ((int)i != which && !(list[i].a.flag & 0x100)) { others = true; break; }
+    for (size_t i = 0; i < n_list; ++i) if ((int)i != which && !(list[i].a.flag & 0x100)) { others = true; break; }
     if (others) {
       s += "\tSA:Z:";
-      for (size_t i = 0; i < list.size(); ++i) {
+      for (size_t i = 0; i < n_list; ++i) {
         const Aln& r = list[i];
         if ((int)i == which || (r.a.flag & 0x100)) continue;
         put_contig(s, bns, r.a.rid); s.push_back(',');
@@ -680,8 +686,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
       }
       for (int i = 0; i < 2; ++i) {
         out_off[2 * k + i] = (int64_t)text.size();
-        std::vector<Aln> one(1, h[i]);
-        aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], one, 0, &h[1 - i]);
+        aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], &h[i], 1, 0, &h[1 - i]);
       }
       continue;
     }
@@ -713,10 +718,10 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
         Aln u = make_aln(o, t, nullptr, nullptr);
         u.a.flag |= xf;
         aa.push_back(u);
-        aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa, 0, &h[1 - i]);
+        aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa.data(), aa.size(), 0, &h[1 - i]);
       } else {
         for (size_t x = 0; x < aa.size(); ++x)
-          aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa, (int)x, &h[1 - i]);
+          aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa.data(), aa.size(), (int)x, &h[1 - i]);
       }
     }
   }

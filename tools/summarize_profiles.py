@@ -51,3 +51,12 @@ traffic["note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from
                    f"(profiles/{tag}_pmc_counters.csv); the x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md")
 json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 print(traffic)
+
+issue = {}
+for k in ("extend", "swalign2", "ext_prepass", "sw_prepass"):
+    if "SQ_INSTS_VALU" in per[k] and "SQ_INSTS_SALU" in per[k]:
+        issue[k] = {"valu": int(sum(per[k]["SQ_INSTS_VALU"]) / len(per[k]["SQ_INSTS_VALU"])),
+                    "salu": int(sum(per[k]["SQ_INSTS_SALU"]) / len(per[k]["SQ_INSTS_SALU"]))}
+issue["note"] = f"wave-instructions per launch (SQ_INSTS_VALU, SQ_INSTS_SALU) from profiles/{tag}_pmc_counters.csv"
+json.dump(issue, open(os.path.join(P, "pmc_issue.json"), "w"), indent=1)
+print(issue)
