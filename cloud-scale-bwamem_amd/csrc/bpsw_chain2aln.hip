@@ -221,7 +221,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void chain2aln_kernel(const C
               aw[side] = w0 << i;
               const int w = min(min(aw[side], maxIns), maxDel);
               const int tl = min(rLen, qLen + w + 2);
-              x = sw_extend_reg_any(lane, qLen, tl, qsrc, ts, P.mat, oDel, eDel, oIns, eIns, w, P.zdrop, P.zmode, hInit, P.tail_bound ? P.mat_max : 0);
+              int oInsT = oIns, eInsT = eIns;  // opaque: keeps the per-lane column constants of every slot count out of long-lived VGPRs
+              asm volatile("" : "+s"(oInsT), "+s"(eInsT));
+              x = sw_extend_reg_any(lane, qLen, tl, qsrc, ts, P.mat, oDel, eDel, oInsT, eInsT, w, P.zdrop, P.zmode, hInit, P.tail_bound ? P.mat_max : 0);
               regScore = x.max;
               if (regScore == prev || x.max_off < (aw[side] >> 1) + (aw[side] >> 2)) break;
             }

@@ -134,7 +134,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 5) void ext_kernel(const uint
         aw[side] = wBand << i;
         const int w = min(min(aw[side], maxIns), maxDel);
         if (reg_path) {
-          r = sw_extend_reg_any(lane, qLen, rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
+          // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
+          // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
+          int oInsT = oIns, eInsT = eIns;
+          asm volatile("" : "+s"(oInsT), "+s"(eInsT));
+          r = sw_extend_reg_any(lane, qLen, rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
         } else {
           r = sw_extend_wave(lane, qLen, rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
         }

@@ -392,7 +392,9 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
                                 const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
                                 const int zmode, const int h0, const int amax) {
   const int oeDel = oDel + eDel, oeIns = oIns + eIns;
-  int Hs[2], Es[2], As[2], plo[2], phi[2], jE[2], c2[2];
+  // register budget (the kernel is compiled for five waves per SIMD): the N-row scores of both columns share a register,
+  // and (j-1)*eIns, j*eIns - oeIns of both columns derive from one per-lane value
+  int Hs[2], Es[2], plo[2], phi2 = 0;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int j = 2 * lane + s;
@@ -400,13 +402,12 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     const int sh = 8 * code;
     plo[s] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
                    (((mat.row[3] >> sh) & 0xff) << 24));
-    phi[s] = (int)(int8_t)((mat.row[4] >> sh) & 0xff);
+    phi2 |= (int)((mat.row[4] >> sh) & 0xff) << (8 * s);
     Hs[s] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
     Es[s] = 0;
-    As[s] = NEG;
-    jE[s] = j * eIns - oeIns;
-    c2[s] = (j - 1) * eIns;
   }
+  const int jE0 = 2 * lane * eIns - oeIns;  // j*eIns - oeIns of the even column; the odd one adds eIns
+  const int kC = oeIns - eIns;              // (j-1)*eIns = (j*eIns - oeIns) + kC
   int mx = vu(h0), max_i = vu(-1), max_j = vu(-1), max_ie = vu(-1), gscore = vu(-1), max_off = vu(0);
   int beg = vu(0), end = vu(qLen);
   int h1raw = vu(h0 - oDel);
@@ -435,21 +436,22 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
       rel[s] = (unsigned)(2 * lane + s - beg);
       upd[s] = rel[s] < spanU;
       act[s] = rel[s] < spanA;
-      const int sc = isN ? phi[s] : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
+      const int sc = isN ? __builtin_amdgcn_sbfe(phi2, 8u * s, 8u) : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
       a[s] = act[s] ? max(Hs[s] + sc, Es[s]) : NEG;
-      As[s] = a[s];
-      Pg[s] = a[s] + jE[s];
+      Pg[s] = a[s] + jE0 + s * eIns;
     }
     int Pl = max(Pg[0], Pg[1]);   // the lane's two columns folded
     int scan_a = max(a[0], a[1]);
     dual_scan_max(Pl, scan_a);
     const int Pprev = wave_shr1(NEG, Pl);  // prefix over the columns of the lanes below
-    const int Pex[2] = {Pprev, max(Pprev, Pg[0])};
+    const int Fe = Pprev - kC - jE0;                         // F(i,j) = Pex - (j-1)*eIns for the even column,
+    const int Fo = max(Pprev, Pg[0]) - kC - jE0 - eIns;      // and for the odd one
+    const int Fs[2] = {Fe, Fo};
     int H[2], En[2];
     unsigned long long zm[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      H[s] = max3i(a[s], Pex[s] - c2[s], 0);  // F(i,j) = max(0, Pex - (j-1)*eIns)
+      H[s] = max3i(a[s], Fs[s], 0);
       zm[s] = __builtin_amdgcn_ballot_w64((act[s] ? H[s] : -1) == 0);
       En[s] = act[s] ? max3i(Es[s] - eDel, H[s] - oeDel, 0) : 0;  // E(i+1,j); eh[end].e = 0
     }
@@ -477,7 +479,7 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     if (m == 0) break;  // SWUtil.scala:184-185
 
     // the LAST column whose a == m (SWUtil.scala:158-161)
-    const int le = s_lead_zeros(__builtin_amdgcn_ballot_w64(As[0] == m)), lo = s_lead_zeros(__builtin_amdgcn_ballot_w64(As[1] == m));
+    const int le = s_lead_zeros(__builtin_amdgcn_ballot_w64(a[0] == m)), lo = s_lead_zeros(__builtin_amdgcn_ballot_w64(a[1] == m));
     const int pe = le >= 0 ? 2 * (63 - le) : -1, po = lo >= 0 ? 2 * (63 - lo) + 1 : -1;
     const int mj = max(pe, po);  // scalar
     const bool improved = m > mx;
