@@ -216,6 +216,16 @@ __device__ __forceinline__ int vu(int s) {
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
+// The z-drop test of a row that did not improve the maximum, with k = (i - max_i) - (mj - max_j) and X = max - m >= 0:
+//   A = k > 0,  B = X - k*eDel > zdrop,  C = X + k*eIns > zdrop.
+// Scala parse (SWUtil.scala:194-199): A && (B || C); for k > 0 and eDel, eIns >= 1 (validated) C >= B, so it is A && C.
+// BWA parse (native/ksw.c:455-461): A ? B : C.
+__device__ __forceinline__ bool zdrop_stop(const int k, const int X, const int eDel, const int eIns, const int zdrop, const int zmode) {
+  const int with_gap = zmode == BPSW_ZDROP_SCALA ? X + k * eIns : X - k * eDel;  // k > 0
+  const int other = X + k * eIns;                                                // k <= 0: the BWA parse only
+  return k > 0 ? with_gap > zdrop : (zmode != BPSW_ZDROP_SCALA && other > zdrop);
+}
+
 // QC: query source, qcode(j) = base code (0..4) of column j < qLen
 template <int S, class QC>
 __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, const QC& qcode,
@@ -328,12 +338,7 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
     const int mj = 64 * sm + bm;  // scalar
     const bool improved = m > mx;
     if (!any_lane(improved) && zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
-      const int di = iv - max_i, dj = mj - max_j;
-      const bool A = di > dj;
-      const bool B = mx - m - (di - dj) * eDel > zdrop;
-      const bool C = mx - m - (dj - di) * eIns > zdrop;
-      const bool stop = zmode == BPSW_ZDROP_SCALA ? (A && (B || C)) : (A ? B : C);
-      if (any_lane(stop)) break;
+      if (any_lane(zdrop_stop((iv - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode))) break;
     }
     {  // SWUtil.scala:187-193
       const int d = mj - iv;
@@ -484,12 +489,7 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     const int mj = max(pe, po);  // scalar
     const bool improved = m > mx;
     if (!any_lane(improved) && zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
-      const int di = iv - max_i, dj = mj - max_j;
-      const bool A = di > dj;
-      const bool B = mx - m - (di - dj) * eDel > zdrop;
-      const bool C = mx - m - (dj - di) * eIns > zdrop;
-      const bool stop = zmode == BPSW_ZDROP_SCALA ? (A && (B || C)) : (A ? B : C);
-      if (any_lane(stop)) break;
+      if (any_lane(zdrop_stop((iv - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode))) break;
     }
     {  // SWUtil.scala:187-193
       const int d = mj - iv;
