@@ -214,7 +214,7 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
-                             const ExtPrepass* d_pre_check) {
+                             const ExtPrepass* d_pre_check, bool counter_zeroed) {
   if (n_tasks <= 0) return hipSuccess;
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
@@ -240,8 +240,10 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   int blocks = (n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int max_blocks = num_cu * per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
-  hipError_t me = hipMemsetAsync(d_counter, 0, sizeof(int), s);
-  if (me != hipSuccess) return me;
+  if (!counter_zeroed) {
+    hipError_t me = hipMemsetAsync(d_counter, 0, sizeof(int), s);
+    if (me != hipSuccess) return me;
+  }
   hipLaunchKernelGGL(ext_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
                      rcap, (int)per_wave, d_counter, d_task_list, d_pre_check);
   return hipGetLastError();

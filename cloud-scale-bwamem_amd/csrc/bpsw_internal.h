@@ -52,13 +52,14 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 size_t ext_lds_per_wave(int qcap, int rcap);
 
 // Launch the extension kernel over a validated batch.
-// d_counter: one device int used as the kernel's task queue head (zeroed on the stream before the launch).
+// d_counter: one device int used as the kernel's task queue head (zeroed on the stream before the launch, unless the caller
+// says it already did: counter_zeroed).
 // d_task_list (optional): the n_tasks task indices this launch handles (else tasks 0..n_tasks-1).
 // d_pre_check (optional): device ExtPrepass written earlier on the same stream; the kernel does nothing when it reports an
 // error or lengths beyond (qcap, rcap) -- the asynchronous device entry sizes the launch before anybody has read the scan back.
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
-                             const ExtPrepass* d_pre_check = nullptr);
+                             const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false);
 // Quad-task kernel (bpsw_extend_qt.hip): s_cols = 4 (sides <= 63 bp) or 9 (<= 143 bp).
 hipError_t launch_ext_qt_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, const int* d_list, int n_list,
                                 int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter, hipStream_t s);

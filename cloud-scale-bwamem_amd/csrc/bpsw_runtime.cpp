@@ -421,7 +421,10 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
   ExtPrepass* d_pre = (ExtPrepass*)c->d_pre.ptr;
   ExtPrepass* h_pre = (ExtPrepass*)c->h_pre.ptr;
-  HIP_TRY(hipMemsetAsync(d_pre, 0, sizeof(ExtPrepass), s));
+  // one fill for the scan record (+0), the bin counts (+64) and the kernel's queue head (+128): every small fill is a kernel
+  // of its own on the stream, and the one between the scan and the main launch used to delay the latter
+  static_assert(sizeof(ExtPrepass) <= 64, "scan buffer layout");
+  HIP_TRY(hipMemsetAsync(d_pre, 0, 128 + 16, s));
   launch_ext_prepass((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, d_pre, s);
   HIP_TRY(hipGetLastError());
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
@@ -431,7 +434,7 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
     // bpsw_last_kernel_ms, which is also where a batch that outgrew the geometry is re-launched.
     HIP_TRY(hipEventRecord(c->ev[4], s));
     HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, ASYNC_QCAP, ASYNC_RCAP, c->num_cu,
-                              (int*)((char*)c->d_pre.ptr + 128), nullptr, s, d_pre));
+                              (int*)((char*)c->d_pre.ptr + 128), nullptr, s, d_pre, true));
     HIP_TRY(hipEventRecord(c->ev[5], s));
     HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
     c->have_ext_ev = true;
@@ -446,7 +449,6 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n_tasks + 16));
   }
-  HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
   if (ext_lane_enabled()) lane_sort_enqueue(c, (const uint32_t*)d_wire, n_tasks, s);
   else launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
   HIP_TRY(hipGetLastError());
