@@ -854,9 +854,12 @@ __global__ void sw_prepass_kernel(const SwJobsDev jobs, const unsigned long long
     mq = max(mq, ql);
     mt = max(mt, tl);
   }
-  if (mq) atomicMax(&pre->max_qlen, mq);
-  if (mt) atomicMax(&pre->max_tlen, mt);
-  if (err) atomicMax(&pre->error, err);
+  mq = wave_max(mq); mt = wave_max(mt); err = wave_max(err);  // one atomic per wavefront and word
+  if ((threadIdx.x & 63) == 0) {
+    if (mq) atomicMax(&pre->max_qlen, mq);
+    if (mt) atomicMax(&pre->max_tlen, mt);
+    if (err) atomicMax(&pre->error, err);
+  }
 }
 
 // bnsGetSeq for n windows: swap / clamp / strand rules of util/BNTSeqUtil.scala:37-59, bases by TgSrc::at
