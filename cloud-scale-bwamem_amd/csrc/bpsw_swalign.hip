@@ -960,7 +960,8 @@ hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_
                             uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check) {
   if (jobs.n <= 0) return hipSuccess;
   int blocks = (jobs.n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  const int max_blocks = num_cu * 8;
+  static const double sw_cap = getenv("BPSW_SW_BLOCKS_PER_CU") ? atof(getenv("BPSW_SW_BLOCKS_PER_CU")) : 8.0;
+  const int max_blocks = (int)(num_cu * sw_cap) > 0 ? (int)(num_cu * sw_cap) : 1;
   if (blocks > max_blocks) blocks = max_blocks;
   const int per_job = (int)(sw_scratch_bytes_per_wave(max_tlen) / 16);
   const int c = (max_qlen + 63) / 64;
