@@ -274,7 +274,9 @@ hipError_t launch_chain2aln_kernel(const ChainBatchDev& B, const ChainParams& P,
                                    int32_t* d_srt_scratch, int srt_per_wave, int num_cu, int* d_counter, hipStream_t s) {
   if (B.n_reads <= 0) return hipSuccess;
   int blocks = (B.n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  const int max_blocks = num_cu * 8;
+  static const double cap = getenv("BPSW_C2A_BLOCKS_PER_CU") ? atof(getenv("BPSW_C2A_BLOCKS_PER_CU")) : 8.0;
+  int max_blocks = (int)(num_cu * (cap > 8.0 ? 8.0 : cap));
+  if (max_blocks < 1) max_blocks = 1;
   if (blocks > max_blocks) blocks = max_blocks;
   hipError_t e = hipMemsetAsync(d_counter, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
