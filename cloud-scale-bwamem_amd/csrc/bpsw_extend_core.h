@@ -351,8 +351,13 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
     // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj
     int lzc, fo, lbase = 65, fbase = bm + 2;
     if (S == 1) {
-      lzc = s_lead_zeros(zm[0] & s_below_mask(bm));
-      fo = s_first_one((zm[0] >> bm) >> 1);
+      if (zm[0] == 0ull) {  // no zero in the band at all -- most rows while the score is high
+        lzc = -1;
+        fo = -1;
+      } else {
+        lzc = s_lead_zeros(zm[0] & s_below_mask(bm));
+        fo = s_first_one((zm[0] >> bm) >> 1);
+      }
     } else {
       lzc = -1;
       fo = -1;
@@ -500,16 +505,21 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
       max_off = improved ? off : max_off;
     }
     // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj
-    const int ze_l = s_lead_zeros(zm[0] & s_below_mask((mj + 1) >> 1));  // even columns 2l < mj
-    const int zo_l = s_lead_zeros(zm[1] & s_below_mask(mj >> 1));        // odd columns 2l+1 < mj
-    const int cl = max(ze_l >= 0 ? 2 * (63 - ze_l) : -1, zo_l >= 0 ? 2 * (63 - zo_l) + 1 : -1);
-    const int se = (mj + 2) >> 1, so = (mj + 1) >> 1;                    // first even / odd lane with a column > mj
-    const int fe = s_first_one((zm[0] >> ((mj + 1) >> 1)) >> ((mj + 1) & 1));
-    const int fo = s_first_one(zm[1] >> so);
-    const int cr = min(fe >= 0 ? 2 * (se + fe) : 1 << 20, fo >= 0 ? 2 * (so + fo) + 1 : 1 << 20);
     const int nb0 = beg + (h1 == 0 ? 1 : 0);
-    beg = cl >= 0 ? vu(cl + 2) : nb0;
-    end = cr < (1 << 20) ? vu(cr + 1) : end + 1;
+    if ((zm[0] | zm[1]) == 0ull) {  // no zero in the band at all -- most rows while the score is high
+      beg = nb0;
+      end = end + 1;
+    } else {
+      const int ze_l = s_lead_zeros(zm[0] & s_below_mask((mj + 1) >> 1));  // even columns 2l < mj
+      const int zo_l = s_lead_zeros(zm[1] & s_below_mask(mj >> 1));        // odd columns 2l+1 < mj
+      const int cl = max(ze_l >= 0 ? 2 * (63 - ze_l) : -1, zo_l >= 0 ? 2 * (63 - zo_l) + 1 : -1);
+      const int se = (mj + 2) >> 1, so = (mj + 1) >> 1;                    // first even / odd lane with a column > mj
+      const int fe = s_first_one((zm[0] >> ((mj + 1) >> 1)) >> ((mj + 1) & 1));
+      const int fo = s_first_one(zm[1] >> so);
+      const int cr = min(fe >= 0 ? 2 * (se + fe) : 1 << 20, fo >= 0 ? 2 * (so + fo) + 1 : 1 << 20);
+      beg = cl >= 0 ? vu(cl + 2) : nb0;
+      end = cr < (1 << 20) ? vu(cr + 1) : end + 1;
+    }
   }
   ExtRes r;
   r.max = __builtin_amdgcn_readfirstlane(mx);
