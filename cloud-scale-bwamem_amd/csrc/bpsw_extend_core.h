@@ -284,10 +284,12 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
       }
       const bool act = rel < spanA;
       const int sc = isN ? phi[s] : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
-      const int a = act ? max(Hs[s] + sc, Es[s]) : NEG;
+      const int araw = max(Hs[s] + sc, Es[s]);  // >= 0: E never goes below 0
+      const int a = act ? araw : NEG;
       As[s] = a;
       int Pg = a + jE[s];
-      scan_a = a;
+      // one slot: the row maximum and its LAST column come out of the same scan
+      scan_a = S == 1 ? (act ? ((araw << 6) | lane) : NEG) : a;
       dual_scan_max(Pg, scan_a);
       if (S > 1) {
         Pg = max(Pg, carry_g);
@@ -307,7 +309,8 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
       Hs[s] = upd ? hsh : Hs[s];
       Es[s] = upd ? En : Es[s];
     }
-    const int m = max(0, S > 1 ? carry_a : __builtin_amdgcn_readlane(scan_a, 63));  // scalar
+    const int mkey = max(0, S > 1 ? carry_a : __builtin_amdgcn_readlane(scan_a, 63));  // scalar
+    const int m = S == 1 ? mkey >> 6 : mkey;
 
     // SWUtil.scala:177-182: j after the column loop is end (or beg for an empty band); h1 there is eh[end].h
     if (any_lane((span > 0 ? end : beg) == qLen)) {
@@ -326,7 +329,7 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
 
     int sm = 0, bm;  // slot and lane of the LAST column whose a == m  (SWUtil.scala:158-161)
     if (S == 1) {
-      bm = 63 - s_lead_zeros(__builtin_amdgcn_ballot_w64(As[0] == m));
+      bm = mkey & 63;
     } else {
       bm = -1;
 #pragma unroll
@@ -440,18 +443,20 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
 
     bool upd[2], act[2];
     unsigned rel[2];
-    int a[2], Pg[2];
+    int a[2], Pg[2], akey[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       rel[s] = (unsigned)(2 * lane + s - beg);
       upd[s] = rel[s] < spanU;
       act[s] = rel[s] < spanA;
       const int sc = isN ? __builtin_amdgcn_sbfe(phi2, 8u * s, 8u) : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
-      a[s] = act[s] ? max(Hs[s] + sc, Es[s]) : NEG;
+      const int araw = max(Hs[s] + sc, Es[s]);  // >= 0: E never goes below 0
+      a[s] = act[s] ? araw : NEG;
+      akey[s] = act[s] ? ((araw << 7) | (2 * lane + s)) : NEG;  // the row maximum and its LAST column in one scan
       Pg[s] = a[s] + jE0 + s * eIns;
     }
     int Pl = max(Pg[0], Pg[1]);   // the lane's two columns folded
-    int scan_a = max(a[0], a[1]);
+    int scan_a = max(akey[0], akey[1]);
     dual_scan_max(Pl, scan_a);
     const int Pprev = wave_shr1(NEG, Pl);  // prefix over the columns of the lanes below
     const int Fe = Pprev - kC - jE0;                         // F(i,j) = Pex - (j-1)*eIns for the even column,
@@ -472,7 +477,8 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
       Hs[s] = upd[s] ? hsh[s] : Hs[s];
       Es[s] = upd[s] ? En[s] : Es[s];
     }
-    const int m = max(0, __builtin_amdgcn_readlane(scan_a, 63));  // scalar
+    const int mkey = max(0, __builtin_amdgcn_readlane(scan_a, 63));  // scalar
+    const int m = mkey >> 7;
 
     // SWUtil.scala:177-182: j after the column loop is end (or beg for an empty band); h1 there is eh[end].h
     if (any_lane((span > 0 ? end : beg) == qLen)) {
@@ -488,10 +494,7 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     }
     if (m == 0) break;  // SWUtil.scala:184-185
 
-    // the LAST column whose a == m (SWUtil.scala:158-161)
-    const int le = s_lead_zeros(__builtin_amdgcn_ballot_w64(a[0] == m)), lo = s_lead_zeros(__builtin_amdgcn_ballot_w64(a[1] == m));
-    const int pe = le >= 0 ? 2 * (63 - le) : -1, po = lo >= 0 ? 2 * (63 - lo) + 1 : -1;
-    const int mj = max(pe, po);  // scalar
+    const int mj = mkey & 127;  // the LAST column whose a == m (SWUtil.scala:158-161)
     const bool improved = m > mx;
     if (!any_lane(improved) && zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
       if (any_lane(zdrop_stop((iv - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode))) break;
