@@ -254,8 +254,9 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
   int h1raw = vu(h0 - oDel);  // h0 - (oDel + eDel*(i+1)) after the decrement below
   int iv = vu(0);             // vector copy of the row index
 
+  const int i_tail = amax > 0 ? qLen : 0x7fffffff;  // first row the tail bound applies to (one scalar compare per row)
   for (int i = 0; i < tLen; ++i, iv += 1) {
-    if (i >= qLen && amax > 0) {  // nothing past this row can change the result (tail_row_bound)
+    if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
       const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
       if (any_lane(U <= mx && U < gscore)) break;
     }
@@ -301,7 +302,7 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
         carry_a = __builtin_amdgcn_readlane(scan_a, 63);
       }
       const int H = max3i(a, Pex - c2[s], 0);  // F(i,j) = max(0, Pex - (j-1)*eIns)
-      zm[s] = __builtin_amdgcn_ballot_w64((act ? H : -1) == 0);
+      zm[s] = __builtin_amdgcn_ballot_w64(H < 1) & __builtin_amdgcn_ballot_w64(act);  // H >= 0: the zero cells of the band
       const int En = act ? max3i(Es[s] - eDel, H - oeDel, 0) : 0;  // E(i+1,j); eh[end].e = 0
       int hsh = wave_shr1(hl_prev, H);                             // H(i,j-1)
       if (S > 1) hl_prev = __builtin_amdgcn_readlane(H, 63);
@@ -426,8 +427,9 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
   int h1raw = vu(h0 - oDel);
   int iv = vu(0);
 
+  const int i_tail = amax > 0 ? qLen : 0x7fffffff;  // first row the tail bound applies to (one scalar compare per row)
   for (int i = 0; i < tLen; ++i, iv += 1) {
-    if (i >= qLen && amax > 0) {  // nothing past this row can change the result (tail_row_bound)
+    if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
       const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
       if (any_lane(U <= mx && U < gscore)) break;
     }
@@ -467,7 +469,7 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       H[s] = max3i(a[s], Fs[s], 0);
-      zm[s] = __builtin_amdgcn_ballot_w64((act[s] ? H[s] : -1) == 0);
+      zm[s] = __builtin_amdgcn_ballot_w64(H[s] < 1) & __builtin_amdgcn_ballot_w64(act[s]);  // H >= 0: the zero cells of the band
       En[s] = act[s] ? max3i(Es[s] - eDel, H[s] - oeDel, 0) : 0;  // E(i+1,j); eh[end].e = 0
     }
     int hsh[2] = {wave_shr1(h1, H[1]), H[0]};  // H(i,j-1)
