@@ -172,6 +172,7 @@ def main():
     # n = 1 / 2 / 3 -- the device is already busy throughout a step, so the default stays 1 and the per-launch durations
     # the roofline entry uses are not stretched by overlap between steps.
     STEPS_IN_FLIGHT = max(1, int(os.environ.get("BENCH_STEPS_IN_FLIGHT", "1")))
+    SW_FIRST = os.environ.get("BENCH_SW_FIRST", "0") == "1"   # issue order of the step's five independent batches
     sets = [[bpsw_hip.Context(local_rank) for _ in range(EXT_BATCHES_PER_STEP + 1)]  # no fallback: raises without a gfx950 device
             for _ in range(STEPS_IN_FLIGHT)]
     ctxs = sets[0]
@@ -221,9 +222,12 @@ def main():
         k = turn % len(sets)
         turn += 1
         collect(k)                  # the step this set ran STEPS_IN_FLIGHT steps ago
+        if SW_FIRST:
+            sets[k][-1].swalign2_batch_device(opt, sj, d_sw_out_all[k].data_ptr(), 0)
         for cx, w, n, dw, do in zip(sets[k], wires, ntasks, d_wires, d_outs_all[k]):
             cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)   # asynchronous, context's own stream
-        sets[k][-1].swalign2_batch_device(opt, sj, d_sw_out_all[k].data_ptr(), 0)
+        if not SW_FIRST:
+            sets[k][-1].swalign2_batch_device(opt, sj, d_sw_out_all[k].data_ptr(), 0)
         busy[k], counted[k] = True, timed
 
     def drain():

@@ -196,14 +196,15 @@ __device__ __forceinline__ int s_first_one(unsigned long long v) {  // -1 when v
 
 // Where the wave-uniform row control runs.  Measured on MI355X (tools/microbench_issue.hip, profiles/): a SIMD issues
 // one integer VALU / DPP / v_cmp / v_readlane wave-instruction per ~3.7 cycles and one SALU instruction per ~3.7
-// cycles; mixed streams from several waves reach about one instruction per 2.4 cycles, and once the GPU is saturated
-// the kernel time follows the TOTAL instruction count (1.15 ns x (VALU + SALU) / SIMD), not the split.  Two builds:
-//   BPSW_EXT_VECTOR_CONTROL 1 (default): uniform values kept in VGPRs through an opaque asm -> 355 M VALU + 200 M SALU
-//                                        per 30 k-task batch, 0.713 ms stand-alone
-//   BPSW_EXT_VECTOR_CONTROL 0          : control on the scalar pipe -> 239 M VALU + 323 M SALU, 0.748 ms stand-alone
-// Both give 2.95 ms per bench step when the step's batches overlap on the device.
+// cycles; mixed streams from several waves reach about one instruction per 2.4 cycles.  Two builds:
+//   BPSW_EXT_VECTOR_CONTROL 1: uniform values kept in VGPRs through an opaque asm (fewer SALU, more VALU instructions)
+//   BPSW_EXT_VECTOR_CONTROL 0: control on the scalar pipe
+// Early in the round the kernel issued 355 M VALU + 200 M SALU (build 1) or 239 M + 323 M (build 0) per 30 k-task batch and
+// both took the same time: the sum was what counted.  After the closed forms and the row-loop work the kernel is at
+// 95 M VALU + 39 M SALU (build 1), the step is bound by its VALU instructions, and build 0 is faster (8 batches in flight
+// 172 -> 176.5 M reads/s, bench step 116.7 -> 118.6): it is the default again.
 #ifndef BPSW_EXT_VECTOR_CONTROL
-#define BPSW_EXT_VECTOR_CONTROL 1
+#define BPSW_EXT_VECTOR_CONTROL 0
 #endif
 __device__ __forceinline__ int vu(int s) {
 #if BPSW_EXT_VECTOR_CONTROL
