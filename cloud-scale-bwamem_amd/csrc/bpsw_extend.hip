@@ -50,7 +50,10 @@ __device__ void load_side(const int lane, const uint32_t* __restrict__ words, co
 __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
 
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 5) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
+#ifndef BPSW_EXT_WAVES_PER_SIMD
+#define BPSW_EXT_WAVES_PER_SIMD 6  // register budget: 80 VGPRs, no spills with the scalar row control
+#endif
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
                                                                      const int lds_per_wave,

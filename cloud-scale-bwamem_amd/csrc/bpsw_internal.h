@@ -262,7 +262,8 @@ struct bpsw_ctx {
   bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
   // asynchronous device entries: a launch whose table scan has not been read back yet (resolved by finish_pending)
   struct PendingExt { bool active = false; const void* d_wire = nullptr; size_t wire_bytes = 0; int n_tasks = 0; void* d_out = nullptr;
-                      hipStream_t s = nullptr; } pend_ext;
+                      hipStream_t s = nullptr; int qcap = 0, rcap = 0; } pend_ext;
+  int ext_geom_q = 0, ext_geom_r = 0;  // longest query / target side of the verified extension launches on this context (speculation)
   struct PendingSw { bool active = false; bpsw_sw_jobs_t jobs; bpsw_opt_t opt; void* d_out = nullptr; hipStream_t s = nullptr;
                      int cap_qlen = 0, cap_tlen = 0; } pend_sw;
   int sw_geom_qlen = 0, sw_geom_tlen = 0;  // geometry of the last verified SW launch on this context (speculation for the next)

@@ -397,7 +397,9 @@ int finish_pending_ext(bpsw_ctx_t* c) {
     c->have_ext_ev = false;
     return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
   }
-  if (h_pre->max_qlen > ASYNC_QCAP || h_pre->max_rlen > ASYNC_RCAP) {  // the kernel left the batch untouched: launch it for real
+  c->ext_geom_q = std::max(c->ext_geom_q, h_pre->max_qlen);
+  c->ext_geom_r = std::max(c->ext_geom_r, h_pre->max_rlen);
+  if (h_pre->max_qlen > p.qcap || h_pre->max_rlen > p.rcap) {  // the kernel left the batch untouched: launch it for real
     int counts[3] = {0, 0, p.n_tasks};
     int rc = ext_device_sync_launch(c, p.d_wire, p.wire_bytes, p.n_tasks, p.d_out, p.s, h_pre, counts);
     if (rc != BPSW_OK) return rc;
@@ -432,9 +434,18 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
     // Asynchronous: scan, main launch (sized for ASYNC_QCAP / ASYNC_RCAP, checking the scan on the device) and the scan's
     // read-back are enqueued back to back; nothing waits.  Errors surface at the next call on this context or at
     // bpsw_last_kernel_ms, which is also where a batch that outgrew the geometry is re-launched.
+    // LDS geometry: the first call on a context is sized for ASYNC_QCAP / ASYNC_RCAP; later ones for the longest sides the
+    // verified calls have shown, plus headroom (a third of the LDS for 2x150 bp reads, so that the launches of several
+    // contexts and the rescue kernel are resident together).  Same caps as launch_ext_kernel's rounding.
+    int qcap = ASYNC_QCAP, rcap = ASYNC_RCAP;
+    if (c->ext_geom_q > 0) {
+      qcap = std::min(ASYNC_QCAP, (c->ext_geom_q + 32 + 31) & ~31);
+      rcap = std::min(ASYNC_RCAP, (c->ext_geom_r + 128 + 63) & ~63);
+    }
     HIP_TRY(hipEventRecord(c->ev[4], s));
-    HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, ASYNC_QCAP, ASYNC_RCAP, c->num_cu,
+    HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu,
                               (int*)((char*)c->d_pre.ptr + 128), nullptr, s, d_pre, true));
+    c->pend_ext.qcap = qcap; c->pend_ext.rcap = rcap;
     HIP_TRY(hipEventRecord(c->ev[5], s));
     HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
     c->have_ext_ev = true;
