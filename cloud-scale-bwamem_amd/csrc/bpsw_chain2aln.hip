@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void chain2aln_kernel(const C
             const int oe_min = min(oIns + eIns, oDel + eDel);
             const bool exact = P.exact_a > 0 && oe_min > 0 && w0 >= 2 && rLen >= qLen && tstage >= qLen &&
                                flank_closed_form(lane, qLen, min(rLen, tstage), qsrc, [ts](int j) { return (int)(ts[j] >> 3); }, P.mat, hInit,
-                                                 P.exact_a, oDel, eDel, oIns, eIns, P.zdrop, P.certify != 0, &x);
+                                                 P.exact_a, oDel, eDel, oIns, eIns, P.zdrop, P.certify, &x);
             if (exact) {
               aw[side] = w0;
               regScore = x.max;

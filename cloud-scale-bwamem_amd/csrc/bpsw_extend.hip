@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
       // near-exact flank: the DP result is known (flank_closed_form); the retry loop would stop after its first try
       const bool exact = exact_a > 0 && rLen >= qLen &&
                          flank_closed_form(lane, qLen, rLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat, hInit, exact_a, oDel,
-                                           eDel, oIns, eIns, sc.zdrop, sc.certify != 0, &r);
+                                           eDel, oIns, eIns, sc.zdrop, sc.certify, &r);
       if (exact) {
         aw[side] = wBand;
         regScore = r.max;

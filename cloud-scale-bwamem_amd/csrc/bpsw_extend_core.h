@@ -657,14 +657,33 @@ __device__ bool single_gap_certificate(const int lane, const int qLen, const int
   return true;
 }
 
+// Two gap opens.  With the default scoring family (match a = 1, every other matrix entry <= -1 so that one imperfect diagonal
+// step costs at least 2, both gap extensions 1, oIns + eIns = oDel + eDel = oe) the form also holds for D = 2*oe + s, s in {0, 1}
+// (three substitutions, D = 15, are a third of the DP rows the single-gap certificate leaves on 2x150 bp reads), under two more
+// tests.  A path with k diagonal steps of deficit P in total, deletions of total length Ld and insertions of total length Li
+// ends in cell (i, i + Li - Ld) with score  Hd(i) + D_i - a*Ld - P - G  (Hd the gapless diagonal, G its gap cost).
+//  * Three or more gaps: G >= 3*oe > D (oe >= 2).  Two deletions (rows < qLen): D - 2a - 2*oe = s - 2 < 0.  One of each, lengths
+//    (1,1): s - 1 - P <= 0, and the cell is (i,i) itself, where a tie changes nothing; longer ones lose e (+a) per base.
+//  * Two insertions: s - P - (Li - 2): not below 0 only for P = 0 (P >= 2 otherwise) and Li <= 2 + s, in a cell RIGHT of the
+//    diagonal, where even a tie would move the last arg-max.  D_i >= 2*oe needs every deficit position behind it (the rest
+//    would have to sum to <= 1), so such a path takes its step of row p_last (the last deficit) on the diagonal shifted by
+//    Li', 2 <= Li' <= 2 + s -- or still has one gap only there, and then that prefix beats the diagonal by
+//    D - oIns - L1 >= oe + s - 1 > 0 and the single-gap certificate refuses the flank.  Test 1: S(t[p_last], q[p_last+L]) != a.
+//  * Two deletions below the query end: the last column at row qLen-1+Ld holds g + s - P - (Ld - 2); a value >= g would move
+//    gscore / max_ie (`gscore <= h1`) or the maximum.  Its last diagonal step is (t[qLen-1+Ld], q[qLen-1]), a match.
+//    Test 2: S(t[qLen-1+L], q[qLen-1]) != a for 2 <= L <= 2 + s.  (Paths ending in a gap there sit oe below a single-gap
+//    prefix, which the certificate bounds by g; one deletion plus one insertion reach at most g + s - 1 - oe.)
+// The single-gap certificate itself is unchanged: its conditions never used D < 2*oe, only its caller did.
 template <class QC, class TC>
 __device__ __forceinline__ bool flank_closed_form(const int lane, const int qLen, const int tLen, const QC& qcode, const TC& tcode,
                                                   const MatRows& mat, const int h0, const int a, const int oDel, const int eDel,
-                                                  const int oIns, const int eIns, const int zdrop, const bool certify,
+                                                  const int oIns, const int eIns, const int zdrop, const int certify,
                                                   ExtRes* out) {
   const int oe_min = min(oIns + eIns, oDel + eDel);
-  const int limit = certify && qLen <= 128 ? 2 * oe_min : oe_min;  // deficit below which the form can still hold
+  const bool two_opens = certify >= 2 && qLen <= 128 && a == 1 && eIns == 1 && eDel == 1 && oIns + eIns == oDel + eDel && oe_min >= 2;
+  const int limit = certify && qLen <= 128 ? (two_opens ? 2 * oe_min + 2 : 2 * oe_min) : oe_min;  // deficit below which the form can still hold
   int D = 0, best = h0, best_i = -1;  // SWUtil.scala:118-121: max = h0, max_i = max_j = -1
+  int p_last = -1;
   for (int j0 = 0; j0 < qLen; j0 += 64) {
     const int j = j0 + lane;
     int d = 0;
@@ -677,10 +696,17 @@ __device__ __forceinline__ bool flank_closed_form(const int lane, const int qLen
       const int v = h0 + pos * a - D;  // m(pos-1): the last row before this deficit
       if (pos >= 1 && v > best) { best = v; best_i = pos - 1; }
       D += __builtin_amdgcn_readlane(d, b);
+      p_last = pos;
       if (D >= limit) return false;
     }
   }
   if (h0 <= D || (zdrop > 0 && D > zdrop)) return false;
+  if (D >= 2 * oe_min) {  // two gap opens: tests 1 and 2 above
+    for (int L = 2; L <= 2 + (D - 2 * oe_min); ++L) {
+      if (p_last + L < qLen && mat_score(mat, tcode(p_last), qcode(p_last + L)) == a) return false;
+      if (qLen - 1 + L < tLen && mat_score(mat, tcode(qLen - 1 + L), qcode(qLen - 1)) == a) return false;
+    }
+  }
   if (D >= oe_min && !single_gap_certificate(lane, qLen, tLen, qcode, tcode, mat, D, oDel, eDel, oIns, eIns)) return false;
   const int g = h0 + qLen * a - D;
   if (g > best) { best = g; best_i = qLen - 1; }

@@ -29,9 +29,10 @@ struct ExtScoring {
   int mat_max;  // max(mat): bounds the scores a task can reach (selects the int16 register path)
   int exact_a;  // match score when the exact-flank shortcut is valid for this matrix (bpsw_extend_core.h), else 0
   int tail_bound;  // 1: stop a call once the rows past the query end cannot change its result (tail_row_bound)
-  int certify;     // 1: single-gap certificate for flanks with a deficit below two gap opens (BPSW_EXT_CERT=0 disables)
+  int certify;     // certify_level(): 1 single-gap certificate for flanks with a deficit below two gap opens, 2 also two opens
 };
 bool certify_enabled();
+int certify_level(const int8_t mat[25]);  // 0 off, 1 single-gap certificate, 2 also the two-gap-open extension
 bool tail_bound_enabled();  // BPSW_EXT_TAIL=0 disables (A/B runs)
 // a > 0 if mat[c][c] == a for the four bases and every other entry is < a; else 0.  BPSW_EXT_EXACT=0 disables.
 int exact_match_score(const int8_t mat[25]);

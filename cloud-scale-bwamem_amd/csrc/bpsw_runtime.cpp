@@ -79,6 +79,17 @@ bool certify_enabled() {
   static const bool off = getenv("BPSW_EXT_CERT") && atoi(getenv("BPSW_EXT_CERT")) == 0;
   return !off;
 }
+// 0: no certificate; 1: single gap (deficit below two gap opens); 2: also a deficit of two gap opens (+1), for matrices with
+// match score 1 and every other entry <= -1 (flank_closed_form, "Two gap opens"); BPSW_EXT_CERT2=0 keeps level 1
+int certify_level(const int8_t mat[25]) {
+  if (!certify_enabled()) return 0;
+  static const bool off2 = getenv("BPSW_EXT_CERT2") && atoi(getenv("BPSW_EXT_CERT2")) == 0;
+  if (off2 || exact_match_score(mat) != 1) return 1;
+  for (int r = 0; r < 5; ++r)
+    for (int c = 0; c < 5; ++c)
+      if (!(r == c && r < 4) && mat[r * 5 + c] > -1) return 1;
+  return 2;
+}
 
 int exact_match_score(const int8_t mat[25]) {
   static const bool off = getenv("BPSW_EXT_EXACT") && atoi(getenv("BPSW_EXT_EXACT")) == 0;  // A/B switch for measurements
@@ -176,7 +187,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.mat_max = 1;
   c->ext_sc.exact_a = exact_match_score(c->ext_mat);
   c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
-  c->ext_sc.certify = certify_enabled() ? 1 : 0;
+  c->ext_sc.certify = certify_level(c->ext_mat);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
   for (int k = 0; e == hipSuccess && k < 2; ++k) {
@@ -228,7 +239,7 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
   c->ext_sc.zdrop_mode = zdrop_mode;
   c->ext_sc.exact_a = exact_match_score(c->ext_mat);
   c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
-  c->ext_sc.certify = certify_enabled() ? 1 : 0;
+  c->ext_sc.certify = certify_level(c->ext_mat);
   return BPSW_OK;
 }
 

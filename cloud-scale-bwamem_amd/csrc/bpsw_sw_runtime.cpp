@@ -414,7 +414,7 @@ int bpsw_chain2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_chains
   P.pen_clip5 = opt->pen_clip5; P.pen_clip3 = opt->pen_clip3; P.w = opt->w; P.zdrop = opt->zdrop; P.zmode = zdrop_mode;
   P.exact_a = exact_match_score(opt->mat);
   P.tail_bound = tail_bound_enabled() ? 1 : 0;
-  P.certify = certify_enabled() ? 1 : 0;
+  P.certify = certify_level(opt->mat);
 
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
