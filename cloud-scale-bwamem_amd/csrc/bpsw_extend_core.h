@@ -668,10 +668,13 @@ __device__ bool single_gap_certificate(const int lane, const int qLen, const int
 //    diagonal, where even a tie would move the last arg-max.  D_i >= 2*oe needs every deficit position behind it (the rest
 //    would have to sum to <= 1), so such a path takes its step of row p_last (the last deficit) on the diagonal shifted by
 //    Li', 2 <= Li' <= 2 + s -- or still has one gap only there, and then that prefix beats the diagonal by
-//    D - oIns - L1 >= oe + s - 1 > 0 and the single-gap certificate refuses the flank.  Test 1: S(t[p_last], q[p_last+L]) != a.
+//    D - oIns - L1 >= oe + s - 1 > 0 and the single-gap certificate refuses the flank.  Test 1: S(t[p_last], q[p_last+L]) != a,
+//    or one of the two deficit rows before it (if there are that many) has no match on any diagonal shifted by 1..L: P = 0
+//    needs every deficit position off the main diagonal.
 //  * Two deletions below the query end: the last column at row qLen-1+Ld holds g + s - P - (Ld - 2); a value >= g would move
 //    gscore / max_ie (`gscore <= h1`) or the maximum.  Its last diagonal step is (t[qLen-1+Ld], q[qLen-1]), a match.
-//    Test 2: S(t[qLen-1+L], q[qLen-1]) != a for 2 <= L <= 2 + s.  (Paths ending in a gap there sit oe below a single-gap
+//    Test 2: S(t[qLen-1+L], q[qLen-1]) != a for 2 <= L <= 2 + s, or one of the last three deficit positions p has no match
+//    S(t[p+sft], q[p]), 1 <= sft <= L.  (Paths ending in a gap there sit oe below a single-gap
 //    prefix, which the certificate bounds by g; one deletion plus one insertion reach at most g + s - 1 - oe.)
 // The single-gap certificate itself is unchanged: its conditions never used D < 2*oe, only its caller did.
 template <class QC, class TC>
@@ -683,7 +686,7 @@ __device__ __forceinline__ bool flank_closed_form(const int lane, const int qLen
   const bool two_opens = certify >= 2 && qLen <= 128 && a == 1 && eIns == 1 && eDel == 1 && oIns + eIns == oDel + eDel && oe_min >= 2;
   const int limit = certify && qLen <= 128 ? (two_opens ? 2 * oe_min + 2 : 2 * oe_min) : oe_min;  // deficit below which the form can still hold
   int D = 0, best = h0, best_i = -1;  // SWUtil.scala:118-121: max = h0, max_i = max_j = -1
-  int p_last = -1;
+  int p_last = -1, p_prev = -1, p_prev2 = -1;  // the last three deficit positions
   for (int j0 = 0; j0 < qLen; j0 += 64) {
     const int j = j0 + lane;
     int d = 0;
@@ -696,15 +699,30 @@ __device__ __forceinline__ bool flank_closed_form(const int lane, const int qLen
       const int v = h0 + pos * a - D;  // m(pos-1): the last row before this deficit
       if (pos >= 1 && v > best) { best = v; best_i = pos - 1; }
       D += __builtin_amdgcn_readlane(d, b);
-      p_last = pos;
+      p_prev2 = p_prev; p_prev = p_last; p_last = pos;
       if (D >= limit) return false;
     }
   }
   if (h0 <= D || (zdrop > 0 && D > zdrop)) return false;
-  if (D >= 2 * oe_min) {  // two gap opens: tests 1 and 2 above
+  if (D >= 2 * oe_min) {  // two gap opens: tests 1 and 2 above, sharpened by the two deficit positions before the last
+    const auto is_match = [&](const int ti, const int qi) {
+      return ti >= 0 && qi >= 0 && ti < tLen && qi < qLen && mat_score(mat, tcode(ti), qcode(qi)) == a;
+    };
     for (int L = 2; L <= 2 + (D - 2 * oe_min); ++L) {
-      if (p_last + L < qLen && mat_score(mat, tcode(p_last), qcode(p_last + L)) == a) return false;
-      if (qLen - 1 + L < tLen && mat_score(mat, tcode(qLen - 1 + L), qcode(qLen - 1)) == a) return false;
+      // P = 0 also needs the steps of rows p_prev, p_prev2 on a shifted diagonal (1..L) and matching there
+      if (is_match(p_last, p_last + L)) {
+        bool m1 = p_prev < 0, m2 = p_prev2 < 0;  // fewer than three deficit positions: no further condition
+        for (int sft = 1; sft <= L; ++sft) { m1 = m1 || is_match(p_prev, p_prev + sft); m2 = m2 || is_match(p_prev2, p_prev2 + sft); }
+        if (m1 && m2) return false;
+      }
+      // ... and the steps that consume q[p] for the three deficit positions p on a diagonal shifted down by 1..L
+      if (is_match(qLen - 1 + L, qLen - 1)) {
+        bool m0 = false, m1 = p_prev < 0, m2 = p_prev2 < 0;
+        for (int sft = 1; sft <= L; ++sft) {
+          m0 = m0 || is_match(p_last + sft, p_last); m1 = m1 || is_match(p_prev + sft, p_prev); m2 = m2 || is_match(p_prev2 + sft, p_prev2);
+        }
+        if (m0 && m1 && m2) return false;
+      }
     }
   }
   if (D >= oe_min && !single_gap_certificate(lane, qLen, tLen, qcode, tcode, mat, D, oDel, eDel, oIns, eIns)) return false;
