@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Soak test aimed at the closed form's two-gap-open extension (bpsw_extend_core.h, flank_closed_form): flanks whose main
+diagonal has a deficit of 14 or 15 under the default scoring (three substitutions; two plus two N; ...), in low-complexity and
+periodic sequence, with the substituted bases and the target tail chosen so that the shifted diagonals of the two exclusion
+tests match more often than by chance.  Usage on a GPU box: python tools/soak_cert2.py [rounds] [tasks_per_round]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("cloud-scale-bwamem_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np  # noqa: E402
+import bpsw_hip  # noqa: E402
+import pyoracle as po  # noqa: E402
+from test_extend_gpu import _manual_tasks  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+per = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+ctx, orc = bpsw_hip.Context(0), po.Oracle()
+total = bad_total = 0
+
+
+def side(rng):
+    n = int(rng.integers(8, 129))
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        q = rng.integers(0, 4, n)
+    elif kind == 1:
+        q = np.full(n, rng.integers(0, 4))
+        q[rng.integers(0, n, max(1, n // 12))] = rng.integers(0, 4)
+    elif kind == 2:
+        q = np.tile(rng.integers(0, 4, int(rng.integers(1, 5))), n)[:n]
+    elif kind == 3:
+        q = rng.integers(0, 2, n)
+    else:
+        q = np.where(rng.random(n) < 0.7, np.tile(rng.integers(0, 4, 2), n)[:n], rng.integers(0, 4, n))
+    q = q.astype(np.int64)
+    r = q.copy()
+    # deficit positions: three substitutions (15), or two + two N (14), or one + five N (15), clustered or spread
+    u = rng.random()
+    n_sub, n_n = (3, 0) if u < 0.6 else ((2, 2) if u < 0.8 else ((1, 5) if u < 0.9 else (int(rng.integers(0, 5)), int(rng.integers(0, 4)))))
+    start = int(rng.integers(0, n))
+    span = int(rng.integers(2, 40)) if rng.random() < 0.6 else n
+    pos = sorted(set(int(min(n - 1, start + rng.integers(0, span))) for _ in range(n_sub + n_n)))
+    rng.shuffle(pos)
+    for k, p in enumerate(pos):
+        if k < n_sub:
+            v = rng.random()
+            cand = None
+            if v < 0.5 and p + 2 < n:      # make the substituted target base equal a query base one to three columns on
+                cand = int(q[p + int(rng.integers(1, min(4, n - p)))])
+            if cand is None or cand == q[p] or cand > 3:
+                cand = int((q[p] + 1 + rng.integers(0, 3)) & 3)
+            r[p] = cand
+        else:
+            if rng.random() < 0.5:
+                r[p] = 4
+            else:
+                q[p] = 4
+    extra = int(rng.integers(0, 40)) if rng.random() < 0.9 else 0
+    v = rng.random()
+    if v < 0.4:       # the query's end again, shifted down by 2 or 3 rows: the two-deletion test
+        pad = rng.integers(0, 4, int(rng.integers(1, 4)))
+        tail = np.concatenate([pad, np.tile(q[-1:], extra + 3)])[: extra + 3]
+    elif v < 0.7:
+        tail = np.tile(q, 2)[: extra]
+    else:
+        tail = rng.integers(0, 5, extra)
+    return q.tolist(), np.concatenate([r, tail]).astype(np.int64).tolist()
+
+
+for rd in range(rounds):
+    rng = np.random.default_rng(31000 + rd)
+    tasks = []
+    for t in range(per):
+        l, r = side(rng), side(rng)
+        h0 = int(rng.integers(16, 60)) if rng.random() < 0.5 else int(rng.integers(16, 150))
+        if rng.random() < 0.1:
+            l = ([], [])
+        tasks.append((l[0], l[1], r[0], r[1], h0, len(l[0])))
+    soa = _manual_tasks(tasks)
+    for (od, ed, oi, ei), w in (((6, 1, 6, 1), 100), ((6, 1, 6, 1), 3), ((6, 1, 6, 1), 2), ((1, 1, 1, 1), 100), ((3, 1, 3, 1), 100), ((2, 1, 2, 1), 7)):
+        soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w
+        wire = bpsw_hip.wire_pack(soa)
+        for zmode, zdrop in ((0, 100), (1, 100), (1, 16), (0, 0)):
+            ctx.set_ext_scoring(po.default_mat(), zdrop, zmode)
+            got = ctx.extend_batch(wire).reshape(-1, 10)
+            want, _ = orc.wire_extend(wire, po.default_mat(), zdrop, zmode)
+            want = want.reshape(-1, 10)
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            total += soa.n
+            if bad.size:
+                bad_total += bad.size
+                print(f"round {rd} gaps {(od, ed, oi, ei)} w {w} z {zmode}/{zdrop}: {bad.size} differ; task {bad[0]} got {got[bad[0]]} want {want[bad[0]]}", flush=True)
+    print(f"round {rd} tasks so far {total} bad {bad_total}", flush=True)
+print("SOAK", {"task_runs": total, "bad": bad_total})
+sys.exit(1 if bad_total else 0)
