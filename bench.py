@@ -18,6 +18,12 @@ import os
 import sys
 import time
 
+# The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), round robin; streams that
+# share a queue run one after the other.  A step's five batches each have their own stream, so with four queues two of them
+# were serialised (the kernel trace showed the rescue kernel and one extension launch on the same queue).  Must be set
+# before the runtime initialises; an executor that runs several task threads wants the same.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (os.path.join(ROOT, "cloud-scale-bwamem_amd"), os.path.join(ROOT, "oracle")):
     if _p not in sys.path:
@@ -327,6 +333,7 @@ def main():
                                "extension + batched pair-end SW rescue (10% of pairs), 1 MI355X per rank",
                    "pairs_per_step_per_gpu": PAIRS_PER_STEP, "ext_tasks_per_step": int(sum(ntasks)),
                    "rescue_jobs_per_step": n_jobs, "steps_in_flight": STEPS_IN_FLIGHT,
+                   "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "parallelism": f"partition->device x{world} (no collective)"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,

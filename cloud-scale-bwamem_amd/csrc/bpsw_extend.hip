@@ -242,13 +242,14 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   }
   // resident workgroups per CU: 8 waves/SIMD = 8 blocks of 4 waves, capped by LDS
   int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
-  // How many persistent workgroups a launch gets per CU.  Filling every wave slot (5 per SIMD) with ONE launch is the slowest
-  // choice: measured on MI355X (tools/ext_kernel_time.py n, reads/s in millions, 1 / 4 / 8 batches in flight, and the bench
-  // step): 5 per CU 65 / 126 / 132 / 93.6; 2 per CU 70 / 134 / 149 / 99.5; 1.5 per CU 67 / 134 / 152 / 109.3; 1 per CU
-  // 52 / 128 / 137 / 107.3; 0.75 per CU 41 / 112 / 117 / 92.5.  A launch's persistent waves only leave when its queue is
-  // empty, so big grids run one after the other, each with its own tail of long tasks; small grids of several launches
-  // (and the rescue kernel of the same step) are resident together and fill each other's tails.
-  static const double cap_per_cu = getenv("BPSW_EXT_BLOCKS_PER_CU") ? atof(getenv("BPSW_EXT_BLOCKS_PER_CU")) : 1.5;
+  // How many persistent workgroups a launch gets per CU.  Filling every wave slot with ONE launch is the slowest choice.
+  // Measured on MI355X with 16 HIP hardware queues (tools/ext_kernel_time.py n; reads/s in millions for 1 / 2 / 4 / 8 / 16 batches
+  // in flight, and the bench step):   2 per CU 72 / 118 / 147 / 189 / 211 / 120.8;   1.5 per CU 73 / 123 / 172 / 204 / 231 / 133.0;
+  // 1.25 per CU 73 / 123 / 177 / 215 / 241 / 136.5;   1 per CU 67 / 114 / 169 / 212 / 237 / 141.4;   0.75 per CU 54 / 93 / 149 /
+  // 197 / 233 / 135.5.  A launch's persistent waves only leave when its queue is empty, so big grids run one after the other,
+  // each with its own tail of long tasks; small grids of several launches (and the rescue kernel of the same step) are
+  // resident together and fill each other's tails.
+  static const double cap_per_cu = getenv("BPSW_EXT_BLOCKS_PER_CU") ? atof(getenv("BPSW_EXT_BLOCKS_PER_CU")) : 1.0;
   double per_cu_f = per_cu < 1 ? 1.0 : (double)per_cu;
   if (per_cu_f > cap_per_cu) per_cu_f = cap_per_cu;
   int blocks = (n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;

@@ -70,6 +70,13 @@ MatRows pack_mat(const int8_t mat[25]) {
   return m;
 }
 
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), round robin, and streams that
+// share a queue are serialised.  Every context owns streams, and an executor drives several contexts at once, so ask for
+// more queues -- effective only when this library is loaded before the runtime initialises (the JVM case; a Python host
+// that imported torch first has to set the variable itself, bench.py does).  Measured on the bench step: 123 -> 132 M
+// reads/s; 24 or more queues oversubscribe the hardware and collapse (62 M and worse with ten streams busy).
+__attribute__((constructor)) static void bpsw_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 bool tail_bound_enabled() {
   static const bool off = getenv("BPSW_EXT_TAIL") && atoi(getenv("BPSW_EXT_TAIL")) == 0;
   return !off;
