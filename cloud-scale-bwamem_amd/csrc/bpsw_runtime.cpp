@@ -197,11 +197,14 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.certify = certify_level(c->ext_mat);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
-  for (int k = 0; e == hipSuccess && k < 2; ++k) {
+  // side streams of the opt-in quad-task experiment only: every stream takes a slot in the round robin over the HIP hardware
+  // queues, and contexts that collide there serialise each other's launches
+  const bool want_side_streams = getenv("BPSW_EXT_QT") && atoi(getenv("BPSW_EXT_QT")) != 0;  // == ext_qt_enabled()
+  for (int k = 0; e == hipSuccess && k < 2 && want_side_streams; ++k) {
     e = hipStreamCreateWithFlags(&c->aux.stream[k], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux.join[k], hipEventDisableTiming);
   }
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux.fork, hipEventDisableTiming);
+  if (e == hipSuccess && want_side_streams) e = hipEventCreateWithFlags(&c->aux.fork, hipEventDisableTiming);
   if (e == hipSuccess) e = c->d_pre.reserve(512);
   if (e == hipSuccess) e = c->h_pre.reserve(512);
   if (e != hipSuccess) {
@@ -249,6 +252,7 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
   c->ext_sc.certify = certify_level(c->ext_mat);
   return BPSW_OK;
 }
+
 
 // The quad-task kernels (bpsw_extend_qt.hip) execute 1.8x fewer instructions than ext_kernel but are not faster at
 // 32 k-read batches on MI355X, so they are opt-in: BPSW_EXT_QT=1.
