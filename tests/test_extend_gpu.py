@@ -235,3 +235,59 @@ def test_tail_row_bound_cases(ctx, orc):
     uneven = po.default_mat(1, 4)
     uneven[2 * 5 + 2] = 3                                               # one base scores more: amax = 3 bounds all of them
     _check(ctx, orc, soa, mat=uneven)
+
+
+def test_two_gap_open_deficits(ctx, orc):
+    """Flanks whose main diagonal has a deficit of two gap opens (+1) -- three substitutions under the default scoring, the
+    closed form's second extension (bpsw_extend_core.h, "Two gap opens") -- in homopolymers and short-period repeats, with the
+    substituted bases and the target tail chosen so that the shifted diagonals of its two exclusion tests match far more often
+    than by chance; three scorings of the family, a wide and a minimal band, both z-drop parses.  (tools/soak_cert2.py is the
+    long form of this test.)"""
+    rng = np.random.default_rng(20261003)
+
+    def side():
+        n = int(rng.integers(8, 129))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            q = rng.integers(0, 4, n)
+        elif kind == 1:
+            q = np.full(n, rng.integers(0, 4)); q[rng.integers(0, n, max(1, n // 12))] = rng.integers(0, 4)
+        elif kind == 2:
+            q = np.tile(rng.integers(0, 4, int(rng.integers(1, 5))), n)[:n]
+        else:
+            q = rng.integers(0, 2, n)
+        q = q.astype(np.int64); r = q.copy()
+        u = rng.random()
+        n_sub, n_n = (3, 0) if u < 0.65 else ((2, 2) if u < 0.85 else (1, 5))
+        start, span = int(rng.integers(0, n)), (int(rng.integers(2, 40)) if rng.random() < 0.6 else n)
+        pos = sorted(set(int(min(n - 1, start + rng.integers(0, span))) for _ in range(n_sub + n_n)))
+        rng.shuffle(pos)
+        for k, p in enumerate(pos):
+            if k < n_sub:
+                cand = int(q[p + int(rng.integers(1, min(4, n - p)))]) if rng.random() < 0.5 and p + 2 < n else -1
+                if cand < 0 or cand == q[p] or cand > 3:
+                    cand = int((q[p] + 1 + rng.integers(0, 3)) & 3)
+                r[p] = cand
+            elif rng.random() < 0.5:
+                r[p] = 4
+            else:
+                q[p] = 4
+        extra = int(rng.integers(0, 40))
+        v = rng.random()
+        if v < 0.4:
+            tail = np.concatenate([rng.integers(0, 4, int(rng.integers(1, 4))), np.tile(q[-1:], extra + 3)])[: extra + 3]
+        elif v < 0.7:
+            tail = np.tile(q, 2)[:extra]
+        else:
+            tail = rng.integers(0, 5, extra)
+        return q.tolist(), np.concatenate([r, tail]).astype(np.int64).tolist()
+
+    tasks = []
+    for _ in range(3000):
+        l, r = side(), side()
+        tasks.append((l[0], l[1], r[0], r[1], int(rng.integers(16, 150)), len(l[0])))
+    soa = _manual_tasks(tasks)
+    for (od, ed, oi, ei), w in (((6, 1, 6, 1), 100), ((6, 1, 6, 1), 2), ((1, 1, 1, 1), 100), ((3, 1, 3, 1), 100)):
+        soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w
+        for zmode, zdrop in ((po.ZDROP_SCALA, 100), (po.ZDROP_BWA, 16)):
+            _check(ctx, orc, soa, zmode=zmode, zdrop=zdrop)
