@@ -64,7 +64,10 @@ struct RegLite {  // what testExtension reads of a region
   int qb, qe;
 };
 
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void chain2aln_kernel(const ChainBatchDev B, const ChainParams P,
+#ifndef BPSW_C2A_WAVES_PER_SIMD
+#define BPSW_C2A_WAVES_PER_SIMD 3  // 141 VGPRs without a bound; a budget for 4 spills 8 registers (measured below)
+#endif
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_C2A_WAVES_PER_SIMD) void chain2aln_kernel(const ChainBatchDev B, const ChainParams P,
                                                                           bpsw_alnreg_t* __restrict__ out_regs,
                                                                           int32_t* __restrict__ out_cnt,
                                                                           int32_t* __restrict__ srt_scratch,
