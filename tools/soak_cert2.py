@@ -20,9 +20,12 @@ ctx, orc = bpsw_hip.Context(0), po.Oracle()
 total = bad_total = 0
 
 
+SHORT = os.environ.get("SOAK_SHORT") == "1"   # short flanks over tiny alphabets: shifted diagonals match all the time
+
+
 def side(rng):
-    n = int(rng.integers(8, 129))
-    kind = int(rng.integers(0, 5))
+    n = int(rng.integers(4, 31)) if SHORT else int(rng.integers(8, 129))
+    kind = int(rng.integers(1, 4)) if SHORT else int(rng.integers(0, 5))
     if kind == 0:
         q = rng.integers(0, 4, n)
     elif kind == 1:
@@ -75,6 +78,8 @@ for rd in range(rounds):
     for t in range(per):
         l, r = side(rng), side(rng)
         h0 = int(rng.integers(16, 60)) if rng.random() < 0.5 else int(rng.integers(16, 150))
+        if SHORT and rng.random() < 0.3:
+            h0 = int(rng.integers(1, 24))
         if rng.random() < 0.1:
             l = ([], [])
         tasks.append((l[0], l[1], r[0], r[1], h0, len(l[0])))
