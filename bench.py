@@ -283,6 +283,42 @@ def main():
     reps = max(3, min(args.steps, 10))
     t_ext_only, t_sw_only = time_only(ext_only, reps), time_only(sw_only, reps)
 
+    # ---- what an executor with ten busy task threads would see: two steps in flight (outside `value`) -----------------
+    two_in_flight = None
+    if STEPS_IN_FLIGHT == 1:
+        try:
+            extra = [bpsw_hip.Context(local_rank) for _ in range(EXT_BATCHES_PER_STEP + 1)]
+            sets2 = [sets[0], extra]
+            outs2 = [d_outs_all[0], [torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks]]
+            sw2 = [d_sw_out_all[0], torch.zeros((n_jobs, 7), dtype=torch.int32, device=dev)]
+
+            def submit(k):
+                for cx, w, n, dw, do in zip(sets2[k], wires, ntasks, d_wires, outs2[k]):
+                    cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)
+                sets2[k][-1].swalign2_batch_device(opt, sj, sw2[k].data_ptr(), 0)
+
+            def wait(k):
+                for cx in sets2[k]:
+                    cx.last_kernel_ms()
+
+            for k in (0, 1):
+                submit(k)
+            for k in (0, 1):
+                wait(k)
+            barrier()
+            t = time.perf_counter()
+            n2 = 2 * reps
+            submit(0)
+            for i in range(1, n2):
+                submit(i & 1)          # the entry itself waits for the step this set ran two steps ago
+            for k in (0, 1):
+                wait(k)
+            barrier()
+            two_in_flight = round(2 * PAIRS_PER_STEP * n2 / (time.perf_counter() - t), 1)
+            del extra
+        except Exception as e:  # noqa: BLE001 -- an extra line must never cost the bench its JSON
+            two_in_flight = repr(e)
+
     # ---- worker2's tail, outside `value`: host-inclusive rate of one calling thread + kernel rate ----
     tail = None
     if rank == 0 and world == 1 and not args.no_tail:   # single-GPU runs only: the scaling runs must not make the other ranks wait
@@ -343,7 +379,9 @@ def main():
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes)}},
         "breakdown": {"extend_only_reads_per_s": round(2 * PAIRS_PER_STEP / t_ext_only, 1), "extend_only_ms_per_step": round(1e3 * t_ext_only, 3),
                       "rescue_only_jobs_per_s": round(n_jobs / t_sw_only, 1), "rescue_only_ms_per_step": round(1e3 * t_sw_only, 3),
-                      "note": "this rank only; same resident inputs, each boundary alone (SURVEY.md 8d i/ii); `value` is (iii) combined",
+                      "two_steps_in_flight_reads_per_s": two_in_flight,
+                      "note": "this rank only; same resident inputs, each boundary alone (SURVEY.md 8d i/ii); `value` is (iii) combined; "
+                              "two_steps_in_flight: the same step with a second set of contexts one step ahead (ten batches in flight)",
                       "worker2_tail": tail},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
