@@ -216,6 +216,7 @@ __device__ __forceinline__ int vu(int s) {
 #endif
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+constexpr int NEG_A = -(1 << 20);  // "no cell" for the register sweeps: below every score, and NEG_A << 7 does not overflow
 
 // The z-drop test of a row that did not improve the maximum, with k = (i - max_i) - (mj - max_j) and X = max - m >= 0:
 //   A = k > 0,  B = X - k*eDel > zdrop,  C = X + k*eIns > zdrop.
@@ -287,11 +288,11 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
       const bool act = rel < spanA;
       const int sc = isN ? phi[s] : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
       const int araw = max(Hs[s] + sc, Es[s]);  // >= 0: E never goes below 0
-      const int a = act ? araw : NEG;
+      const int a = act ? araw : NEG_A;
       As[s] = a;
       int Pg = a + jE[s];
-      // one slot: the row maximum and its LAST column come out of the same scan
-      scan_a = S == 1 ? (act ? ((araw << 6) | lane) : NEG) : a;
+      // one slot: the row maximum and its LAST column come out of the same scan (NEG_A << 6 stays far below 0)
+      scan_a = S == 1 ? ((a << 6) | lane) : a;
       dual_scan_max(Pg, scan_a);
       if (S > 1) {
         Pg = max(Pg, carry_g);
@@ -454,8 +455,8 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
       act[s] = rel[s] < spanA;
       const int sc = isN ? __builtin_amdgcn_sbfe(phi2, 8u * s, 8u) : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
       const int araw = max(Hs[s] + sc, Es[s]);  // >= 0: E never goes below 0
-      a[s] = act[s] ? araw : NEG;
-      akey[s] = act[s] ? ((araw << 7) | (2 * lane + s)) : NEG;  // the row maximum and its LAST column in one scan
+      a[s] = act[s] ? araw : NEG_A;
+      akey[s] = (a[s] << 7) | (2 * lane + s);  // the row maximum and its LAST column in one scan (NEG_A << 7 stays far below 0)
       Pg[s] = a[s] + jE0 + s * eIns;
     }
     int Pl = max(Pg[0], Pg[1]);   // the lane's two columns folded
