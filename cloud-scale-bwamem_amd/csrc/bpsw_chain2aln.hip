@@ -212,9 +212,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_C2A_WAVES_PER_SIMD) void
             ExtRes x = {0, 0, 0, 0, 0, 0};
             // near-exact flank: the DP result is known without running it (bpsw_extend_core.h, flank_closed_form)
             const int oe_min = min(oIns + eIns, oDel + eDel);
-            const bool exact = P.exact_a > 0 && oe_min > 0 && w0 >= 2 && rLen >= qLen && tstage >= qLen &&
-                               flank_closed_form(lane, qLen, min(rLen, tstage), qsrc, [ts](int j) { return (int)(ts[j] >> 3); }, P.mat, hInit,
-                                                 P.exact_a, oDel, eDel, oIns, eIns, P.zdrop, P.certify, &x);
+            const auto tsrc = [ts](int j) { return (int)(ts[j] >> 3); };
+            const bool exact = P.exact_a > 0 && oe_min > 0 && w0 >= 2 &&
+                               ((rLen >= qLen && tstage >= qLen &&
+                                 flank_closed_form(lane, qLen, min(rLen, tstage), qsrc, tsrc, P.mat, hInit, P.exact_a, oDel, eDel, oIns, eIns,
+                                                   P.zdrop, P.certify, &x)) ||
+                                (P.certify >= 3 && flank_start_gap_form(lane, qLen, min(rLen, tstage), qsrc, tsrc, P.mat, hInit, P.exact_a, oDel,
+                                                                        eDel, oIns, eIns, P.zdrop, w0, &x)));
             if (exact) {
               aw[side] = w0;
               regScore = x.max;

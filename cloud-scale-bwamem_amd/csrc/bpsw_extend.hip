@@ -121,9 +121,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
       const bool reg_path = qLen <= 255 && oIns + eIns > 0;
       ExtRes r = {0, 0, 0, 0, 0, 0};
       // near-exact flank: the DP result is known (flank_closed_form); the retry loop would stop after its first try
-      const bool exact = exact_a > 0 && rLen >= qLen &&
-                         flank_closed_form(lane, qLen, rLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat, hInit, exact_a, oDel,
-                                           eDel, oIns, eIns, sc.zdrop, sc.certify, &r);
+      const bool exact = exact_a > 0 &&
+                         ((rLen >= qLen && flank_closed_form(lane, qLen, rLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat,
+                                                             hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, sc.certify, &r)) ||
+                          (sc.certify >= 3 && flank_start_gap_form(lane, qLen, rLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat,
+                                                                   hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
       if (exact) {
         aw[side] = wBand;
         regScore = r.max;

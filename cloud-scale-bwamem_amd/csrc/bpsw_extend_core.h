@@ -733,6 +733,74 @@ __device__ __forceinline__ bool flank_closed_form(const int lane, const int qLen
   return true;
 }
 
+// One gap of ONE base right at the start of the flank, everything after it matching -- a third of the flanks that carry an
+// indel (the seed is a maximal exact match, so when the first difference is the indel it sits at position 0).  Default scoring
+// family as above (a = 1, imperfect steps cost >= 2, gap extensions 1, oIns + eIns = oDel + eDel = oe).
+//  * Insertion (the read has one base more): t[i] == q[i+1] for i <= n-2.  The path "insert q[0], then the diagonal" gives
+//    R(i) = h0 - oe + a(i+1) in cell (i, i+1).  Any path into cell (i, i+d) takes at most min(i, i+d) + 1 diagonal steps and
+//    pays at least o + |d|e, so it scores at most R(i) - (d-1) for d >= 2 and R(i) + a - 2a|d| for d <= -1: every cell
+//    off the two diagonals d = 0, 1 stays strictly below R(i); a restart from a zero cell gives at most a(i+1) < R(i) (h0 > oe);
+//    cell (i,i) is the gapless M(i) = h0 + sum of the main diagonal, or something at least a below R(i).  With M(i) <= h0
+//    (checked; the main diagonal starts with a mismatch and is unrelated sequence after it) no row improves on h0 until R
+//    does, from then on every row improves in column i+1 up to row n-2, where the path reaches the last column:
+//    max = gscore = h0 - oe + a(n-1), max_i = max_ie = n-2, max_j = n-1, max_off = 1.  Below that row only the diagonal
+//    shifted DOWN by one or two could come back, with R + a in cell (n, n-1) resp. exactly R in cell (n+1, n-1) (a tie moves
+//    gscore to the later row); they cannot when their gap-at-the-start paths are not perfect (any other path into those cells
+//    takes the mismatch (t0,q0)): periodic sequence fails this and is left to the DP.
+//  * Deletion (the reference has one base more): t[i+1] == q[i] for i <= n-1, R'(r) = h0 - oe + a r in cell (r, r-1), last cell
+//    (n, n-1): max = gscore = h0 - oe + a n, max_i = max_ie = n, max_j = n-1, max_off = 1.  Cells right of the main diagonal
+//    are bounded by R'(r) + a for the shift +1 and by R'(r) for +2 only: both drop by >= 2 when their gap-at-the-start path
+//    begins with a mismatch ((t0,q1) resp. (t0,q2)); every other path into them takes (t0,q0).  Ties with cells LEFT of
+//    the row maximum do not move the last arg-max.
+//  * Trimming keeps the path: the cells next to it on the side away from the main diagonal are >= R - oe > 0 (h0 >= 2 oe),
+//    so the nearest zero is at least two columns off; the band needs w >= 4 (the caller's retry stops at max_off = 1 < 3).
+//    Z-drop: non-improving rows have i - max_i - (mj - max_j) in {0, -1} and max - m <= oe - a, never above zdrop >= oe.
+template <class QC, class TC>
+__device__ bool flank_start_gap_form(const int lane, const int n, const int tLen, const QC& qcode, const TC& tcode, const MatRows& mat,
+                                     const int h0, const int a, const int oDel, const int eDel, const int oIns, const int eIns,
+                                     const int zdrop, const int wBand, ExtRes* out) {
+  const int oe = oIns + eIns;
+  if (!(a == 1 && eIns == 1 && eDel == 1 && oe == oDel + eDel && oe >= 2)) return false;
+  if (wBand < 4 || h0 < 2 * oe + 1 || (zdrop > 0 && zdrop < oe) || n < oe + 3 || n > 255) return false;
+  bool ins = tLen >= n - 1, del = tLen >= n + 1;
+  if (!ins && !del) return false;
+  bool del2 = tLen >= n + 2;  // the diagonal shifted down by TWO perfect as well: its gap-at-the-start path ties the insertion form's gscore
+  int carry = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const bool valid = j < n, has_t = valid && j < tLen;
+    const int q = valid ? qcode(j) : 4;
+    const int tm = has_t ? tcode(j) : 4;
+    const int sm = has_t ? mat_score(mat, tm, q) : 0;
+    const int S = wave_scan_add(sm) + carry;  // M(j) - h0
+    carry = __builtin_amdgcn_readlane(S, 63);
+    if (any_lane(has_t && S > 0)) return false;  // the main diagonal got back above h0
+    if (ins && any_lane(valid && j <= n - 2 && mat_score(mat, tm, qcode(min(j + 1, n - 1))) != a)) ins = false;
+    if (del && any_lane(valid && mat_score(mat, tcode(min(j + 1, tLen - 1)), q) != a)) del = false;
+    if (del2 && any_lane(valid && mat_score(mat, tcode(min(j + 2, tLen - 1)), q) != a)) del2 = false;
+    if (!ins && !del) return false;
+  }
+  // The insertion form also needs the two diagonals below the main one imperfect: a deletion of one base at the start followed by n
+  // matches gives R + a in cell (n, n-1), one of two bases gives exactly R in cell (n+1, n-1) -- and `gscore <= h1` lets the later
+  // row win a tie.  (A deletion opened later takes the mismatch (t0,q0) first and is at least 2 lower.)
+  if (ins && (del || del2)) return false;
+  if (del) {
+    // row 0 has no cell of the path yet: its maximum must be the main-diagonal cell h0 + s0, above every restart (<= a) and
+    // above the cells fed from row -1 (<= h0 - oe - 1 once (t0,q1), (t0,q2) are mismatches) -- else the last arg-max of row 0
+    // sits somewhere to the right and the trimming cuts the path off (found by tools/soak_cert2.py with oe = 2, h0 = 5)
+    const int s0 = mat_score(mat, tcode(0), qcode(0));
+    if (h0 + s0 <= a || s0 + oe + 1 <= 0) return false;
+    if (mat_score(mat, tcode(0), qcode(1)) == a) return false;                // n >= 5 here
+    if (mat_score(mat, tcode(0), qcode(2)) == a) return false;
+    const int g = h0 - oe + a * n;
+    out->max = g; out->qle = n; out->tle = n + 1; out->gtle = n + 1; out->gscore = g; out->max_off = 1;
+    return true;
+  }
+  const int g = h0 - oe + a * (n - 1);
+  out->max = g; out->qle = n; out->tle = n - 1; out->gtle = n - 1; out->gscore = g; out->max_off = 1;
+  return true;
+}
+
 // query source of a wire-batch task: nibble stream `words`, first column at base qStart
 struct NibbleQ {
   const uint32_t* __restrict__ words;

@@ -87,7 +87,8 @@ bool certify_enabled() {
   return !off;
 }
 // 0: no certificate; 1: single gap (deficit below two gap opens); 2: also a deficit of two gap opens (+1), for matrices with
-// match score 1 and every other entry <= -1 (flank_closed_form, "Two gap opens"); BPSW_EXT_CERT2=0 keeps level 1
+// match score 1 and every other entry <= -1 (flank_closed_form, "Two gap opens"); BPSW_EXT_CERT2=0 keeps level 1;
+// 3: also flank_start_gap_form; BPSW_EXT_GAP1=0 keeps level 2
 int certify_level(const int8_t mat[25]) {
   if (!certify_enabled()) return 0;
   static const bool off2 = getenv("BPSW_EXT_CERT2") && atoi(getenv("BPSW_EXT_CERT2")) == 0;
@@ -95,7 +96,8 @@ int certify_level(const int8_t mat[25]) {
   for (int r = 0; r < 5; ++r)
     for (int c = 0; c < 5; ++c)
       if (!(r == c && r < 4) && mat[r * 5 + c] > -1) return 1;
-  return 2;
+  static const bool off3 = getenv("BPSW_EXT_GAP1") && atoi(getenv("BPSW_EXT_GAP1")) == 0;
+  return off3 ? 2 : 3;  // 3: also the one-base gap at the start of a flank (flank_start_gap_form)
 }
 
 int exact_match_score(const int8_t mat[25]) {

@@ -241,8 +241,9 @@ def test_two_gap_open_deficits(ctx, orc):
     """Flanks whose main diagonal has a deficit of two gap opens (+1) -- three substitutions under the default scoring, the
     closed form's second extension (bpsw_extend_core.h, "Two gap opens") -- in homopolymers and short-period repeats, with the
     substituted bases and the target tail chosen so that the shifted diagonals of its two exclusion tests match far more often
-    than by chance; three scorings of the family, a wide and a minimal band, both z-drop parses.  (tools/soak_cert2.py is the
-    long form of this test.)"""
+    than by chance; and flanks with a one-base gap at their start (flank_start_gap_form), with periodic sequence, small h0 and
+    extra differences that must make the form step back; three scorings of the family, a wide and a minimal band, both z-drop
+    parses.  (tools/soak_cert2.py is the long form of this test.)"""
     rng = np.random.default_rng(20261003)
 
     def side():
@@ -282,10 +283,26 @@ def test_two_gap_open_deficits(ctx, orc):
             tail = rng.integers(0, 5, extra)
         return q.tolist(), np.concatenate([r, tail]).astype(np.int64).tolist()
 
+    def gap_side():   # a one-base gap at (or near) the start of the flank and (nearly) nothing else: flank_start_gap_form
+        n = int(rng.integers(5, 132))
+        kind = int(rng.integers(0, 3))
+        q = (rng.integers(0, 4, n) if kind == 0 else np.tile(rng.integers(0, 4, int(rng.integers(1, 4))), n)[:n] if kind == 1
+             else rng.integers(0, 2, n)).astype(np.int64)
+        L = 1 if rng.random() < 0.8 else int(rng.integers(2, 4))
+        p = 0 if rng.random() < 0.8 else int(rng.integers(1, 6))
+        r = np.concatenate([q[:p], q[p + L:]]) if rng.random() < 0.5 else np.concatenate([q[:p], rng.integers(0, 4, L), q[p:]])
+        r = r.copy()
+        if rng.random() < 0.25 and len(r) > 2:
+            x = int(rng.integers(0, len(r))); r[x] = (r[x] + 1 + rng.integers(0, 3)) & 3
+        extra = int(rng.integers(0, 30))
+        tail = rng.integers(0, 5, extra) if rng.random() < 0.5 else np.tile(q[-3:], extra)[:extra]
+        return q.tolist(), np.concatenate([r, tail]).astype(np.int64).tolist()
+
     tasks = []
     for _ in range(3000):
-        l, r = side(), side()
-        tasks.append((l[0], l[1], r[0], r[1], int(rng.integers(16, 150)), len(l[0])))
+        l = gap_side() if rng.random() < 0.35 else side()
+        r = gap_side() if rng.random() < 0.35 else side()
+        tasks.append((l[0], l[1], r[0], r[1], int(rng.integers(3, 30)) if rng.random() < 0.2 else int(rng.integers(16, 150)), len(l[0])))
     soa = _manual_tasks(tasks)
     for (od, ed, oi, ei), w in (((6, 1, 6, 1), 100), ((6, 1, 6, 1), 2), ((1, 1, 1, 1), 100), ((3, 1, 3, 1), 100)):
         soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w

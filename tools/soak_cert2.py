@@ -23,7 +23,34 @@ total = bad_total = 0
 SHORT = os.environ.get("SOAK_SHORT") == "1"   # short flanks over tiny alphabets: shifted diagonals match all the time
 
 
+def gap_side(rng):
+    """a one-base (sometimes longer) gap at or near the start of the flank and nothing else, or nearly nothing: flank_start_gap_form"""
+    n = int(rng.integers(4, 40)) if SHORT else int(rng.integers(5, 132))
+    kind = int(rng.integers(0, 4))
+    q = (rng.integers(0, 4, n) if kind == 0 else np.tile(rng.integers(0, 4, int(rng.integers(1, 4))), n)[:n] if kind == 1
+         else rng.integers(0, 2, n) if kind == 2 else np.where(rng.random(n) < 0.6, rng.integers(0, 4), rng.integers(0, 4, n))).astype(np.int64)
+    L = 1 if rng.random() < 0.8 else int(rng.integers(2, 4))
+    p = 0 if rng.random() < 0.8 else int(rng.integers(1, 6))
+    if rng.random() < 0.5:      # the read has L bases more
+        r = np.concatenate([q[:p], q[p + L:]])
+    else:                       # the reference has L bases more
+        r = np.concatenate([q[:p], rng.integers(0, 4, L), q[p:]])
+    r = r.copy()
+    u = rng.random()
+    if u < 0.25 and len(r) > 2:  # one more difference somewhere: the form must refuse
+        x = int(rng.integers(0, len(r)))
+        r[x] = 4 if rng.random() < 0.2 else (r[x] + 1 + rng.integers(0, 3)) & 3
+    elif u < 0.3:
+        q = q.copy(); q[int(rng.integers(0, n))] = 4
+    extra = int(rng.integers(0, 30)) if rng.random() < 0.85 else 0
+    v = rng.random()
+    tail = rng.integers(0, 5, extra) if v < 0.5 else (np.tile(q[-3:], extra)[:extra] if v < 0.8 else np.tile(q, 2)[:extra])
+    return q.tolist(), np.concatenate([r, tail]).astype(np.int64).tolist()
+
+
 def side(rng):
+    if rng.random() < 0.35:
+        return gap_side(rng)
     n = int(rng.integers(4, 31)) if SHORT else int(rng.integers(8, 129))
     kind = int(rng.integers(1, 4)) if SHORT else int(rng.integers(0, 5))
     if kind == 0:
