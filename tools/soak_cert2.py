@@ -20,6 +20,16 @@ ctx, orc = bpsw_hip.Context(0), po.Oracle()
 total = bad_total = 0
 
 
+# matrices of the family the forms accept (match 1, everything else <= -1) and one they must refuse (a mismatch of 0 ... -1 only for N)
+def _mat(b, nscore):
+    m = po.default_mat(1, b).copy()
+    m[m == -1] = nscore if b != 1 else -1
+    for k in range(5):
+        m[4 * 5 + k] = nscore; m[k * 5 + 4] = nscore
+    return m
+
+
+MATS = [po.default_mat(), po.default_mat(), _mat(1, -1), _mat(2, -3), _mat(6, -1)] if os.environ.get("SOAK_MATS") == "1" else [po.default_mat()]
 SHORT = os.environ.get("SOAK_SHORT") == "1"   # short flanks over tiny alphabets: shifted diagonals match all the time
 
 
@@ -115,9 +125,10 @@ for rd in range(rounds):
         soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w
         wire = bpsw_hip.wire_pack(soa)
         for zmode, zdrop in ((0, 100), (1, 100), (1, 16), (0, 0)):
-            ctx.set_ext_scoring(po.default_mat(), zdrop, zmode)
+            mat = MATS[(rd + zmode + zdrop) % len(MATS)]
+            ctx.set_ext_scoring(mat, zdrop, zmode)
             got = ctx.extend_batch(wire).reshape(-1, 10)
-            want, _ = orc.wire_extend(wire, po.default_mat(), zdrop, zmode)
+            want, _ = orc.wire_extend(wire, mat, zdrop, zmode)
             want = want.reshape(-1, 10)
             bad = np.nonzero((got != want).any(axis=1))[0]
             total += soa.n
