@@ -354,7 +354,7 @@ class Context:
         st = g.as_struct()
         out_cnt = np.zeros(2 * g.group_size, dtype=np.int32)
         cap = int(g.regs.shape[0] + 4 * g.ref_rb.shape[0] + 16)
-        out = np.zeros(cap, dtype=ALNREG_DTYPE)
+        out = np.empty(cap, dtype=ALNREG_DTYPE)   # the library writes the first `total` records; zeroing 10 MB per call was most of the call
         total = C.c_int64(0)
         _chk(self.lib, self.lib.bpsw_matesw_group(self.h, C.byref(opt), C.byref(st), mode, _ptr(out_cnt), _ptr(out), cap,
                                                  C.byref(total)), "bpsw_matesw_group")

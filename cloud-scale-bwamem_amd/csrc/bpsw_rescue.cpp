@@ -390,6 +390,9 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       std::vector<int32_t> q_len(nj), t_len(nj);
       std::vector<int64_t> q_off(nj), t_off(nj);
       std::vector<uint8_t> q_rev(nj);
+      // only the mates some job aligns travel to the device (a tenth of the group's reads), not the whole read pool
+      std::vector<uint8_t> qpool;
+      std::vector<int64_t> mate_slot(2 * (size_t)G_, -1);
       std::vector<uint8_t> tpool;
       size_t tbytes = 0;
       if (!pac_mode)
@@ -399,7 +402,13 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       for (size_t t = 0; t < nj; ++t) {
         const int64_t x = want[t];
         const int e = end_of_row[(size_t)(x >> 2)], mate = e ^ 1, r = (int)(x & 3);
-        q_len[t] = g->seq_len[mate]; q_off[t] = g->seq_off[mate];
+        q_len[t] = g->seq_len[mate];
+        if (mate_slot[(size_t)mate] < 0) {
+          mate_slot[(size_t)mate] = (int64_t)qpool.size();
+          qpool.insert(qpool.end(), g->seq_pool + g->seq_off[mate], g->seq_pool + g->seq_off[mate] + g->seq_len[mate]);
+          qpool.resize((qpool.size() + 15) & ~(size_t)15, 0);
+        }
+        q_off[t] = mate_slot[(size_t)mate];
         q_rev[t] = ((r >> 1) != (r & 1)) ? 1 : 0;  // native/bwamem_pair.c:177
         t_len[t] = (int32_t)S.ref_len[x];
         if (pac_mode) {  // window_ok held, so the window starts at ref_rb[x] unclamped
@@ -414,8 +423,9 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       memset(&jobs, 0, sizeof jobs);
       jobs.n = (int32_t)nj; jobs.xtra = xtra_base;  // KSW_XBYTE is ignored by SWAlign
       jobs.q_len = q_len.data(); jobs.t_len = t_len.data(); jobs.q_off = q_off.data(); jobs.t_off = t_off.data();
-      jobs.q_rev = q_rev.data(); jobs.q_pool = g->seq_pool; jobs.t_pool = pac_mode ? nullptr : tpool.data();
-      jobs.q_pool_bytes = g->seq_pool_bytes; jobs.t_pool_bytes = pac_mode ? 0 : tpool.size();
+      if (qpool.empty()) qpool.resize(16, 0);
+      jobs.q_rev = q_rev.data(); jobs.q_pool = qpool.data(); jobs.t_pool = pac_mode ? nullptr : tpool.data();
+      jobs.q_pool_bytes = qpool.size(); jobs.t_pool_bytes = pac_mode ? 0 : tpool.size();
       const size_t first = S.results.size() / 7;
       S.results.resize(7 * (first + nj));
       S.used.resize(first + nj, 0);
