@@ -401,7 +401,7 @@ class Context:
         st.read_pool_bytes = b.read_pool.size
         cap = int(b.seed_len.shape[0]) + 8
         out_cnt = np.zeros(max(b.n_reads, 1), np.int32)
-        out = np.zeros(cap, dtype=ALNREG_DTYPE)
+        out = np.empty(cap, dtype=ALNREG_DTYPE)   # the library writes the first `total` records
         total = C.c_int64(0)
         _chk(self.lib, self.lib.bpsw_chain2aln_batch(self.h, C.byref(opt), C.byref(st), zdrop_mode, flags, _ptr(out_cnt), _ptr(out), cap,
                                                     C.byref(total)), "bpsw_chain2aln_batch")
@@ -613,7 +613,7 @@ def _ctx_sam_pe_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA"):
     need = C.c_size_t(0)
     cap = 1024 * max(1, 2 * g.group_size)
     while True:
-        buf = np.zeros(cap, np.uint8)
+        buf = np.empty(cap, np.uint8)   # the library writes off[-1] bytes
         rc = self.lib.bpsw_sam_pe_batch(self.h, C.byref(opt), C.byref(topt), C.byref(st), _ptr(buf), cap, _ptr(off), C.byref(need),
                                         _ptr(out_regs))
         if rc == -3 and need.value > cap:   # BPSW_ERR_CAPACITY
@@ -633,8 +633,8 @@ def _ctx_worker2_batch(self, opt: Opt, topt: TailOpt, g: "TailGroupSoA", rescue_
     need, total = C.c_size_t(0), C.c_int64(0)
     cap, rcap = 1024 * max(1, 2 * g.group_size), int(regs.shape[0]) + 8 * g.group_size + 64
     while True:
-        buf = np.zeros(cap, np.uint8)
-        out_regs = np.zeros(rcap, ALNREG_DTYPE)
+        buf = np.empty(cap, np.uint8)
+        out_regs = np.empty(rcap, ALNREG_DTYPE)
         rc = self.lib.bpsw_worker2_batch(self.h, C.byref(opt), C.byref(topt), C.byref(st), rescue_mode, _ptr(buf), cap, _ptr(off),
                                          C.byref(need), _ptr(cnt), _ptr(out_regs), rcap, C.byref(total))
         if rc == -3 and (need.value > cap or total.value > rcap):
