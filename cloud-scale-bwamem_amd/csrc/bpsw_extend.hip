@@ -24,7 +24,10 @@ namespace bpsw {
 namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr int EXT_CHUNK = 1;  // tasks per dequeue (larger chunks measured slower: the tail grows faster than the atomic traffic shrinks)
+#ifndef BPSW_EXT_CHUNK
+#define BPSW_EXT_CHUNK 1
+#endif
+constexpr int EXT_CHUNK = BPSW_EXT_CHUNK;  // tasks per dequeue (larger chunks measured slower: the tail grows faster than the atomic traffic shrinks)
 
 // stage the target of one side in LDS as 8*code bytes (the shift the register path feeds to v_bfe)
 __device__ void load_target_shifts(const int lane, const uint32_t* __restrict__ words, const int rStart, const int rLen,
