@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- pair-end 2x150 bp reads aligned/sec through the MI355X batched Smith-Waterman path.
+"""bench.py -- reads aligned/sec through the MI355X batched Smith-Waterman path, measured the way SURVEY.md 8(d) defines it:
+wall clock of the HOST-BUFFER C ABI calls the two JNI symbols make, H2D / D2H and the whole boundary-1 host layer included.
 
-One step = one pass of the hot path over one synthetic batch of PAIRS_PER_STEP read pairs (BASELINE.json
-configs[2] shape: 2x150 bp, 1 % substitutions, 0.1 % indels, 10 % of pairs need mate rescue):
-  * boundary 2: the extension wire batches of those reads (<= 32768 reads per batch, as the reference's
-    run_test.sh uses -bSWExtSize 32768), device-resident, through bpsw_extend_batch_device;
-  * boundary 1: the SWAlign2 rescue jobs of those pairs, device-resident, through bpsw_swalign2_batch_device.
-Inputs are already in HBM when the timed region starts.  N>1: one process per GPU (torch.distributed over
-RCCL for the barrier and the max-over-ranks only; the path has no data-path collective), each rank
-aligns its own shard of pairs ("weak" scaling: Spark partition -> device).
+One step = one pass of the hot path over PAIRS_PER_STEP DISTINCT synthetic read pairs (default workload: BASELINE.json
+configs[2], 2x150 bp, 1 % substitutions, 0.1 % indels, 10 % of the pairs need mate rescue; 1 048 576 pairs per step):
+  * boundary 2: one bpsw_extend_batch call per wire batch of 32 768 reads (the reference's -bSWExtSize 32768, run_test.sh:7;
+    the call behind MemChainToAlignBatched.scala:175-176), host wire bytes in, host int16 results out;
+  * boundary 1: one bpsw_matesw_group call per group of 4 096 pairs (the call behind native/jni_mate_sw.c:534 /
+    MemSamPe.scala:2091-2092): speculation, H2D, the SW kernel, D2H, the sequential replay and sort/dedup, host arrays out.
+The calls are made by T native host threads (csrc/bpsw_feeder.cpp), one context each, the way T Spark task threads of one
+executor call the JNI symbols; inputs are generated up front and live in host memory, outputs land in host memory, and a
+sample of the TIMED outputs is compared with the oracle after the timed region ("verified").
+`breakdown.device_resident` keeps the round-1 figure (inputs already in HBM, asynchronous device entries, kernels only).
 
+N>1: one process per GPU (torch.distributed over RCCL for the barrier and the max-over-ranks only; the path has no
+data-path collective), each rank streams its own shard of pairs ("weak" scaling: Spark partition -> device).
+
+--config {2,3,5} (or BENCH_CONFIG) selects the SURVEY.md 8(d) workload: 3 (default) as above, 2 = single-end 150 bp
+(extension only), 5 = 2x250 bp at 8 % / 2 % error with a 1 % tail at 20 % (the wide-band regime).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -19,9 +27,8 @@ import sys
 import time
 
 # The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), round robin; streams that
-# share a queue run one after the other.  A step's five batches each have their own stream, so with four queues two of them
-# were serialised (the kernel trace showed the rescue kernel and one extension launch on the same queue).  Must be set
-# before the runtime initialises; an executor that runs several task threads wants the same.
+# share a queue run one after the other.  Every feeder thread owns a context with its own stream.  Must be set before the
+# runtime initialises; an executor that runs several task threads wants the same.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -31,82 +38,242 @@ for _p in (os.path.join(ROOT, "cloud-scale-bwamem_amd"), os.path.join(ROOT, "ora
 
 import numpy as np  # noqa: E402
 
-READ_LEN = 150
 READS_PER_EXT_BATCH = 32768       # reference: -bSWExtSize 32768 (run_test.sh:7); idx travels as int16
-EXT_BATCHES_PER_STEP = 4
-PAIRS_PER_STEP = READS_PER_EXT_BATCH * EXT_BATCHES_PER_STEP // 2   # 65536 pairs = 131072 reads
-RESCUE_JOBS_PER_PAIR = 0.11       # p_resc = 10 % (+ multi-anchor pairs), SURVEY.md 8(d) config 3
+PAIRS_PER_GROUP = 4096            # boundary-1 group size
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+INT_VALU_PEAK_OPS = 256 * 4 * 16 * 2.4e9   # 256 CUs x 4 SIMD16 x 2.4 GHz: int32 lane-ops/s at one op per lane per cycle
+
+# SURVEY.md 8(d) workloads, keyed by the survey's config number
+WORKLOADS = {
+    3: dict(label="configs[2]: 10M-pair-shaped stream of pair-end 2x150bp synthetic reads (1% sub, 0.1% indel) vs a chr21-sized "
+                  "coordinate space, batched seed extension + batched pair-end SW rescue (10% of pairs)",
+            metric="pair-end 2x150bp reads aligned/sec", read_len=150, sub=0.01, indel=0.001, tail_frac=0.0, tail_sub=0.2,
+            tail_indel=0.02, p_resc=0.10, mate_sub=0.02, mate_indel=0.002, paired=True, ext_batches=64, groups=256),
+    2: dict(label="configs[1]: single-end 150bp synthetic reads (1% sub, 0.1% indel), HIP seed extension only",
+            metric="single-end 150bp reads aligned/sec", read_len=150, sub=0.01, indel=0.001, tail_frac=0.0, tail_sub=0.2,
+            tail_indel=0.02, p_resc=0.0, mate_sub=0.0, mate_indel=0.0, paired=False, ext_batches=32, groups=0),
+    5: dict(label="configs[4]: pair-end 2x250bp high-error synthetic reads (8% sub, 2% indel, 1% of reads at 20%/2%), "
+                  "wide-band extension + pair-end SW rescue (25% of pairs)",
+            metric="pair-end 2x250bp reads aligned/sec", read_len=250, sub=0.08, indel=0.02, tail_frac=0.01, tail_sub=0.20,
+            tail_indel=0.02, p_resc=0.25, mate_sub=0.08, mate_indel=0.02, paired=True, ext_batches=8, groups=32),
+}
 
 
-def build_inputs(rank: int):
-    from bpsw_hip import synth, wire_pack
-    seed0 = synth.CONFIG_SEED_BASE + 3 + 1000 * rank
-    wires, ntasks, soas = [], [], []
-    for b in range(EXT_BATCHES_PER_STEP):
-        soa = synth.ext_tasks(READS_PER_EXT_BATCH, read_len=READ_LEN, sub_rate=0.01, indel_rate=0.001, n_rate=0.001,
-                              seed=seed0 + b)
-        wires.append(wire_pack(soa))
-        soas.append(soa)
-        ntasks.append(soa.n)
-    n_jobs = int(PAIRS_PER_STEP * RESCUE_JOBS_PER_PAIR)
-    jobs = synth.sw_jobs(n_jobs, read_len=READ_LEN, win_min=400, win_max=400, sub_rate=0.02, indel_rate=0.002,
-                         unrelated_frac=0.05, decoy_frac=0.1, rev_frac=1.0, seed=seed0 + 100)
-    return soas, wires, ntasks, jobs
+def ext_seed(cfg_no, rank, b):
+    from bpsw_hip import synth
+    return synth.CONFIG_SEED_BASE + cfg_no + 1000 * rank + 7 * b
 
 
-def cpu_baseline(soas, wires, ntasks, jobs, xtra):
-    """The reference's CPU path timed on this box's host cores, on a bounded sample of the same step.
+def grp_seed(cfg_no, rank, g):
+    from bpsw_hip import synth
+    return synth.CONFIG_SEED_BASE + cfg_no + 1000 * rank + 500_000 + 13 * g
 
-    kind "reference": oracle/_ref/libbwaref.so (the reference's own C built in place by oracle/Makefile): ksw_extend2 under
-    the extension() control for boundary 2 and the SSE2 ksw_align2 that jniNative.so runs for boundary 1, one whole step
-    per thread on every host core (the reference is one Spark task thread per core).  kind "port": the scalar oracle
-    (oracle/bpsw_oracle.c), one thread, when the reference build did not travel with the snapshot."""
+
+def make_ext_soa(W, cfg_no, rank, b):
+    from bpsw_hip import synth
+    return synth.ext_tasks(READS_PER_EXT_BATCH, read_len=W["read_len"], sub_rate=W["sub"], indel_rate=W["indel"], n_rate=0.001,
+                           tail_frac=W["tail_frac"], tail_sub_rate=W["tail_sub"], tail_indel_rate=W["tail_indel"],
+                           seed=ext_seed(cfg_no, rank, b))
+
+
+def make_group(W, cfg_no, rank, g):
+    from bpsw_hip import synth
+    return synth.rescue_group_fast(PAIRS_PER_GROUP, read_len=W["read_len"], seed=grp_seed(cfg_no, rank, g), p_resc=W["p_resc"],
+                                   sub_rate=W["mate_sub"], indel_rate=W["mate_indel"])
+
+
+def build_inputs(W, cfg_no, rank, workers):
+    """every wire batch and rescue group of one step, distinct, in host memory (numpy); generation is threaded (the C
+    generators release the GIL)"""
+    from concurrent.futures import ThreadPoolExecutor
+    import bpsw_hip
+
+    def one_wire(b):
+        soa = make_ext_soa(W, cfg_no, rank, b)
+        return bpsw_hip.wire_pack(soa), soa.n
+
+    with ThreadPoolExecutor(workers) as ex:
+        wn = list(ex.map(one_wire, range(W["ext_batches"])))
+        groups = list(ex.map(lambda g: make_group(W, cfg_no, rank, g), range(W["groups"])))
+    return [w for w, _ in wn], [n for _, n in wn], groups
+
+
+def gpu_numa_cpus(dev_index):
+    """CPUs of the NUMA node the GPU hangs off (sysfs), restricted to this process's affinity; [] when unknown"""
+    try:
+        import torch
+        bus = torch.cuda.get_device_properties(dev_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id") else None
+        dom = getattr(torch.cuda.get_device_properties(dev_index), "pci_domain_id", 0)
+        devn = getattr(torch.cuda.get_device_properties(dev_index), "pci_device_id", 0)
+        if bus is None:
+            return [], None
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{devn:02x}.0/numa_node"
+        node = int(open(path).read().strip())
+        if node < 0:
+            return [], node
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0)
+        return [c for c in cpus if c in allowed], node
+    except Exception:
+        return [], None
+
+
+def reduce_over_ranks(elapsed, device):
+    """the N>1 protocol of the contract: MAX of the ranks' elapsed times, and how many ranks took part (SUM of ones);
+    `device` is where the reduction tensors live (the rank's GPU under RCCL, "cpu" under gloo)"""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    one = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(one.item())
+
+
+def whole_job_rate(reads_per_step_per_rank, steps, world, elapsed_max):
+    """`value`: the reads ALL ranks aligned in the timed region over the slowest rank's time"""
+    return reads_per_step_per_rank * steps * world / elapsed_max
+
+
+def cpu_baseline(W, cfg_no, rank, xtra):
+    """The reference's CPU kernels timed on this box's host cores, on a bounded sample of the same workload.
+
+    kind "reference": oracle/_ref/libbwaref.so (the reference's own C built in place by oracle/Makefile): the reference's
+    ksw_extend2 under the builder's restatement of the extension() control loop (oracle/ref_shim.c) for boundary 2, and the
+    reference's own mem_group_matesw (SSE2 ksw_align2 + its bookkeeping, native/bwamem_pair.c:115-228) for boundary 1 -- NOT
+    the Scala+JNI path under a JVM (no JVM exists here); one unit per thread on every host core.
+    kind "port": the scalar oracle (oracle/bpsw_oracle.c), one thread, when the reference build did not travel."""
     import pyoracle as po
-    n_jobs = len(jobs["q_len"])
+    soa = make_ext_soa(W, cfg_no, rank, 0)
+    n_grp = (READS_PER_EXT_BATCH // 2) // PAIRS_PER_GROUP if W["paired"] else 0   # groups holding the same number of reads as one wire batch
+    groups = [make_group(W, cfg_no, rank, g) for g in range(n_grp)]
+    unit_reads = READS_PER_EXT_BATCH
     if os.path.exists(po.REF_SO):
         from concurrent.futures import ThreadPoolExecutor
         ref = po.Ref()
         mat = po.default_mat()
+        ropt = po.Oracle().default_opt()
         cores = max(1, min(len(os.sched_getaffinity(0)), 64))
 
-        def one_step(_):
-            for soa in soas:
-                ref.extend_batch(soa, mat)
-            ref.align2_batch(mat, 6, 1, 6, 1, xtra, **jobs)
+        def unit(_):
+            ref.extend_batch(soa, mat)
+            for g in groups:
+                ref.matesw_group(ropt, g)
 
         one = time.perf_counter()
-        one_step(0)
+        unit(0)
         one = time.perf_counter() - one
-        reps = max(1, int(round(3.0 / max(one, 1e-3))))          # ~3 s of wall per thread, ~3 s x cores of CPU work
+        reps = max(1, int(round(4.0 / max(one, 1e-3))))          # ~4 s of wall per thread
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:                     # ctypes releases the GIL inside the C loops
-            list(ex.map(one_step, range(cores * reps)))
+            list(ex.map(unit, range(cores * reps)))
         dt = time.perf_counter() - t0
         return {
-            "value": round(cores * reps * 2 * PAIRS_PER_STEP / dt, 1), "unit": "reads/s", "cores": cores, "kind": "reference",
-            "sample": f"{cores * reps} whole steps ({sum(ntasks)} extension tasks + {n_jobs} rescue jobs each) in {dt:.2f}s on "
-                      f"{cores} threads; reference ksw_extend2 (scalar) + ksw_align2 (SSE2) from oracle/_ref; "
-                      f"1 thread alone: {2 * PAIRS_PER_STEP / one:.0f} reads/s",
+            "value": round(cores * reps * unit_reads / dt, 1), "unit": "reads/s", "cores": cores, "kind": "reference",
+            "sample": f"{cores * reps} units of {unit_reads} reads ({soa.n} extension tasks + {n_grp} rescue groups of {PAIRS_PER_GROUP} pairs) "
+                      f"in {dt:.2f}s on {cores} threads; reference C kernels (scalar ksw_extend2 under the builder's batch loop, "
+                      f"mem_group_matesw with SSE2 ksw_align2) from oracle/_ref, no JVM; 1 thread alone: {unit_reads / one:.0f} reads/s",
         }
+    import bpsw_hip
     orc = po.Oracle()
+    wire = bpsw_hip.wire_pack(soa)
     t0 = time.perf_counter()
-    _, cells_ext = orc.wire_extend(wires[0])
+    orc.wire_extend(wire)
     t_ext = time.perf_counter() - t0
-    ns = min(1500, n_jobs)
-    sub = dict(jobs)
-    for k in ("q_len", "t_len", "q_off", "t_off", "q_rev"):
-        sub[k] = jobs[k][:ns]
+    t_grp = 0.0
+    if groups:
+        t0 = time.perf_counter()
+        orc.matesw_group(orc.default_opt(), groups[0], po.RESCUE_C)
+        t_grp = time.perf_counter() - t0
+    sec_per_read = t_ext / unit_reads + (t_grp / (2 * PAIRS_PER_GROUP) if groups else 0.0)
+    return {"value": round(1.0 / sec_per_read, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"one wire batch of {unit_reads} reads in {t_ext:.2f}s + one rescue group of {PAIRS_PER_GROUP} pairs in {t_grp:.2f}s, "
+                      f"oracle/bpsw_oracle.c single thread"}
+
+
+def verify_sample(W, cfg_no, rank, wires, ext_outs, groups, grp_cnts, grp_regs, grp_totals, rng):
+    """a random sample of the TIMED outputs against the oracle: ~2k extension tasks out of two wire batches, and whole
+    rescue groups until >= 500 SW jobs are covered.  Returns the counts; raises on any difference."""
+    import bpsw_hip
+    import pyoracle as po
+    orc = po.Oracle()
+    n_ext = n_pairs = n_jobs = 0
+    if wires:
+        for b in rng.choice(len(wires), size=min(2, len(wires)), replace=False):
+            soa = make_ext_soa(W, cfg_no, rank, int(b))
+            sel = np.sort(rng.choice(soa.n, size=min(1024, soa.n), replace=False))
+            sub_wire = bpsw_hip.wire_pack(soa.subset(sel))
+            want, _ = orc.wire_extend(sub_wire)
+            got = ext_outs[int(b)].reshape(-1, 10)[sel]
+            if not np.array_equal(got, np.asarray(want).reshape(-1, 10)):
+                raise SystemExit(f"bench: extension outputs of timed wire batch {b} differ from the oracle")
+            n_ext += len(sel)
+    gi = list(rng.permutation(len(groups)))
+    while gi and n_jobs < 500:
+        g = int(gi.pop())
+        wcnt, wregs, jobs, _ = orc.matesw_group(orc.default_opt(), groups[g], po.RESCUE_C)
+        got_cnt, got = grp_cnts[g], grp_regs[g][: int(grp_totals[g])]
+        if not (np.array_equal(got_cnt, wcnt) and len(got) == len(wregs) and all(np.array_equal(got[f], wregs[f]) for f in got.dtype.names)):
+            raise SystemExit(f"bench: rescue outputs of timed group {g} differ from the oracle")
+        n_pairs += groups[g].group_size
+        n_jobs += int(jobs)
+    return {"ext_tasks": int(n_ext), "rescue_pairs": int(n_pairs), "rescue_jobs": int(n_jobs), "mismatches": 0}
+
+
+def device_resident_breakdown(W, cfg_no, rank, wires, ntasks, dev, local_rank, reps):
+    """the round-1 measurement, kept as a breakdown: four wire batches + the rescue jobs of the same 65 536 pairs already in
+    HBM, issued through the asynchronous device entries on five contexts; kernels only (no H2D/D2H, no boundary-1 host layer)"""
+    import torch
+    import bpsw_hip
+    from bpsw_hip import synth
+    nb = min(4, len(wires))
+    pairs = nb * READS_PER_EXT_BATCH // 2
+    ctxs = [bpsw_hip.Context(local_rank) for _ in range(nb + 1)]
+    opt = bpsw_hip.default_opt()
+    xtra = bpsw_hip.KSW_XSUBO | bpsw_hip.KSW_XSTART | bpsw_hip.KSW_XBYTE | 19
+    d_wires = [torch.from_numpy(w).to(dev) for w in wires[:nb]]
+    d_outs = [torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks[:nb]]
+    n_jobs = int(pairs * 0.11) if W["paired"] else 0
+    sj = d_sw_out = None
+    if n_jobs:
+        jobs = synth.sw_jobs(n_jobs, read_len=W["read_len"], win_min=400, win_max=400, sub_rate=W["mate_sub"], indel_rate=W["mate_indel"],
+                             unrelated_frac=0.05, decoy_frac=0.1, rev_frac=1.0, seed=ext_seed(cfg_no, rank, 0) + 100)
+        d_jobs = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in jobs.items()}
+        d_sw_out = torch.zeros((n_jobs, 7), dtype=torch.int32, device=dev)
+        sj = bpsw_hip.SwJobs()
+        sj.n, sj.xtra = n_jobs, xtra
+        for k in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool"):
+            setattr(sj, k, d_jobs[k].data_ptr())
+        sj.q_pool_bytes, sj.t_pool_bytes = d_jobs["q_pool"].numel(), d_jobs["t_pool"].numel()
+    torch.cuda.synchronize(dev)
+
+    def step():
+        for cx, w, n, dw, do in zip(ctxs, wires[:nb], ntasks[:nb], d_wires, d_outs):
+            cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)
+        if sj is not None:
+            ctxs[-1].swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
+
+    def wait():
+        for cx in ctxs:
+            cx.last_kernel_ms()
+
+    for _ in range(3):
+        step()
+        wait()
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    _, cells_sw = orc.sw_align2_jobs(orc.default_opt(), xtra, **sub)
-    t_sw = time.perf_counter() - t0
-    # seconds of CPU per read of the step = extension share + rescue share
-    sec_per_read = t_ext / READS_PER_EXT_BATCH + (t_sw / ns) * n_jobs / (2.0 * PAIRS_PER_STEP)
-    return {
-        "value": round(1.0 / sec_per_read, 1), "unit": "reads/s", "cores": 1, "kind": "port",
-        "sample": f"{ntasks[0]} extension tasks ({READS_PER_EXT_BATCH} reads) in {t_ext:.2f}s + {ns} SWAlign2 jobs in {t_sw:.2f}s, "
-                  f"oracle/bpsw_oracle.c single thread; {cells_ext / t_ext / 1e9:.3f} / {cells_sw / t_sw / 1e9:.3f} GCUPS",
-    }
+    for _ in range(reps):
+        step()
+        wait()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    for cx in ctxs:
+        cx.close()
+    return {"reads_per_s": round(2 * pairs / dt, 1), "ms_per_65536_pairs": round(1e3 * dt * 65536 / pairs, 4), "pairs": pairs, "rescue_jobs": n_jobs,
+            "note": "inputs resident in HBM, asynchronous *_device entries, kernels only: no H2D/D2H, no boundary-1 host layer; NOT `value`"}
 
 
 def tail_breakdown(ctx, opt, n_pairs: int = 4096):
@@ -140,9 +307,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=int(os.environ.get("BENCH_CONFIG", "3")), choices=sorted(WORKLOADS),
+                    help="SURVEY.md 8(d) workload number (3 = BASELINE.json configs[2], the metric's configuration)")
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("BENCH_THREADS", "0")), help="host feeder threads per GPU (0: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tail", action="store_true", help="skip the worker2-tail breakdown entry")
+    ap.add_argument("--no-extras", action="store_true", help="skip every breakdown outside the timed region")
     args = ap.parse_args()
+    W = WORKLOADS[args.config]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -154,6 +326,19 @@ def main():
     if os.environ.get("BENCH_FORCE_DEVICE") is not None:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     backend = os.environ.get("BENCH_BACKEND", "nccl")
+
+    # ---- host placement: feeder threads (and the pinned staging they first touch) on the NUMA node of this rank's GPU ----
+    numa_cpus, numa_node = gpu_numa_cpus(local_rank)
+    allowed = sorted(os.sched_getaffinity(0))
+    ranks_on_node = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    share = numa_cpus if numa_cpus else allowed[(local_rank % ranks_on_node)::ranks_on_node] if distributed else allowed
+    n_threads = args.threads if args.threads > 0 else max(2, min(16, len(share)))
+    if share and (numa_cpus or distributed):
+        try:
+            os.sched_setaffinity(0, share)   # before the inputs are generated: first touch puts them on the GPU's node
+        except OSError:
+            pass
+
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,77 +353,25 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import bpsw_hip
+    from bpsw_hip import feeder as fd
     import ctypes as C
-    # One context per extension batch of the step plus one for the rescue jobs, all on this rank's GPU: each context
-    # owns a stream, so the independent batches of a step overlap on the device the way concurrent Spark task
-    # threads of one executor overlap their JNI calls (the reference native code is re-entrant for that reason).
-    # BENCH_STEPS_IN_FLIGHT=n (default 1) rotates n such sets over the steps: the entries are asynchronous, so the host can
-    # submit step k+1 while the device still works on step k; a set is reused only after its previous step has been waited
-    # for, and the timed region ends with every step complete.  Measured on MI355X: 1.451 / 1.430 / 1.420 ms per step for
-    # n = 1 / 2 / 3 -- the device is already busy throughout a step, so the default stays 1 and the per-launch durations
-    # the roofline entry uses are not stretched by overlap between steps.
-    STEPS_IN_FLIGHT = max(1, int(os.environ.get("BENCH_STEPS_IN_FLIGHT", "1")))
-    SW_FIRST = os.environ.get("BENCH_SW_FIRST", "0") == "1"   # issue order of the step's five independent batches
-    sets = [[bpsw_hip.Context(local_rank) for _ in range(EXT_BATCHES_PER_STEP + 1)]  # no fallback: raises without a gfx950 device
-            for _ in range(STEPS_IN_FLIGHT)]
-    ctxs = sets[0]
-    ctx = ctxs[-1]
     opt = bpsw_hip.default_opt()
     xtra = bpsw_hip.KSW_XSUBO | bpsw_hip.KSW_XSTART | bpsw_hip.KSW_XBYTE | 19   # MemSamPe.scala:1187-1189
 
-    soas, wires, ntasks, jobs = build_inputs(rank)
-    # ---- make everything resident in HBM before the timed region ---------------------------------
-    d_wires = [torch.from_numpy(w).to(dev) for w in wires]
-    d_outs_all = [[torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks] for _ in sets]
-    d_outs = d_outs_all[0]
-    d_jobs = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in jobs.items()}
-    n_jobs = int(jobs["q_len"].shape[0])
-    d_sw_out_all = [torch.zeros((n_jobs, 7), dtype=torch.int32, device=dev) for _ in sets]
-    d_sw_out = d_sw_out_all[0]
-    sj = bpsw_hip.SwJobs()
-    sj.n, sj.xtra = n_jobs, xtra
-    for k in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool"):
-        setattr(sj, k, d_jobs[k].data_ptr())
-    sj.q_pool_bytes, sj.t_pool_bytes = d_jobs["q_pool"].numel(), d_jobs["t_pool"].numel()
-    torch.cuda.synchronize(dev)
-
-    ext_ms_sum, sw_ms_sum, ext_launches, sw_launches = 0.0, 0.0, 0, 0
-    busy = [False] * len(sets)      # set has a submitted step that has not been waited for
-    counted = [False] * len(sets)   # ... and that step belongs to the timed region
-    turn = 0
-
-    def collect(k: int):
-        """wait for the step submitted on set k; HIP events on the launch streams, recorded inside the library"""
-        nonlocal ext_ms_sum, sw_ms_sum, ext_launches, sw_launches
-        if not busy[k]:
-            return
-        for cx in sets[k][:-1]:
-            e, _ = cx.last_kernel_ms()
-            if counted[k]:
-                ext_ms_sum += e
-                ext_launches += 1
-        _, s_ms = sets[k][-1].last_kernel_ms()
-        if counted[k]:
-            sw_ms_sum += s_ms
-            sw_launches += 1
-        busy[k] = False
-
-    def step(timed: bool):
-        nonlocal turn
-        k = turn % len(sets)
-        turn += 1
-        collect(k)                  # the step this set ran STEPS_IN_FLIGHT steps ago
-        if SW_FIRST:
-            sets[k][-1].swalign2_batch_device(opt, sj, d_sw_out_all[k].data_ptr(), 0)
-        for cx, w, n, dw, do in zip(sets[k], wires, ntasks, d_wires, d_outs_all[k]):
-            cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)   # asynchronous, context's own stream
-        if not SW_FIRST:
-            sets[k][-1].swalign2_batch_device(opt, sj, d_sw_out_all[k].data_ptr(), 0)
-        busy[k], counted[k] = True, timed
-
-    def drain():
-        for k in range(len(sets)):
-            collect(k)
+    t_gen = time.perf_counter()
+    wires, ntasks, groups = build_inputs(W, args.config, rank, workers=max(2, min(16, len(allowed))))
+    t_gen = time.perf_counter() - t_gen
+    ext_outs = [np.zeros(10 * n, np.int16) for n in ntasks]
+    structs = [g.as_struct() for g in groups]
+    grp_cnts = [np.zeros(2 * g.group_size, np.int32) for g in groups]
+    grp_regs = [np.empty(int(g.regs.shape[0] + g.ref_rb.shape[0] + 16), bpsw_hip.ALNREG_DTYPE) for g in groups]
+    only = os.environ.get("BENCH_ONLY", "")      # diagnostics: "ext" / "grp" time one boundary alone (the JSON line then is not the metric)
+    if only == "ext":
+        groups, structs, grp_cnts, grp_regs = [], [], [], []
+    elif only == "grp":
+        wires, ntasks, ext_outs = [], [], []
+    items, order = fd.make_items(wires, ext_outs, groups, structs, grp_cnts, grp_regs)
+    F = fd.Feeder(n_threads, local_rank, opt, bpsw_hip.RESCUE_C, cpus=share if (numa_cpus or distributed) else None)  # no fallback: raises without a gfx950 device
 
     def barrier():
         if distributed:
@@ -246,93 +379,44 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step(False)
-    drain()
+        F.run(items)
+    F.reset_stats()
     barrier()
+    cpu0 = os.times()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
-    drain()                         # every one of the K steps complete, results in HBM
+        F.run(items)                 # every call of the step complete, results in host memory
     barrier()
     elapsed = time.perf_counter() - t0
+    cpu1 = os.times()
+    cpu_busy = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / elapsed   # host CPUs busy during the timed region (this rank)
+    st = F.stats_sum()
+    call_ms = {"extend": [it.ms for it in items if it.kind == 0], "matesw_group": [it.ms for it in items if it.kind == 1]}
+    grp_totals = [0] * len(groups)
+    for it, (kind, i) in zip(items, order):
+        if kind == 1:
+            grp_totals[i] = it.out_total
+    ranks_seen = world
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, ranks_seen = reduce_over_ranks(elapsed, dev if backend == "nccl" else "cpu")
 
-    reads_total = 2 * PAIRS_PER_STEP * args.steps * world
-    value = reads_total / elapsed
+    reads_per_step = READS_PER_EXT_BATCH * W["ext_batches"]
+    pairs_per_step = reads_per_step // 2 if W["paired"] else 0
+    assert only or not W["paired"] or pairs_per_step == PAIRS_PER_GROUP * W["groups"]
+    value = whole_job_rate(reads_per_step, args.steps, world, elapsed)
 
-    # ---- the two boundaries on their own (outside the timed region of `value`) ------
-    def time_only(fn, reps):
-        fn()
-        barrier()
-        t = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        barrier()
-        return (time.perf_counter() - t) / reps
+    # ---- a sample of the timed outputs against the oracle (outside the timed region; the only use of oracle/ besides cpu_baseline)
+    verified = verify_sample(W, args.config, rank, wires, ext_outs, groups, grp_cnts, grp_regs, grp_totals,
+                             np.random.default_rng(1234 + rank)) if rank == 0 else None
 
-    def ext_only():
-        for cx, w, n, dw, do in zip(ctxs, wires, ntasks, d_wires, d_outs):
-            cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)
-
-    def sw_only():
-        ctx.swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
-
-    reps = max(3, min(args.steps, 10))
-    t_ext_only, t_sw_only = time_only(ext_only, reps), time_only(sw_only, reps)
-
-    # ---- what an executor with ten busy task threads would see: two steps in flight (outside `value`) -----------------
-    two_in_flight = None
-    if STEPS_IN_FLIGHT == 1:
-        try:
-            extra = [bpsw_hip.Context(local_rank) for _ in range(EXT_BATCHES_PER_STEP + 1)]
-            sets2 = [sets[0], extra]
-            outs2 = [d_outs_all[0], [torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks]]
-            sw2 = [d_sw_out_all[0], torch.zeros((n_jobs, 7), dtype=torch.int32, device=dev)]
-
-            def submit(k):
-                for cx, w, n, dw, do in zip(sets2[k], wires, ntasks, d_wires, outs2[k]):
-                    cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)
-                sets2[k][-1].swalign2_batch_device(opt, sj, sw2[k].data_ptr(), 0)
-
-            def wait(k):
-                for cx in sets2[k]:
-                    cx.last_kernel_ms()
-
-            for k in (0, 1):
-                submit(k)
-            for k in (0, 1):
-                wait(k)
-            barrier()
-            t = time.perf_counter()
-            n2 = 2 * reps
-            submit(0)
-            for i in range(1, n2):
-                submit(i & 1)          # the entry itself waits for the step this set ran two steps ago
-            for k in (0, 1):
-                wait(k)
-            barrier()
-            two_in_flight = round(2 * PAIRS_PER_STEP * n2 / (time.perf_counter() - t), 1)
-            del extra
-        except Exception as e:  # noqa: BLE001 -- an extra line must never cost the bench its JSON
-            two_in_flight = repr(e)
-
-    # ---- worker2's tail, outside `value`: host-inclusive rate of one calling thread + kernel rate ----
-    tail = None
-    if rank == 0 and world == 1 and not args.no_tail:   # single-GPU runs only: the scaling runs must not make the other ranks wait
-        try:
-            tail = tail_breakdown(ctx, opt)
-        except Exception as e:  # noqa: BLE001 -- a breakdown line must never cost the bench its JSON
-            tail = {"error": repr(e)}
-
-    # ---- roofline of the dominant kernel (algorithmic bytes: DESIGN.md) -------------
-    ext_bytes = sum(int(w.size) + 20 * n for w, n in zip(wires, ntasks)) / len(wires)          # per launch
-    sw_bytes = float(jobs["q_len"].sum() + jobs["t_len"].sum() + 28 * n_jobs)                  # per launch
-    ext_avg_ms = ext_ms_sum / max(ext_launches, 1)
-    sw_avg_ms = sw_ms_sum / max(sw_launches, 1)
-    dominant = "extend" if ext_ms_sum >= sw_ms_sum else "swalign2"
+    # ---- per-kernel figures from the HIP events the library records on its launch streams during the timed region ----
+    ext_launches, sw_launches = int(st["ext_calls"]), int(st["sw_calls"])
+    ext_avg_ms = st["ext_kernel_ms"] / max(ext_launches, 1)
+    sw_avg_ms = st["sw_kernel_ms"] / max(sw_launches, 1)
+    ext_bytes = (sum(int(w.size) for w in wires) + 20 * sum(ntasks)) / max(len(wires), 1)      # per launch (SURVEY.md 8d B_ext)
+    win_len = float(np.mean([float(g.ref_len[g.ref_len > 0].mean()) for g in groups[:8]])) if groups else 0.0
+    sw_bytes = (st["sw_jobs"] / max(sw_launches, 1)) * (W["read_len"] + win_len + 28)           # per launch (B_sw)
+    dominant = "extend" if st["ext_kernel_ms"] >= st["sw_kernel_ms"] else "swalign2"
     dom_bytes, dom_ms = (ext_bytes, ext_avg_ms) if dominant == "extend" else (sw_bytes, sw_avg_ms)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = None
@@ -342,56 +426,64 @@ def main():
             traffic = json.load(open(pmc_path)).get(dominant)
         except Exception:
             traffic = None
+    host_ms = {k: {"mean": round(float(np.mean(v)), 4), "p50": round(float(np.median(v)), 4), "max": round(float(np.max(v)), 4)} if v else None
+               for k, v in call_ms.items()}
+    pcie_bytes_per_step = sum(int(w.size) for w in wires) + 20 * sum(ntasks)   # boundary 2 both ways; boundary 1 below
+    pcie_bytes_per_step += int((st["sw_jobs"] / max(args.steps, 1)) * (W["read_len"] + win_len + 28 + 29))
 
-    # What actually binds these kernels: instruction issue.  Wave-instructions per step from the committed
-    # PMC pass, over the live step time, against the measured issue rates of one SIMD (tools/ubench/valu_rate.hip).
-    issue = None
-    try:
-        pi = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
-        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        per_step = EXT_BATCHES_PER_STEP * (pi["extend"]["valu"] + pi["extend"]["salu"] + pi["ext_prepass"]["valu"] + pi["ext_prepass"]["salu"]) \
-            + pi["swalign2"]["valu"] + pi["swalign2"]["salu"] + pi["sw_prepass"]["valu"] + pi["sw_prepass"]["salu"]
-        ns = 1e9 * (elapsed / args.steps) / (per_step / (4.0 * n_cu))
-        issue = {"wave_insts_per_step": int(per_step), "simds": 4 * n_cu, "ns_per_inst_per_simd": round(ns, 3),
-                 "measured_issue_ns": {"one_kind_stream": 1.8, "mixed_valu_salu_streams": 1.15},
-                 "frac_of_mixed_issue_rate": round(1.15 / ns, 3),
-                 "note": "instruction counts: profiles/pmc_issue.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU, same command); "
-                         "issue rates: profiles/r01g_valu_rate.txt, profiles/r01_microbench_issue.txt"}
-    except Exception:
-        issue = None
+    extras = {}
+    if not args.no_extras:
+        try:
+            extras["device_resident"] = device_resident_breakdown(W, args.config, rank, wires, ntasks, dev, local_rank, reps=max(3, min(args.steps, 10)))
+        except Exception as e:  # noqa: BLE001 -- a breakdown line must never cost the bench its JSON
+            extras["device_resident"] = {"error": repr(e)}
+        if rank == 0 and world == 1 and not args.no_tail and args.config == 3:
+            try:
+                extras["worker2_tail"] = tail_breakdown(F.ctxs[0], opt)
+            except Exception as e:  # noqa: BLE001
+                extras["worker2_tail"] = {"error": repr(e)}
 
     out = {
-        "metric": "pair-end 2x150bp reads aligned/sec",
+        "metric": W["metric"],
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "configs[2]: pair-end 2x150bp synthetic reads (1% sub, 0.1% indel), batched seed "
-                               "extension + batched pair-end SW rescue (10% of pairs), 1 MI355X per rank",
-                   "pairs_per_step_per_gpu": PAIRS_PER_STEP, "ext_tasks_per_step": int(sum(ntasks)),
-                   "rescue_jobs_per_step": n_jobs, "steps_in_flight": STEPS_IN_FLIGHT,
-                   "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                   "parallelism": f"partition->device x{world} (no collective)"},
+        "vs_baseline": None, "dtype": "int32 (extension) / packed u16 (rescue SW, exact under the 255 score cap)", "data": "synthetic",
+        "config": {"workload": W["label"], "survey_config": args.config,
+                   "pairs_per_step_per_gpu": pairs_per_step, "reads_per_step_per_gpu": reads_per_step,
+                   "ext_batches_per_step": W["ext_batches"], "reads_per_ext_batch": READS_PER_EXT_BATCH,
+                   "ext_tasks_per_step": int(sum(ntasks)), "rescue_groups_per_step": W["groups"], "pairs_per_group": PAIRS_PER_GROUP,
+                   "rescue_jobs_per_step": int(st["sw_jobs"] / max(args.steps, 1)),
+                   "distinct_pairs_streamed": int(pairs_per_step * args.steps * world) if W["paired"] else 0,
+                   "timed_region": "host buffers in, host buffers out: bpsw_extend_batch per wire batch + bpsw_matesw_group per group "
+                                   "(H2D, kernels, D2H, speculate/replay, sort/dedup all inside)",
+                   "host_threads_per_gpu": n_threads, "numa_node": numa_node, "feeder_cpus": len(share),
+                   "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "ranks_seen": ranks_seen,
+                   "parallelism": f"partition->device x{world} (no collective)", "input_generation_s": round(t_gen, 1)},
+        "verified": verified,
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4)},
-        "issue": issue,
-        "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes)},
-                    "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes)}},
-        "breakdown": {"extend_only_reads_per_s": round(2 * PAIRS_PER_STEP / t_ext_only, 1), "extend_only_ms_per_step": round(1e3 * t_ext_only, 3),
-                      "rescue_only_jobs_per_s": round(n_jobs / t_sw_only, 1), "rescue_only_ms_per_step": round(1e3 * t_sw_only, 3),
-                      "two_steps_in_flight_reads_per_s": two_in_flight,
-                      "note": "this rank only; same resident inputs, each boundary alone (SURVEY.md 8d i/ii); `value` is (iii) combined; "
-                              "two_steps_in_flight: the same step with a second set of contexts one step ahead (ten batches in flight)",
-                      "worker2_tail": tail},
+                     "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
+                     "note": "launch duration = HIP events on the launch stream inside the library, averaged over the timed region; launches of "
+                             "different host threads overlap on the device, so this is the time a launch spends sharing the GPU"},
+        "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes),
+                               "h2d_ms_avg": round(st["ext_h2d_ms"] / max(ext_launches, 1), 4), "d2h_ms_avg": round(st["ext_d2h_ms"] / max(ext_launches, 1), 4)},
+                    "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes),
+                                 "jobs": int(st["sw_jobs"]), "replay_rounds": int(st["sw_replayed_rounds"]), "wasted_jobs": int(st["sw_wasted"]),
+                                 "h2d_ms_avg": round(st["sw_h2d_ms"] / max(sw_launches, 1), 4), "d2h_ms_avg": round(st["sw_d2h_ms"] / max(sw_launches, 1), 4)}},
+        "host": {"cpus_busy": round(cpu_busy, 2), "call_ms": host_ms,
+                 "phase_ms_per_call": {"extend": {k: round(st["ext_" + k + "_ms"] / max(ext_launches, 1), 4) for k in ("host_in", "wait", "dev", "host_out")},
+                                       "matesw_group": {k: round(st["grp_" + k + "_ms"] / max(int(st["grp_calls"]), 1), 4)
+                                                        for k in ("plan", "pack", "wait", "dev", "replay", "out")}}, "pcie_bytes_per_step": int(pcie_bytes_per_step),
+                 "pcie_GBps": round(pcie_bytes_per_step * args.steps / elapsed / 1e9, 3)},
+        "breakdown": extras,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(soas, wires, ntasks, jobs, xtra)
+        out["cpu_baseline"] = cpu_baseline(W, args.config, rank, xtra)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    for cx in ctxs:
-        cx.close()
+    F.close()
     if distributed:
         dist.destroy_process_group()
 

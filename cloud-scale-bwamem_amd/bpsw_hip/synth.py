@@ -515,3 +515,49 @@ def tail_pairs(n_pairs: int, ref_bases: np.ndarray, ann_off, ann_len, dups=(), r
                       seed_cnt=np.array(seed_cnt, np.int32), seed_rbeg=np.array(s_rb, np.int64),
                       seed_qbeg=np.array(s_qb, np.int32), seed_len=np.array(s_len, np.int32))
     return b, names, np.concatenate(quals), pes
+
+
+class _GroupCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_pairs", C.c_int32), ("read_len", C.c_int32), ("l_pac", C.c_int64),
+                ("p_resc", C.c_double), ("sub_rate", C.c_double), ("indel_rate", C.c_double), ("p_multi_anchor", C.c_double),
+                ("p_wrong_mate", C.c_double), ("max_matesw", C.c_int32), ("pen_unpaired", C.c_int32), ("low", C.c_int32),
+                ("high", C.c_int32), ("avg", C.c_double), ("std", C.c_double)]
+
+
+def rescue_group_fast(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE + 3, l_pac: int = 46_709_983,
+                      p_resc: float = 0.10, sub_rate: float = 0.02, indel_rate: float = 0.002, p_multi_anchor: float = 0.10,
+                      p_wrong_mate: float = 0.05, max_matesw: int = 100, pen_unpaired: int = 17):
+    """rescue_group()'s model (FR library, windows shipped as bytes, no backing reference) generated by libbpsw_synth.so:
+    a million pairs in seconds, for bench.py.  Same layout, different random stream."""
+    from . import RescueGroupSoA, ALNREG_DTYPE
+    lib = _load()
+    lib.bpsw_synth_rescue_group.restype = C.c_int
+    avg, std = 400.0, 50.0
+    low, high = int(avg - 4 * std), int(avg + 4 * std)
+    cfg = _GroupCfg(seed=seed, n_pairs=n_pairs, read_len=read_len, l_pac=l_pac, p_resc=p_resc, sub_rate=sub_rate,
+                    indel_rate=indel_rate, p_multi_anchor=p_multi_anchor, p_wrong_mate=p_wrong_mate, max_matesw=max_matesw,
+                    pen_unpaired=pen_unpaired, low=low, high=high, avg=avg, std=std)
+    n = n_pairs
+    Lp = (read_len + 15) & ~15
+    wp = (high - low + 2 * read_len + 15) & ~15
+    seq_len, seq_off = np.zeros(2 * n, np.int32), np.zeros(2 * n, np.int64)
+    seq_pool = np.empty(max(2 * n * Lp, 16), np.uint8)
+    reg_cnt, ref_cnt = np.zeros(2 * n, np.int32), np.zeros(2 * n, np.int32)
+    regs = np.empty(6 * n + 1, ALNREG_DTYPE)
+    rows_cap = 4 * n + 1
+    ref_rb, ref_re = np.empty(4 * rows_cap, np.int64), np.empty(4 * rows_cap, np.int64)
+    ref_len, ref_off = np.empty(4 * rows_cap, np.int64), np.empty(4 * rows_cap, np.int64)
+    ref_pool = np.empty(max(rows_cap * wp, 16), np.uint8)
+    counts = np.zeros(4, np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.bpsw_synth_rescue_group(C.byref(cfg), vp(seq_len), vp(seq_off), vp(seq_pool), C.c_size_t(seq_pool.size), vp(reg_cnt),
+                                     vp(regs), C.c_size_t(regs.shape[0]), vp(ref_cnt), vp(ref_rb), vp(ref_re), vp(ref_len), vp(ref_off),
+                                     C.c_size_t(rows_cap), vp(ref_pool), C.c_size_t(ref_pool.size), vp(counts))
+    if rc != 0:
+        raise BpswError("synthetic rescue group: pool too small")
+    nreg, nrow, sb, rb_ = (int(v) for v in counts)
+    pes = [(0, 0, 1, 0.0, 0.0), (low, high, 0, avg, std), (0, 0, 1, 0.0, 0.0), (0, 0, 1, 0.0, 0.0)]
+    return RescueGroupSoA(group_size=n, l_pac=l_pac, pes=pes, seq_len=seq_len, seq_off=seq_off, seq_pool=seq_pool[:max(sb, 16)].copy(),
+                          reg_cnt=reg_cnt, regs=regs[:nreg].copy(), ref_cnt=ref_cnt, ref_rb=ref_rb[:4 * nrow].copy(),
+                          ref_re=ref_re[:4 * nrow].copy(), ref_len=ref_len[:4 * nrow].copy(), ref_off=ref_off[:4 * nrow].copy(),
+                          ref_pool=ref_pool[:max(rb_, 16)].copy())

@@ -199,6 +199,7 @@ hipError_t launch_chain2aln_kernel(const ChainBatchDev& B, const ChainParams& P,
                                    int32_t* d_srt_scratch, int srt_per_wave, int num_cu, int* d_counter, hipStream_t s);
 // memSortAndDedup on a host vector (bpsw_rescue.cpp): mode BPSW_RESCUE_C or BPSW_RESCUE_SCALA; returns the new size
 int sort_dedup_regs(std::vector<bpsw_alnreg_t>& v, float mask_level_redun, int mode);
+void rescue_scratch_free(void* p);
 
 // ---- error text -----------------------------------------------------------------------------------
 void set_error(const std::string& msg);
@@ -231,6 +232,26 @@ struct DeviceRef {
   std::vector<std::string> ann_name;
 };
 DeviceRef& device_ref(int device);
+
+// Device streams for the blocking host-buffer entry points.  A calling thread needs a stream only for the device phase of its
+// call (H2D, kernel, D2H), not while it stages bytes or replays bookkeeping on the host; and the GPU has a fixed number of
+// hardware queues (GPU_MAX_HW_QUEUES, 16 here): more busy streams than queues makes the runtime time-slice queues and
+// throughput collapses (measured: 24 streams busy = half the rate of 16).  So the device phases of all contexts of a device
+// share a pool of BPSW_STREAM_POOL streams (default 16; 0 = every context uses its own stream): an executor may run more
+// task threads than the device has queues, and their host phases overlap the others' device phases.
+struct StreamLease {
+  int device;
+  hipStream_t s;
+  bool pooled;
+  double wait_ms;  // time spent waiting for a free stream
+  explicit StreamLease(bpsw_ctx* c);
+  ~StreamLease();
+  StreamLease(const StreamLease&) = delete;
+  StreamLease& operator=(const StreamLease&) = delete;
+};
+double wall_ms();
+int zerocopy_mask();  // BPSW_ZEROCOPY, see bpsw_runtime.cpp
+bool spin_wait();  // BPSW_SPIN_WAIT=1: busy-wait for the device instead of sleeping on a blocking event
 // snapshot of the reference loaded on c's device (l_pac == 0: none)
 void ref_snapshot(const bpsw_ctx* c, const uint8_t** pac, long long* l_pac);
 
@@ -244,9 +265,20 @@ inline int finish_pending(bpsw_ctx* c) {
   return a != BPSW_OK ? a : b;
 }
 
-// runs SWAlign2 jobs whose arrays live in host memory; used by bpsw_swalign2_batch and the rescue layer.
+// runs SWAlign2 jobs whose arrays live in host memory; used by bpsw_swalign2_batch.
 // Caller holds ctx->mu and has set the device.
 int run_sw_jobs_host(bpsw_ctx* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* jobs, int32_t* out);
+// The same in two steps for callers that build the job table in place (the rescue layer packs straight into the pinned
+// staging block): sw_stage_begin lays the block out for n jobs and the two pool sizes, the caller fills
+// base + o_* (q_len/t_len int32, q_off/t_off int64 relative to the pools, q_rev bytes, the pools), sw_stage_run launches.
+// The caller is responsible for what run_sw_jobs_host validates (1 <= q_len, sequences inside their pools / the reference).
+struct SwStage {
+  int n;
+  size_t o_qlen, o_tlen, o_qoff, o_toff, o_qrev, o_qpool, o_tpool, total, q_pool_bytes, t_pool_bytes;
+  uint8_t* base;
+};
+int sw_stage_begin(bpsw_ctx* c, int n, size_t q_pool_bytes, size_t t_pool_bytes, SwStage* st);
+int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st, int mq, int mt, bool pac_mode, const int32_t** results);
 
 }  // namespace bpsw
 
@@ -274,6 +306,7 @@ struct bpsw_ctx {
   bool have_tail_ev = false;
 
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
+  void* rescue_scratch = nullptr;  // bpsw_rescue.cpp: vectors reused across bpsw_matesw_group calls (freed by rescue_scratch_free)
   bpsw_stats_t stats;
   float last_ext_ms = 0.f, last_sw_ms = 0.f;
   bool have_ext_ev = false, have_sw_ev = false;

@@ -157,16 +157,30 @@ inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* dist) {  //
   return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
 }
 
+// Per-context scratch of bpsw_matesw_group: every vector keeps its capacity between calls, so the steady state allocates nothing.
+struct Want { int64_t x; int32_t mate; };  // window index (anchor row * 4 + orientation) and the end (2k + i) whose read is aligned
+struct Scratch {
+  std::vector<int64_t> reg_base, ref_base;  // per end 2k+i: first region / first anchor row
+  std::vector<int32_t> job_of;              // per window x: job index, -1 = not launched
+  std::vector<int32_t> results;             // 7 ints per launched job
+  std::vector<uint8_t> used;                // per job: consumed by the replay
+  std::vector<Want> want, want_next;
+  std::vector<int32_t> touched;             // pairs with at least one window to align, ascending
+  std::vector<int64_t> mate_slot;           // per end: offset of the read in the staged mate pool, -1 = not staged
+  std::vector<int32_t> staged_mates;        // ends whose mate_slot is set (to reset it)
+  std::vector<Reg> arena;                   // final lists of the touched pairs
+  std::vector<int64_t> fin_off;             // per touched pair x end: offset into arena
+  std::vector<int32_t> fin_cnt;
+  std::vector<uint8_t> done;                // per touched pair
+  std::vector<Reg> anchors[2], v[2];
+};
+
 struct Group {
   const bpsw_opt_t* opt;
   const bpsw_rescue_group_t* g;
   int mode;
-  std::vector<int64_t> reg_base, ref_base;  // per (k,i): first region / first anchor row
-  std::vector<int32_t> job_of;              // per window x: job index, -1 = not launched
-  std::vector<int32_t> results;             // 7 ints per launched job
-  std::vector<uint8_t> used;                // per job: consumed by the replay
-  const int64_t* ref_len;                   // per window x: g->ref_len, or derived from (rb, re) in coordinate mode
-  std::vector<Reg> anchors[2];              // scratch of replay_pair, kept across pairs (no allocation per pair)
+  bool pac_mode;
+  Scratch* S;
 };
 
 void skip_flags(const Group& G, const Reg& a, const Reg* mates, size_t n_mates, int skip[4]) {
@@ -180,7 +194,19 @@ void skip_flags(const Group& G, const Reg& a, const Reg* mates, size_t n_mates, 
   }
 }
 
-inline bool window_ok(const Group& G, int64_t x) { return G.ref_len[x] == G.g->ref_re[x] - G.g->ref_rb[x]; }
+// length of window x as the SW sees it: shipped with the bytes, or -- coordinate mode, SURVEY.md 8f.2 -- what bnsGetSeq
+// (util/BNTSeqUtil.scala:37-59) would return for (rb, re): swap, clamp to [0, 2 l_pac), nothing when it bridges the strands
+inline int64_t win_len(const Group& G, int64_t x) {
+  if (!G.pac_mode) return G.g->ref_len[x];
+  int64_t b = G.g->ref_rb[x], e = G.g->ref_re[x];
+  if (b < 0 && e < 0) return 0;  // (-1,-1): failed orientation, MemSamPe.scala:1863-1868
+  if (e < b) std::swap(b, e);
+  if (e > (G.g->l_pac << 1)) e = G.g->l_pac << 1;
+  if (b < 0) b = 0;
+  if (!(b >= G.g->l_pac || e <= G.g->l_pac)) return 0;
+  return e - b > 0 ? e - b : 0;
+}
+inline bool window_ok(const Group& G, int64_t x) { return win_len(G, x) == G.g->ref_re[x] - G.g->ref_rb[x]; }
 
 // region built from an SWAlign2 result: native/bwamem_pair.c:203-212 / MemSamPe.scala:1192-1212
 bool make_region(const Group& G, const int32_t aln[7], int r, int l_ms, int64_t x, Reg* out) {
@@ -203,8 +229,19 @@ bool make_region(const Group& G, const int32_t aln[7], int r, int l_ms, int64_t 
   return true;
 }
 
-// One anchor against the mate list.  Returns false when a needed SW result is missing (x appended to `missing`).
-bool precompute(Group& G, const Reg& a, int l_ms, std::vector<Reg>& ma, int64_t xrow, std::vector<int64_t>& missing) {
+// SW result of window x for the replay: nullptr when it has not been computed yet.  A mate without bases (l_ms < 1, e.g.
+// an adapter-trimmed read) never becomes a job: the reference's ksw_align2 returns score 0 for it, which is no region.
+static const int32_t kNoHit[7] = {0, -1, -1, -1, -1, -1, -1};
+inline const int32_t* result_of(Group& G, int64_t x, int l_ms) {
+  if (l_ms < 1) return kNoHit;
+  const int job = G.S->job_of[(size_t)x];
+  if (job < 0) return nullptr;
+  G.S->used[(size_t)job] = 1;
+  return &G.S->results[7 * (size_t)job];
+}
+
+// One anchor against the mate list.  Returns false when a needed SW result is missing (the window goes to `missing`).
+bool precompute(Group& G, const Reg& a, int l_ms, int mate_end, std::vector<Reg>& ma, int64_t xrow, std::vector<Want>& missing) {
   int skip[4];
   skip_flags(G, a, ma.data(), ma.size(), skip);
   if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return true;
@@ -214,11 +251,10 @@ bool precompute(Group& G, const Reg& a, int l_ms, std::vector<Reg>& ma, int64_t 
       if (skip[r]) continue;
       const int64_t x = xrow * 4 + r;
       if (window_ok(G, x)) {
-        const int job = G.job_of[(size_t)x];
-        if (job < 0) { missing.push_back(x); return false; }
-        G.used[(size_t)job] = 1;
+        const int32_t* res = result_of(G, x, l_ms);
+        if (!res) { missing.push_back({x, mate_end}); return false; }
         Reg b;
-        if (make_region(G, &G.results[7 * (size_t)job], r, l_ms, x, &b)) {
+        if (make_region(G, res, r, l_ms, x, &b)) {
           // keep the list sorted by score: insert before the first lower score (native/bwamem_pair.c:213-219)
           size_t at = 0;
           while (at < ma.size() && !(ma[at].score < b.score)) ++at;
@@ -238,11 +274,10 @@ bool precompute(Group& G, const Reg& a, int l_ms, std::vector<Reg>& ma, int64_t 
     if (skip[r]) continue;
     const int64_t x = xrow * 4 + r;
     if (window_ok(G, x)) {
-      const int job = G.job_of[(size_t)x];
-      if (job < 0) { missing.push_back(x); return false; }
-      G.used[(size_t)job] = 1;
+      const int32_t* res = result_of(G, x, l_ms);
+      if (!res) { missing.push_back({x, mate_end}); return false; }
       Reg b;
-      if (make_region(G, &G.results[7 * (size_t)job], r, l_ms, x, &b)) upd.push_back(b);
+      if (make_region(G, res, r, l_ms, x, &b)) upd.push_back(b);
       ++n;
     }
     if (n) {
@@ -264,11 +299,11 @@ bool precompute(Group& G, const Reg& a, int l_ms, std::vector<Reg>& ma, int64_t 
 }
 
 // Replays pair k from its initial state.  Returns false (and fills `missing`) if a result is not available yet.
-bool replay_pair(Group& G, int k, std::vector<Reg> v[2], std::vector<int64_t>& missing) {
+bool replay_pair(Group& G, int k, std::vector<Reg> v[2], std::vector<Want>& missing) {
   const bpsw_rescue_group_t* g = G.g;
-  std::vector<Reg>* tmp = G.anchors;
+  std::vector<Reg>* tmp = G.S->anchors;
   for (int i = 0; i < 2; ++i) {
-    const Reg* first = g->regs + G.reg_base[(size_t)(2 * k + i)];
+    const Reg* first = g->regs + G.S->reg_base[(size_t)(2 * k + i)];
     v[i].assign(first, first + g->reg_cnt[2 * k + i]);
     tmp[i].clear();
     for (const Reg& r : v[i])  // anchors: filtered copy taken before any rescue (native/bwamem_pair.c:126-131)
@@ -277,18 +312,26 @@ bool replay_pair(Group& G, int k, std::vector<Reg> v[2], std::vector<int64_t>& m
   for (int i = 0; i < 2; ++i) {
     const int na = std::min<int>((int)tmp[i].size(), std::min<int>(G.opt->max_matesw, g->ref_cnt[2 * k + i]));
     for (int j = 0; j < na; ++j)
-      if (!precompute(G, tmp[i][(size_t)j], g->seq_len[2 * k + !i], v[!i], G.ref_base[(size_t)(2 * k + i)] + j, missing))
+      if (!precompute(G, tmp[i][(size_t)j], g->seq_len[2 * k + !i], 2 * k + !i, v[!i], G.S->ref_base[(size_t)(2 * k + i)] + j, missing))
         return false;
   }
   return true;
 }
 
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
 }  // namespace
 
 namespace bpsw {
 int sort_dedup_regs(std::vector<bpsw_alnreg_t>& v, float mask_level_redun, int mode) { return sort_dedup(v, mask_level_redun, mode); }
+void rescue_scratch_free(void* p) { delete (Scratch*)p; }
 }  // namespace bpsw
 
+// The host layer runs once per group on the calling thread, between the JNI marshalling and the kernel, and at 4 096 pairs
+// per group its cost rivals the kernel's: it is written as ONE sequential pass over the group's arrays (prefix sums,
+// validation and speculation together; a properly paired end costs two loads and one distance test), the wanted jobs are
+// packed straight into the pinned staging block the kernel reads, only the pairs with a job are replayed, and the output is
+// assembled with one memcpy per run of untouched pairs.
 extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_rescue_group_t* g, int mode,
                                  int32_t* out_cnt, bpsw_alnreg_t* out_regs, int64_t out_cap, int64_t* out_total) {
   if (!c || !opt || !g || !out_cnt || !out_total) return fail(BPSW_ERR_ARG, "matesw_group: null argument");
@@ -300,181 +343,205 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
   if (he != hipSuccess) return fail(BPSW_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
   { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
 
-  Group S;
-  S.opt = opt; S.g = g; S.mode = mode;
-  S.reg_base.resize(2 * (size_t)G_ + 1); S.ref_base.resize(2 * (size_t)G_ + 1);
-  int64_t nreg = 0, nref = 0;
-  for (int e = 0; e < 2 * G_; ++e) {
-    if (g->reg_cnt[e] < 0 || g->ref_cnt[e] < 0 || g->seq_len[e] < 0) return fail(BPSW_ERR_ARG, "matesw_group: negative count");
-    if ((uint64_t)(g->seq_off[e] + g->seq_len[e]) > g->seq_pool_bytes) return fail(BPSW_ERR_ARG, "matesw_group: mate outside seq_pool");
-    S.reg_base[(size_t)e] = nreg; S.ref_base[(size_t)e] = nref;
-    nreg += g->reg_cnt[e]; nref += g->ref_cnt[e];
-  }
+  const double t_begin = wall_ms();
+  double t_pack = 0., t_replay = 0.;
+  if (!c->rescue_scratch) c->rescue_scratch = new Scratch();
+  Scratch& S = *(Scratch*)c->rescue_scratch;
+  Group GR;
+  GR.opt = opt; GR.g = g; GR.mode = mode; GR.S = &S;
   // with ref_pool == NULL the windows are named by (rb, re) only and read from the 2-bit reference
-  // loaded on the context; their lengths follow bnsGetSeq (util/BNTSeqUtil.scala:37-59)
-  const bool pac_mode = g->ref_pool == nullptr && nref > 0;
-  std::vector<int64_t> derived_len;
-  if (pac_mode) {
+  // loaded on the context; their lengths follow bnsGetSeq (win_len)
+  GR.pac_mode = g->ref_pool == nullptr;
+  const bool rescue_on = (opt->flag & 0x20) == 0;  // MEM_F_NO_RESCUE, native/bwamem.h:18
+
+  // ---- 1. one pass: prefix sums, validation, speculation against the initial lists -----------------------------------
+  S.reg_base.resize(2 * (size_t)G_ + 1); S.ref_base.resize(2 * (size_t)G_ + 1);
+  S.want.clear(); S.touched.clear();
+  int64_t nreg = 0, nref = 0;
+  for (int k = 0; k < G_; ++k) {
+    int64_t base[2], rowb[2];
+    for (int i = 0; i < 2; ++i) {
+      const int e = 2 * k + i;
+      if (g->reg_cnt[e] < 0 || g->ref_cnt[e] < 0 || g->seq_len[e] < 0) return fail(BPSW_ERR_ARG, "matesw_group: negative count");
+      if ((uint64_t)(g->seq_off[e] + g->seq_len[e]) > g->seq_pool_bytes) return fail(BPSW_ERR_ARG, "matesw_group: mate outside seq_pool");
+      S.reg_base[(size_t)e] = base[i] = nreg; S.ref_base[(size_t)e] = rowb[i] = nref;
+      nreg += g->reg_cnt[e]; nref += g->ref_cnt[e];
+    }
+    if (!rescue_on) continue;
+    bool touched = false;
+    for (int i = 0; i < 2; ++i) {
+      const int e = 2 * k + i, mate = e ^ 1;
+      if (g->seq_len[mate] < 1 || g->reg_cnt[e] == 0 || g->ref_cnt[e] == 0) continue;
+      const Reg* init = g->regs + base[i];
+      const Reg* minit = g->regs + base[!i];
+      const int n_init = g->reg_cnt[e], n_mate = g->reg_cnt[mate];
+      const int thr = init[0].score - opt->pen_unpaired;
+      int j = 0;
+      for (int ai = 0; ai < n_init; ++ai) {
+        const Reg& a = init[ai];
+        if (!(a.score >= thr)) continue;
+        if (j >= opt->max_matesw || j >= g->ref_cnt[e]) break;
+        int skip[4];
+        skip_flags(GR, a, minit, (size_t)n_mate, skip);
+        if (skip[0] + skip[1] + skip[2] + skip[3] != 4) {
+          const int64_t xrow = rowb[i] + j;
+          for (int r = 0; r < 4; ++r)
+            if (!skip[r] && window_ok(GR, xrow * 4 + r)) { S.want.push_back({xrow * 4 + r, mate}); touched = true; }
+        }
+        ++j;
+      }
+    }
+    if (touched) S.touched.push_back(k);
+  }
+  S.reg_base[2 * (size_t)G_] = nreg; S.ref_base[2 * (size_t)G_] = nref;
+  if (GR.pac_mode && nref > 0) {
     const uint8_t* d_pac = nullptr;
     long long loaded = 0;
     ref_snapshot(c, &d_pac, &loaded);
     if (loaded <= 0) return fail(BPSW_ERR_ARG, "matesw_group: ref_pool is null and no reference is loaded (bpsw_ref_load)");
     if (loaded != g->l_pac) return fail(BPSW_ERR_ARG, "matesw_group: l_pac differs from the loaded reference");
-    derived_len.resize((size_t)(4 * nref));
-    for (int64_t x = 0; x < 4 * nref; ++x) {
-      int64_t b = g->ref_rb[x], e = g->ref_re[x], len = 0;
-      if (!(b < 0 && e < 0)) {  // (-1,-1): failed orientation, MemSamPe.scala:1863-1868
-        if (e < b) std::swap(b, e);
-        if (e > (g->l_pac << 1)) e = g->l_pac << 1;
-        if (b < 0) b = 0;
-        len = e - b > 0 ? e - b : 0;
-        if (!(b >= g->l_pac || e <= g->l_pac)) len = 0;  // bridging the strands: bnsGetSeq returns nothing
-      }
-      derived_len[(size_t)x] = len;
-    }
-    S.ref_len = derived_len.data();
-  } else {
-    for (int64_t x = 0; x < 4 * nref; ++x)
-      if (g->ref_len[x] > 0 && (g->ref_off[x] < 0 || (uint64_t)(g->ref_off[x] + g->ref_len[x]) > g->ref_pool_bytes))
-        return fail(BPSW_ERR_ARG, "matesw_group: window outside ref_pool");
-    S.ref_len = g->ref_len;
   }
   S.job_of.assign((size_t)(4 * nref), -1);
+  S.results.clear(); S.used.clear();
+  const double t_planned = wall_ms();
 
-  const bool rescue_on = (opt->flag & 0x20) == 0;  // MEM_F_NO_RESCUE, native/bwamem.h:18
-  std::vector<int64_t> want;  // windows whose SW result the next GPU round computes
-  // pairs with at least one window to align; the lists of the others come out exactly as they went in (every anchor of
-  // theirs is skipped or has no usable window, and only an SW result can change a list)
-  std::vector<uint8_t> touched((size_t)G_, 0);
-  if (rescue_on) {
-    // ---- 1. speculate against the initial lists --------------------------------------------
-    for (int k = 0; k < G_; ++k) {
-      const Reg* init[2] = {g->regs + S.reg_base[(size_t)(2 * k)], g->regs + S.reg_base[(size_t)(2 * k + 1)]};
-      const int n_init[2] = {g->reg_cnt[2 * k], g->reg_cnt[2 * k + 1]};
-      for (int i = 0; i < 2; ++i) {
-        if (g->seq_len[2 * k + !i] < 1) continue;
-        int j = 0;
-        for (int ai = 0; ai < n_init[i]; ++ai) {
-          const Reg& a = init[i][ai];
-          if (!(a.score >= init[i][0].score - opt->pen_unpaired)) continue;
-          if (j >= opt->max_matesw || j >= g->ref_cnt[2 * k + i]) break;
-          int skip[4];
-          skip_flags(S, a, init[!i], (size_t)n_init[!i], skip);
-          const int64_t xrow = S.ref_base[(size_t)(2 * k + i)] + j;
-          for (int r = 0; r < 4; ++r)
-            if (!skip[r] && window_ok(S, xrow * 4 + r)) { want.push_back(xrow * 4 + r); touched[(size_t)k] = 1; }
-          ++j;
-        }
-      }
-    }
-  }
-  // window -> (pair, end): needed to find the mate of a job
-  std::vector<int32_t> end_of_row((size_t)nref);
-  for (int e = 0; e < 2 * G_; ++e)
-    for (int64_t j = 0; j < g->ref_cnt[e]; ++j) end_of_row[(size_t)(S.ref_base[(size_t)e] + j)] = e;
-
-  const int xtra_base = BPSW_KSW_XSUBO | BPSW_KSW_XSTART | (opt->min_seed_len * opt->a);
-  // final lists, in the order the pairs complete: one arena, (offset, count) per end
-  std::vector<Reg> arena;
-  std::vector<int64_t> fin_off(2 * (size_t)G_, -1);  // -1: the input list, untouched
-  std::vector<int32_t> fin_cnt(2 * (size_t)G_, 0);
-  std::vector<uint8_t> done((size_t)G_, 0);
-  std::vector<Reg> v[2];
-  uint64_t rounds = 0, speculated = want.size();
+  const int xtra_base = BPSW_KSW_XSUBO | BPSW_KSW_XSTART | (opt->min_seed_len * opt->a);  // KSW_XBYTE is ignored by SWAlign
+  const size_t nt = S.touched.size();
+  S.arena.clear();
+  S.fin_off.assign(2 * nt, 0); S.fin_cnt.assign(2 * nt, 0); S.done.assign(nt, 0);
+  S.mate_slot.assign(2 * (size_t)G_, (int64_t)-1);
+  S.staged_mates.clear();
+  uint64_t rounds = 0;
+  const uint64_t speculated = S.want.size();
+  size_t n_done = 0;
   for (;;) {
-    // ---- 2. one flat GPU batch ----------------------------------------------------------------
-    if (!want.empty()) {
-      std::sort(want.begin(), want.end());
-      want.erase(std::unique(want.begin(), want.end()), want.end());
-      const size_t nj = want.size();
-      std::vector<int32_t> q_len(nj), t_len(nj);
-      std::vector<int64_t> q_off(nj), t_off(nj);
-      std::vector<uint8_t> q_rev(nj);
-      // only the mates some job aligns travel to the device (a tenth of the group's reads), not the whole read pool
-      std::vector<uint8_t> qpool;
-      std::vector<int64_t> mate_slot(2 * (size_t)G_, -1);
-      std::vector<uint8_t> tpool;
-      size_t tbytes = 0;
-      if (!pac_mode)
-        for (size_t t = 0; t < nj; ++t) tbytes += ((size_t)g->ref_len[want[t]] + 15) & ~(size_t)15;
-      tpool.resize(tbytes ? tbytes : 16);
+    // ---- 2. one flat GPU batch, packed in place in the pinned staging block ---------------------------------------------
+    if (!S.want.empty()) {
+      const double t_p0 = wall_ms();
+      if (rounds > 0) {  // later rounds collect their windows out of order and possibly twice
+        std::sort(S.want.begin(), S.want.end(), [](const Want& p, const Want& q) { return p.x < q.x; });
+        S.want.erase(std::unique(S.want.begin(), S.want.end(), [](const Want& p, const Want& q) { return p.x == q.x; }), S.want.end());
+      }
+      const size_t nj = S.want.size();
+      // sizes first: only the mates some job aligns travel to the device (a tenth of the group's reads), each once
+      size_t qbytes = 0, tbytes = 0;
+      int mq = 0, mt = 0;
+      for (const int32_t m : S.staged_mates) S.mate_slot[(size_t)m] = -1;
+      S.staged_mates.clear();
+      for (size_t t = 0; t < nj; ++t) {
+        const Want& w = S.want[t];
+        if (S.mate_slot[(size_t)w.mate] < 0) {
+          S.mate_slot[(size_t)w.mate] = (int64_t)qbytes;
+          S.staged_mates.push_back(w.mate);
+          qbytes += align16((size_t)g->seq_len[w.mate]);
+          mq = std::max(mq, g->seq_len[w.mate]);
+        }
+        const int64_t len = win_len(GR, w.x);
+        if (len > BPSW_SW_MAX_TLEN) return fail(BPSW_ERR_LIMIT, "matesw_group: window longer than the kernel limit");
+        if (!GR.pac_mode) {
+          if (g->ref_off[w.x] < 0 || (uint64_t)(g->ref_off[w.x] + len) > g->ref_pool_bytes)
+            return fail(BPSW_ERR_ARG, "matesw_group: window outside ref_pool");
+          tbytes += align16((size_t)len);
+        }
+        mt = std::max(mt, (int)len);
+      }
+      SwStage st;
+      int rc = sw_stage_begin(c, (int)nj, qbytes ? qbytes : 16, GR.pac_mode ? 0 : (tbytes ? tbytes : 16), &st);
+      if (rc != BPSW_OK) return rc;
+      int32_t* q_len = (int32_t*)(st.base + st.o_qlen);
+      int32_t* t_len = (int32_t*)(st.base + st.o_tlen);
+      int64_t* q_off = (int64_t*)(st.base + st.o_qoff);
+      int64_t* t_off = (int64_t*)(st.base + st.o_toff);
+      uint8_t* q_rev = st.base + st.o_qrev;
+      uint8_t* qpool = st.base + st.o_qpool;
+      uint8_t* tpool = st.base + st.o_tpool;
+      for (const int32_t m : S.staged_mates) {
+        uint8_t* dst = qpool + S.mate_slot[(size_t)m];
+        const size_t ln = (size_t)g->seq_len[m];
+        memcpy(dst, g->seq_pool + g->seq_off[m], ln);
+        memset(dst + ln, 0, align16(ln) - ln);
+      }
       size_t at = 0;
       for (size_t t = 0; t < nj; ++t) {
-        const int64_t x = want[t];
-        const int e = end_of_row[(size_t)(x >> 2)], mate = e ^ 1, r = (int)(x & 3);
-        q_len[t] = g->seq_len[mate];
-        if (mate_slot[(size_t)mate] < 0) {
-          mate_slot[(size_t)mate] = (int64_t)qpool.size();
-          qpool.insert(qpool.end(), g->seq_pool + g->seq_off[mate], g->seq_pool + g->seq_off[mate] + g->seq_len[mate]);
-          qpool.resize((qpool.size() + 15) & ~(size_t)15, 0);
-        }
-        q_off[t] = mate_slot[(size_t)mate];
+        const Want& w = S.want[t];
+        const int r = (int)(w.x & 3);
+        q_len[t] = g->seq_len[w.mate];
+        q_off[t] = S.mate_slot[(size_t)w.mate];
         q_rev[t] = ((r >> 1) != (r & 1)) ? 1 : 0;  // native/bwamem_pair.c:177
-        t_len[t] = (int32_t)S.ref_len[x];
-        if (pac_mode) {  // window_ok held, so the window starts at ref_rb[x] unclamped
-          t_off[t] = g->ref_rb[x];
+        const int64_t len = win_len(GR, w.x);
+        t_len[t] = (int32_t)len;
+        if (GR.pac_mode) {  // window_ok held, so the window starts at ref_rb[x] unclamped
+          t_off[t] = g->ref_rb[w.x];
           continue;
         }
         t_off[t] = (int64_t)at;
-        memcpy(tpool.data() + at, g->ref_pool + g->ref_off[x], (size_t)g->ref_len[x]);
-        at += ((size_t)g->ref_len[x] + 15) & ~(size_t)15;
+        memcpy(tpool + at, g->ref_pool + g->ref_off[w.x], (size_t)len);
+        at += align16((size_t)len);
       }
-      bpsw_sw_jobs_t jobs;
-      memset(&jobs, 0, sizeof jobs);
-      jobs.n = (int32_t)nj; jobs.xtra = xtra_base;  // KSW_XBYTE is ignored by SWAlign
-      jobs.q_len = q_len.data(); jobs.t_len = t_len.data(); jobs.q_off = q_off.data(); jobs.t_off = t_off.data();
-      if (qpool.empty()) qpool.resize(16, 0);
-      jobs.q_rev = q_rev.data(); jobs.q_pool = qpool.data(); jobs.t_pool = pac_mode ? nullptr : tpool.data();
-      jobs.q_pool_bytes = qpool.size(); jobs.t_pool_bytes = pac_mode ? 0 : tpool.size();
-      const size_t first = S.results.size() / 7;
-      S.results.resize(7 * (first + nj));
-      S.used.resize(first + nj, 0);
-      int rc = run_sw_jobs_host(c, opt, &jobs, S.results.data() + 7 * first);
+      const double t_p1 = wall_ms();
+      const int32_t* res = nullptr;
+      rc = sw_stage_run(c, opt, xtra_base, st, mq, mt, GR.pac_mode, &res);
       if (rc != BPSW_OK) return rc;
-      for (size_t t = 0; t < nj; ++t) S.job_of[(size_t)want[t]] = (int32_t)(first + t);
-      want.clear();
+      const size_t first = S.results.size() / 7;
+      S.results.insert(S.results.end(), res, res + 7 * nj);
+      S.used.resize(first + nj, 0);
+      for (size_t t = 0; t < nj; ++t) S.job_of[(size_t)S.want[t].x] = (int32_t)(first + t);
+      S.want.clear();
+      t_pack += t_p1 - t_p0;
     }
-    // ---- 3. replay -----------------------------------------------------------------------------
-    bool all_done = true;
-    for (int k = 0; k < G_; ++k) {
-      if (done[(size_t)k]) continue;
-      if (!rescue_on || !touched[(size_t)k]) {
-        fin_cnt[(size_t)(2 * k)] = g->reg_cnt[2 * k];
-        fin_cnt[(size_t)(2 * k + 1)] = g->reg_cnt[2 * k + 1];
-        done[(size_t)k] = 1;
-        continue;
-      }
-      if (!replay_pair(S, k, v, want)) {
-        all_done = false;
-        continue;
-      }
+    // ---- 3. replay the pairs that had a job ------------------------------------------------------------------------
+    const double t_r0 = wall_ms();
+    for (size_t ti = 0; ti < nt; ++ti) {
+      if (S.done[ti]) continue;
+      const int k = S.touched[ti];
+      if (!replay_pair(GR, k, S.v, S.want)) continue;
       for (int i = 0; i < 2; ++i) {
-        fin_off[(size_t)(2 * k + i)] = (int64_t)arena.size();
-        fin_cnt[(size_t)(2 * k + i)] = (int32_t)v[i].size();
-        arena.insert(arena.end(), v[i].begin(), v[i].end());
+        S.fin_off[2 * ti + (size_t)i] = (int64_t)S.arena.size();
+        S.fin_cnt[2 * ti + (size_t)i] = (int32_t)S.v[i].size();
+        S.arena.insert(S.arena.end(), S.v[i].begin(), S.v[i].end());
       }
-      done[(size_t)k] = 1;
+      S.done[ti] = 1;
+      ++n_done;
     }
-    if (all_done) break;
+    t_replay += wall_ms() - t_r0;
+    if (n_done == nt) break;
     ++rounds;
-    if (want.empty()) return fail(BPSW_ERR_DEVICE, "matesw_group: replay stalled");  // cannot happen
+    if (S.want.empty()) return fail(BPSW_ERR_DEVICE, "matesw_group: replay stalled");  // cannot happen
   }
   uint64_t wasted = 0;
   for (uint8_t u : S.used) wasted += u ? 0 : 1;
   c->stats.sw_speculated += speculated; c->stats.sw_replayed_rounds += rounds; c->stats.sw_wasted += wasted;
 
-  int64_t total = 0;
-  for (int e = 0; e < 2 * G_; ++e) {
-    out_cnt[e] = fin_cnt[(size_t)e];
-    total += out_cnt[e];
+  // ---- 4. output: the lists of the untouched pairs come out exactly as they went in (every anchor of theirs is skipped or
+  // has no usable window, and only an SW result can change a list): one memcpy per run between two touched pairs -----------
+  const double t_o0 = wall_ms();
+  c->stats.grp_calls++; c->stats.grp_pairs += (uint64_t)G_;
+  c->stats.grp_plan_ms += t_planned - t_begin; c->stats.grp_pack_ms += t_pack; c->stats.grp_replay_ms += t_replay;
+  int64_t total = nreg;
+  for (size_t ti = 0; ti < nt; ++ti) {
+    const int k = S.touched[ti];
+    total += (int64_t)S.fin_cnt[2 * ti] + S.fin_cnt[2 * ti + 1] - g->reg_cnt[2 * k] - g->reg_cnt[2 * k + 1];
   }
   *out_total = total;
   if (total > out_cap || (total > 0 && !out_regs)) return fail(BPSW_ERR_CAPACITY, "matesw_group: out_regs too small");
-  int64_t at = 0;
-  for (int e = 0; e < 2 * G_; ++e) {
-    const Reg* src = fin_off[(size_t)e] < 0 ? g->regs + S.reg_base[(size_t)e] : arena.data() + fin_off[(size_t)e];
-    if (fin_cnt[(size_t)e]) memcpy(out_regs + at, src, sizeof(Reg) * (size_t)fin_cnt[(size_t)e]);
-    at += fin_cnt[(size_t)e];
+  if (G_ > 0) memcpy(out_cnt, g->reg_cnt, sizeof(int32_t) * 2 * (size_t)G_);
+  int64_t at = 0, src_from = 0;  // output position; first input region not yet copied
+  for (size_t ti = 0; ti <= nt; ++ti) {
+    const int k = ti < nt ? S.touched[ti] : G_;
+    const int64_t run_end = S.reg_base[2 * (size_t)k];  // regions before pair k
+    if (run_end > src_from) {
+      memcpy(out_regs + at, g->regs + src_from, sizeof(Reg) * (size_t)(run_end - src_from));
+      at += run_end - src_from;
+    }
+    if (ti == nt) break;
+    for (int i = 0; i < 2; ++i) {
+      const int32_t cnt = S.fin_cnt[2 * ti + (size_t)i];
+      out_cnt[2 * k + i] = cnt;
+      if (cnt) memcpy(out_regs + at, S.arena.data() + S.fin_off[2 * ti + (size_t)i], sizeof(Reg) * (size_t)cnt);
+      at += cnt;
+    }
+    src_from = S.reg_base[2 * (size_t)k + 2];
   }
+  c->stats.grp_out_ms += wall_ms() - t_o0;
   return BPSW_OK;
 }

@@ -6,7 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
 #include <atomic>
+#include <condition_variable>
 
 #include "bpsw_internal.h"
 
@@ -144,6 +147,84 @@ static std::vector<int> allowed_devices() {
   return all;
 }
 
+bool spin_wait() {
+  static const bool on = getenv("BPSW_SPIN_WAIT") && atoi(getenv("BPSW_SPIN_WAIT")) != 0;
+  return on;
+}
+
+// Which small transfers bypass the copy engines: the kernels read / write pinned host memory directly over PCIe.  With sixteen
+// streams busy the SDMA engines were the bottleneck of the host-buffer path -- 640 copies per million pairs, most of them a few
+// hundred KB, each paying the engine's fixed cost and queueing behind the others (H2D 0.08 ms alone, 0.3-0.4 ms under load).
+// bit 0: extension results, bit 1: SW results, bit 2: SW job table + sequences.  BPSW_ZEROCOPY=0 restores the copies.
+int zerocopy_mask() {
+  static const int m = getenv("BPSW_ZEROCOPY") ? atoi(getenv("BPSW_ZEROCOPY")) : 7;
+  return m;
+}
+
+double wall_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
+// ---- the per-device stream pool behind StreamLease (bpsw_internal.h) -------------------------------------------------
+namespace {
+struct StreamPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<hipStream_t> idle;
+  int created = 0;
+};
+StreamPool& stream_pool(int device) {
+  static StreamPool table[64];
+  return table[device >= 0 && device < 64 ? device : 0];
+}
+int stream_pool_cap() {
+  static const int cap = [] {
+    const char* e = getenv("BPSW_STREAM_POOL");
+    int v = e ? atoi(e) : 16;
+    return v < 0 ? 0 : (v > 64 ? 64 : v);
+  }();
+  return cap;
+}
+}  // namespace
+
+StreamLease::StreamLease(bpsw_ctx* c) : device(c->device), s(c->stream), pooled(false), wait_ms(0.) {
+  const int cap = stream_pool_cap();
+  if (cap == 0) return;
+  StreamPool& P = stream_pool(device);
+  const double t0 = wall_ms();
+  std::unique_lock<std::mutex> lk(P.mu);
+  for (;;) {
+    if (!P.idle.empty()) {
+      s = P.idle.back();
+      P.idle.pop_back();
+      pooled = true;
+      break;
+    }
+    if (P.created < cap) {
+      hipStream_t ns = nullptr;
+      if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
+        ++P.created;
+        s = ns;
+        pooled = true;
+      }  // else: fall back to the context's own stream for this call
+      break;
+    }
+    P.cv.wait(lk);
+  }
+  wait_ms = wall_ms() - t0;
+}
+StreamLease::~StreamLease() {
+  if (!pooled) return;
+  StreamPool& P = stream_pool(device);
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.idle.push_back(s);
+  }
+  P.cv.notify_one();
+}
+
 }  // namespace bpsw
 
 using namespace bpsw;
@@ -181,6 +262,14 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
     if (device >= n) return fail(BPSW_ERR_ARG, "bpsw_create: device index out of range");
   }
   HIP_TRY(hipSetDevice(device));
+  if (!spin_wait()) {
+    // Waiting host threads sleep until the device interrupts instead of spinning on the completion signal (the runtime's
+    // default when CPUs outnumber contexts): an executor's task threads share a CPU quota, and on this path two thirds of
+    // a call is waiting for the device.  Process-wide for this device; an error (flags already fixed by the host program)
+    // only means the host program's choice stands.
+    (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    (void)hipGetLastError();
+  }
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -198,7 +287,10 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
   c->ext_sc.certify = certify_level(c->ext_mat);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreate(&c->ev[i]);
+  // the events the blocking entry points wait on put the calling thread to sleep (interrupt-driven) instead of spinning:
+  // an executor's task threads share a CPU quota, and a spinning waiter takes it from the threads doing host work
+  // (BPSW_SPIN_WAIT=1 restores the runtime's default busy wait for A/B runs)
+  for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreateWithFlags(&c->ev[i], spin_wait() ? hipEventDefault : hipEventBlockingSync);
   // side streams of the opt-in quad-task experiment only: every stream takes a slot in the round robin over the HIP hardware
   // queues, and contexts that collide there serialise each other's launches
   const bool want_side_streams = getenv("BPSW_EXT_QT") && atoi(getenv("BPSW_EXT_QT")) != 0;  // == ext_qt_enabled()
@@ -226,6 +318,7 @@ void bpsw_destroy(bpsw_ctx_t* c) {
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
   c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release();
   c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();
+  rescue_scratch_free(c->rescue_scratch);
   for (int i = 0; i < 8; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int k = 0; k < 2; ++k) {
@@ -334,47 +427,63 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
   HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n + 16));
   HIP_TRY(c->h_stage_in.reserve(wire_bytes));
   HIP_TRY(c->h_stage_out.reserve(out_bytes));
+  const double t_in = wall_ms();
   memcpy(c->h_stage_in.ptr, wire, wire_bytes);
-  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  // bin the tasks on the device (which kernel handles which), read the three counts back, launch
-  int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
-  int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
-  const bool use_lane = ext_lane_enabled();
-  const bool use_qt = !use_lane && (int8_t)wire[2] + (int8_t)wire[3] > 0 && ext_qt_enabled();
-  h_counts[0] = h_counts[1] = 0; h_counts[2] = n;
-  if (use_lane) {
-    lane_sort_enqueue(c, (const uint32_t*)c->d_wire.ptr, n, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    rc = lane_launch(c, (const uint32_t*)c->d_wire.ptr, n, (int16_t*)c->d_out.ptr, mq, mr, h_counts, c->stream);
-    if (rc != BPSW_OK) return rc;
+  const double t_staged = wall_ms();
+  double t_dev0, t_dev1;
+  {
+    StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
+    hipStream_t s = lease.s;
+    t_dev0 = wall_ms();
+    HIP_TRY(hipEventRecord(c->ev[0], s));
+    HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(c->ev[1], s));
+    // bin the tasks on the device (which kernel handles which), read the three counts back, launch
+    int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
+    int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
+    const bool use_lane = ext_lane_enabled();
+    const bool use_qt = !use_lane && (int8_t)wire[2] + (int8_t)wire[3] > 0 && ext_qt_enabled();
+    h_counts[0] = h_counts[1] = 0; h_counts[2] = n;
+    if (use_lane) {
+      lane_sort_enqueue(c, (const uint32_t*)c->d_wire.ptr, n, s);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipEventRecord(c->ev[1], s));
+      rc = lane_launch(c, (const uint32_t*)c->d_wire.ptr, n, (int16_t*)c->d_out.ptr, mq, mr, h_counts, s);
+      if (rc != BPSW_OK) return rc;
+    }
+    if (use_qt) {
+      HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
+      launch_ext_bin((const uint32_t*)c->d_wire.ptr, n, (int*)c->d_ext_lists.ptr, d_counts, s);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipEventRecord(c->ev[1], s));
+    }
+    // results: written by the kernel straight into the pinned staging buffer (20 B per task, posted PCIe writes), or into
+    // device memory and copied back
+    const bool zc_out = (zerocopy_mask() & 1) && !use_lane;
+    int16_t* k_out = zc_out ? (int16_t*)c->h_stage_out.ptr : (int16_t*)c->d_out.ptr;
+    if (!use_lane)
+      HIP_TRY(launch_ext_all((const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, n, k_out, c->ext_sc, mq, mr, c->num_cu,
+                             (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts, use_qt, c->aux, s));
+    HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(c->ev[3], s));
+    HIP_TRY(hipEventSynchronize(c->ev[3]));  // the last operation of the call on this stream
+    t_dev1 = wall_ms();
+    c->stats.ext_wait_ms += lease.wait_ms;
   }
-  if (use_qt) {
-    HIP_TRY(hipMemsetAsync(d_counts, 0, 16, c->stream));
-    launch_ext_bin((const uint32_t*)c->d_wire.ptr, n, (int*)c->d_ext_lists.ptr, d_counts, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  }
-  if (!use_lane)
-    HIP_TRY(launch_ext_all((const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, n, (int16_t*)c->d_out.ptr, c->ext_sc, mq, mr, c->num_cu,
-                           (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts, use_qt, c->aux, c->stream));
-  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(out, c->h_stage_out.ptr, out_bytes);
+  const double t_out = wall_ms();
   float a = 0, b = 0, d = 0;
   (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
   (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n; c->stats.ext_wire_bytes += wire_bytes;
   c->stats.ext_h2d_ms += a; c->stats.ext_kernel_ms += b; c->stats.ext_d2h_ms += d;
+  c->stats.ext_host_in_ms += t_staged - t_in; c->stats.ext_dev_ms += t_dev1 - t_dev0; c->stats.ext_host_out_ms += t_out - t_dev1;
   c->last_ext_ms = b;
   c->have_ext_ev = false;
   return BPSW_OK;

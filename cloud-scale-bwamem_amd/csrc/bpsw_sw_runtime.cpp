@@ -44,7 +44,76 @@ void ref_snapshot(const bpsw_ctx* c, const uint8_t** pac, long long* l_pac) {
   *l_pac = r.l_pac;
 }
 
-// Stage the job table + pools in one pinned buffer, one H2D copy, one launch, one D2H copy.
+// Layout of a staged SW batch in c->h_stage_in (job table SoA + the two byte pools, every part 16-byte aligned).
+int sw_stage_begin(bpsw_ctx* c, int n, size_t q_pool_bytes, size_t t_pool_bytes, SwStage* st) {
+  st->n = n;
+  st->q_pool_bytes = q_pool_bytes; st->t_pool_bytes = t_pool_bytes;
+  st->o_qlen = 0; st->o_tlen = align16(st->o_qlen + 4 * (size_t)n); st->o_qoff = align16(st->o_tlen + 4 * (size_t)n);
+  st->o_toff = align16(st->o_qoff + 8 * (size_t)n); st->o_qrev = align16(st->o_toff + 8 * (size_t)n);
+  st->o_qpool = align16(st->o_qrev + (size_t)n); st->o_tpool = align16(st->o_qpool + q_pool_bytes);
+  st->total = align16(st->o_tpool + t_pool_bytes);
+  HIP_TRY(c->h_stage_in.reserve(st->total));
+  HIP_TRY(c->h_stage_out.reserve(28 * (size_t)n));
+  st->base = (uint8_t*)c->h_stage_in.ptr;
+  return BPSW_OK;
+}
+
+// One launch over a batch staged by sw_stage_begin (and filled by the caller): H2D (or the kernel reads the pinned block
+// itself), kernel, D2H.  *results = 7 int32 per job in the pinned result buffer, valid until the next call on the context.
+int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st, int mq, int mt, bool pac_mode, const int32_t** results) {
+  SwScoring sc;
+  int rc = make_scoring(opt, xtra, &sc);
+  if (rc != BPSW_OK) return rc;
+  const int n = st.n;
+  const uint8_t* d_pac = nullptr;
+  long long l_pac = 0;
+  ref_snapshot(c, &d_pac, &l_pac);
+  if (pac_mode && l_pac <= 0) return fail(BPSW_ERR_ARG, "swalign: t_pool is null and no reference is loaded (bpsw_ref_load)");
+  if (mq > BPSW_SW_MAX_QLEN || mt > BPSW_SW_MAX_TLEN) return fail(BPSW_ERR_LIMIT, "swalign: sequence longer than the kernel limit");
+  const size_t out_bytes = 28 * (size_t)n;
+  // zero-copy (bpsw_runtime.cpp, zerocopy_mask): the kernel reads the staging block and writes its results over PCIe
+  const bool zc_in = (zerocopy_mask() & 4) != 0, zc_out = (zerocopy_mask() & 2) != 0;
+  if (!zc_in) HIP_TRY(c->d_sw_in.reserve(st.total));
+  if (!zc_out) HIP_TRY(c->d_sw_out.reserve(out_bytes));
+  const size_t scratch = sw_scratch_bytes_per_wave(mt) * (size_t)sw_resident_waves(c->num_cu);
+  HIP_TRY(c->d_sw_scratch.reserve(scratch));
+  uint8_t* h = st.base;
+  uint8_t* d = zc_in ? h : (uint8_t*)c->d_sw_in.ptr;
+  int32_t* k_out = zc_out ? (int32_t*)c->h_stage_out.ptr : (int32_t*)c->d_sw_out.ptr;
+  SwJobsDev dev;
+  dev.n = n;
+  dev.q_len = (const int32_t*)(d + st.o_qlen); dev.t_len = (const int32_t*)(d + st.o_tlen);
+  dev.q_off = (const int64_t*)(d + st.o_qoff); dev.t_off = (const int64_t*)(d + st.o_toff);
+  dev.q_rev = d + st.o_qrev; dev.q_pool = d + st.o_qpool; dev.t_pool = pac_mode ? nullptr : d + st.o_tpool;
+  dev.pac = d_pac; dev.l_pac = l_pac;
+  {
+    StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
+    hipStream_t s = lease.s;
+    const double t_dev0 = wall_ms();
+    HIP_TRY(hipEventRecord(c->ev[0], s));
+    if (!zc_in) HIP_TRY(hipMemcpyAsync(d, h, st.total, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(c->ev[1], s));
+    HIP_TRY(launch_sw_kernel(dev, sc, mq, mt, k_out, (uint32_t*)c->d_sw_scratch.ptr, c->num_cu, s));
+    HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_sw_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(c->ev[3], s));
+    HIP_TRY(hipEventSynchronize(c->ev[3]));  // the last operation of the call on this stream
+    c->stats.grp_wait_ms += lease.wait_ms;
+    c->stats.grp_dev_ms += wall_ms() - t_dev0;
+  }
+  float a = 0, b = 0, e = 0;
+  (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&e, c->ev[2], c->ev[3]);
+  c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)n;
+  c->stats.sw_h2d_ms += a; c->stats.sw_kernel_ms += b; c->stats.sw_d2h_ms += e;
+  c->last_sw_ms = b;
+  c->have_sw_ev = false;
+  *results = (const int32_t*)c->h_stage_out.ptr;
+  return BPSW_OK;
+}
+
+// Jobs whose arrays live in host memory: validate, stage the job table + pools in one pinned block, run.
 int run_sw_jobs_host(bpsw_ctx* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* j, int32_t* out) {
   SwScoring sc;
   int rc = make_scoring(opt, j->xtra, &sc);
@@ -72,50 +141,19 @@ int run_sw_jobs_host(bpsw_ctx* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* j
     if (tl > mt) mt = tl;
   }
   if (mq > BPSW_SW_MAX_QLEN || mt > BPSW_SW_MAX_TLEN) return fail(BPSW_ERR_LIMIT, "swalign: sequence longer than the kernel limit");
-
-  // layout of the staging block
-  const size_t o_qlen = 0, o_tlen = align16(o_qlen + 4 * (size_t)n), o_qoff = align16(o_tlen + 4 * (size_t)n);
-  const size_t o_toff = align16(o_qoff + 8 * (size_t)n), o_qrev = align16(o_toff + 8 * (size_t)n);
-  const size_t o_qpool = align16(o_qrev + (size_t)n), o_tpool = align16(o_qpool + j->q_pool_bytes);
-  const size_t total = align16(o_tpool + t_pool_bytes);
-  const size_t out_bytes = 28 * (size_t)n;
-  HIP_TRY(c->h_stage_in.reserve(total));
-  HIP_TRY(c->d_sw_in.reserve(total));
-  HIP_TRY(c->h_stage_out.reserve(out_bytes));
-  HIP_TRY(c->d_sw_out.reserve(out_bytes));
-  const size_t scratch = sw_scratch_bytes_per_wave(mt) * (size_t)sw_resident_waves(c->num_cu);
-  HIP_TRY(c->d_sw_scratch.reserve(scratch));
-  uint8_t* h = (uint8_t*)c->h_stage_in.ptr;
-  memcpy(h + o_qlen, j->q_len, 4 * (size_t)n); memcpy(h + o_tlen, j->t_len, 4 * (size_t)n);
-  memcpy(h + o_qoff, j->q_off, 8 * (size_t)n); memcpy(h + o_toff, j->t_off, 8 * (size_t)n);
-  memcpy(h + o_qrev, j->q_rev, (size_t)n);
-  memcpy(h + o_qpool, j->q_pool, j->q_pool_bytes);
-  if (!pac_mode) memcpy(h + o_tpool, j->t_pool, t_pool_bytes);
-  uint8_t* d = (uint8_t*)c->d_sw_in.ptr;
-  SwJobsDev dev;
-  dev.n = n;
-  dev.q_len = (const int32_t*)(d + o_qlen); dev.t_len = (const int32_t*)(d + o_tlen);
-  dev.q_off = (const int64_t*)(d + o_qoff); dev.t_off = (const int64_t*)(d + o_toff);
-  dev.q_rev = d + o_qrev; dev.q_pool = d + o_qpool; dev.t_pool = pac_mode ? nullptr : d + o_tpool;
-  dev.pac = d_pac; dev.l_pac = l_pac;
-
-  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  HIP_TRY(launch_sw_kernel(dev, sc, mq, mt, (int32_t*)c->d_sw_out.ptr, (uint32_t*)c->d_sw_scratch.ptr, c->num_cu, c->stream));
-  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_sw_out.ptr, out_bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  memcpy(out, c->h_stage_out.ptr, out_bytes);
-  float a = 0, b = 0, e = 0;
-  (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
-  (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-  (void)hipEventElapsedTime(&e, c->ev[2], c->ev[3]);
-  c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)n;
-  c->stats.sw_h2d_ms += a; c->stats.sw_kernel_ms += b; c->stats.sw_d2h_ms += e;
-  c->last_sw_ms = b;
-  c->have_sw_ev = false;
+  SwStage st;
+  rc = sw_stage_begin(c, n, j->q_pool_bytes, t_pool_bytes, &st);
+  if (rc != BPSW_OK) return rc;
+  uint8_t* h = st.base;
+  memcpy(h + st.o_qlen, j->q_len, 4 * (size_t)n); memcpy(h + st.o_tlen, j->t_len, 4 * (size_t)n);
+  memcpy(h + st.o_qoff, j->q_off, 8 * (size_t)n); memcpy(h + st.o_toff, j->t_off, 8 * (size_t)n);
+  memcpy(h + st.o_qrev, j->q_rev, (size_t)n);
+  memcpy(h + st.o_qpool, j->q_pool, j->q_pool_bytes);
+  if (!pac_mode) memcpy(h + st.o_tpool, j->t_pool, t_pool_bytes);
+  const int32_t* res = nullptr;
+  rc = sw_stage_run(c, opt, j->xtra, st, mq, mt, pac_mode, &res);
+  if (rc != BPSW_OK) return rc;
+  memcpy(out, res, 28 * (size_t)n);
   return BPSW_OK;
 }
 

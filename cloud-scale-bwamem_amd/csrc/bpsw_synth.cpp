@@ -191,3 +191,135 @@ int bpsw_synth_sw_jobs(const bpsw_synth_sw_cfg_t* c, int32_t* q_len, int32_t* t_
 }
 
 }  // extern "C"
+
+// ---- pair-end rescue groups (boundary 1), the flat layout of bpsw_rescue_group_t -------------------------------------
+// Same model as bpsw_hip/synth.py::rescue_group without a backing reference (FR library, insert ~ N(400, 50^2), windows of
+// random bases with the mutated mate planted where the insert puts it), written here because bench.py needs a million
+// distinct pairs per step and the Python loop makes two thousand a second.
+namespace {
+struct SynReg { int64_t rb, re; int32_t qb, qe, score, truesc, sub, csub, sub_n, w, seedcov, secondary; uint64_t hash; };
+static_assert(sizeof(SynReg) == 64, "bpsw_alnreg_t layout");
+double gauss(Rng& g) {  // Box-Muller, one value per call
+  double u1 = g.uni(), u2 = g.uni();
+  if (u1 < 1e-300) u1 = 1e-300;
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+}  // namespace
+
+extern "C" {
+
+typedef struct {
+  uint64_t seed;
+  int32_t n_pairs, read_len;
+  int64_t l_pac;
+  double p_resc, sub_rate, indel_rate, p_multi_anchor, p_wrong_mate;
+  int32_t max_matesw, pen_unpaired;
+  int32_t low, high;  // the FR insert-size bounds (the other three orientations are `failed`)
+  double avg, std;
+} bpsw_synth_group_cfg_t;
+
+// Capacities the caller must provide for n pairs of read length L:
+//   seq_*: 2n, seq_pool: 2n * align16(L); reg_cnt/ref_cnt: 2n; regs: 6n; ref_rb/re/len/off: 16n; ref_pool: 4n * align16(high - low + 2L)
+// out_counts[4] = {regs, anchor rows, seq_pool bytes, ref_pool bytes}.  Returns 0, or -1 when a pool is too small.
+int bpsw_synth_rescue_group(const bpsw_synth_group_cfg_t* c, int32_t* seq_len, int64_t* seq_off, uint8_t* seq_pool, size_t seq_cap,
+                            int32_t* reg_cnt, void* regs_v, size_t regs_cap, int32_t* ref_cnt, int64_t* ref_rb, int64_t* ref_re,
+                            int64_t* ref_len, int64_t* ref_off, size_t rows_cap, uint8_t* ref_pool, size_t ref_cap,
+                            int64_t out_counts[4]) {
+  SynReg* regs = (SynReg*)regs_v;
+  Rng g(c->seed);
+  const int L = c->read_len;
+  const int64_t l2 = c->l_pac << 1;
+  std::vector<uint8_t> clean[2], rd[2], tmp;
+  std::vector<int> rpos;
+  std::vector<uint8_t> src((size_t)L * 2 + 64);
+  size_t seq_at = 0, ref_at = 0, nreg = 0, nrow = 0;
+  auto mk = [&](int64_t rb, int score, int qb, int qe) {
+    SynReg r;
+    memset(&r, 0, sizeof r);
+    r.rb = rb; r.re = rb + (qe - qb); r.qb = qb; r.qe = qe; r.score = score; r.truesc = score; r.w = 100;
+    r.seedcov = (qe - qb) / 2; r.secondary = -1; r.hash = g.next() >> 2;
+    return r;
+  };
+  for (int k = 0; k < c->n_pairs; ++k) {
+    const int64_t P = 2000 + (int64_t)(g.next() % (uint64_t)(c->l_pac - 5000));
+    int ins = (int)(c->avg + c->std * gauss(g));
+    if (ins < c->low + 20) ins = c->low + 20;
+    if (ins > c->high - 20) ins = c->high - 20;
+    for (int i = 0; i < 2; ++i) {
+      // a clean locus with some spare bases behind it for deletions, mutated into a read of exactly L bases
+      for (auto& b : src) b = (uint8_t)g.base();
+      clean[i].assign(src.begin(), src.begin() + L);
+      make_read(g, src.data(), (int)src.size(), L, c->sub_rate, c->indel_rate, 0.0, tmp, rpos);
+      rd[i] = tmp;
+    }
+    for (int i = 0; i < L / 2; ++i) std::swap(rd[1][(size_t)i], rd[1][(size_t)(L - 1 - i)]);  // end 1 is sequenced from the reverse strand
+    for (auto& b : rd[1]) b = b < 4 ? (uint8_t)(3 - b) : b;
+    const int64_t true_rb[2] = {P, l2 - (P + ins)};
+    bool have[2] = {true, true};
+    if (g.uni() < c->p_resc) have[g.below(2)] = false;
+    SynReg er[2][3];
+    int ne[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) {
+      if (have[i]) {
+        er[i][ne[i]++] = mk(true_rb[i], L - g.below(8), 0, L);
+        if (g.uni() < c->p_multi_anchor) er[i][ne[i]++] = mk(true_rb[i] + 1 + g.below(3), er[i][0].score - g.below(c->pen_unpaired), 0, L);
+        if (g.uni() < 0.15) er[i][ne[i]++] = mk((int64_t)(g.next() % (uint64_t)(l2 - L)), er[i][0].score - c->pen_unpaired - 5, 10, L - 20);
+      } else if (g.uni() < c->p_wrong_mate) {
+        er[i][ne[i]++] = mk((int64_t)(g.next() % (uint64_t)(l2 - L)), L / 2, 0, L / 2 + 10);
+      }
+      std::stable_sort(er[i], er[i] + ne[i], [](const SynReg& x, const SynReg& y) { return x.score > y.score; });
+    }
+    const size_t Lp = ((size_t)L + 15) & ~(size_t)15;
+    for (int i = 0; i < 2; ++i) {
+      if (seq_at + Lp > seq_cap) return -1;
+      seq_len[2 * k + i] = L; seq_off[2 * k + i] = (int64_t)seq_at;
+      memcpy(seq_pool + seq_at, rd[i].data(), (size_t)L);
+      memset(seq_pool + seq_at + L, 0, Lp - (size_t)L);
+      seq_at += Lp;
+    }
+    for (int i = 0; i < 2; ++i) {
+      if (nreg + (size_t)ne[i] > regs_cap) return -1;
+      reg_cnt[2 * k + i] = ne[i];
+      for (int j = 0; j < ne[i]; ++j) regs[nreg++] = er[i][j];
+      int na = 0;
+      for (int j = 0; j < ne[i] && na < c->max_matesw; ++j)
+        if (er[i][j].score >= er[i][0].score - c->pen_unpaired) ++na;
+      ref_cnt[2 * k + i] = na;
+      if (nrow + (size_t)na > rows_cap) return -1;
+      int ja = 0;
+      for (int j = 0; j < ne[i] && ja < na; ++j) {
+        if (!(er[i][j].score >= er[i][0].score - c->pen_unpaired)) continue;
+        const SynReg& a = er[i][j];
+        for (int r = 0; r < 4; ++r) {
+          const size_t x = 4 * nrow + (size_t)r;
+          if (r != 1) { ref_rb[x] = -1; ref_re[x] = -1; ref_len[x] = 0; ref_off[x] = 0; continue; }  // failed orientations
+          // getAlnRegRefJNI, MemSamPe.scala:1810-1878: r = 1 is reversed and "larger"
+          int64_t rb = a.rb + c->low - L, re = a.rb + c->high;
+          if (rb < 0) rb = 0;
+          if (re > l2) re = l2;
+          const int64_t n = re > rb ? re - rb : 0;
+          const size_t np = ((size_t)n + 15) & ~(size_t)15;
+          if (ref_at + np > ref_cap) return -1;
+          uint8_t* w = ref_pool + ref_at;
+          for (int64_t t = 0; t < n; ++t) w[t] = (uint8_t)g.base();
+          memset(w + n, 0, np - (size_t)n);
+          const int64_t d = a.rb - true_rb[i];
+          if (d > -8 && d < 8 && n >= L) {  // the mate lies `ins - L` past the true anchor start, on the anchor's strand
+            const int64_t off = (a.rb - rb) + (ins - L) + (true_rb[i] - a.rb);
+            if (off >= 0 && off <= n - L) {
+              const std::vector<uint8_t>& cm = clean[1 - i];
+              for (int t = 0; t < L; ++t) w[off + t] = i == 0 ? cm[(size_t)t] : (uint8_t)(3 - cm[(size_t)(L - 1 - t)]);
+            }
+          }
+          ref_rb[x] = rb; ref_re[x] = re; ref_len[x] = n; ref_off[x] = (int64_t)ref_at;
+          ref_at += np;
+        }
+        ++nrow; ++ja;
+      }
+    }
+  }
+  out_counts[0] = (int64_t)nreg; out_counts[1] = (int64_t)nrow; out_counts[2] = (int64_t)seq_at; out_counts[3] = (int64_t)ref_at;
+  return 0;
+}
+
+}  // extern "C"

@@ -364,6 +364,12 @@ typedef struct {
   uint64_t sw_calls, sw_jobs, sw_speculated, sw_replayed_rounds, sw_wasted;
   double ext_h2d_ms, ext_kernel_ms, ext_d2h_ms;
   double sw_h2d_ms, sw_kernel_ms, sw_d2h_ms, sw_host_ms;
+  /* wall-clock phases of the host-buffer entry points, summed over calls (ms): staging copy in, waiting for a device
+   * stream of the pool, device phase (H2D + kernel + D2H until the stream is idle), staging copy out; for the group
+   * rescue: speculation, job packing, waiting, device phase, replay, output copy */
+  double ext_host_in_ms, ext_wait_ms, ext_dev_ms, ext_host_out_ms;
+  double grp_plan_ms, grp_pack_ms, grp_wait_ms, grp_dev_ms, grp_replay_ms, grp_out_ms;
+  uint64_t grp_calls, grp_pairs;
 } bpsw_stats_t;
 int bpsw_get_stats(bpsw_ctx_t *ctx, bpsw_stats_t *out);
 int bpsw_reset_stats(bpsw_ctx_t *ctx);

@@ -1,10 +1,13 @@
 """The N>1 path of bench.py on CPU: two processes, gloo backend.  The hot path has no data-path collective
 (Spark partition -> device), so what multi-rank runs rely on is (1) every rank deriving a disjoint,
-deterministic shard of the synthetic pairs from its rank, and (2) the barrier / MAX-over-ranks timing protocol and
-the whole-job aggregation.  Both are exercised here without a GPU; the kernels themselves are covered by -m gpu."""
+deterministic shard of the synthetic pairs from its rank -- bench.build_inputs itself, on a cut-down workload -- and
+(2) bench.py's own barrier / MAX-over-ranks / ranks-seen reduction and whole-job aggregation (bench.reduce_over_ranks,
+bench.whole_job_rate) around a really timed region.  No GPU is needed; the kernels are covered by -m gpu, and the
+partition -> context -> device mapping of the JNI shim by tests/test_jni_shim.py."""
 import os
 import socket
 import sys
+import time
 
 import numpy as np
 import torch
@@ -22,29 +25,39 @@ def _free_port():
     return p
 
 
+def _small_workload(bench):
+    W = dict(bench.WORKLOADS[3])
+    W["ext_batches"], W["groups"] = 2, 2
+    bench.READS_PER_EXT_BATCH, bench.PAIRS_PER_GROUP = 512, 64   # the generators take the sizes from the module
+    return W
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.join(ROOT, "cloud-scale-bwamem_amd"))
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
-    from bpsw_hip import synth, wire_pack
+    W = _small_workload(bench)
 
-    # (1) rank-dependent shard: same generator, seed offset by rank (bench.build_inputs); small sizes here
-    seed0 = synth.CONFIG_SEED_BASE + 3 + 1000 * rank
-    soa = synth.ext_tasks(256, read_len=bench.READ_LEN, seed=seed0)
-    wire = wire_pack(soa)
-    digest = torch.tensor([int(np.frombuffer(wire.tobytes(), np.uint8).astype(np.int64).sum()), soa.n], dtype=torch.int64)
-    gathered = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    # (1) this rank's shard, by bench.py's own generator
+    wires, ntasks, groups = bench.build_inputs(W, 3, rank, workers=2)
+    digest = torch.tensor([int(sum(int(w.astype(np.int64).sum()) for w in wires)), int(sum(ntasks)),
+                           int(sum(int(g.seq_pool.astype(np.int64).sum()) for g in groups))], dtype=torch.int64)
+    gathered = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(gathered, digest)
 
-    # (2) timing protocol of bench.py: barrier, local elapsed, MAX over ranks, whole-job aggregate
+    # (2) bench.py's timing protocol around a timed region whose length depends on the rank (rank 1 is the slow one)
     dist.barrier()
-    elapsed = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)   # rank 1 is the slow one
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    reads_total = 2 * bench.PAIRS_PER_STEP * 3 * world
-    value = reads_total / float(elapsed.item())
-    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([g.tolist() for g in gathered] + [[value, elapsed.item()]], dtype=np.float64))
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))
+    dist.barrier()                      # as in bench.py: the timed region ends with a barrier, so every rank waits for the slowest
+    elapsed = time.perf_counter() - t0
+    elapsed_max, ranks_seen = bench.reduce_over_ranks(elapsed, "cpu")
+    reads_per_step = bench.READS_PER_EXT_BATCH * W["ext_batches"]
+    value = bench.whole_job_rate(reads_per_step, 3, world, elapsed_max)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"),
+            np.array([g.tolist() for g in gathered] + [[value, elapsed_max, ranks_seen], [elapsed, reads_per_step, 0]], dtype=np.float64))
     dist.destroy_process_group()
 
 
@@ -52,17 +65,26 @@ def test_two_rank_sharding_and_timing_protocol(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
-    assert np.array_equal(r0, r1)                      # every rank sees the same gathered view and the same aggregate
-    assert r0[0, 0] != r0[1, 0]                        # shards differ between ranks
-    import bench
-    assert abs(r0[2, 1] - 0.020) < 1e-12               # MAX over ranks
-    assert abs(r0[2, 0] - 2 * bench.PAIRS_PER_STEP * 3 * 2 / 0.020) < 1e-3   # whole-job reads / max time
+    assert np.array_equal(r0[:3], r1[:3])              # every rank sees the same gathered view and the same aggregate
+    assert r0[0, 0] != r0[1, 0] and r0[0, 2] != r0[1, 2]   # the ranks' wire batches and rescue groups differ
+    value, elapsed_max, ranks_seen = r0[2]
+    assert ranks_seen == 2
+    assert elapsed_max >= max(r0[3, 0], r1[3, 0]) - 1e-9 and elapsed_max >= 0.1   # MAX over ranks, and it covers the slow rank's sleep
+    assert abs(value - r0[3, 1] * 3 * 2 / elapsed_max) < 1e-6 * value       # whole-job reads / max time
 
 
 def test_rank_shards_are_deterministic():
     sys.path.insert(0, os.path.join(ROOT, "cloud-scale-bwamem_amd"))
-    from bpsw_hip import synth, wire_pack
-    a = wire_pack(synth.ext_tasks(128, seed=synth.CONFIG_SEED_BASE + 3 + 1000))
-    b = wire_pack(synth.ext_tasks(128, seed=synth.CONFIG_SEED_BASE + 3 + 1000))
-    c = wire_pack(synth.ext_tasks(128, seed=synth.CONFIG_SEED_BASE + 3))
-    assert np.array_equal(a, b) and not np.array_equal(a[: min(a.size, c.size)], c[: min(a.size, c.size)])
+    sys.path.insert(0, ROOT)
+    import bench
+    saved = bench.READS_PER_EXT_BATCH, bench.PAIRS_PER_GROUP
+    try:
+        W = _small_workload(bench)
+        a = bench.build_inputs(W, 3, 1, workers=2)
+        b = bench.build_inputs(W, 3, 1, workers=2)
+        c = bench.build_inputs(W, 3, 0, workers=2)
+    finally:
+        bench.READS_PER_EXT_BATCH, bench.PAIRS_PER_GROUP = saved
+    assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0])) and a[1] == b[1]
+    assert all(np.array_equal(x.seq_pool, y.seq_pool) and np.array_equal(x.regs, y.regs) for x, y in zip(a[2], b[2]))
+    assert not all(x.size == y.size and np.array_equal(x, y) for x, y in zip(a[0], c[0]))
