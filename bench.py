@@ -2,8 +2,10 @@
 """bench.py -- reads aligned/sec through the MI355X batched Smith-Waterman path, measured the way SURVEY.md 8(d) defines it:
 wall clock of the HOST-BUFFER C ABI calls the two JNI symbols make, H2D / D2H and the whole boundary-1 host layer included.
 
-One step = one pass of the hot path over PAIRS_PER_STEP DISTINCT synthetic read pairs (default workload: BASELINE.json
-configs[2], 2x150 bp, 1 % substitutions, 0.1 % indels, 10 % of the pairs need mate rescue; 1 048 576 pairs per step):
+One step = the hot path over 3 145 728 synthetic read pairs: three passes over a set of 1 048 576 DISTINCT pairs (2.3 GB of
+host inputs, far beyond any cache, so a pass never finds its data warm; three so that the driver's 20 steps time a full
+second).  Default workload: BASELINE.json configs[2], 2x150 bp, 1 % substitutions, 0.1 % indels, 10 % of the pairs need mate
+rescue.  Per pass:
   * boundary 2: one bpsw_extend_batch call per wire batch of 32 768 reads (the reference's -bSWExtSize 32768, run_test.sh:7;
     the call behind MemChainToAlignBatched.scala:175-176), host wire bytes in, host int16 results out;
   * boundary 1: one bpsw_matesw_group call per group of 4 096 pairs (the call behind native/jni_mate_sw.c:534 /
@@ -48,14 +50,14 @@ WORKLOADS = {
     3: dict(label="configs[2]: 10M-pair-shaped stream of pair-end 2x150bp synthetic reads (1% sub, 0.1% indel) vs a chr21-sized "
                   "coordinate space, batched seed extension + batched pair-end SW rescue (10% of pairs)",
             metric="pair-end 2x150bp reads aligned/sec", read_len=150, sub=0.01, indel=0.001, tail_frac=0.0, tail_sub=0.2,
-            tail_indel=0.02, p_resc=0.10, mate_sub=0.02, mate_indel=0.002, paired=True, ext_batches=64, groups=256),
+            tail_indel=0.02, p_resc=0.10, mate_sub=0.02, mate_indel=0.002, paired=True, ext_batches=64, groups=256, passes=3),
     2: dict(label="configs[1]: single-end 150bp synthetic reads (1% sub, 0.1% indel), HIP seed extension only",
             metric="single-end 150bp reads aligned/sec", read_len=150, sub=0.01, indel=0.001, tail_frac=0.0, tail_sub=0.2,
-            tail_indel=0.02, p_resc=0.0, mate_sub=0.0, mate_indel=0.0, paired=False, ext_batches=32, groups=0),
+            tail_indel=0.02, p_resc=0.0, mate_sub=0.0, mate_indel=0.0, paired=False, ext_batches=32, groups=0, passes=8),
     5: dict(label="configs[4]: pair-end 2x250bp high-error synthetic reads (8% sub, 2% indel, 1% of reads at 20%/2%), "
                   "wide-band extension + pair-end SW rescue (25% of pairs)",
             metric="pair-end 2x250bp reads aligned/sec", read_len=250, sub=0.08, indel=0.02, tail_frac=0.01, tail_sub=0.20,
-            tail_indel=0.02, p_resc=0.25, mate_sub=0.08, mate_indel=0.02, paired=True, ext_batches=8, groups=32),
+            tail_indel=0.02, p_resc=0.25, mate_sub=0.08, mate_indel=0.02, paired=True, ext_batches=8, groups=32, passes=2),
 }
 
 
@@ -332,7 +334,9 @@ def main():
     allowed = sorted(os.sched_getaffinity(0))
     ranks_on_node = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     share = numa_cpus if numa_cpus else allowed[(local_rank % ranks_on_node)::ranks_on_node] if distributed else allowed
-    n_threads = args.threads if args.threads > 0 else max(2, min(16, len(share)))
+    # 24: the device phases of the calls share a pool of 16 streams (bpsw_internal.h, StreamLease), and half as many threads
+    # again keep it full while the others stage bytes or replay bookkeeping; more change nothing
+    n_threads = args.threads if args.threads > 0 else max(2, min(24, len(share)))
     if share and (numa_cpus or distributed):
         try:
             os.sched_setaffinity(0, share)   # before the inputs are generated: first touch puts them on the GPU's node
@@ -378,14 +382,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    passes = W["passes"]
+    for _ in range(args.warmup * passes):
         F.run(items)
     F.reset_stats()
     barrier()
     cpu0 = os.times()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        F.run(items)                 # every call of the step complete, results in host memory
+    for _ in range(args.steps * passes):
+        F.run(items)                 # every call of the pass complete, results in host memory
     barrier()
     elapsed = time.perf_counter() - t0
     cpu1 = os.times()
@@ -400,9 +405,10 @@ def main():
     if distributed:
         elapsed, ranks_seen = reduce_over_ranks(elapsed, dev if backend == "nccl" else "cpu")
 
-    reads_per_step = READS_PER_EXT_BATCH * W["ext_batches"]
+    reads_per_pass = READS_PER_EXT_BATCH * W["ext_batches"]
+    assert only or not W["paired"] or reads_per_pass // 2 == PAIRS_PER_GROUP * W["groups"]
+    reads_per_step = reads_per_pass * passes
     pairs_per_step = reads_per_step // 2 if W["paired"] else 0
-    assert only or not W["paired"] or pairs_per_step == PAIRS_PER_GROUP * W["groups"]
     value = whole_job_rate(reads_per_step, args.steps, world, elapsed)
 
     # ---- a sample of the timed outputs against the oracle (outside the timed region; the only use of oracle/ besides cpu_baseline)
@@ -428,7 +434,7 @@ def main():
             traffic = None
     host_ms = {k: {"mean": round(float(np.mean(v)), 4), "p50": round(float(np.median(v)), 4), "max": round(float(np.max(v)), 4)} if v else None
                for k, v in call_ms.items()}
-    pcie_bytes_per_step = sum(int(w.size) for w in wires) + 20 * sum(ntasks)   # boundary 2 both ways; boundary 1 below
+    pcie_bytes_per_step = passes * (sum(int(w.size) for w in wires) + 20 * sum(ntasks))   # boundary 2 both ways; boundary 1 below
     pcie_bytes_per_step += int((st["sw_jobs"] / max(args.steps, 1)) * (W["read_len"] + win_len + 28 + 29))
 
     extras = {}
@@ -450,10 +456,11 @@ def main():
         "vs_baseline": None, "dtype": "int32 (extension) / packed u16 (rescue SW, exact under the 255 score cap)", "data": "synthetic",
         "config": {"workload": W["label"], "survey_config": args.config,
                    "pairs_per_step_per_gpu": pairs_per_step, "reads_per_step_per_gpu": reads_per_step,
-                   "ext_batches_per_step": W["ext_batches"], "reads_per_ext_batch": READS_PER_EXT_BATCH,
-                   "ext_tasks_per_step": int(sum(ntasks)), "rescue_groups_per_step": W["groups"], "pairs_per_group": PAIRS_PER_GROUP,
+                   "passes_per_step": passes, "distinct_reads_per_pass": reads_per_pass,
+                   "ext_batches_per_step": passes * W["ext_batches"], "reads_per_ext_batch": READS_PER_EXT_BATCH,
+                   "ext_tasks_per_step": passes * int(sum(ntasks)), "rescue_groups_per_step": passes * W["groups"], "pairs_per_group": PAIRS_PER_GROUP,
                    "rescue_jobs_per_step": int(st["sw_jobs"] / max(args.steps, 1)),
-                   "distinct_pairs_streamed": int(pairs_per_step * args.steps * world) if W["paired"] else 0,
+                   "reads_streamed_in_timed_region": int(reads_per_step * args.steps * world),
                    "timed_region": "host buffers in, host buffers out: bpsw_extend_batch per wire batch + bpsw_matesw_group per group "
                                    "(H2D, kernels, D2H, speculate/replay, sort/dedup all inside)",
                    "host_threads_per_gpu": n_threads, "numa_node": numa_node, "feeder_cpus": len(share),

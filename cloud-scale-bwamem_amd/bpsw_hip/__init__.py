@@ -25,7 +25,7 @@ KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
 
 # every symbol include/bpsw.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
-    "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_last_error", "bpsw_version",
+    "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_device_slots", "bpsw_device_for_partition", "bpsw_last_error", "bpsw_version",
     "bpsw_set_ext_scoring", "bpsw_extend_batch", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",

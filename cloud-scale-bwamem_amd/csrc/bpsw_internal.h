@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -221,7 +222,41 @@ struct PinnedBuffer {
 
 // The 2-bit reference (bpsw_ref_load) is shared by every context of a device: the JNI shim keeps one context per
 // Spark task thread, and 20 copies of a 0.8 GB genome would be pointless.
+// Readers (every call that launches kernels over the resident reference) hold the gate for the duration of the call; a load /
+// unload holds it exclusively while it frees or reallocates the buffers, so that no thread can sit between taking the device
+// pointer and launching while another context replaces the reference (one context per task thread share one reference).
+// Reader-preferring: a nested read never waits for a queued writer, only for an active one.
+struct RefGate {
+  std::mutex m;
+  std::condition_variable cv;
+  int readers = 0;
+  bool writing = false;
+  void read_lock() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !writing; }); ++readers; }
+  void read_unlock() { std::lock_guard<std::mutex> lk(m); if (--readers == 0) cv.notify_all(); }
+  void write_lock() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !writing && readers == 0; }); writing = true; }
+  void write_unlock() { { std::lock_guard<std::mutex> lk(m); writing = false; } cv.notify_all(); }
+};
+struct RefHold {  // RAII read side of the gate; movable
+  RefGate* g = nullptr;
+  RefHold() = default;
+  explicit RefHold(RefGate* gate) : g(gate) { if (g) g->read_lock(); }
+  RefHold(RefHold&& o) noexcept : g(o.g) { o.g = nullptr; }
+  RefHold& operator=(RefHold&& o) noexcept { if (this != &o) { release(); g = o.g; o.g = nullptr; } return *this; }
+  RefHold(const RefHold&) = delete;
+  RefHold& operator=(const RefHold&) = delete;
+  void release() { if (g) { g->read_unlock(); g = nullptr; } }
+  ~RefHold() { release(); }
+};
+struct RefWriteHold {
+  RefGate* g;
+  explicit RefWriteHold(RefGate* gate) : g(gate) { g->write_lock(); }
+  ~RefWriteHold() { g->write_unlock(); }
+  RefWriteHold(const RefWriteHold&) = delete;
+  RefWriteHold& operator=(const RefWriteHold&) = delete;
+};
+
 struct DeviceRef {
+  RefGate gate;
   std::mutex mu;
   DeviceBuffer buf;
   long long l_pac = 0;
@@ -250,10 +285,13 @@ struct StreamLease {
   StreamLease& operator=(const StreamLease&) = delete;
 };
 double wall_ms();
+hipError_t wait_event(bpsw_ctx* c, hipEvent_t ev, int kind);  // kind 0: extension call, 1: SW call (separate duration estimates)
 int zerocopy_mask();  // BPSW_ZEROCOPY, see bpsw_runtime.cpp
 bool spin_wait();  // BPSW_SPIN_WAIT=1: busy-wait for the device instead of sleeping on a blocking event
-// snapshot of the reference loaded on c's device (l_pac == 0: none)
-void ref_snapshot(const bpsw_ctx* c, const uint8_t** pac, long long* l_pac);
+// snapshot of the reference loaded on c's device (l_pac == 0: none).  The returned hold keeps load / unload out until it is
+// destroyed: keep it alive until the kernels that use `pac` have been waited for (the asynchronous device entries, which return
+// before that, rely on the hipDeviceSynchronize a load / unload performs after it has got the gate).
+[[nodiscard]] RefHold ref_snapshot(const bpsw_ctx* c, const uint8_t** pac, long long* l_pac);
 
 // Asynchronous device entries (bpsw_extend_batch_device, bpsw_swalign2_batch_device) leave a launch whose table scan has not
 // been read back; every entry point that reuses the context's scan buffers or stream resolves it first.  Caller holds c->mu
@@ -298,7 +336,9 @@ struct bpsw_ctx {
                       hipStream_t s = nullptr; int qcap = 0, rcap = 0; } pend_ext;
   int ext_geom_q = 0, ext_geom_r = 0;  // longest query / target side of the verified extension launches on this context (speculation)
   struct PendingSw { bool active = false; bpsw_sw_jobs_t jobs; bpsw_opt_t opt; void* d_out = nullptr; hipStream_t s = nullptr;
-                     int cap_qlen = 0, cap_tlen = 0; } pend_sw;
+                     int cap_qlen = 0, cap_tlen = 0;
+                     bool verified = false;  // launched after the scan was read back: nothing to resolve, only to wait for
+  } pend_sw;
   int sw_geom_qlen = 0, sw_geom_tlen = 0;  // geometry of the last verified SW launch on this context (speculation for the next)
   float last_tail_ms = 0.f;
   int last_tail_jobs = 0, last_tail_resubmitted = 0;
@@ -306,6 +346,7 @@ struct bpsw_ctx {
   bool have_tail_ev = false;
 
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
+  double wait_est_ms[2] = {0., 0.};  // wait_event: running average of the device-phase waits (extension, SW)
   void* rescue_scratch = nullptr;  // bpsw_rescue.cpp: vectors reused across bpsw_matesw_group calls (freed by rescue_scratch_free)
   bpsw_stats_t stats;
   float last_ext_ms = 0.f, last_sw_ms = 0.f;

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,10 +34,12 @@
 namespace {
 
 // One context per (thread, device): Spark runs several task threads per executor JVM and the reference
-// native code is re-entrant, so calls from different threads must not serialise on one stream.
+// native code is re-entrant, so calls from different threads must not serialise on one stream.  The context is released by
+// the thread_local destructor when the task thread exits (stream, arenas, pinned staging).
 struct ThreadCtx {
   bpsw_ctx_t* ctx = nullptr;
   int device = -1;
+  int partition = -1, slot = -1;  // what the last call on this thread saw (bpsw_jni_thread_info, for the tests)
   ~ThreadCtx() {
     if (ctx) bpsw_destroy(ctx);
   }
@@ -48,27 +51,49 @@ void clear_pending(JNIEnv* env) {
 }
 
 // Spark partition -> device (north_star: "Spark-partition -> device index").  The partition id is not in
-// either JNI signature; org.apache.spark.TaskContext.get().partitionId() is reachable through JNIEnv.
+// either JNI signature; org.apache.spark.TaskContext.get().partitionId() is reachable through JNIEnv.  The class and the two
+// method IDs are resolved once per process (a global reference keeps the class, and with it the IDs, alive).
+struct SparkIds {
+  jclass cls = nullptr;
+  jmethodID get = nullptr, pid = nullptr;
+};
+std::mutex g_ids_mu;
+std::atomic<const SparkIds*> g_spark{nullptr};
+std::atomic<bool> g_no_spark{false};  // TaskContext is not on the class path (a harness, not an executor): do not ask again
+
 int spark_partition_id(JNIEnv* env) {
-  jclass cls = jni::FindClass(env, "org/apache/spark/TaskContext");
-  if (!cls || jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
-  jmethodID get = jni::GetStaticMethodID(env, cls, "get", "()Lorg/apache/spark/TaskContext;");
-  if (!get || jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
-  jobject tc = jni::CallStaticObjectMethod(env, cls, get);
+  const SparkIds* ids = g_spark.load(std::memory_order_acquire);
+  if (!ids) {
+    if (g_no_spark.load(std::memory_order_relaxed)) return -1;
+    std::lock_guard<std::mutex> lk(g_ids_mu);
+    ids = g_spark.load(std::memory_order_acquire);
+    if (!ids) {
+      jclass cls = jni::FindClass(env, "org/apache/spark/TaskContext");
+      if (!cls || jni::ExceptionCheck(env)) { clear_pending(env); g_no_spark.store(true); return -1; }
+      SparkIds* n = new SparkIds();
+      n->get = jni::GetStaticMethodID(env, cls, "get", "()Lorg/apache/spark/TaskContext;");
+      n->pid = (n->get && !jni::ExceptionCheck(env)) ? jni::GetMethodID(env, cls, "partitionId", "()I") : nullptr;
+      if (!n->get || !n->pid || jni::ExceptionCheck(env)) { clear_pending(env); delete n; return -1; }
+      n->cls = (jclass)jni::NewGlobalRef(env, cls);
+      jni::DeleteLocalRef(env, cls);
+      if (!n->cls) { clear_pending(env); delete n; return -1; }
+      g_spark.store(n, std::memory_order_release);
+      ids = n;
+    }
+  }
+  jobject tc = jni::CallStaticObjectMethod(env, ids->cls, ids->get);
   if (!tc || jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
-  jmethodID pid = jni::GetMethodID(env, cls, "partitionId", "()I");
-  if (!pid || jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
-  const jint id = jni::CallIntMethod(env, tc, pid);
+  const jint id = jni::CallIntMethod(env, tc, ids->pid);
+  jni::DeleteLocalRef(env, tc);
   if (jni::ExceptionCheck(env)) { clear_pending(env); return -1; }
   return (int)id;
 }
 
 bpsw_ctx_t* thread_context(JNIEnv* env) {
-  const int ndev = bpsw_device_count();
-  if (ndev <= 0) return nullptr;
-  int want = -1;
   const int part = spark_partition_id(env);
-  if (part >= 0) want = part % ndev;
+  const int want = bpsw_device_for_partition(part);  // entry (partition mod count) of BPSW_DEVICES; -1 without a TaskContext
+  t_ctx.partition = part;
+  t_ctx.slot = part >= 0 && bpsw_device_slots() > 0 ? part % bpsw_device_slots() : -1;
   if (t_ctx.ctx && (want < 0 || want == t_ctx.device)) return t_ctx.ctx;
   if (t_ctx.ctx) { bpsw_destroy(t_ctx.ctx); t_ctx.ctx = nullptr; }
   // want < 0: no TaskContext (harness) -> bpsw_create spreads threads round-robin over BPSW_DEVICES
@@ -103,6 +128,70 @@ bool load_reg_ids(JNIEnv* env, jclass c, RegIds* r) {  // MemAlnRegType.scala:26
          r->width && r->seedCov && r->secondary && r->hash && !jni::ExceptionCheck(env);
 }
 
+// Everything mateSWJNI looks up by name (native/jni_mate_sw.c:102-143 does the same ~55 GetFieldID + 6 FindClass on every
+// call): resolved on the first call, classes held as global references so that the field IDs stay valid.  FindClass from a
+// native method consults the class loader of the calling class (MateSWJNI's), the same on every call.
+struct MateIds {
+  jclass regCls, optCls, pesCls, mateCls, seqCls, refCls;
+  jfieldID opt_int[16], opt_mlr, opt_mat;
+  jfieldID pes_low, pes_high, pes_failed, pes_avg, pes_std;
+  jfieldID seq_rid, seq_pid, seq_len, seq_trans;
+  RegIds rf;
+  jfieldID mRid, mPid, mReg, mAln;
+  jfieldID rRid, rPid, rReg, rB, rE, rL, rRef[4];
+};
+std::atomic<const MateIds*> g_mate{nullptr};
+
+// nullptr: a class or field is missing; the JVM's NoClassDefFoundError / NoSuchFieldError is pending
+const MateIds* mate_ids(JNIEnv* env) {
+  const MateIds* ids = g_mate.load(std::memory_order_acquire);
+  if (ids) return ids;
+  std::lock_guard<std::mutex> lk(g_ids_mu);
+  ids = g_mate.load(std::memory_order_acquire);
+  if (ids) return ids;
+  MateIds m;
+  memset(&m, 0, sizeof m);
+  jclass regCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemAlnRegType");
+  jclass optCls = regCls ? jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemOptType") : nullptr;
+  jclass pesCls = optCls ? jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemPeStat") : nullptr;
+  jclass mateCls = pesCls ? jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/MateSWType") : nullptr;
+  jclass seqCls = mateCls ? jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/SeqSWType") : nullptr;
+  jclass refCls = seqCls ? jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/RefSWType") : nullptr;
+  if (!refCls) return nullptr;
+  static const char* opt_names[16] = {"a", "b", "oDel", "eDel", "oIns", "eIns", "penUnpaired", "penClip5", "penClip3", "w",
+                                      "zdrop", "T", "flag", "minSeedLen", "maxIns", "maxMatesw"};  // native/jni_mate_sw.c:102-128
+  for (int i = 0; i < 16; ++i)
+    if (!(m.opt_int[i] = jni::GetFieldID(env, optCls, opt_names[i], "I"))) return nullptr;
+  m.opt_mlr = jni::GetFieldID(env, optCls, "maskLevelRedun", "F");
+  m.opt_mat = jni::GetFieldID(env, optCls, "mat", "[B");
+  m.pes_low = jni::GetFieldID(env, pesCls, "low", "I"); m.pes_high = jni::GetFieldID(env, pesCls, "high", "I");
+  m.pes_failed = jni::GetFieldID(env, pesCls, "failed", "I");
+  m.pes_avg = jni::GetFieldID(env, pesCls, "avg", "D"); m.pes_std = jni::GetFieldID(env, pesCls, "std", "D");
+  m.seq_rid = jni::GetFieldID(env, seqCls, "readIdx", "I"); m.seq_pid = jni::GetFieldID(env, seqCls, "pairIdx", "I");
+  m.seq_len = jni::GetFieldID(env, seqCls, "seqLength", "I"); m.seq_trans = jni::GetFieldID(env, seqCls, "seqTrans", "[B");
+  if (!load_reg_ids(env, regCls, &m.rf)) return nullptr;
+  m.mRid = jni::GetFieldID(env, mateCls, "readIdx", "I"); m.mPid = jni::GetFieldID(env, mateCls, "pairIdx", "I");
+  m.mReg = jni::GetFieldID(env, mateCls, "regIdx", "I");
+  m.mAln = jni::GetFieldID(env, mateCls, "alnReg", "Lcs/ucla/edu/bwaspark/datatype/MemAlnRegType;");
+  m.rRid = jni::GetFieldID(env, refCls, "readIdx", "I"); m.rPid = jni::GetFieldID(env, refCls, "pairIdx", "I");
+  m.rReg = jni::GetFieldID(env, refCls, "regIdx", "I");
+  m.rB = jni::GetFieldID(env, refCls, "rBegArray", "[J"); m.rE = jni::GetFieldID(env, refCls, "rEndArray", "[J");
+  m.rL = jni::GetFieldID(env, refCls, "lenArray", "[J");
+  static const char* ref_names[4] = {"ref0", "ref1", "ref2", "ref3"};
+  for (int r = 0; r < 4; ++r) m.rRef[r] = jni::GetFieldID(env, refCls, ref_names[r], "[B");
+  if (!m.opt_mlr || !m.opt_mat || !m.pes_low || !m.pes_high || !m.pes_failed || !m.pes_avg || !m.pes_std || !m.seq_rid ||
+      !m.seq_pid || !m.seq_len || !m.seq_trans || !m.mRid || !m.mPid || !m.mReg || !m.mAln || !m.rRid || !m.rPid || !m.rReg ||
+      !m.rB || !m.rE || !m.rL || !m.rRef[0] || !m.rRef[1] || !m.rRef[2] || !m.rRef[3] || jni::ExceptionCheck(env))
+    return nullptr;
+  m.regCls = (jclass)jni::NewGlobalRef(env, regCls); m.optCls = (jclass)jni::NewGlobalRef(env, optCls);
+  m.pesCls = (jclass)jni::NewGlobalRef(env, pesCls); m.mateCls = (jclass)jni::NewGlobalRef(env, mateCls);
+  m.seqCls = (jclass)jni::NewGlobalRef(env, seqCls); m.refCls = (jclass)jni::NewGlobalRef(env, refCls);
+  if (!m.regCls || !m.optCls || !m.pesCls || !m.mateCls || !m.seqCls || !m.refCls) return nullptr;  // OutOfMemoryError pending
+  const MateIds* pub = new MateIds(m);
+  g_mate.store(pub, std::memory_order_release);
+  return pub;
+}
+
 void read_bytes(JNIEnv* env, jbyteArray arr, std::vector<uint8_t>& pool, int64_t* off, int32_t* len) {
   *off = (int64_t)pool.size();
   *len = 0;
@@ -117,6 +206,14 @@ void read_bytes(JNIEnv* env, jbyteArray arr, std::vector<uint8_t>& pool, int64_t
 }  // namespace
 
 extern "C" {
+
+// What the last JNI call on the calling thread resolved (for the tests; not a JNI symbol): out = {partition id seen (-1: no
+// TaskContext), entry of BPSW_DEVICES it maps to, HIP device of the thread's context}; returns the context as an integer
+// (two threads never share one) or 0 when the thread has none.
+JNIEXPORT uint64_t bpsw_jni_thread_info(int32_t out[3]) {
+  if (out) { out[0] = t_ctx.partition; out[1] = t_ctx.slot; out[2] = t_ctx.device; }
+  return (uint64_t)(uintptr_t)t_ctx.ctx;
+}
 
 JNIEXPORT void JNICALL Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld(JNIEnv*, jobject) {
   printf("Hello World from %s (%d HIP device(s))\n", bpsw_version(), bpsw_device_count());
@@ -149,32 +246,17 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
     throw_runtime(env, "bPSW: mateSWJNI: bad arguments");
     return nullptr;
   }
-  // classes are resolved inside the native call so that the executor's class loader is the one consulted
-  jclass regCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemAlnRegType");
-  jclass optCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemOptType");
-  jclass pesCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/datatype/MemPeStat");
-  jclass mateCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/MateSWType");
-  jclass seqCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/SeqSWType");
-  jclass refCls = jni::FindClass(env, "cs/ucla/edu/bwaspark/jni/RefSWType");
-  if (!regCls || !optCls || !pesCls || !mateCls || !seqCls || !refCls) return nullptr;  // NoClassDefFoundError pending
-
+  const MateIds* ids = mate_ids(env);
+  if (!ids) return nullptr;  // NoClassDefFoundError / NoSuchFieldError pending
+  jclass regCls = ids->regCls, mateCls = ids->mateCls;
   // ---- MemOptType (native/jni_mate_sw.c:102-128, 177-221) ----
   bpsw_opt_t opt;
   bpsw_opt_default(&opt);
   {
-    struct { const char* name; int32_t* dst; } ints[] = {
-        {"a", &opt.a}, {"b", &opt.b}, {"oDel", &opt.o_del}, {"eDel", &opt.e_del}, {"oIns", &opt.o_ins},
-        {"eIns", &opt.e_ins}, {"penUnpaired", &opt.pen_unpaired}, {"penClip5", &opt.pen_clip5},
-        {"penClip3", &opt.pen_clip3}, {"w", &opt.w}, {"zdrop", &opt.zdrop}, {"T", &opt.T}, {"flag", &opt.flag},
-        {"minSeedLen", &opt.min_seed_len}, {"maxIns", &opt.max_ins}, {"maxMatesw", &opt.max_matesw}};
-    for (auto& f : ints) {
-      jfieldID id = jni::GetFieldID(env, optCls, f.name, "I");
-      if (!id) return nullptr;
-      *f.dst = jni::GetIntField(env, optObj, id);
-    }
-    jfieldID mlr = jni::GetFieldID(env, optCls, "maskLevelRedun", "F");
-    jfieldID matId = jni::GetFieldID(env, optCls, "mat", "[B");
-    if (!mlr || !matId) return nullptr;
+    int32_t* dst[16] = {&opt.a, &opt.b, &opt.o_del, &opt.e_del, &opt.o_ins, &opt.e_ins, &opt.pen_unpaired, &opt.pen_clip5,
+                        &opt.pen_clip3, &opt.w, &opt.zdrop, &opt.T, &opt.flag, &opt.min_seed_len, &opt.max_ins, &opt.max_matesw};
+    for (int i = 0; i < 16; ++i) *dst[i] = jni::GetIntField(env, optObj, ids->opt_int[i]);
+    jfieldID mlr = ids->opt_mlr, matId = ids->opt_mat;
     opt.mask_level_redun = jni::GetFloatField(env, optObj, mlr);
     jbyteArray matArr = (jbyteArray)jni::GetObjectField(env, optObj, matId);
     if (!matArr || jni::GetArrayLength(env, matArr) < 25) { throw_runtime(env, "bPSW: mateSWJNI: opt.mat must hold 25 bytes"); return nullptr; }
@@ -187,10 +269,7 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
   g.group_size = groupSize;
   g.l_pac = pacLen;
   {  // ---- MemPeStat[4] (native/jni_mate_sw.c:225-236) ----
-    jfieldID low = jni::GetFieldID(env, pesCls, "low", "I"), high = jni::GetFieldID(env, pesCls, "high", "I");
-    jfieldID failed = jni::GetFieldID(env, pesCls, "failed", "I");
-    jfieldID avg = jni::GetFieldID(env, pesCls, "avg", "D"), sd = jni::GetFieldID(env, pesCls, "std", "D");
-    if (!low || !high || !failed || !avg || !sd) return nullptr;
+    jfieldID low = ids->pes_low, high = ids->pes_high, failed = ids->pes_failed, avg = ids->pes_avg, sd = ids->pes_std;
     for (int r = 0; r < 4; ++r) {
       jobject o = jni::GetObjectArrayElement(env, pesArr, r);
       if (!o) { throw_runtime(env, "bPSW: mateSWJNI: pes must hold 4 MemPeStat"); return nullptr; }
@@ -207,9 +286,7 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
   auto end_index = [&](jint k, jint i) -> long { return (k < 0 || k >= groupSize || i < 0 || i > 1) ? -1 : 2l * k + i; };
 
   {  // ---- SeqSWType[] (native/jni_mate_sw.c:258-278) ----
-    jfieldID rid = jni::GetFieldID(env, seqCls, "readIdx", "I"), pid = jni::GetFieldID(env, seqCls, "pairIdx", "I");
-    jfieldID slen = jni::GetFieldID(env, seqCls, "seqLength", "I"), strans = jni::GetFieldID(env, seqCls, "seqTrans", "[B");
-    if (!rid || !pid || !slen || !strans) return nullptr;
+    jfieldID rid = ids->seq_rid, pid = ids->seq_pid, slen = ids->seq_len, strans = ids->seq_trans;
     const jsize n = jni::GetArrayLength(env, seqArr);
     for (jsize s = 0; s < n; ++s) {
       jobject o = jni::GetObjectArrayElement(env, seqArr, s);
@@ -224,12 +301,8 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       jni::DeleteLocalRef(env, o);
     }
   }
-  RegIds rf;
-  if (!load_reg_ids(env, regCls, &rf)) return nullptr;
-  jfieldID mRid = jni::GetFieldID(env, mateCls, "readIdx", "I"), mPid = jni::GetFieldID(env, mateCls, "pairIdx", "I");
-  jfieldID mReg = jni::GetFieldID(env, mateCls, "regIdx", "I");
-  jfieldID mAln = jni::GetFieldID(env, mateCls, "alnReg", "Lcs/ucla/edu/bwaspark/datatype/MemAlnRegType;");
-  if (!mRid || !mPid || !mReg || !mAln) return nullptr;
+  const RegIds& rf = ids->rf;
+  jfieldID mRid = ids->mRid, mPid = ids->mPid, mReg = ids->mReg, mAln = ids->mAln;
 
   std::vector<bpsw_alnreg_t> regs;
   {  // ---- MateSWType[] -> regions grouped by (k,i) in arrival order (native/jni_mate_sw.c:300-345) ----
@@ -271,13 +344,8 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
     }
     const size_t rows = (size_t)base[ends];
     ref_rb.assign(4 * rows, -1); ref_re.assign(4 * rows, -1); ref_len.assign(4 * rows, 0); ref_off.assign(4 * rows, 0);
-    jfieldID rRid = jni::GetFieldID(env, refCls, "readIdx", "I"), rPid = jni::GetFieldID(env, refCls, "pairIdx", "I");
-    jfieldID rReg = jni::GetFieldID(env, refCls, "regIdx", "I");
-    jfieldID rB = jni::GetFieldID(env, refCls, "rBegArray", "[J"), rE = jni::GetFieldID(env, refCls, "rEndArray", "[J");
-    jfieldID rL = jni::GetFieldID(env, refCls, "lenArray", "[J");
-    jfieldID rRef[4] = {jni::GetFieldID(env, refCls, "ref0", "[B"), jni::GetFieldID(env, refCls, "ref1", "[B"),
-                        jni::GetFieldID(env, refCls, "ref2", "[B"), jni::GetFieldID(env, refCls, "ref3", "[B")};
-    if (!rRid || !rPid || !rReg || !rB || !rE || !rL || !rRef[0] || !rRef[1] || !rRef[2] || !rRef[3]) return nullptr;
+    jfieldID rRid = ids->rRid, rPid = ids->rPid, rReg = ids->rReg, rB = ids->rB, rE = ids->rE, rL = ids->rL;
+    const jfieldID* rRef = ids->rRef;
     const jsize n = jni::GetArrayLength(env, refArr);
     for (jsize s = 0; s < n; ++s) {
       if (jni::PushLocalFrame(env, 16) != JNI_OK) return nullptr;

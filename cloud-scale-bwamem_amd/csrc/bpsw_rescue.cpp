@@ -394,10 +394,11 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
     if (touched) S.touched.push_back(k);
   }
   S.reg_base[2 * (size_t)G_] = nreg; S.ref_base[2 * (size_t)G_] = nref;
+  RefHold ref_hold;  // coordinate mode: the reference stays put until the last round's kernel has been waited for
   if (GR.pac_mode && nref > 0) {
     const uint8_t* d_pac = nullptr;
     long long loaded = 0;
-    ref_snapshot(c, &d_pac, &loaded);
+    ref_hold = ref_snapshot(c, &d_pac, &loaded);
     if (loaded <= 0) return fail(BPSW_ERR_ARG, "matesw_group: ref_pool is null and no reference is loaded (bpsw_ref_load)");
     if (loaded != g->l_pac) return fail(BPSW_ERR_ARG, "matesw_group: l_pac differs from the loaded reference");
   }

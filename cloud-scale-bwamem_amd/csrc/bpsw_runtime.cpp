@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
 #include <time.h>
 
 #include <atomic>
@@ -74,11 +75,10 @@ MatRows pack_mat(const int8_t mat[25]) {
 }
 
 // The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), round robin, and streams that
-// share a queue are serialised.  Every context owns streams, and an executor drives several contexts at once, so ask for
-// more queues -- effective only when this library is loaded before the runtime initialises (the JVM case; a Python host
-// that imported torch first has to set the variable itself, bench.py does).  Measured on the bench step: 123 -> 132 M
-// reads/s; 24 or more queues oversubscribe the hardware and collapse (62 M and worse with ten streams busy).
-__attribute__((constructor)) static void bpsw_ask_for_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// share a queue are serialised.  The device phases of the blocking entry points run on a pool of 16 streams (StreamLease), so
+// the executor should be started with GPU_MAX_HW_QUEUES=16 in its environment (bench.py sets it before the
+// runtime initialises).  The library does not set it itself: setenv from a library constructor inside a multi-threaded JVM
+// races with every getenv of the process.  24 or more queues oversubscribe the hardware and throughput collapses.
 
 bool tail_bound_enabled() {
   static const bool off = getenv("BPSW_EXT_TAIL") && atoi(getenv("BPSW_EXT_TAIL")) == 0;
@@ -161,6 +161,38 @@ int zerocopy_mask() {
   return m;
 }
 
+// Waiting for the device phase of a blocking call.  The runtime's own waits (hipStreamSynchronize, hipEventSynchronize, even
+// with hipDeviceScheduleBlockingSync / hipEventBlockingSync) keep the calling thread on a CPU for most of a sub-millisecond
+// wait (measured: 16 threads that wait two thirds of their time keep 14 CPUs busy), and an executor's task threads share a
+// CPU quota.  So: sleep through most of the expected duration (a running average of this context's previous waits of the
+// same kind), then poll the event, first yielding and -- if the device is late -- with short sleeps.  BPSW_SPIN_WAIT=1
+// restores hipEventSynchronize.
+hipError_t wait_event(bpsw_ctx* c, hipEvent_t ev, int kind) {
+  if (spin_wait()) return hipEventSynchronize(ev);
+  double& est = c->wait_est_ms[kind & 1];
+  const double t0 = wall_ms();
+  if (est > 0.15) {
+    const double nap_us = est * 700.0 - 60.0;  // 70 % of the estimate, less the kernel's default timer slack
+    if (nap_us > 20.0) {
+      timespec ts = {0, (long)(nap_us * 1000.0)};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  hipError_t e;
+  int polls = 0;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) {
+    if (++polls < 64 && wall_ms() - t0 < est * 1.3 + 0.05) {
+      sched_yield();
+    } else {
+      timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  const double took = wall_ms() - t0;
+  est = est <= 0. ? took : 0.75 * est + 0.25 * took;
+  return e;
+}
+
 double wall_ms() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -232,12 +264,25 @@ using namespace bpsw;
 extern "C" {
 
 const char* bpsw_last_error(void) { return g_err.c_str(); }
-const char* bpsw_version(void) { return "bPSW-hip 0.1 (gfx950)"; }
+const char* bpsw_version(void) {
+#ifdef BPSW_EXPERIMENTAL_KERNELS
+  return "bPSW-hip 0.2 (gfx950) +experimental-kernels";
+#else
+  return "bPSW-hip 0.2 (gfx950)";
+#endif
+}
 
 int bpsw_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int bpsw_device_slots(void) { return (int)allowed_devices().size(); }
+int bpsw_device_for_partition(int partition) {
+  if (partition < 0) return -1;
+  const std::vector<int> devs = allowed_devices();
+  return devs.empty() ? -1 : devs[(size_t)partition % devs.size()];
 }
 
 void bpsw_opt_default(bpsw_opt_t* o) {  // datatype/MemOptType.scala:28-73
@@ -293,7 +338,11 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreateWithFlags(&c->ev[i], spin_wait() ? hipEventDefault : hipEventBlockingSync);
   // side streams of the opt-in quad-task experiment only: every stream takes a slot in the round robin over the HIP hardware
   // queues, and contexts that collide there serialise each other's launches
+#ifdef BPSW_EXPERIMENTAL_KERNELS
   const bool want_side_streams = getenv("BPSW_EXT_QT") && atoi(getenv("BPSW_EXT_QT")) != 0;  // == ext_qt_enabled()
+#else
+  const bool want_side_streams = false;
+#endif
   for (int k = 0; e == hipSuccess && k < 2 && want_side_streams; ++k) {
     e = hipStreamCreateWithFlags(&c->aux.stream[k], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux.join[k], hipEventDisableTiming);
@@ -349,6 +398,9 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
 }
 
 
+#ifdef BPSW_EXPERIMENTAL_KERNELS
+// Built only with `make EXPERIMENTAL=1`: the two alternative formulations of the extension kernel that DESIGN.md 4.1 measures
+// against ext_kernel and keeps as experiments.  The default library carries one extension kernel and none of this.
 // The quad-task kernels (bpsw_extend_qt.hip) execute 1.8x fewer instructions than ext_kernel but are not faster at
 // 32 k-read batches on MI355X, so they are opt-in: BPSW_EXT_QT=1.
 static bool ext_qt_enabled() {
@@ -377,6 +429,36 @@ static int lane_launch(bpsw_ctx_t* c, const uint32_t* d_wire, int n, int16_t* d_
                               lane_list + n, s));
   return BPSW_OK;
 }
+
+// The launches of one host-buffer batch with the experimental kernels: bin / sort on the device, read the counts back, launch.
+static int ext_experimental_launch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int n, int mq, int mr, int16_t* k_out,
+                                   hipStream_t s) {
+  int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
+  int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
+  const bool use_lane = ext_lane_enabled();
+  const bool use_qt = !use_lane && (int8_t)wire[2] + (int8_t)wire[3] > 0 && ext_qt_enabled();
+  h_counts[0] = h_counts[1] = 0; h_counts[2] = n;
+  if (use_lane) {
+    lane_sort_enqueue(c, (const uint32_t*)c->d_wire.ptr, n, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventRecord(c->ev[1], s));
+    return lane_launch(c, (const uint32_t*)c->d_wire.ptr, n, k_out, mq, mr, h_counts, s);
+  }
+  if (use_qt) {
+    HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
+    launch_ext_bin((const uint32_t*)c->d_wire.ptr, n, (int*)c->d_ext_lists.ptr, d_counts, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventRecord(c->ev[1], s));
+  }
+  HIP_TRY(launch_ext_all((const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, n, k_out, c->ext_sc, mq, mr, c->num_cu,
+                         (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts, use_qt, c->aux, s));
+  return BPSW_OK;
+}
+#endif  // BPSW_EXPERIMENTAL_KERNELS
 
 // ------------------------------------------------------------------------------------- boundary 2
 static inline int rd16(const uint8_t* b, size_t at) { return (int16_t)(b[at] | (b[at + 1] << 8)); }
@@ -424,7 +506,9 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
   const size_t out_bytes = 20 * (size_t)n;
   HIP_TRY(c->d_wire.reserve(wire_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
+#ifdef BPSW_EXPERIMENTAL_KERNELS
   HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n + 16));
+#endif
   HIP_TRY(c->h_stage_in.reserve(wire_bytes));
   HIP_TRY(c->h_stage_out.reserve(out_bytes));
   const double t_in = wall_ms();
@@ -438,40 +522,22 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
     HIP_TRY(hipEventRecord(c->ev[0], s));
     HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(c->ev[1], s));
-    // bin the tasks on the device (which kernel handles which), read the three counts back, launch
-    int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
-    int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
-    const bool use_lane = ext_lane_enabled();
-    const bool use_qt = !use_lane && (int8_t)wire[2] + (int8_t)wire[3] > 0 && ext_qt_enabled();
-    h_counts[0] = h_counts[1] = 0; h_counts[2] = n;
-    if (use_lane) {
-      lane_sort_enqueue(c, (const uint32_t*)c->d_wire.ptr, n, s);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      HIP_TRY(hipEventRecord(c->ev[1], s));
-      rc = lane_launch(c, (const uint32_t*)c->d_wire.ptr, n, (int16_t*)c->d_out.ptr, mq, mr, h_counts, s);
-      if (rc != BPSW_OK) return rc;
-    }
-    if (use_qt) {
-      HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
-      launch_ext_bin((const uint32_t*)c->d_wire.ptr, n, (int*)c->d_ext_lists.ptr, d_counts, s);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      HIP_TRY(hipEventRecord(c->ev[1], s));
-    }
     // results: written by the kernel straight into the pinned staging buffer (20 B per task, posted PCIe writes), or into
     // device memory and copied back
-    const bool zc_out = (zerocopy_mask() & 1) && !use_lane;
+    const bool zc_out = (zerocopy_mask() & 1) != 0;
     int16_t* k_out = zc_out ? (int16_t*)c->h_stage_out.ptr : (int16_t*)c->d_out.ptr;
-    if (!use_lane)
-      HIP_TRY(launch_ext_all((const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, n, k_out, c->ext_sc, mq, mr, c->num_cu,
-                             (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts, use_qt, c->aux, s));
+#ifdef BPSW_EXPERIMENTAL_KERNELS
+    if (ext_lane_enabled() || ext_qt_enabled()) {
+      rc = ext_experimental_launch(c, wire, wire_bytes, n, mq, mr, k_out, s);
+      if (rc != BPSW_OK) return rc;
+    } else
+#endif
+      HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, c->ext_sc, mq, mr, c->num_cu,
+                                (int*)((char*)c->d_pre.ptr + 128), nullptr, s));
     HIP_TRY(hipEventRecord(c->ev[2], s));
     if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(c->ev[3], s));
-    HIP_TRY(hipEventSynchronize(c->ev[3]));  // the last operation of the call on this stream
+    HIP_TRY(wait_event(c, c->ev[3], 0));  // the last operation of the call on this stream
     t_dev1 = wall_ms();
     c->stats.ext_wait_ms += lease.wait_ms;
   }
@@ -493,23 +559,34 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
 // reference flank the kernels accept; 29.8 KB per workgroup, i.e. 5 workgroups per CU -- what the VGPR budget allows anyway.
 static const int ASYNC_QCAP = 256, ASYNC_RCAP = 4096;
 
-// the synchronous geometry-dependent launch (quad-task / lane experiments, and batches that outgrow the async geometry)
+// the synchronous geometry-dependent launch (batches that outgrow the async geometry; the experimental kernels)
 static int ext_device_sync_launch(bpsw_ctx_t* c, const void* d_wire, size_t wire_bytes, int n_tasks, void* d_out, hipStream_t s,
                                   const ExtPrepass* h_pre, const int* h_counts) {
   HIP_TRY(hipEventRecord(c->ev[4], s));
+#ifdef BPSW_EXPERIMENTAL_KERNELS
   if (ext_lane_enabled()) {
     int rc = lane_launch(c, (const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, h_pre->max_qlen, h_pre->max_rlen, h_counts, s);
     if (rc != BPSW_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[5], s));
+    HIP_TRY(hipStreamSynchronize(s));  // the experiments are synchronous: nothing of theirs is left in flight on `s`
     c->have_ext_ev = true;
     return BPSW_OK;
   }
-  const bool use_qt = h_pre->reserved != 0 && ext_qt_enabled();  // reserved: set by the scan when oIns + eIns > 0
-  int counts[3] = {h_counts[0], h_counts[1], h_counts[2]};
-  if (!use_qt) { counts[0] = counts[1] = 0; counts[2] = n_tasks; }
-  HIP_TRY(launch_ext_all((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen,
-                         h_pre->max_rlen, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, counts,
-                         use_qt, c->aux, s));
+  if (h_pre->reserved != 0 && ext_qt_enabled()) {  // reserved: set by the scan when oIns + eIns > 0
+    const int counts[3] = {h_counts[0], h_counts[1], h_counts[2]};
+    HIP_TRY(launch_ext_all((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen,
+                           h_pre->max_rlen, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, counts,
+                           true, c->aux, s));
+    HIP_TRY(hipEventRecord(c->ev[5], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->have_ext_ev = true;
+    return BPSW_OK;
+  }
+#else
+  (void)wire_bytes; (void)h_counts;
+#endif
+  HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen, h_pre->max_rlen, c->num_cu,
+                            (int*)((char*)c->d_pre.ptr + 128), nullptr, s));
   HIP_TRY(hipEventRecord(c->ev[5], s));
   c->have_ext_ev = true;
   return BPSW_OK;
@@ -563,7 +640,12 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   launch_ext_prepass((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, d_pre, s);
   HIP_TRY(hipGetLastError());
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
-  if (!ext_lane_enabled() && !ext_qt_enabled()) {
+#ifdef BPSW_EXPERIMENTAL_KERNELS
+  const bool experiments = ext_lane_enabled() || ext_qt_enabled();
+#else
+  const bool experiments = false;
+#endif
+  if (!experiments) {
     // Asynchronous: scan, main launch (sized for ASYNC_QCAP / ASYNC_RCAP, checking the scan on the device) and the scan's
     // read-back are enqueued back to back; nothing waits.  Errors surface at the next call on this context or at
     // bpsw_last_kernel_ms, which is also where a batch that outgrew the geometry is re-launched.
@@ -586,6 +668,7 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
     c->pend_ext.d_out = d_out; c->pend_ext.s = s;
     return BPSW_OK;
   }
+#ifdef BPSW_EXPERIMENTAL_KERNELS
   // experiments (quad-task / lane kernels): bin the tasks in the same pass, read the scan back, then launch
   int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
   int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
@@ -602,6 +685,9 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   if (h_pre->max_qlen > BPSW_EXT_MAX_QLEN || h_pre->max_rlen > BPSW_EXT_MAX_RLEN)
     return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
   return ext_device_sync_launch(c, d_wire, wire_bytes, n_tasks, d_out, s, h_pre, h_counts);
+#else
+  return fail(BPSW_ERR_DEVICE, "extend_device: unreachable");
+#endif
 }
 
 int bpsw_get_stats(bpsw_ctx_t* c, bpsw_stats_t* out) {

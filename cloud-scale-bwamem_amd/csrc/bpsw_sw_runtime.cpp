@@ -37,11 +37,13 @@ DeviceRef& device_ref(int device) {
   static DeviceRef table[64];
   return table[device >= 0 && device < 64 ? device : 0];
 }
-void ref_snapshot(const bpsw_ctx* c, const uint8_t** pac, long long* l_pac) {
+RefHold ref_snapshot(const bpsw_ctx* c, const uint8_t** pac, long long* l_pac) {
   DeviceRef& r = device_ref(c->device);
+  RefHold hold(&r.gate);
   std::lock_guard<std::mutex> g(r.mu);
   *pac = (const uint8_t*)r.buf.ptr;
   *l_pac = r.l_pac;
+  return hold;
 }
 
 // Layout of a staged SW batch in c->h_stage_in (job table SoA + the two byte pools, every part 16-byte aligned).
@@ -67,7 +69,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
   const int n = st.n;
   const uint8_t* d_pac = nullptr;
   long long l_pac = 0;
-  ref_snapshot(c, &d_pac, &l_pac);
+  const RefHold ref_hold = ref_snapshot(c, &d_pac, &l_pac);
   if (pac_mode && l_pac <= 0) return fail(BPSW_ERR_ARG, "swalign: t_pool is null and no reference is loaded (bpsw_ref_load)");
   if (mq > BPSW_SW_MAX_QLEN || mt > BPSW_SW_MAX_TLEN) return fail(BPSW_ERR_LIMIT, "swalign: sequence longer than the kernel limit");
   const size_t out_bytes = 28 * (size_t)n;
@@ -97,7 +99,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     HIP_TRY(hipEventRecord(c->ev[2], s));
     if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_sw_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(c->ev[3], s));
-    HIP_TRY(hipEventSynchronize(c->ev[3]));  // the last operation of the call on this stream
+    HIP_TRY(wait_event(c, c->ev[3], 1));  // the last operation of the call on this stream
     c->stats.grp_wait_ms += lease.wait_ms;
     c->stats.grp_dev_ms += wall_ms() - t_dev0;
   }
@@ -125,7 +127,7 @@ int run_sw_jobs_host(bpsw_ctx* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* j
   const bool pac_mode = j->t_pool == nullptr;  // windows named by coordinates
   const uint8_t* d_pac = nullptr;
   long long l_pac = 0;
-  ref_snapshot(c, &d_pac, &l_pac);
+  const RefHold ref_hold = ref_snapshot(c, &d_pac, &l_pac);
   if (pac_mode && l_pac <= 0) return fail(BPSW_ERR_ARG, "swalign: t_pool is null and no reference is loaded (bpsw_ref_load)");
   const size_t t_pool_bytes = pac_mode ? 0 : j->t_pool_bytes;
   int mq = 0, mt = 0;
@@ -177,6 +179,7 @@ int finish_pending_sw(bpsw_ctx* c) {
   bpsw_ctx::PendingSw p = c->pend_sw;
   c->pend_sw.active = false;
   HIP_TRY(hipStreamSynchronize(p.s));
+  if (p.verified) return BPSW_OK;
   const SwPrepass* h_pre = (const SwPrepass*)((const char*)c->h_pre.ptr + 256);
   if (h_pre->error) { c->have_sw_ev = false; return fail(BPSW_ERR_ARG, "swalign_device: job sequence outside its pool (or window outside / bridging the reference)"); }
   if (h_pre->max_qlen > BPSW_SW_MAX_QLEN || h_pre->max_tlen > BPSW_SW_MAX_TLEN) {
@@ -190,7 +193,7 @@ int finish_pending_sw(bpsw_ctx* c) {
     if (rc != BPSW_OK) return rc;
     const uint8_t* d_pac = nullptr;
     long long l_pac = 0;
-    ref_snapshot(c, &d_pac, &l_pac);
+    const RefHold ref_hold = ref_snapshot(c, &d_pac, &l_pac);
     SwJobsDev dev;
     dev.n = p.jobs.n; dev.q_len = p.jobs.q_len; dev.t_len = p.jobs.t_len; dev.q_off = p.jobs.q_off; dev.t_off = p.jobs.t_off;
     dev.q_rev = p.jobs.q_rev; dev.q_pool = p.jobs.q_pool; dev.t_pool = p.jobs.t_pool; dev.pac = d_pac; dev.l_pac = l_pac;
@@ -218,7 +221,7 @@ int bpsw_swalign2_batch_device(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_
   std::lock_guard<std::mutex> g(c->mu);
   const uint8_t* d_pac = nullptr;
   long long l_pac = 0;
-  ref_snapshot(c, &d_pac, &l_pac);
+  const RefHold ref_hold = ref_snapshot(c, &d_pac, &l_pac);
   if (!j->t_pool && l_pac <= 0) return fail(BPSW_ERR_ARG, "swalign_device: t_pool is null and no reference is loaded (bpsw_ref_load)");
   HIP_TRY(hipSetDevice(c->device));
   rc = finish_pending(c);
@@ -247,7 +250,7 @@ int bpsw_swalign2_batch_device(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_
       HIP_TRY(hipMemcpyAsync(h_pre, d_pre, sizeof(SwPrepass), hipMemcpyDeviceToHost, s));
       c->have_sw_ev = true;
       c->pend_sw.active = true; c->pend_sw.jobs = *j; c->pend_sw.opt = *opt; c->pend_sw.d_out = d_out; c->pend_sw.s = s;
-      c->pend_sw.cap_qlen = cap_q; c->pend_sw.cap_tlen = cap_t;
+      c->pend_sw.cap_qlen = cap_q; c->pend_sw.cap_tlen = cap_t; c->pend_sw.verified = false;
       return BPSW_OK;
     }
   }
@@ -267,6 +270,10 @@ int bpsw_swalign2_batch_device(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_
   HIP_TRY(hipEventRecord(c->ev[7], s));
   c->have_sw_ev = true;
   c->sw_geom_qlen = h_pre->max_qlen; c->sw_geom_tlen = h_pre->max_tlen;
+  // the launch uses the context's scratch rows and may sit on a caller's stream: the next call on the context (which may use
+  // another stream) and bpsw_destroy wait for it through the same record the speculative path leaves
+  c->pend_sw.active = true; c->pend_sw.jobs = *j; c->pend_sw.opt = *opt; c->pend_sw.d_out = d_out; c->pend_sw.s = s;
+  c->pend_sw.verified = true;
   return BPSW_OK;
 }
 
@@ -278,6 +285,7 @@ int bpsw_ref_load(bpsw_ctx_t* c, const uint8_t* pac, int64_t l_pac) {
   HIP_TRY(hipSetDevice(c->device));
   { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   DeviceRef& r = device_ref(c->device);
+  RefWriteHold wr(&r.gate);  // no call may be between its snapshot and its last wait
   std::lock_guard<std::mutex> gr(r.mu);
   const size_t bytes = (size_t)((l_pac + 3) >> 2);
   HIP_TRY(hipDeviceSynchronize());  // nothing in flight may still read the previous reference
@@ -293,6 +301,7 @@ int bpsw_ref_unload(bpsw_ctx_t* c) {
   HIP_TRY(hipSetDevice(c->device));
   { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   DeviceRef& r = device_ref(c->device);
+  RefWriteHold wr(&r.gate);
   std::lock_guard<std::mutex> gr(r.mu);
   HIP_TRY(hipDeviceSynchronize());
   r.buf.release();
@@ -304,7 +313,7 @@ int64_t bpsw_ref_length(const bpsw_ctx_t* c) {
   if (!c) return 0;
   const uint8_t* p = nullptr;
   long long l = 0;
-  ref_snapshot(c, &p, &l);
+  const RefHold ref_hold = ref_snapshot(c, &p, &l);
   return (int64_t)l;
 }
 
@@ -316,7 +325,7 @@ int bpsw_ref_fetch(bpsw_ctx_t* c, int32_t n, const int64_t* beg, const int64_t* 
   std::lock_guard<std::mutex> g(c->mu);
   const uint8_t* d_pac = nullptr;
   long long l_pac = 0;
-  ref_snapshot(c, &d_pac, &l_pac);
+  const RefHold ref_hold = ref_snapshot(c, &d_pac, &l_pac);
   if (l_pac <= 0) return fail(BPSW_ERR_ARG, "ref_fetch: no reference is loaded (bpsw_ref_load)");
   HIP_TRY(hipSetDevice(c->device));
   { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
@@ -362,7 +371,7 @@ int bpsw_chain2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_chains
   std::lock_guard<std::mutex> g(c->mu);
   const uint8_t* d_pac = nullptr;
   long long l_pac = 0;
-  ref_snapshot(c, &d_pac, &l_pac);
+  const RefHold ref_hold = ref_snapshot(c, &d_pac, &l_pac);
   if (l_pac <= 0) return fail(BPSW_ERR_ARG, "chain2aln: no reference is loaded (bpsw_ref_load)");
   HIP_TRY(hipSetDevice(c->device));
   { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }

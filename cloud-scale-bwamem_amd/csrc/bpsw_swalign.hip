@@ -960,7 +960,11 @@ hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_
                             uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check) {
   if (jobs.n <= 0) return hipSuccess;
   int blocks = (jobs.n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  static const double sw_cap = getenv("BPSW_SW_BLOCKS_PER_CU") ? atof(getenv("BPSW_SW_BLOCKS_PER_CU")) : 8.0;
+  // at most 8: the row scratch is sized for sw_resident_waves() = 8 workgroups per CU (a larger grid would index past it)
+  static const double sw_cap = [] {
+    const double v = getenv("BPSW_SW_BLOCKS_PER_CU") ? atof(getenv("BPSW_SW_BLOCKS_PER_CU")) : 8.0;
+    return v > 8.0 ? 8.0 : (v > 0.0 ? v : 8.0);
+  }();
   const int max_blocks = (int)(num_cu * sw_cap) > 0 ? (int)(num_cu * sw_cap) : 1;
   if (blocks > max_blocks) blocks = max_blocks;
   const int per_job = (int)(sw_scratch_bytes_per_wave(max_tlen) / 16);

@@ -47,10 +47,12 @@ struct BnsView {
   std::vector<long long> off;
   std::vector<int32_t> len;
   std::vector<std::string> name;
+  RefHold hold;  // the reference and the contig table stay put while this view lives
 };
 
 int snapshot_bns(const bpsw_ctx* c, BnsView* v) {
   DeviceRef& r = device_ref(c->device);
+  v->hold = RefHold(&r.gate);
   std::lock_guard<std::mutex> g(r.mu);
   if (r.l_pac <= 0 || !r.buf.ptr) return fail(BPSW_ERR_ARG, "tail: no reference loaded on this device (bpsw_ref_load)");
   if (r.ann_off.empty() || !r.ann.ptr) return fail(BPSW_ERR_ARG, "tail: no contig table loaded on this device (bpsw_bns_load)");
@@ -492,6 +494,7 @@ int bpsw_bns_load(bpsw_ctx_t* c, int32_t n_seqs, const int64_t* offset, const in
   HIP_TRY(hipSetDevice(c->device));
   { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
   DeviceRef& r = device_ref(c->device);
+  RefWriteHold wr(&r.gate);
   std::lock_guard<std::mutex> gr(r.mu);
   if (r.l_pac <= 0) return fail(BPSW_ERR_ARG, "bns_load: load the reference first (bpsw_ref_load)");
   long long at = 0;

@@ -51,6 +51,8 @@ enum {
   JNI_SLOT_ExceptionClear = 17,
   JNI_SLOT_PushLocalFrame = 19,
   JNI_SLOT_PopLocalFrame = 20,
+  JNI_SLOT_NewGlobalRef = 21,
+  JNI_SLOT_DeleteGlobalRef = 22,
   JNI_SLOT_DeleteLocalRef = 23,
   JNI_SLOT_AllocObject = 27,
   JNI_SLOT_GetMethodID = 33,
@@ -101,6 +103,8 @@ inline void ExceptionClear(JNIEnv* e) { fn<void (*)(JNIEnv*)>(e, JNI_SLOT_Except
 inline jboolean ExceptionCheck(JNIEnv* e) { return fn<jboolean (*)(JNIEnv*)>(e, JNI_SLOT_ExceptionCheck)(e); }
 inline jint PushLocalFrame(JNIEnv* e, jint cap) { return fn<jint (*)(JNIEnv*, jint)>(e, JNI_SLOT_PushLocalFrame)(e, cap); }
 inline jobject PopLocalFrame(JNIEnv* e, jobject r) { return fn<jobject (*)(JNIEnv*, jobject)>(e, JNI_SLOT_PopLocalFrame)(e, r); }
+inline jobject NewGlobalRef(JNIEnv* e, jobject o) { return fn<jobject (*)(JNIEnv*, jobject)>(e, JNI_SLOT_NewGlobalRef)(e, o); }
+inline void DeleteGlobalRef(JNIEnv* e, jobject o) { fn<void (*)(JNIEnv*, jobject)>(e, JNI_SLOT_DeleteGlobalRef)(e, o); }
 inline void DeleteLocalRef(JNIEnv* e, jobject o) { fn<void (*)(JNIEnv*, jobject)>(e, JNI_SLOT_DeleteLocalRef)(e, o); }
 inline jobject AllocObject(JNIEnv* e, jclass c) { return fn<jobject (*)(JNIEnv*, jclass)>(e, JNI_SLOT_AllocObject)(e, c); }
 inline jmethodID GetMethodID(JNIEnv* e, jclass c, const char* n, const char* s) { return fn<jmethodID (*)(JNIEnv*, jclass, const char*, const char*)>(e, JNI_SLOT_GetMethodID)(e, c, n, s); }

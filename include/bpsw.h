@@ -63,6 +63,11 @@ int bpsw_device_count(void);
 int bpsw_create(int device, bpsw_ctx_t **out);
 void bpsw_destroy(bpsw_ctx_t *ctx);
 int bpsw_device_of(const bpsw_ctx_t *ctx);
+/* Spark partition -> device (the north_star's "Spark-partition -> device index"; reference: one accelerator per executor,
+ * src/main/jni_fpga/sw_extend_fpga.c:116-193).  The devices contexts are spread over are the entries of BPSW_DEVICES
+ * ("0,2,3"; an index may repeat; default: every visible device in order); partition p runs on entry p mod count. */
+int bpsw_device_slots(void);                  /* number of entries; 0 = no usable device */
+int bpsw_device_for_partition(int partition); /* HIP device index of that entry, -1 = no usable device / negative partition */
 const char *bpsw_last_error(void); /* thread-local text of the last failing call */
 const char *bpsw_version(void);
 

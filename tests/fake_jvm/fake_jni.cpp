@@ -9,9 +9,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "jni_min.h"
@@ -32,17 +35,28 @@ struct FObj {
 };
 struct FField { std::string name, sig; };
 
-struct Jvm {
-  std::vector<std::unique_ptr<FObj>> heap;
+// What a real JVM keeps for the life of the process: loaded classes and their field / method IDs.  The shim caches both
+// (global references + IDs) across calls, so they must outlive the per-call object heap below.  `lookups` counts FindClass /
+// GetFieldID / GetMethodID calls, so a test can see that a second call resolves nothing by name.
+struct ClassWorld {
+  std::mutex mu;
+  std::vector<std::unique_ptr<FObj>> classes_heap;
   std::vector<std::unique_ptr<FField>> fields;
   std::map<std::string, FObj*> classes;
+  std::atomic<long> lookups{0};
+  std::atomic<long> global_refs{0};
+};
+ClassWorld g_world;
+
+struct Jvm {
+  std::vector<std::unique_ptr<FObj>> heap;
   bool pending = false;
   std::string pending_msg;
   int partition = -1;  // >= 0: org.apache.spark.TaskContext.get().partitionId() answers this
   long calls[JNI_SLOT_COUNT] = {0};
   FObj* alloc(const std::string& cls) { heap.emplace_back(new FObj()); heap.back()->cls = cls; return heap.back().get(); }
 };
-Jvm* g_vm = nullptr;
+thread_local Jvm* g_vm = nullptr;  // one fake JVM per driver call, one driver call per thread
 
 const char* kKnown[] = {"cs/ucla/edu/bwaspark/datatype/MemAlnRegType", "cs/ucla/edu/bwaspark/datatype/MemOptType",
                         "cs/ucla/edu/bwaspark/datatype/MemPeStat", "cs/ucla/edu/bwaspark/jni/MateSWType",
@@ -58,14 +72,22 @@ jclass f_FindClass(JNIEnv*, const char* name) {
   for (const char* k : kKnown) ok |= strcmp(k, name) == 0;
   if (strcmp(name, "org/apache/spark/TaskContext") == 0) ok = g_vm->partition >= 0;
   if (!ok) { g_vm->pending = true; g_vm->pending_msg = std::string("NoClassDefFoundError: ") + name; return nullptr; }
-  auto it = g_vm->classes.find(name);
-  if (it != g_vm->classes.end()) return J(it->second);
-  FObj* c = g_vm->alloc("class");
-  c->objs["name"] = nullptr;
+  g_world.lookups++;
+  std::lock_guard<std::mutex> lk(g_world.mu);
+  auto it = g_world.classes.find(name);
+  if (it != g_world.classes.end()) return J(it->second);
+  g_world.classes_heap.emplace_back(new FObj());
+  FObj* c = g_world.classes_heap.back().get();
   c->cls = std::string("class:") + name;
-  g_vm->classes[name] = c;
+  g_world.classes[name] = c;
   return J(c);
 }
+jobject f_NewGlobalRef(JNIEnv*, jobject o) {  // only classes are ever made global by the shim; they live in g_world already
+  if (o && O(o)->cls.rfind("class:", 0) != 0) { fprintf(stderr, "fake_jni: NewGlobalRef of a non-class object\n"); abort(); }
+  g_world.global_refs++;
+  return o;
+}
+void f_DeleteGlobalRef(JNIEnv*, jobject) { g_world.global_refs--; }
 jint f_ThrowNew(JNIEnv*, jclass c, const char* msg) {
   g_vm->pending = true;
   g_vm->pending_msg = O(c)->cls.substr(6) + ": " + msg;
@@ -79,8 +101,10 @@ void f_DeleteLocalRef(JNIEnv*, jobject) {}
 jobject f_AllocObject(JNIEnv*, jclass c) { return J(g_vm->alloc(O(c)->cls.substr(6))); }
 jfieldID f_GetFieldID(JNIEnv*, jclass, const char* name, const char* sig) {
   g_vm->calls[JNI_SLOT_GetFieldID]++;
-  g_vm->fields.emplace_back(new FField{name, sig});
-  return reinterpret_cast<jfieldID>(g_vm->fields.back().get());
+  g_world.lookups++;
+  std::lock_guard<std::mutex> lk(g_world.mu);
+  g_world.fields.emplace_back(new FField{name, sig});
+  return reinterpret_cast<jfieldID>(g_world.fields.back().get());
 }
 const FField* F(jfieldID f) { return reinterpret_cast<const FField*>(f); }
 jobject f_GetObjectField(JNIEnv*, jobject o, jfieldID f) {
@@ -95,8 +119,10 @@ void f_SetObjectField(JNIEnv*, jobject o, jfieldID f, jobject v) { O(o)->objs[F(
 void f_SetIntField(JNIEnv*, jobject o, jfieldID f, jint v) { O(o)->ints[F(f)->name] = v; }
 void f_SetLongField(JNIEnv*, jobject o, jfieldID f, jlong v) { O(o)->ints[F(f)->name] = v; }
 jmethodID f_GetMethodID(JNIEnv*, jclass, const char* name, const char*) {
-  g_vm->fields.emplace_back(new FField{name, "()"});
-  return reinterpret_cast<jmethodID>(g_vm->fields.back().get());
+  g_world.lookups++;
+  std::lock_guard<std::mutex> lk(g_world.mu);
+  g_world.fields.emplace_back(new FField{name, "()"});
+  return reinterpret_cast<jmethodID>(g_world.fields.back().get());
 }
 jmethodID f_GetStaticMethodID(JNIEnv* e, jclass c, const char* name, const char* sig) { return f_GetMethodID(e, c, name, sig); }
 jobject f_CallStaticObjectMethod(JNIEnv*, jclass, jmethodID, ...) { return J(g_vm->alloc("org/apache/spark/TaskContext")); }
@@ -159,7 +185,7 @@ struct Env {
     SET(GetStaticMethodID); SET(CallStaticObjectMethod); SET(CallIntMethod); SET(GetArrayLength); SET(NewObjectArray);
     SET(GetObjectArrayElement); SET(SetObjectArrayElement); SET(NewShortArray); SET(GetByteArrayRegion);
     SET(GetIntArrayRegion); SET(GetLongArrayRegion); SET(SetShortArrayRegion); SET(NewLongArray); SET(SetLongArrayRegion);
-    SET(NewByteArray); SET(SetByteArrayRegion); SET(GetDoubleArrayRegion);
+    SET(NewByteArray); SET(SetByteArrayRegion); SET(GetDoubleArrayRegion); SET(NewGlobalRef); SET(DeleteGlobalRef);
 #undef SET
     env = &table;
   }
@@ -411,6 +437,38 @@ int fake_jvm_sam_pe_tail(const char* lib, int partition, const uint8_t* pac, int
   if (*out_bytes > out_cap) { snprintf(err, (size_t)errcap, "out_cap too small"); return -1; }
   memcpy(out_text, O(r)->bytes.data(), (size_t)*out_bytes);
   memcpy(out_off, off->la.data(), 8 * ((size_t)n2 + 1));
+  return 0;
+}
+
+// name lookups (FindClass / GetFieldID / GetMethodID) the shim has made in this process so far, and live global references
+long fake_jvm_lookups(void) { return g_world.lookups.load(); }
+long fake_jvm_global_refs(void) { return g_world.global_refs.load(); }
+
+// n task threads of one executor, thread t reporting Spark partition partitions[t], each pushing the same wire batch through
+// swExtendFPGAJNI `calls` times.  outs: n x ret_task_num int16; info: n x 4 int64 = {partition seen, BPSW_DEVICES entry,
+// HIP device, context handle} from bpsw_jni_thread_info on that thread.  Returns 0, or the first non-zero code of a thread.
+int fake_jvm_extend_threads(const char* lib, int n, const int* partitions, const uint8_t* wire, int wire_bytes, int ret_task_num,
+                            int calls, int16_t* outs, int64_t* info, char* err, int errcap) {
+  std::vector<std::thread> th;
+  std::vector<int> rc((size_t)n, 0);
+  std::vector<std::string> errs((size_t)n);
+  typedef uint64_t (*InfoFn)(int32_t*);
+  char e0[256] = {0};
+  InfoFn info_fn = (InfoFn)load_symbol(lib, "bpsw_jni_thread_info", e0, sizeof e0);
+  if (!info_fn) { snprintf(err, (size_t)errcap, "%s", e0); return -1; }
+  for (int t = 0; t < n; ++t)
+    th.emplace_back([&, t] {
+      char e[512] = {0};
+      for (int c = 0; c < calls && rc[(size_t)t] == 0; ++c)
+        rc[(size_t)t] = fake_jvm_extend(lib, partitions[t], wire, wire_bytes, ret_task_num, outs + (size_t)t * (size_t)ret_task_num, e, sizeof e);
+      int32_t three[3] = {-2, -2, -2};
+      const uint64_t ctx = info_fn(three);
+      info[4 * t] = three[0]; info[4 * t + 1] = three[1]; info[4 * t + 2] = three[2]; info[4 * t + 3] = (int64_t)ctx;
+      errs[(size_t)t] = e;
+    });
+  for (auto& x : th) x.join();
+  for (int t = 0; t < n; ++t)
+    if (rc[(size_t)t] != 0) { snprintf(err, (size_t)errcap, "thread %d: %s", t, errs[(size_t)t].c_str()); return rc[(size_t)t]; }
   return 0;
 }
 

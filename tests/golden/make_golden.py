@@ -23,13 +23,33 @@ from bpsw_hip import synth  # noqa: E402
 ref = po.Ref()
 mat = po.default_mat()
 rng = np.random.default_rng(20261003)
-ONLY = set(sys.argv[1:])  # optional: file stems to (re)write, e.g. `make_golden.py bns_get_seq`; default all
+# usage: make_golden.py [--check] [stem ...]
+#   stems: the files to (re)write, e.g. `make_golden.py bns_get_seq`; default all
+#   --check: write nothing; regenerate every file in memory and fail (exit 1) when an array differs from the committed one --
+#            "a committed script generated them" stays true only as long as this passes (tests/test_golden.py runs it)
+CHECK = "--check" in sys.argv[1:]
+ONLY = set(a for a in sys.argv[1:] if not a.startswith("--"))
 _savez = np.savez_compressed
+_mismatch = []
 
 
 def _filtered_savez(path, **kw):
     stem = os.path.splitext(os.path.basename(path))[0]
     if ONLY and stem not in ONLY:
+        return
+    if CHECK:
+        if not os.path.exists(path):
+            _mismatch.append(f"{stem}: not committed")
+            return
+        old = np.load(path)
+        for k, v in kw.items():
+            v = np.asarray(v)
+            if k not in old.files or old[k].shape != v.shape or old[k].dtype != v.dtype or not np.array_equal(old[k], v):
+                _mismatch.append(f"{stem}.{k}")
+        for k in old.files:
+            if k not in kw:
+                _mismatch.append(f"{stem}.{k}: no longer generated")
+        print("checked", os.path.basename(path))
         return
     _savez(path, **kw)
     print("wrote", os.path.basename(path))
@@ -234,7 +254,7 @@ def regions_of(batch, opt):
 
 
 for stem, n_pairs, es, ei, flag, seed in (("mem_sam_pe", 160, 0.02, 0.006, 0, 20261008),
-                                          ("mem_sam_pe_all", 60, 0.03, 0.01, po.MEM_F_ALL, 20261009)):
+                                          ("mem_sam_pe_all", 90, 0.03, 0.01, po.MEM_F_ALL, 20261009)):
     tb, names, quals, pes = synth.tail_pairs(n_pairs, bases4, ann_off4, ann_len4, dups4, sub_rate=es, indel_rate=ei, seed=seed)
     rc, rg = regions_of(tb, opt4)
     g4 = bpsw_hip.make_tail_group(tb, names, quals, pes, rc, rg, ann_off4, ann_len4, ann_names4, id0=4242)
@@ -272,3 +292,9 @@ assert int(alns["n_cigar"].max()) <= 32 and int(alns["md_len"].max()) <= 160
 np.savez_compressed(os.path.join(HERE, "mem_reg2aln.npz"), l_pac=int(sum(contigs)), pac=pac4, ann_off=ann_off4, ann_len=ann_len4,
                     read_len=np.array(jl, np.int32), read_off=np.array(jo, np.int64), read_pool=tb.read_pool, regs=rg, alns=alns,
                     cigar=cig, md=md)
+
+if CHECK:
+    if _mismatch:
+        print("golden fixtures differ from what this script generates now:", ", ".join(_mismatch))
+        sys.exit(1)
+    print("all committed fixtures regenerate bit-identically")

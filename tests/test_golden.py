@@ -39,7 +39,9 @@ def test_sw_align2_vs_ksw_align2_golden(orc):
         xtra = po.KSW_XSUBO | po.KSW_XSTART | po.KSW_XBYTE | 19
         got, _ = orc.sw_align2(q, t, opt, xtra)
         assert np.array_equal(got[[0, 1, 2, 5, 6]], want[[0, 1, 2, 5, 6]])  # score, te, qe, tb, qb
-        assert got[3] <= want[3] or want[3] < 0 or True                      # B8: C may report a larger score2
+        # B8: the C's padded SSE2 rows can only ADD second-best candidates, so where the two differ the C reports the larger
+        # score2 (or one where the true DP has none, -1), never a smaller one
+        assert got[3] <= want[3]
         exact2 += int(np.array_equal(got[[3, 4]], want[[3, 4]]))
     assert exact2 > 0.9 * len(z["out"])   # the SSE2 padding effect is a few per cent
 
@@ -162,3 +164,16 @@ def test_chain2aln_vs_mem_chain2aln_golden(orc):
     for f in regs.dtype.names:
         assert np.array_equal(regs[f], z["out_regs"][f]), f
     assert n_ext > 300 and len(regs) < len(b.seed_len)       # extensions ran; contained seeds were skipped
+
+
+def test_committed_fixtures_are_what_the_committed_script_generates():
+    """tests/golden/*.npz must stay reproducible: make_golden.py --check regenerates every file from the reference's own C
+    (oracle/_ref) and the seeded generators, and fails when an array differs from the committed one (a generator that changed
+    after the files were written made three of them stale once).  Needs the reference build, which exists where
+    /root/reference does; on the GPU box the committed files are simply used."""
+    import subprocess
+    import sys
+    if not os.path.exists(po.REF_SO):
+        pytest.skip("oracle/_ref not built here")
+    r = subprocess.run([sys.executable, os.path.join(G, "make_golden.py"), "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

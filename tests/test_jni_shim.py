@@ -177,3 +177,65 @@ def test_sam_pe_tail_through_jni_matches_c_abi(fake, ctx, orc):
     text = out[:nb.value].tobytes()
     got = [text[int(out_off[i]):int(out_off[i + 1])] for i in range(n2)]
     assert got == want
+
+
+@pytest.mark.gpu
+def test_class_and_field_ids_are_resolved_once(fake, ctx):
+    """native/jni_mate_sw.c:102-143 looks ~55 fields and 6 classes up by name on every call; the shim does it on the first call
+    only (classes held as global references) -- the second mateSWJNI makes no FindClass / GetFieldID / GetMethodID at all"""
+    fake.fake_jvm_lookups.restype = C.c_long
+    fake.fake_jvm_global_refs.restype = C.c_long
+    g = synth.rescue_group(40, seed=405, p_resc=0.4)
+    rc, cnt0, regs0, _, msg = _matesw(fake, g, partition=2)
+    assert rc == 0, msg
+    before = fake.fake_jvm_lookups()
+    rc, cnt1, regs1, frames, msg = _matesw(fake, g, partition=2)
+    assert rc == 0, msg
+    assert fake.fake_jvm_lookups() == before
+    assert fake.fake_jvm_global_refs() >= 6
+    assert frames == 0 and np.array_equal(cnt0, cnt1)
+    region_fields_equal(regs0, regs1)
+
+
+@pytest.mark.gpu
+def test_eight_task_threads_partition_to_device_slots(fake, ctx):
+    """Multi-GPU readiness on a one-GPU box (SURVEY.md 8e): BPSW_DEVICES lists four entries (all the same physical device here;
+    on an 8-GPU node they would be 0..7), eight task threads report partitions 0..7 through the fake TaskContext.  Every thread
+    must land on entry `partition mod 4` of the list, own a context no other thread shares (one stream and one set of arenas per
+    task thread), and compute the right answer while the others run."""
+    lib = bpsw_hip.load_library()
+    lib.bpsw_device_slots.restype = C.c_int
+    lib.bpsw_device_for_partition.restype = C.c_int
+    fake.fake_jvm_extend_threads.restype = C.c_int
+    soa = synth.ext_tasks(3000, seed=78)
+    wire = bpsw_hip.wire_pack(soa)
+    want = ctx.extend_batch(wire)
+    saved = os.environ.get("BPSW_DEVICES")
+    os.environ["BPSW_DEVICES"] = "0,0,0,0"
+    try:
+        assert lib.bpsw_device_slots() == 4
+        assert [lib.bpsw_device_for_partition(p) for p in range(8)] == [0] * 8 and lib.bpsw_device_for_partition(-1) == -1
+        n = 8
+        parts = np.arange(n, dtype=np.int32)
+        outs = np.zeros((n, 10 * soa.n), np.int16)
+        info = np.zeros((n, 4), np.int64)
+        err = C.create_string_buffer(512)
+        rc = fake.fake_jvm_extend_threads(bpsw_hip.LIB_PATH.encode(), n, _vp(parts), _vp(wire), int(wire.size), 10 * soa.n, 3,
+                                          _vp(outs), _vp(info), err, 512)
+        assert rc == 0, err.value.decode()
+    finally:
+        if saved is None:
+            os.environ.pop("BPSW_DEVICES", None)
+        else:
+            os.environ["BPSW_DEVICES"] = saved
+    for t in range(n):
+        assert np.array_equal(outs[t], want)
+        assert info[t, 0] == t and info[t, 1] == t % 4 and info[t, 2] == 0      # partition seen, BPSW_DEVICES entry, device
+    assert len(set(int(h) for h in info[:, 3])) == n and 0 not in info[:, 3]     # eight distinct live contexts
+
+
+def test_partition_slots_without_a_device():
+    lib = bpsw_hip.load_library()
+    if lib.bpsw_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    assert lib.bpsw_device_slots() == 0 and lib.bpsw_device_for_partition(3) == -1
