@@ -70,7 +70,7 @@ jclass f_FindClass(JNIEnv*, const char* name) {
   g_vm->calls[JNI_SLOT_FindClass]++;
   bool ok = false;
   for (const char* k : kKnown) ok |= strcmp(k, name) == 0;
-  if (strcmp(name, "org/apache/spark/TaskContext") == 0) ok = g_vm->partition >= 0;
+  if (strcmp(name, "org/apache/spark/TaskContext") == 0) ok = true;  // on the class path; get() is null outside a task
   if (!ok) { g_vm->pending = true; g_vm->pending_msg = std::string("NoClassDefFoundError: ") + name; return nullptr; }
   g_world.lookups++;
   std::lock_guard<std::mutex> lk(g_world.mu);
@@ -125,7 +125,9 @@ jmethodID f_GetMethodID(JNIEnv*, jclass, const char* name, const char*) {
   return reinterpret_cast<jmethodID>(g_world.fields.back().get());
 }
 jmethodID f_GetStaticMethodID(JNIEnv* e, jclass c, const char* name, const char* sig) { return f_GetMethodID(e, c, name, sig); }
-jobject f_CallStaticObjectMethod(JNIEnv*, jclass, jmethodID, ...) { return J(g_vm->alloc("org/apache/spark/TaskContext")); }
+jobject f_CallStaticObjectMethod(JNIEnv*, jclass, jmethodID, ...) {  // TaskContext.get(): null when the thread runs no task
+  return g_vm->partition >= 0 ? J(g_vm->alloc("org/apache/spark/TaskContext")) : nullptr;
+}
 jint f_CallIntMethod(JNIEnv*, jobject, jmethodID, ...) { return g_vm->partition; }
 jsize f_GetArrayLength(JNIEnv*, jarray a) {
   FObj* o = O(a);
