@@ -26,7 +26,7 @@ KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
 # every symbol include/bpsw.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
     "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_device_slots", "bpsw_device_for_partition", "bpsw_last_error", "bpsw_version",
-    "bpsw_set_ext_scoring", "bpsw_extend_batch", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
+    "bpsw_set_ext_scoring", "bpsw_set_ext_shortcuts", "bpsw_extend_batch", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
@@ -146,6 +146,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_destroy.restype = None
     lib.bpsw_device_of.argtypes = [C.c_void_p]
     lib.bpsw_set_ext_scoring.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.bpsw_set_ext_shortcuts.argtypes = [C.c_void_p, C.c_int]
     lib.bpsw_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.bpsw_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     lib.bpsw_wire_size.argtypes = [C.POINTER(ExtTasks)]
@@ -298,6 +299,9 @@ class Context:
         _chk(self.lib, self.lib.bpsw_set_ext_scoring(self.h, _ptr(m), zdrop, zdrop_mode), "bpsw_set_ext_scoring")
 
     # boundary 2 ------------------------------------------------------------------------------
+    def set_ext_shortcuts(self, mask: int = -1):
+        _chk(self.lib, self.lib.bpsw_set_ext_shortcuts(self.h, C.c_int(mask)), "bpsw_set_ext_shortcuts")
+
     def extend_batch(self, wire: np.ndarray) -> np.ndarray:
         """swExtendFPGAJNI(n*10, wire) -> int16[10*n]"""
         wire = np.ascontiguousarray(wire, dtype=np.uint8)

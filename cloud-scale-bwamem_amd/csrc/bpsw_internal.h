@@ -37,6 +37,7 @@ int certify_level(const int8_t mat[25]);  // 0 off, 1 single-gap certificate, 2 
 bool tail_bound_enabled();  // BPSW_EXT_TAIL=0 disables (A/B runs)
 // a > 0 if mat[c][c] == a for the four bases and every other entry is < a; else 0.  BPSW_EXT_EXACT=0 disables.
 int exact_match_score(const int8_t mat[25]);
+void apply_shortcuts(int mask, const int8_t mat[25], int* exact_a, int* certify, int* tail_bound);  // bpsw_set_ext_shortcuts
 
 // ---- extension (boundary 2) -------------------------------------------------------------------
 // Result of the device-side table scan that validates a wire batch before the main launch.
@@ -346,6 +347,7 @@ struct bpsw_ctx {
   bool have_tail_ev = false;
 
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
+  int shortcut_mask = 31;  // bpsw_set_ext_shortcuts
   double wait_est_ms[2] = {0., 0.};  // wait_event: running average of the device-phase waits (extension, SW)
   void* rescue_scratch = nullptr;  // bpsw_rescue.cpp: vectors reused across bpsw_matesw_group calls (freed by rescue_scratch_free)
   bpsw_stats_t stats;

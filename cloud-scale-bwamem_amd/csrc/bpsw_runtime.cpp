@@ -116,6 +116,17 @@ int exact_match_score(const int8_t mat[25]) {
   return a;
 }
 
+// The exact shortcuts of the extension (bpsw_extend_core.h) as the context's mask allows them: bit 0 closed form for near-exact
+// flanks, 1 single-gap certificate, 2 two gap opens, 3 one-base gap at the start of a flank, 4 tail-row bound; the environment
+// switches (BPSW_EXT_EXACT / CERT / CERT2 / GAP1 / TAIL = 0) and the scoring matrix can only take shortcuts away.
+void apply_shortcuts(int mask, const int8_t mat[25], int* exact_a, int* certify, int* tail_bound) {
+  *exact_a = (mask & 1) ? exact_match_score(mat) : 0;
+  int lvl = *exact_a > 0 ? certify_level(mat) : 0;
+  const int allowed = !(mask & 2) ? 0 : (!(mask & 4) ? 1 : (!(mask & 8) ? 2 : 3));
+  *certify = lvl < allowed ? lvl : allowed;
+  *tail_bound = ((mask & 16) && tail_bound_enabled()) ? 1 : 0;
+}
+
 static void default_mat(int8_t mat[25], int a, int b) {  // bwaFillScmat, datatype/MemOptType.scala:58-73
   int k = 0;
   for (int i = 0; i < 4; ++i) {
@@ -328,9 +339,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.zdrop = 100;
   c->ext_sc.zdrop_mode = BPSW_ZDROP_SCALA;
   c->ext_sc.mat_max = 1;
-  c->ext_sc.exact_a = exact_match_score(c->ext_mat);
-  c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
-  c->ext_sc.certify = certify_level(c->ext_mat);
+  apply_shortcuts(c->shortcut_mask, c->ext_mat, &c->ext_sc.exact_a, &c->ext_sc.certify, &c->ext_sc.tail_bound);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   // the events the blocking entry points wait on put the calling thread to sleep (interrupt-driven) instead of spinning:
   // an executor's task threads share a CPU quota, and a spinning waiter takes it from the threads doing host work
@@ -381,6 +390,14 @@ void bpsw_destroy(bpsw_ctx_t* c) {
 
 int bpsw_device_of(const bpsw_ctx_t* c) { return c ? c->device : -1; }
 
+int bpsw_set_ext_shortcuts(bpsw_ctx_t* c, int mask) {
+  if (!c) return fail(BPSW_ERR_ARG, "null context");
+  std::lock_guard<std::mutex> g(c->mu);
+  c->shortcut_mask = mask < 0 ? 31 : (mask & 31);
+  apply_shortcuts(c->shortcut_mask, c->ext_mat, &c->ext_sc.exact_a, &c->ext_sc.certify, &c->ext_sc.tail_bound);
+  return BPSW_OK;
+}
+
 int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdrop_mode) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   if (zdrop_mode != BPSW_ZDROP_SCALA && zdrop_mode != BPSW_ZDROP_BWA) return fail(BPSW_ERR_ARG, "bad zdrop_mode");
@@ -391,9 +408,7 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
   for (int k = 1; k < 25; ++k) c->ext_sc.mat_max = c->ext_mat[k] > c->ext_sc.mat_max ? c->ext_mat[k] : c->ext_sc.mat_max;
   c->ext_sc.zdrop = zdrop;
   c->ext_sc.zdrop_mode = zdrop_mode;
-  c->ext_sc.exact_a = exact_match_score(c->ext_mat);
-  c->ext_sc.tail_bound = tail_bound_enabled() ? 1 : 0;
-  c->ext_sc.certify = certify_level(c->ext_mat);
+  apply_shortcuts(c->shortcut_mask, c->ext_mat, &c->ext_sc.exact_a, &c->ext_sc.certify, &c->ext_sc.tail_bound);
   return BPSW_OK;
 }
 

@@ -459,9 +459,7 @@ int bpsw_chain2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_chains
   for (int k = 1; k < 25; ++k) P.mat_max = opt->mat[k] > P.mat_max ? opt->mat[k] : P.mat_max;
   P.a = opt->a; P.o_del = opt->o_del; P.e_del = opt->e_del; P.o_ins = opt->o_ins; P.e_ins = opt->e_ins;
   P.pen_clip5 = opt->pen_clip5; P.pen_clip3 = opt->pen_clip3; P.w = opt->w; P.zdrop = opt->zdrop; P.zmode = zdrop_mode;
-  P.exact_a = exact_match_score(opt->mat);
-  P.tail_bound = tail_bound_enabled() ? 1 : 0;
-  P.certify = certify_level(opt->mat);
+  apply_shortcuts(c->shortcut_mask, opt->mat, &P.exact_a, &P.certify, &P.tail_bound);
 
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));

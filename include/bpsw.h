@@ -75,6 +75,12 @@ const char *bpsw_version(void);
 /* defaults: MemOptType (datatype/MemOptType.scala:28-73): a=1 b=4 N=-1, zdrop=100, Scala z-drop parse */
 int bpsw_set_ext_scoring(bpsw_ctx_t *ctx, const int8_t mat[25], int zdrop, int zdrop_mode);
 
+/* Which of the kernel's EXACT shortcuts may replace the DP of an extension flank (results are identical either
+ * way, this is an A/B and test switch): bit 0 closed form for near-exact flanks, bit 1 single-gap certificate, bit 2 its
+ * two-gap-open extension, bit 3 one-base gap at the start of a flank, bit 4 tail-row bound.  mask < 0 or 31: all (default).
+ * Applies to bpsw_extend_batch* and bpsw_chain2aln_batch on this context. */
+int bpsw_set_ext_shortcuts(bpsw_ctx_t *ctx, int mask);
+
 /* ---- boundary 2: batched seed extension -------------------------------------------------- */
 /*
  * wire = header(32 B) | task table (32 B x n) | nibble-packed sequences, exactly the byte[] built

@@ -1,0 +1,33 @@
+"""One-minute slices of the adversarial soak tools, so that the driver's GPU run witnesses them (they used to live only in
+tools/ and profiles/*.txt): tools/soak_cert2.py aims at the extension kernel's exact shortcuts (flanks whose deficit sits at the
+boundaries of the closed forms, in low-complexity and periodic sequence, six gap-cost / band settings, both z-drop parses);
+tools/soak_sw.py at the rescue SW kernels (mates of 1..256 bases, every columns-per-lane variant of the packed kernel, repeats,
+N, decoys, six scorings x six flag sets).  Every result is compared with the oracle's full DP."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOOLS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(TOOLS, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_soak_slice_extension_shortcuts():
+    lines = []
+    total, bad = _load("soak_cert2").run(rounds=1000, per=4000, time_limit=50, log=lines.append)
+    assert bad == 0, "\n".join(lines[-5:])
+    assert total > 200_000
+
+
+def test_soak_slice_rescue_sw():
+    lines = []
+    total, bad = _load("soak_sw").run(rounds=1000, per=1500, time_limit=50, log=lines.append)
+    assert bad == 0, "\n".join(lines[-5:])
+    assert total > 50_000

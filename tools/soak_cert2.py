@@ -14,10 +14,6 @@ import bpsw_hip  # noqa: E402
 import pyoracle as po  # noqa: E402
 from test_extend_gpu import _manual_tasks  # noqa: E402
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-per = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
-ctx, orc = bpsw_hip.Context(0), po.Oracle()
-total = bad_total = 0
 
 
 # matrices of the family the forms accept (match 1, everything else <= -1) and one they must refuse (a mismatch of 0 ... -1 only for N)
@@ -109,32 +105,47 @@ def side(rng):
     return q.tolist(), np.concatenate([r, tail]).astype(np.int64).tolist()
 
 
-for rd in range(rounds):
-    rng = np.random.default_rng(31000 + rd)
-    tasks = []
-    for t in range(per):
-        l, r = side(rng), side(rng)
-        h0 = int(rng.integers(16, 60)) if rng.random() < 0.5 else int(rng.integers(16, 150))
-        if SHORT and rng.random() < 0.3:
-            h0 = int(rng.integers(1, 24))
-        if rng.random() < 0.1:
-            l = ([], [])
-        tasks.append((l[0], l[1], r[0], r[1], h0, len(l[0])))
-    soa = _manual_tasks(tasks)
-    for (od, ed, oi, ei), w in (((6, 1, 6, 1), 100), ((6, 1, 6, 1), 3), ((6, 1, 6, 1), 2), ((1, 1, 1, 1), 100), ((3, 1, 3, 1), 100), ((2, 1, 2, 1), 7)):
-        soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w
-        wire = bpsw_hip.wire_pack(soa)
-        for zmode, zdrop in ((0, 100), (1, 100), (1, 16), (0, 0)):
-            mat = MATS[(rd + zmode + zdrop) % len(MATS)]
-            ctx.set_ext_scoring(mat, zdrop, zmode)
-            got = ctx.extend_batch(wire).reshape(-1, 10)
-            want, _ = orc.wire_extend(wire, mat, zdrop, zmode)
-            want = want.reshape(-1, 10)
-            bad = np.nonzero((got != want).any(axis=1))[0]
-            total += soa.n
-            if bad.size:
-                bad_total += bad.size
-                print(f"round {rd} gaps {(od, ed, oi, ei)} w {w} z {zmode}/{zdrop}: {bad.size} differ; task {bad[0]} got {got[bad[0]]} want {want[bad[0]]}", flush=True)
-    print(f"round {rd} tasks so far {total} bad {bad_total}", flush=True)
-print("SOAK", {"task_runs": total, "bad": bad_total})
-sys.exit(1 if bad_total else 0)
+def run(rounds=20, per=4000, time_limit=None, log=print):
+    """`rounds` rounds of `per` two-sided tasks each (six gap-cost / band settings x four z-drop settings per round); stops early
+    after `time_limit` seconds.  Returns (task runs compared, differences).  tests/test_soak_gpu.py runs a one-minute slice."""
+    import time
+    ctx, orc = bpsw_hip.Context(0), po.Oracle()
+    t_start = time.time()
+    total = bad_total = 0
+    for rd in range(rounds):
+        if time_limit is not None and time.time() - t_start > time_limit:
+            break
+        rng = np.random.default_rng(31000 + rd)
+        tasks = []
+        for t in range(per):
+            l, r = side(rng), side(rng)
+            h0 = int(rng.integers(16, 60)) if rng.random() < 0.5 else int(rng.integers(16, 150))
+            if SHORT and rng.random() < 0.3:
+                h0 = int(rng.integers(1, 24))
+            if rng.random() < 0.1:
+                l = ([], [])
+            tasks.append((l[0], l[1], r[0], r[1], h0, len(l[0])))
+        soa = _manual_tasks(tasks)
+        for (od, ed, oi, ei), w in (((6, 1, 6, 1), 100), ((6, 1, 6, 1), 3), ((6, 1, 6, 1), 2), ((1, 1, 1, 1), 100), ((3, 1, 3, 1), 100), ((2, 1, 2, 1), 7)):
+            soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w
+            wire = bpsw_hip.wire_pack(soa)
+            for zmode, zdrop in ((0, 100), (1, 100), (1, 16), (0, 0)):
+                mat = MATS[(rd + zmode + zdrop) % len(MATS)]
+                ctx.set_ext_scoring(mat, zdrop, zmode)
+                got = ctx.extend_batch(wire).reshape(-1, 10)
+                want, _ = orc.wire_extend(wire, mat, zdrop, zmode)
+                want = want.reshape(-1, 10)
+                bad = np.nonzero((got != want).any(axis=1))[0]
+                total += soa.n
+                if bad.size:
+                    bad_total += bad.size
+                    log(f"round {rd} gaps {(od, ed, oi, ei)} w {w} z {zmode}/{zdrop}: {bad.size} differ; task {bad[0]} got {got[bad[0]]} want {want[bad[0]]}")
+        log(f"round {rd} tasks so far {total} bad {bad_total}")
+    ctx.close()
+    return total, bad_total
+
+
+if __name__ == "__main__":
+    total, bad_total = run(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 4000)
+    print("SOAK", {"task_runs": total, "bad": bad_total})
+    sys.exit(1 if bad_total else 0)
