@@ -134,6 +134,24 @@ def random_pac(l_pac: int, seed: int = CONFIG_SEED_BASE + 77):
     return pac, bases
 
 
+class PacBases:
+    """bases[a:b] of the forward strand, unpacked on demand from a 2-bit .pac (for references too long to unpack whole)"""
+
+    def __init__(self, pac: np.ndarray, l_pac: int):
+        self.pac, self.l_pac = pac, l_pac
+
+    def __len__(self):
+        return self.l_pac
+
+    def __getitem__(self, sl):
+        a, b, step = sl.indices(self.l_pac)
+        assert step == 1
+        if b <= a:
+            return np.zeros(0, np.uint8)
+        k = np.arange(a, b, dtype=np.int64)
+        return ((self.pac[k >> 2] >> ((~k & 3) << 1)) & 3).astype(np.uint8)
+
+
 def window_bases(bases: np.ndarray, l_pac: int, rb: int, re: int) -> np.ndarray:
     """bnsGetSeq on unpacked forward bases (data generation only): empty when the window bridges the strands"""
     rb, re = max(rb, 0), min(re, 2 * l_pac)
@@ -147,13 +165,14 @@ def window_bases(bases: np.ndarray, l_pac: int, rb: int, re: int) -> np.ndarray:
 def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE + 3, l_pac: int = 46_709_983,
                  p_resc: float = 0.10, all_orientations: bool = False, sub_rate: float = 0.02, indel_rate: float = 0.002,
                  p_multi_anchor: float = 0.10, p_wrong_mate: float = 0.05, max_matesw: int = 100, pen_unpaired: int = 17,
-                 ref_bases: np.ndarray | None = None):
+                 ref_bases: np.ndarray | None = None, positions=None):
     """Synthetic pair-end group (FR library, insert ~ N(400, 50^2)) in the flat layout of include/bpsw.h.
 
     Each pair has an anchor on one end; with probability p_resc the mate has no consistent hit, so the
     reference's mem_matesw would run SWAlign2 on the rescue window (which contains the mutated mate).
-    With ref_bases (the unpacked forward strand of a reference of length l_pac) reads and windows are cut from that
-    reference, so the same group can be submitted with bytes or, after ref_load, with coordinates only.
+    With ref_bases (the unpacked forward strand of a reference of length l_pac -- anything that answers ref_bases[a:b], e.g.
+    PacBases) reads and windows are cut from that reference, so the same group can be submitted with bytes or, after ref_load,
+    with coordinates only.  positions: forward start of the first len(positions) pairs (the rest are drawn at random).
     """
     from . import RescueGroupSoA, ALNREG_DTYPE
     rng = np.random.default_rng(seed)
@@ -199,6 +218,8 @@ def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE
 
     for k in range(n_pairs):
         P = int(rng.integers(2000, l_pac - 3000))
+        if positions is not None and k < len(positions):
+            P = int(positions[k])
         ins = int(np.clip(rng.normal(avg, std), low + 20, high - 20))
         clean = [rng.integers(0, 4, L).astype(np.uint8), rng.integers(0, 4, L).astype(np.uint8)]  # forward-strand loci
         if ref_bases is not None:
@@ -265,7 +286,7 @@ def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE
 
 def read_chains(n_reads: int, ref_bases: np.ndarray, l_pac: int, read_len: int = 150, sub_rate: float = 0.01,
                 indel_rate: float = 0.001, tail_frac: float = 0.0, min_seed: int = 19, p_subseed: float = 0.3,
-                p_shifted: float = 0.15, p_decoy: float = 0.3, seed: int = CONFIG_SEED_BASE + 9):
+                p_shifted: float = 0.15, p_decoy: float = 0.3, seed: int = CONFIG_SEED_BASE + 9, positions=None):
     """Reads with their seed chains, as memChainToAlnBatched (MemChainToAlignBatched.scala:380-616) receives them.
 
     A read is a mutated substring of either strand of the reference; its chain holds the exact-match runs >= min_seed
@@ -282,6 +303,8 @@ def read_chains(n_reads: int, ref_bases: np.ndarray, l_pac: int, read_len: int =
         rev = rng.random() < 0.5
         lo, hi = (l_pac + 600, 2 * l_pac - L - 600) if rev else (600, l_pac - L - 600)
         rb0 = int(rng.integers(lo, hi))
+        if positions is not None and r < len(positions):   # a start in the doubled coordinate space, given by the caller
+            rb0 = int(positions[r])
         seg = window_bases(ref_bases, l_pac, rb0, rb0 + L + 60)
         es, ei = sub_rate, indel_rate
         if tail_frac > 0 and rng.random() < tail_frac:
