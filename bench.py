@@ -57,7 +57,7 @@ WORKLOADS = {
     5: dict(label="configs[4]: pair-end 2x250bp high-error synthetic reads (8% sub, 2% indel, 1% of reads at 20%/2%), "
                   "wide-band extension + pair-end SW rescue (25% of pairs)",
             metric="pair-end 2x250bp reads aligned/sec", read_len=250, sub=0.08, indel=0.02, tail_frac=0.01, tail_sub=0.20,
-            tail_indel=0.02, p_resc=0.25, mate_sub=0.08, mate_indel=0.02, paired=True, ext_batches=8, groups=32, passes=2),
+            tail_indel=0.02, p_resc=0.25, mate_sub=0.08, mate_indel=0.02, paired=True, ext_batches=32, groups=128, passes=1),
 }
 
 

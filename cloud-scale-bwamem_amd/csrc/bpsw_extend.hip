@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
           // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
           int oInsT = oIns, eInsT = eIns;
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
-          r = sw_extend_reg_any(lane, qLen, rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
+          r = sw_extend_reg_any(lane, qLen, rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, eh);
         } else {
           r = sw_extend_wave(lane, qLen, rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
         }
@@ -188,6 +188,7 @@ __global__ void ext_prepass_kernel(const uint32_t* __restrict__ wire, const unsi
     const int oIns = (int8_t)((hdr0 >> 16) & 0xff), eIns = (int8_t)((hdr0 >> 24) & 0xff);
     const int oDel = (int8_t)(hdr0 & 0xff), eDel = (int8_t)((hdr0 >> 8) & 0xff);
     if (oIns < 0 || eIns < 1 || oDel < 0 || eDel < 1) err = 2;  // the prefix-scan form of F needs oIns >= 0; e = 0 divides by zero in SWUtil.scala:110-115
+    if ((int8_t)((wire[1] >> 16) & 0xff) < 0) err = 2;         // band width is a signed byte
     pre->reserved = oIns + eIns > 0 ? 1 : 0;                    // quad-task kernels are usable
   }
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {

@@ -228,12 +228,22 @@ __device__ __forceinline__ bool zdrop_stop(const int k, const int X, const int e
   return k > 0 ? with_gap > zdrop : (zmode != BPSW_ZDROP_SCALA && other > zdrop);
 }
 
+// The wave-uniform state of a call in flight, handed from the slot sweep (sw_extend_reg) to the sliding sweep
+// (sw_extend_il2<true>) together with the (H,E) row in LDS: see sw_extend_reg_any.
+struct ExtCarry {
+  int handed;  // 1: the slot sweep stopped before row `row` and left the state here and in eh[]
+  int mx, max_i, max_j, max_ie, gscore, max_off, beg, end, h1raw, row;
+};
+
 // QC: query source, qcode(j) = base code (0..4) of column j < qLen
+// eh / carry (optional): LDS row of qLen + 2 (H,E) pairs and the hand-over record.  When given, the sweep stops at the first
+// row whose band [beg, end] fits the 128-column window of the sliding sweep and leaves the call's state there.
 template <int S, class QC>
 __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, const QC& qcode,
                                 const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
                                 const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
-                                const int zmode, const int h0, const int amax) {
+                                const int zmode, const int h0, const int amax, int2* __restrict__ eh = nullptr,
+                                ExtCarry* __restrict__ carry = nullptr) {
   const int oeDel = oDel + eDel, oeIns = oIns + eIns;
   int Hs[S], Es[S], As[S], plo[S], phi[S], jE[S], c2[S];
 #pragma unroll
@@ -261,6 +271,25 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
     if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
       const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
       if (any_lane(U <= mx && U < gscore)) break;
+    }
+    if (S > 2 && carry) {  // this row's band fits the sliding sweep's window: hand the call over (sw_extend_reg_any)
+      const int nb = max(beg, iv - w), ne = min(min(end, iv + (w + 1)), qLen);
+      if (any_lane(ne - (nb & ~1) <= 127)) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const int j = 64 * s + lane;
+          if (j <= qLen) eh[j] = make_int2(Hs[s], Es[s]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        carry->handed = 1;
+        carry->mx = __builtin_amdgcn_readfirstlane(mx); carry->max_i = __builtin_amdgcn_readfirstlane(max_i);
+        carry->max_j = __builtin_amdgcn_readfirstlane(max_j); carry->max_ie = __builtin_amdgcn_readfirstlane(max_ie);
+        carry->gscore = __builtin_amdgcn_readfirstlane(gscore); carry->max_off = __builtin_amdgcn_readfirstlane(max_off);
+        carry->beg = __builtin_amdgcn_readfirstlane(beg); carry->end = __builtin_amdgcn_readfirstlane(end);
+        carry->h1raw = __builtin_amdgcn_readfirstlane(h1raw); carry->row = i;
+        return ExtRes{0, 0, 0, 0, 0, 0};
+      }
     }
     const int tsv = ts[i];  // 8 * target base, same in every lane
     const bool isN = tsv == 32;
@@ -402,35 +431,65 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
 #ifndef BPSW_EXT_INTERLEAVE
 #define BPSW_EXT_INTERLEAVE 1
 #endif
-template <class QC>
+// SLIDE = true: the same sweep over a WINDOW of 128 columns that follows the band, for flanks of any length.  The band of a
+// row -- the columns with a positive score around the best cell -- is 44 columns wide on average and at most 127 for 99.7 % of
+// the rows of 2x250 bp reads at 8 % / 2 % error, however long the flank; the slot sweep (sw_extend_reg<3>, <4>) pays for its
+// three or four slots mostly in scalar control (measured: 93 VALU + 171 SALU instructions per row for three slots, 96 + 210
+// for four, against 94 + 53 here).  Lane l holds columns base + 2l and base + 2l + 1; the per-lane constants of the prefix
+// scan depend only on the column's position in the window (F(i,j) = max_k (a(k) + k e - oe) - (j-1) e is invariant under a
+// shift of the origin); when the band's right end leaves the window, the window moves up to the band's left end: the (H,E)
+// state shifts down by (new base - base) / 2 lanes (ds_bpermute), the profile of the new columns is reloaded.  Columns that
+// enter the window are never read before they are written (SWUtil.scala:174-175 writes eh[end] before the band can grow over
+// it).  A row whose band does not fit 128 columns ends the sweep with *overflow = 1: the caller runs the call again on the slot
+// sweep.  `in`: continue a call the slot sweep started (its first rows did not fit), state in eh[] and *in.
+template <bool SLIDE, class QC>
 __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, const QC& qcode,
                                 const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
                                 const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
-                                const int zmode, const int h0, const int amax) {
+                                const int zmode, const int h0, const int amax, const int2* __restrict__ eh = nullptr,
+                                const ExtCarry* __restrict__ in = nullptr, int* __restrict__ overflow = nullptr) {
   const int oeDel = oDel + eDel, oeIns = oIns + eIns;
   // register budget (the kernel is compiled for five waves per SIMD): the N-row scores of both columns share a register,
   // and (j-1)*eIns, j*eIns - oeIns of both columns derive from one per-lane value
   int Hs[2], Es[2], plo[2], phi2 = 0;
+  int base = (SLIDE && in) ? (max(in->beg, in->row - w) & ~1) : 0;  // first column of the window (even)
+  const auto load_profile = [&]() {
+    phi2 = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int j = base + 2 * lane + s;
+      const int code = j < qLen ? qcode(j) : 4;
+      const int sh = 8 * code;
+      plo[s] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
+                     (((mat.row[3] >> sh) & 0xff) << 24));
+      phi2 |= (int)((mat.row[4] >> sh) & 0xff) << (8 * s);
+    }
+  };
+  load_profile();
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int j = 2 * lane + s;
-    const int code = j < qLen ? qcode(j) : 4;
-    const int sh = 8 * code;
-    plo[s] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
-                   (((mat.row[3] >> sh) & 0xff) << 24));
-    phi2 |= (int)((mat.row[4] >> sh) & 0xff) << (8 * s);
-    Hs[s] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
-    Es[s] = 0;
+    const int j = base + 2 * lane + s;
+    if (SLIDE && in) {
+      const int2 v = j <= qLen ? eh[j] : make_int2(0, 0);
+      Hs[s] = v.x;
+      Es[s] = v.y;
+    } else {
+      Hs[s] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
+      Es[s] = 0;
+    }
   }
-  const int jE0 = 2 * lane * eIns - oeIns;  // j*eIns - oeIns of the even column; the odd one adds eIns
+  const int jE0 = 2 * lane * eIns - oeIns;  // j*eIns - oeIns of the even column, j counted from the window's origin; the odd one adds eIns
   const int kC = oeIns - eIns;              // (j-1)*eIns = (j*eIns - oeIns) + kC
-  int mx = vu(h0), max_i = vu(-1), max_j = vu(-1), max_ie = vu(-1), gscore = vu(-1), max_off = vu(0);
-  int beg = vu(0), end = vu(qLen);
-  int h1raw = vu(h0 - oDel);
-  int iv = vu(0);
+  const bool cont = SLIDE && in;
+  int mx = vu(cont ? in->mx : h0), max_i = vu(cont ? in->max_i : -1), max_j = vu(cont ? in->max_j : -1);
+  int max_ie = vu(cont ? in->max_ie : -1), gscore = vu(cont ? in->gscore : -1), max_off = vu(cont ? in->max_off : 0);
+  int beg = vu(cont ? in->beg : 0), end = vu(cont ? in->end : qLen);
+  int h1raw = vu(cont ? in->h1raw : h0 - oDel);
+  const int i0 = cont ? in->row : 0;
+  int iv = vu(i0);
 
   const int i_tail = amax > 0 ? qLen : 0x7fffffff;  // first row the tail bound applies to (one scalar compare per row)
-  for (int i = 0; i < tLen; ++i, iv += 1) {
+  for (int i = i0; i < tLen; ++i, iv += 1) {
     if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
       const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
       if (any_lane(U <= mx && U < gscore)) break;
@@ -441,6 +500,22 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     const int h1 = max(0, h1raw);      // SWUtil.scala:137-138
     beg = max(beg, iv - w);            // SWUtil.scala:140-142
     end = min(min(end, iv + (w + 1)), qLen);
+    if (SLIDE && any_lane(end - base > 127)) {  // column `end` (written this row) lies beyond the window: move the window up
+      const int nb = __builtin_amdgcn_readfirstlane(beg) & ~1;
+      if (__builtin_amdgcn_readfirstlane(end) - nb > 127) {  // a band wider than the window: not for this sweep
+        *overflow = 1;
+        return ExtRes{0, 0, 0, 0, 0, 0};
+      }
+      const int from = (lane + ((nb - base) >> 1)) << 2;  // byte address of the source lane; lanes past 63 wrap and fetch
+#pragma unroll                                            // columns the band has not reached yet (never read before written)
+      for (int s = 0; s < 2; ++s) {
+        Hs[s] = __builtin_amdgcn_ds_bpermute(from, Hs[s]);
+        Es[s] = __builtin_amdgcn_ds_bpermute(from, Es[s]);
+      }
+      base = nb;
+      load_profile();
+    }
+    const int rbeg = beg - base;       // the band in window coordinates
     const int span = end - beg;
     const unsigned spanA = (unsigned)max(span, 0);
     const unsigned spanU = (unsigned)max(span + 1, 0);
@@ -450,7 +525,7 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     int a[2], Pg[2], akey[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      rel[s] = (unsigned)(2 * lane + s - beg);
+      rel[s] = (unsigned)(2 * lane + s - rbeg);
       upd[s] = rel[s] < spanU;
       act[s] = rel[s] < spanA;
       const int sc = isN ? __builtin_amdgcn_sbfe(phi2, 8u * s, 8u) : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
@@ -488,7 +563,7 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     if (any_lane((span > 0 ? end : beg) == qLen)) {
       int hlast = h1;
       if (any_lane(span > 0)) {
-        const int e = __builtin_amdgcn_readfirstlane(end);
+        const int e = __builtin_amdgcn_readfirstlane(end) - __builtin_amdgcn_readfirstlane(base);
         const int he = __builtin_amdgcn_readlane(Hs[0], e >> 1), ho = __builtin_amdgcn_readlane(Hs[1], e >> 1);
         hlast = (e & 1) ? ho : he;
       }
@@ -498,7 +573,8 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     }
     if (m == 0) break;  // SWUtil.scala:184-185
 
-    const int mj = mkey & 127;  // the LAST column whose a == m (SWUtil.scala:158-161)
+    const int mjr = mkey & 127;    // the LAST column whose a == m (SWUtil.scala:158-161), in window coordinates
+    const int mj = base + mjr;
     const bool improved = m > mx;
     if (!any_lane(improved) && zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
       if (any_lane(zdrop_stop((iv - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode))) break;
@@ -517,15 +593,15 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
       beg = nb0;
       end = end + 1;
     } else {
-      const int ze_l = s_lead_zeros(zm[0] & s_below_mask((mj + 1) >> 1));  // even columns 2l < mj
-      const int zo_l = s_lead_zeros(zm[1] & s_below_mask(mj >> 1));        // odd columns 2l+1 < mj
+      const int ze_l = s_lead_zeros(zm[0] & s_below_mask((mjr + 1) >> 1));  // even columns 2l < mj
+      const int zo_l = s_lead_zeros(zm[1] & s_below_mask(mjr >> 1));        // odd columns 2l+1 < mj
       const int cl = max(ze_l >= 0 ? 2 * (63 - ze_l) : -1, zo_l >= 0 ? 2 * (63 - zo_l) + 1 : -1);
-      const int se = (mj + 2) >> 1, so = (mj + 1) >> 1;                    // first even / odd lane with a column > mj
-      const int fe = s_first_one((zm[0] >> ((mj + 1) >> 1)) >> ((mj + 1) & 1));
+      const int se = (mjr + 2) >> 1, so = (mjr + 1) >> 1;                   // first even / odd lane with a column > mj
+      const int fe = s_first_one((zm[0] >> ((mjr + 1) >> 1)) >> ((mjr + 1) & 1));
       const int fo = s_first_one(zm[1] >> so);
       const int cr = min(fe >= 0 ? 2 * (se + fe) : 1 << 20, fo >= 0 ? 2 * (so + fo) + 1 : 1 << 20);
-      beg = cl >= 0 ? vu(cl + 2) : nb0;
-      end = cr < (1 << 20) ? vu(cr + 1) : end + 1;
+      beg = cl >= 0 ? vu(base + cl + 2) : nb0;
+      end = cr < (1 << 20) ? vu(base + cr + 1) : end + 1;
     }
   }
   ExtRes r;
@@ -808,26 +884,47 @@ struct NibbleQ {
   __device__ __forceinline__ int operator()(int j) const { return nibble_at(words, qStart + j); }
 };
 
-// SWExtend on the register path for any qLen <= 255 (S = number of 64-column slots)
+// SWExtend on the register path for any qLen <= 255.  Up to 63 columns: one column per lane; up to 127: two per lane; longer
+// flanks: the sliding 128-column window (sw_extend_il2<true>), started by the slot sweep when the first rows are wider than the
+// window (eh: LDS row for the hand-over, qLen + 2 pairs; without it such calls stay on the slot sweep), and run again on the
+// slot sweep in the rare case that a later row outgrows the window.  BPSW_EXT_SLIDE=0 at compile time: slot sweep only.
+#ifndef BPSW_EXT_SLIDE
+#define BPSW_EXT_SLIDE 1
+#endif
 template <class QC>
 __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qLen, const int tLen, const QC& qcode,
                                                     const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
                                                     const int eDel, const int oIns, const int eIns, const int w,
-                                                    const int zdrop, const int zmode, const int h0, const int amax) {
-  switch ((qLen + 64) >> 6) {
-    case 1: return sw_extend_reg<1>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+                                                    const int zdrop, const int zmode, const int h0, const int amax,
+                                                    int2* __restrict__ eh = nullptr) {
+  const int slots = (qLen + 64) >> 6;
+  if (slots == 1) return sw_extend_reg<1>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 #if BPSW_EXT_INTERLEAVE
-    case 2: return sw_extend_il2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+  if (slots == 2) return sw_extend_il2<false>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 #else
-    case 2: return sw_extend_reg<2>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+  if (slots == 2) return sw_extend_reg<2>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 #endif
-    // Longer flanks stay on the slot sweep.  A version of the interleaved sweep with three and four columns per lane was
-    // measured on 2x250 bp reads at 8 % substitutions / 2 % indels: 7.35 against 7.9 M reads/s -- with that many errors the
-    // positive part of a row is narrow, the slot sweep skips the slots the band does not touch, and the interleaved sweep
-    // always pays for all of a lane's columns (it also pushed the kernel past its register budget).
-    case 3: return sw_extend_reg<3>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-    default: return sw_extend_reg<4>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+#if BPSW_EXT_SLIDE
+  {
+    int overflow = 0;
+    ExtRes r;
+    if (min(qLen, w + 1) <= 127) {  // row 0's band [0, min(qLen, w+1)] fits the window
+      r = sw_extend_il2<true>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, nullptr, nullptr, &overflow);
+      if (!overflow) return r;
+    } else if (eh) {
+      ExtCarry c;
+      c.handed = 0;
+      r = slots == 3 ? sw_extend_reg<3>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c)
+                     : sw_extend_reg<4>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c);
+      if (!c.handed) return r;
+      r = sw_extend_il2<true>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c, &overflow);
+      if (!overflow) return r;
+    }
   }
+#endif
+  // the slot sweep from the first row to the last
+  if (slots == 3) return sw_extend_reg<3>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+  return sw_extend_reg<4>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 }
 
 // Wave-level dequeue: lane 0 alone performs one returning atomic add, the result is broadcast.  Written as

@@ -488,6 +488,7 @@ static int scan_wire(const uint8_t* wire, size_t bytes, int* n_out, int* maxq, i
   if (n < 0 || 32 + 32 * (size_t)n > bytes) return fail(BPSW_ERR_ARG, "extend: task table exceeds the buffer");
   if ((int8_t)wire[0] < 0 || (int8_t)wire[1] < 1 || (int8_t)wire[2] < 0 || (int8_t)wire[3] < 1)
     return fail(BPSW_ERR_ARG, "extend: gap opens must be >= 0 and gap extensions >= 1 (a zero extension divides by zero in SWUtil.scala:110-115)");
+  if ((int8_t)wire[6] < 0) return fail(BPSW_ERR_ARG, "extend: negative band width (w travels as a signed byte: at most 127)");
   int mq = 0, mr = 0;
   const size_t words = bytes >> 2;
   for (int t = 0; t < n; ++t) {

@@ -17,6 +17,12 @@
 static int64_t g_ext_rows = 0, g_ext_calls = 0;
 int64_t orc_diag_ext_rows(int reset) { int64_t r = g_ext_rows; if (reset) g_ext_rows = 0; return r; }
 int64_t orc_diag_ext_calls(int reset) { int64_t r = g_ext_calls; if (reset) g_ext_calls = 0; return r; }
+/* diagnostics for kernel design: histogram of the band width end - beg + 1 of every SWExtend row (bucket = width / 8, the
+ * last bucket takes everything from 256 columns up), and the same weighted by nothing else -- read with orc_diag_ext_widths */
+static int64_t g_ext_width_hist[33];
+void orc_diag_ext_widths(int64_t out[33], int reset) {
+  for (int k = 0; k < 33; ++k) { out[k] = g_ext_width_hist[k]; if (reset) g_ext_width_hist[k] = 0; }
+}
 
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int iabs(int a) { return a < 0 ? -a : a; }
@@ -92,6 +98,7 @@ void orc_sw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
     }
     eh_h[end] = h1; /* SW:174-175 */
     eh_e[end] = 0;
+    { const int wd = end - beg + 1; ++g_ext_width_hist[wd < 0 ? 0 : (wd >= 256 ? 32 : wd >> 3)]; }
     if (j == qlen) { /* SW:177-182; j == max(beg,end) after the loop */
       if (gscore <= h1) { max_ie = i; gscore = h1; }
     }

@@ -2,7 +2,7 @@
 tools/ and profiles/*.txt): tools/soak_cert2.py aims at the extension kernel's exact shortcuts (flanks whose deficit sits at the
 boundaries of the closed forms, in low-complexity and periodic sequence, six gap-cost / band settings, both z-drop parses);
 tools/soak_sw.py at the rescue SW kernels (mates of 1..256 bases, every columns-per-lane variant of the packed kernel, repeats,
-N, decoys, six scorings x six flag sets).  Every result is compared with the oracle's full DP."""
+N, decoys, six scorings x six flag sets); tools/soak_long.py at long extension flanks.  Every result is compared with the oracle's full DP."""
 import importlib.util
 import os
 
@@ -24,6 +24,15 @@ def test_soak_slice_extension_shortcuts():
     total, bad = _load("soak_cert2").run(rounds=1000, per=4000, time_limit=50, log=lines.append)
     assert bad == 0, "\n".join(lines[-5:])
     assert total > 200_000
+
+
+def test_soak_slice_long_flanks_sliding_window():
+    """tools/soak_long.py: flanks of 64..255 bases (the sliding-window sweep of csrc/bpsw_extend_core.h, its hand-over from the slot
+    sweep, its window moves and its overflow fallback), wide bands, the doubled band of the retry"""
+    lines = []
+    total, bad = _load("soak_long").run(rounds=1000, per=1000, time_limit=40, log=lines.append)
+    assert bad == 0, "\n".join(lines[-5:])
+    assert total > 50_000
 
 
 def test_soak_slice_rescue_sw():
