@@ -196,33 +196,45 @@ def cpu_baseline(W, cfg_no, rank, xtra):
                       f"oracle/bpsw_oracle.c single thread"}
 
 
-def verify_sample(W, cfg_no, rank, wires, ext_outs, groups, grp_cnts, grp_regs, grp_totals, rng):
+def verify_sample(W, cfg_no, rank, wires, ext_outs, groups, grp_cnts, grp_regs, grp_totals, rng, ctx):
     """a random sample of the TIMED outputs against the oracle: ~2k extension tasks out of two wire batches, and whole
-    rescue groups until >= 500 SW jobs are covered.  Returns the counts; raises on any difference."""
+    rescue groups until >= 500 SW jobs are covered; raises on any difference.  The same sample gives the useful work per
+    task / job for the GCUPS figures: DP cell updates as the oracle counts them (the cells the reference's SWExtend /
+    SWAlign2 loops touch), split for the extension by how the kernel produced the side's result (bpsw_extend_batch_classify:
+    exact shortcut = no cell was computed, DP swept = the cells were computed)."""
     import bpsw_hip
     import pyoracle as po
     orc = po.Oracle()
     n_ext = n_pairs = n_jobs = 0
+    cells_closed = cells_dp = cells_sw = 0
     if wires:
         for b in rng.choice(len(wires), size=min(2, len(wires)), replace=False):
             soa = make_ext_soa(W, cfg_no, rank, int(b))
             sel = np.sort(rng.choice(soa.n, size=min(1024, soa.n), replace=False))
             sub_wire = bpsw_hip.wire_pack(soa.subset(sel))
-            want, _ = orc.wire_extend(sub_wire)
+            want, _, side_cells = orc.wire_extend_sides(sub_wire)
             got = ext_outs[int(b)].reshape(-1, 10)[sel]
             if not np.array_equal(got, np.asarray(want).reshape(-1, 10)):
                 raise SystemExit(f"bench: extension outputs of timed wire batch {b} differ from the oracle")
+            again, how = ctx.extend_batch_classify(sub_wire)
+            if not np.array_equal(again, np.asarray(want)):
+                raise SystemExit("bench: classify run differs from the oracle")
+            cells_closed += int(side_cells[how == 1].sum())
+            cells_dp += int(side_cells[how == 2].sum())
             n_ext += len(sel)
     gi = list(rng.permutation(len(groups)))
     while gi and n_jobs < 500:
         g = int(gi.pop())
-        wcnt, wregs, jobs, _ = orc.matesw_group(orc.default_opt(), groups[g], po.RESCUE_C)
+        wcnt, wregs, jobs, cells = orc.matesw_group(orc.default_opt(), groups[g], po.RESCUE_C)
         got_cnt, got = grp_cnts[g], grp_regs[g][: int(grp_totals[g])]
         if not (np.array_equal(got_cnt, wcnt) and len(got) == len(wregs) and all(np.array_equal(got[f], wregs[f]) for f in got.dtype.names)):
             raise SystemExit(f"bench: rescue outputs of timed group {g} differ from the oracle")
         n_pairs += groups[g].group_size
         n_jobs += int(jobs)
-    return {"ext_tasks": int(n_ext), "rescue_pairs": int(n_pairs), "rescue_jobs": int(n_jobs), "mismatches": 0}
+        cells_sw += int(cells)
+    work = {"ext_cells_per_task_closed_form": cells_closed / max(n_ext, 1), "ext_cells_per_task_dp_run": cells_dp / max(n_ext, 1),
+            "sw_cells_per_job": cells_sw / max(n_jobs, 1)}
+    return {"ext_tasks": int(n_ext), "rescue_pairs": int(n_pairs), "rescue_jobs": int(n_jobs), "mismatches": 0}, work
 
 
 def device_resident_breakdown(W, cfg_no, rank, wires, ntasks, dev, local_rank, reps):
@@ -412,8 +424,8 @@ def main():
     value = whole_job_rate(reads_per_step, args.steps, world, elapsed)
 
     # ---- a sample of the timed outputs against the oracle (outside the timed region; the only use of oracle/ besides cpu_baseline)
-    verified = verify_sample(W, args.config, rank, wires, ext_outs, groups, grp_cnts, grp_regs, grp_totals,
-                             np.random.default_rng(1234 + rank)) if rank == 0 else None
+    verified, work = verify_sample(W, args.config, rank, wires, ext_outs, groups, grp_cnts, grp_regs, grp_totals,
+                                   np.random.default_rng(1234 + rank), F.ctxs[0]) if rank == 0 else (None, None)
 
     # ---- per-kernel figures from the HIP events the library records on its launch streams during the timed region ----
     ext_launches, sw_launches = int(st["ext_calls"]), int(st["sw_calls"])
@@ -437,6 +449,31 @@ def main():
     pcie_bytes_per_step = passes * (sum(int(w.size) for w in wires) + 20 * sum(ntasks))   # boundary 2 both ways; boundary 1 below
     pcie_bytes_per_step += int((st["sw_jobs"] / max(args.steps, 1)) * (W["read_len"] + win_len + 28 + 29))
 
+    # ---- useful work: DP cell updates per second, and what fraction of the integer-VALU ceiling they are.
+    # Cells as the reference's loops count them (oracle); an extension side the kernel resolved by an exact shortcut contributes
+    # its cells to `closed_form` (they were never computed), a swept side to `dp_run`.  Ceiling: 256 CUs x 4 SIMD16 x 2.4 GHz
+    # int32 lane-operations per second, at ~12 operations per extension cell (SWUtil.scala:151-170) and ~11 per
+    # local-SW cell (SWUtil.scala:484-505).
+    gcups = valu = None
+    if work is not None:
+        step_s = elapsed / args.steps
+        ext_tasks_step = passes * float(sum(ntasks))
+        sw_jobs_step = st["sw_jobs"] / max(args.steps, 1)
+        c_closed = ext_tasks_step * work["ext_cells_per_task_closed_form"]
+        c_dp = ext_tasks_step * work["ext_cells_per_task_dp_run"]
+        c_sw = sw_jobs_step * work["sw_cells_per_job"]
+        gcups = {"extend_dp_run": round(c_dp / step_s / 1e9, 2), "extend_closed_form": round(c_closed / step_s / 1e9, 2),
+                 "rescue_sw": round(c_sw / step_s / 1e9, 2), "computed": round((c_dp + c_sw) / step_s / 1e9, 2),
+                 "reference_equivalent": round((c_dp + c_closed + c_sw) / step_s / 1e9, 2),
+                 "cells_per_ext_task": round(work["ext_cells_per_task_closed_form"] + work["ext_cells_per_task_dp_run"], 1),
+                 "cells_per_rescue_job": round(work["sw_cells_per_job"], 1),
+                 "note": "per rank; cells = the reference's DP cell updates (oracle counters on the verified sample); closed_form = cells of "
+                         "extension sides an exact shortcut resolved without computing them"}
+        ops_run = 12.0 * c_dp + 11.0 * c_sw
+        ops_ref = 12.0 * (c_dp + c_closed) + 11.0 * c_sw
+        valu = {"computed_cells": round(ops_run / step_s / INT_VALU_PEAK_OPS, 4), "reference_equivalent_cells": round(ops_ref / step_s / INT_VALU_PEAK_OPS, 4),
+                "ceiling_int32_lane_ops_per_s": INT_VALU_PEAK_OPS, "ops_per_cell": {"extend": 12, "rescue_sw": 11}}
+
     extras = {}
     if not args.no_extras:
         try:
@@ -453,8 +490,9 @@ def main():
         "metric": W["metric"],
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int32 (extension) / packed u16 (rescue SW, exact under the 255 score cap)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "int32+u16", "data": "synthetic",
         "config": {"workload": W["label"], "survey_config": args.config,
+                   "dtype_note": "extension DP in int32; rescue SW in packed u16, two jobs per wavefront (exact: a pass stops at the 255 score cap, SWUtil.scala:423,537)",
                    "pairs_per_step_per_gpu": pairs_per_step, "reads_per_step_per_gpu": reads_per_step,
                    "passes_per_step": passes, "distinct_reads_per_pass": reads_per_pass,
                    "ext_batches_per_step": passes * W["ext_batches"], "reads_per_ext_batch": READS_PER_EXT_BATCH,
@@ -472,6 +510,7 @@ def main():
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                      "note": "launch duration = HIP events on the launch stream inside the library, averaged over the timed region; launches of "
                              "different host threads overlap on the device, so this is the time a launch spends sharing the GPU"},
+        "gcups": gcups, "frac_of_valu_ceiling": valu,
         "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes),
                                "h2d_ms_avg": round(st["ext_h2d_ms"] / max(ext_launches, 1), 4), "d2h_ms_avg": round(st["ext_d2h_ms"] / max(ext_launches, 1), 4)},
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes),

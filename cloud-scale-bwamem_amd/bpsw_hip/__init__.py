@@ -26,7 +26,7 @@ KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
 # every symbol include/bpsw.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
     "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_device_slots", "bpsw_device_for_partition", "bpsw_last_error", "bpsw_version",
-    "bpsw_set_ext_scoring", "bpsw_set_ext_shortcuts", "bpsw_extend_batch", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
+    "bpsw_set_ext_scoring", "bpsw_set_ext_shortcuts", "bpsw_extend_batch", "bpsw_extend_batch_classify", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
@@ -309,6 +309,17 @@ class Context:
         out = np.zeros(max(10 * n, 1), dtype=np.int16)
         _chk(self.lib, self.lib.bpsw_extend_batch(self.h, _ptr(wire), wire.size, _ptr(out), out.size), "bpsw_extend_batch")
         return out[: 10 * n]
+
+    def extend_batch_classify(self, wire: np.ndarray):
+        """extend_batch + per task and side how the result was produced (0 empty side, 1 exact shortcut, 2 DP swept)"""
+        wire = np.ascontiguousarray(wire, dtype=np.uint8)
+        n = int(np.frombuffer(wire[8:12].tobytes(), dtype="<i4")[0]) if wire.size >= 12 else 0
+        out = np.zeros(max(10 * n, 1), dtype=np.int16)
+        how = np.zeros((max(n, 1), 2), dtype=np.uint8)
+        self.lib.bpsw_extend_batch_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        _chk(self.lib, self.lib.bpsw_extend_batch_classify(self.h, _ptr(wire), wire.size, _ptr(out), out.size, _ptr(how)),
+             "bpsw_extend_batch_classify")
+        return out[: 10 * n], how[:n]
 
     def extend_batch_device(self, d_wire_ptr: int, wire_bytes: int, n_tasks: int, d_out_ptr: int, stream: int = 0):
         _chk(self.lib, self.lib.bpsw_extend_batch_device(self.h, C.c_void_p(d_wire_ptr), wire_bytes, n_tasks,

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
                                                              hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, sc.certify, &r)) ||
                           (sc.certify >= 3 && flank_start_gap_form(lane, qLen, rLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat,
                                                                    hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
+      if (sc.side_how && lane == 0) sc.side_how[2 * (size_t)task + side] = exact ? 1 : 2;  // diagnostics only
       if (exact) {
         aw[side] = wBand;
         regScore = r.max;

@@ -31,6 +31,7 @@ struct ExtScoring {
   int exact_a;  // match score when the exact-flank shortcut is valid for this matrix (bpsw_extend_core.h), else 0
   int tail_bound;  // 1: stop a call once the rows past the query end cannot change its result (tail_row_bound)
   int certify;     // certify_level(): 1 single-gap certificate for flanks with a deficit below two gap opens, 2 also two opens
+  uint8_t* side_how;  // optional (bpsw_extend_batch_classify): per task and side, 1 = resolved by an exact shortcut, 2 = DP swept
 };
 bool certify_enabled();
 int certify_level(const int8_t mat[25]);  // 0 off, 1 single-gap certificate, 2 also the two-gap-open extension

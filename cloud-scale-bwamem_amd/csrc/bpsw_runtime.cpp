@@ -339,6 +339,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.zdrop = 100;
   c->ext_sc.zdrop_mode = BPSW_ZDROP_SCALA;
   c->ext_sc.mat_max = 1;
+  c->ext_sc.side_how = nullptr;
   apply_shortcuts(c->shortcut_mask, c->ext_mat, &c->ext_sc.exact_a, &c->ext_sc.certify, &c->ext_sc.tail_bound);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   // the events the blocking entry points wait on put the calling thread to sleep (interrupt-driven) instead of spinning:
@@ -509,7 +510,18 @@ static int scan_wire(const uint8_t* wire, size_t bytes, int* n_out, int* maxq, i
   return BPSW_OK;
 }
 
+static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how);
+
 int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len) {
+  return extend_batch_impl(c, wire, wire_bytes, out, out_len, nullptr);
+}
+
+int bpsw_extend_batch_classify(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how) {
+  if (!side_how) return fail(BPSW_ERR_ARG, "extend_classify: null side_how");
+  return extend_batch_impl(c, wire, wire_bytes, out, out_len, side_how);
+}
+
+static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   int n = 0, mq = 0, mr = 0;
   int rc = scan_wire(wire, wire_bytes, &n, &mq, &mr);
@@ -548,8 +560,17 @@ int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int
       if (rc != BPSW_OK) return rc;
     } else
 #endif
-      HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, c->ext_sc, mq, mr, c->num_cu,
+    {
+      ExtScoring sc = c->ext_sc;
+      if (side_how) {  // diagnostics: the kernel notes per side whether a shortcut or the DP produced the result
+        HIP_TRY(c->d_ext_lists.reserve(2 * (size_t)n + 16));
+        HIP_TRY(hipMemsetAsync(c->d_ext_lists.ptr, 0, 2 * (size_t)n, s));
+        sc.side_how = (uint8_t*)c->d_ext_lists.ptr;
+      }
+      HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, mq, mr, c->num_cu,
                                 (int*)((char*)c->d_pre.ptr + 128), nullptr, s));
+      if (side_how) HIP_TRY(hipMemcpyAsync(side_how, c->d_ext_lists.ptr, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipEventRecord(c->ev[2], s));
     if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(c->ev[3], s));

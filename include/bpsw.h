@@ -90,6 +90,11 @@ int bpsw_set_ext_shortcuts(bpsw_ctx_t *ctx, int mask);
  */
 int bpsw_extend_batch(bpsw_ctx_t *ctx, const uint8_t *wire, size_t wire_bytes, int16_t *out, size_t out_len);
 
+/* Diagnostics: bpsw_extend_batch that also reports, per task and side (side_how[2 t] left, [2 t + 1] right; 2 n bytes), how the
+ * result was produced: 0 = the side is empty, 1 = an exact shortcut (bpsw_set_ext_shortcuts), 2 = the DP was swept.  bench.py
+ * uses it to split the useful cell updates per second into "DP run" and "closed form". */
+int bpsw_extend_batch_classify(bpsw_ctx_t *ctx, const uint8_t *wire, size_t wire_bytes, int16_t *out, size_t out_len, uint8_t *side_how);
+
 /* Same computation with the wire batch and the result already resident in device memory
  * (used by bench.py; d_wire must be 16-byte aligned).  hip_stream is a hipStream_t or NULL for the context's stream.
  * ASYNCHRONOUS: the device-side table scan, the main launch and the scan's read-back are enqueued back to back and the call

@@ -134,8 +134,17 @@ void orc_sw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
 
 /* ------------------------------------------------------------ extension task */
 /* C2AB:789-883 */
+static void orc_extension_sides(const orc_ext_param_t *p, int zdrop_mode, orc_ext_ret_t *ret, int64_t *cells, int64_t *side_cells);
 void orc_extension(const orc_ext_param_t *p, int zdrop_mode, orc_ext_ret_t *ret, int64_t *cells) {
+  orc_extension_sides(p, zdrop_mode, ret, cells, NULL);
+}
+/* side_cells (optional): DP cells of the left / right side of this task, every band try included (bench.py's GCUPS split) */
+static void orc_extension_sides(const orc_ext_param_t *p, int zdrop_mode, orc_ext_ret_t *ret, int64_t *cells, int64_t *side_cells) {
   const int MAX_BAND_TRY = 2; /* C2AB:50 */
+  int64_t local_cells = 0;
+  if (!cells) cells = &local_cells;
+  const int64_t cells_at_start = *cells;
+  int64_t cells_after_left = *cells;
   int aw0 = p->w, aw1 = p->w;
   int qle = -1, tle = -1, gtle = -1, gscore = -1, maxoff = -1;
   int i, brk, prev = -1, reg_score = p->reg_score;
@@ -161,6 +170,7 @@ void orc_extension(const orc_ext_param_t *p, int zdrop_mode, orc_ext_ret_t *ret,
       ret->q_beg = 0; ret->r_beg = -gtle; ret->true_score = gscore;
     }
   }
+  cells_after_left = *cells;
   if (p->right_qlen > 0) { /* C2AB:844-876 */
     const int sc0 = reg_score;
     for (i = 0, brk = 0; i < MAX_BAND_TRY && !brk; ++i) {
@@ -180,6 +190,7 @@ void orc_extension(const orc_ext_param_t *p, int zdrop_mode, orc_ext_ret_t *ret,
   }
   ret->width = aw0 > aw1 ? aw0 : aw1; /* C2AB:877-879 */
   ret->idx = p->idx;
+  if (side_cells) { side_cells[0] = cells_after_left - cells_at_start; side_cells[1] = *cells - cells_after_left; }
 }
 
 /* ------------------------------------------------------- boundary-2 wire format */
@@ -254,8 +265,19 @@ size_t orc_wire_pack(int n, const orc_ext_param_t *tasks, uint8_t *buf, size_t c
   return total;
 }
 
+static int orc_wire_extend_impl(const uint8_t *wire, size_t bytes, const int8_t mat[25], int zdrop, int zdrop_mode,
+                                int16_t *out, int64_t *cells, int64_t *side_cells);
 int orc_wire_extend(const uint8_t *wire, size_t bytes, const int8_t mat[25], int zdrop, int zdrop_mode,
                     int16_t *out, int64_t *cells) {
+  return orc_wire_extend_impl(wire, bytes, mat, zdrop, zdrop_mode, out, cells, NULL);
+}
+/* the same, also reporting the DP cells of every side: side_cells[2 t] left, [2 t + 1] right */
+int orc_wire_extend_sides(const uint8_t *wire, size_t bytes, const int8_t mat[25], int zdrop, int zdrop_mode,
+                          int16_t *out, int64_t *cells, int64_t *side_cells) {
+  return orc_wire_extend_impl(wire, bytes, mat, zdrop, zdrop_mode, out, cells, side_cells);
+}
+static int orc_wire_extend_impl(const uint8_t *wire, size_t bytes, const int8_t mat[25], int zdrop, int zdrop_mode,
+                                int16_t *out, int64_t *cells, int64_t *side_cells) {
   if (bytes < 32) return -1;
   const int n = get32(wire, 8);
   if (n < 0 || 32 + 32 * (size_t)n > bytes) return -1;
@@ -281,7 +303,7 @@ int orc_wire_extend(const uint8_t *wire, size_t bytes, const int8_t mat[25], int
     p.left_qs = tmp; p.right_qs = tmp + p.left_qlen;
     p.left_rs = p.right_qs + p.right_qlen; p.right_rs = p.left_rs + p.left_rlen;
     orc_ext_ret_t r;
-    orc_extension(&p, zdrop_mode, &r, cells);
+    orc_extension_sides(&p, zdrop_mode, &r, cells, side_cells ? side_cells + 2 * (size_t)i : NULL);
     int16_t *o = out + 10 * (size_t)i; /* C2AB:181-188 */
     o[0] = (int16_t)(r.idx & 0xffff); o[1] = (int16_t)((r.idx >> 16) & 0xffff);
     o[2] = (int16_t)r.q_beg; o[3] = (int16_t)r.q_end; o[4] = (int16_t)r.r_beg; o[5] = (int16_t)r.r_end;

@@ -116,6 +116,19 @@ class Oracle:
             raise ValueError("malformed wire batch")
         return out[: 10 * n], cells.value
 
+    def wire_extend_sides(self, wire, mat=None, zdrop=100, zdrop_mode=ZDROP_SCALA):
+        """wire_extend that also reports the DP cells of every side -> (int16[10n], cells, int64[n, 2])"""
+        wire = np.ascontiguousarray(wire, np.uint8)
+        m = np.ascontiguousarray(default_mat() if mat is None else mat, np.int8)
+        n = int(np.frombuffer(wire[8:12].tobytes(), "<i4")[0])
+        out = np.zeros(max(10 * n, 1), np.int16)
+        sides = np.zeros((max(n, 1), 2), np.int64)
+        cells = C.c_int64(0)
+        rc = self.lib.orc_wire_extend_sides(_vp(wire), C.c_size_t(wire.size), _vp(m), zdrop, zdrop_mode, _vp(out), C.byref(cells), _vp(sides))
+        if rc < 0:
+            raise ValueError("malformed wire batch")
+        return out[: 10 * n], cells.value, sides[:n]
+
     def wire_pack_soa(self, soa, mat=None):
         """pack an ExtTaskSoA through the ORACLE's packer (MemChainToAlignBatched.scala:76-172)"""
         m = np.ascontiguousarray(default_mat() if mat is None else mat, np.int8)
