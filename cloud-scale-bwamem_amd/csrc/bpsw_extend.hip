@@ -24,10 +24,6 @@ namespace bpsw {
 namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
-#ifndef BPSW_EXT_CHUNK
-#define BPSW_EXT_CHUNK 1
-#endif
-constexpr int EXT_CHUNK = BPSW_EXT_CHUNK;  // tasks per dequeue (larger chunks measured slower: the tail grows faster than the atomic traffic shrinks)
 
 // stage the target of one side in LDS as 8*code bytes (the shift the register path feeds to v_bfe)
 __device__ void load_target_shifts(const int lane, const uint32_t* __restrict__ words, const int rStart, const int rLen,
@@ -59,7 +55,7 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
-                                                                     const int lds_per_wave,
+                                                                     const int lds_per_wave, const int chunk, const int guide_cap,
                                                                      int* __restrict__ next_task,
                                                                      const int* __restrict__ task_list,
                                                                      const ExtPrepass* __restrict__ pre) {
@@ -90,12 +86,27 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
   // One counter word sustains only ~90 returning atomics per microsecond chip-wide (MI355X_MICROARCH.md, row
   // "dequeue"), which at one atomic per task would cap a 30 k-task batch near 0.4 ms; waves therefore take tickets
   // in chunks of EXT_CHUNK consecutive tasks.
-  int ticket = 0, ticket_end = 0;
+  // Guided dequeue (chunk == 0, the default): a wave takes (tasks left) / (2 x waves) tickets at a time, at most guide_cap, and single
+  // tasks once the queue runs low -- the tail, where balance matters, is still served task by task, and the early part costs a
+  // sixth of the atomics.  Every dequeue is a device-scope atomic that goes to the memory side (the XCDs' L2s are not coherent
+  // with each other): at one per task the queue alone was as much fabric traffic as the tasks' own bytes.
+  const int total_waves = (int)gridDim.x * WAVES_PER_BLOCK;
+  int ticket = 0, ticket_end = 0, take = chunk > 0 ? chunk : max(1, min(guide_cap, n_tasks / (2 * total_waves)));
   for (;;) {
     if (ticket == ticket_end) {
-      ticket = dequeue_task(next_task) * EXT_CHUNK;
-      ticket_end = min(ticket + EXT_CHUNK, n_tasks);
-      if (ticket >= n_tasks) break;
+      ticket = dequeue_task(next_task, take);
+      ticket_end = min(ticket + take, n_tasks);
+      if (chunk == 0) take = max(1, min(guide_cap, (n_tasks - ticket_end) / (2 * total_waves)));
+      if (ticket >= n_tasks) {
+        // The last wave to leave puts the queue back to zero for the next launch on this context: next_task[1] counts the waves
+        // that have taken their last ticket.  Saves the fill kernel that used to zero the head before every launch.
+        const int gone = dequeue_task(next_task + 1);
+        if (gone == (int)gridDim.x * WAVES_PER_BLOCK - 1 && lane == 0) {
+          next_task[0] = 0;
+          next_task[1] = 0;
+        }
+        break;
+      }
     }
     const int task = task_list ? uni(task_list[ticket]) : ticket;  // n_tasks counts the entries of task_list when given
     ++ticket;
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
     const int aw0 = aw[0], aw1 = aw[1];
     const int width = aw0 > aw1 ? aw0 : aw1;
     if (lane == 0) {  // MemChainToAlignBatched.scala:181-188: 10 int16 per task
-      uint32_t* o = reinterpret_cast<uint32_t*>(out + 10 * (size_t)task);
+      uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)sc.out_stride * (size_t)task);
       o[0] = (uint32_t)idx;
       o[1] = ((uint32_t)outQBeg & 0xffffu) | ((uint32_t)outQEnd << 16);
       o[2] = ((uint32_t)outRBeg & 0xffffu) | ((uint32_t)outREnd << 16);
@@ -263,12 +274,12 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   int max_blocks = (int)(num_cu * per_cu_f);
   if (max_blocks < 1) max_blocks = 1;
   if (blocks > max_blocks) blocks = max_blocks;
-  if (!counter_zeroed) {
-    hipError_t me = hipMemsetAsync(d_counter, 0, sizeof(int), s);
-    if (me != hipSuccess) return me;
-  }
+  (void)counter_zeroed;  // the queue head (d_counter[0], [1]) is zero between launches: the kernel's last wave resets it
+  // tasks per dequeue: 0 = guided (see the kernel), n > 0 = fixed chunks of n (1 balances a lone launch best)
+  static const int chunk = [] { const int v = getenv("BPSW_EXT_CHUNK") ? atoi(getenv("BPSW_EXT_CHUNK")) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();  // 0: guided
+  static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   hipLaunchKernelGGL(ext_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
-                     rcap, (int)per_wave, d_counter, d_task_list, d_pre_check);
+                     rcap, (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check);
   return hipGetLastError();
 }
 

@@ -932,8 +932,8 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
 // `if (lane == 0) atomicAdd(...)` hipcc threaded that branch together with the lane-0 result store at the end
 // of the previous iteration and peeled the other 63 lanes out of the loop, which breaks every cross-lane
 // operation of the row sweep.
-__device__ __forceinline__ int dequeue_task(int* counter) {
-  int v = 1;
+__device__ __forceinline__ int dequeue_task(int* counter, const int count = 1) {
+  int v = count;
   unsigned long long saved;
   asm volatile(
       "s_mov_b64 %1, exec\n\t"

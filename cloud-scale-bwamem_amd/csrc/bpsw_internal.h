@@ -31,6 +31,8 @@ struct ExtScoring {
   int exact_a;  // match score when the exact-flank shortcut is valid for this matrix (bpsw_extend_core.h), else 0
   int tail_bound;  // 1: stop a call once the rows past the query end cannot change its result (tail_row_bound)
   int certify;     // certify_level(): 1 single-gap certificate for flanks with a deficit below two gap opens, 2 also two opens
+  int out_stride;     // int16 units between the result records of consecutive tasks: 10 (the caller's layout) or 16 (one 32-byte
+                      // slot per task in the pinned staging buffer: a record never straddles two write sectors)
   uint8_t* side_how;  // optional (bpsw_extend_batch_classify): per task and side, 1 = resolved by an exact shortcut, 2 = DP swept
 };
 bool certify_enabled();
@@ -56,8 +58,8 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 size_t ext_lds_per_wave(int qcap, int rcap);
 
 // Launch the extension kernel over a validated batch.
-// d_counter: one device int used as the kernel's task queue head (zeroed on the stream before the launch, unless the caller
-// says it already did: counter_zeroed).
+// d_counter: two device ints, the kernel's task queue head and the count of waves that have left; both zero when the launch
+// starts (the context zeroes them once, the kernel's last wave puts them back).
 // d_task_list (optional): the n_tasks task indices this launch handles (else tasks 0..n_tasks-1).
 // d_pre_check (optional): device ExtPrepass written earlier on the same stream; the kernel does nothing when it reports an
 // error or lengths beyond (qcap, rcap) -- the asynchronous device entry sizes the launch before anybody has read the scan back.

@@ -340,6 +340,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.zdrop_mode = BPSW_ZDROP_SCALA;
   c->ext_sc.mat_max = 1;
   c->ext_sc.side_how = nullptr;
+  c->ext_sc.out_stride = 10;
   apply_shortcuts(c->shortcut_mask, c->ext_mat, &c->ext_sc.exact_a, &c->ext_sc.certify, &c->ext_sc.tail_bound);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   // the events the blocking entry points wait on put the calling thread to sleep (interrupt-driven) instead of spinning:
@@ -359,6 +360,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   }
   if (e == hipSuccess && want_side_streams) e = hipEventCreateWithFlags(&c->aux.fork, hipEventDisableTiming);
   if (e == hipSuccess) e = c->d_pre.reserve(512);
+  if (e == hipSuccess) e = hipMemset(c->d_pre.ptr, 0, 512);  // scan records and the self-resetting queue heads of ext_kernel
   if (e == hipSuccess) e = c->h_pre.reserve(512);
   if (e != hipSuccess) {
     bpsw_destroy(c);
@@ -532,13 +534,16 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   HIP_TRY(hipSetDevice(c->device));
   { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
   const size_t out_bytes = 20 * (size_t)n;
+  // (32-byte result slots in the pinned buffer were tried: the 16 + 4 byte stores of a record then cost two write sectors each,
+  // more fabric writes than back-to-back 20-byte records that merge in L2, and the host-side gather cost more than the memcpy)
+  bool zc_slots = false;
   HIP_TRY(c->d_wire.reserve(wire_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
 #ifdef BPSW_EXPERIMENTAL_KERNELS
   HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n + 16));
 #endif
   HIP_TRY(c->h_stage_in.reserve(wire_bytes));
-  HIP_TRY(c->h_stage_out.reserve(out_bytes));
+  HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_bytes));
   const double t_in = wall_ms();
   memcpy(c->h_stage_in.ptr, wire, wire_bytes);
   const double t_staged = wall_ms();
@@ -556,12 +561,14 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     int16_t* k_out = zc_out ? (int16_t*)c->h_stage_out.ptr : (int16_t*)c->d_out.ptr;
 #ifdef BPSW_EXPERIMENTAL_KERNELS
     if (ext_lane_enabled() || ext_qt_enabled()) {
+      zc_slots = false;  // the experimental kernels write 20-byte records back to back
       rc = ext_experimental_launch(c, wire, wire_bytes, n, mq, mr, k_out, s);
       if (rc != BPSW_OK) return rc;
     } else
 #endif
     {
       ExtScoring sc = c->ext_sc;
+      if (zc_out) sc.out_stride = 16;
       if (side_how) {  // diagnostics: the kernel notes per side whether a shortcut or the DP produced the result
         HIP_TRY(c->d_ext_lists.reserve(2 * (size_t)n + 16));
         HIP_TRY(hipMemsetAsync(c->d_ext_lists.ptr, 0, 2 * (size_t)n, s));
@@ -578,7 +585,16 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     t_dev1 = wall_ms();
     c->stats.ext_wait_ms += lease.wait_ms;
   }
-  memcpy(out, c->h_stage_out.ptr, out_bytes);
+  if (zc_slots) {  // gather the 20-byte records out of their 32-byte slots
+    const uint8_t* src = (const uint8_t*)c->h_stage_out.ptr;
+    uint8_t* dst = (uint8_t*)out;
+    for (int t = 0; t < n; ++t) {
+      memcpy(dst + 20 * (size_t)t, src + 32 * (size_t)t, 16);
+      memcpy(dst + 20 * (size_t)t + 16, src + 32 * (size_t)t + 16, 4);
+    }
+  } else {
+    memcpy(out, c->h_stage_out.ptr, out_bytes);
+  }
   const double t_out = wall_ms();
   float a = 0, b = 0, d = 0;
   (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);

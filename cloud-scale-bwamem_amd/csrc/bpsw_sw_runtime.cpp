@@ -465,7 +465,7 @@ int bpsw_chain2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_chains
   HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
   HIP_TRY(launch_chain2aln_kernel(B, P, (bpsw_alnreg_t*)(dout + o_regs), (int32_t*)(dout + o_cnt), (int32_t*)c->d_sw_scratch.ptr,
-                                  srt_per_wave, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), c->stream));
+                                  srt_per_wave, c->num_cu, (int*)((char*)c->d_pre.ptr + 384), c->stream));  // its own queue head: +128 belongs to ext_kernel, which expects it zero
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -754,19 +754,27 @@ __device__ void swp_pass(const int lane, const Duo& J, const int (&on)[2], const
   }
 }
 
-template <int C>
+// KL: the packed row keys (one word per step and wave, written by the booking lanes, read once by second_best) stay in LDS --
+// scratch_per_job + PK_KEY_PAD words per wave of dynamic shared memory -- instead of making a round trip through HBM, which was
+// 4.5x the kernel's compulsory traffic (profiles/pmc_traffic.json, round 1).  The launcher picks KL for windows up to
+// PK_KEYS_LDS_MAX rows (every 2x150 / 2x250 bp rescue window); longer windows keep the scratch rows in HBM.
+constexpr int PK_KEY_PAD = 128;        // steps past the last target row: pipe depth (<= 56) + group rounding + the tail lanes
+constexpr int PK_KEYS_LDS_MAX = 1536;  // rows; 4 waves x (1536 + 128) words = 26 KB per workgroup
+template <int C, bool KL>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void swp_kernel(const SwJobsDev jobs, const SwScoring sc, const int bias,
                                                                      int32_t* __restrict__ out,
                                                                      uint32_t* __restrict__ scratch,
                                                                      const int scratch_per_job,
                                                                      const SwPrepass* __restrict__ pre) {
   __shared__ uint32_t tbuf_all[WAVES_PER_BLOCK][PK_TBUF + PK_G];
+  extern __shared__ uint32_t key_rows[];
   if (pre && (pre->error != 0 || pre->max_qlen > (PK_LAST + 1) * C || ((pre->max_tlen + 63) & ~63) > scratch_per_job)) return;
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
   const int slot = uni((int)blockIdx.x * WAVES_PER_BLOCK + wave);
   uint32_t* tbuf = tbuf_all[wave];
-  uint32_t* keys = scratch + (size_t)slot * 4 * (size_t)scratch_per_job;  // packed row keys, one word per step: <= max_tlen + 70 words
+  // packed row keys, one word per step: <= max_tlen + 70 words
+  uint32_t* keys = KL ? key_rows + (size_t)wave * (size_t)(scratch_per_job + PK_KEY_PAD) : scratch + (size_t)slot * 4 * (size_t)scratch_per_job;
   const int maxScore = 255 - abs(sc.b);  // SWUtil.scala:423
   const int xtra = sc.xtra;
   const int stride = gridDim.x * WAVES_PER_BLOCK;
@@ -890,7 +898,13 @@ __global__ void ref_fetch_kernel(const uint8_t* __restrict__ pac, const long lon
 template <int C>
 hipError_t launch_pk(const SwJobsDev& jobs, const SwScoring& sc, int bias, int32_t* d_out, uint32_t* d_scratch, int per_job,
                      int blocks, hipStream_t s, const SwPrepass* pre) {
-  hipLaunchKernelGGL(swp_kernel<C>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, bias, d_out, d_scratch, per_job, pre);
+  static const bool keys_hbm = getenv("BPSW_SW_KEYS_LDS") && atoi(getenv("BPSW_SW_KEYS_LDS")) == 0;  // A/B switch
+  if (per_job <= PK_KEYS_LDS_MAX && !keys_hbm) {
+    const size_t lds = sizeof(uint32_t) * WAVES_PER_BLOCK * (size_t)(per_job + PK_KEY_PAD);
+    hipLaunchKernelGGL((swp_kernel<C, true>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, jobs, sc, bias, d_out, d_scratch, per_job, pre);
+  } else {
+    hipLaunchKernelGGL((swp_kernel<C, false>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, bias, d_out, d_scratch, per_job, pre);
+  }
   return hipGetLastError();
 }
 
