@@ -282,6 +282,7 @@ struct StreamLease {
   int device;
   hipStream_t s;
   bool pooled;
+  int slot = -1;   // index of the pooled stream
   double wait_ms;  // time spent waiting for a free stream
   explicit StreamLease(bpsw_ctx* c);
   ~StreamLease();

@@ -161,7 +161,8 @@ inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* dist) {  //
 struct Want { int64_t x; int32_t mate; };  // window index (anchor row * 4 + orientation) and the end (2k + i) whose read is aligned
 struct Scratch {
   std::vector<int64_t> reg_base, ref_base;  // per end 2k+i: first region / first anchor row
-  std::vector<int32_t> job_of;              // per window x: job index, -1 = not launched
+  std::vector<int64_t> job_x;               // launched windows, ascending within a round (round boundaries in job_round)
+  std::vector<size_t> job_round;            // first job of every round; job_x[job_round[r] .. job_round[r+1]) is sorted
   std::vector<int32_t> results;             // 7 ints per launched job
   std::vector<uint8_t> used;                // per job: consumed by the replay
   std::vector<Want> want, want_next;
@@ -234,10 +235,21 @@ bool make_region(const Group& G, const int32_t aln[7], int r, int l_ms, int64_t 
 static const int32_t kNoHit[7] = {0, -1, -1, -1, -1, -1, -1};
 inline const int32_t* result_of(Group& G, int64_t x, int l_ms) {
   if (l_ms < 1) return kNoHit;
-  const int job = G.S->job_of[(size_t)x];
-  if (job < 0) return nullptr;
-  G.S->used[(size_t)job] = 1;
-  return &G.S->results[7 * (size_t)job];
+  // the launched windows are kept sorted per round (a table over all 4 x anchors windows would have to be cleared per call):
+  // binary search, newest round first -- almost always the only one
+  const Scratch& S = *G.S;
+  for (size_t r = S.job_round.size(); r-- > 0;) {
+    const size_t lo = S.job_round[r], hi = r + 1 < S.job_round.size() ? S.job_round[r + 1] : S.job_x.size();
+    const int64_t* first = S.job_x.data() + lo;
+    const int64_t* last = S.job_x.data() + hi;
+    const int64_t* it = std::lower_bound(first, last, x);
+    if (it != last && *it == x) {
+      const size_t job = (size_t)(it - S.job_x.data());
+      G.S->used[job] = 1;
+      return &S.results[7 * job];
+    }
+  }
+  return nullptr;
 }
 
 // One anchor against the mate list.  Returns false when a needed SW result is missing (the window goes to `missing`).
@@ -402,7 +414,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
     if (loaded <= 0) return fail(BPSW_ERR_ARG, "matesw_group: ref_pool is null and no reference is loaded (bpsw_ref_load)");
     if (loaded != g->l_pac) return fail(BPSW_ERR_ARG, "matesw_group: l_pac differs from the loaded reference");
   }
-  S.job_of.assign((size_t)(4 * nref), -1);
+  S.job_x.clear(); S.job_round.clear();
   S.results.clear(); S.used.clear();
   const double t_planned = wall_ms();
 
@@ -486,7 +498,8 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       const size_t first = S.results.size() / 7;
       S.results.insert(S.results.end(), res, res + 7 * nj);
       S.used.resize(first + nj, 0);
-      for (size_t t = 0; t < nj; ++t) S.job_of[(size_t)S.want[t].x] = (int32_t)(first + t);
+      S.job_round.push_back(first);
+      for (size_t t = 0; t < nj; ++t) S.job_x.push_back(S.want[t].x);   // ascending: the first round is generated in order, later ones are sorted
       S.want.clear();
       t_pack += t_p1 - t_p0;
     }

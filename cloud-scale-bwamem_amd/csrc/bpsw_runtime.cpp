@@ -54,6 +54,7 @@ hipError_t PinnedBuffer::reserve(size_t bytes) {
   if (ptr) (void)hipHostFree(ptr);
   ptr = nullptr;
   cap = 0;
+  // (coarse-grained pinned memory, hipHostMallocNonCoherent, was tried for the zero-copy reads of the SW kernel: no difference)
   hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
   if (e == hipSuccess) cap = want;
   return e;
@@ -215,8 +216,8 @@ namespace {
 struct StreamPool {
   std::mutex mu;
   std::condition_variable cv;
-  std::vector<hipStream_t> idle;
-  int created = 0;
+  std::vector<hipStream_t> streams;
+  std::vector<int> pending;  // calls that have taken the stream and not finished waiting for their work
 };
 StreamPool& stream_pool(int device) {
   static StreamPool table[64];
@@ -230,6 +231,18 @@ int stream_pool_cap() {
   }();
   return cap;
 }
+// BPSW_STREAM_SHARE (default 1; 2 and 3 measured no better: 124-128 against 130 M reads/s, the device is the limit): how many calls may have work on one pooled stream at a time.  With 1 a stream is handed over
+// only after its holder has seen its work complete, and sits idle for the hand-over (wake-up of the waiter, its enqueue); with 2
+// the next call's copies and kernel are already queued behind the running one, in stream order, so the stream never drains
+// while callers are waiting.  The number of busy streams -- what the hardware queues limit -- is the same.
+int stream_share() {
+  static const int n = [] {
+    const char* e = getenv("BPSW_STREAM_SHARE");
+    const int v = e ? atoi(e) : 1;
+    return v < 1 ? 1 : (v > 8 ? 8 : v);
+  }();
+  return n;
+}
 }  // namespace
 
 StreamLease::StreamLease(bpsw_ctx* c) : device(c->device), s(c->stream), pooled(false), wait_ms(0.) {
@@ -239,23 +252,26 @@ StreamLease::StreamLease(bpsw_ctx* c) : device(c->device), s(c->stream), pooled(
   const double t0 = wall_ms();
   std::unique_lock<std::mutex> lk(P.mu);
   for (;;) {
-    if (!P.idle.empty()) {
-      s = P.idle.back();
-      P.idle.pop_back();
-      pooled = true;
-      break;
-    }
-    if (P.created < cap) {
+    int best = -1;
+    for (size_t k = 0; k < P.streams.size(); ++k)
+      if (best < 0 || P.pending[k] < P.pending[(size_t)best]) best = (int)k;
+    if (best >= 0 && P.pending[(size_t)best] == 0) { slot = best; break; }  // an idle stream
+    if ((int)P.streams.size() < cap) {
       hipStream_t ns = nullptr;
       if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
-        ++P.created;
-        s = ns;
-        pooled = true;
-      }  // else: fall back to the context's own stream for this call
-      break;
+        P.streams.push_back(ns);
+        P.pending.push_back(0);
+        slot = (int)P.streams.size() - 1;
+        break;
+      }
+      if (best < 0) { wait_ms = wall_ms() - t0; return; }  // no pooled stream at all: the context's own stream for this call
     }
+    if (best >= 0 && P.pending[(size_t)best] < stream_share()) { slot = best; break; }  // queue behind the least loaded stream
     P.cv.wait(lk);
   }
+  ++P.pending[(size_t)slot];
+  s = P.streams[(size_t)slot];
+  pooled = true;
   wait_ms = wall_ms() - t0;
 }
 StreamLease::~StreamLease() {
@@ -263,7 +279,7 @@ StreamLease::~StreamLease() {
   StreamPool& P = stream_pool(device);
   {
     std::lock_guard<std::mutex> lk(P.mu);
-    P.idle.push_back(s);
+    --P.pending[(size_t)slot];
   }
   P.cv.notify_one();
 }
@@ -568,7 +584,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
 #endif
     {
       ExtScoring sc = c->ext_sc;
-      if (zc_out) sc.out_stride = 16;
+      if (zc_slots) sc.out_stride = 16;
       if (side_how) {  // diagnostics: the kernel notes per side whether a shortcut or the DP produced the result
         HIP_TRY(c->d_ext_lists.reserve(2 * (size_t)n + 16));
         HIP_TRY(hipMemsetAsync(c->d_ext_lists.ptr, 0, 2 * (size_t)n, s));
