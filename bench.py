@@ -10,7 +10,7 @@ rescue.  Per pass:
     the call behind MemChainToAlignBatched.scala:175-176), host wire bytes in, host int16 results out;
   * boundary 1: one bpsw_matesw_group call per group of 4 096 pairs (the call behind native/jni_mate_sw.c:534 /
     MemSamPe.scala:2091-2092): speculation, H2D, the SW kernel, D2H, the sequential replay and sort/dedup, host arrays out.
-The calls are made by T native host threads (csrc/bpsw_feeder.cpp), one context each, the way T Spark task threads of one
+The calls are made by T = 32 native host threads (csrc/bpsw_feeder.cpp), one context each, the way T Spark task threads of one
 executor call the JNI symbols; inputs are generated up front and live in host memory, outputs land in host memory, and a
 sample of the TIMED outputs is compared with the oracle after the timed region ("verified").
 `breakdown.device_resident` keeps the round-1 figure (inputs already in HBM, asynchronous device entries, kernels only).
@@ -31,7 +31,7 @@ import time
 # The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), round robin; streams that
 # share a queue run one after the other.  Every feeder thread owns a context with its own stream.  Must be set before the
 # runtime initialises; an executor that runs several task threads wants the same.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (os.path.join(ROOT, "cloud-scale-bwamem_amd"), os.path.join(ROOT, "oracle")):
@@ -346,9 +346,9 @@ def main():
     allowed = sorted(os.sched_getaffinity(0))
     ranks_on_node = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     share = numa_cpus if numa_cpus else allowed[(local_rank % ranks_on_node)::ranks_on_node] if distributed else allowed
-    # 24: the device phases of the calls share a pool of 16 streams (bpsw_internal.h, StreamLease), and half as many threads
+    # 32: the device phases of the calls share a pool of 20 streams (bpsw_internal.h, StreamLease), and half as many threads
     # again keep it full while the others stage bytes or replay bookkeeping; more change nothing
-    n_threads = args.threads if args.threads > 0 else max(2, min(24, len(share)))
+    n_threads = args.threads if args.threads > 0 else max(2, min(32, len(share)))
     if share and (numa_cpus or distributed):
         try:
             os.sched_setaffinity(0, share)   # before the inputs are generated: first touch puts them on the GPU's node

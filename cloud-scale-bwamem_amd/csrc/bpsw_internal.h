@@ -274,9 +274,9 @@ DeviceRef& device_ref(int device);
 
 // Device streams for the blocking host-buffer entry points.  A calling thread needs a stream only for the device phase of its
 // call (H2D, kernel, D2H), not while it stages bytes or replays bookkeeping on the host; and the GPU has a fixed number of
-// hardware queues (GPU_MAX_HW_QUEUES, 16 here): more busy streams than queues makes the runtime time-slice queues and
-// throughput collapses (measured: 24 streams busy = half the rate of 16).  So the device phases of all contexts of a device
-// share a pool of BPSW_STREAM_POOL streams (default 16; 0 = every context uses its own stream): an executor may run more
+// hardware queues (GPU_MAX_HW_QUEUES): beyond about 22 busy queues throughput collapses (measured on the bench: 16 queues
+// 131, 18: 136, 20: 138, 22: 141 M reads/s, 24: 59, 32: 34).  So the device phases of all contexts of a device
+// share a pool of BPSW_STREAM_POOL streams (default 20; 0 = every context uses its own stream): an executor may run more
 // task threads than the device has queues, and their host phases overlap the others' device phases.
 struct StreamLease {
   int device;

@@ -76,8 +76,8 @@ MatRows pack_mat(const int8_t mat[25]) {
 }
 
 // The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), round robin, and streams that
-// share a queue are serialised.  The device phases of the blocking entry points run on a pool of 16 streams (StreamLease), so
-// the executor should be started with GPU_MAX_HW_QUEUES=16 in its environment (bench.py sets it before the
+// share a queue are serialised.  The device phases of the blocking entry points run on a pool of 20 streams (StreamLease), so
+// the executor should be started with GPU_MAX_HW_QUEUES=20 in its environment (bench.py sets it before the
 // runtime initialises).  The library does not set it itself: setenv from a library constructor inside a multi-threaded JVM
 // races with every getenv of the process.  24 or more queues oversubscribe the hardware and throughput collapses.
 
@@ -226,7 +226,7 @@ StreamPool& stream_pool(int device) {
 int stream_pool_cap() {
   static const int cap = [] {
     const char* e = getenv("BPSW_STREAM_POOL");
-    int v = e ? atoi(e) : 16;
+    int v = e ? atoi(e) : 20;
     return v < 0 ? 0 : (v > 64 ? 64 : v);
   }();
   return cap;
