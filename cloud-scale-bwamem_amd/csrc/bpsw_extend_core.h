@@ -291,8 +291,8 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
         return ExtRes{0, 0, 0, 0, 0, 0};
       }
     }
-    const int tsv = ts[i];  // 8 * target base, same in every lane
-    const bool isN = tsv == 32;
+    const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base, same in every lane
+    const bool isN = tsv == 32;  // wave-uniform
     h1raw -= eDel;
     const int h1 = max(0, h1raw);      // SWUtil.scala:137-138
     beg = max(beg, iv - w);            // SWUtil.scala:140-142
@@ -315,7 +315,9 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
         continue;
       }
       const bool act = rel < spanA;
-      const int sc = isN ? phi[s] : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
+      int sc;
+      if (isN) sc = phi[s];  // a scalar branch (N rows are rare), not a select on every row
+      else sc = __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
       const int araw = max(Hs[s] + sc, Es[s]);  // >= 0: E never goes below 0
       const int a = act ? araw : NEG_A;
       As[s] = a;
@@ -338,8 +340,13 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
       int hsh = wave_shr1(hl_prev, H);                             // H(i,j-1)
       if (S > 1) hl_prev = __builtin_amdgcn_readlane(H, 63);
       hsh = rel == 0u ? h1 : hsh;                                  // eh[beg].h = h1, SWUtil.scala:153
-      Hs[s] = upd ? hsh : Hs[s];
-      Es[s] = upd ? En : Es[s];
+      if (S == 1) {  // one slot: every lane is written (columns outside the band are never read before the band rewrites them, see sw_extend_il2)
+        Hs[s] = hsh;
+        Es[s] = En;
+      } else {
+        Hs[s] = upd ? hsh : Hs[s];
+        Es[s] = upd ? En : Es[s];
+      }
     }
     const int mkey = max(0, S > 1 ? carry_a : __builtin_amdgcn_readlane(scan_a, 63));  // scalar
     const int m = S == 1 ? mkey >> 6 : mkey;
@@ -483,7 +490,10 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
   const bool cont = SLIDE && in;
   int mx = vu(cont ? in->mx : h0), max_i = vu(cont ? in->max_i : -1), max_j = vu(cont ? in->max_j : -1);
   int max_ie = vu(cont ? in->max_ie : -1), gscore = vu(cont ? in->gscore : -1), max_off = vu(cont ? in->max_off : 0);
-  int beg = vu(cont ? in->beg : 0), end = vu(cont ? in->end : qLen);
+  // The band's right end lives in a vector register between rows and in a scalar register within a row.  It is wave-uniform by
+  // construction (ballots, scalar bit scans), but the compiler takes the loop-carried value for divergent and then computes the
+  // clamp, the span and every test that hangs on it with vector instructions -- on the pipe that is full.
+  int beg = vu(cont ? in->beg : 0), end_v = SLIDE ? vu(cont ? in->end : qLen) : (cont ? in->end : qLen);
   int h1raw = vu(cont ? in->h1raw : h0 - oDel);
   const int i0 = cont ? in->row : 0;
   int iv = vu(i0);
@@ -492,14 +502,19 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
   for (int i = i0; i < tLen; ++i, iv += 1) {
     if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
       const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
-      if (any_lane(U <= mx && U < gscore)) break;
+      if (SLIDE ? any_lane(U <= mx && U < gscore) : (U <= mx && U < gscore)) break;
     }
-    const int tsv = ts[i];
-    const bool isN = tsv == 32;
+    const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base: one LDS byte, the same in every lane
+    const bool isN = tsv == 32;  // wave-uniform: an N row takes a scalar branch instead of two selects per column on every row
     h1raw -= eDel;
     const int h1 = max(0, h1raw);      // SWUtil.scala:137-138
     beg = max(beg, iv - w);            // SWUtil.scala:140-142
-    end = min(min(end, iv + (w + 1)), qLen);
+    int end;  // = min(end, iv + w + 1, qLen)
+    if (SLIDE) {  // (the sliding sweep keeps the plain form: with the scalar form below its row costs 28 scalar instructions more)
+      end = min(min(end_v, iv + (w + 1)), qLen);
+    } else {      // on the scalar pipe: a C expression of these scalars is still selected as v_min3_i32
+      asm("s_min_i32 %0, %1, %2\n\ts_min_i32 %0, %0, %3" : "=&s"(end) : "s"(__builtin_amdgcn_readfirstlane(end_v)), "s"(iv + (w + 1)), "s"(qLen) : "scc");
+    }
     if (SLIDE && any_lane(end - base > 127)) {  // column `end` (written this row) lies beyond the window: move the window up
       const int nb = __builtin_amdgcn_readfirstlane(beg) & ~1;
       if (__builtin_amdgcn_readfirstlane(end) - nb > 127) {  // a band wider than the window: not for this sweep
@@ -518,17 +533,22 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
     const int rbeg = beg - base;       // the band in window coordinates
     const int span = end - beg;
     const unsigned spanA = (unsigned)max(span, 0);
-    const unsigned spanU = (unsigned)max(span + 1, 0);
 
-    bool upd[2], act[2];
+    bool act[2];
     unsigned rel[2];
-    int a[2], Pg[2], akey[2];
+    int a[2], Pg[2], akey[2], scv[2];
+    if (isN) {
+      scv[0] = __builtin_amdgcn_sbfe(phi2, 0u, 8u);
+      scv[1] = __builtin_amdgcn_sbfe(phi2, 8u, 8u);
+    } else {
+      scv[0] = __builtin_amdgcn_sbfe(plo[0], (unsigned)tsv, 8u);
+      scv[1] = __builtin_amdgcn_sbfe(plo[1], (unsigned)tsv, 8u);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       rel[s] = (unsigned)(2 * lane + s - rbeg);
-      upd[s] = rel[s] < spanU;
       act[s] = rel[s] < spanA;
-      const int sc = isN ? __builtin_amdgcn_sbfe(phi2, 8u * s, 8u) : __builtin_amdgcn_sbfe(plo[s], (unsigned)tsv, 8u);
+      const int sc = scv[s];
       const int araw = max(Hs[s] + sc, Es[s]);  // >= 0: E never goes below 0
       a[s] = act[s] ? araw : NEG_A;
       akey[s] = (a[s] << 7) | (2 * lane + s);  // the row maximum and its LAST column in one scan (NEG_A << 7 stays far below 0)
@@ -553,16 +573,19 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       hsh[s] = rel[s] == 0u ? h1 : hsh[s];  // eh[beg].h = h1, SWUtil.scala:153
-      Hs[s] = upd[s] ? hsh[s] : Hs[s];
-      Es[s] = upd[s] ? En[s] : Es[s];
+      // Written in EVERY lane, not only for the columns beg..end the reference writes: a column outside the band is never read
+      // again before the band has written it -- beg never decreases, and a column that enters on the right was eh[end] of the row
+      // before (SWUtil.scala:174-175, 202-214: the new end is at most the old end + 1) -- so what the other lanes hold is free.
+      Hs[s] = hsh[s];
+      Es[s] = En[s];
     }
     const int mkey = max(0, __builtin_amdgcn_readlane(scan_a, 63));  // scalar
     const int m = mkey >> 7;
 
     // SWUtil.scala:177-182: j after the column loop is end (or beg for an empty band); h1 there is eh[end].h
-    if (any_lane((span > 0 ? end : beg) == qLen)) {
+    if (SLIDE ? any_lane((span > 0 ? end : beg) == qLen) : (span > 0 ? end : beg) == qLen) {
       int hlast = h1;
-      if (any_lane(span > 0)) {
+      if (SLIDE ? any_lane(span > 0) : span > 0) {
         const int e = __builtin_amdgcn_readfirstlane(end) - __builtin_amdgcn_readfirstlane(base);
         const int he = __builtin_amdgcn_readlane(Hs[0], e >> 1), ho = __builtin_amdgcn_readlane(Hs[1], e >> 1);
         hlast = (e & 1) ? ho : he;
@@ -603,6 +626,8 @@ __device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, 
       beg = cl >= 0 ? vu(base + cl + 2) : nb0;
       end = cr < (1 << 20) ? vu(base + cr + 1) : end + 1;
     }
+    if (SLIDE) end_v = end;
+    else asm volatile("v_mov_b32 %0, %1" : "=v"(end_v) : "s"(end));
   }
   ExtRes r;
   r.max = __builtin_amdgcn_readfirstlane(mx);
