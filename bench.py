@@ -437,13 +437,15 @@ def main():
     dominant = "extend" if st["ext_kernel_ms"] >= st["sw_kernel_ms"] else "swalign2"
     dom_bytes, dom_ms = (ext_bytes, ext_avg_ms) if dominant == "extend" else (sw_bytes, sw_avg_ms)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None
+    traffic = traffic_x2 = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from rocprofv3 --pmc passes
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get(dominant)
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get(dominant)
+            traffic_x2 = pmc.get("detail", {}).get(dominant, {}).get("fetch_size_x2_plus_write_size")
         except Exception:
-            traffic = None
+            traffic = traffic_x2 = None
     host_ms = {k: {"mean": round(float(np.mean(v)), 4), "p50": round(float(np.median(v)), 4), "max": round(float(np.max(v)), 4)} if v else None
                for k, v in call_ms.items()}
     pcie_bytes_per_step = passes * (sum(int(w.size) for w in wires) + 20 * sum(ntasks))   # boundary 2 both ways; boundary 1 below
@@ -506,7 +508,9 @@ def main():
                    "parallelism": f"partition->device x{world} (no collective)", "input_generation_s": round(t_gen, 1)},
         "verified": verified,
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_2xfetch_plus_write": traffic_x2,
+                     "traffic_note": "profiles/pmc_traffic.json, per launch: L2->fabric read requests by their size (FETCH_SIZE tallies each at 64 B) + "
+                                     "WRITE_SIZE; the second figure is the blanket 2*FETCH_SIZE + WRITE_SIZE",
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                      "note": "launch duration = HIP events on the launch stream inside the library, averaged over the timed region; launches of "
                              "different host threads overlap on the device, so this is the time a launch spends sharing the GPU"},

@@ -50,7 +50,9 @@ __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xff
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
 
 #ifndef BPSW_EXT_WAVES_PER_SIMD
-#define BPSW_EXT_WAVES_PER_SIMD 6  // register budget: 80 VGPRs, no spills with the scalar row control
+// register budget.  Five waves per SIMD: 96 VGPRs and no scratch.  Six (80 VGPRs) ran the bench step at the same rate, but three
+// dwords per lane spilled -- one scratch store per task, 1.4 MB of the launch's 2.4 MB of WRITE_SIZE (tools/pmc_traffic_quick.sh).
+#define BPSW_EXT_WAVES_PER_SIMD 5
 #endif
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,

@@ -109,6 +109,9 @@ struct SwJobsDev {  // all device pointers
   const uint8_t* t_pool;          // nullptr: windows are coordinates (t_off) into the 2-bit reference below
   const uint8_t* pac = nullptr;
   long long l_pac = 0;
+  // optional: the same table as 32-byte records {q_off, t_off (int64), q_len, t_len, q_rev, 0 (int32)} -- what the packed kernel
+  // reads when the table sits in pinned host memory: one 64-byte request per pair of jobs instead of five
+  const uint32_t* packed = nullptr;
 };
 
 struct SwPrepass {
@@ -317,7 +320,7 @@ int run_sw_jobs_host(bpsw_ctx* c, const bpsw_opt_t* opt, const bpsw_sw_jobs_t* j
 // The caller is responsible for what run_sw_jobs_host validates (1 <= q_len, sequences inside their pools / the reference).
 struct SwStage {
   int n;
-  size_t o_qlen, o_tlen, o_qoff, o_toff, o_qrev, o_qpool, o_tpool, total, q_pool_bytes, t_pool_bytes;
+  size_t o_qlen, o_tlen, o_qoff, o_toff, o_qrev, o_qpool, o_tpool, o_packed, total, q_pool_bytes, t_pool_bytes;
   uint8_t* base;
 };
 int sw_stage_begin(bpsw_ctx* c, int n, size_t q_pool_bytes, size_t t_pool_bytes, SwStage* st);

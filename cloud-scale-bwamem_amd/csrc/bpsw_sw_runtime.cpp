@@ -53,7 +53,8 @@ int sw_stage_begin(bpsw_ctx* c, int n, size_t q_pool_bytes, size_t t_pool_bytes,
   st->o_qlen = 0; st->o_tlen = align16(st->o_qlen + 4 * (size_t)n); st->o_qoff = align16(st->o_tlen + 4 * (size_t)n);
   st->o_toff = align16(st->o_qoff + 8 * (size_t)n); st->o_qrev = align16(st->o_toff + 8 * (size_t)n);
   st->o_qpool = align16(st->o_qrev + (size_t)n); st->o_tpool = align16(st->o_qpool + q_pool_bytes);
-  st->total = align16(st->o_tpool + t_pool_bytes);
+  st->o_packed = (st->o_tpool + t_pool_bytes + 63) & ~(size_t)63;  // job records for the packed kernel (sw_stage_run)
+  st->total = align16(st->o_packed + 32 * (size_t)n);
   HIP_TRY(c->h_stage_in.reserve(st->total));
   HIP_TRY(c->h_stage_out.reserve(28 * (size_t)n));
   st->base = (uint8_t*)c->h_stage_in.ptr;
@@ -88,6 +89,17 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
   dev.q_off = (const int64_t*)(d + st.o_qoff); dev.t_off = (const int64_t*)(d + st.o_toff);
   dev.q_rev = d + st.o_qrev; dev.q_pool = d + st.o_qpool; dev.t_pool = pac_mode ? nullptr : d + st.o_tpool;
   dev.pac = d_pac; dev.l_pac = l_pac;
+  {  // the table once more as 32-byte records (SwJobsDev::packed)
+    const int32_t* ql = (const int32_t*)(h + st.o_qlen); const int32_t* tl = (const int32_t*)(h + st.o_tlen);
+    const int64_t* qo = (const int64_t*)(h + st.o_qoff); const int64_t* to = (const int64_t*)(h + st.o_toff);
+    const uint8_t* qr = h + st.o_qrev;
+    uint32_t* rec = (uint32_t*)(h + st.o_packed);
+    for (int i = 0; i < n; ++i, rec += 8) {
+      memcpy(rec, qo + i, 8); memcpy(rec + 2, to + i, 8);
+      rec[4] = (uint32_t)ql[i]; rec[5] = (uint32_t)tl[i]; rec[6] = qr[i]; rec[7] = 0;
+    }
+    dev.packed = (const uint32_t*)(d + st.o_packed);
+  }
   {
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
     hipStream_t s = lease.s;

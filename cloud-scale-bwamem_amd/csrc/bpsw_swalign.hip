@@ -758,6 +758,7 @@ __device__ void swp_pass(const int lane, const Duo& J, const int (&on)[2], const
 // scratch_per_job + PK_KEY_PAD words per wave of dynamic shared memory -- instead of making a round trip through HBM, which was
 // 4.5x the kernel's compulsory traffic (profiles/pmc_traffic.json, round 1).  The launcher picks KL for windows up to
 // PK_KEYS_LDS_MAX rows (every 2x150 / 2x250 bp rescue window); longer windows keep the scratch rows in HBM.
+constexpr int PK_MATE_LDS = 320;       // bytes per staged mate: (PK_LAST + 1) * C <= 285 columns for C <= 5
 constexpr int PK_KEY_PAD = 128;        // steps past the last target row: pipe depth (<= 56) + group rounding + the tail lanes
 constexpr int PK_KEYS_LDS_MAX = 1536;  // rows; 4 waves x (1536 + 128) words = 26 KB per workgroup
 template <int C, bool KL>
@@ -767,6 +768,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void swp_kernel(const SwJobsD
                                                                      const int scratch_per_job,
                                                                      const SwPrepass* __restrict__ pre) {
   __shared__ uint32_t tbuf_all[WAVES_PER_BLOCK][PK_TBUF + PK_G];
+  __shared__ uint8_t mate_all[WAVES_PER_BLOCK][2][PK_MATE_LDS];
   extern __shared__ uint32_t key_rows[];
   if (pre && (pre->error != 0 || pre->max_qlen > (PK_LAST + 1) * C || ((pre->max_tlen + 63) & ~63) > scratch_per_job)) return;
   const int lane = threadIdx.x & 63;
@@ -785,21 +787,42 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void swp_kernel(const SwJobsD
   for (int duo = slot; duo < nduo; duo += stride) {
     Duo J;
     int job[2], on[2], qCols[2], zero2[2] = {0, 0}, stop1[2], D[2];
+    // both job records with one load when the table came as records (in the host path it sits in pinned host memory, where
+    // every load instruction is a PCIe request of its own): lanes 0-7 hold job 2*duo, lanes 8-15 job 2*duo + 1
+    uint32_t recw = 0;
+    if (jobs.packed && lane < 16 && 2 * duo + (lane >> 3) < jobs.n) recw = jobs.packed[16 * (size_t)duo + lane];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       job[g] = 2 * duo + g;
       on[g] = job[g] < jobs.n ? 1 : 0;
       const int jj = on[g] ? job[g] : 0;
-      J.qLenRaw[g] = uni(jobs.q_len[jj]);
-      J.tLen[g] = uni(jobs.t_len[jj]);
-      J.qrev[g] = uni((int)jobs.q_rev[jj]);
-      J.q[g] = jobs.q_pool + jobs.q_off[jj];
-      const long long toff = jobs.t_off[jj];
+      long long qoff, toff;
+      if (jobs.packed) {
+        const auto field = [&](const int k) { return (unsigned)__builtin_amdgcn_readlane((int)recw, 8 * g + k); };
+        qoff = (long long)(((unsigned long long)field(1) << 32) | field(0));
+        toff = (long long)(((unsigned long long)field(3) << 32) | field(2));
+        J.qLenRaw[g] = (int)field(4); J.tLen[g] = (int)field(5); J.qrev[g] = (int)field(6);
+      } else {
+        J.qLenRaw[g] = uni(jobs.q_len[jj]);
+        J.tLen[g] = uni(jobs.t_len[jj]);
+        J.qrev[g] = uni((int)jobs.q_rev[jj]);
+        qoff = jobs.q_off[jj];
+        toff = jobs.t_off[jj];
+      }
+      // the mate goes to LDS once, 64 consecutive bytes per load: both passes build their column profiles from it (they used
+      // to read it from the pool byte by strided byte, C loads per pass over the same lines)
+      uint8_t* mate = mate_all[wave][g];
+      const uint8_t* src = jobs.q_pool + qoff;
+      const int ncopy = on[g] ? min(J.qLenRaw[g], PK_MATE_LDS) : 0;
+      for (int k = lane; k < ncopy; k += 64) mate[k] = src[k];
+      J.q[g] = mate;
       J.tbytes[g] = jobs.t_pool ? jobs.t_pool + toff : nullptr;
       J.rb[g] = toff;
       qCols[g] = J.qLenRaw[g];
       stop1[g] = min(endScore0, maxScore);  // SWUtil.scala:537
     }
+    __builtin_amdgcn_wave_barrier();
     PkRes f[2];
     swp_pass<C>(lane, J, on, qCols, false, zero2, zero2, jobs.pac, jobs.l_pac, sc, bias, stop1, tbuf, keys, D, f);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the keys written by the tail lanes -> all lanes
