@@ -26,7 +26,7 @@ KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
 # every symbol include/bpsw.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
     "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_device_slots", "bpsw_device_for_partition", "bpsw_last_error", "bpsw_version",
-    "bpsw_set_ext_scoring", "bpsw_set_ext_shortcuts", "bpsw_extend_batch", "bpsw_extend_batch_classify", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack",
+    "bpsw_set_ext_scoring", "bpsw_set_ext_shortcuts", "bpsw_extend_batch", "bpsw_extend_batch_classify", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack", "bpsw_wire_coords_size", "bpsw_wire_coords_pack",
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
@@ -78,6 +78,13 @@ class ExtTasks(C.Structure):  # bpsw_ext_tasks_t
                [(n, C.c_void_p) for n in ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "left_q_off",
                                           "left_r_off", "right_q_off", "right_r_off", "reg_score", "q_beg", "h0", "idx",
                                           "pool")]
+
+
+class ExtCoordTasks(C.Structure):  # bpsw_ext_coord_tasks_t
+    _fields_ = [("n", C.c_int32)] + [(n, C.c_int32) for n in ("o_del", "e_del", "o_ins", "e_ins", "pen_clip5",
+                                                                "pen_clip3", "w", "mat_max")] + \
+               [(n, C.c_void_p) for n in ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "left_q_off", "right_q_off",
+                                          "reg_score", "q_beg", "h0", "idx", "seed_len", "seed_rbeg", "pool")]
 
 
 class SwJobs(C.Structure):  # bpsw_sw_jobs_t
@@ -152,6 +159,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_wire_size.argtypes = [C.POINTER(ExtTasks)]
     lib.bpsw_wire_size.restype = C.c_size_t
     lib.bpsw_wire_pack.argtypes = [C.POINTER(ExtTasks), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.bpsw_wire_coords_size.argtypes = [C.POINTER(ExtCoordTasks)]
+    lib.bpsw_wire_coords_size.restype = C.c_size_t
+    lib.bpsw_wire_coords_pack.argtypes = [C.POINTER(ExtCoordTasks), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.bpsw_opt_default.argtypes = [C.POINTER(Opt)]
     lib.bpsw_opt_default.restype = None
     lib.bpsw_swalign2_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(SwJobs), C.c_void_p]
@@ -257,6 +267,64 @@ class ExtTaskSoA:
         assert self.pool.dtype == np.uint8
         t.pool = self.pool.ctypes.data
         return t
+
+
+@dataclass
+class ExtCoordTaskSoA:
+    """bpsw_ext_coord_tasks_t: ExtParam without the target flanks, which the seed's coordinates name."""
+    left_qlen: np.ndarray
+    left_rlen: np.ndarray
+    right_qlen: np.ndarray
+    right_rlen: np.ndarray
+    left_q_off: np.ndarray
+    right_q_off: np.ndarray
+    reg_score: np.ndarray
+    q_beg: np.ndarray
+    h0: np.ndarray
+    idx: np.ndarray
+    seed_len: np.ndarray
+    seed_rbeg: np.ndarray
+    pool: np.ndarray
+    o_del: int = 6
+    e_del: int = 1
+    o_ins: int = 6
+    e_ins: int = 1
+    pen_clip5: int = 5
+    pen_clip3: int = 5
+    w: int = 100
+    mat_max: int = 1
+
+    @property
+    def n(self) -> int:
+        return int(self.left_qlen.shape[0])
+
+    def as_struct(self) -> ExtCoordTasks:
+        t = ExtCoordTasks()
+        t.n = self.n
+        for f in ("o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "w", "mat_max"):
+            setattr(t, f, int(getattr(self, f)))
+        for f in ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "reg_score", "q_beg", "h0", "idx", "seed_len"):
+            a = getattr(self, f)
+            assert a.dtype == np.int32 and a.flags.c_contiguous
+            setattr(t, f, a.ctypes.data)
+        for f in ("left_q_off", "right_q_off", "seed_rbeg"):
+            a = getattr(self, f)
+            assert a.dtype == np.int64 and a.flags.c_contiguous
+            setattr(t, f, a.ctypes.data)
+        assert self.pool.dtype == np.uint8
+        t.pool = self.pool.ctypes.data
+        return t
+
+
+def wire_coords_pack(tasks: ExtCoordTaskSoA) -> np.ndarray:
+    """A coordinate batch (wire format 2, include/bpsw.h) for bpsw_extend_batch / swExtendFPGAJNI."""
+    lib = load_library()
+    st = tasks.as_struct()
+    size = lib.bpsw_wire_coords_size(C.byref(st))
+    buf = np.zeros(size, dtype=np.uint8)
+    used = C.c_size_t(0)
+    _chk(lib, lib.bpsw_wire_coords_pack(C.byref(st), _ptr(buf), size, C.byref(used)), "bpsw_wire_coords_pack")
+    return buf[: used.value]
 
 
 def wire_pack(tasks: ExtTaskSoA) -> np.ndarray:

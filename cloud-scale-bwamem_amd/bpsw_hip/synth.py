@@ -379,6 +379,57 @@ def read_chains(n_reads: int, ref_bases: np.ndarray, l_pac: int, read_len: int =
                          seed_rbeg=np.array(s_rb, np.int64), seed_qbeg=np.array(s_qb, np.int32), seed_len=np.array(s_len, np.int32))
 
 
+def coord_ext_tasks(chains, ref_bases: np.ndarray, a: int = 1, w: int = 100, seed: int = CONFIG_SEED_BASE + 10, pad_max: int = 40):
+    """Extension tasks for the seeds of `read_chains` output, twice: as a coordinate batch (ExtCoordTaskSoA: query flanks +
+    the seed's coordinates) and as the byte tasks the Scala driver builds for the same seeds (ExtTaskSoA: leftRs / rightRs
+    copied out of bnsGetSeq's window, MemChainToAlignBatched.scala:500-545).  The window around a seed is the query flank plus
+    calMaxGap-like slack of random size, clipped to the seed's strand as getMaxSpan does (:654-677)."""
+    from . import ExtCoordTaskSoA, ExtTaskSoA
+    rng = np.random.default_rng(seed)
+    l_pac = int(chains.l_pac)
+    lq_a, lr_a, rq_a, rr_a, lqo, rqo, lro, rro, sc_a, qb_a, h0_a, idx_a, sl_a, srb_a = ([] for _ in range(14))
+    pool, at = [], 0
+
+    def add(seq):
+        nonlocal at
+        off = at
+        pool.append(np.asarray(seq, np.uint8)); at += len(seq)
+        return off
+    s_at = 0
+    ch_at = 0
+    for r in range(len(chains.read_len)):
+        L = int(chains.read_len[r])
+        read = chains.read_pool[int(chains.read_off[r]): int(chains.read_off[r]) + L]
+        for _ in range(int(chains.chain_cnt[r])):
+            ns = int(chains.seed_cnt[ch_at]); ch_at += 1
+            for k in range(ns):
+                rb, qb, ln = int(chains.seed_rbeg[s_at + k]), int(chains.seed_qbeg[s_at + k]), int(chains.seed_len[s_at + k])
+                lo_s, hi_s = (0, l_pac) if rb < l_pac else (l_pac, 2 * l_pac)
+                lq, rq = qb, L - (qb + ln)
+                lr = min(lq + int(rng.integers(0, pad_max + 1)), rb - lo_s) if lq else 0
+                rr = min(rq + int(rng.integers(0, pad_max + 1)), hi_s - (rb + ln)) if rq else 0
+                if rng.random() < 0.05:
+                    lr = min(lr, max(0, lq - 3))   # a target flank shorter than the query flank
+                lwin = window_bases(ref_bases, l_pac, rb - lr, rb)[::-1] if lr else np.zeros(0, np.uint8)
+                rwin = window_bases(ref_bases, l_pac, rb + ln, rb + ln + rr) if rr else np.zeros(0, np.uint8)
+                lq_a.append(lq); lr_a.append(lr); rq_a.append(rq); rr_a.append(rr)
+                lqo.append(add(read[:qb][::-1])); rqo.append(add(read[qb + ln:]))
+                lro.append(add(lwin)); rro.append(add(rwin))
+                sc_a.append(ln * a); qb_a.append(qb); h0_a.append(ln * a); idx_a.append(len(idx_a) & 0x7fff)
+                sl_a.append(ln); srb_a.append(rb)
+            s_at += ns
+    i32 = lambda v: np.array(v, np.int32)  # noqa: E731
+    i64 = lambda v: np.array(v, np.int64)  # noqa: E731
+    poolv = np.concatenate(pool + [np.zeros(16, np.uint8)])
+    co = ExtCoordTaskSoA(left_qlen=i32(lq_a), left_rlen=i32(lr_a), right_qlen=i32(rq_a), right_rlen=i32(rr_a), left_q_off=i64(lqo),
+                         right_q_off=i64(rqo), reg_score=i32(sc_a), q_beg=i32(qb_a), h0=i32(h0_a), idx=i32(idx_a), seed_len=i32(sl_a),
+                         seed_rbeg=i64(srb_a), pool=poolv, w=w, mat_max=a)
+    by = ExtTaskSoA(left_qlen=i32(lq_a), left_rlen=i32(lr_a), right_qlen=i32(rq_a), right_rlen=i32(rr_a), left_q_off=i64(lqo),
+                    left_r_off=i64(lro), right_q_off=i64(rqo), right_r_off=i64(rro), reg_score=i32(sc_a), q_beg=i32(qb_a), h0=i32(h0_a),
+                    idx=i32(idx_a), pool=poolv, w=w, mat_max=a)
+    return co, by
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # worker2's tail (SURVEY.md 8f.1 / 8f.4): pairs with their seed chains over a multi-contig reference
 def contig_reference(contig_lens, seed: int = CONFIG_SEED_BASE + 78, dup_len: int = 1500):

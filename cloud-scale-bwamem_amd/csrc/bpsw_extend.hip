@@ -25,24 +25,49 @@ namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
 
+// target sources of one side: the nibble stream of a wire batch, or the device-resident 2-bit reference (coordinate batches)
+struct NibbleT {
+  const uint32_t* __restrict__ words;
+  int rStart;
+  __device__ __forceinline__ int operator()(int i) const { return nibble_at(words, rStart + i); }
+};
+struct PacT {  // bnsGetSeq, util/BNTSeqUtil.scala:56-73: positions >= l_pac are the reverse strand, complemented
+  const uint8_t* __restrict__ pac;
+  long long l_pac, pos;
+  int step;  // -1: the left flank walks backwards from the seed (MemChainToAlignBatched.scala:511-517)
+  __device__ __forceinline__ int operator()(int i) const {
+    const long long p = pos + (long long)step * i;
+    const bool rev = p >= l_pac;
+    const long long k = rev ? (l_pac << 1) - 1 - p : p;
+    const int b = (pac[k >> 2] >> ((~k & 3) << 1)) & 3;
+    return rev ? 3 - b : b;
+  }
+};
+struct LdsShiftT {  // a target already staged as 8*code bytes
+  const uint8_t* __restrict__ ts;
+  __device__ __forceinline__ int operator()(int i) const { return (int)(ts[i] >> 3); }
+};
+
 // stage the target of one side in LDS as 8*code bytes (the shift the register path feeds to v_bfe)
-__device__ void load_target_shifts(const int lane, const uint32_t* __restrict__ words, const int rStart, const int rLen,
-                                   uint8_t* __restrict__ ts) {
+template <class T>
+__device__ void load_target_shifts(const int lane, const T& tsrc, const int rLen, uint8_t* __restrict__ ts) {
   __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < rLen; i += 64) ts[i] = (uint8_t)(8 * nibble_at(words, rStart + i));
+  for (int i = lane; i < rLen; i += 64) ts[i] = (uint8_t)(8 * tsrc(i));
   __builtin_amdgcn_wave_barrier();
 }
 
 // Unpack one side of a task into LDS: the 5 x qLen query profile and the target bytes.
+template <class T>
 __device__ void load_side(const int lane, const uint32_t* __restrict__ words, const int qStart, const int qLen,
-                          const int rStart, const int rLen, const MatRows& mat, int8_t* __restrict__ qp,
+                          const T& tsrc, const int rLen, const MatRows& mat, int8_t* __restrict__ qp,
                           uint8_t* __restrict__ ts) {
+  __builtin_amdgcn_wave_barrier();
   for (int j = lane; j < qLen; j += 64) {
     const int c = nibble_at(words, qStart + j);
 #pragma unroll
     for (int k = 0; k < 5; ++k) qp[k * qLen + j] = (int8_t)((mat.row[k] >> (8 * c)) & 0xff);
   }
-  for (int i = lane; i < rLen; i += 64) ts[i] = (uint8_t)nibble_at(words, rStart + i);
+  for (int i = lane; i < rLen; i += 64) ts[i] = (uint8_t)tsrc(i);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -54,6 +79,9 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 // dwords per lane spilled -- one scratch store per task, 1.4 MB of the launch's 2.4 MB of WRITE_SIZE (tools/pmc_traffic_quick.sh).
 #define BPSW_EXT_WAVES_PER_SIMD 5
 #endif
+// COORD: a coordinate batch (include/bpsw.h, "wire format 2") -- 40-byte task records, query flanks only, the target flanks are
+// read from the device-resident reference (bnsGetSeq of MemChainToAlignBatched.scala:363 moves to the device).
+template <bool COORD>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
@@ -112,8 +140,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
     }
     const int task = task_list ? uni(task_list[ticket]) : ticket;  // n_tasks counts the entries of task_list when given
     ++ticket;
-    const uint32_t* rec = wire + 8 + 8 * (size_t)task;  // MemChainToAlignBatched.scala:95-117
+    const uint32_t* rec = wire + 8 + (COORD ? 10 : 8) * (size_t)task;  // MemChainToAlignBatched.scala:95-117
     const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
+    // coordinate batch: the seed's start in the doubled reference and its length (in the slot of the redundant 16-bit idx)
+    const long long seedRb = COORD ? (long long)(((unsigned long long)uni((int)rec[9]) << 32) | (unsigned)uni((int)rec[8])) : 0ll;
+    const int seedLen = COORD ? uni(hi16(r4)) : 0;
     const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
     const uint32_t* words = wire + (size_t)uni((int)rec[2]);
     const int regScore0 = uni(lo16(r3)), qBeg = uni(hi16(r3)), h0 = uni(lo16(r4));
@@ -136,20 +167,33 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
       // register path: needs one lane per column 0..qLen and oeIns > 0 (see sw_extend_reg)
       const bool reg_path = qLen <= 255 && oIns + eIns > 0;
       ExtRes r = {0, 0, 0, 0, 0, 0};
+      const NibbleT tnib = {words, rStart};
+      const PacT tpac = {sc.pac, sc.l_pac, side ? seedRb + seedLen : seedRb - 1, side ? 1 : -1};
+      // Row i needs i - w <= qLen, so at most qLen + w + 1 rows of a side are ever swept (the row at i = qLen + w has an empty
+      // band and ends the call): a coordinate batch stages only those, before the shortcuts, which then read LDS too.
+      const int tstage = COORD ? min(rLen, qLen + (wBand << 1) + 2) : rLen;
+      if (COORD && reg_path) load_target_shifts(lane, tpac, tstage, ts);
       // near-exact flank: the DP result is known (flank_closed_form); the retry loop would stop after its first try
-      const bool exact = exact_a > 0 &&
-                         ((rLen >= qLen && flank_closed_form(lane, qLen, rLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat,
-                                                             hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, sc.certify, &r)) ||
-                          (sc.certify >= 3 && flank_start_gap_form(lane, qLen, rLen, NibbleQ{words, qStart}, NibbleQ{words, rStart}, sc.mat,
-                                                                   hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
+      const auto shortcuts = [&](const auto& tsrc, const int tl) {
+        return exact_a > 0 &&
+               ((rLen >= qLen && tl >= qLen && flank_closed_form(lane, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
+                                                                hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, sc.certify, &r)) ||
+                (sc.certify >= 3 && flank_start_gap_form(lane, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
+                                                         hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
+      };
+      bool exact;
+      if constexpr (COORD) exact = reg_path && shortcuts(LdsShiftT{ts}, tstage);
+      else exact = shortcuts(tnib, rLen);
       if (sc.side_how && lane == 0) sc.side_how[2 * (size_t)task + side] = exact ? 1 : 2;  // diagnostics only
       if (exact) {
         aw[side] = wBand;
         regScore = r.max;
       } else if (reg_path) {
-        load_target_shifts(lane, words, rStart, rLen, ts);
+        if (!COORD) load_target_shifts(lane, tnib, rLen, ts);
+      } else if constexpr (COORD) {
+        load_side(lane, words, qStart, qLen, tpac, tstage, sc.mat, qp, ts);
       } else {
-        load_side(lane, words, qStart, qLen, rStart, rLen, sc.mat, qp, ts);
+        load_side(lane, words, qStart, qLen, tnib, rLen, sc.mat, qp, ts);
       }
       for (int i = 0; i < 2 && !exact; ++i) {  // MAX_BAND_TRY
         const int prev = regScore;
@@ -160,9 +204,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
           // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
           int oInsT = oIns, eInsT = eIns;
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
-          r = sw_extend_reg_any(lane, qLen, rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, eh);
+          r = sw_extend_reg_any(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, eh);
         } else {
-          r = sw_extend_wave(lane, qLen, rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
+          r = sw_extend_wave(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
         }
         regScore = r.max;
         if (regScore == prev || r.max_off < (aw[side] >> 1) + (aw[side] >> 2)) break;
@@ -203,6 +247,7 @@ __global__ void ext_prepass_kernel(const uint32_t* __restrict__ wire, const unsi
     const int oDel = (int8_t)(hdr0 & 0xff), eDel = (int8_t)((hdr0 >> 8) & 0xff);
     if (oIns < 0 || eIns < 1 || oDel < 0 || eDel < 1) err = 2;  // the prefix-scan form of F needs oIns >= 0; e = 0 divides by zero in SWUtil.scala:110-115
     if ((int8_t)((wire[1] >> 16) & 0xff) < 0) err = 2;         // band width is a signed byte
+    if ((wire[1] >> 24) != 0) err = 5;                          // header byte 7: a coordinate batch (format 2) goes through bpsw_extend_batch
     pre->reserved = oIns + eIns > 0 ? 1 : 0;                    // quad-task kernels are usable
   }
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {
@@ -243,6 +288,8 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check, bool counter_zeroed) {
   if (n_tasks <= 0) return hipSuccess;
+  const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
+  const void* fn = coord ? reinterpret_cast<const void*>(ext_kernel<true>) : reinterpret_cast<const void*>(ext_kernel<false>);
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
   rcap = (rcap + 63) & ~63;
@@ -250,11 +297,12 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   const size_t lds = per_wave * WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device
-  static std::atomic<size_t> attr_set[64];
+  static std::atomic<size_t> attr_set_v[2][64];
+  std::atomic<size_t>* attr_set = attr_set_v[coord ? 1 : 0];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (lds > 64 * 1024 && lds > attr_set[dev].load(std::memory_order_relaxed)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ext_kernel),
+    hipError_t e = hipFuncSetAttribute(fn,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     size_t seen = attr_set[dev].load(std::memory_order_relaxed);
@@ -280,8 +328,12 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   // tasks per dequeue: 0 = guided (see the kernel), n > 0 = fixed chunks of n (1 balances a lone launch best)
   static const int chunk = [] { const int v = getenv("BPSW_EXT_CHUNK") ? atoi(getenv("BPSW_EXT_CHUNK")) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();  // 0: guided
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
-  hipLaunchKernelGGL(ext_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
-                     rcap, (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check);
+  if (coord)
+    hipLaunchKernelGGL(ext_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
+                       rcap, (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check);
+  else
+    hipLaunchKernelGGL(ext_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
+                       rcap, (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check);
   return hipGetLastError();
 }
 

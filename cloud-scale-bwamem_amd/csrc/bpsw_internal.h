@@ -34,6 +34,9 @@ struct ExtScoring {
   int out_stride;     // int16 units between the result records of consecutive tasks: 10 (the caller's layout) or 16 (one 32-byte
                       // slot per task in the pinned staging buffer: a record never straddles two write sectors)
   uint8_t* side_how;  // optional (bpsw_extend_batch_classify): per task and side, 1 = resolved by an exact shortcut, 2 = DP swept
+  // coordinate batches only (wire format 2, include/bpsw.h): the device-resident 2-bit reference the target flanks come from
+  const uint8_t* pac;
+  long long l_pac;
 };
 bool certify_enabled();
 int certify_level(const int8_t mat[25]);  // 0 off, 1 single-gap certificate, 2 also the two-gap-open extension

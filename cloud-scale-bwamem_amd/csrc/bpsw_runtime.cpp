@@ -357,6 +357,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   c->ext_sc.mat_max = 1;
   c->ext_sc.side_how = nullptr;
   c->ext_sc.out_stride = 10;
+  c->ext_sc.pac = nullptr; c->ext_sc.l_pac = 0;
   apply_shortcuts(c->shortcut_mask, c->ext_mat, &c->ext_sc.exact_a, &c->ext_sc.certify, &c->ext_sc.tail_bound);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   // the events the blocking entry points wait on put the calling thread to sleep (interrupt-driven) instead of spinning:
@@ -501,30 +502,52 @@ static inline int rd32(const uint8_t* b, size_t at) {
 }
 
 // Host-side twin of ext_prepass_kernel: validates the table, returns the LDS capacities.
-static int scan_wire(const uint8_t* wire, size_t bytes, int* n_out, int* maxq, int* maxr) {
+// Validates a wire batch on the host.  *coord: the batch is a coordinate batch (wire format 2: byte 7 of the header is 2, 40-byte
+// records, query flanks only); l_pac is the length of the loaded reference (0: none), needed to check its coordinates.
+static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_out, int* maxq, int* maxr, bool* coord) {
   if (!wire || bytes < 32 || (bytes & 3)) return fail(BPSW_ERR_ARG, "extend: wire batch shorter than its header or not word sized");
   const int n = rd32(wire, 8);
-  if (n < 0 || 32 + 32 * (size_t)n > bytes) return fail(BPSW_ERR_ARG, "extend: task table exceeds the buffer");
+  const int fmt = wire[7];
+  if (fmt != 0 && fmt != BPSW_WIRE_COORDS) return fail(BPSW_ERR_ARG, "extend: unknown wire format (header byte 7)");
+  const bool co = fmt == BPSW_WIRE_COORDS;
+  const size_t rec_bytes = co ? 40 : 32;
+  if (n < 0 || 32 + rec_bytes * (size_t)n > bytes) return fail(BPSW_ERR_ARG, "extend: task table exceeds the buffer");
   if ((int8_t)wire[0] < 0 || (int8_t)wire[1] < 1 || (int8_t)wire[2] < 0 || (int8_t)wire[3] < 1)
     return fail(BPSW_ERR_ARG, "extend: gap opens must be >= 0 and gap extensions >= 1 (a zero extension divides by zero in SWUtil.scala:110-115)");
   if ((int8_t)wire[6] < 0) return fail(BPSW_ERR_ARG, "extend: negative band width (w travels as a signed byte: at most 127)");
+  if (co && l_pac <= 0) return fail(BPSW_ERR_ARG, "extend: a coordinate batch needs the reference on the device (bpsw_ref_load)");
+  const int wband = (int8_t)wire[6];
   int mq = 0, mr = 0;
   const size_t words = bytes >> 2;
   for (int t = 0; t < n; ++t) {
-    const size_t at = 32 + 32 * (size_t)t;
+    const size_t at = 32 + rec_bytes * (size_t)t;
     const int lq = rd16(wire, at), lr = rd16(wire, at + 2), rq = rd16(wire, at + 4), rr = rd16(wire, at + 6);
     if (lq < 0 || lr < 0 || rq < 0 || rr < 0) return fail(BPSW_ERR_ARG, "extend: negative sequence length in task table");
     const long long pos = rd32(wire, at + 8);
-    const long long w = ((long long)lq + lr + rq + rr + 7) / 8;
-    if (pos < 8 + 8ll * n || (unsigned long long)(pos + w) > words)
+    const long long w = co ? ((long long)lq + rq + 7) / 8 : ((long long)lq + lr + rq + rr + 7) / 8;
+    if (pos < 8 + (long long)(rec_bytes / 4) * n || (unsigned long long)(pos + w) > words)
       return fail(BPSW_ERR_ARG, "extend: task sequence offset outside the buffer");
     if (lq > mq) mq = lq;
     if (rq > mq) mq = rq;
-    if (lr > mr) mr = lr;
-    if (rr > mr) mr = rr;
+    if (co) {
+      // the flanks [rb - lr, rb) and [rb + len, rb + len + rr) must lie on one strand of the doubled reference, as the windows
+      // of getMaxSpan do (MemChainToAlignBatched.scala:654-677)
+      const int len = rd16(wire, at + 18);
+      long long rb;
+      memcpy(&rb, wire + at + 32, 8);
+      const long long lo = rb - lr, hi = rb + len + rr;
+      if (len < 0 || lo < 0 || hi > (l_pac << 1) || (lo < l_pac && hi > l_pac))
+        return fail(BPSW_ERR_ARG, "extend: task window outside the reference or bridging its two strands");
+      const int sl = std::min(lr, lq + 2 * wband + 2), sr = std::min(rr, rq + 2 * wband + 2);  // what the kernel stages (ext_kernel<true>)
+      if (sl > mr) mr = sl;
+      if (sr > mr) mr = sr;
+    } else {
+      if (lr > mr) mr = lr;
+      if (rr > mr) mr = rr;
+    }
   }
   if (mq > BPSW_EXT_MAX_QLEN || mr > BPSW_EXT_MAX_RLEN) return fail(BPSW_ERR_LIMIT, "extend: sequence longer than the kernel limit");
-  *n_out = n; *maxq = mq; *maxr = mr;
+  *n_out = n; *maxq = mq; *maxr = mr; *coord = co;
   return BPSW_OK;
 }
 
@@ -542,12 +565,17 @@ int bpsw_extend_batch_classify(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_b
 static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   int n = 0, mq = 0, mr = 0;
-  int rc = scan_wire(wire, wire_bytes, &n, &mq, &mr);
+  bool coord = false;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const uint8_t* d_pac = nullptr;
+  long long l_pac = 0;
+  RefHold ref_hold;  // a coordinate batch reads the loaded reference: it stays put until the kernel has been waited for
+  if (wire && wire_bytes >= 32 && wire[7] == BPSW_WIRE_COORDS) ref_hold = ref_snapshot(c, &d_pac, &l_pac);
+  int rc = scan_wire(wire, wire_bytes, l_pac, &n, &mq, &mr, &coord);
   if (rc != BPSW_OK) return rc;
   if (!out || out_len < 10 * (size_t)n) return fail(BPSW_ERR_CAPACITY, "extend: result buffer smaller than 10*n int16");
   if (n == 0) return BPSW_OK;
-  std::lock_guard<std::mutex> g(c->mu);
-  HIP_TRY(hipSetDevice(c->device));
   { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
   const size_t out_bytes = 20 * (size_t)n;
   // (32-byte result slots in the pinned buffer were tried: the 16 + 4 byte stores of a record then cost two write sectors each,
@@ -585,6 +613,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     {
       ExtScoring sc = c->ext_sc;
       if (zc_slots) sc.out_stride = 16;
+      if (coord) { sc.pac = d_pac; sc.l_pac = l_pac; }
       if (side_how) {  // diagnostics: the kernel notes per side whether a shortcut or the DP produced the result
         HIP_TRY(c->d_ext_lists.reserve(2 * (size_t)n + 16));
         HIP_TRY(hipMemsetAsync(c->d_ext_lists.ptr, 0, 2 * (size_t)n, s));

@@ -120,6 +120,32 @@ typedef struct {
 size_t bpsw_wire_size(const bpsw_ext_tasks_t *t);
 int bpsw_wire_pack(const bpsw_ext_tasks_t *t, uint8_t *buf, size_t cap, size_t *bytes);
 
+/* Coordinate batches ("wire format 2"): the same call -- and the same JNI symbol, swExtendFPGAJNI(n, bytes) --
+ * accepts a batch that names the target flanks by reference coordinates instead of shipping their bases, when the reference
+ * is on the device (bpsw_ref_load).  It replaces bnsGetSeq + the leftRs/rightRs copies + their nibble packing
+ * (MemChainToAlignBatched.scala:363, 511-517, 534-541, 143-161) on the caller's side and about a third of the bytes per task.
+ *   header      as format 1, with byte 7 = BPSW_WIRE_COORDS (format 1 leaves it 0)
+ *   task record 40 bytes: the 32 bytes of format 1 (leftQlen, leftRlen, rightQlen, rightRlen int16; word offset of the task's
+ *               nibbles; regScore, qBeg, h0 int16; maxIns/maxDel shorts; idx int32) with the seed length (int16) in the slot of
+ *               the redundant 16-bit idx (bytes 18-19), then the seed's rBeg in [0, 2*l_pac) as int64 (bytes 32-39)
+ *   nibbles     leftQs then rightQs only (leftQs reversed, as in format 1)
+ * The left target flank is base(rBeg - 1 - i), i < leftRlen; the right one base(rBeg + len + i), i < rightRlen, with base() the
+ * doubled-strand lookup of bnsGetSeq (util/BNTSeqUtil.scala:56-73); a flank must not leave [0, 2*l_pac) nor bridge the strands
+ * (getMaxSpan, MemChainToAlignBatched.scala:654-677, guarantees both).  Results are identical to format 1 on the same tasks. */
+#define BPSW_WIRE_COORDS 2
+typedef struct {
+  int32_t n;
+  int32_t o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w; /* header fields */
+  int32_t mat_max;
+  const int32_t *left_qlen, *left_rlen, *right_qlen, *right_rlen;
+  const int64_t *left_q_off, *right_q_off; /* into pool; left flank already reversed */
+  const int32_t *reg_score, *q_beg, *h0, *idx, *seed_len;
+  const int64_t *seed_rbeg;
+  const uint8_t *pool;
+} bpsw_ext_coord_tasks_t;
+size_t bpsw_wire_coords_size(const bpsw_ext_coord_tasks_t *t);
+int bpsw_wire_coords_pack(const bpsw_ext_coord_tasks_t *t, uint8_t *buf, size_t cap, size_t *bytes);
+
 /* ---- boundary 1: pair-end mate-SW rescue -------------------------------------------------- */
 typedef struct { /* == mem_alnreg_t native/bwamem.h:49-61 == MemAlnRegType.scala:26-38 */
   int64_t rb, re;

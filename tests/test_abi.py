@@ -62,3 +62,34 @@ def test_packer_rejects_small_buffer():
     used = C.c_size_t(0)
     rc = lib.bpsw_wire_pack(C.byref(st), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(used))
     assert rc == -3 and used.value == lib.bpsw_wire_size(C.byref(st))
+
+
+def test_coordinate_batch_layout_against_the_format_1_batch():
+    """wire format 2 (include/bpsw.h): every field a format-1 record has is at the same place, the seed length sits in the
+    16-bit idx slot, the seed's rBeg follows as int64, and the nibble area holds leftQs + rightQs only -- checked against the
+    format-1 bytes of the same tasks (which test_host_packer_matches_scala_packer_restatement pins on the Scala packer)."""
+    l_pac = 60_013
+    pac, bases = synth.random_pac(l_pac, seed=5)
+    chains = synth.read_chains(40, bases, l_pac, read_len=100, seed=6)
+    co, by = synth.coord_ext_tasks(chains, bases, seed=7)
+    w1, w2 = bpsw_hip.wire_pack(by), bpsw_hip.wire_coords_pack(co)
+    n = co.n
+    assert list(w2[:7]) == list(w1[:7]) and w2[7] == 2 and w1[7] == 0
+    assert np.array_equal(w2[8:12], w1[8:12])
+
+    def nibbles(wire, word_off, count):
+        words = np.frombuffer(wire.tobytes(), "<u4")
+        return [int((words[word_off + k // 8] >> (4 * (7 - k % 8))) & 15) for k in range(count)]
+    for t in range(n):
+        a, b = 32 + 32 * t, 32 + 40 * t
+        assert np.array_equal(w2[b: b + 8], w1[a: a + 8])              # four lengths
+        assert np.array_equal(w2[b + 12: b + 18], w1[a + 12: a + 18])  # regScore, qBeg, h0
+        assert np.array_equal(w2[b + 20: b + 32], w1[a + 20: a + 32])  # maxIns / maxDel shorts, idx
+        assert int(np.frombuffer(w2[b + 18: b + 20].tobytes(), "<i2")[0]) == int(co.seed_len[t])
+        assert int(np.frombuffer(w2[b + 32: b + 40].tobytes(), "<i8")[0]) == int(co.seed_rbeg[t])
+        lq, rq = int(co.left_qlen[t]), int(co.right_qlen[t])
+        o1 = int(np.frombuffer(w1[a + 8: a + 12].tobytes(), "<i4")[0])
+        o2 = int(np.frombuffer(w2[b + 8: b + 12].tobytes(), "<i4")[0])
+        assert o2 >= (32 + 40 * n) // 4
+        assert nibbles(w2, o2, lq + rq) == nibbles(w1, o1, lq + rq)
+    assert w2.size == 32 + 40 * n + 4 * sum(((int(co.left_qlen[t]) + int(co.right_qlen[t]) + 1) // 2 + 3) // 4 for t in range(n))

@@ -27,6 +27,23 @@ s1 = ctx.stats()
 out["extend_host_entry"] = {"reads_per_s": 32768 * R / dt, "tasks": soa.n, "wire_bytes": int(wire.size), "ms_per_call": 1e3 * dt / R,
                             "h2d_ms": (s1.ext_h2d_ms - s0.ext_h2d_ms) / R, "kernel_ms": (s1.ext_kernel_ms - s0.ext_kernel_ms) / R,
                             "d2h_ms": (s1.ext_d2h_ms - s0.ext_d2h_ms) / R}
+# the same tasks as a byte batch and as a coordinate batch (wire format 2: target flanks read from the device-resident reference)
+l_pac = 4_000_037
+pac, bases = synth.random_pac(l_pac, seed=91)
+chains = synth.read_chains(16384, bases, l_pac, read_len=150, sub_rate=0.01, indel_rate=0.001, seed=92, p_subseed=0.0, p_shifted=0.0, p_decoy=0.0)
+co, by = synth.coord_ext_tasks(chains, bases, seed=93)
+ctx.ref_load(pac, l_pac)
+for name, w in (("extend_bytes_batch", bpsw_hip.wire_pack(by)), ("extend_coordinate_batch", bpsw_hip.wire_coords_pack(co))):
+    for _ in range(3):
+        ctx.extend_batch(w)
+    s0 = ctx.stats()
+    t0 = time.perf_counter()
+    for _ in range(R):
+        ctx.extend_batch(w)
+    dt = time.perf_counter() - t0
+    s1 = ctx.stats()
+    out[name] = {"tasks": co.n, "wire_bytes": int(w.size), "bytes_per_task": round(w.size / co.n, 1), "ms_per_call": 1e3 * dt / R,
+                 "h2d_ms": (s1.ext_h2d_ms - s0.ext_h2d_ms) / R, "kernel_ms": (s1.ext_kernel_ms - s0.ext_kernel_ms) / R}
 for pairs in (10, 256, 4096, 16384):
     # -sbatch 10 is the reference default (commandline/BWAMEMCommand.scala:28): most calls then carry 0-2 SW jobs,
     # so average over many different groups
