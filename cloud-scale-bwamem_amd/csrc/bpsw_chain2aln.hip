@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_C2A_WAVES_PER_SIMD) void
         long long rb = srb, re = srb + sl;
         if (sqb > 0 || sqb + sl != qlen) {
           const int lq = sqb, rq = qlen - (sqb + sl);
-          int aw[2] = {w0, w0};
+          int awSide = w0, awMax = w0;  // the band tried last on this side / the widest over both sides (no array: a dynamically indexed one lives in scratch memory)
           int regScore = sl * a;
           int outQBeg = 0, outRBeg = 0, outQEnd = rq, outREnd = 0, trueScore = regScore, sc = -1;
           for (int side = 0; side < 2; ++side) {
@@ -220,21 +220,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_C2A_WAVES_PER_SIMD) void
                                 (P.certify >= 3 && flank_start_gap_form(lane, qLen, min(rLen, tstage), qsrc, tsrc, P.mat, hInit, P.exact_a, oDel,
                                                                         eDel, oIns, eIns, P.zdrop, w0, &x)));
             if (exact) {
-              aw[side] = w0;
+              awSide = w0;
               regScore = x.max;
             }
             for (int i = 0; i < 2 && !exact; ++i) {  // MAX_BAND_TRY
               const int prev = regScore;
-              aw[side] = w0 << i;
-              const int w = min(min(aw[side], maxIns), maxDel);
+              awSide = w0 << i;
+              const int w = min(min(awSide, maxIns), maxDel);
               const int tl = min(rLen, qLen + w + 2);
               int oInsT = oIns, eInsT = eIns;  // opaque: keeps the per-lane column constants of every slot count out of long-lived VGPRs
               asm volatile("" : "+s"(oInsT), "+s"(eInsT));
               x = sw_extend_reg_any(lane, qLen, tl, qsrc, ts, P.mat, oDel, eDel, oInsT, eInsT, w, P.zdrop, P.zmode, hInit, P.tail_bound ? P.mat_max : 0);
               regScore = x.max;
-              if (regScore == prev || x.max_off < (aw[side] >> 1) + (aw[side] >> 2)) break;
+              if (regScore == prev || x.max_off < (awSide >> 1) + (awSide >> 2)) break;
             }
             sc = regScore;
+            awMax = max(awMax, awSide);
             const bool local = x.gscore <= 0 || x.gscore <= regScore - penClip;
             if (side == 0) {
               outQBeg = local ? sqb - x.qle : 0;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_C2A_WAVES_PER_SIMD) void
           }
           qb = outQBeg; rb = outRBeg + srb;  // :590-599
           qe = outQEnd + sqb + sl; re = outREnd + srb + sl;
-          score = sc; truesc = trueScore; width = aw[0] > aw[1] ? aw[0] : aw[1];
+          score = sc; truesc = trueScore; width = awMax;
         }
         // ---- computeSeedCoverage, :891-907 ----
         int cov = 0;

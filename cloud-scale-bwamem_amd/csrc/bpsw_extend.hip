@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
     const int idx = uni((int)rec[7]);
 
     // extension(), MemChainToAlignBatched.scala:789-883: side 0 = left (penClip5), side 1 = right (penClip3)
-    int aw[2] = {wBand, wBand};
+    int awSide = wBand, awMax = wBand;  // the band tried last on this side / the widest over both sides (no array: a dynamically indexed one lives in scratch memory)
     int regScore = regScore0;
     int outQBeg = 0, outRBeg = 0, outQEnd = rq, outREnd = 0, trueScore = regScore0, score = -1;
     for (int side = 0; side < 2; ++side) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
       else exact = shortcuts(tnib, rLen);
       if (sc.side_how && lane == 0) sc.side_how[2 * (size_t)task + side] = exact ? 1 : 2;  // diagnostics only
       if (exact) {
-        aw[side] = wBand;
+        awSide = wBand;
         regScore = r.max;
       } else if (reg_path) {
         if (!COORD) load_target_shifts(lane, tnib, rLen, ts);
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
       }
       for (int i = 0; i < 2 && !exact; ++i) {  // MAX_BAND_TRY
         const int prev = regScore;
-        aw[side] = wBand << i;
-        const int w = min(min(aw[side], maxIns), maxDel);
+        awSide = wBand << i;
+        const int w = min(min(awSide, maxIns), maxDel);
         if (reg_path) {
           // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
           // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
@@ -209,9 +209,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
           r = sw_extend_wave(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
         }
         regScore = r.max;
-        if (regScore == prev || r.max_off < (aw[side] >> 1) + (aw[side] >> 2)) break;
+        if (regScore == prev || r.max_off < (awSide >> 1) + (awSide >> 2)) break;
       }
       score = regScore;
+      awMax = max(awMax, awSide);
       const bool local = r.gscore <= 0 || r.gscore <= regScore - penClip;  // local extension vs reaching the query end
       if (side == 0) {
         outQBeg = local ? qBeg - r.qle : 0;
@@ -223,8 +224,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
         trueScore += (local ? regScore : r.gscore) - sc0;
       }
     }
-    const int aw0 = aw[0], aw1 = aw[1];
-    const int width = aw0 > aw1 ? aw0 : aw1;
+    const int width = awMax;
     if (lane == 0) {  // MemChainToAlignBatched.scala:181-188: 10 int16 per task
       uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)sc.out_stride * (size_t)task);
       o[0] = (uint32_t)idx;
