@@ -446,6 +446,18 @@ def main():
             traffic_x2 = pmc.get("detail", {}).get(dominant, {}).get("fetch_size_x2_plus_write_size")
         except Exception:
             traffic = traffic_x2 = None
+    # the committed rocprofv3 --kernel-trace --stats summary of this same command: the dominant kernel's average duration there
+    trace_ms = None
+    try:
+        import csv
+        import glob
+        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_bench.csv")))[-1:]:
+            for r in csv.DictReader(open(fn)):
+                if ("swp_kernel" if dominant == "swalign2" else "ext_kernel") in r["Name"]:
+                    trace_ms = round(float(r["AverageNs"]) * 1e-6, 4)
+                    break
+    except Exception:
+        trace_ms = None
     host_ms = {k: {"mean": round(float(np.mean(v)), 4), "p50": round(float(np.median(v)), 4), "max": round(float(np.max(v)), 4)} if v else None
                for k, v in call_ms.items()}
     pcie_bytes_per_step = passes * (sum(int(w.size) for w in wires) + 20 * sum(ntasks))   # boundary 2 both ways; boundary 1 below
@@ -512,8 +524,11 @@ def main():
                      "traffic_note": "profiles/pmc_traffic.json, per launch: L2->fabric read requests by their size (FETCH_SIZE tallies each at 64 B) + "
                                      "WRITE_SIZE; the second figure is the blanket 2*FETCH_SIZE + WRITE_SIZE",
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
-                     "note": "launch duration = HIP events on the launch stream inside the library, averaged over the timed region; launches of "
-                             "different host threads overlap on the device, so this is the time a launch spends sharing the GPU"},
+                     "avg_launch_ms_kernel_trace": trace_ms,
+                     "note": "launch duration = HIP events attached to the kernel's dispatch on its launch stream inside the library, averaged over "
+                             "the timed region; launches of different host threads overlap on the device, so this is the time a launch spends "
+                             "sharing the GPU.  The events see about 0.06 ms of dispatch latency per launch that a kernel trace does not: "
+                             "avg_launch_ms_kernel_trace is the rocprofv3 --kernel-trace --stats average of this command committed under profiles/"},
         "gcups": gcups, "frac_of_valu_ceiling": valu,
         "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes),
                                "h2d_ms_avg": round(st["ext_h2d_ms"] / max(ext_launches, 1), 4), "d2h_ms_avg": round(st["ext_d2h_ms"] / max(ext_launches, 1), 4)},

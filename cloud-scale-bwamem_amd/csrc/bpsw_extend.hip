@@ -286,7 +286,7 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
-                             const ExtPrepass* d_pre_check, bool counter_zeroed) {
+                             const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev) {
   if (n_tasks <= 0) return hipSuccess;
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
   const void* fn = coord ? reinterpret_cast<const void*>(ext_kernel<true>) : reinterpret_cast<const void*>(ext_kernel<false>);
@@ -329,10 +329,10 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   static const int chunk = [] { const int v = getenv("BPSW_EXT_CHUNK") ? atoi(getenv("BPSW_EXT_CHUNK")) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();  // 0: guided
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   if (coord)
-    hipLaunchKernelGGL(ext_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
+    BPSW_LAUNCH(kev, ext_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
                        rcap, (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check);
   else
-    hipLaunchKernelGGL(ext_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
+    BPSW_LAUNCH(kev, ext_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
                        rcap, (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check);
   return hipGetLastError();
 }

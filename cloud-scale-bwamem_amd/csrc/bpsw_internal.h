@@ -14,7 +14,22 @@
 
 struct bpsw_ctx;
 
+#include <hip/hip_ext.h>
+
 namespace bpsw {
+
+// Events attached to ONE kernel dispatch (hipExtLaunchKernelGGL): start / stop carry the dispatch's own begin and end timestamps,
+// which is what a kernel trace reports.  An event recorded before and after a launch brackets the dispatch latency too (65 us per
+// launch on the loaded bench).  Both null: a plain launch.
+struct KernelEvents {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+#define BPSW_LAUNCH(ev, kernel, grid, block, lds, stream, ...)                                                          \
+  do {                                                                                                                   \
+    if ((ev).start || (ev).stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, (ev).start, (ev).stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                               \
+  } while (0)
+
 
 // ---- scoring block handed to the kernels by value -------------------------------------------
 struct MatRows {
@@ -68,7 +83,7 @@ size_t ext_lds_per_wave(int qcap, int rcap);
 // error or lengths beyond (qcap, rcap) -- the asynchronous device entry sizes the launch before anybody has read the scan back.
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
-                             const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false);
+                             const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false, KernelEvents kev = KernelEvents());
 // Quad-task kernel (bpsw_extend_qt.hip): s_cols = 4 (sides <= 63 bp) or 9 (<= 143 bp).
 hipError_t launch_ext_qt_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, const int* d_list, int n_list,
                                 int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter, hipStream_t s);
@@ -132,7 +147,7 @@ bool sw_quad_enabled();  // four rescue jobs per wavefront for mates <= 160 base
 int sw_resident_waves(int num_cu);
 // d_pre_check: as for launch_ext_kernel (the launch is sized for max_qlen / max_tlen speculatively).
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
-                            uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check = nullptr);
+                            uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check = nullptr, KernelEvents kev = KernelEvents());
 
 // ---- global alignment + CIGAR -------------------------------------------------
 struct GlobalJobsDev {  // all device pointers

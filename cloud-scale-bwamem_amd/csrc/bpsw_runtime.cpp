@@ -592,13 +592,14 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   memcpy(c->h_stage_in.ptr, wire, wire_bytes);
   const double t_staged = wall_ms();
   double t_dev0, t_dev1;
+  bool kernel_was_last = false;
   {
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
     hipStream_t s = lease.s;
     t_dev0 = wall_ms();
     HIP_TRY(hipEventRecord(c->ev[0], s));
     HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(c->ev[1], s));
+    bool on_dispatch = false;  // ev[1] / ev[2] ride on the kernel's own dispatch (KernelEvents, bpsw_internal.h)
     // results: written by the kernel straight into the pinned staging buffer (20 B per task, posted PCIe writes), or into
     // device memory and copied back
     const bool zc_out = (zerocopy_mask() & 1) != 0;
@@ -606,6 +607,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
 #ifdef BPSW_EXPERIMENTAL_KERNELS
     if (ext_lane_enabled() || ext_qt_enabled()) {
       zc_slots = false;  // the experimental kernels write 20-byte records back to back
+      HIP_TRY(hipEventRecord(c->ev[1], s));
       rc = ext_experimental_launch(c, wire, wire_bytes, n, mq, mr, k_out, s);
       if (rc != BPSW_OK) return rc;
     } else
@@ -619,14 +621,19 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         HIP_TRY(hipMemsetAsync(c->d_ext_lists.ptr, 0, 2 * (size_t)n, s));
         sc.side_how = (uint8_t*)c->d_ext_lists.ptr;
       }
+      KernelEvents kev;
+      kev.start = c->ev[1]; kev.stop = c->ev[2];
+      on_dispatch = true;
       HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, mq, mr, c->num_cu,
-                                (int*)((char*)c->d_pre.ptr + 128), nullptr, s));
+                                (int*)((char*)c->d_pre.ptr + 128), nullptr, s, nullptr, false, kev));
       if (side_how) HIP_TRY(hipMemcpyAsync(side_how, c->d_ext_lists.ptr, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (!on_dispatch) HIP_TRY(hipEventRecord(c->ev[2], s));
+    const bool kernel_is_last = on_dispatch && zc_out && !side_how;  // then the call waits for the kernel's own stop event
+    kernel_was_last = kernel_is_last;
     if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(c->ev[3], s));
-    HIP_TRY(wait_event(c, c->ev[3], 0));  // the last operation of the call on this stream
+    if (!kernel_is_last) HIP_TRY(hipEventRecord(c->ev[3], s));
+    HIP_TRY(wait_event(c, kernel_is_last ? c->ev[2] : c->ev[3], 0));  // the last operation of the call on this stream
     t_dev1 = wall_ms();
     c->stats.ext_wait_ms += lease.wait_ms;
   }
@@ -644,7 +651,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   float a = 0, b = 0, d = 0;
   (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-  (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
+  if (!kernel_was_last) (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n; c->stats.ext_wire_bytes += wire_bytes;
   c->stats.ext_h2d_ms += a; c->stats.ext_kernel_ms += b; c->stats.ext_d2h_ms += d;
   c->stats.ext_host_in_ms += t_staged - t_in; c->stats.ext_dev_ms += t_dev1 - t_dev0; c->stats.ext_host_out_ms += t_out - t_dev1;

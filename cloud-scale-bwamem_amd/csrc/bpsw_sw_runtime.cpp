@@ -104,21 +104,27 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
     hipStream_t s = lease.s;
     const double t_dev0 = wall_ms();
-    HIP_TRY(hipEventRecord(c->ev[0], s));
-    if (!zc_in) HIP_TRY(hipMemcpyAsync(d, h, st.total, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(c->ev[1], s));
-    HIP_TRY(launch_sw_kernel(dev, sc, mq, mt, k_out, (uint32_t*)c->d_sw_scratch.ptr, c->num_cu, s));
-    HIP_TRY(hipEventRecord(c->ev[2], s));
-    if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_sw_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(c->ev[3], s));
-    HIP_TRY(wait_event(c, c->ev[3], 1));  // the last operation of the call on this stream
+    // ev[1] / ev[2] ride on the kernel's own dispatch (KernelEvents): its begin and end as a kernel trace sees them, and two marker
+    // packets fewer per call; only copies get markers of their own
+    if (!zc_in) {
+      HIP_TRY(hipEventRecord(c->ev[0], s));
+      HIP_TRY(hipMemcpyAsync(d, h, st.total, hipMemcpyHostToDevice, s));
+    }
+    KernelEvents kev;
+    kev.start = c->ev[1]; kev.stop = c->ev[2];
+    HIP_TRY(launch_sw_kernel(dev, sc, mq, mt, k_out, (uint32_t*)c->d_sw_scratch.ptr, c->num_cu, s, nullptr, kev));
+    if (!zc_out) {
+      HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_sw_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipEventRecord(c->ev[3], s));
+    }
+    HIP_TRY(wait_event(c, zc_out ? c->ev[2] : c->ev[3], 1));  // the last operation of the call on this stream
     c->stats.grp_wait_ms += lease.wait_ms;
     c->stats.grp_dev_ms += wall_ms() - t_dev0;
   }
   float a = 0, b = 0, e = 0;
-  (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+  if (!zc_in) (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-  (void)hipEventElapsedTime(&e, c->ev[2], c->ev[3]);
+  if (!zc_out) (void)hipEventElapsedTime(&e, c->ev[2], c->ev[3]);
   c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)n;
   c->stats.sw_h2d_ms += a; c->stats.sw_kernel_ms += b; c->stats.sw_d2h_ms += e;
   c->last_sw_ms = b;

@@ -920,21 +920,21 @@ __global__ void ref_fetch_kernel(const uint8_t* __restrict__ pac, const long lon
 
 template <int C>
 hipError_t launch_pk(const SwJobsDev& jobs, const SwScoring& sc, int bias, int32_t* d_out, uint32_t* d_scratch, int per_job,
-                     int blocks, hipStream_t s, const SwPrepass* pre) {
+                     int blocks, hipStream_t s, const SwPrepass* pre, KernelEvents kev) {
   static const bool keys_hbm = getenv("BPSW_SW_KEYS_LDS") && atoi(getenv("BPSW_SW_KEYS_LDS")) == 0;  // A/B switch
   if (per_job <= PK_KEYS_LDS_MAX && !keys_hbm) {
     const size_t lds = sizeof(uint32_t) * WAVES_PER_BLOCK * (size_t)(per_job + PK_KEY_PAD);
-    hipLaunchKernelGGL((swp_kernel<C, true>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, jobs, sc, bias, d_out, d_scratch, per_job, pre);
+    BPSW_LAUNCH(kev, (swp_kernel<C, true>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, jobs, sc, bias, d_out, d_scratch, per_job, pre);
   } else {
-    hipLaunchKernelGGL((swp_kernel<C, false>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, bias, d_out, d_scratch, per_job, pre);
+    BPSW_LAUNCH(kev, (swp_kernel<C, false>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, bias, d_out, d_scratch, per_job, pre);
   }
   return hipGetLastError();
 }
 
 template <int C>
 hipError_t launch_c(const SwJobsDev& jobs, const SwScoring& sc, int32_t* d_out, uint32_t* d_scratch, int per_wave,
-                    int blocks, hipStream_t s, const SwPrepass* pre) {
-  hipLaunchKernelGGL(sw_kernel<C>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_wave, pre);
+                    int blocks, hipStream_t s, const SwPrepass* pre, KernelEvents kev) {
+  BPSW_LAUNCH(kev, sw_kernel<C>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_wave, pre);
   return hipGetLastError();
 }
 
@@ -994,7 +994,7 @@ bool sw_pack_enabled(const SwScoring& sc) { return sw_pack_bias(sc) >= 0; }
 int sw_resident_waves(int num_cu) { return num_cu * 8 * WAVES_PER_BLOCK; }
 
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
-                            uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check) {
+                            uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check, KernelEvents kev) {
   if (jobs.n <= 0) return hipSuccess;
   int blocks = (jobs.n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   // at most 8: the row scratch is sized for sw_resident_waves() = 8 workgroups per CU (a larger grid would index past it)
@@ -1011,25 +1011,25 @@ hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_
     int pblocks = ((jobs.n + 1) / 2 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (pblocks > max_blocks) pblocks = max_blocks;
     const int pc = (max_qlen + PK_LAST) / (PK_LAST + 1);  // columns per lane over the 64 - PK_TAIL lanes that hold the query
-    if (pc <= 1) return launch_pk<1>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
-    if (pc == 2) return launch_pk<2>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
-    if (pc == 3) return launch_pk<3>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
-    if (pc == 4) return launch_pk<4>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
-    return launch_pk<5>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check);
+    if (pc <= 1) return launch_pk<1>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check, kev);
+    if (pc == 2) return launch_pk<2>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check, kev);
+    if (pc == 3) return launch_pk<3>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check, kev);
+    if (pc == 4) return launch_pk<4>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check, kev);
+    return launch_pk<5>(jobs, sc, bias, d_out, d_scratch, per_job, pblocks, s, d_pre_check, kev);
   }
   if (max_qlen <= 16 * Q4C && sw_quad_for(jobs.n, num_cu)) {  // four jobs per wavefront
     int qblocks = (jobs.n + 4 * WAVES_PER_BLOCK - 1) / (4 * WAVES_PER_BLOCK);
     if (qblocks > max_blocks) qblocks = max_blocks;
-    hipLaunchKernelGGL(sw4_kernel, dim3(qblocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_job, d_pre_check);
+    BPSW_LAUNCH(kev, sw4_kernel, dim3(qblocks), dim3(64 * WAVES_PER_BLOCK), 0, s, jobs, sc, d_out, d_scratch, per_job, d_pre_check);
     return hipGetLastError();
   }
   const int per_wave = per_job;  // one job per wave: the first quarter of the wave's scratch
-  if (c <= 1) return launch_c<1>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
-  if (c == 2) return launch_c<2>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
-  if (c == 3) return launch_c<3>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
-  if (c == 4) return launch_c<4>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
-  if (c <= 6) return launch_c<6>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
-  if (c <= 8) return launch_c<8>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check);
+  if (c <= 1) return launch_c<1>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check, kev);
+  if (c == 2) return launch_c<2>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check, kev);
+  if (c == 3) return launch_c<3>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check, kev);
+  if (c == 4) return launch_c<4>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check, kev);
+  if (c <= 6) return launch_c<6>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check, kev);
+  if (c <= 8) return launch_c<8>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check, kev);
   return hipErrorInvalidValue;
 }
 
