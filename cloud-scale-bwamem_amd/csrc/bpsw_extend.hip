@@ -81,8 +81,13 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 #endif
 // COORD: a coordinate batch (include/bpsw.h, "wire format 2") -- 40-byte task records, query flanks only, the target flanks are
 // read from the device-resident reference (bnsGetSeq of MemChainToAlignBatched.scala:363 moves to the device).
-template <bool COORD>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
+// SHORT: the kernel for tasks whose two query flanks have at most EXT_SHORT_QMAX bases -- every task of 2x150 bp reads but a few.
+// It carries only the one- and two-columns-per-lane sweeps and the shortcuts, needs 48 VGPRs instead of 90 and no LDS but the
+// target bytes, so eight of its waves share a SIMD: a wave of this kernel is bound by the latency of its row (1 200 cycles alone
+// on a SIMD for ~230 cycles of vector and ~250 of scalar pipe time), and the rows of more waves fill each other's gaps.  It skips
+// the other tasks; the host, which has seen every record (scan_wire), sends those to the full kernel as a task list.
+template <bool COORD, bool SHORT>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
                                                                      const int lds_per_wave, const int chunk, const int guide_cap,
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
   unsigned char* base = smem + (size_t)wave * lds_per_wave;
   int2* eh = reinterpret_cast<int2*>(base);
   int8_t* qp = reinterpret_cast<int8_t*>(base + 8 * (size_t)(qcap + 2));
-  uint8_t* ts = reinterpret_cast<uint8_t*>(qp + 5 * (size_t)qcap);
+  uint8_t* ts = SHORT ? base : reinterpret_cast<uint8_t*>(qp + 5 * (size_t)qcap);  // SHORT: the target bytes are all the LDS a wave has
 
   // header, MemChainToAlignBatched.scala:78-84 (signed bytes)
   const uint32_t hdr0 = wire[0], hdr1 = wire[1];
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
     const long long seedRb = COORD ? (long long)(((unsigned long long)uni((int)rec[9]) << 32) | (unsigned)uni((int)rec[8])) : 0ll;
     const int seedLen = COORD ? uni(hi16(r4)) : 0;
     const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
+    if (SHORT && (lq > EXT_SHORT_QMAX || rq > EXT_SHORT_QMAX)) continue;  // the full kernel's task (the host lists it: ext_task_is_long)
     const uint32_t* words = wire + (size_t)uni((int)rec[2]);
     const int regScore0 = uni(lo16(r3)), qBeg = uni(hi16(r3)), h0 = uni(lo16(r4));
     const int lMaxIns = max(1, uni(lo16(r5))), lMaxDel = max(1, uni(hi16(r5)));  // SWUtil.scala:110-115
@@ -190,6 +196,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
         regScore = r.max;
       } else if (reg_path) {
         if (!COORD) load_target_shifts(lane, tnib, rLen, ts);
+      } else if constexpr (SHORT) {
+        // (never: the host sends a batch whose gap costs rule the register path out to the full kernel)
       } else if constexpr (COORD) {
         load_side(lane, words, qStart, qLen, tpac, tstage, sc.mat, qp, ts);
       } else {
@@ -199,7 +207,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
         const int prev = regScore;
         awSide = wBand << i;
         const int w = min(min(awSide, maxIns), maxDel);
-        if (reg_path) {
+        if constexpr (SHORT) {
+          int oInsT = oIns, eInsT = eIns;  // opaque copies, as below
+          asm volatile("" : "+s"(oInsT), "+s"(eInsT));
+          r = sw_extend_reg_short(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
+        } else if (reg_path) {
           // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
           // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
           int oInsT = oIns, eInsT = eIns;
@@ -286,19 +298,20 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
-                             const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev) {
+                             const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev, bool short_kernel) {
   if (n_tasks <= 0) return hipSuccess;
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
-  const void* fn = coord ? reinterpret_cast<const void*>(ext_kernel<true>) : reinterpret_cast<const void*>(ext_kernel<false>);
+  const void* fn = short_kernel ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, true>) : reinterpret_cast<const void*>(ext_kernel<false, true>))
+                                : (coord ? reinterpret_cast<const void*>(ext_kernel<true, false>) : reinterpret_cast<const void*>(ext_kernel<false, false>));
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
   rcap = (rcap + 63) & ~63;
-  const size_t per_wave = ext_lds_per_wave(qcap, rcap);
+  const size_t per_wave = short_kernel ? (((size_t)rcap + 15) & ~(size_t)15) : ext_lds_per_wave(qcap, rcap);
   const size_t lds = per_wave * WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device
-  static std::atomic<size_t> attr_set_v[2][64];
-  std::atomic<size_t>* attr_set = attr_set_v[coord ? 1 : 0];
+  static std::atomic<size_t> attr_set_v[4][64];
+  std::atomic<size_t>* attr_set = attr_set_v[(coord ? 1 : 0) + (short_kernel ? 2 : 0)];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (lds > 64 * 1024 && lds > attr_set[dev].load(std::memory_order_relaxed)) {
@@ -318,8 +331,11 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   // each with its own tail of long tasks; small grids of several launches (and the rescue kernel of the same step) are
   // resident together and fill each other's tails.
   static const double cap_per_cu = getenv("BPSW_EXT_BLOCKS_PER_CU") ? atof(getenv("BPSW_EXT_BLOCKS_PER_CU")) : 1.0;
+  // the 48-VGPR kernel: two workgroups per CU (bench step, reads/s in millions at 1 / 1.5 / 2 / 3 per CU: 152.5 / 158.1 / 157.5 / 147.2,
+  // against 151.7 for the full kernel alone on the same box)
+  static const double cap_per_cu_short = getenv("BPSW_EXT_SHORT_BLOCKS_PER_CU") ? atof(getenv("BPSW_EXT_SHORT_BLOCKS_PER_CU")) : 2.0;
   double per_cu_f = per_cu < 1 ? 1.0 : (double)per_cu;
-  if (per_cu_f > cap_per_cu) per_cu_f = cap_per_cu;
+  if (per_cu_f > (short_kernel ? cap_per_cu_short : cap_per_cu)) per_cu_f = short_kernel ? cap_per_cu_short : cap_per_cu;
   int blocks = (n_tasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   int max_blocks = (int)(num_cu * per_cu_f);
   if (max_blocks < 1) max_blocks = 1;
@@ -328,12 +344,15 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   // tasks per dequeue: 0 = guided (see the kernel), n > 0 = fixed chunks of n (1 balances a lone launch best)
   static const int chunk = [] { const int v = getenv("BPSW_EXT_CHUNK") ? atoi(getenv("BPSW_EXT_CHUNK")) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();  // 0: guided
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
-  if (coord)
-    BPSW_LAUNCH(kev, ext_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
-                       rcap, (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check);
-  else
-    BPSW_LAUNCH(kev, ext_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap,
-                       rcap, (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check);
+#define BPSW_EXT_GO(CO, SH)                                                                                                     \
+  BPSW_LAUNCH(kev, (ext_kernel<CO, SH>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap, rcap, \
+              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check)
+  if (short_kernel) {
+    if (coord) BPSW_EXT_GO(true, true); else BPSW_EXT_GO(false, true);
+  } else {
+    if (coord) BPSW_EXT_GO(true, false); else BPSW_EXT_GO(false, false);
+  }
+#undef BPSW_EXT_GO
   return hipGetLastError();
 }
 

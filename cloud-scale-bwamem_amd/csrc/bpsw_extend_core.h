@@ -952,6 +952,22 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
   return sw_extend_reg<4>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 }
 
+// The two sweeps that need few registers: flanks of at most EXT_SHORT_QMAX bases (one or two columns per lane, no window, no LDS row).
+// ext_kernel<.., SHORT> is built from these alone and fits 48 VGPRs -- eight waves per SIMD instead of five (bpsw_extend.hip).
+constexpr int EXT_SHORT_QMAX = 127;
+template <class QC>
+__device__ __forceinline__ ExtRes sw_extend_reg_short(const int lane, const int qLen, const int tLen, const QC& qcode,
+                                                      const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
+                                                      const int eDel, const int oIns, const int eIns, const int w,
+                                                      const int zdrop, const int zmode, const int h0, const int amax) {
+  if (qLen < 64) return sw_extend_reg<1>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+#if BPSW_EXT_INTERLEAVE
+  return sw_extend_il2<false>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+#else
+  return sw_extend_reg<2>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+#endif
+}
+
 // Wave-level dequeue: lane 0 alone performs one returning atomic add, the result is broadcast.  Written as
 // a single asm statement so that the compiler sees no lane-dependent branch here: with a C-level
 // `if (lane == 0) atomicAdd(...)` hipcc threaded that branch together with the lane-0 result store at the end

@@ -83,7 +83,9 @@ size_t ext_lds_per_wave(int qcap, int rcap);
 // error or lengths beyond (qcap, rcap) -- the asynchronous device entry sizes the launch before anybody has read the scan back.
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
-                             const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false, KernelEvents kev = KernelEvents());
+                             const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false, KernelEvents kev = KernelEvents(),
+                             bool short_kernel = false);
+// short_kernel: the 48-VGPR variant for tasks whose query flanks have at most 127 bases; it skips the others (bpsw_extend.hip)
 // Quad-task kernel (bpsw_extend_qt.hip): s_cols = 4 (sides <= 63 bp) or 9 (<= 143 bp).
 hipError_t launch_ext_qt_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, const int* d_list, int n_list,
                                 int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter, hipStream_t s);
@@ -373,6 +375,7 @@ struct bpsw_ctx {
 
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
   int shortcut_mask = 31;  // bpsw_set_ext_shortcuts
+  std::vector<int> ext_long_tasks;  // scratch of bpsw_extend_batch: the tasks of the current batch that go to the full kernel
   double wait_est_ms[2] = {0., 0.};  // wait_event: running average of the device-phase waits (extension, SW)
   void* rescue_scratch = nullptr;  // bpsw_rescue.cpp: vectors reused across bpsw_matesw_group calls (freed by rescue_scratch_free)
   bpsw_stats_t stats;

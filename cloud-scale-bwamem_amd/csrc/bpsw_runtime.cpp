@@ -504,7 +504,8 @@ static inline int rd32(const uint8_t* b, size_t at) {
 // Host-side twin of ext_prepass_kernel: validates the table, returns the LDS capacities.
 // Validates a wire batch on the host.  *coord: the batch is a coordinate batch (wire format 2: byte 7 of the header is 2, 40-byte
 // records, query flanks only); l_pac is the length of the loaded reference (0: none), needed to check its coordinates.
-static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_out, int* maxq, int* maxr, bool* coord) {
+static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_out, int* maxq, int* maxr, bool* coord,
+                     std::vector<int>* long_tasks, int* maxr_short) {
   if (!wire || bytes < 32 || (bytes & 3)) return fail(BPSW_ERR_ARG, "extend: wire batch shorter than its header or not word sized");
   const int n = rd32(wire, 8);
   const int fmt = wire[7];
@@ -517,8 +518,12 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
   if ((int8_t)wire[6] < 0) return fail(BPSW_ERR_ARG, "extend: negative band width (w travels as a signed byte: at most 127)");
   if (co && l_pac <= 0) return fail(BPSW_ERR_ARG, "extend: a coordinate batch needs the reference on the device (bpsw_ref_load)");
   const int wband = (int8_t)wire[6];
-  int mq = 0, mr = 0;
+  int mq = 0, mr = 0, mrs = 0;
   const size_t words = bytes >> 2;
+  // tasks for the full kernel (a query flank above 127 bases; every task when the gap costs rule out the register sweeps):
+  // the 48-VGPR kernel serves the others (bpsw_extend.hip, ext_kernel<.., SHORT>)
+  const bool all_long = (int8_t)wire[2] + (int8_t)wire[3] <= 0;
+  long_tasks->clear();
   for (int t = 0; t < n; ++t) {
     const size_t at = 32 + rec_bytes * (size_t)t;
     const int lq = rd16(wire, at), lr = rd16(wire, at + 2), rq = rd16(wire, at + 4), rr = rd16(wire, at + 6);
@@ -529,6 +534,9 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
       return fail(BPSW_ERR_ARG, "extend: task sequence offset outside the buffer");
     if (lq > mq) mq = lq;
     if (rq > mq) mq = rq;
+    const bool is_long = all_long || lq > 127 || rq > 127;
+    if (is_long) long_tasks->push_back(t);
+    int task_mr = 0;
     if (co) {
       // the flanks [rb - lr, rb) and [rb + len, rb + len + rr) must lie on one strand of the doubled reference, as the windows
       // of getMaxSpan do (MemChainToAlignBatched.scala:654-677)
@@ -539,15 +547,15 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
       if (len < 0 || lo < 0 || hi > (l_pac << 1) || (lo < l_pac && hi > l_pac))
         return fail(BPSW_ERR_ARG, "extend: task window outside the reference or bridging its two strands");
       const int sl = std::min(lr, lq + 2 * wband + 2), sr = std::min(rr, rq + 2 * wband + 2);  // what the kernel stages (ext_kernel<true>)
-      if (sl > mr) mr = sl;
-      if (sr > mr) mr = sr;
+      task_mr = std::max(sl, sr);
     } else {
-      if (lr > mr) mr = lr;
-      if (rr > mr) mr = rr;
+      task_mr = std::max(lr, rr);
     }
+    if (task_mr > mr) mr = task_mr;
+    if (!is_long && task_mr > mrs) mrs = task_mr;
   }
   if (mq > BPSW_EXT_MAX_QLEN || mr > BPSW_EXT_MAX_RLEN) return fail(BPSW_ERR_LIMIT, "extend: sequence longer than the kernel limit");
-  *n_out = n; *maxq = mq; *maxr = mr; *coord = co;
+  *n_out = n; *maxq = mq; *maxr = mr; *coord = co; *maxr_short = mrs;
   return BPSW_OK;
 }
 
@@ -572,8 +580,18 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   long long l_pac = 0;
   RefHold ref_hold;  // a coordinate batch reads the loaded reference: it stays put until the kernel has been waited for
   if (wire && wire_bytes >= 32 && wire[7] == BPSW_WIRE_COORDS) ref_hold = ref_snapshot(c, &d_pac, &l_pac);
-  int rc = scan_wire(wire, wire_bytes, l_pac, &n, &mq, &mr, &coord);
+  std::vector<int>& long_tasks = c->ext_long_tasks;
+  int mr_short = 0;
+  int rc = scan_wire(wire, wire_bytes, l_pac, &n, &mq, &mr, &coord, &long_tasks, &mr_short);
   if (rc != BPSW_OK) return rc;
+  // Launch plan: the 48-VGPR kernel over the whole batch (it skips the long tasks) and the full kernel over the list of long
+  // ones -- or the full kernel alone when most tasks are long (2x250 bp reads) or the split is switched off (BPSW_EXT_SPLIT=0)
+  static const bool split_on = !(getenv("BPSW_EXT_SPLIT") && atoi(getenv("BPSW_EXT_SPLIT")) == 0);
+  const int n_long = (int)long_tasks.size();
+  const bool use_short = split_on && 2 * (size_t)n_long <= (size_t)n;
+  const bool use_full = !use_short || n_long > 0;
+  const size_t list_off = (wire_bytes + 15) & ~(size_t)15;
+  const size_t stage_bytes = (use_short && use_full) ? list_off + 4 * (size_t)n_long : wire_bytes;
   if (!out || out_len < 10 * (size_t)n) return fail(BPSW_ERR_CAPACITY, "extend: result buffer smaller than 10*n int16");
   if (n == 0) return BPSW_OK;
   { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
@@ -581,15 +599,16 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // (32-byte result slots in the pinned buffer were tried: the 16 + 4 byte stores of a record then cost two write sectors each,
   // more fabric writes than back-to-back 20-byte records that merge in L2, and the host-side gather cost more than the memcpy)
   bool zc_slots = false;
-  HIP_TRY(c->d_wire.reserve(wire_bytes));
+  HIP_TRY(c->d_wire.reserve(stage_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
 #ifdef BPSW_EXPERIMENTAL_KERNELS
   HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n + 16));
 #endif
-  HIP_TRY(c->h_stage_in.reserve(wire_bytes));
+  HIP_TRY(c->h_stage_in.reserve(stage_bytes));
   HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_bytes));
   const double t_in = wall_ms();
   memcpy(c->h_stage_in.ptr, wire, wire_bytes);
+  if (stage_bytes > wire_bytes) memcpy((char*)c->h_stage_in.ptr + list_off, long_tasks.data(), 4 * (size_t)n_long);  // rides on the same copy
   const double t_staged = wall_ms();
   double t_dev0, t_dev1;
   bool kernel_was_last = false;
@@ -598,7 +617,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     hipStream_t s = lease.s;
     t_dev0 = wall_ms();
     HIP_TRY(hipEventRecord(c->ev[0], s));
-    HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, s));
     bool on_dispatch = false;  // ev[1] / ev[2] ride on the kernel's own dispatch (KernelEvents, bpsw_internal.h)
     // results: written by the kernel straight into the pinned staging buffer (20 B per task, posted PCIe writes), or into
     // device memory and copied back
@@ -621,11 +640,21 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         HIP_TRY(hipMemsetAsync(c->d_ext_lists.ptr, 0, 2 * (size_t)n, s));
         sc.side_how = (uint8_t*)c->d_ext_lists.ptr;
       }
-      KernelEvents kev;
-      kev.start = c->ev[1]; kev.stop = c->ev[2];
       on_dispatch = true;
-      HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, mq, mr, c->num_cu,
-                                (int*)((char*)c->d_pre.ptr + 128), nullptr, s, nullptr, false, kev));
+      int* d_queue = (int*)((char*)c->d_pre.ptr + 128);
+      if (use_short) {
+        KernelEvents kev;
+        kev.start = c->ev[1]; kev.stop = use_full ? nullptr : c->ev[2];
+        HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 127), mr_short, c->num_cu, d_queue, nullptr, s,
+                                  nullptr, false, kev, true));
+      }
+      if (use_full) {
+        KernelEvents kev;
+        kev.start = use_short ? nullptr : c->ev[1]; kev.stop = c->ev[2];
+        const int* d_list = use_short ? (const int*)((const char*)c->d_wire.ptr + list_off) : nullptr;
+        HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, use_short ? n_long : n, k_out, sc, mq, mr, c->num_cu, d_queue, d_list, s,
+                                  nullptr, false, kev, false));
+      }
       if (side_how) HIP_TRY(hipMemcpyAsync(side_how, c->d_ext_lists.ptr, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
     }
     if (!on_dispatch) HIP_TRY(hipEventRecord(c->ev[2], s));
