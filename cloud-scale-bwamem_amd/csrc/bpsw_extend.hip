@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
       const int qStart = side ? lq : 0, rStart = side ? lq + rq + lr : lq + rq;
       const int maxIns = side ? rMaxIns : lMaxIns, maxDel = side ? rMaxDel : lMaxDel;
       const int penClip = side ? penClip3 : penClip5;
-      const int hInit = side ? regScore : h0;  // the right extension starts from the score after the left one
+      const int hInit = uni(side ? regScore : h0);  // the right extension starts from the score after the left one (uni: see `exact` below)
       const int sc0 = regScore;
       // register path: needs one lane per column 0..qLen and oeIns > 0 (see sw_extend_reg)
       const bool reg_path = qLen <= 255 && oIns + eIns > 0;
@@ -187,13 +187,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
                 (sc.certify >= 3 && flank_start_gap_form(lane, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
                                                          hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
       };
-      bool exact;
-      if constexpr (COORD) exact = reg_path && shortcuts(LdsShiftT{ts}, tstage);
-      else exact = shortcuts(tnib, rLen);
+      bool exact_v;
+      if constexpr (COORD) exact_v = reg_path && shortcuts(LdsShiftT{ts}, tstage);
+      else exact_v = shortcuts(tnib, rLen);
+      // wave-uniform by construction (the shortcuts decide on wave reductions), but not to the compiler: without this the DP below
+      // sits in what it takes for divergent control flow and its whole scalar state is kept in vector registers
+      const bool exact = uni(exact_v ? 1 : 0) != 0;
       if (sc.side_how && lane == 0) sc.side_how[2 * (size_t)task + side] = exact ? 1 : 2;  // diagnostics only
       if (exact) {
         awSide = wBand;
-        regScore = r.max;
+        regScore = uni(r.max);
       } else if (reg_path) {
         if (!COORD) load_target_shifts(lane, tnib, rLen, ts);
       } else if constexpr (SHORT) {
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
       for (int i = 0; i < 2 && !exact; ++i) {  // MAX_BAND_TRY
         const int prev = regScore;
         awSide = wBand << i;
-        const int w = min(min(awSide, maxIns), maxDel);
+        const int w = uni(min(min(awSide, maxIns), maxDel));
         if constexpr (SHORT) {
           int oInsT = oIns, eInsT = eIns;  // opaque copies, as below
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
         } else {
           r = sw_extend_wave(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
         }
-        regScore = r.max;
+        regScore = uni(r.max);
         if (regScore == prev || r.max_off < (awSide >> 1) + (awSide >> 2)) break;
       }
       score = regScore;

@@ -909,6 +909,376 @@ struct NibbleQ {
   __device__ __forceinline__ int operator()(int j) const { return nibble_at(words, qStart + j); }
 };
 
+#ifndef BPSW_EXT_LEAN
+#define BPSW_EXT_LEAN 1  // 0: the sweeps of round 1 / early round 2 (sw_extend_reg<1>, sw_extend_il2) everywhere
+#endif
+// ---- the two-columns-per-lane sweep once more, written for its instruction count ---------------------------------------------
+// A SIMD issues about one instruction per 2.6 cycles whatever pipe it goes to: a row costs what its vector AND
+// scalar AND branch instructions add up to.  sw_extend_il2 spends 69 scalar instructions and 15 branches per row on a control
+// flow the compiler derives from nested breaks and from conditions it cannot prove uniform (boolean phis materialised as
+// s_cselect_b64 / s_and_b64 exec pairs, v_cmp + s_cmp for a compare of two scalars).  Here every loop-carried scalar is pinned to a
+// scalar register (see smax2 / smin2 below for what was dragging them onto the vector pipe), every
+// break sits at the top level of the loop body, and the rare parts (N rows, the rows past the query end, z-drop) are out of line.
+// Same arithmetic, same order of evaluation as sw_extend_il2<false> (which stays, for the sliding sweep and as the reference the
+// tests compare this one with: BPSW_EXT_LEAN=0 at build time).
+// min / max of two SCALARS whose result stays scalar: the DAG combiner folds max(max(a, b), c) into a three-operand node that exists
+// only as a vector instruction (v_max3_i32), and the vector result then drags every user -- the band ends, the whole row control --
+// onto the vector pipe.  The readfirstlane hides the inner result from that combine and folds away when its operand is scalar.
+__device__ __forceinline__ int smax2(int a, int b) { return __builtin_amdgcn_readfirstlane(max(a, b)); }
+__device__ __forceinline__ int smin2(int a, int b) { return __builtin_amdgcn_readfirstlane(min(a, b)); }
+template <class QC>
+__device__ ExtRes sw_extend_lean2(const int lane, const int qLen, const int tLen, const QC& qcode,
+                                  const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
+                                  const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
+                                  const int zmode, const int h0, const int amax) {
+  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
+  int Hs[2], Es[2], plo[2], phi2 = 0;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = 2 * lane + s;
+    const int code = j < qLen ? qcode(j) : 4;
+    const int sh = 8 * code;
+    plo[s] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
+                   (((mat.row[3] >> sh) & 0xff) << 24));
+    phi2 |= (int)((mat.row[4] >> sh) & 0xff) << (8 * s);
+    Hs[s] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
+    Es[s] = 0;
+  }
+  const int jE0 = 2 * lane * eIns - oeIns;  // j*eIns - oeIns of the even column; the odd one adds eIns
+  const int kC = oeIns - eIns;              // (j-1)*eIns = (j*eIns - oeIns) + kC
+  const int col0 = 2 * lane, col1 = 2 * lane + 1;
+  int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+  int beg = 0, end = qLen, h1raw = h0 - oDel;
+  const int i_tail = amax > 0 ? qLen : 0x7fffffff;
+  const int w1 = w + 1;
+  for (int i = 0; i < tLen; ++i) {
+    if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
+      const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
+      const int stop = (U <= mx ? 1 : 0) & (U < gscore ? 1 : 0);
+      if (stop) break;
+    }
+    const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base
+    h1raw -= eDel;
+    const int h1 = smax2(0, h1raw);    // SWUtil.scala:137-138
+    beg = smax2(beg, i - w);           // SWUtil.scala:140-142
+    end = smin2(smin2(end, i + w1), qLen);
+    const int span = end - beg;
+    const unsigned spanA = (unsigned)smax2(span, 0);
+    int scv[2];
+    if (__builtin_expect(tsv == 32, 0)) {  // an N row
+      scv[0] = __builtin_amdgcn_sbfe(phi2, 0u, 8u);
+      scv[1] = __builtin_amdgcn_sbfe(phi2, 8u, 8u);
+      asm volatile("" : "+v"(scv[0]), "+v"(scv[1]));  // keeps the branch: two selects per row otherwise
+    } else {
+      scv[0] = __builtin_amdgcn_sbfe(plo[0], (unsigned)tsv, 8u);
+      scv[1] = __builtin_amdgcn_sbfe(plo[1], (unsigned)tsv, 8u);
+    }
+    const unsigned rel0 = (unsigned)(col0 - beg), rel1 = (unsigned)(col1 - beg);
+    const bool act0 = rel0 < spanA, act1 = rel1 < spanA;
+    const int a0 = act0 ? max(Hs[0] + scv[0], Es[0]) : NEG_A;
+    const int a1 = act1 ? max(Hs[1] + scv[1], Es[1]) : NEG_A;
+    const int Pg0 = a0 + jE0, Pg1 = a1 + jE0 + eIns;
+    int Pl = max(Pg0, Pg1);
+    int scan_a = max((a0 << 7) | col0, (a1 << 7) | col1);  // the row maximum and its LAST column in one scan
+    dual_scan_max(Pl, scan_a);
+    const int Pprev = wave_shr1(NEG, Pl);
+    const int H0 = max3i(a0, Pprev - kC - jE0, 0);
+    const int H1 = max3i(a1, max(Pprev, Pg0) - kC - jE0 - eIns, 0);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(act0), m1 = __builtin_amdgcn_ballot_w64(act1);
+    const unsigned long long z0 = __builtin_amdgcn_ballot_w64(H0 < 1) & m0, z1 = __builtin_amdgcn_ballot_w64(H1 < 1) & m1;
+    const int En0 = act0 ? max3i(Es[0] - eDel, H0 - oeDel, 0) : 0;
+    const int En1 = act1 ? max3i(Es[1] - eDel, H1 - oeDel, 0) : 0;
+    const int hs0 = wave_shr1(h1, H1), hs1 = H0;  // H(i,j-1)
+    Hs[0] = rel0 == 0u ? h1 : hs0;               // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_il2)
+    Hs[1] = rel1 == 0u ? h1 : hs1;
+    Es[0] = En0;
+    Es[1] = En1;
+    const int mkey = smax2(0, __builtin_amdgcn_readlane(scan_a, 63));
+    const int m = mkey >> 7, mj = mkey & 127;
+
+    // SWUtil.scala:177-182: j after the column loop is end (or beg for an empty band); h1 there is eh[end].h
+    const int jlast = span > 0 ? end : beg;
+    if (jlast == qLen) {
+      int hlast = h1;
+      if (span > 0) {
+        const int he = __builtin_amdgcn_readlane(Hs[0], end >> 1), ho = __builtin_amdgcn_readlane(Hs[1], end >> 1);
+        hlast = (end & 1) ? ho : he;
+      }
+      const bool better = gscore <= hlast;
+      max_ie = better ? i : max_ie;
+      gscore = better ? hlast : gscore;
+    }
+    if (m == 0) break;  // SWUtil.scala:184-185
+    if (m > mx) {       // SWUtil.scala:187-193
+      const int d = mj - i;
+      max_off = smax2(max_off, smax2(d, -d));
+      mx = m; max_i = i; max_j = mj;
+    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      const int stop = zdrop_stop((i - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode) ? 1 : 0;
+      if (stop) break;
+    }
+    // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj
+    const int nb0 = beg + (h1 == 0 ? 1 : 0);
+    if ((z0 | z1) == 0ull) {  // no zero in the band at all
+      beg = nb0;
+      end = end + 1;
+    } else {
+      const int ze_l = s_lead_zeros(z0 & s_below_mask((mj + 1) >> 1));  // even columns 2l < mj
+      const int zo_l = s_lead_zeros(z1 & s_below_mask(mj >> 1));        // odd columns 2l+1 < mj
+      const int cl = smax2(ze_l >= 0 ? 2 * (63 - ze_l) : -1, zo_l >= 0 ? 2 * (63 - zo_l) + 1 : -1);
+      const int se = (mj + 2) >> 1, so = (mj + 1) >> 1;                 // first even / odd lane with a column > mj
+      const int fe = s_first_one((z0 >> ((mj + 1) >> 1)) >> ((mj + 1) & 1));
+      const int fo = s_first_one(z1 >> so);
+      const int cr = smin2(fe >= 0 ? 2 * (se + fe) : 1 << 20, fo >= 0 ? 2 * (so + fo) + 1 : 1 << 20);
+      beg = cl >= 0 ? cl + 2 : nb0;
+      end = cr < (1 << 20) ? cr + 1 : end + 1;
+    }
+  }
+  ExtRes r;
+  r.max = mx; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+  return r;
+}
+
+// The sliding 128-column window (sw_extend_il2<true>: flanks of any length, continuation of a call the slot sweep started) in the
+// same style.  `in` / `eh` / `overflow` as there.
+template <class QC>
+__device__ ExtRes sw_extend_leanS(const int lane, const int qLen, const int tLen, const QC& qcode,
+                                  const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
+                                  const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
+                                  const int zmode, const int h0, const int amax, const int2* __restrict__ eh,
+                                  const ExtCarry* __restrict__ in, int* __restrict__ overflow) {
+  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
+  const auto cin = [&](int ExtCarry::*f, const int fresh) { return in ? __builtin_amdgcn_readfirstlane(in->*f) : fresh; };
+  int Hs[2], Es[2], plo[2], phi2 = 0;
+  int base = in ? (smax2(cin(&ExtCarry::beg, 0), cin(&ExtCarry::row, 0) - w) & ~1) : 0;  // first column of the window (even)
+  const auto load_profile = [&]() {
+    phi2 = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int j = base + 2 * lane + s;
+      const int code = j < qLen ? qcode(j) : 4;
+      const int sh = 8 * code;
+      plo[s] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
+                     (((mat.row[3] >> sh) & 0xff) << 24));
+      phi2 |= (int)((mat.row[4] >> sh) & 0xff) << (8 * s);
+    }
+  };
+  load_profile();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = base + 2 * lane + s;
+    if (in) {
+      const int2 v = j <= qLen ? eh[j] : make_int2(0, 0);
+      Hs[s] = v.x;
+      Es[s] = v.y;
+    } else {
+      Hs[s] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
+      Es[s] = 0;
+    }
+  }
+  const int jE0 = 2 * lane * eIns - oeIns;  // j*eIns - oeIns of the even column, j counted from the window's origin
+  const int kC = oeIns - eIns;
+  const int col0 = 2 * lane, col1 = 2 * lane + 1;  // window coordinates
+  int mx = cin(&ExtCarry::mx, h0), max_i = cin(&ExtCarry::max_i, -1), max_j = cin(&ExtCarry::max_j, -1);
+  int max_ie = cin(&ExtCarry::max_ie, -1), gscore = cin(&ExtCarry::gscore, -1), max_off = cin(&ExtCarry::max_off, 0);
+  int beg = cin(&ExtCarry::beg, 0), end = cin(&ExtCarry::end, qLen), h1raw = cin(&ExtCarry::h1raw, h0 - oDel);
+  const int i0 = cin(&ExtCarry::row, 0);
+  const int i_tail = amax > 0 ? qLen : 0x7fffffff;
+  const int w1 = w + 1;
+  for (int i = i0; i < tLen; ++i) {
+    if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
+      const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
+      const int stop = (U <= mx ? 1 : 0) & (U < gscore ? 1 : 0);
+      if (stop) break;
+    }
+    const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base
+    h1raw -= eDel;
+    const int h1 = smax2(0, h1raw);    // SWUtil.scala:137-138
+    beg = smax2(beg, i - w);           // SWUtil.scala:140-142
+    end = smin2(smin2(end, i + w1), qLen);
+    if (end - base > 127) {  // column `end` (written this row) lies beyond the window: move the window up
+      const int nb = beg & ~1;
+      if (end - nb > 127) {  // a band wider than the window: not for this sweep
+        *overflow = 1;
+        return ExtRes{0, 0, 0, 0, 0, 0};
+      }
+      const int from = (lane + ((nb - base) >> 1)) << 2;  // byte address of the source lane; lanes past 63 wrap and fetch
+#pragma unroll                                            // columns the band has not reached yet (never read before written)
+      for (int s = 0; s < 2; ++s) {
+        Hs[s] = __builtin_amdgcn_ds_bpermute(from, Hs[s]);
+        Es[s] = __builtin_amdgcn_ds_bpermute(from, Es[s]);
+      }
+      base = nb;
+      load_profile();
+    }
+    const int rbeg = beg - base;       // the band in window coordinates
+    const int span = end - beg;
+    const unsigned spanA = (unsigned)smax2(span, 0);
+    int scv[2];
+    if (__builtin_expect(tsv == 32, 0)) {  // an N row
+      scv[0] = __builtin_amdgcn_sbfe(phi2, 0u, 8u);
+      scv[1] = __builtin_amdgcn_sbfe(phi2, 8u, 8u);
+      asm volatile("" : "+v"(scv[0]), "+v"(scv[1]));  // keeps the branch: two selects per row otherwise
+    } else {
+      scv[0] = __builtin_amdgcn_sbfe(plo[0], (unsigned)tsv, 8u);
+      scv[1] = __builtin_amdgcn_sbfe(plo[1], (unsigned)tsv, 8u);
+    }
+    const unsigned rel0 = (unsigned)(col0 - rbeg), rel1 = (unsigned)(col1 - rbeg);
+    const bool act0 = rel0 < spanA, act1 = rel1 < spanA;
+    const int a0 = act0 ? max(Hs[0] + scv[0], Es[0]) : NEG_A;
+    const int a1 = act1 ? max(Hs[1] + scv[1], Es[1]) : NEG_A;
+    const int Pg0 = a0 + jE0, Pg1 = a1 + jE0 + eIns;
+    int Pl = max(Pg0, Pg1);
+    int scan_a = max((a0 << 7) | col0, (a1 << 7) | col1);  // the row maximum and its LAST column (window coordinates) in one scan
+    dual_scan_max(Pl, scan_a);
+    const int Pprev = wave_shr1(NEG, Pl);
+    const int H0 = max3i(a0, Pprev - kC - jE0, 0);
+    const int H1 = max3i(a1, max(Pprev, Pg0) - kC - jE0 - eIns, 0);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(act0), m1 = __builtin_amdgcn_ballot_w64(act1);
+    const unsigned long long z0 = __builtin_amdgcn_ballot_w64(H0 < 1) & m0, z1 = __builtin_amdgcn_ballot_w64(H1 < 1) & m1;
+    const int En0 = act0 ? max3i(Es[0] - eDel, H0 - oeDel, 0) : 0;
+    const int En1 = act1 ? max3i(Es[1] - eDel, H1 - oeDel, 0) : 0;
+    const int hs0 = wave_shr1(h1, H1), hs1 = H0;  // H(i,j-1)
+    Hs[0] = rel0 == 0u ? h1 : hs0;               // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_il2)
+    Hs[1] = rel1 == 0u ? h1 : hs1;
+    Es[0] = En0;
+    Es[1] = En1;
+    const int mkey = smax2(0, __builtin_amdgcn_readlane(scan_a, 63));
+    const int m = mkey >> 7, mjr = mkey & 127, mj = base + mjr;
+
+    const int jlast = span > 0 ? end : beg;  // SWUtil.scala:177-182
+    if (jlast == qLen) {
+      int hlast = h1;
+      if (span > 0) {
+        const int e = end - base;
+        const int he = __builtin_amdgcn_readlane(Hs[0], e >> 1), ho = __builtin_amdgcn_readlane(Hs[1], e >> 1);
+        hlast = (e & 1) ? ho : he;
+      }
+      const bool better = gscore <= hlast;
+      max_ie = better ? i : max_ie;
+      gscore = better ? hlast : gscore;
+    }
+    if (m == 0) break;  // SWUtil.scala:184-185
+    if (m > mx) {       // SWUtil.scala:187-193
+      const int d = mj - i;
+      max_off = smax2(max_off, smax2(d, -d));
+      mx = m; max_i = i; max_j = mj;
+    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      const int stop = zdrop_stop((i - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode) ? 1 : 0;
+      if (stop) break;
+    }
+    // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj (window coordinates + base)
+    const int nb0 = beg + (h1 == 0 ? 1 : 0);
+    if ((z0 | z1) == 0ull) {
+      beg = nb0;
+      end = end + 1;
+    } else {
+      const int ze_l = s_lead_zeros(z0 & s_below_mask((mjr + 1) >> 1));
+      const int zo_l = s_lead_zeros(z1 & s_below_mask(mjr >> 1));
+      const int cl = smax2(ze_l >= 0 ? 2 * (63 - ze_l) : -1, zo_l >= 0 ? 2 * (63 - zo_l) + 1 : -1);
+      const int se = (mjr + 2) >> 1, so = (mjr + 1) >> 1;
+      const int fe = s_first_one((z0 >> ((mjr + 1) >> 1)) >> ((mjr + 1) & 1));
+      const int fo = s_first_one(z1 >> so);
+      const int cr = smin2(fe >= 0 ? 2 * (se + fe) : 1 << 20, fo >= 0 ? 2 * (so + fo) + 1 : 1 << 20);
+      beg = cl >= 0 ? base + cl + 2 : nb0;
+      end = cr < (1 << 20) ? base + cr + 1 : end + 1;
+    }
+  }
+  ExtRes r;
+  r.max = mx; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+  return r;
+}
+
+// The one-column-per-lane sweep (qLen <= 63) in the same style: see sw_extend_lean2.
+template <class QC>
+__device__ ExtRes sw_extend_lean1(const int lane, const int qLen, const int tLen, const QC& qcode,
+                                  const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
+                                  const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
+                                  const int zmode, const int h0, const int amax) {
+  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
+  const int code = lane < qLen ? qcode(lane) : 4;
+  const int sh = 8 * code;
+  const int plo = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
+                        (((mat.row[3] >> sh) & 0xff) << 24));
+  const int phi = (int)(int8_t)((mat.row[4] >> sh) & 0xff);
+  int Hs = lane == 0 ? h0 : max(0, h0 - oeIns - (lane - 1) * eIns);  // row -1, SWUtil.scala:97-104
+  int Es = 0;
+  const int jE = lane * eIns - oeIns;  // j*eIns - oeIns
+  const int kC = oeIns - eIns;         // (j-1)*eIns = (j*eIns - oeIns) + kC
+  int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+  int beg = 0, end = qLen, h1raw = h0 - oDel;
+  const int i_tail = amax > 0 ? qLen : 0x7fffffff;
+  const int w1 = w + 1;
+  for (int i = 0; i < tLen; ++i) {
+    if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
+      const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
+      const int stop = (U <= mx ? 1 : 0) & (U < gscore ? 1 : 0);
+      if (stop) break;
+    }
+    const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base
+    h1raw -= eDel;
+    const int h1 = smax2(0, h1raw);    // SWUtil.scala:137-138
+    beg = smax2(beg, i - w);           // SWUtil.scala:140-142
+    end = smin2(smin2(end, i + w1), qLen);
+    const int span = end - beg;
+    const unsigned spanA = (unsigned)smax2(span, 0);
+    int scv;
+    if (__builtin_expect(tsv == 32, 0)) {  // an N row
+      scv = phi;
+      asm volatile("" : "+v"(scv));  // keeps the branch: a select per row otherwise
+    } else {
+      scv = __builtin_amdgcn_sbfe(plo, (unsigned)tsv, 8u);
+    }
+    const unsigned rel = (unsigned)(lane - beg);
+    const bool act = rel < spanA;
+    const int a = act ? max(Hs + scv, Es) : NEG_A;
+    const int Pg = a + jE;
+    int Pl = Pg;
+    int scan_a = (a << 7) | lane;  // the row maximum and its LAST column in one scan
+    dual_scan_max(Pl, scan_a);
+    const int Pprev = wave_shr1(NEG, Pl);
+    const int H = max3i(a, Pprev - kC - jE, 0);
+    const unsigned long long z = __builtin_amdgcn_ballot_w64(H < 1) & __builtin_amdgcn_ballot_w64(act);
+    const int En = act ? max3i(Es - eDel, H - oeDel, 0) : 0;
+    const int hs = wave_shr1(h1, H);  // H(i,j-1)
+    Hs = rel == 0u ? h1 : hs;         // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_il2)
+    Es = En;
+    const int mkey = smax2(0, __builtin_amdgcn_readlane(scan_a, 63));
+    const int m = mkey >> 7, mj = mkey & 127;
+
+    const int jlast = span > 0 ? end : beg;  // SWUtil.scala:177-182
+    if (jlast == qLen) {
+      const int hlast = span > 0 ? __builtin_amdgcn_readlane(Hs, end) : h1;  // end == qLen <= 63 here
+      const bool better = gscore <= hlast;
+      max_ie = better ? i : max_ie;
+      gscore = better ? hlast : gscore;
+    }
+    if (m == 0) break;  // SWUtil.scala:184-185
+    if (m > mx) {       // SWUtil.scala:187-193
+      const int d = mj - i;
+      max_off = smax2(max_off, smax2(d, -d));
+      mx = m; max_i = i; max_j = mj;
+    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      const int stop = zdrop_stop((i - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode) ? 1 : 0;
+      if (stop) break;
+    }
+    // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj
+    const int nb0 = beg + (h1 == 0 ? 1 : 0);
+    if (z == 0ull) {
+      beg = nb0;
+      end = end + 1;
+    } else {
+      const int lzc = s_lead_zeros(z & s_below_mask(mj));
+      const int fo = s_first_one((z >> mj) >> 1);
+      beg = lzc >= 0 ? 65 - lzc : nb0;
+      end = fo >= 0 ? mj + 2 + fo : end + 1;
+    }
+  }
+  ExtRes r;
+  r.max = mx; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+  return r;
+}
+
 // SWExtend on the register path for any qLen <= 255.  Up to 63 columns: one column per lane; up to 127: two per lane; longer
 // flanks: the sliding 128-column window (sw_extend_il2<true>), started by the slot sweep when the first rows are wider than the
 // window (eh: LDS row for the hand-over, qLen + 2 pairs; without it such calls stay on the slot sweep), and run again on the
@@ -923,6 +1293,10 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
                                                     const int zdrop, const int zmode, const int h0, const int amax,
                                                     int2* __restrict__ eh = nullptr) {
   const int slots = (qLen + 64) >> 6;
+#if BPSW_EXT_LEAN
+  if (slots == 1) return sw_extend_lean1(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+  if (slots == 2) return sw_extend_lean2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+#endif
   if (slots == 1) return sw_extend_reg<1>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 #if BPSW_EXT_INTERLEAVE
   if (slots == 2) return sw_extend_il2<false>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
@@ -934,7 +1308,11 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
     int overflow = 0;
     ExtRes r;
     if (min(qLen, w + 1) <= 127) {  // row 0's band [0, min(qLen, w+1)] fits the window
+#if BPSW_EXT_LEAN
+      r = sw_extend_leanS(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, nullptr, nullptr, &overflow);
+#else
       r = sw_extend_il2<true>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, nullptr, nullptr, &overflow);
+#endif
       if (!overflow) return r;
     } else if (eh) {
       ExtCarry c;
@@ -942,7 +1320,11 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
       r = slots == 3 ? sw_extend_reg<3>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c)
                      : sw_extend_reg<4>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c);
       if (!c.handed) return r;
+#if BPSW_EXT_LEAN
+      r = sw_extend_leanS(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c, &overflow);
+#else
       r = sw_extend_il2<true>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c, &overflow);
+#endif
       if (!overflow) return r;
     }
   }
@@ -960,8 +1342,14 @@ __device__ __forceinline__ ExtRes sw_extend_reg_short(const int lane, const int 
                                                       const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
                                                       const int eDel, const int oIns, const int eIns, const int w,
                                                       const int zdrop, const int zmode, const int h0, const int amax) {
+#if BPSW_EXT_LEAN
+  if (qLen < 64) return sw_extend_lean1(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+#else
   if (qLen < 64) return sw_extend_reg<1>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#if BPSW_EXT_INTERLEAVE
+#endif
+#if BPSW_EXT_LEAN
+  return sw_extend_lean2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+#elif BPSW_EXT_INTERLEAVE
   return sw_extend_il2<false>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 #else
   return sw_extend_reg<2>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
