@@ -81,20 +81,27 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 #endif
 // COORD: a coordinate batch (include/bpsw.h, "wire format 2") -- 40-byte task records, query flanks only, the target flanks are
 // read from the device-resident reference (bnsGetSeq of MemChainToAlignBatched.scala:363 moves to the device).
-// SHORT: the kernel for tasks whose two query flanks have at most EXT_SHORT_QMAX bases -- every task of 2x150 bp reads but a few.
-// It carries only the one- and two-columns-per-lane sweeps and the shortcuts, needs 48 VGPRs instead of 90 and no LDS but the
-// target bytes, so eight of its waves share a SIMD: a wave of this kernel is bound by the latency of its row (1 200 cycles alone
-// on a SIMD for ~230 cycles of vector and ~250 of scalar pipe time), and the rows of more waves fill each other's gaps.  It skips
-// the other tasks; the host, which has seen every record (scan_wire), sends those to the full kernel as a task list.
+// SHORT: the kernel for tasks whose two query flanks have at most `short_qmax` bases (127: every task of 2x150 bp reads but a few;
+// 255: also nearly every task of 2x250 bp reads).  It carries only the lean sweeps (one / two columns per lane, the sliding
+// window) and the shortcuts, needs 48 VGPRs instead of 87 and no LDS but the target bytes, so eight of its waves share a SIMD: a
+// wave of this kernel is bound by the latency of its row (1 200 cycles alone on a SIMD), and the rows of more waves fill each
+// other's gaps.  It skips longer tasks: the host, which has seen every record (scan_wire), lists those for the full kernel.  A
+// task that turns out to need what this kernel lacks -- a band wider than the 128-column window, on its first row (the doubled
+// band of a retry) or later -- is DEFERRED: appended to the same list (defer[0] = entries so far, defer[1..] = task indices),
+// which the full kernel, launched behind this one on the stream, reads its task count from.
 template <bool COORD, bool SHORT>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks_arg,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
                                                                      const int lds_per_wave, const int chunk, const int guide_cap,
                                                                      int* __restrict__ next_task,
-                                                                     const int* __restrict__ task_list,
-                                                                     const ExtPrepass* __restrict__ pre) {
+                                                                     const int* __restrict__ task_list_arg,
+                                                                     const ExtPrepass* __restrict__ pre,
+                                                                     int* __restrict__ defer, const int short_qmax) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // the full kernel behind a SHORT launch: its task list and count are what the host listed plus what that launch deferred
+  const int n_tasks = (!SHORT && defer) ? uni(defer[0]) : n_tasks_arg;
+  const int* __restrict__ task_list = (!SHORT && defer) ? defer + 1 : task_list_arg;
   // asynchronous entry (bpsw_extend_batch_device): the table scan ran just before on the same stream and nobody has read
   // it back yet -- a malformed batch, or one whose tasks outgrow the LDS this launch was sized for, is left untouched
   if (pre && (pre->error != 0 || pre->max_qlen > qcap || pre->max_rlen > rcap)) return;
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
     const long long seedRb = COORD ? (long long)(((unsigned long long)uni((int)rec[9]) << 32) | (unsigned)uni((int)rec[8])) : 0ll;
     const int seedLen = COORD ? uni(hi16(r4)) : 0;
     const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
-    if (SHORT && (lq > EXT_SHORT_QMAX || rq > EXT_SHORT_QMAX)) continue;  // the full kernel's task (the host lists it: ext_task_is_long)
+    if (SHORT && (lq > short_qmax || rq > short_qmax)) continue;  // the full kernel's task (the host has listed it)
+    bool deferred = false;
     const uint32_t* words = wire + (size_t)uni((int)rec[2]);
     const int regScore0 = uni(lo16(r3)), qBeg = uni(hi16(r3)), h0 = uni(lo16(r4));
     const int lMaxIns = max(1, uni(lo16(r5))), lMaxDel = max(1, uni(hi16(r5)));  // SWUtil.scala:110-115
@@ -213,7 +221,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
         if constexpr (SHORT) {
           int oInsT = oIns, eInsT = eIns;  // opaque copies, as below
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
-          r = sw_extend_reg_short(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
+          int ov = 0;
+          r = sw_extend_reg_short(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+          if (uni(ov)) { deferred = true; break; }
         } else if (reg_path) {
           // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
           // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
         regScore = uni(r.max);
         if (regScore == prev || r.max_off < (awSide >> 1) + (awSide >> 2)) break;
       }
+      if (SHORT && deferred) break;
       score = regScore;
       awMax = max(awMax, awSide);
       const bool local = r.gscore <= 0 || r.gscore <= regScore - penClip;  // local extension vs reaching the query end
@@ -238,6 +249,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
         outREnd = local ? r.tle : r.gtle;
         trueScore += (local ? regScore : r.gscore) - sc0;
       }
+    }
+    if (SHORT && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
+      if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
+      continue;
     }
     const int width = awMax;
     if (lane == 0) {  // MemChainToAlignBatched.scala:181-188: 10 int16 per task
@@ -301,8 +316,9 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
-                             const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev, bool short_kernel) {
-  if (n_tasks <= 0) return hipSuccess;
+                             const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev, bool short_kernel, int* d_defer,
+                             int short_qmax) {
+  if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
   const void* fn = short_kernel ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, true>) : reinterpret_cast<const void*>(ext_kernel<false, true>))
                                 : (coord ? reinterpret_cast<const void*>(ext_kernel<true, false>) : reinterpret_cast<const void*>(ext_kernel<false, false>));
@@ -349,7 +365,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
 #define BPSW_EXT_GO(CO, SH)                                                                                                     \
   BPSW_LAUNCH(kev, (ext_kernel<CO, SH>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap, rcap, \
-              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check)
+              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax)
   if (short_kernel) {
     if (coord) BPSW_EXT_GO(true, true); else BPSW_EXT_GO(false, true);
   } else {

@@ -1334,25 +1334,33 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
   return sw_extend_reg<4>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 }
 
-// The two sweeps that need few registers: flanks of at most EXT_SHORT_QMAX bases (one or two columns per lane, no window, no LDS row).
+// The sweeps that need few registers: one or two columns per lane and the sliding window, none of which needs an LDS row.
 // ext_kernel<.., SHORT> is built from these alone and fits 48 VGPRs -- eight waves per SIMD instead of five (bpsw_extend.hip).
-constexpr int EXT_SHORT_QMAX = 127;
+constexpr int EXT_SHORT_QMAX = 255;  // the register sweeps' limit; the host may set a launch's limit lower (127: no window, no deferral)
 template <class QC>
 __device__ __forceinline__ ExtRes sw_extend_reg_short(const int lane, const int qLen, const int tLen, const QC& qcode,
                                                       const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
                                                       const int eDel, const int oIns, const int eIns, const int w,
-                                                      const int zdrop, const int zmode, const int h0, const int amax) {
+                                                      const int zdrop, const int zmode, const int h0, const int amax,
+                                                      int* __restrict__ overflow) {
 #if BPSW_EXT_LEAN
   if (qLen < 64) return sw_extend_lean1(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+  if (qLen < 128) return sw_extend_lean2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+  // longer flanks (the kernel admits them up to 255 bases): the sliding window, when row 0's band [0, min(qLen, w+1)] fits it and
+  // as long as no later row outgrows it -- else *overflow = 1 and the task goes to the full kernel
+  if (min(qLen, w + 1) > 127) {
+    *overflow = 1;
+    return ExtRes{0, 0, 0, 0, 0, 0};
+  }
+  return sw_extend_leanS(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, nullptr, nullptr, overflow);
 #else
   if (qLen < 64) return sw_extend_reg<1>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#endif
-#if BPSW_EXT_LEAN
-  return sw_extend_lean2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#elif BPSW_EXT_INTERLEAVE
+  if (qLen >= 128) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
+#if BPSW_EXT_INTERLEAVE
   return sw_extend_il2<false>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
 #else
   return sw_extend_reg<2>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+#endif
 #endif
 }
 

@@ -84,8 +84,10 @@ size_t ext_lds_per_wave(int qcap, int rcap);
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false, KernelEvents kev = KernelEvents(),
-                             bool short_kernel = false);
-// short_kernel: the 48-VGPR variant for tasks whose query flanks have at most 127 bases; it skips the others (bpsw_extend.hip)
+                             bool short_kernel = false, int* d_defer = nullptr, int short_qmax = 127);
+// short_kernel: the 48-VGPR variant for tasks whose query flanks have at most short_qmax bases; it skips the others and appends
+// the tasks it cannot finish to d_defer ([0] = count, [1..] = task indices).  The full kernel with d_defer set reads its task count
+// and list from there (n_tasks then only sizes the grid) -- bpsw_extend.hip
 // Quad-task kernel (bpsw_extend_qt.hip): s_cols = 4 (sides <= 63 bp) or 9 (<= 143 bp).
 hipError_t launch_ext_qt_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, const int* d_list, int n_list,
                                 int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter, hipStream_t s);

@@ -505,7 +505,7 @@ static inline int rd32(const uint8_t* b, size_t at) {
 // Validates a wire batch on the host.  *coord: the batch is a coordinate batch (wire format 2: byte 7 of the header is 2, 40-byte
 // records, query flanks only); l_pac is the length of the loaded reference (0: none), needed to check its coordinates.
 static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_out, int* maxq, int* maxr, bool* coord,
-                     std::vector<int>* long_tasks, int* maxr_short) {
+                     std::vector<int>* long_tasks, int* maxr_short, bool* any_mid) {
   if (!wire || bytes < 32 || (bytes & 3)) return fail(BPSW_ERR_ARG, "extend: wire batch shorter than its header or not word sized");
   const int n = rd32(wire, 8);
   const int fmt = wire[7];
@@ -520,10 +520,12 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
   const int wband = (int8_t)wire[6];
   int mq = 0, mr = 0, mrs = 0;
   const size_t words = bytes >> 2;
-  // tasks for the full kernel (a query flank above 127 bases; every task when the gap costs rule out the register sweeps):
-  // the 48-VGPR kernel serves the others (bpsw_extend.hip, ext_kernel<.., SHORT>)
+  // tasks for the full kernel (a query flank above 255 bases; every task when the gap costs rule out the register sweeps):
+  // the 48-VGPR kernel serves the others (bpsw_extend.hip, ext_kernel<.., SHORT>); "mid" tasks (a flank of 128-255 bases) run
+  // on its sliding window and may be deferred to the full kernel from the device
   const bool all_long = (int8_t)wire[2] + (int8_t)wire[3] <= 0;
   long_tasks->clear();
+  bool mid = false;
   for (int t = 0; t < n; ++t) {
     const size_t at = 32 + rec_bytes * (size_t)t;
     const int lq = rd16(wire, at), lr = rd16(wire, at + 2), rq = rd16(wire, at + 4), rr = rd16(wire, at + 6);
@@ -534,7 +536,8 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
       return fail(BPSW_ERR_ARG, "extend: task sequence offset outside the buffer");
     if (lq > mq) mq = lq;
     if (rq > mq) mq = rq;
-    const bool is_long = all_long || lq > 127 || rq > 127;
+    const bool is_long = all_long || lq > 255 || rq > 255;
+    if (!is_long && (lq > 127 || rq > 127)) mid = true;
     if (is_long) long_tasks->push_back(t);
     int task_mr = 0;
     if (co) {
@@ -555,7 +558,7 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
     if (!is_long && task_mr > mrs) mrs = task_mr;
   }
   if (mq > BPSW_EXT_MAX_QLEN || mr > BPSW_EXT_MAX_RLEN) return fail(BPSW_ERR_LIMIT, "extend: sequence longer than the kernel limit");
-  *n_out = n; *maxq = mq; *maxr = mr; *coord = co; *maxr_short = mrs;
+  *n_out = n; *maxq = mq; *maxr = mr; *coord = co; *maxr_short = mrs; *any_mid = mid;
   return BPSW_OK;
 }
 
@@ -582,16 +585,21 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   if (wire && wire_bytes >= 32 && wire[7] == BPSW_WIRE_COORDS) ref_hold = ref_snapshot(c, &d_pac, &l_pac);
   std::vector<int>& long_tasks = c->ext_long_tasks;
   int mr_short = 0;
-  int rc = scan_wire(wire, wire_bytes, l_pac, &n, &mq, &mr, &coord, &long_tasks, &mr_short);
+  bool any_mid = false;
+  int rc = scan_wire(wire, wire_bytes, l_pac, &n, &mq, &mr, &coord, &long_tasks, &mr_short, &any_mid);
   if (rc != BPSW_OK) return rc;
   // Launch plan: the 48-VGPR kernel over the whole batch (it skips the long tasks) and the full kernel over the list of long
   // ones -- or the full kernel alone when most tasks are long (2x250 bp reads) or the split is switched off (BPSW_EXT_SPLIT=0)
   static const bool split_on = !(getenv("BPSW_EXT_SPLIT") && atoi(getenv("BPSW_EXT_SPLIT")) == 0);
   const int n_long = (int)long_tasks.size();
   const bool use_short = split_on && 2 * (size_t)n_long <= (size_t)n;
-  const bool use_full = !use_short || n_long > 0;
+  const bool use_full = !use_short || n_long > 0 || any_mid;  // any_mid: the 48-VGPR kernel may defer tasks from the device
+  // behind the wire bytes: the full kernel's list as [count, task indices...]; the host stages its own entries and the count, the
+  // 48-VGPR kernel appends (room for every task)
   const size_t list_off = (wire_bytes + 15) & ~(size_t)15;
-  const size_t stage_bytes = (use_short && use_full) ? list_off + 4 * (size_t)n_long : wire_bytes;
+  const bool with_list = use_short && use_full;
+  const size_t stage_bytes = with_list ? list_off + 4 * (1 + (size_t)n_long) : wire_bytes;
+  const size_t dev_bytes = with_list ? list_off + 4 * (1 + (size_t)n) : wire_bytes;
   if (!out || out_len < 10 * (size_t)n) return fail(BPSW_ERR_CAPACITY, "extend: result buffer smaller than 10*n int16");
   if (n == 0) return BPSW_OK;
   { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
@@ -599,7 +607,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // (32-byte result slots in the pinned buffer were tried: the 16 + 4 byte stores of a record then cost two write sectors each,
   // more fabric writes than back-to-back 20-byte records that merge in L2, and the host-side gather cost more than the memcpy)
   bool zc_slots = false;
-  HIP_TRY(c->d_wire.reserve(stage_bytes));
+  HIP_TRY(c->d_wire.reserve(dev_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
 #ifdef BPSW_EXPERIMENTAL_KERNELS
   HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n + 16));
@@ -608,7 +616,11 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_bytes));
   const double t_in = wall_ms();
   memcpy(c->h_stage_in.ptr, wire, wire_bytes);
-  if (stage_bytes > wire_bytes) memcpy((char*)c->h_stage_in.ptr + list_off, long_tasks.data(), 4 * (size_t)n_long);  // rides on the same copy
+  if (with_list) {  // rides on the same copy
+    int* hl = (int*)((char*)c->h_stage_in.ptr + list_off);
+    hl[0] = n_long;
+    if (n_long) memcpy(hl + 1, long_tasks.data(), 4 * (size_t)n_long);
+  }
   const double t_staged = wall_ms();
   double t_dev0, t_dev1;
   bool kernel_was_last = false;
@@ -642,18 +654,21 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       }
       on_dispatch = true;
       int* d_queue = (int*)((char*)c->d_pre.ptr + 128);
+      int* d_list = with_list ? (int*)((char*)c->d_wire.ptr + list_off) : nullptr;
       if (use_short) {
         KernelEvents kev;
         kev.start = c->ev[1]; kev.stop = use_full ? nullptr : c->ev[2];
-        HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 127), mr_short, c->num_cu, d_queue, nullptr, s,
-                                  nullptr, false, kev, true));
+        HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 255), mr_short, c->num_cu, d_queue, nullptr, s,
+                                  nullptr, false, kev, true, d_list, any_mid ? 255 : 127));
       }
       if (use_full) {
         KernelEvents kev;
         kev.start = use_short ? nullptr : c->ev[1]; kev.stop = c->ev[2];
-        const int* d_list = use_short ? (const int*)((const char*)c->d_wire.ptr + list_off) : nullptr;
-        HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, use_short ? n_long : n, k_out, sc, mq, mr, c->num_cu, d_queue, d_list, s,
-                                  nullptr, false, kev, false));
+        // behind the 48-VGPR kernel: the list it completed on the device (grid sized for what it can hold at most: the mid tasks
+        // are a subset of all -- a handful of workgroups when the host listed nothing itself)
+        const int grid_tasks = !use_short ? n : (any_mid ? std::max(n_long, std::min(n, 4 * c->num_cu)) : n_long);
+        HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, grid_tasks, k_out, sc, mq, mr, c->num_cu, d_queue, nullptr, s,
+                                  nullptr, false, kev, false, use_short ? d_list : nullptr));
       }
       if (side_how) HIP_TRY(hipMemcpyAsync(side_how, c->d_ext_lists.ptr, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
     }
