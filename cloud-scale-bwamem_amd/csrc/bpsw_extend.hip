@@ -89,7 +89,8 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 // task that turns out to need what this kernel lacks -- a band wider than the 128-column window, on its first row (the doubled
 // band of a retry) or later -- is DEFERRED: appended to the same list (defer[0] = entries so far, defer[1..] = task indices),
 // which the full kernel, launched behind this one on the stream, reads its task count from.
-template <bool COORD, bool SHORT>
+// SHORT: 0 the full kernel; 1 flanks up to 127 bases (no window: the leanest build, what 2x150 bp batches run on); 2 up to 255
+template <bool COORD, int SHORT>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks_arg,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
   // the full kernel behind a SHORT launch: its task list and count are what the host listed plus what that launch deferred
   const int n_tasks = (!SHORT && defer) ? uni(defer[0]) : n_tasks_arg;
   const int* __restrict__ task_list = (!SHORT && defer) ? defer + 1 : task_list_arg;
+  if (!SHORT && defer && n_tasks == 0) return;  // nothing was listed or deferred: the queue heads stay as they are (zero)
   // asynchronous entry (bpsw_extend_batch_device): the table scan ran just before on the same stream and nobody has read
   // it back yet -- a malformed batch, or one whose tasks outgrow the LDS this launch was sized for, is left untouched
   if (pre && (pre->error != 0 || pre->max_qlen > qcap || pre->max_rlen > rcap)) return;
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
           int oInsT = oIns, eInsT = eIns;  // opaque copies, as below
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
           int ov = 0;
-          r = sw_extend_reg_short(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
-          if (uni(ov)) { deferred = true; break; }
+          r = sw_extend_reg_short<SHORT == 2>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+          if (SHORT == 2 && uni(ov)) { deferred = true; break; }
         } else if (reg_path) {
           // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
           // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
         regScore = uni(r.max);
         if (regScore == prev || r.max_off < (awSide >> 1) + (awSide >> 2)) break;
       }
-      if (SHORT && deferred) break;
+      if (SHORT == 2 && deferred) break;
       score = regScore;
       awMax = max(awMax, awSide);
       const bool local = r.gscore <= 0 || r.gscore <= regScore - penClip;  // local extension vs reaching the query end
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PE
         trueScore += (local ? regScore : r.gscore) - sc0;
       }
     }
-    if (SHORT && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
+    if (SHORT == 2 && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
       if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
       continue;
     }
@@ -320,8 +322,10 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
                              int short_qmax) {
   if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
-  const void* fn = short_kernel ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, true>) : reinterpret_cast<const void*>(ext_kernel<false, true>))
-                                : (coord ? reinterpret_cast<const void*>(ext_kernel<true, false>) : reinterpret_cast<const void*>(ext_kernel<false, false>));
+  const int variant = !short_kernel ? 0 : (short_qmax <= 127 ? 1 : 2);
+  const void* fn = variant == 0 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 0>) : reinterpret_cast<const void*>(ext_kernel<false, 0>))
+                 : variant == 1 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 1>) : reinterpret_cast<const void*>(ext_kernel<false, 1>))
+                                : (coord ? reinterpret_cast<const void*>(ext_kernel<true, 2>) : reinterpret_cast<const void*>(ext_kernel<false, 2>));
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
   rcap = (rcap + 63) & ~63;
@@ -329,8 +333,8 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   const size_t lds = per_wave * WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device
-  static std::atomic<size_t> attr_set_v[4][64];
-  std::atomic<size_t>* attr_set = attr_set_v[(coord ? 1 : 0) + (short_kernel ? 2 : 0)];
+  static std::atomic<size_t> attr_set_v[6][64];
+  std::atomic<size_t>* attr_set = attr_set_v[(coord ? 1 : 0) + 2 * variant];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (lds > 64 * 1024 && lds > attr_set[dev].load(std::memory_order_relaxed)) {
@@ -366,10 +370,12 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
 #define BPSW_EXT_GO(CO, SH)                                                                                                     \
   BPSW_LAUNCH(kev, (ext_kernel<CO, SH>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap, rcap, \
               (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax)
-  if (short_kernel) {
-    if (coord) BPSW_EXT_GO(true, true); else BPSW_EXT_GO(false, true);
+  if (variant == 1) {
+    if (coord) BPSW_EXT_GO(true, 1); else BPSW_EXT_GO(false, 1);
+  } else if (variant == 2) {
+    if (coord) BPSW_EXT_GO(true, 2); else BPSW_EXT_GO(false, 2);
   } else {
-    if (coord) BPSW_EXT_GO(true, false); else BPSW_EXT_GO(false, false);
+    if (coord) BPSW_EXT_GO(true, 0); else BPSW_EXT_GO(false, 0);
   }
 #undef BPSW_EXT_GO
   return hipGetLastError();

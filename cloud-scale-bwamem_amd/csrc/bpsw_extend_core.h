@@ -1337,7 +1337,7 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
 // The sweeps that need few registers: one or two columns per lane and the sliding window, none of which needs an LDS row.
 // ext_kernel<.., SHORT> is built from these alone and fits 48 VGPRs -- eight waves per SIMD instead of five (bpsw_extend.hip).
 constexpr int EXT_SHORT_QMAX = 255;  // the register sweeps' limit; the host may set a launch's limit lower (127: no window, no deferral)
-template <class QC>
+template <bool WINDOW, class QC>
 __device__ __forceinline__ ExtRes sw_extend_reg_short(const int lane, const int qLen, const int tLen, const QC& qcode,
                                                       const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
                                                       const int eDel, const int oIns, const int eIns, const int w,
@@ -1345,9 +1345,9 @@ __device__ __forceinline__ ExtRes sw_extend_reg_short(const int lane, const int 
                                                       int* __restrict__ overflow) {
 #if BPSW_EXT_LEAN
   if (qLen < 64) return sw_extend_lean1(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-  if (qLen < 128) return sw_extend_lean2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-  // longer flanks (the kernel admits them up to 255 bases): the sliding window, when row 0's band [0, min(qLen, w+1)] fits it and
-  // as long as no later row outgrows it -- else *overflow = 1 and the task goes to the full kernel
+  if (!WINDOW || qLen < 128) return sw_extend_lean2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+  // longer flanks (the WINDOW build of the kernel admits them up to 255 bases): the sliding window, when row 0's band
+  // [0, min(qLen, w+1)] fits it and as long as no later row outgrows it -- else *overflow = 1 and the task goes to the full kernel
   if (min(qLen, w + 1) > 127) {
     *overflow = 1;
     return ExtRes{0, 0, 0, 0, 0, 0};

@@ -377,7 +377,7 @@ struct bpsw_ctx {
 
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
   int shortcut_mask = 31;  // bpsw_set_ext_shortcuts
-  std::vector<int> ext_long_tasks;  // scratch of bpsw_extend_batch: the tasks of the current batch that go to the full kernel
+  std::vector<int> ext_long_tasks, ext_mid_tasks;  // scratch of bpsw_extend_batch: the tasks of the current batch that go to the full kernel / have a flank of 128-255 bases
   double wait_est_ms[2] = {0., 0.};  // wait_event: running average of the device-phase waits (extension, SW)
   void* rescue_scratch = nullptr;  // bpsw_rescue.cpp: vectors reused across bpsw_matesw_group calls (freed by rescue_scratch_free)
   bpsw_stats_t stats;

@@ -505,7 +505,7 @@ static inline int rd32(const uint8_t* b, size_t at) {
 // Validates a wire batch on the host.  *coord: the batch is a coordinate batch (wire format 2: byte 7 of the header is 2, 40-byte
 // records, query flanks only); l_pac is the length of the loaded reference (0: none), needed to check its coordinates.
 static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_out, int* maxq, int* maxr, bool* coord,
-                     std::vector<int>* long_tasks, int* maxr_short, bool* any_mid) {
+                     std::vector<int>* long_tasks, std::vector<int>* mid_tasks, int* maxr_short, int* n_mid_out) {
   if (!wire || bytes < 32 || (bytes & 3)) return fail(BPSW_ERR_ARG, "extend: wire batch shorter than its header or not word sized");
   const int n = rd32(wire, 8);
   const int fmt = wire[7];
@@ -525,7 +525,8 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
   // on its sliding window and may be deferred to the full kernel from the device
   const bool all_long = (int8_t)wire[2] + (int8_t)wire[3] <= 0;
   long_tasks->clear();
-  bool mid = false;
+  mid_tasks->clear();
+  int mid = 0;
   for (int t = 0; t < n; ++t) {
     const size_t at = 32 + rec_bytes * (size_t)t;
     const int lq = rd16(wire, at), lr = rd16(wire, at + 2), rq = rd16(wire, at + 4), rr = rd16(wire, at + 6);
@@ -537,7 +538,8 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
     if (lq > mq) mq = lq;
     if (rq > mq) mq = rq;
     const bool is_long = all_long || lq > 255 || rq > 255;
-    if (!is_long && (lq > 127 || rq > 127)) mid = true;
+    const bool is_mid = !is_long && (lq > 127 || rq > 127);
+    if (is_mid) { ++mid; mid_tasks->push_back(t); }
     if (is_long) long_tasks->push_back(t);
     int task_mr = 0;
     if (co) {
@@ -558,7 +560,7 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
     if (!is_long && task_mr > mrs) mrs = task_mr;
   }
   if (mq > BPSW_EXT_MAX_QLEN || mr > BPSW_EXT_MAX_RLEN) return fail(BPSW_ERR_LIMIT, "extend: sequence longer than the kernel limit");
-  *n_out = n; *maxq = mq; *maxr = mr; *coord = co; *maxr_short = mrs; *any_mid = mid;
+  *n_out = n; *maxq = mq; *maxr = mr; *coord = co; *maxr_short = mrs; *n_mid_out = mid;
   return BPSW_OK;
 }
 
@@ -585,9 +587,19 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   if (wire && wire_bytes >= 32 && wire[7] == BPSW_WIRE_COORDS) ref_hold = ref_snapshot(c, &d_pac, &l_pac);
   std::vector<int>& long_tasks = c->ext_long_tasks;
   int mr_short = 0;
-  bool any_mid = false;
-  int rc = scan_wire(wire, wire_bytes, l_pac, &n, &mq, &mr, &coord, &long_tasks, &mr_short, &any_mid);
+  int n_mid = 0;
+  std::vector<int>& mid_tasks = c->ext_mid_tasks;
+  int rc = scan_wire(wire, wire_bytes, l_pac, &n, &mq, &mr, &coord, &long_tasks, &mid_tasks, &mr_short, &n_mid);
   if (rc != BPSW_OK) return rc;
+  // A batch with few mid tasks (2x150 bp reads: the flanks of 128-131 bases) runs the build without the window, whose rows cost
+  // 4 % less, and lists its mid tasks for the full kernel like the long ones; a batch of mostly mid tasks (2x250 bp) runs the
+  // window build, which defers on the device.
+  const bool window_build = 16 * (size_t)n_mid > (size_t)n;
+  if (!window_build && n_mid > 0) {
+    long_tasks.insert(long_tasks.end(), mid_tasks.begin(), mid_tasks.end());
+    n_mid = 0;
+  }
+  const bool any_mid = n_mid > 0;
   // Launch plan: the 48-VGPR kernel over the whole batch (it skips the long tasks) and the full kernel over the list of long
   // ones -- or the full kernel alone when most tasks are long (2x250 bp reads) or the split is switched off (BPSW_EXT_SPLIT=0)
   static const bool split_on = !(getenv("BPSW_EXT_SPLIT") && atoi(getenv("BPSW_EXT_SPLIT")) == 0);
@@ -664,9 +676,10 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       if (use_full) {
         KernelEvents kev;
         kev.start = use_short ? nullptr : c->ev[1]; kev.stop = c->ev[2];
-        // behind the 48-VGPR kernel: the list it completed on the device (grid sized for what it can hold at most: the mid tasks
-        // are a subset of all -- a handful of workgroups when the host listed nothing itself)
-        const int grid_tasks = !use_short ? n : (any_mid ? std::max(n_long, std::min(n, 4 * c->num_cu)) : n_long);
+        // behind the 48-VGPR kernel: the list it completed on the device (what it may have deferred is unknown to the host
+        // -- a subset of the mid tasks, normally a small one: a quarter of them sizes the grid; an empty list costs a launch that
+        // returns at once)
+        const int grid_tasks = !use_short ? n : n_long + (n_mid + 3) / 4 + (any_mid ? 4 : 0);
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, grid_tasks, k_out, sc, mq, mr, c->num_cu, d_queue, nullptr, s,
                                   nullptr, false, kev, false, use_short ? d_list : nullptr));
       }

@@ -762,7 +762,8 @@ constexpr int PK_MATE_LDS = 320;       // bytes per staged mate: (PK_LAST + 1) *
 constexpr int PK_KEY_PAD = 128;        // steps past the last target row: pipe depth (<= 56) + group rounding + the tail lanes
 constexpr int PK_KEYS_LDS_MAX = 1536;  // rows; 4 waves x (1536 + 128) words = 26 KB per workgroup
 template <int C, bool KL>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void swp_kernel(const SwJobsDev jobs, const SwScoring sc, const int bias,
+// (five waves per SIMD for up to three columns per lane: 91 VGPRs without a spill instead of 97; more columns keep four)
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? 5 : 4) void swp_kernel(const SwJobsDev jobs, const SwScoring sc, const int bias,
                                                                      int32_t* __restrict__ out,
                                                                      uint32_t* __restrict__ scratch,
                                                                      const int scratch_per_job,

@@ -20,7 +20,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        k = "extend" if "ext_kernel" in r["Kernel_Name"] else ("swalign2" if "swp_kernel" in r["Kernel_Name"] else None)
+        k = ("extend_full" if ", 0>" in r["Kernel_Name"] else "extend") if "ext_kernel" in r["Kernel_Name"] else ("swalign2" if "swp_kernel" in r["Kernel_Name"] else None)
         if k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):

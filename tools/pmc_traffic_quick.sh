@@ -15,7 +15,7 @@ per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for fn in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
-            k = "extend" if "ext_kernel" in r["Kernel_Name"] else ("swalign2" if "swp_kernel" in r["Kernel_Name"] else None)
+            k = ("extend_full" if ", 0>" in r["Kernel_Name"] else "extend") if "ext_kernel" in r["Kernel_Name"] else ("swalign2" if "swp_kernel" in r["Kernel_Name"] else None)
             if k:
                 per.setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
 d = json.loads([l for l in open(f"{out}/FETCH_SIZE.json") if l.startswith("{")][-1])

@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -14,6 +15,9 @@ P = os.path.join(ROOT, "profiles")
 
 
 def short(name):
+    m = re.search(r"ext_kernel<\w+, (\d)>", name)   # <COORD, SHORT>: 0 = the full kernel (listed / deferred tasks), 1 / 2 = the 48-VGPR builds
+    if m:
+        return "extend_full" if m.group(1) == "0" else "extend"
     for k, v in (("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("swp_kernel", "swalign2"), ("sw4_kernel", "swalign2"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
                  ("reg2aln", "reg2aln"), ("chain2aln", "chain2aln"), ("ext_qt", "extend_qt"), ("global_kernel", "global")):
         if k in name:
