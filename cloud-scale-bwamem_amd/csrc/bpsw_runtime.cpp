@@ -594,7 +594,8 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // A batch with few mid tasks (2x150 bp reads: the flanks of 128-131 bases) runs the build without the window, whose rows cost
   // 4 % less, and lists its mid tasks for the full kernel like the long ones; a batch of mostly mid tasks (2x250 bp) runs the
   // window build, which defers on the device.
-  const bool window_build = 16 * (size_t)n_mid > (size_t)n;
+  static const long window_share = getenv("BPSW_EXT_WINDOW_SHARE") ? atol(getenv("BPSW_EXT_WINDOW_SHARE")) : 16;  // A/B switch
+  const bool window_build = (size_t)window_share * (size_t)n_mid > (size_t)n;
   if (!window_build && n_mid > 0) {
     long_tasks.insert(long_tasks.end(), mid_tasks.begin(), mid_tasks.end());
     n_mid = 0;
