@@ -4,16 +4,19 @@
 // of the Scala extension() (MemChainToAlignBatched.scala:789-883): left then right SWExtend
 // (SWUtil.scala:61-230) with up to MAX_BAND_TRY=2 band widths, bit-exact.
 //
-// How: one task per 64-lane wavefront, four independent waves per workgroup, no workgroup barrier.
-// The DP is row-synchronous because the band [beg,end) of row i+1 is derived from the finished row i
-// (SWUtil.scala:201-214).  A row is swept in 64-column chunks:
+// How: one task per 64-lane wavefront, four independent waves per workgroup, no workgroup barrier, tasks pulled from a
+// self-resetting work queue by persistent workgroups.  The DP is row-synchronous because the band [beg,end) of row i+1 is
+// derived from the finished row i (SWUtil.scala:201-214).  A row lives in registers, one or two columns per lane
+// (bpsw_extend_core.h: sw_extend_lean1 / lean2, and leanS on a 128-column window that follows the band for longer flanks):
 //   a(j)   = max(H(i-1,j-1) + S(i,j), E(i,j))                      per lane
 //   F(i,j) = max(0, max_{k<j}(a(k) - oeIns - (j-1-k)*eIns))        wave max-plus prefix scan (DPP)
 //   H(i,j) = max(a(j), F(i,j)),  E(i+1,j) = max(E(i,j)-eDel, H(i,j)-oeDel, 0)
-// (valid because oIns >= 0, checked on the host).  The (H,E) row lives in LDS as int2 per column, the
-// 5 x qLen query profile as int8, the unpacked target as bytes.  Row maximum + LAST arg-max
-// (SWUtil.scala:158-161) come from a wave max-reduce + ballot; the band trimming loops
-// (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
+// (valid because oIns >= 0, checked on the host).  Row maximum + LAST arg-max (SWUtil.scala:158-161) ride on a second scan; the
+// band trimming loops (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
+// Before any DP a flank goes through the exact shortcuts (closed forms, certificates: bpsw_extend_core.h), which resolve most
+// flanks of low-error reads.  Three builds (ext_kernel<COORD, SHORT>): two 48-VGPR ones at eight waves per SIMD for flanks up to
+// 127 / 255 bases, and the full one (slot sweeps for wide-band retries, an LDS-row sweep for flanks above 255 bases) for what
+// the host lists or the window build defers.
 #include <stdlib.h>
 
 #include <atomic>
@@ -91,7 +94,10 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 // which the full kernel, launched behind this one on the stream, reads its task count from.
 // SHORT: 0 the full kernel; 1 flanks up to 127 bases (no window: the leanest build, what 2x150 bp batches run on); 2 up to 255
 template <bool COORD, int SHORT>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? 8 : BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks_arg,
+#ifndef BPSW_EXT_SHORT_WAVES_PER_SIMD
+#define BPSW_EXT_SHORT_WAVES_PER_SIMD 8
+#endif
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_PER_SIMD : BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks_arg,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
                                                                      const int lds_per_wave, const int chunk, const int guide_cap,
