@@ -12,10 +12,11 @@ python3 - <<'PY'
 import csv, glob, collections
 out = "gpurun_out/prof_cfg"
 st = glob.glob(out + "/stats5/**/*kernel_stats.csv", recursive=True)
-with open(out + "/r02_cfg5_kernel_stats.csv", "w") as f:
-    f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+with open(out + "/r02_cfg5_kernel_stats.csv", "w", newline="") as f:
+    wr = csv.writer(f)
+    wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
     for r in csv.DictReader(open(st[0])):
-        f.write(f"{r['Name']},{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']}\n")
+        wr.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob(out + "/pmc5/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):

@@ -28,10 +28,11 @@ def short(name):
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    with open(os.path.join(P, f"{tag}_kernel_stats_bench.csv"), "w") as f:
-        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+    with open(os.path.join(P, f"{tag}_kernel_stats_bench.csv"), "w", newline="") as f:
+        wr = csv.writer(f)   # kernel names contain commas: quoted
+        wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
         for r in rows:
-            f.write(f"{r['Name']},{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['Percentage']}\n")
+            wr.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
     print("kernel stats:", [(short(r["Name"]), r["Calls"], r["AverageNs"]) for r in rows[:4]])
 
 per = defaultdict(lambda: defaultdict(list))
