@@ -308,3 +308,46 @@ def test_two_gap_open_deficits(ctx, orc):
         soa.o_del, soa.e_del, soa.o_ins, soa.e_ins, soa.w = od, ed, oi, ei, w
         for zmode, zdrop in ((po.ZDROP_SCALA, 100), (po.ZDROP_BWA, 16)):
             _check(ctx, orc, soa, zmode=zmode, zdrop=zdrop)
+
+
+def _flank(rng, n, sub, indel):
+    """query of n bases and a target made from it (substitutions / indels) with a random tail"""
+    q = rng.integers(0, 4, n).tolist()
+    t = []
+    for b in q:
+        u = rng.random()
+        if u < indel / 2:
+            continue
+        if u < indel:
+            t.append(int(rng.integers(0, 4)))
+        t.append(int((b + 1 + rng.integers(0, 3)) & 3) if rng.random() < sub else int(b))
+    return q, t + rng.integers(0, 4, int(rng.integers(20, 140))).tolist()
+
+
+@pytest.mark.parametrize("mid_share,w", [(0.0, 100), (0.03, 100), (0.3, 100), (0.9, 100), (0.3, 70), (0.9, 127), (0.03, 5)])
+def test_launch_plans_of_the_split_kernel(ctx, orc, mid_share, w):
+    """a batch runs on the 48-VGPR build without the window plus the full kernel for its listed tasks (few flanks of
+    128-255 bases), or on the window build, which defers on the device what it cannot finish -- a band wider than 128 columns: the
+    doubled band of a retry (w = 70 -> 140, 127 -> 254) or a first row of min(qLen, w + 1) > 127 columns -- or, with flanks above
+    255 bases in the batch, also on the full kernel for the host's list.  Every mix must give the oracle's results."""
+    rng = np.random.default_rng(int(1000 * mid_share) + w)
+    tasks = []
+    for t in range(1500):
+        u = rng.random()
+        if u < mid_share:
+            n1, n2 = int(rng.integers(128, 256)), int(rng.integers(1, 256))
+        elif u < mid_share + 0.02:
+            n1, n2 = int(rng.integers(256, 400)), int(rng.integers(1, 200))       # the full kernel's own (LDS-row sweep)
+        else:
+            n1, n2 = int(rng.integers(1, 128)), int(rng.integers(1, 128))
+        if rng.random() < 0.5:
+            n1, n2 = n2, n1
+        sub = float(rng.choice([0.0, 0.02, 0.08, 0.2]))
+        indel = float(rng.choice([0.0, 0.01, 0.04]))
+        lq, lr = _flank(rng, n1, sub, indel)
+        rq, rr = _flank(rng, n2, sub, indel)
+        tasks.append((lq, lr, rq, rr, int(rng.choice([19, 30, 60, 120])), n1))
+    soa = _manual_tasks(tasks)
+    soa.w = w
+    for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
+        _check(ctx, orc, soa, zmode=zmode)
