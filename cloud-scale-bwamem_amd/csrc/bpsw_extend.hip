@@ -166,8 +166,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
     const long long seedRb = COORD ? (long long)(((unsigned long long)uni((int)rec[9]) << 32) | (unsigned)uni((int)rec[8])) : 0ll;
     const int seedLen = COORD ? uni(hi16(r4)) : 0;
     const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
-    if (SHORT && (lq > short_qmax || rq > short_qmax)) continue;  // the full kernel's task (the host has listed it)
+    // short_qmax < 0 (the asynchronous device entry, where no host has seen the records): nobody has listed the tasks this build
+    // cannot take -- a flank above -short_qmax bases, or any task when the gap costs rule out the register sweeps -- so it defers
+    // them itself; short_qmax > 0: the host has listed them for the full kernel
     bool deferred = false;
+    if (SHORT) {
+      const int qm = short_qmax < 0 ? -short_qmax : short_qmax;
+      const bool too_long = lq > qm || rq > qm || (SHORT == 2 && short_qmax < 0 && oIns + eIns <= 0);
+      if (too_long) {
+        if (SHORT == 2 && short_qmax < 0) {
+          if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
+        }
+        continue;
+      }
+    }
     const uint32_t* words = wire + (size_t)uni((int)rec[2]);
     const int regScore0 = uni(lo16(r3)), qBeg = uni(hi16(r3)), h0 = uni(lo16(r4));
     const int lMaxIns = max(1, uni(lo16(r5))), lMaxDel = max(1, uni(hi16(r5)));  // SWUtil.scala:110-115
@@ -328,7 +340,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
                              int short_qmax) {
   if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
-  const int variant = !short_kernel ? 0 : (short_qmax <= 127 ? 1 : 2);
+  const int variant = !short_kernel ? 0 : ((short_qmax < 0 ? -short_qmax : short_qmax) <= 127 ? 1 : 2);
   const void* fn = variant == 0 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 0>) : reinterpret_cast<const void*>(ext_kernel<false, 0>))
                  : variant == 1 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 1>) : reinterpret_cast<const void*>(ext_kernel<false, 1>))
                                 : (coord ? reinterpret_cast<const void*>(ext_kernel<true, 2>) : reinterpret_cast<const void*>(ext_kernel<false, 2>));

@@ -794,6 +794,7 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   HIP_TRY(hipSetDevice(c->device));
   { int rc = finish_pending(c); if (rc != BPSW_OK) return rc; }  // the scan buffers of this context are about to be reused
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  HIP_TRY(c->d_ext_lists.reserve(4 * ((size_t)n_tasks + 1) + 16));  // the full kernel's device-side task list (nothing pending: safe to grow)
   ExtPrepass* d_pre = (ExtPrepass*)c->d_pre.ptr;
   ExtPrepass* h_pre = (ExtPrepass*)c->h_pre.ptr;
   // one fill for the scan record (+0), the bin counts (+64) and the kernel's queue head (+128): every small fill is a kernel
@@ -821,8 +822,21 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
       rcap = std::min(ASYNC_RCAP, (c->ext_geom_r + 128 + 63) & ~63);
     }
     HIP_TRY(hipEventRecord(c->ev[4], s));
-    HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu,
-                              (int*)((char*)c->d_pre.ptr + 128), nullptr, s, d_pre, true));
+    static const bool split_on = !(getenv("BPSW_EXT_SPLIT") && atoi(getenv("BPSW_EXT_SPLIT")) == 0);
+    int* d_queue = (int*)((char*)c->d_pre.ptr + 128);
+    if (split_on) {
+      // the 48-VGPR window build over every task, deferring on the device what it cannot take (nobody has seen the records
+      // here), and the full kernel behind it for that list; both check the scan and leave a bad batch untouched
+      int* d_list = (int*)c->d_ext_lists.ptr;
+      HIP_TRY(hipMemsetAsync(d_list, 0, sizeof(int), s));
+      HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu, d_queue, nullptr, s,
+                                d_pre, true, KernelEvents(), true, d_list, -255));
+      HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, std::min(n_tasks, c->num_cu), (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu,
+                                d_queue, nullptr, s, d_pre, true, KernelEvents(), false, d_list));
+    } else {
+      HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu, d_queue, nullptr, s,
+                                d_pre, true));
+    }
     c->pend_ext.qcap = qcap; c->pend_ext.rcap = rcap;
     HIP_TRY(hipEventRecord(c->ev[5], s));
     HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
