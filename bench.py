@@ -458,6 +458,21 @@ def main():
                     break
     except Exception:
         trace_ms = None
+    # fraction of the SIMDs' instruction issue rate: vector + scalar wave-instructions of the timed region (per-launch counts from the
+    # committed rocprofv3 --pmc passes of this command, profiles/pmc_issue.json) at the 2.6 cycles per instruction a SIMD sustains on
+    # these kernels' mix, over 1024 SIMDs at 2.4 GHz
+    issue_frac = None
+    try:
+        pi = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
+        e = pi.get("extend_per_call") or pi.get("extend")
+        w = pi.get("swalign2")
+        if e and w and args.config == 3:
+            instr = ext_launches * (e["valu"] + e["salu"]) + sw_launches * (w["valu"] + w["salu"])
+            issue_frac = {"frac": round(instr * 2.6 / (1024 * 2.4e9 * elapsed), 3), "wave_instructions_in_timed_region": int(instr),
+                          "cycles_per_instruction": 2.6, "simds": 1024, "clock_hz": 2.4e9,
+                          "note": "vector + scalar instructions only (branches and waits excluded); counts per launch from profiles/pmc_issue.json"}
+    except Exception:
+        issue_frac = None
     host_ms = {k: {"mean": round(float(np.mean(v)), 4), "p50": round(float(np.median(v)), 4), "max": round(float(np.max(v)), 4)} if v else None
                for k, v in call_ms.items()}
     pcie_bytes_per_step = passes * (sum(int(w.size) for w in wires) + 20 * sum(ntasks))   # boundary 2 both ways; boundary 1 below
@@ -529,7 +544,7 @@ def main():
                              "the timed region; launches of different host threads overlap on the device, so this is the time a launch spends "
                              "sharing the GPU.  The events see about 0.06 ms of dispatch latency per launch that a kernel trace does not: "
                              "avg_launch_ms_kernel_trace is the rocprofv3 --kernel-trace --stats average of this command committed under profiles/"},
-        "gcups": gcups, "frac_of_valu_ceiling": valu,
+        "gcups": gcups, "frac_of_valu_ceiling": valu, "frac_of_issue_rate": issue_frac,
         "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes),
                                "h2d_ms_avg": round(st["ext_h2d_ms"] / max(ext_launches, 1), 4), "d2h_ms_avg": round(st["ext_d2h_ms"] / max(ext_launches, 1), 4)},
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes),

@@ -86,6 +86,11 @@ for k in ("extend", "swalign2", "ext_prepass", "sw_prepass"):
     if "SQ_INSTS_VALU" in per[k] and "SQ_INSTS_SALU" in per[k]:
         issue[k] = {"valu": int(sum(per[k]["SQ_INSTS_VALU"]) / len(per[k]["SQ_INSTS_VALU"])),
                     "salu": int(sum(per[k]["SQ_INSTS_SALU"]) / len(per[k]["SQ_INSTS_SALU"]))}
-issue["note"] = f"wave-instructions per launch (SQ_INSTS_VALU, SQ_INSTS_SALU) from profiles/{tag}_pmc_counters.csv"
+# per bpsw_extend_batch CALL: the 48-VGPR launch plus the full-kernel launch behind it (listed / deferred tasks), when there is one
+if "extend" in issue and "SQ_INSTS_VALU" in per["extend_full"]:
+    calls = len(per["extend"]["SQ_INSTS_VALU"])
+    issue["extend_per_call"] = {"valu": int((sum(per["extend"]["SQ_INSTS_VALU"]) + sum(per["extend_full"]["SQ_INSTS_VALU"])) / calls),
+                                "salu": int((sum(per["extend"]["SQ_INSTS_SALU"]) + sum(per["extend_full"]["SQ_INSTS_SALU"])) / calls)}
+issue["note"] = f"wave-instructions per launch (SQ_INSTS_VALU, SQ_INSTS_SALU) from profiles/{tag}_pmc_counters.csv; extend_per_call = both extension launches of a call"
 json.dump(issue, open(os.path.join(P, "pmc_issue.json"), "w"), indent=1)
 print(issue)
