@@ -88,31 +88,6 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
 // short_kernel: the 48-VGPR variant for tasks whose query flanks have at most short_qmax bases; it skips the others and appends
 // the tasks it cannot finish to d_defer ([0] = count, [1..] = task indices).  The full kernel with d_defer set reads its task count
 // and list from there (n_tasks then only sizes the grid) -- bpsw_extend.hip
-// Quad-task kernel (bpsw_extend_qt.hip): s_cols = 4 (sides <= 63 bp) or 9 (<= 143 bp).
-hipError_t launch_ext_qt_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, const int* d_list, int n_list,
-                                int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter, hipStream_t s);
-struct ExtStreams {  // two auxiliary streams + events so the independent launches of one batch overlap
-  hipStream_t stream[2];
-  hipEvent_t fork, join[2];
-};
-// Splits the tasks of a validated batch into three lists (d_lists[bin * n_tasks + k]) and counts (d_counts[3], zeroed
-// by the caller): bin 0 -> quad-task S=4, bin 1 -> quad-task S=9, bin 2 -> one task per wave (ext_kernel).
-void launch_ext_bin(const uint32_t* d_wire, int n_tasks, int* d_lists, int* d_counts, hipStream_t s);
-// All launches of one extension batch; h_counts are the three bin sizes read back by the caller.
-// d_counters: three device ints (one queue head per launch).
-hipError_t launch_ext_all(const uint32_t* d_wire, size_t wire_words, int n_tasks, int16_t* d_out, const ExtScoring& sc,
-                          int qcap, int rcap, int num_cu, int* d_counters, const int* d_lists, const int h_counts[3],
-                          bool use_qt, const ExtStreams& aux, hipStream_t s);
-
-// Lane-per-task kernel (bpsw_extend_lane.hip): 64 tasks per wavefront.
-// Sort: d_counts[0] = tasks in d_lane_list (ordered by left query length), [1] = tasks in d_fb_list (for ext_kernel),
-// [2] = longest side among lane tasks, [3] = largest leftQlen + rightQlen.  One workgroup; d_counts need not be zeroed.
-void launch_ext_lane_sort(const uint32_t* d_wire, int n_tasks, int mat_max, int* d_lane_list, int* d_fb_list, int* d_counts,
-                          hipStream_t s);
-size_t ext_lane_lds_bytes(int max_side, int max_qsum);
-hipError_t launch_ext_lane_kernel(const uint32_t* d_wire, const int* d_list, int n_list, int16_t* d_out, const ExtScoring& sc,
-                                  int max_side, int max_qsum, hipStream_t s);
-
 // ---- local SW (boundary 1) ---------------------------------------------------------------------
 struct SwScoring {
   MatRows mat;
@@ -355,7 +330,6 @@ struct bpsw_ctx {
   int num_cu = 256;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  bpsw::ExtStreams aux = {{nullptr, nullptr}, nullptr, {nullptr, nullptr}};
   std::mutex mu;
   bpsw::ExtScoring ext_sc;
   int8_t ext_mat[25];

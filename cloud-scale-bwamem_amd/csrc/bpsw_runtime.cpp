@@ -292,11 +292,7 @@ extern "C" {
 
 const char* bpsw_last_error(void) { return g_err.c_str(); }
 const char* bpsw_version(void) {
-#ifdef BPSW_EXPERIMENTAL_KERNELS
-  return "bPSW-hip 0.2 (gfx950) +experimental-kernels";
-#else
   return "bPSW-hip 0.2 (gfx950)";
-#endif
 }
 
 int bpsw_device_count(void) {
@@ -364,18 +360,6 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   // an executor's task threads share a CPU quota, and a spinning waiter takes it from the threads doing host work
   // (BPSW_SPIN_WAIT=1 restores the runtime's default busy wait for A/B runs)
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreateWithFlags(&c->ev[i], spin_wait() ? hipEventDefault : hipEventBlockingSync);
-  // side streams of the opt-in quad-task experiment only: every stream takes a slot in the round robin over the HIP hardware
-  // queues, and contexts that collide there serialise each other's launches
-#ifdef BPSW_EXPERIMENTAL_KERNELS
-  const bool want_side_streams = getenv("BPSW_EXT_QT") && atoi(getenv("BPSW_EXT_QT")) != 0;  // == ext_qt_enabled()
-#else
-  const bool want_side_streams = false;
-#endif
-  for (int k = 0; e == hipSuccess && k < 2 && want_side_streams; ++k) {
-    e = hipStreamCreateWithFlags(&c->aux.stream[k], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux.join[k], hipEventDisableTiming);
-  }
-  if (e == hipSuccess && want_side_streams) e = hipEventCreateWithFlags(&c->aux.fork, hipEventDisableTiming);
   if (e == hipSuccess) e = c->d_pre.reserve(512);
   if (e == hipSuccess) e = hipMemset(c->d_pre.ptr, 0, 512);  // scan records and the self-resetting queue heads of ext_kernel
   if (e == hipSuccess) e = c->h_pre.reserve(512);
@@ -399,11 +383,6 @@ void bpsw_destroy(bpsw_ctx_t* c) {
   rescue_scratch_free(c->rescue_scratch);
   for (int i = 0; i < 8; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-  for (int k = 0; k < 2; ++k) {
-    if (c->aux.stream[k]) (void)hipStreamDestroy(c->aux.stream[k]);
-    if (c->aux.join[k]) (void)hipEventDestroy(c->aux.join[k]);
-  }
-  if (c->aux.fork) (void)hipEventDestroy(c->aux.fork);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -433,67 +412,6 @@ int bpsw_set_ext_scoring(bpsw_ctx_t* c, const int8_t mat[25], int zdrop, int zdr
 }
 
 
-#ifdef BPSW_EXPERIMENTAL_KERNELS
-// Built only with `make EXPERIMENTAL=1`: the two alternative formulations of the extension kernel that DESIGN.md 4.1 measures
-// against ext_kernel and keeps as experiments.  The default library carries one extension kernel and none of this.
-// The quad-task kernels (bpsw_extend_qt.hip) execute 1.8x fewer instructions than ext_kernel but are not faster at
-// 32 k-read batches on MI355X, so they are opt-in: BPSW_EXT_QT=1.
-static bool ext_qt_enabled() {
-  static const bool on = getenv("BPSW_EXT_QT") && atoi(getenv("BPSW_EXT_QT")) != 0;
-  return on;
-}
-
-// BPSW_EXT_MODE=lane: the lane-per-task kernel (bpsw_extend_lane.hip) takes every task that fits it.
-static bool ext_lane_enabled() {
-  static const bool on = getenv("BPSW_EXT_MODE") && std::string(getenv("BPSW_EXT_MODE")) == "lane";
-  return on;
-}
-
-// Lane-per-task path: enqueue the sort (its four counts land in d_pre + 64), and, once the caller has read them back,
-// the launches.
-static void lane_sort_enqueue(bpsw_ctx_t* c, const uint32_t* d_wire, int n, hipStream_t s) {
-  int* lane_list = (int*)c->d_ext_lists.ptr;
-  launch_ext_lane_sort(d_wire, n, c->ext_sc.mat_max, lane_list, lane_list + n, (int*)((char*)c->d_pre.ptr + 64), s);
-}
-static int lane_launch(bpsw_ctx_t* c, const uint32_t* d_wire, int n, int16_t* d_out, int mq, int mr, const int h_counts[4],
-                       hipStream_t s) {
-  const int* lane_list = (const int*)c->d_ext_lists.ptr;
-  HIP_TRY(launch_ext_lane_kernel(d_wire, lane_list, h_counts[0], d_out, c->ext_sc, h_counts[2], h_counts[3], s));
-  if (h_counts[1] > 0)
-    HIP_TRY(launch_ext_kernel(d_wire, h_counts[1], d_out, c->ext_sc, mq, mr, c->num_cu, (int*)((char*)c->d_pre.ptr + 128),
-                              lane_list + n, s));
-  return BPSW_OK;
-}
-
-// The launches of one host-buffer batch with the experimental kernels: bin / sort on the device, read the counts back, launch.
-static int ext_experimental_launch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int n, int mq, int mr, int16_t* k_out,
-                                   hipStream_t s) {
-  int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
-  int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
-  const bool use_lane = ext_lane_enabled();
-  const bool use_qt = !use_lane && (int8_t)wire[2] + (int8_t)wire[3] > 0 && ext_qt_enabled();
-  h_counts[0] = h_counts[1] = 0; h_counts[2] = n;
-  if (use_lane) {
-    lane_sort_enqueue(c, (const uint32_t*)c->d_wire.ptr, n, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipEventRecord(c->ev[1], s));
-    return lane_launch(c, (const uint32_t*)c->d_wire.ptr, n, k_out, mq, mr, h_counts, s);
-  }
-  if (use_qt) {
-    HIP_TRY(hipMemsetAsync(d_counts, 0, 16, s));
-    launch_ext_bin((const uint32_t*)c->d_wire.ptr, n, (int*)c->d_ext_lists.ptr, d_counts, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipEventRecord(c->ev[1], s));
-  }
-  HIP_TRY(launch_ext_all((const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, n, k_out, c->ext_sc, mq, mr, c->num_cu,
-                         (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, h_counts, use_qt, c->aux, s));
-  return BPSW_OK;
-}
-#endif  // BPSW_EXPERIMENTAL_KERNELS
 
 // ------------------------------------------------------------------------------------- boundary 2
 static inline int rd16(const uint8_t* b, size_t at) { return (int16_t)(b[at] | (b[at + 1] << 8)); }
@@ -548,6 +466,9 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
       const int len = rd16(wire, at + 18);
       long long rb;
       memcpy(&rb, wire + at + 32, 8);
+      // rb comes straight from the caller's bytes: range-check it before any arithmetic (lr, rr, len are int16, so lo / hi cannot
+      // overflow afterwards; an rb near INT64_MAX used to wrap hi negative and pass every test below)
+      if (rb < 0 || rb > (l_pac << 1)) return fail(BPSW_ERR_ARG, "extend: task window outside the reference or bridging its two strands");
       const long long lo = rb - lr, hi = rb + len + rr;
       if (len < 0 || lo < 0 || hi > (l_pac << 1) || (lo < l_pac && hi > l_pac))
         return fail(BPSW_ERR_ARG, "extend: task window outside the reference or bridging its two strands");
@@ -622,9 +543,6 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   bool zc_slots = false;
   HIP_TRY(c->d_wire.reserve(dev_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
-#ifdef BPSW_EXPERIMENTAL_KERNELS
-  HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n + 16));
-#endif
   HIP_TRY(c->h_stage_in.reserve(stage_bytes));
   HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_bytes));
   const double t_in = wall_ms();
@@ -648,14 +566,6 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     // device memory and copied back
     const bool zc_out = (zerocopy_mask() & 1) != 0;
     int16_t* k_out = zc_out ? (int16_t*)c->h_stage_out.ptr : (int16_t*)c->d_out.ptr;
-#ifdef BPSW_EXPERIMENTAL_KERNELS
-    if (ext_lane_enabled() || ext_qt_enabled()) {
-      zc_slots = false;  // the experimental kernels write 20-byte records back to back
-      HIP_TRY(hipEventRecord(c->ev[1], s));
-      rc = ext_experimental_launch(c, wire, wire_bytes, n, mq, mr, k_out, s);
-      if (rc != BPSW_OK) return rc;
-    } else
-#endif
     {
       ExtScoring sc = c->ext_sc;
       if (zc_slots) sc.out_stride = 16;
@@ -726,28 +636,7 @@ static const int ASYNC_QCAP = 256, ASYNC_RCAP = 4096;
 static int ext_device_sync_launch(bpsw_ctx_t* c, const void* d_wire, size_t wire_bytes, int n_tasks, void* d_out, hipStream_t s,
                                   const ExtPrepass* h_pre, const int* h_counts) {
   HIP_TRY(hipEventRecord(c->ev[4], s));
-#ifdef BPSW_EXPERIMENTAL_KERNELS
-  if (ext_lane_enabled()) {
-    int rc = lane_launch(c, (const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, h_pre->max_qlen, h_pre->max_rlen, h_counts, s);
-    if (rc != BPSW_OK) return rc;
-    HIP_TRY(hipEventRecord(c->ev[5], s));
-    HIP_TRY(hipStreamSynchronize(s));  // the experiments are synchronous: nothing of theirs is left in flight on `s`
-    c->have_ext_ev = true;
-    return BPSW_OK;
-  }
-  if (h_pre->reserved != 0 && ext_qt_enabled()) {  // reserved: set by the scan when oIns + eIns > 0
-    const int counts[3] = {h_counts[0], h_counts[1], h_counts[2]};
-    HIP_TRY(launch_ext_all((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen,
-                           h_pre->max_rlen, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), (const int*)c->d_ext_lists.ptr, counts,
-                           true, c->aux, s));
-    HIP_TRY(hipEventRecord(c->ev[5], s));
-    HIP_TRY(hipStreamSynchronize(s));
-    c->have_ext_ev = true;
-    return BPSW_OK;
-  }
-#else
   (void)wire_bytes; (void)h_counts;
-#endif
   HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, h_pre->max_qlen, h_pre->max_rlen, c->num_cu,
                             (int*)((char*)c->d_pre.ptr + 128), nullptr, s));
   HIP_TRY(hipEventRecord(c->ev[5], s));
@@ -804,12 +693,7 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
   launch_ext_prepass((const uint32_t*)d_wire, wire_bytes >> 2, n_tasks, d_pre, s);
   HIP_TRY(hipGetLastError());
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n_tasks; c->stats.ext_wire_bytes += wire_bytes;
-#ifdef BPSW_EXPERIMENTAL_KERNELS
-  const bool experiments = ext_lane_enabled() || ext_qt_enabled();
-#else
-  const bool experiments = false;
-#endif
-  if (!experiments) {
+  {
     // Asynchronous: scan, main launch (sized for ASYNC_QCAP / ASYNC_RCAP, checking the scan on the device) and the scan's
     // read-back are enqueued back to back; nothing waits.  Errors surface at the next call on this context or at
     // bpsw_last_kernel_ms, which is also where a batch that outgrew the geometry is re-launched.
@@ -845,26 +729,6 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
     c->pend_ext.d_out = d_out; c->pend_ext.s = s;
     return BPSW_OK;
   }
-#ifdef BPSW_EXPERIMENTAL_KERNELS
-  // experiments (quad-task / lane kernels): bin the tasks in the same pass, read the scan back, then launch
-  int* d_counts = (int*)((char*)c->d_pre.ptr + 64);
-  int* h_counts = (int*)((char*)c->h_pre.ptr + 64);
-  if (12 * (size_t)n_tasks + 16 > c->d_ext_lists.cap) {
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(c->d_ext_lists.reserve(12 * (size_t)n_tasks + 16));
-  }
-  if (ext_lane_enabled()) lane_sort_enqueue(c, (const uint32_t*)d_wire, n_tasks, s);
-  else launch_ext_bin((const uint32_t*)d_wire, n_tasks, (int*)c->d_ext_lists.ptr, d_counts, s);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h_pre, d_pre, 128, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (h_pre->error) return fail(BPSW_ERR_ARG, "extend_device: malformed wire batch (code " + std::to_string(h_pre->error) + ")");
-  if (h_pre->max_qlen > BPSW_EXT_MAX_QLEN || h_pre->max_rlen > BPSW_EXT_MAX_RLEN)
-    return fail(BPSW_ERR_LIMIT, "extend_device: sequence longer than the kernel limit");
-  return ext_device_sync_launch(c, d_wire, wire_bytes, n_tasks, d_out, s, h_pre, h_counts);
-#else
-  return fail(BPSW_ERR_DEVICE, "extend_device: unreachable");
-#endif
 }
 
 int bpsw_get_stats(bpsw_ctx_t* c, bpsw_stats_t* out) {

@@ -105,6 +105,15 @@ def test_rejects_what_it_cannot_run(refctx):
     bad[32 + 32: 32 + 40] = rb.view(np.uint8)
     with pytest.raises(bpsw_hip.BpswError):
         refctx.extend_batch(bad)
+    # a seed coordinate near INT64_MAX / INT64_MIN: rb + len + rr used to wrap and pass the window tests (the kernel would
+    # then have read the reference at a garbage offset); it is range-checked before any arithmetic now
+    for evil in (np.iinfo(np.int64).max - 10, np.iinfo(np.int64).max, np.iinfo(np.int64).min, np.iinfo(np.int64).min + 70_000,
+                 -1, 2 * l_pac + 1):
+        bad = wire_c.copy()
+        bad[32 + 32: 32 + 40] = np.array([evil], np.int64).view(np.uint8)
+        with pytest.raises(bpsw_hip.BpswError):
+            refctx.extend_batch(bad)
+    assert np.array_equal(refctx.extend_batch(wire_c), refctx.extend_batch(bpsw_hip.wire_pack(by)))  # the context still works
 
 
 def test_coordinate_batch_through_the_jni_symbol(refctx, fake):
