@@ -28,29 +28,6 @@ namespace {
 
 constexpr int WAVES_PER_BLOCK = 4;
 
-// target sources of one side: the nibble stream of a wire batch, or the device-resident 2-bit reference (coordinate batches)
-struct NibbleT {
-  const uint32_t* __restrict__ words;
-  int rStart;
-  __device__ __forceinline__ int operator()(int i) const { return nibble_at(words, rStart + i); }
-};
-struct PacT {  // bnsGetSeq, util/BNTSeqUtil.scala:56-73: positions >= l_pac are the reverse strand, complemented
-  const uint8_t* __restrict__ pac;
-  long long l_pac, pos;
-  int step;  // -1: the left flank walks backwards from the seed (MemChainToAlignBatched.scala:511-517)
-  __device__ __forceinline__ int operator()(int i) const {
-    const long long p = pos + (long long)step * i;
-    const bool rev = p >= l_pac;
-    const long long k = rev ? (l_pac << 1) - 1 - p : p;
-    const int b = (pac[k >> 2] >> ((~k & 3) << 1)) & 3;
-    return rev ? 3 - b : b;
-  }
-};
-struct LdsShiftT {  // a target already staged as 8*code bytes
-  const uint8_t* __restrict__ ts;
-  __device__ __forceinline__ int operator()(int i) const { return (int)(ts[i] >> 3); }
-};
-
 // stage the target of one side in LDS as 8*code bytes (the shift the register path feeds to v_bfe)
 template <class T>
 __device__ void load_target_shifts(const int lane, const T& tsrc, const int rLen, uint8_t* __restrict__ ts) {
@@ -104,7 +81,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
                                                                      int* __restrict__ next_task,
                                                                      const int* __restrict__ task_list_arg,
                                                                      const ExtPrepass* __restrict__ pre,
-                                                                     int* __restrict__ defer, const int short_qmax) {
+                                                                     int* __restrict__ defer, const int short_qmax,
+                                                                     uint8_t* __restrict__ qflag, uint4* __restrict__ qcarry,
+                                                                     const int quad_qmax) {
   extern __shared__ __align__(16) unsigned char smem[];
   // the full kernel behind a SHORT launch: its task list and count are what the host listed plus what that launch deferred
   const int n_tasks = (!SHORT && defer) ? uni(defer[0]) : n_tasks_arg;
@@ -169,7 +148,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
     // short_qmax < 0 (the asynchronous device entry, where no host has seen the records): nobody has listed the tasks this build
     // cannot take -- a flank above -short_qmax bases, or any task when the gap costs rule out the register sweeps -- so it defers
     // them itself; short_qmax > 0: the host has listed them for the full kernel
-    bool deferred = false;
+    bool deferred = false, handed = false;
     if (SHORT) {
       const int qm = short_qmax < 0 ? -short_qmax : short_qmax;
       const bool too_long = lq > qm || rq > qm || (SHORT == 2 && short_qmax < 0 && oIns + eIns <= 0);
@@ -221,6 +200,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
       // wave-uniform by construction (the shortcuts decide on wave reductions), but not to the compiler: without this the DP below
       // sits in what it takes for divergent control flow and its whole scalar state is kept in vector registers
       const bool exact = uni(exact_v ? 1 : 0) != 0;
+      // A flank that needs the DP goes to the quad kernel (bpsw_extend_quad.hip: four flanks per wavefront), with what extension()
+      // has computed so far, when it -- and, from the left flank, the right one as well -- fits that kernel's columns.
+      if (SHORT && qflag && !exact && qLen <= quad_qmax && (side || rq <= quad_qmax)) {
+        if (side) store_lane0_b128(qcarry + task, make_uint4(((uint32_t)regScore & 0xffffu) | ((uint32_t)outQBeg << 16),
+                                                             ((uint32_t)outRBeg & 0xffffu) | ((uint32_t)trueScore << 16), (uint32_t)awMax, 0u));
+        store_lane0_b8(qflag + task, 1 + side);  // a plain store: no list, no atomic (bpsw_extend_quad.hip)
+        handed = true;
+        break;
+      }
       if (sc.side_how && lane == 0) sc.side_how[2 * (size_t)task + side] = exact ? 1 : 2;  // diagnostics only
       if (exact) {
         awSide = wBand;
@@ -238,6 +226,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
         const int prev = regScore;
         awSide = wBand << i;
         const int w = uni(min(min(awSide, maxIns), maxDel));
+        // the retry doubles the band; when the EFFECTIVE band min(w << 1, maxIns, maxDel) is the one just swept, the sweep would
+        // repeat itself row by row (SWUtil.scala:110-115: w is all of the band the call sees): only the reported width changes
+        if (i == 1 && w == uni(min(min(wBand, maxIns), maxDel))) break;
         if constexpr (SHORT) {
           int oInsT = oIns, eInsT = eIns;  // opaque copies, as below
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
@@ -270,6 +261,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
         trueScore += (local ? regScore : r.gscore) - sc0;
       }
     }
+    if (SHORT && handed) continue;  // the quad kernel finishes the task and writes its record
     if (SHORT == 2 && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
       if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
       continue;
@@ -337,7 +329,7 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev, bool short_kernel, int* d_defer,
-                             int short_qmax) {
+                             int short_qmax, uint8_t* d_qflag, uint4* d_qcarry, int quad_qmax) {
   if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
   const int variant = !short_kernel ? 0 : ((short_qmax < 0 ? -short_qmax : short_qmax) <= 127 ? 1 : 2);
@@ -387,7 +379,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
 #define BPSW_EXT_GO(CO, SH)                                                                                                     \
   BPSW_LAUNCH(kev, (ext_kernel<CO, SH>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap, rcap, \
-              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax)
+              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_qflag, d_qcarry, quad_qmax)
   if (variant == 1) {
     if (coord) BPSW_EXT_GO(true, 1); else BPSW_EXT_GO(false, 1);
   } else if (variant == 2) {

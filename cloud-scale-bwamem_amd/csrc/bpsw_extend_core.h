@@ -909,6 +909,29 @@ struct NibbleQ {
   __device__ __forceinline__ int operator()(int j) const { return nibble_at(words, qStart + j); }
 };
 
+// target sources of one side: the nibble stream of a wire batch, or the device-resident 2-bit reference (coordinate batches)
+struct NibbleT {
+  const uint32_t* __restrict__ words;
+  int rStart;
+  __device__ __forceinline__ int operator()(int i) const { return nibble_at(words, rStart + i); }
+};
+struct PacT {  // bnsGetSeq, util/BNTSeqUtil.scala:56-73: positions >= l_pac are the reverse strand, complemented
+  const uint8_t* __restrict__ pac;
+  long long l_pac, pos;
+  int step;  // -1: the left flank walks backwards from the seed (MemChainToAlignBatched.scala:511-517)
+  __device__ __forceinline__ int operator()(int i) const {
+    const long long p = pos + (long long)step * i;
+    const bool rev = p >= l_pac;
+    const long long k = rev ? (l_pac << 1) - 1 - p : p;
+    const int b = (pac[k >> 2] >> ((~k & 3) << 1)) & 3;
+    return rev ? 3 - b : b;
+  }
+};
+struct LdsShiftT {  // a target already staged as 8*code bytes
+  const uint8_t* __restrict__ ts;
+  __device__ __forceinline__ int operator()(int i) const { return (int)(ts[i] >> 3); }
+};
+
 #ifndef BPSW_EXT_LEAN
 #define BPSW_EXT_LEAN 1  // 0: the sweeps of round 1 / early round 2 (sw_extend_reg<1>, sw_extend_il2) everywhere
 #endif
@@ -1382,6 +1405,33 @@ __device__ __forceinline__ int dequeue_task(int* counter, const int count = 1) {
       : "v"(counter)
       : "memory");
   return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Stores by lane 0 alone, as single asm statements for the same reason as dequeue_task: a C-level `if (lane == 0) store`
+// in the task loop invites the compiler to thread lane 0 and the other 63 lanes through different copies of the loop.
+__device__ __forceinline__ void store_lane0_b8(uint8_t* p, int v) {
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b64 exec, 1\n\t"
+      "global_store_byte %1, %2, off\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(saved)
+      : "v"(p), "v"(v)
+      : "memory");
+}
+typedef unsigned int bpsw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_lane0_b128(uint4* p, uint4 val) {
+  const bpsw_u32x4 v = {val.x, val.y, val.z, val.w};
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b64 exec, 1\n\t"
+      "global_store_dwordx4 %1, %2, off\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(saved)
+      : "v"(p), "v"(v)
+      : "memory");
 }
 
 }  // namespace

@@ -84,10 +84,14 @@ size_t ext_lds_per_wave(int qcap, int rcap);
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false, KernelEvents kev = KernelEvents(),
-                             bool short_kernel = false, int* d_defer = nullptr, int short_qmax = 127);
-// short_kernel: the 48-VGPR variant for tasks whose query flanks have at most short_qmax bases; it skips the others and appends
-// the tasks it cannot finish to d_defer ([0] = count, [1..] = task indices).  The full kernel with d_defer set reads its task count
-// and list from there (n_tasks then only sizes the grid) -- bpsw_extend.hip
+                             bool short_kernel = false, int* d_defer = nullptr, int short_qmax = 127, uint8_t* d_qflag = nullptr,
+                             uint4* d_qcarry = nullptr, int quad_qmax = 0);
+// d_qflag / d_qcarry (48-VGPR builds only): the flanks that need the DP and have at most quad_qmax bases are handed to the quad
+// kernel (bpsw_extend_quad.hip) instead of being swept here: d_qflag[task] = 1 + side (zero at launch; the quad kernel puts it back),
+// d_qcarry[task] = the state of extension() after a resolved left flank.
+hipError_t launch_ext_quad_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, uint8_t* d_qflag, const uint4* d_carry,
+                                  int n_hint, int n_tasks, int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter,
+                                  hipStream_t s, KernelEvents kev = KernelEvents());
 // ---- local SW (boundary 1) ---------------------------------------------------------------------
 struct SwScoring {
   MatRows mat;
@@ -335,6 +339,8 @@ struct bpsw_ctx {
   int8_t ext_mat[25];
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
   bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
+  int quad_cap_n = 0;         // tasks the flag region of d_quad is sized for
+  bpsw::DeviceBuffer d_quad;  // the quad kernel's hand-over flags and carry records (bpsw_extend_quad.hip): [flag byte per task | carry]
   // asynchronous device entries: a launch whose table scan has not been read back yet (resolved by finish_pending)
   struct PendingExt { bool active = false; const void* d_wire = nullptr; size_t wire_bytes = 0; int n_tasks = 0; void* d_out = nullptr;
                       hipStream_t s = nullptr; int qcap = 0, rcap = 0; } pend_ext;

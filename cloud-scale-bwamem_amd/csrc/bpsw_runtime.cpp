@@ -378,7 +378,7 @@ void bpsw_destroy(bpsw_ctx_t* c) {
   if (c->pend_sw.active && c->pend_sw.s) (void)hipStreamSynchronize(c->pend_sw.s);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
-  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release();
+  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release(); c->d_quad.release();
   c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();
   rescue_scratch_free(c->rescue_scratch);
   for (int i = 0; i < 8; ++i)
@@ -486,6 +486,7 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
 }
 
 static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how);
+static inline bool side_how_blocks_quad(const uint8_t*) { return false; }  // the classify entry runs the same launch plan
 
 int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len) {
   return extend_batch_impl(c, wire, wire_bytes, out, out_len, nullptr);
@@ -543,6 +544,23 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   bool zc_slots = false;
   HIP_TRY(c->d_wire.reserve(dev_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
+  // The quad kernel (bpsw_extend_quad.hip: four flanks per wavefront) can take the flanks whose shortcuts fail from the 48-VGPR
+  // kernel: a flag byte per task + carry records in a buffer of the context.  Opt-in (BPSW_EXT_QUAD=1): it sweeps a DP row in 80
+  // instructions instead of 134, but nearly all of them are half-rate vector instructions, and on the bench it runs at parity
+  // with the one-task-per-wave sweeps at best.
+  static const int quad_mode = getenv("BPSW_EXT_QUAD") ? atoi(getenv("BPSW_EXT_QUAD")) : 0;
+  static const bool quad_hint_all = getenv("BPSW_QUAD_HINT_ALL") && atoi(getenv("BPSW_QUAD_HINT_ALL")) != 0;  // size the quad grid for every task (diagnostics)
+  const bool use_quad = quad_mode != 0 && use_short && !side_how_blocks_quad(side_how);
+  // layout [one flag byte per task | carry records], the flags sized for the largest batch seen (quad_cap_n), NOT for this batch:
+  // a flag byte must never lie where an earlier, smaller batch kept its carry records
+  bool quad_fresh = false;
+  if (use_quad && n > c->quad_cap_n) {
+    const size_t cap_n = (((size_t)n + (size_t)n / 2 + 4096) + 63) & ~(size_t)63;
+    HIP_TRY(c->d_quad.reserve(cap_n + 16 * cap_n));
+    c->quad_cap_n = (int)cap_n;
+    quad_fresh = true;  // cleared on the launch stream, in front of ext_kernel (a hipMemset on the null stream is not ordered with it)
+  }
+  const size_t quad_carry_off = (size_t)c->quad_cap_n;
   HIP_TRY(c->h_stage_in.reserve(stage_bytes));
   HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_bytes));
   const double t_in = wall_ms();
@@ -580,9 +598,20 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       int* d_list = with_list ? (int*)((char*)c->d_wire.ptr + list_off) : nullptr;
       if (use_short) {
         KernelEvents kev;
-        kev.start = c->ev[1]; kev.stop = use_full ? nullptr : c->ev[2];
+        kev.start = c->ev[1]; kev.stop = (use_full || use_quad) ? nullptr : c->ev[2];
+        uint8_t* d_quad = use_quad ? (uint8_t*)c->d_quad.ptr : nullptr;
+        uint4* d_qcarry = use_quad ? (uint4*)((char*)c->d_quad.ptr + quad_carry_off) : nullptr;
+        // the flags are zero when ext_kernel starts: the quad kernel leaves them so, a new buffer is cleared here
+        if (quad_fresh) HIP_TRY(hipMemsetAsync(c->d_quad.ptr, 0, c->d_quad.cap, s));
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 255), mr_short, c->num_cu, d_queue, nullptr, s,
-                                  nullptr, false, kev, true, d_list, any_mid ? 255 : 127));
+                                  nullptr, false, kev, true, d_list, any_mid ? 255 : 127, d_quad, d_qcarry, 128));
+        if (use_quad) {
+          // behind it on the stream: the flanks it handed over (how many, only the device knows: a third of the tasks sizes the grid)
+          KernelEvents qev;
+          qev.stop = use_full ? nullptr : c->ev[2];
+          HIP_TRY(launch_ext_quad_kernel(8, (const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, d_quad, d_qcarry, quad_hint_all ? n : n / 3 + 16, n, k_out, sc,
+                                         c->num_cu, (int*)((char*)c->d_pre.ptr + 192), s, qev));
+        }
       }
       if (use_full) {
         KernelEvents kev;

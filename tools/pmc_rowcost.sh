@@ -15,7 +15,7 @@ d = ast.literal_eval(line)
 tot = {}
 for f in glob.glob(f"{out}/pmc_{L}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "ext_kernel" in r["Kernel_Name"]:
+        if "ext_kernel" in r["Kernel_Name"] or "ext_quad_kernel" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0) + float(r["Counter_Value"])
 per = {k: v / d["launches"] / d["rows"] for k, v in tot.items()}
 print("L", L, d, "insts_per_row", {k: round(v, 1) for k, v in per.items()}, "sum", round(sum(per.values()), 1))
