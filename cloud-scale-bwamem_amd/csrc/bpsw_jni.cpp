@@ -26,6 +26,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <time.h>
 #include <vector>
 
 #include "bpsw.h"
@@ -101,6 +102,15 @@ bpsw_ctx_t* thread_context(JNIEnv* env) {
   t_ctx.device = bpsw_device_of(t_ctx.ctx);
   return t_ctx.ctx;
 }
+
+double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+}
+// wall time of the last JNI call on this thread, split at the C ABI: marshalling in, the bpsw_* call, marshalling out (bpsw_jni_last_times)
+struct ShimTimes { double in_us, call_us, out_us, units; };
+thread_local ShimTimes t_times = {0, 0, 0, 0};
 
 void throw_runtime(JNIEnv* env, const std::string& msg) {
   clear_pending(env);
@@ -192,15 +202,48 @@ const MateIds* mate_ids(JNIEnv* env) {
   return pub;
 }
 
-void read_bytes(JNIEnv* env, jbyteArray arr, std::vector<uint8_t>& pool, int64_t* off, int32_t* len) {
-  *off = (int64_t)pool.size();
+// Byte pool that is never value-initialised: a std::vector<uint8_t>::resize would zero-fill what GetByteArrayRegion is about to
+// overwrite (a second touch of every sequence and window byte of a call).
+struct BytePool {
+  uint8_t* p = nullptr;
+  size_t n = 0, cap = 0;
+  ~BytePool() { free(p); }
+  void clear() { n = 0; }
+  uint8_t* grow(size_t add) {
+    if (n + add > cap) {
+      size_t want = cap ? cap : (size_t)1 << 20;
+      while (want < n + add) want <<= 1;
+      p = static_cast<uint8_t*>(realloc(p, want));
+      cap = want;
+    }
+    uint8_t* at = p + n;
+    n += add;
+    return at;
+  }
+  void pad16() {  // keep every sequence 16-byte aligned for the device; the pad bytes are zero
+    const size_t pad = (16 - (n & 15)) & 15;
+    if (pad) memset(grow(pad), 0, pad);
+  }
+};
+// What a mateSWJNI call builds for bpsw_matesw_group, kept per thread and reused: a call of 4 096 pairs moves ~10 MB through these,
+// and allocating (and zero-filling) them afresh on every call was a measurable part of the shim.
+struct MateScratch {
+  std::vector<int32_t> seq_len, reg_cnt, ref_cnt, out_cnt;
+  std::vector<int64_t> seq_off, at, base, ref_rb, ref_re, ref_len, ref_off;
+  std::vector<long> where;
+  std::vector<bpsw_alnreg_t> regs, tmp, out;
+  BytePool seq_pool, ref_pool;
+};
+thread_local MateScratch t_ms;
+
+void read_bytes(JNIEnv* env, jbyteArray arr, BytePool& pool, int64_t* off, int32_t* len) {
+  *off = (int64_t)pool.n;
   *len = 0;
   if (!arr) return;
   const jsize n = jni::GetArrayLength(env, arr);
-  pool.resize(pool.size() + (size_t)n);
-  if (n > 0) jni::GetByteArrayRegion(env, arr, 0, n, reinterpret_cast<jbyte*>(pool.data() + *off));
+  if (n > 0) jni::GetByteArrayRegion(env, arr, 0, n, reinterpret_cast<jbyte*>(pool.grow((size_t)n)));
   *len = n;
-  pool.resize((pool.size() + 15) & ~(size_t)15);  // keep every sequence 16-byte aligned for the device
+  pool.pad16();
 }
 
 }  // namespace
@@ -215,6 +258,12 @@ JNIEXPORT uint64_t bpsw_jni_thread_info(int32_t out[3]) {
   return (uint64_t)(uintptr_t)t_ctx.ctx;
 }
 
+// Wall time of the last swExtendFPGAJNI / mateSWJNI call on the calling thread (for the shim micro-benchmark; not a JNI symbol):
+// out = {marshalling in (us), the C ABI call (us), marshalling out (us), units (tasks / regions returned)}.
+JNIEXPORT void bpsw_jni_last_times(double out[4]) {
+  if (out) { out[0] = t_times.in_us; out[1] = t_times.call_us; out[2] = t_times.out_us; out[3] = t_times.units; }
+}
+
 JNIEXPORT void JNICALL Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld(JNIEnv*, jobject) {
   printf("Hello World from %s (%d HIP device(s))\n", bpsw_version(), bpsw_device_count());
 }
@@ -224,17 +273,27 @@ JNIEXPORT jshortArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swEx
                                                                                             jint retTaskNum,
                                                                                             jbyteArray arrayIn) {
   if (!arrayIn || retTaskNum < 0) { throw_runtime(env, "bPSW: swExtendFPGAJNI: bad arguments"); return nullptr; }
+  const double t0 = now_us();
   const jsize bytes = jni::GetArrayLength(env, arrayIn);
-  std::vector<uint8_t> wire((size_t)bytes);
-  if (bytes > 0) jni::GetByteArrayRegion(env, arrayIn, 0, bytes, reinterpret_cast<jbyte*>(wire.data()));
-  std::vector<int16_t> out((size_t)retTaskNum > 0 ? (size_t)retTaskNum : 1, 0);
   bpsw_ctx_t* ctx = thread_context(env);
   if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
-  const int rc = bpsw_extend_batch(ctx, wire.data(), wire.size(), out.data(), (size_t)retTaskNum);
+  // Single touch: the JVM's bytes go straight into the context's pinned staging block, from where the copy engine reads them
+  // (the reference does one memcpy into its shared-memory segment, src/main/jni_fpga/sw_extend_fpga.c:146-155); the results are
+  // handed to SetShortArrayRegion from the pinned block the kernel wrote them to.  No heap allocation, no second copy.
+  uint8_t* stage = nullptr;
+  if (bpsw_extend_stage(ctx, (size_t)bytes, &stage) != BPSW_OK) { throw_runtime(env, std::string("bPSW: swExtendFPGAJNI: ") + bpsw_last_error()); return nullptr; }
+  if (bytes > 0) jni::GetByteArrayRegion(env, arrayIn, 0, bytes, reinterpret_cast<jbyte*>(stage));
+  const double t1 = now_us();
+  const int16_t* res = nullptr;
+  size_t res_len = 0;
+  const int rc = bpsw_extend_commit(ctx, (size_t)bytes, &res, &res_len);
   if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: swExtendFPGAJNI: ") + bpsw_last_error()); return nullptr; }
-  jshortArray ret = jni::NewShortArray(env, retTaskNum);
+  if (res_len > (size_t)retTaskNum) { throw_runtime(env, "bPSW: swExtendFPGAJNI: retTaskNum smaller than 10 shorts per task"); return nullptr; }
+  const double t2 = now_us();
+  jshortArray ret = jni::NewShortArray(env, retTaskNum);  // (a new Java array is zero-filled by the JVM)
   if (!ret) return nullptr;  // OutOfMemoryError already pending
-  if (retTaskNum > 0) jni::SetShortArrayRegion(env, ret, 0, retTaskNum, out.data());
+  if (res_len > 0) jni::SetShortArrayRegion(env, ret, 0, (jsize)res_len, res);
+  t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)(res_len / 10)};
   return ret;
 }
 
@@ -246,6 +305,7 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
     throw_runtime(env, "bPSW: mateSWJNI: bad arguments");
     return nullptr;
   }
+  const double t0 = now_us();
   const MateIds* ids = mate_ids(env);
   if (!ids) return nullptr;  // NoClassDefFoundError / NoSuchFieldError pending
   jclass regCls = ids->regCls, mateCls = ids->mateCls;
@@ -280,9 +340,12 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
     }
   }
   const size_t ends = 2 * (size_t)groupSize;
-  std::vector<int32_t> seq_len(ends, 0), reg_cnt(ends, 0), ref_cnt(ends, 0);
-  std::vector<int64_t> seq_off(ends, 0);
-  std::vector<uint8_t> seq_pool, ref_pool;
+  MateScratch& ms = t_ms;
+  std::vector<int32_t>&seq_len = ms.seq_len, &reg_cnt = ms.reg_cnt, &ref_cnt = ms.ref_cnt;
+  std::vector<int64_t>& seq_off = ms.seq_off;
+  seq_len.assign(ends, 0); reg_cnt.assign(ends, 0); ref_cnt.assign(ends, 0); seq_off.assign(ends, 0);
+  BytePool &seq_pool = ms.seq_pool, &ref_pool = ms.ref_pool;
+  seq_pool.clear(); ref_pool.clear();
   auto end_index = [&](jint k, jint i) -> long { return (k < 0 || k >= groupSize || i < 0 || i > 1) ? -1 : 2l * k + i; };
 
   {  // ---- SeqSWType[] (native/jni_mate_sw.c:258-278) ----
@@ -304,11 +367,12 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
   const RegIds& rf = ids->rf;
   jfieldID mRid = ids->mRid, mPid = ids->mPid, mReg = ids->mReg, mAln = ids->mAln;
 
-  std::vector<bpsw_alnreg_t> regs;
+  std::vector<bpsw_alnreg_t>& regs = ms.regs;
   {  // ---- MateSWType[] -> regions grouped by (k,i) in arrival order (native/jni_mate_sw.c:300-345) ----
     const jsize n = jni::GetArrayLength(env, mateArr);
-    std::vector<bpsw_alnreg_t> tmp((size_t)n);
-    std::vector<long> where((size_t)n);
+    std::vector<bpsw_alnreg_t>& tmp = ms.tmp;
+    std::vector<long>& where = ms.where;
+    tmp.resize((size_t)n); where.resize((size_t)n);
     for (jsize s = 0; s < n; ++s) {
       jobject o = jni::GetObjectArrayElement(env, mateArr, s);
       const long e = o ? end_index(jni::GetIntField(env, o, mRid), jni::GetIntField(env, o, mPid)) : -1;
@@ -327,17 +391,19 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       jni::DeleteLocalRef(env, a);
       jni::DeleteLocalRef(env, o);
     }
-    std::vector<int64_t> at(ends + 1, 0);
+    std::vector<int64_t>& at = ms.at;
+    at.assign(ends + 1, 0);
     for (size_t e = 0; e < ends; ++e) at[e + 1] = at[e] + reg_cnt[e];
     regs.resize((size_t)n);
     for (jsize s = 0; s < n; ++s) regs[(size_t)at[(size_t)where[(size_t)s]]++] = tmp[(size_t)s];
   }
-  std::vector<int64_t> ref_rb, ref_re, ref_len, ref_off;
+  std::vector<int64_t>&ref_rb = ms.ref_rb, &ref_re = ms.ref_re, &ref_len = ms.ref_len, &ref_off = ms.ref_off;
   size_t coord_windows = 0, byte_windows = 0;
   {  // ---- refSizeArray + RefSWType[] (native/jni_mate_sw.c:352-518) ----
     if (jni::GetArrayLength(env, refSizeArr) < (jsize)ends) { throw_runtime(env, "bPSW: mateSWJNI: refSizeArray too short"); return nullptr; }
     if (ends) jni::GetIntArrayRegion(env, refSizeArr, 0, (jsize)ends, ref_cnt.data());
-    std::vector<int64_t> base(ends + 1, 0);
+    std::vector<int64_t>& base = ms.base;
+    base.assign(ends + 1, 0);
     for (size_t e = 0; e < ends; ++e) {
       if (ref_cnt[e] < 0) { throw_runtime(env, "bPSW: mateSWJNI: negative refSizeArray entry"); return nullptr; }
       base[e + 1] = base[e] + ref_cnt[e];
@@ -375,12 +441,12 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       jni::PopLocalFrame(env, nullptr);
     }
   }
-  if (seq_pool.empty()) seq_pool.resize(16);
-  if (ref_pool.empty()) ref_pool.resize(16);
-  g.seq_len = seq_len.data(); g.seq_off = seq_off.data(); g.seq_pool = seq_pool.data(); g.seq_pool_bytes = seq_pool.size();
+  if (seq_pool.n == 0) memset(seq_pool.grow(16), 0, 16);
+  if (ref_pool.n == 0) memset(ref_pool.grow(16), 0, 16);
+  g.seq_len = seq_len.data(); g.seq_off = seq_off.data(); g.seq_pool = seq_pool.p; g.seq_pool_bytes = seq_pool.n;
   g.reg_cnt = reg_cnt.data(); g.regs = regs.data(); g.ref_cnt = ref_cnt.data();
   g.ref_rb = ref_rb.data(); g.ref_re = ref_re.data(); g.ref_len = ref_len.data(); g.ref_off = ref_off.data();
-  g.ref_pool = ref_pool.data(); g.ref_pool_bytes = ref_pool.size();
+  g.ref_pool = ref_pool.p; g.ref_pool_bytes = ref_pool.n;
   if (coord_windows > 0) {
     if (byte_windows > 0) { throw_runtime(env, "bPSW: mateSWJNI: RefSWType windows must all carry bytes or all be coordinates"); return nullptr; }
     g.ref_pool = nullptr; g.ref_pool_bytes = 0; g.ref_len = nullptr; g.ref_off = nullptr;
@@ -388,9 +454,12 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
 
   bpsw_ctx_t* ctx = thread_context(env);
   if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
-  std::vector<int32_t> out_cnt(ends ? ends : 1);
-  std::vector<bpsw_alnreg_t> out(regs.size() + 4 * ref_rb.size() / 4 + 16);
+  std::vector<int32_t>& out_cnt = ms.out_cnt;
+  std::vector<bpsw_alnreg_t>& out = ms.out;
+  out_cnt.resize(ends ? ends : 1);
+  out.resize(regs.size() + 4 * ref_rb.size() / 4 + 16);
   int64_t total = 0;
+  const double t1 = now_us();
   const char* compat = getenv("BPSW_MATESW_COMPAT");
   const int mode = (compat && strcmp(compat, "scala") == 0) ? BPSW_RESCUE_SCALA : BPSW_RESCUE_C;
   int rc = bpsw_matesw_group(ctx, &opt, &g, mode, out_cnt.data(), out.data(), (int64_t)out.size(), &total);
@@ -401,6 +470,7 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
   if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: mateSWJNI: ") + bpsw_last_error()); return nullptr; }
 
   // ---- result: MateSWType[] in (k, i, rank) order (native/jni_mate_sw.c:548-591) ----
+  const double t2 = now_us();
   jobjectArray ret = jni::NewObjectArray(env, (jsize)total, mateCls, nullptr);
   if (!ret) return nullptr;
   int64_t at = 0;
@@ -422,6 +492,7 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       jni::SetObjectArrayElement(env, ret, (jsize)at, m);
       jni::PopLocalFrame(env, nullptr);
     }
+  t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)total};
   return ret;
 }
 

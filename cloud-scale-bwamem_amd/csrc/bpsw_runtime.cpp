@@ -485,11 +485,31 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
   return BPSW_OK;
 }
 
-static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how);
+static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how,
+                             const int16_t** out_view = nullptr);
 static inline bool side_how_blocks_quad(const uint8_t*) { return false; }  // the classify entry runs the same launch plan
 
 int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len) {
   return extend_batch_impl(c, wire, wire_bytes, out, out_len, nullptr);
+}
+
+int bpsw_extend_stage(bpsw_ctx_t* c, size_t bytes, uint8_t** buf) {
+  if (!c || !buf) return fail(BPSW_ERR_ARG, "extend_stage: null argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
+  // room for the batch and for the task list the launch plan may stage behind it (at most one int per 32-byte record)
+  HIP_TRY(c->h_stage_in.reserve(bytes + bytes / 8 + 4096));
+  *buf = (uint8_t*)c->h_stage_in.ptr;
+  return BPSW_OK;
+}
+
+int bpsw_extend_commit(bpsw_ctx_t* c, size_t wire_bytes, const int16_t** out, size_t* out_len) {
+  if (!c || !out) return fail(BPSW_ERR_ARG, "extend_commit: null argument");
+  if (!c->h_stage_in.ptr) return fail(BPSW_ERR_ARG, "extend_commit: nothing staged (call bpsw_extend_stage first)");
+  const int rc = extend_batch_impl(c, (const uint8_t*)c->h_stage_in.ptr, wire_bytes, nullptr, 0, nullptr, out);
+  if (rc == BPSW_OK && out_len) *out_len = *out ? 10 * (size_t)rd32((const uint8_t*)c->h_stage_in.ptr, 8) : 0;
+  return rc;
 }
 
 int bpsw_extend_batch_classify(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how) {
@@ -497,7 +517,10 @@ int bpsw_extend_batch_classify(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_b
   return extend_batch_impl(c, wire, wire_bytes, out, out_len, side_how);
 }
 
-static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how) {
+// wire == the context's pinned staging block (bpsw_extend_stage): the batch is already where the copy engine reads it, nothing is
+// copied in.  out_view: the caller takes the results where the kernel wrote them (the pinned result block), nothing is copied out.
+static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how,
+                             const int16_t** out_view) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   int n = 0, mq = 0, mr = 0;
   bool coord = false;
@@ -535,7 +558,8 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   const bool with_list = use_short && use_full;
   const size_t stage_bytes = with_list ? list_off + 4 * (1 + (size_t)n_long) : wire_bytes;
   const size_t dev_bytes = with_list ? list_off + 4 * (1 + (size_t)n) : wire_bytes;
-  if (!out || out_len < 10 * (size_t)n) return fail(BPSW_ERR_CAPACITY, "extend: result buffer smaller than 10*n int16");
+  if (!out_view && (!out || out_len < 10 * (size_t)n)) return fail(BPSW_ERR_CAPACITY, "extend: result buffer smaller than 10*n int16");
+  if (out_view) *out_view = nullptr;
   if (n == 0) return BPSW_OK;
   { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
   const size_t out_bytes = 20 * (size_t)n;
@@ -561,10 +585,12 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     quad_fresh = true;  // cleared on the launch stream, in front of ext_kernel (a hipMemset on the null stream is not ordered with it)
   }
   const size_t quad_carry_off = (size_t)c->quad_cap_n;
+  const bool staged = wire == (const uint8_t*)c->h_stage_in.ptr;
+  if (staged && stage_bytes > c->h_stage_in.cap) return fail(BPSW_ERR_ARG, "extend_commit: the staged batch is larger than what bpsw_extend_stage was asked for");
   HIP_TRY(c->h_stage_in.reserve(stage_bytes));
   HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_bytes));
   const double t_in = wall_ms();
-  memcpy(c->h_stage_in.ptr, wire, wire_bytes);
+  if (!staged) memcpy(c->h_stage_in.ptr, wire, wire_bytes);
   if (with_list) {  // rides on the same copy
     int* hl = (int*)((char*)c->h_stage_in.ptr + list_off);
     hl[0] = n_long;
@@ -641,6 +667,8 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       memcpy(dst + 20 * (size_t)t, src + 32 * (size_t)t, 16);
       memcpy(dst + 20 * (size_t)t + 16, src + 32 * (size_t)t + 16, 4);
     }
+  } else if (out_view) {
+    *out_view = (const int16_t*)c->h_stage_out.ptr;  // valid until the next call on this context
   } else {
     memcpy(out, c->h_stage_out.ptr, out_bytes);
   }

@@ -90,6 +90,15 @@ int bpsw_set_ext_shortcuts(bpsw_ctx_t *ctx, int mask);
  */
 int bpsw_extend_batch(bpsw_ctx_t *ctx, const uint8_t *wire, size_t wire_bytes, int16_t *out, size_t out_len);
 
+/* Single-touch form of bpsw_extend_batch for callers that can fill a buffer themselves (the JNI shim: GetByteArrayRegion of
+ * swExtendFPGAJNI's byte[] straight into pinned memory, where the reference does one memcpy into its shared-memory segment,
+ * src/main/jni_fpga/sw_extend_fpga.c:146-155).  bpsw_extend_stage returns the context's pinned staging block with room for
+ * `bytes`; the caller writes the wire batch there and calls bpsw_extend_commit, which runs the batch without copying it again
+ * and returns a VIEW of the 10*n int16 results where the kernel wrote them (*out, *out_len int16; valid until the next call on
+ * the context; n == 0 gives *out == NULL).  One thread per context, as everywhere. */
+int bpsw_extend_stage(bpsw_ctx_t *ctx, size_t bytes, uint8_t **buf);
+int bpsw_extend_commit(bpsw_ctx_t *ctx, size_t wire_bytes, const int16_t **out, size_t *out_len);
+
 /* Diagnostics: bpsw_extend_batch that also reports, per task and side (side_how[2 t] left, [2 t + 1] right; 2 n bytes), how the
  * result was produced: 0 = the side is empty, 1 = an exact shortcut (bpsw_set_ext_shortcuts), 2 = the DP was swept.  bench.py
  * uses it to split the useful cell updates per second into "DP run" and "closed form". */

@@ -18,17 +18,12 @@ ROOT = os.path.dirname(HERE)
 FAKE_SO = os.path.join(HERE, "fake_jvm", "libfakejvm.so")
 
 
+from bpsw_hip import jnishim
+
+
 @pytest.fixture(scope="module")
 def fake():
-    src = os.path.join(HERE, "fake_jvm", "fake_jni.cpp")
-    if not os.path.exists(FAKE_SO) or os.path.getmtime(FAKE_SO) < os.path.getmtime(src):
-        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "cloud-scale-bwamem_amd", "csrc"),
-                        "-o", FAKE_SO, src, "-ldl"], check=True)
-    bpsw_hip.load_library()   # torch first (one HIP runtime per process), then the product library
-    lib = C.CDLL(FAKE_SO)
-    lib.fake_jvm_extend.restype = C.c_int
-    lib.fake_jvm_matesw.restype = C.c_int
-    return lib
+    return jnishim.load_fake()[0]
 
 
 def _vp(a):
@@ -36,29 +31,11 @@ def _vp(a):
 
 
 def _extend(fake, wire, n, partition=-1):
-    out = np.zeros(max(10 * n, 1), np.int16)
-    err = C.create_string_buffer(512)
-    rc = fake.fake_jvm_extend(bpsw_hip.LIB_PATH.encode(), partition, _vp(wire), int(wire.size), 10 * n, _vp(out), err, 512)
-    return rc, out[: 10 * n], err.value.decode()
+    return jnishim.extend(fake, wire, n, partition)
 
 
 def _matesw(fake, g, partition=-1, pac=None):
-    opt = bpsw_hip.default_opt()
-    ints = np.array([opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.pen_unpaired, opt.pen_clip5, opt.pen_clip3,
-                     opt.w, opt.zdrop, opt.T, opt.flag, opt.min_seed_len, opt.max_ins, opt.max_matesw], np.int32)
-    mat = np.array(list(opt.mat), np.int8)
-    pes = np.array([[p[0], p[1], p[2], p[3], p[4]] for p in g.pes], np.float64)
-    out_cnt = np.zeros(2 * g.group_size + 1, np.int32)
-    cap = int(g.regs.shape[0] + g.ref_rb.shape[0] + 16)
-    out = np.zeros(cap, bpsw_hip.ALNREG_DTYPE)
-    total, frames = C.c_int64(0), C.c_long(0)
-    err = C.create_string_buffer(512)
-    rc = fake.fake_jvm_matesw(bpsw_hip.LIB_PATH.encode(), partition, _vp(ints), C.c_float(opt.mask_level_redun), _vp(mat),
-                              C.c_int64(g.l_pac), _vp(pes), g.group_size, _vp(g.seq_len), _vp(g.seq_off), _vp(g.seq_pool),
-                              _vp(g.reg_cnt), _vp(g.regs), _vp(g.ref_cnt), _vp(g.ref_rb), _vp(g.ref_re), _vp(g.ref_len),
-                              _vp(g.ref_off), _vp(g.ref_pool), _vp(out_cnt), _vp(out), C.c_int64(cap), C.byref(total),
-                              C.byref(frames), err, 512, _vp(pac) if pac is not None else None)
-    return rc, out_cnt[: 2 * g.group_size], out[: total.value], frames.value, err.value.decode()
+    return jnishim.matesw(fake, g, partition, pac)
 
 
 def test_without_a_device_the_shim_raises_a_java_exception(fake):
@@ -69,6 +46,19 @@ def test_without_a_device_the_shim_raises_a_java_exception(fake):
     assert rc == 1 and msg.startswith("java/lang/RuntimeException: bPSW: no usable HIP device")
     rc, _, _, frames, msg = _matesw(fake, synth.rescue_group(4, seed=3, p_resc=0.5))
     assert rc == 1 and "RuntimeException" in msg and frames == 0       # every PushLocalFrame was popped
+
+
+@pytest.mark.gpu
+def test_shim_clock_splits_a_call_at_the_c_abi(fake, ctx):
+    """bpsw_jni_last_times (the shim micro-benchmark's clock): the three parts are measured and the marshalling of a wire batch --
+    one GetByteArrayRegion into pinned staging, one SetShortArrayRegion out of the pinned result block -- stays a small part"""
+    soa = synth.ext_tasks(8000, seed=78)
+    grp = synth.rescue_group(200, seed=79, p_resc=0.3)
+    r = jnishim.shim_rate(bpsw_hip.wire_pack(soa), soa.n, grp, reps=3)
+    e, m = r["swExtendFPGAJNI"], r["mateSWJNI"]
+    assert e["c_abi_call_us"] > 0 and e["marshal_in_us"] > 0 and e["marshal_out_us"] >= 0
+    assert e["shim_share_of_call"] < 0.5
+    assert m["c_abi_call_us"] > 0 and m["regions_out"] >= m["regions_in"] > 0
 
 
 @pytest.mark.gpu

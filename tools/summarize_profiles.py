@@ -19,7 +19,7 @@ def short(name):
     if m:
         return "extend_full" if m.group(1) == "0" else "extend"
     for k, v in (("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("swp_kernel", "swalign2"), ("sw4_kernel", "swalign2"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
-                 ("reg2aln", "reg2aln"), ("chain2aln", "chain2aln"), ("ext_qt", "extend_qt"), ("global_kernel", "global")):
+                 ("reg2aln", "reg2aln"), ("chain2aln", "chain2aln"), ("ext_quad", "extend_quad"), ("global_kernel", "global")):
         if k in name:
             return v
     return name[:40]
