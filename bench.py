@@ -260,6 +260,65 @@ def verify_sample(W, cfg_no, rank, wires, ext_outs, groups, grp_cnts, grp_regs, 
     return {"ext_tasks": int(n_ext), "rescue_pairs": int(n_pairs), "rescue_jobs": int(n_jobs), "mismatches": 0}, work
 
 
+CHR21_LEN = 46_709_983   # GRCh38 chr21 (BASELINE.json configs[1..2]): the length of the counter-hash reference of the coordinate batches
+
+
+def coordinate_batches_breakdown(W, cfg_no, rank, F, fd, wires, groups, structs, grp_cnts, grp_regs, passes, workers):
+    """SURVEY.md 8f.2 in the timed path: the SAME step with the extension batches shipped as COORDINATE batches (wire format 2,
+    include/bpsw.h: query flanks + the seed's reference coordinates; the target flanks are read from the 2-bit reference resident
+    on the device) instead of format 1 (the as-is contract, which `value` is measured on).  The reads are drawn from a chr21-sized
+    counter-hash reference (csrc/bpsw_synth.cpp: bpsw_synth_hash_pac / bpsw_synth_ext_tasks_ref -- the same generator as the
+    format-1 batches with a reference behind it), a sample of the outputs is compared with the oracle run on the byte form of the
+    same tasks.  Reports the rate and the bytes per task of both formats."""
+    from concurrent.futures import ThreadPoolExecutor
+    import bpsw_hip
+    import pyoracle as po
+    from bpsw_hip import synth
+    pac = synth.hash_pac(CHR21_LEN, synth.CONFIG_SEED_BASE + 21)
+    F.ctxs[0].ref_load(pac, CHR21_LEN)   # one copy per device, seen by every context of the device
+
+    def one(b):
+        by, co = synth.ext_tasks_ref(READS_PER_EXT_BATCH, pac, CHR21_LEN, read_len=W["read_len"], sub_rate=W["sub"], indel_rate=W["indel"],
+                                     n_rate=0.001, tail_frac=W["tail_frac"], tail_sub_rate=W["tail_sub"], tail_indel_rate=W["tail_indel"],
+                                     seed=ext_seed(cfg_no, rank, b) + 77)
+        return bpsw_hip.wire_coords_pack(co), co.n, (int(bpsw_hip.wire_pack(by).size) if b < 2 else 0)
+
+    with ThreadPoolExecutor(workers) as ex:
+        made = list(ex.map(one, range(W["ext_batches"])))
+    cw = [m[0] for m in made]
+    cn = [m[1] for m in made]
+    outs = [np.zeros(10 * n, np.int16) for n in cn]
+    items, order = fd.make_items(cw, outs, groups, structs, grp_cnts, grp_regs)
+    reps = max(2, passes // 2)
+    F.run(items)                       # warm-up pass
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        F.run(items)
+    dt = time.perf_counter() - t0
+    # a sample of these outputs against the oracle on the byte form of the same tasks
+    orc = po.Oracle()
+    checked = 0
+    for b in (0, len(cw) - 1):
+        by, co = synth.ext_tasks_ref(READS_PER_EXT_BATCH, pac, CHR21_LEN, read_len=W["read_len"], sub_rate=W["sub"], indel_rate=W["indel"],
+                                     n_rate=0.001, tail_frac=W["tail_frac"], tail_sub_rate=W["tail_sub"], tail_indel_rate=W["tail_indel"],
+                                     seed=ext_seed(cfg_no, rank, b) + 77)
+        sel = np.arange(0, by.n, max(1, by.n // 512))
+        want, _ = orc.wire_extend(bpsw_hip.wire_pack(by.subset(sel)))
+        if not np.array_equal(outs[b].reshape(-1, 10)[sel], np.asarray(want).reshape(-1, 10)):
+            raise SystemExit(f"bench: coordinate-batch outputs of batch {b} differ from the oracle on the byte form of the same tasks")
+        checked += len(sel)
+    reads = READS_PER_EXT_BATCH * W["ext_batches"]
+    f1 = sum(m[2] for m in made[:2]) / max(sum(cn[:2]), 1)
+    f2 = sum(int(w.size) for w in cw) / max(sum(cn), 1)
+    return {"reads_per_s": round(reads * reps / dt, 1), "ms_per_pass": round(1e3 * dt / reps, 3), "passes_timed": reps,
+            "wire_bytes_per_task": {"format_1_as_is": round(f1, 1), "format_2_coordinates": round(f2, 1)},
+            "reference": f"counter-hash 2-bit reference of {CHR21_LEN} bases (chr21-sized), resident on the device ({(CHR21_LEN + 3) // 4} bytes)",
+            "verified_tasks": int(checked),
+            "note": "same timed region as `value` (host buffers in and out, every boundary-1 group of the step included) with the extension "
+                    "batches in wire format 2; needs the Scala driver to ship (rBeg, len) instead of leftRs / rightRs (INTEGRATION.md), so it is a "
+                    "breakdown, not the metric"}
+
+
 def device_resident_breakdown(W, cfg_no, rank, wires, ntasks, dev, local_rank, reps):
     """the round-1 measurement, kept as a breakdown: four wire batches + the rescue jobs of the same 65 536 pairs already in
     HBM, issued through the asynchronous device entries on five contexts; kernels only (no H2D/D2H, no boundary-1 host layer)"""
@@ -560,6 +619,12 @@ def main():
             extras["device_resident"] = device_resident_breakdown(W, args.config, rank, wires, ntasks, dev, local_rank, reps=max(3, min(args.steps, 10)))
         except Exception as e:  # noqa: BLE001 -- a breakdown line must never cost the bench its JSON
             extras["device_resident"] = {"error": repr(e)}
+        if rank == 0 and world == 1 and wires and only == "":
+            try:
+                extras["coordinate_batches"] = coordinate_batches_breakdown(W, args.config, rank, F, fd, wires, groups, structs, grp_cnts, grp_regs,
+                                                                            passes, max(2, min(8, len(share))))
+            except Exception as e:  # noqa: BLE001
+                extras["coordinate_batches"] = {"error": repr(e)}
         if rank == 0 and world == 1 and wires and groups:
             # what the JNI shim adds around the C ABI calls the timed region makes (fake JNIEnv: a JVM exists on neither box)
             try:
@@ -621,7 +686,11 @@ def main():
                  "phase_ms_per_call": {"extend": {k: round(st["ext_" + k + "_ms"] / max(ext_launches, 1), 4) for k in ("host_in", "wait", "dev", "host_out")},
                                        "matesw_group": {k: round(st["grp_" + k + "_ms"] / max(int(st["grp_calls"]), 1), 4)
                                                         for k in ("plan", "pack", "wait", "dev", "replay", "out")}}, "pcie_bytes_per_step": int(pcie_bytes_per_step),
-                 "pcie_GBps": round(pcie_bytes_per_step * args.steps / elapsed / 1e9, 3)},
+                 "pcie_GBps": round(pcie_bytes_per_step * args.steps / elapsed / 1e9, 3),
+                 "dram_bytes_per_step_est": int(passes * (3 * sum(int(w.size) for w in wires) + 2 * 20 * sum(ntasks)) + 3 * (pcie_bytes_per_step - passes * (sum(int(w.size) for w in wires) + 20 * sum(ntasks)))),
+                 "dram_note": "estimate of host DRAM traffic per step: a wire batch is read by the staging memcpy, written to the pinned block and read by the "
+                              "copy engine (3 touches; the JNI shim now writes it into the pinned block directly, 2 touches); results are written over PCIe and "
+                              "read once; the rescue inputs that travel are read, written to pinned staging and read over PCIe"},
         "breakdown": extras,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

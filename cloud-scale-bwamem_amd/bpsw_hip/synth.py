@@ -67,6 +67,51 @@ def ext_tasks(n_reads: int, read_len: int = 150, sub_rate: float = 0.01, indel_r
     return ExtTaskSoA(pool=pool[: max(used.value, 1)].copy(), **{k: v[:n].copy() for k, v in f.items()})
 
 
+def hash_pac(l_pac: int, seed: int = CONFIG_SEED_BASE + 77) -> np.ndarray:
+    """A 2-bit .pac of l_pac i.i.d. bases from a counter hash (SURVEY.md 8d: any window can be regenerated from its coordinates);
+    chr21-sized references take a fraction of a second"""
+    lib = _load()
+    pac = np.zeros((l_pac + 3) // 4, np.uint8)
+    lib.bpsw_synth_hash_pac(C.c_int64(l_pac), C.c_uint64(seed), pac.ctypes.data_as(C.c_void_p))
+    return pac
+
+
+def ext_tasks_ref(n_reads: int, pac: np.ndarray, l_pac: int, read_len: int = 150, sub_rate: float = 0.01, indel_rate: float = 0.001,
+                  n_rate: float = 0.001, tail_frac: float = 0.0, tail_sub_rate: float = 0.2, tail_indel_rate: float = 0.02,
+                  seed: int = CONFIG_SEED_BASE + 3, second_seed: bool = True):
+    """ext_tasks with the reads drawn from the reference `pac`: returns (byte tasks, coordinate tasks) of the SAME seeds -- what the
+    Scala driver ships today (ExtTaskSoA) and what a coordinate batch ships instead (ExtCoordTaskSoA, wire format 2)"""
+    from . import ExtCoordTaskSoA
+    lib = _load()
+    lib.bpsw_synth_ext_tasks_ref.restype = C.c_int
+    cfg = _ExtCfg(seed=seed, n_reads=n_reads, read_len=read_len, sub_rate=sub_rate, indel_rate=indel_rate,
+                  n_rate=n_rate, tail_frac=tail_frac, tail_sub_rate=tail_sub_rate, tail_indel_rate=tail_indel_rate,
+                  a=1, o_del=6, e_del=1, o_ins=6, e_ins=1, w=100, min_seed_len=19, second_seed=int(second_seed))
+    cap = 2 * n_reads + 1
+    i32 = lambda: np.zeros(cap, dtype=np.int32)  # noqa: E731
+    i64 = lambda: np.zeros(cap, dtype=np.int64)  # noqa: E731
+    f = dict(left_qlen=i32(), left_rlen=i32(), right_qlen=i32(), right_rlen=i32(), left_q_off=i64(), left_r_off=i64(),
+             right_q_off=i64(), right_r_off=i64(), reg_score=i32(), q_beg=i32(), h0=i32(), idx=i32())
+    srb, sln = i64(), i32()
+    pool_cap = int(cap) * (4 * read_len + 16)
+    pool = np.zeros(pool_cap, dtype=np.uint8)
+    used = C.c_size_t(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    pac = np.ascontiguousarray(pac, np.uint8)
+    n = lib.bpsw_synth_ext_tasks_ref(C.byref(cfg), vp(pac), C.c_int64(l_pac), vp(f["left_qlen"]), vp(f["left_rlen"]), vp(f["right_qlen"]),
+                                     vp(f["right_rlen"]), vp(f["left_q_off"]), vp(f["left_r_off"]), vp(f["right_q_off"]),
+                                     vp(f["right_r_off"]), vp(f["reg_score"]), vp(f["q_beg"]), vp(f["h0"]), vp(f["idx"]), vp(srb), vp(sln),
+                                     vp(pool), C.c_size_t(pool_cap), C.byref(used))
+    if n < 0:
+        raise BpswError("synthetic pool too small (or the reference shorter than a read's window)")
+    poolv = pool[: max(used.value, 1)].copy()
+    by = ExtTaskSoA(pool=poolv, **{k: v[:n].copy() for k, v in f.items()})
+    co = ExtCoordTaskSoA(pool=poolv, seed_len=sln[:n].copy(), seed_rbeg=srb[:n].copy(),
+                         **{k: f[k][:n].copy() for k in ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "left_q_off", "right_q_off",
+                                                         "reg_score", "q_beg", "h0", "idx")})
+    return by, co
+
+
 def sw_jobs(n_jobs: int, read_len: int = 150, win_min: int = 450, win_max: int = 750, sub_rate: float = 0.02,
             indel_rate: float = 0.002, n_rate: float = 0.001, unrelated_frac: float = 0.25, decoy_frac: float = 0.5,
             rev_frac: float = 0.5, seed: int = CONFIG_SEED_BASE + 3):

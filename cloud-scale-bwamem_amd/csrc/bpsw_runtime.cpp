@@ -227,7 +227,18 @@ int stream_pool_cap() {
   static const int cap = [] {
     const char* e = getenv("BPSW_STREAM_POOL");
     int v = e ? atoi(e) : 20;
-    return v < 0 ? 0 : (v > 64 ? 64 : v);
+    v = v < 0 ? 0 : (v > 64 ? 64 : v);
+    // The runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and serialises the streams that
+    // share one: more pooled streams than queues buys nothing, so the pool is clamped to the queue count -- and an executor that was
+    // started without the variable is told once, because it runs at a fraction of the rate it could.
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    const int queues = q && atoi(q) > 0 ? atoi(q) : 4;
+    if (v > queues) {
+      if (!q) fprintf(stderr, "bPSW: GPU_MAX_HW_QUEUES is not set: the HIP runtime gives this process 4 hardware queues, so only 4 calls run on the "
+                              "GPU at a time; start the executor with GPU_MAX_HW_QUEUES=20 (two executors per GPU: 10 each)\n");
+      v = queues;
+    }
+    return v;
   }();
   return cap;
 }

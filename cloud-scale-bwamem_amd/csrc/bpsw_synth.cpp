@@ -135,6 +135,97 @@ int bpsw_synth_ext_tasks(const bpsw_synth_ext_cfg_t* c, int32_t* left_qlen, int3
   return nt;
 }
 
+// ---- the same tasks over a REFERENCE ("windows are generated on demand from a counter-based hash") ------------
+// bpsw_synth_hash_pac fills a 2-bit .pac (BWA layout: base k = pac[k>>2] >> ((~k&3)<<1) & 3) of l_pac i.i.d. bases from a
+// counter hash (splitmix64 of seed + k/32: 32 bases per word), so a reference of any length costs no RNG state and any window
+// can be regenerated from its coordinates.
+static inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+void bpsw_synth_hash_pac(int64_t l_pac, uint64_t seed, uint8_t* pac) {
+  const int64_t n_bytes = (l_pac + 3) / 4;
+  for (int64_t w = 0; 8 * w < n_bytes; ++w) {
+    const uint64_t h = splitmix64(seed + (uint64_t)w);
+    for (int b = 0; b < 8 && 8 * w + b < n_bytes; ++b) pac[8 * w + b] = (uint8_t)(h >> (8 * b));
+  }
+  if (l_pac & 3) pac[n_bytes - 1] &= (uint8_t)(0xff << (2 * (4 - (l_pac & 3))));  // bases past l_pac are zero
+}
+static inline int pac_base2(const uint8_t* pac, int64_t l_pac, int64_t k) {  // doubled coordinates, bnsGetSeq (BNTSeqUtil.scala:56-73)
+  const bool rev = k >= l_pac;
+  const int64_t f = rev ? 2 * l_pac - 1 - k : k;
+  const int b = (pac[f >> 2] >> ((~f & 3) << 1)) & 3;
+  return rev ? 3 - b : b;
+}
+
+// bpsw_synth_ext_tasks with every read drawn from the reference `pac` (uniform position, either strand): the same seeds, the
+// same flanks, emitted BOTH as byte tasks (left_r_off / right_r_off: the target flanks copied out of the reference, what the
+// Scala driver ships today) and as coordinates (seed_rbeg in [0, 2*l_pac), seed_len: what a coordinate batch ships instead,
+// include/bpsw.h "wire format 2").  A read's window lies on one strand, so no flank bridges the two.
+int bpsw_synth_ext_tasks_ref(const bpsw_synth_ext_cfg_t* c, const uint8_t* pac, int64_t l_pac, int32_t* left_qlen, int32_t* left_rlen,
+                             int32_t* right_qlen, int32_t* right_rlen, int64_t* left_q_off, int64_t* left_r_off, int64_t* right_q_off,
+                             int64_t* right_r_off, int32_t* reg_score, int32_t* q_beg, int32_t* h0, int32_t* idx, int64_t* seed_rbeg,
+                             int32_t* seed_len, uint8_t* pool, size_t pool_cap, size_t* pool_used) {
+  Rng g(c->seed);
+  const int L = c->read_len;
+  const int flank = L + cal_max_gap(L, c->a, c->o_del, c->e_del, c->o_ins, c->e_ins, c->w) + 8;
+  const size_t win = (size_t)L * 3 + 2 * (size_t)flank + 64;
+  if (l_pac < (int64_t)win + 2) return -1;
+  std::vector<uint8_t> ref(win), read;
+  std::vector<int> rpos;
+  std::vector<Seed> seeds;
+  size_t used = 0;
+  int nt = 0;
+  for (int rd = 0; rd < c->n_reads; ++rd) {
+    const int64_t strand = (g.next() >> 63) ? l_pac : 0;
+    const int64_t w0 = strand + (int64_t)(g.next() % (uint64_t)(l_pac - (int64_t)win));  // the window, in doubled coordinates
+    for (size_t k = 0; k < win; ++k) ref[k] = (uint8_t)pac_base2(pac, l_pac, w0 + (int64_t)k);
+    const bool tail = g.uni() < c->tail_frac;
+    const double sub = tail ? c->tail_sub_rate : c->sub_rate, ind = tail ? c->tail_indel_rate : c->indel_rate;
+    const int origin = flank;
+    make_read(g, ref.data() + origin, (int)ref.size() - origin - flank, L, sub, ind, c->n_rate, read, rpos);
+    seeds.clear();
+    for (int i = 0; i < L;) {
+      if (rpos[i] < 0) { ++i; continue; }
+      int j = i + 1;
+      while (j < L && rpos[j] == rpos[j - 1] + 1) ++j;
+      if (j - i >= c->min_seed_len) seeds.push_back({i, origin + rpos[i], j - i});
+      i = j;
+    }
+    if (seeds.empty()) continue;
+    std::stable_sort(seeds.begin(), seeds.end(), [](const Seed& x, const Seed& y) { return x.len > y.len; });
+    int n_emit = 1;
+    if (c->second_seed && seeds.size() > 1 && seeds[0].len * 5 < L * 2) n_emit = 2;
+    for (int e = 0; e < n_emit; ++e) {
+      const Seed s = seeds[e];
+      const int lq = s.qb, rq = L - (s.qb + s.len);
+      if (lq == 0 && rq == 0) continue;
+      int lr = lq ? lq + cal_max_gap(lq, c->a, c->o_del, c->e_del, c->o_ins, c->e_ins, c->w) : 0;
+      int rr = rq ? rq + cal_max_gap(rq, c->a, c->o_del, c->e_del, c->o_ins, c->e_ins, c->w) : 0;
+      if (lr > s.rb) lr = s.rb;
+      if (rr > (int)ref.size() - (s.rb + s.len)) rr = (int)ref.size() - (s.rb + s.len);
+      const size_t need = (size_t)lq + lr + rq + rr;
+      if (used + need > pool_cap) return -1;
+      left_qlen[nt] = lq; left_rlen[nt] = lr; right_qlen[nt] = rq; right_rlen[nt] = rr;
+      left_q_off[nt] = (int64_t)used;
+      for (int i = 0; i < lq; ++i) pool[used++] = read[lq - 1 - i];
+      left_r_off[nt] = (int64_t)used;
+      for (int i = 0; i < lr; ++i) pool[used++] = ref[s.rb - 1 - i];
+      right_q_off[nt] = (int64_t)used;
+      for (int i = 0; i < rq; ++i) pool[used++] = read[s.qb + s.len + i];
+      right_r_off[nt] = (int64_t)used;
+      for (int i = 0; i < rr; ++i) pool[used++] = ref[s.rb + s.len + i];
+      reg_score[nt] = s.len * c->a; h0[nt] = s.len * c->a; q_beg[nt] = s.qb; idx[nt] = rd;
+      seed_rbeg[nt] = w0 + s.rb; seed_len[nt] = s.len;
+      ++nt;
+    }
+  }
+  if (pool_used) *pool_used = used;
+  return nt;
+}
+
 typedef struct {
   uint64_t seed;
   int32_t n_jobs, read_len;

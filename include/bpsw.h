@@ -59,7 +59,11 @@ typedef struct bpsw_ctx bpsw_ctx_t;
 
 /* ---- life cycle ------------------------------------------------------------------------- */
 int bpsw_device_count(void);
-/* device < 0: pick from BPSW_DEVICES / round robin (INTEGRATION.md "device selection") */
+/* device < 0: pick from BPSW_DEVICES / round robin (INTEGRATION.md "device selection").
+ * Side effects on the PROCESS, both documented in INTEGRATION.md: the first bpsw_create on a device asks the HIP runtime for
+ * interrupt-driven waits on it (hipSetDeviceFlags(hipDeviceScheduleBlockingSync); BPSW_SPIN_WAIT=1 leaves the runtime's default),
+ * and the device phases of all contexts of a device share a pool of min(BPSW_STREAM_POOL = 20, GPU_MAX_HW_QUEUES) streams --
+ * GPU_MAX_HW_QUEUES must be in the executor's environment before the runtime initialises (unset: 4 queues, one warning on stderr). */
 int bpsw_create(int device, bpsw_ctx_t **out);
 void bpsw_destroy(bpsw_ctx_t *ctx);
 int bpsw_device_of(const bpsw_ctx_t *ctx);

@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# the library's stream pool is clamped to the process's HIP hardware queues (default 4): the multi-threaded tests want what an
+# executor is told to set; must be in the environment before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "cloud-scale-bwamem_amd")
 for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):

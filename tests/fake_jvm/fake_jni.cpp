@@ -21,11 +21,27 @@
 
 namespace {
 
+// Field names are interned to small integers once (GetFieldID does it for the shim, the drivers below for the harness), and an
+// object keeps its fields in slot-indexed vectors: a Get<Type>Field is an index, as in a JVM (an offset), not a string-keyed map
+// lookup -- the shim's micro-benchmark (bpsw_hip/jnishim.py) times the shim, not this harness.
+int intern_field(const std::string& name);
+template <class T>
+struct Slots {
+  std::vector<T> v;
+  std::vector<uint8_t> has;
+  T& at_id(int id) {
+    if ((size_t)id >= v.size()) { v.resize((size_t)id + 1, T()); has.resize((size_t)id + 1, 0); }
+    has[(size_t)id] = 1;
+    return v[(size_t)id];
+  }
+  const T* find_id(int id) const { return ((size_t)id < v.size() && has[(size_t)id]) ? &v[(size_t)id] : nullptr; }
+  T& operator[](const std::string& name) { return at_id(intern_field(name)); }  // harness side: by name
+};
 struct FObj {
   std::string cls;  // class name, or "[B" "[S" "[I" "[J" "[L" for arrays, or "class" for a jclass handle
-  std::map<std::string, int64_t> ints;
-  std::map<std::string, double> dbls;
-  std::map<std::string, FObj*> objs;
+  Slots<int64_t> ints;
+  Slots<double> dbls;
+  Slots<FObj*> objs;
   std::vector<int8_t> bytes;
   std::vector<int16_t> shorts;
   std::vector<int32_t> ia;
@@ -33,7 +49,7 @@ struct FObj {
   std::vector<double> da;
   std::vector<FObj*> elems;
 };
-struct FField { std::string name, sig; };
+struct FField { std::string name, sig; int id; };
 
 // What a real JVM keeps for the life of the process: loaded classes and their field / method IDs.  The shim caches both
 // (global references + IDs) across calls, so they must outlive the per-call object heap below.  `lookups` counts FindClass /
@@ -47,6 +63,16 @@ struct ClassWorld {
   std::atomic<long> global_refs{0};
 };
 ClassWorld g_world;
+int intern_field(const std::string& name) {
+  static std::mutex mu;
+  static std::map<std::string, int> ids;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = ids.find(name);
+  if (it != ids.end()) return it->second;
+  const int id = (int)ids.size();
+  ids[name] = id;
+  return id;
+}
 
 struct Jvm {
   std::vector<std::unique_ptr<FObj>> heap;
@@ -103,21 +129,21 @@ jfieldID f_GetFieldID(JNIEnv*, jclass, const char* name, const char* sig) {
   g_vm->calls[JNI_SLOT_GetFieldID]++;
   g_world.lookups++;
   std::lock_guard<std::mutex> lk(g_world.mu);
-  g_world.fields.emplace_back(new FField{name, sig});
+  g_world.fields.emplace_back(new FField{name, sig, intern_field(name)});
   return reinterpret_cast<jfieldID>(g_world.fields.back().get());
 }
 const FField* F(jfieldID f) { return reinterpret_cast<const FField*>(f); }
 jobject f_GetObjectField(JNIEnv*, jobject o, jfieldID f) {
-  auto it = O(o)->objs.find(F(f)->name);
-  return it == O(o)->objs.end() ? nullptr : J(it->second);
+  FObj* const* p = O(o)->objs.find_id(F(f)->id);
+  return p ? J(*p) : nullptr;
 }
-jint f_GetIntField(JNIEnv*, jobject o, jfieldID f) { return (jint)O(o)->ints[F(f)->name]; }
-jlong f_GetLongField(JNIEnv*, jobject o, jfieldID f) { return (jlong)O(o)->ints[F(f)->name]; }
-jfloat f_GetFloatField(JNIEnv*, jobject o, jfieldID f) { return (jfloat)O(o)->dbls[F(f)->name]; }
-jdouble f_GetDoubleField(JNIEnv*, jobject o, jfieldID f) { return O(o)->dbls[F(f)->name]; }
-void f_SetObjectField(JNIEnv*, jobject o, jfieldID f, jobject v) { O(o)->objs[F(f)->name] = O(v); }
-void f_SetIntField(JNIEnv*, jobject o, jfieldID f, jint v) { O(o)->ints[F(f)->name] = v; }
-void f_SetLongField(JNIEnv*, jobject o, jfieldID f, jlong v) { O(o)->ints[F(f)->name] = v; }
+jint f_GetIntField(JNIEnv*, jobject o, jfieldID f) { const int64_t* p = O(o)->ints.find_id(F(f)->id); return p ? (jint)*p : 0; }
+jlong f_GetLongField(JNIEnv*, jobject o, jfieldID f) { const int64_t* p = O(o)->ints.find_id(F(f)->id); return p ? (jlong)*p : 0; }
+jfloat f_GetFloatField(JNIEnv*, jobject o, jfieldID f) { const double* p = O(o)->dbls.find_id(F(f)->id); return p ? (jfloat)*p : 0.f; }
+jdouble f_GetDoubleField(JNIEnv*, jobject o, jfieldID f) { const double* p = O(o)->dbls.find_id(F(f)->id); return p ? *p : 0.0; }
+void f_SetObjectField(JNIEnv*, jobject o, jfieldID f, jobject v) { O(o)->objs.at_id(F(f)->id) = O(v); }
+void f_SetIntField(JNIEnv*, jobject o, jfieldID f, jint v) { O(o)->ints.at_id(F(f)->id) = v; }
+void f_SetLongField(JNIEnv*, jobject o, jfieldID f, jlong v) { O(o)->ints.at_id(F(f)->id) = v; }
 jmethodID f_GetMethodID(JNIEnv*, jclass, const char* name, const char*) {
   g_world.lookups++;
   std::lock_guard<std::mutex> lk(g_world.mu);

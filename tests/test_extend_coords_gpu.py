@@ -126,3 +126,24 @@ def test_coordinate_batch_through_the_jni_symbol(refctx, fake):
     rc, got, msg = _extend(fake, wire_c, co.n, 2)
     assert rc == 0, msg
     assert np.array_equal(got, want)
+
+
+def test_reference_backed_c_generator_both_forms_agree(refctx, orc):
+    """csrc/bpsw_synth.cpp bpsw_synth_ext_tasks_ref (what `bench.py` ships as coordinate batches): the byte form and the coordinate
+    form of the same seeds give the same results, equal to the oracle; the target flanks of the byte form are bnsGetSeq's windows"""
+    l_pac = 3_000_017
+    pac = synth.hash_pac(l_pac, seed=91)
+    refctx.ref_load(pac, l_pac)
+    by, co = synth.ext_tasks_ref(3000, pac, l_pac, read_len=150, sub_rate=0.02, indel_rate=0.002, seed=92)
+    assert by.n == co.n and by.n > 2000 and (co.seed_rbeg >= l_pac).any() and (co.seed_rbeg < l_pac).any()   # both strands
+    wire_b, wire_c = bpsw_hip.wire_pack(by), bpsw_hip.wire_coords_pack(co)
+    want, _ = orc.wire_extend(wire_b)
+    assert np.array_equal(refctx.extend_batch(wire_b), want)
+    assert np.array_equal(refctx.extend_batch(wire_c), want)
+    for t in range(0, by.n, 97):
+        rb, ln, lr, rr = int(co.seed_rbeg[t]), int(co.seed_len[t]), int(by.left_rlen[t]), int(by.right_rlen[t])
+        if rr:
+            assert np.array_equal(np.asarray(orc.bns_get_seq(l_pac, pac, rb + ln, rb + ln + rr)), by.pool[int(by.right_r_off[t]): int(by.right_r_off[t]) + rr])
+        if lr:
+            assert np.array_equal(np.asarray(orc.bns_get_seq(l_pac, pac, rb - lr, rb))[::-1], by.pool[int(by.left_r_off[t]): int(by.left_r_off[t]) + lr])
+    assert wire_c.size < 0.7 * wire_b.size
