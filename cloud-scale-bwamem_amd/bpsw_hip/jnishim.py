@@ -3,9 +3,9 @@ tests/fake_jvm/fake_jni.cpp, and the shim's own clock (bpsw_jni_last_times: mars
 the last call on the thread) tells what the marshalling costs at the reference's batch sizes.  Not part of the product path.
 
 What the figures mean: for swExtendFPGAJNI the fake env's GetByteArrayRegion / SetShortArrayRegion are memcpys, as HotSpot's are
--- representative.  For mateSWJNI the fake env keeps an object's fields in a map keyed by name, so each of the ~15 Get<Type>Field
-calls per region costs far more than HotSpot's (a handful of ns each): its ns-per-region figure is an UPPER bound on a real JVM for
-the field traffic and says nothing about GC or safepoints."""
+-- representative.  For mateSWJNI the fake env's objects are heap-allocated structs with slot-indexed fields (an index per access,
+like an offset in a JVM, but a `new` with three vectors per AllocObject): its ns-per-region figures are an UPPER bound on a real
+JVM for the field traffic and the allocation, and say nothing about GC or safepoints."""
 import ctypes as C
 import os
 import subprocess
@@ -100,6 +100,7 @@ def shim_rate(wire, n_tasks, group, reps=5):
                             "marshal_in_ns_per_region_in": round(1e3 * float(a[0]) / max(n_in, 1), 1),
                             "marshal_out_ns_per_region_out": round(1e3 * float(a[2]) / max(a[3], 1), 1),
                             "shim_share_of_call": round(float((a[0] + a[2]) / max(a[0] + a[1] + a[2], 1e-9)), 4)}
-    res["note"] = ("fake JNIEnv (tests/fake_jvm): array regions are memcpys as in HotSpot; object fields live in a name-keyed map, so the "
-                   "per-region figures of mateSWJNI are an upper bound on a JVM's field traffic and exclude GC / safepoints; one calling thread")
+    res["note"] = ("fake JNIEnv (tests/fake_jvm): array regions are memcpys as in HotSpot; objects are heap-allocated C++ structs with "
+                   "slot-indexed fields and every Get<Type>Field goes through the function table, so the per-region figures of mateSWJNI are "
+                   "an upper bound on a JVM's field traffic and allocation, and exclude GC / safepoints; one calling thread")
     return res

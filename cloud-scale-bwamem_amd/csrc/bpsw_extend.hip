@@ -22,6 +22,7 @@
 #include <atomic>
 
 #include "bpsw_extend_core.h"
+#include "bpsw_extend_rows.h"
 
 namespace bpsw {
 namespace {
@@ -233,8 +234,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
           int oInsT = oIns, eInsT = eIns;  // opaque copies, as below
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
           int ov = 0;
+#if BPSW_EXT_ADAPTIVE
+          r = sw_extend_adaptive<SHORT == 2>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+#else
           r = sw_extend_reg_short<SHORT == 2>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
-          if (SHORT == 2 && uni(ov)) { deferred = true; break; }
+#endif
+          if (uni(ov)) { deferred = true; break; }
         } else if (reg_path) {
           // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
           // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD

@@ -1,0 +1,469 @@
+// bpsw_extend_rows.h -- the SWExtend row sweep of the 48-VGPR extension kernels (ext_kernel<.., SHORT>) in its third form: an
+// ADAPTIVE window, and a hand-written row loop.
+//
+// What a DP row costs is the pipe time of its instructions: ~4.5 cycles of a SIMD for a half-rate vector
+// instruction (max / min / compare / select / DPP -- most of this kernel), ~2.3 for a full-rate one, ~3.7 for a scalar one, and
+// the sum is what a row takes.  Two things follow.
+//   * One column per lane is much cheaper than two (44 against 75 vector instructions per row), and the band of a row -- the
+//     positive cells around the best one -- fits 64 columns for three rows in four even of 2x250 bp reads at 8 % / 2 % error.  So the
+//     sweep keeps the (H,E) row in a 64-column window with ONE column per lane while the band fits, switches to a 128-column
+//     window with two columns per lane while it does not, and back (ds_bpermute moves the state between the layouts; a column that
+//     enters a window is never read before the band has written it, see sw_extend_il2).
+//   * Half of a row's instructions were scalar control that the compiler builds around a loop with four exits (boolean flags in
+//     SGPR pairs, s_and_b64 vcc / exec before every uniform branch, re-materialised constants).  The one-column loop -- the one that
+//     serves most rows -- is written in GCN assembly here (rows1_asm): every rare case (an N row, a window that has to move, an
+//     empty band) leaves the loop with the row untouched and is served by the C++ form of the same row (rows_cpp<1>), so the
+//     assembly holds only the common path: 32 vector + ~45 scalar instructions per row against 44 + 65.
+// Same arithmetic, same order of evaluation as sw_extend_lean1 / lean2 / leanS (bpsw_extend_core.h), which stay for the full
+// kernel and chain2aln_kernel; BPSW_EXT_ADAPTIVE=0 at build time puts the 48-VGPR kernels back on them.
+#pragma once
+#include "bpsw_extend_core.h"
+
+namespace bpsw {
+namespace {
+
+#ifndef BPSW_EXT_ADAPTIVE
+#define BPSW_EXT_ADAPTIVE 1
+#endif
+#ifndef BPSW_EXT_ROWS_ASM
+#define BPSW_EXT_ROWS_ASM 1  // 0: the C++ form of the one-column loop everywhere (A/B runs, and the reference the tests compare with)
+#endif
+
+// the call's state between the pieces of the sweep: wave-uniform scalars, and per lane the (H,E) row and the profile
+struct RowState {
+  int i, beg, end, h1raw, mx, max_i, max_j, max_ie, gscore, max_off;
+  int base;            // first column of the window
+  int H0, E0, H1, E1;  // one column per lane: column base + lane in H0 / E0; two: columns base + 2 lane, base + 2 lane + 1
+  int plo0, plo1, phi2;
+};
+enum { ROWS_DONE = 0, ROWS_MORE = 1, ROWS_OTHER_MODE = 2, ROWS_SLOW = 3, ROWS_OVERFLOW = 4 };
+constexpr int ROWS_NARROW = 52;  // a band of at most this many columns goes (back) to one column per lane; wider than 63 must leave it
+
+template <int COLS, class QC>
+__device__ __forceinline__ void rows_load_profile(RowState& st, const QC& qcode, const MatRows& mat, const int qLen, const int lane) {
+  st.phi2 = 0;
+#pragma unroll
+  for (int s = 0; s < COLS; ++s) {
+    const int j = st.base + COLS * lane + s;
+    const int code = (j >= 0 && j < qLen) ? qcode(j) : 4;
+    const int sh = 8 * code;
+    const int p = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
+                        (((mat.row[3] >> sh) & 0xff) << 24));
+    if (s == 0) st.plo0 = p; else st.plo1 = p;
+    st.phi2 |= (int)((mat.row[4] >> sh) & 0xff) << (8 * s);
+  }
+}
+
+// The C++ form of the sweep over a window, COLS columns per lane (1: 64 columns, 2: 128), for at most max_rows rows.  It serves
+// every row the assembly loop declines, every row of the two-column layout, and is the reference the assembly is tested against.
+//   ROWS_DONE        the call is over (m == 0, z-drop, the tail-row bound, the last target row)
+//   ROWS_MORE        max_rows rows swept
+//   ROWS_OTHER_MODE  COLS == 1: the next row's band does not fit 64 columns; COLS == 2: it fits ROWS_NARROW columns again
+//   ROWS_OVERFLOW    COLS == 2: the next row's band does not fit 128 columns (the task goes to the full kernel)
+// In the last two cases the row has not been touched.
+template <int COLS, class QC>
+__device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int tLen, const QC& qcode, const uint8_t* __restrict__ ts,
+                        const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
+                        const int zmode, const int h0, const int amax, int max_rows) {
+  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
+  const int jE0 = COLS * lane * eIns - oeIns;  // j*eIns - oeIns of the lane's first column, j counted from the window's origin
+  const int kC = oeIns - eIns;
+  const int col0 = COLS * lane, col1 = COLS * lane + 1;
+  const int WIN = 64 * COLS;
+  int i = st.i, beg = st.beg, end = st.end, h1raw = st.h1raw, mx = st.mx, max_i = st.max_i, max_j = st.max_j, max_ie = st.max_ie;
+  int gscore = st.gscore, max_off = st.max_off, base = st.base;
+  int Hs0 = st.H0, Es0 = st.E0, Hs1 = st.H1, Es1 = st.E1;
+  const int i_tail = amax > 0 ? qLen : 0x7fffffff;
+  const int w1 = w + 1;
+  int ret = ROWS_DONE;
+  const auto save = [&]() {
+    st.i = i; st.beg = beg; st.end = end; st.h1raw = h1raw; st.mx = mx; st.max_i = max_i; st.max_j = max_j; st.max_ie = max_ie;
+    st.gscore = gscore; st.max_off = max_off; st.base = base; st.H0 = Hs0; st.E0 = Es0; st.H1 = Hs1; st.E1 = Es1;
+  };
+  for (; i < tLen; ++i) {
+    if (max_rows-- <= 0) { ret = ROWS_MORE; break; }
+    if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
+      const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
+      const int stop = (U <= mx ? 1 : 0) & (U < gscore ? 1 : 0);
+      if (stop) break;
+    }
+    const int nbeg = smax2(beg, i - w);           // SWUtil.scala:140-142 (idempotent: an untouched row may be clamped again)
+    const int nend = smin2(smin2(end, i + w1), qLen);
+    if (COLS == 2 && nend - nbeg <= ROWS_NARROW && nend > nbeg) { beg = nbeg; end = nend; ret = ROWS_OTHER_MODE; break; }
+    if (nend - base > WIN - 1) {  // column `end` (written this row) lies beyond the window: move the window up
+      const int nb = COLS == 2 ? (nbeg & ~1) : nbeg;
+      if (nend - nb > WIN - 1) { beg = nbeg; end = nend; ret = COLS == 1 ? ROWS_OTHER_MODE : ROWS_OVERFLOW; break; }
+      const int from = (lane + ((nb - base) / COLS)) << 2;  // byte address of the source lane; lanes past 63 wrap and fetch
+      Hs0 = __builtin_amdgcn_ds_bpermute(from, Hs0);        // columns the band has not reached yet (never read before written)
+      Es0 = __builtin_amdgcn_ds_bpermute(from, Es0);
+      if (COLS == 2) {
+        Hs1 = __builtin_amdgcn_ds_bpermute(from, Hs1);
+        Es1 = __builtin_amdgcn_ds_bpermute(from, Es1);
+      }
+      base = nb;
+      st.base = base;
+      rows_load_profile<COLS>(st, qcode, mat, qLen, lane);
+    }
+    beg = nbeg; end = nend;
+    const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base
+    h1raw -= eDel;
+    const int h1 = smax2(0, h1raw);    // SWUtil.scala:137-138
+    const int rbeg = beg - base;       // the band in window coordinates
+    const int span = end - beg;
+    const unsigned spanA = (unsigned)smax2(span, 0);
+    int scv0, scv1 = 0;
+    if (__builtin_expect(tsv == 32, 0)) {  // an N row
+      scv0 = __builtin_amdgcn_sbfe(st.phi2, 0u, 8u);
+      scv1 = __builtin_amdgcn_sbfe(st.phi2, 8u, 8u);
+      asm volatile("" : "+v"(scv0), "+v"(scv1));  // keeps the branch: two selects per row otherwise
+    } else {
+      scv0 = __builtin_amdgcn_sbfe(st.plo0, (unsigned)tsv, 8u);
+      if (COLS == 2) scv1 = __builtin_amdgcn_sbfe(st.plo1, (unsigned)tsv, 8u);
+    }
+    const unsigned rel0 = (unsigned)(col0 - rbeg), rel1 = (unsigned)(col1 - rbeg);
+    const bool act0 = rel0 < spanA, act1 = COLS == 2 && rel1 < spanA;
+    const int a0 = act0 ? max(Hs0 + scv0, Es0) : NEG_A;
+    const int a1 = act1 ? max(Hs1 + scv1, Es1) : NEG_A;
+    const int Pg0 = a0 + jE0, Pg1 = a1 + jE0 + eIns;
+    int Pl = COLS == 2 ? max(Pg0, Pg1) : Pg0;
+    int scan_a = COLS == 2 ? max((a0 << 7) | col0, (a1 << 7) | col1) : ((a0 << 7) | col0);  // the row maximum and its LAST column
+    dual_scan_max(Pl, scan_a);
+    const int Pprev = wave_shr1(NEG, Pl);
+    const int H0 = max3i(a0, Pprev - kC - jE0, 0);
+    const int H1 = COLS == 2 ? max3i(a1, max(Pprev, Pg0) - kC - jE0 - eIns, 0) : 0;
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(act0), m1 = COLS == 2 ? __builtin_amdgcn_ballot_w64(act1) : 0ull;
+    const unsigned long long z0 = __builtin_amdgcn_ballot_w64(H0 < 1) & m0;
+    const unsigned long long z1 = COLS == 2 ? (__builtin_amdgcn_ballot_w64(H1 < 1) & m1) : 0ull;
+    const int En0 = act0 ? max3i(Es0 - eDel, H0 - oeDel, 0) : 0;
+    const int En1 = act1 ? max3i(Es1 - eDel, H1 - oeDel, 0) : 0;
+    if (COLS == 2) {
+      const int hs0 = wave_shr1(h1, H1);  // H(i,j-1)
+      Hs0 = rel0 == 0u ? h1 : hs0;       // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_il2)
+      Hs1 = rel1 == 0u ? h1 : H0;
+      Es1 = En1;
+    } else {
+      const int hs = wave_shr1(h1, H0);
+      Hs0 = rel0 == 0u ? h1 : hs;
+    }
+    Es0 = En0;
+    const int mkey = smax2(0, __builtin_amdgcn_readlane(scan_a, 63));
+    const int m = mkey >> 7, mjr = mkey & 127, mj = base + mjr;
+
+    const int jlast = span > 0 ? end : beg;  // SWUtil.scala:177-182
+    if (jlast == qLen) {
+      int hlast = h1;
+      if (span > 0) {
+        const int e = end - base;
+        if (COLS == 2) {
+          const int he = __builtin_amdgcn_readlane(Hs0, e >> 1), ho = __builtin_amdgcn_readlane(Hs1, e >> 1);
+          hlast = (e & 1) ? ho : he;
+        } else {
+          hlast = __builtin_amdgcn_readlane(Hs0, e);
+        }
+      }
+      const bool better = gscore <= hlast;
+      max_ie = better ? i : max_ie;
+      gscore = better ? hlast : gscore;
+    }
+    if (m == 0) break;  // SWUtil.scala:184-185
+    if (m > mx) {       // SWUtil.scala:187-193
+      const int d = mj - i;
+      max_off = smax2(max_off, smax2(d, -d));
+      mx = m; max_i = i; max_j = mj;
+    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      const int stop = zdrop_stop((i - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode) ? 1 : 0;
+      if (stop) break;
+    }
+    // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj (window coordinates + base)
+    const int nb0 = beg + (h1 == 0 ? 1 : 0);
+    if ((z0 | z1) == 0ull) {
+      beg = nb0;
+      end = end + 1;
+    } else if (COLS == 2) {
+      const int ze_l = s_lead_zeros(z0 & s_below_mask((mjr + 1) >> 1));
+      const int zo_l = s_lead_zeros(z1 & s_below_mask(mjr >> 1));
+      const int cl = smax2(ze_l >= 0 ? 2 * (63 - ze_l) : -1, zo_l >= 0 ? 2 * (63 - zo_l) + 1 : -1);
+      const int se = (mjr + 2) >> 1, so = (mjr + 1) >> 1;
+      const int fe = s_first_one((z0 >> ((mjr + 1) >> 1)) >> ((mjr + 1) & 1));
+      const int fo = s_first_one(z1 >> so);
+      const int cr = smin2(fe >= 0 ? 2 * (se + fe) : 1 << 20, fo >= 0 ? 2 * (so + fo) + 1 : 1 << 20);
+      beg = cl >= 0 ? base + cl + 2 : nb0;
+      end = cr < (1 << 20) ? base + cr + 1 : end + 1;
+    } else {
+      const int lzc = s_lead_zeros(z0 & s_below_mask(mjr));
+      const int fo = s_first_one((z0 >> mjr) >> 1);
+      beg = lzc >= 0 ? base + 65 - lzc : nb0;
+      end = fo >= 0 ? mj + 2 + fo : end + 1;
+    }
+  }
+  save();
+  return ret;
+}
+
+// ---- the one-column loop in assembly ---------------------------------------------------------------------------------------
+// Sweeps rows i .. row_end-1 of the window layout COLS == 1 (lane l holds column base + l), the common path only.  Leaves with
+//   ROWS_DONE  the call is over            ROWS_MORE  i == row_end (the caller reloads the target chunk or ends the call)
+//   ROWS_SLOW  row i is one the loop does not serve (an N row, column `end` beyond the window, an empty band): the row has not
+//              been touched (the band clamp, which is idempotent, may have been applied) -- rows_cpp<1> sweeps it.
+// vTS: 8 * target base of rows (i & ~63) + lane.  Register use: see the operand list.  DPP reads need two wait states behind the
+// VALU write of their operand, v_readlane / v_writelane with a scalar lane select none when a SALU instruction wrote it.
+__device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int qLen, const int row_end, const int vTS, const int w,
+                                         const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
+                                         const int i_tail, const int u0, const int qa) {
+  int vH = st.H0, vE = st.E0;
+  const int vP = st.plo0;
+  const int vNegC = -(lane * eIns);     // g(k) = a(k) + k*eIns = a - vNegC;  F(j) = Pex(j) + vNegC + (eIns - oeIns)
+  int vPp = NEG;                        // the exclusive prefix: lane 0 keeps "nothing to the left"
+  int vNEG = NEG_A;
+  int s_i = st.i, s_beg = st.beg, s_end = st.end, s_h1raw = st.h1raw, s_mx = st.mx, s_maxi = st.max_i, s_maxj = st.max_j;
+  int s_maxie = st.max_ie, s_gs = st.gscore, s_moff = st.max_off;
+  const int s_base = st.base, s_b65 = st.base + 65, s_w1 = w + 1, s_nkc = eIns - oeIns;
+  // z-drop of a row that did not improve: k = (i - max_i) - (mj - max_j), X = max - m.  k > 0: X + k * zpos > zdrop with zpos = eIns
+  // (Scala parse: its B || C is C) or -eDel (BWA parse: B); k <= 0: the BWA parse alone tests X + k * eIns (zdrop_stop)
+  const int s_zpos = uni(zmode == BPSW_ZDROP_SCALA ? eIns : -eDel), s_zneg = uni(zmode == BPSW_ZDROP_SCALA ? 0 : 1);
+  int reason;
+  int vS, vA, vG, vK, vT0;
+  int t, h1, span, mkey, m, mj, mja, t1, t2, t3, t4;
+  unsigned long long act, z, u64;
+  asm volatile(
+      "L_row_%=:\n\t"
+      "s_cmp_ge_i32 %[i], %[itail]\n\t"
+      "s_cbranch_scc1 L_tail_%=\n\t"
+      "L_rowb_%=:\n\t"
+      "v_readlane_b32 %[t], %[vTS], %[i]\n\t"                 // 8 * target base of row i (lane i & 63)
+      "s_sub_i32 %[t1], %[i], %[w]\n\t"
+      "s_max_i32 %[beg], %[beg], %[t1]\n\t"                   // beg = max(beg, i - w)            SWUtil.scala:140-142
+      "s_add_i32 %[t1], %[i], %[w1]\n\t"
+      "s_min_i32 %[end], %[end], %[t1]\n\t"
+      "s_min_i32 %[end], %[end], %[qlen]\n\t"                 // end = min(end, i + w + 1, qLen)
+      "s_sub_i32 %[t2], %[end], %[base]\n\t"
+      "s_cmp_gt_i32 %[t2], 63\n\t"
+      "s_cbranch_scc1 L_slow_%=\n\t"                          // column `end` beyond the window
+      "s_cmp_eq_u32 %[t], 32\n\t"
+      "s_cbranch_scc1 L_slow_%=\n\t"                          // an N row
+      "s_sub_i32 %[span], %[end], %[beg]\n\t"
+      "s_cmp_lt_i32 %[span], 1\n\t"
+      "s_cbranch_scc1 L_slow_%=\n\t"                          // an empty band
+      "s_sub_i32 m0, %[beg], %[base]\n\t"                     // rbeg, the band's left end in window coordinates (in M0: v_writelane takes one SGPR + M0)
+      "v_bfe_i32 %[vS], %[vP], %[t], 8\n\t"
+      "v_subrev_u32 %[vT0], m0, %[vLane]\n\t"                 // rel = lane - rbeg
+      "v_cmp_gt_u32 %[act], %[span], %[vT0]\n\t"              // act = rel < span (unsigned)
+      "v_add_u32 %[vA], %[vH], %[vS]\n\t"
+      "v_max_i32 %[vA], %[vA], %[vE]\n\t"
+      "v_cndmask_b32 %[vA], %[vNEG], %[vA], %[act]\n\t"       // a = max(H(i-1,j-1) + s, E) or "no cell"
+      "v_sub_u32 %[vG], %[vA], %[vNegC]\n\t"                  // g = a + j*eIns
+      "v_lshl_or_b32 %[vK], %[vA], 7, %[vLane]\n\t"           // a << 7 | column: the row maximum and its LAST column in one scan
+      "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t"             // (scalar work in the wait states of the scans)
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_max_i32 %[h1], %[h1raw], 0\n\t"                      // h1 = max(0, h0 - oDel - eDel*(i+1))   SWUtil.scala:137-138
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_cmp_eq_u32 %[h1], 0\n\t"
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_addc_u32 %[t3], %[beg], 0\n\t"                       // nb0 = beg + (h1 == 0)
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  // exclusive prefix of g
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t"
+      "v_add3_u32 %[vS], %[vPp], %[vNegC], %[nkc]\n\t"        // F = Pex - (j-1)*eIns - oeIns
+      "v_max_i32 %[vT0], %[vA], %[vS]\n\t"                    // H (>= 0 wherever the cell is in the band: E never goes below 0)
+      "v_cmp_gt_i32 vcc, 1, %[vT0]\n\t"                       // H == 0
+      "v_subrev_u32 %[vE], %[edel], %[vE]\n\t"
+      "v_subrev_u32 %[vS], %[oedel], %[vT0]\n\t"
+      "v_max3_i32 %[vE], %[vE], %[vS], 0\n\t"                 // E(i+1,j) = max(E - eDel, H - oeDel, 0)
+      "v_cndmask_b32 %[vE], 0, %[vE], %[act]\n\t"             // eh[end].e = 0
+      "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  // eh[j].h = H(i,j-1)
+      "s_and_b64 %[z], vcc, %[act]\n\t"                       // the zero cells of the band
+      "v_writelane_b32 %[vH], %[h1], m0\n\t"                  // eh[beg].h = h1                        SWUtil.scala:153
+      // SWUtil.scala:177-182: j after the column loop is end (the band is not empty); h1 there is eh[end].h
+      "s_cmp_lg_u32 %[end], %[qlen]\n\t"
+      "s_cbranch_scc1 L_nogs_%=\n\t"
+      "s_nop 0\n\t"
+      "v_readlane_b32 %[t1], %[vH], %[t2]\n\t"                // lane end - base
+      "s_cmp_le_i32 %[gs], %[t1]\n\t"
+      "s_cselect_b32 %[maxie], %[i], %[maxie]\n\t"
+      "s_max_i32 %[gs], %[gs], %[t1]\n\t"
+      "L_nogs_%=:\n\t"
+      "s_cmp_lt_i32 %[mkey], 128\n\t"
+      "s_cbranch_scc1 L_done_%=\n\t"                          // m == 0                                SWUtil.scala:184-185
+      "s_lshr_b32 %[m], %[mkey], 7\n\t"
+      "s_and_b32 %[mj], %[mkey], 127\n\t"
+      "s_add_i32 %[mja], %[mj], %[base]\n\t"
+      "s_cmp_gt_i32 %[m], %[mx]\n\t"
+      "s_cbranch_scc0 L_noimp_%=\n\t"
+      "s_sub_i32 %[t1], %[mja], %[i]\n\t"                     // SWUtil.scala:187-193
+      "s_abs_i32 %[t1], %[t1]\n\t"
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t"
+      "s_mov_b32 %[mx], %[m]\n\t"
+      "s_mov_b32 %[maxi], %[i]\n\t"
+      "s_mov_b32 %[maxj], %[mja]\n\t"
+      "L_trim_%=:\n\t"                                        // band trimming, SWUtil.scala:202-214
+      "s_cmp_eq_u64 %[z], 0\n\t"
+      "s_cbranch_scc1 L_nozero_%=\n\t"
+      "s_bfm_b64 %[u64], %[mj], 0\n\t"
+      "s_and_b64 %[u64], %[u64], %[z]\n\t"
+      "s_flbit_i32_b64 %[t1], %[u64]\n\t"                     // last zero left of mj (leading-zero count, -1: none)
+      "s_lshr_b64 %[u64], %[z], %[mj]\n\t"
+      "s_lshr_b64 %[u64], %[u64], 1\n\t"
+      "s_ff1_i32_b64 %[t2], %[u64]\n\t"                       // first zero right of mj (-1: none)
+      "s_sub_i32 %[t4], %[b65], %[t1]\n\t"
+      "s_cmp_lt_i32 %[t1], 0\n\t"
+      "s_cselect_b32 %[beg], %[t3], %[t4]\n\t"
+      "s_add_i32 %[t4], %[mja], %[t2]\n\t"
+      "s_add_i32 %[t4], %[t4], 2\n\t"
+      "s_add_i32 %[t1], %[end], 1\n\t"
+      "s_cmp_lt_i32 %[t2], 0\n\t"
+      "s_cselect_b32 %[end], %[t1], %[t4]\n\t"
+      "s_branch L_next_%=\n\t"
+      "L_nozero_%=:\n\t"
+      "s_mov_b32 %[beg], %[t3]\n\t"
+      "s_add_i32 %[end], %[end], 1\n\t"
+      "L_next_%=:\n\t"
+      "s_add_i32 %[i], %[i], 1\n\t"
+      "s_cmp_lt_i32 %[i], %[rowend]\n\t"
+      "s_cbranch_scc1 L_row_%=\n\t"
+      "s_mov_b32 %[reason], 1\n\t"                            // ROWS_MORE
+      "s_branch L_out_%=\n\t"
+      "L_noimp_%=:\n\t"                                       // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      "s_cmp_lt_i32 %[zdrop], 1\n\t"
+      "s_cbranch_scc1 L_trim_%=\n\t"
+      "s_sub_i32 %[t1], %[i], %[maxi]\n\t"
+      "s_sub_i32 %[t2], %[mja], %[maxj]\n\t"
+      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"                     // k
+      "s_sub_i32 %[t2], %[mx], %[m]\n\t"                      // X
+      "s_cmp_gt_i32 %[t1], 0\n\t"
+      "s_cbranch_scc0 L_zneg_%=\n\t"
+      "s_mul_i32 %[t4], %[t1], %[zpos]\n\t"
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t"
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t"
+      "s_cbranch_scc1 L_done_%=\n\t"
+      "s_branch L_trim_%=\n\t"
+      "L_zneg_%=:\n\t"
+      "s_cmp_eq_u32 %[zneg], 0\n\t"
+      "s_cbranch_scc1 L_trim_%=\n\t"
+      "s_mul_i32 %[t4], %[t1], %[eins]\n\t"
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t"
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t"
+      "s_cbranch_scc1 L_done_%=\n\t"
+      "s_branch L_trim_%=\n\t"
+      "L_tail_%=:\n\t"                                        // tail_row_bound: U = max(u0 - i*eDel, qa); over once U <= max and U < gscore
+      "s_mul_i32 %[t1], %[i], %[edel]\n\t"
+      "s_sub_i32 %[t1], %[u0], %[t1]\n\t"
+      "s_max_i32 %[t1], %[t1], %[qa]\n\t"
+      "s_cmp_le_i32 %[t1], %[mx]\n\t"
+      "s_cbranch_scc0 L_rowb_%=\n\t"
+      "s_cmp_lt_i32 %[t1], %[gs]\n\t"
+      "s_cbranch_scc0 L_rowb_%=\n\t"
+      "L_done_%=:\n\t"
+      "s_mov_b32 %[reason], 0\n\t"                            // ROWS_DONE
+      "s_branch L_out_%=\n\t"
+      "L_slow_%=:\n\t"
+      "s_mov_b32 %[reason], 3\n\t"                            // ROWS_SLOW
+      "L_out_%=:\n\t"
+      : [vH] "+v"(vH), [vE] "+v"(vE), [vPp] "+v"(vPp), [i] "+s"(s_i), [beg] "+s"(s_beg), [end] "+s"(s_end), [h1raw] "+s"(s_h1raw),
+        [mx] "+s"(s_mx), [maxi] "+s"(s_maxi), [maxj] "+s"(s_maxj), [maxie] "+s"(s_maxie), [gs] "+s"(s_gs), [moff] "+s"(s_moff),
+        [reason] "=&s"(reason), [vS] "=&v"(vS), [vA] "=&v"(vA), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [t] "=&s"(t),
+        [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja),
+        [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [act] "=&s"(act), [z] "=&s"(z), [u64] "=&s"(u64)
+      : [vP] "v"(vP), [vLane] "v"(lane), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end), [qlen] "s"(qLen),
+        [base] "s"(s_base), [b65] "s"(s_b65), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc),
+        [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [u0] "s"(u0), [qa] "s"(qa)
+      : "vcc", "scc", "memory");  // (M0 is written too: the compiler never keeps a value in it across statements on gfx9)
+  st.H0 = vH; st.E0 = vE;
+  st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.mx = s_mx; st.max_i = s_maxi; st.max_j = s_maxj;
+  st.max_ie = s_maxie; st.gscore = s_gs; st.max_off = s_moff;
+  return reason;
+}
+
+// SWExtend on the adaptive window, for flanks of up to 255 bases (WINDOW) or 127 (no window: the band always fits two columns per
+// lane, and the layout still changes with the band).  *overflow = 1: a band wider than 128 columns, the task is not for this build.
+template <bool WINDOW, class QC>
+__device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int tLen, const QC& qcode, const uint8_t* __restrict__ ts,
+                                     const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w,
+                                     const int zdrop, const int zmode, const int h0, const int amax, int* __restrict__ overflow) {
+  const int oeIns = oIns + eIns, oeDel = oDel + eDel;
+  RowState st;
+  st.i = 0; st.beg = 0; st.end = qLen; st.h1raw = h0 - oDel;
+  st.mx = h0; st.max_i = -1; st.max_j = -1; st.max_ie = -1; st.gscore = -1; st.max_off = 0;  // SWUtil.scala:118-125
+  st.base = 0;
+  // row 0 spans min(qLen, w + 1) columns (+ the column `end` it writes)
+  int cols = min(qLen, w + 1) <= 63 ? 1 : 2;
+  if (min(qLen, w + 1) > 127) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
+  st.H1 = 0; st.E1 = 0; st.plo1 = 0;
+  if (cols == 1) {
+    rows_load_profile<1>(st, qcode, mat, qLen, lane);
+    st.H0 = lane == 0 ? h0 : max(0, h0 - oeIns - (lane - 1) * eIns);  // row -1, SWUtil.scala:97-104
+    st.E0 = 0;
+  } else {
+    rows_load_profile<2>(st, qcode, mat, qLen, lane);
+    const int j0 = 2 * lane, j1 = 2 * lane + 1;
+    st.H0 = j0 == 0 ? h0 : max(0, h0 - oeIns - (j0 - 1) * eIns);
+    st.H1 = max(0, h0 - oeIns - (j1 - 1) * eIns);
+    st.E0 = 0; st.E1 = 0;
+  }
+  const int i_tail = amax > 0 ? qLen : 0x7fffffff;
+  const int u0 = h0 + qLen * amax - oDel + (qLen - 1) * eDel, qa = qLen * amax;  // tail_row_bound(i) = max(u0 - i*eDel, qa)
+  int vTS = 0, ts_chunk = -1;
+  for (;;) {
+    int r;
+    if (cols == 1) {
+#if BPSW_EXT_ROWS_ASM
+      if (st.i >= tLen) break;
+      if ((st.i >> 6) != ts_chunk) {  // 8 * target base of the 64 rows around row i, one per lane
+        ts_chunk = st.i >> 6;
+        const int at = (ts_chunk << 6) + lane;
+        vTS = at < tLen ? (int)ts[at] : 0;
+      }
+      r = rows1_asm(st, lane, qLen, min(tLen, (ts_chunk + 1) << 6), vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa);
+      if (r == ROWS_SLOW)
+#endif
+        r = rows_cpp<1>(st, lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
+      if (r == ROWS_OTHER_MODE) {  // the band outgrew 64 columns: two columns per lane, window at the band's left end
+        const int nb = st.beg & ~1;
+        if (st.end - nb > 127) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
+        const int src0 = (nb - st.base + 2 * lane) << 2, src1 = src0 + 4;  // lanes past 63 wrap: columns the band has not reached
+        const int h0v = __builtin_amdgcn_ds_bpermute(src0, st.H0), h1v = __builtin_amdgcn_ds_bpermute(src1, st.H0);
+        const int e0v = __builtin_amdgcn_ds_bpermute(src0, st.E0), e1v = __builtin_amdgcn_ds_bpermute(src1, st.E0);
+        st.H0 = h0v; st.H1 = h1v; st.E0 = e0v; st.E1 = e1v;
+        st.base = nb;
+        rows_load_profile<2>(st, qcode, mat, qLen, lane);
+        cols = 2;
+        continue;
+      }
+    } else {
+      r = rows_cpp<2>(st, lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, 0x7fffffff);
+      if (r == ROWS_OVERFLOW) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
+      if (r == ROWS_OTHER_MODE) {  // the band fits one column per lane again: window at its left end
+        const int nb = st.beg;
+        const int col = nb + lane - st.base;  // this lane's new column, in the old window
+        const int src = (col >> 1) << 2;
+        const int ha = __builtin_amdgcn_ds_bpermute(src, st.H0), hb = __builtin_amdgcn_ds_bpermute(src, st.H1);
+        const int ea = __builtin_amdgcn_ds_bpermute(src, st.E0), eb = __builtin_amdgcn_ds_bpermute(src, st.E1);
+        st.H0 = (col & 1) ? hb : ha;
+        st.E0 = (col & 1) ? eb : ea;
+        st.base = nb;
+        rows_load_profile<1>(st, qcode, mat, qLen, lane);
+        cols = 1;
+        ts_chunk = -1;
+        continue;
+      }
+    }
+    if (r == ROWS_DONE) break;
+  }
+  (void)WINDOW;
+  ExtRes res;
+  res.max = st.mx; res.qle = st.max_j + 1; res.tle = st.max_i + 1; res.gtle = st.max_ie + 1; res.gscore = st.gscore; res.max_off = st.max_off;
+  return res;
+}
+
+}  // namespace
+}  // namespace bpsw

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""At which call size does the GPU path win?  One calling thread, the HOST-BUFFER entry points the two JNI symbols call, at the
+sizes the reference's flags produce (-FPGASWExtThreshold 64 / -bSWExtSize, run_test.sh:7; -sbatch 10,
+commandline/BWAMEMCommand.scala:28,43), against the reference's own C on ONE host core for the same inputs (oracle/_ref:
+ksw_extend2 under the builder's batch loop, mem_group_matesw).  A small call is latency-bound on the GPU -- one SW job is a serial
+chain of ~0.1 ms for a single wavefront -- so the table tells a maintainer the smallest batch at which the plug-in pays
+(INTEGRATION.md).  Test infrastructure (it times the oracle's reference build); usage on a GPU box: python tests/small_call_table.py"""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (os.path.join(ROOT, "cloud-scale-bwamem_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import bpsw_hip  # noqa: E402
+import pyoracle as po  # noqa: E402
+from bpsw_hip import synth  # noqa: E402
+
+
+def timed(fn, items, reps):
+    for it in items:
+        fn(it)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for it in items:
+            fn(it)
+    return 1e3 * (time.perf_counter() - t0) / (reps * len(items))
+
+
+def main():
+    ctx = bpsw_hip.Context(0)
+    opt = bpsw_hip.default_opt()
+    ref = po.Ref() if po.Ref.available() else None
+    ropt = po.Oracle().default_opt()
+    mat = po.default_mat()
+    out = {"extend": [], "matesw_group": []}
+    for n in (64, 256, 1024, 4096, 32768):
+        k = 16 if n <= 1024 else 4
+        soas = [synth.ext_tasks(int(n * 1.08), read_len=150, seed=synth.CONFIG_SEED_BASE + 3 + 31 * j) for j in range(k)]
+        soas = [s.subset(np.arange(min(n, s.n))) for s in soas]
+        wires = [bpsw_hip.wire_pack(s) for s in soas]
+        gpu = timed(lambda w: ctx.extend_batch(w), wires, 20 if n <= 1024 else 6)
+        cpu = timed(lambda s: ref.extend_batch(s, mat), soas, 3 if n <= 1024 else 1) if ref else None
+        out["extend"].append({"tasks_per_call": int(np.mean([s.n for s in soas])), "gpu_ms_per_call": round(gpu, 4),
+                              "gpu_us_per_task": round(1e3 * gpu / n, 3), "reference_c_one_core_ms": round(cpu, 4) if cpu else None,
+                              "gpu_speedup_vs_one_core": round(cpu / gpu, 2) if cpu else None})
+    for pairs in (10, 64, 256, 1024, 4096):
+        k = 40 if pairs <= 64 else (8 if pairs <= 1024 else 3)
+        groups = [synth.rescue_group_fast(pairs, seed=synth.CONFIG_SEED_BASE + 3 + 17 * j, p_resc=0.10) for j in range(k)]
+        s0 = ctx.stats()
+        gpu = timed(lambda g: ctx.matesw_group(opt, g), groups, 10 if pairs <= 256 else 4)
+        s1 = ctx.stats()
+        cpu = timed(lambda g: ref.matesw_group(ropt, g), groups, 2 if pairs <= 256 else 1) if ref else None
+        out["matesw_group"].append({"pairs_per_call": pairs, "sw_jobs_per_call": round((s1.sw_jobs - s0.sw_jobs) / max(s1.grp_calls - s0.grp_calls, 1), 2),
+                                    "gpu_ms_per_call": round(gpu, 4), "gpu_us_per_pair": round(1e3 * gpu / pairs, 3),
+                                    "reference_c_one_core_ms": round(cpu, 4) if cpu else None,
+                                    "gpu_speedup_vs_one_core": round(cpu / gpu, 2) if cpu else None})
+    out["note"] = ("one calling thread, distinct inputs per call, host buffers in and out; reference C = oracle/_ref (the reference's own ksw_extend2 / "
+                   "mem_group_matesw with SSE2 ksw_align2) on one host core of the GPU box; p_resc = 10 % of the pairs need rescue (configs[2])")
+    print(json.dumps(out, indent=1))
+    print("\n| boundary | call size | GPU ms / call | reference C, one core, ms | GPU / one core |\n|---|---|---|---|---|")
+    for r in out["extend"]:
+        print(f"| swExtendFPGAJNI | {r['tasks_per_call']} tasks | {r['gpu_ms_per_call']} | {r['reference_c_one_core_ms']} | {r['gpu_speedup_vs_one_core']}x |")
+    for r in out["matesw_group"]:
+        print(f"| mateSWJNI | {r['pairs_per_call']} pairs ({r['sw_jobs_per_call']} SW jobs) | {r['gpu_ms_per_call']} | {r['reference_c_one_core_ms']} | {r['gpu_speedup_vs_one_core']}x |")
+
+
+if __name__ == "__main__":
+    main()
