@@ -384,6 +384,250 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
   return reason;
 }
 
+// ---- the two-column loop in assembly ---------------------------------------------------------------------------------------
+// The same for the layout COLS == 2 (lane l holds columns base + 2l in H0 / E0 and base + 2l + 1 in H1 / E1).  It also leaves with
+// ROWS_SLOW when the band has become narrow enough for one column per lane (rows_cpp<2> then reports ROWS_OTHER_MODE).
+__device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int qLen, const int row_end, const int vTS, const int w,
+                                         const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
+                                         const int i_tail, const int u0, const int qa) {
+  int vH0 = st.H0, vE0 = st.E0, vH1 = st.H1, vE1 = st.E1;
+  const int vP0 = st.plo0, vP1 = st.plo1;
+  const int vL2 = 2 * lane;               // the lane's even column, in window coordinates
+  const int vNegC = -(2 * lane * eIns);   // g(k) = a(k) + k*eIns;  F(j) = Pex(j) - (j-1)*eIns - oeIns
+  int vPp = NEG;
+  int vNEG = NEG_A;
+  int s_i = st.i, s_beg = st.beg, s_end = st.end, s_h1raw = st.h1raw, s_mx = st.mx, s_maxi = st.max_i, s_maxj = st.max_j;
+  int s_maxie = st.max_ie, s_gs = st.gscore, s_moff = st.max_off;
+  const int s_base = st.base, s_w1 = w + 1, s_nkc = eIns - oeIns, s_nkc1 = -oeIns;
+  const int s_zpos = uni(zmode == BPSW_ZDROP_SCALA ? eIns : -eDel), s_zneg = uni(zmode == BPSW_ZDROP_SCALA ? 0 : 1);
+  int reason;
+  int vS0, vS1, vA0, vA1, vG0, vG, vK, vT0, vT1, vh1;
+  int t, h1, span, mkey, m, mj, mja, t1, t2, t3, t4, t5, t6;
+  unsigned long long act0, act1, z0, z1, u64;
+  asm volatile(
+      "L_row_%=:\n\t"
+      "s_cmp_ge_i32 %[i], %[itail]\n\t"
+      "s_cbranch_scc1 L_tail_%=\n\t"
+      "L_rowb_%=:\n\t"
+      "v_readlane_b32 %[t], %[vTS], %[i]\n\t"
+      "s_sub_i32 %[t1], %[i], %[w]\n\t"
+      "s_max_i32 %[beg], %[beg], %[t1]\n\t"                   // SWUtil.scala:140-142
+      "s_add_i32 %[t1], %[i], %[w1]\n\t"
+      "s_min_i32 %[end], %[end], %[t1]\n\t"
+      "s_min_i32 %[end], %[end], %[qlen]\n\t"
+      "s_sub_i32 %[t2], %[end], %[base]\n\t"
+      "s_cmp_gt_i32 %[t2], 127\n\t"
+      "s_cbranch_scc1 L_slow_%=\n\t"                          // column `end` beyond the window
+      "s_cmp_eq_u32 %[t], 32\n\t"
+      "s_cbranch_scc1 L_slow_%=\n\t"                          // an N row
+      "s_sub_i32 %[span], %[end], %[beg]\n\t"
+      "s_cmp_lt_i32 %[span], %[narrow1]\n\t"
+      "s_cbranch_scc1 L_slow_%=\n\t"                          // an empty band, or one that fits one column per lane again
+      "s_sub_i32 m0, %[beg], %[base]\n\t"                     // rbeg
+      "v_bfe_i32 %[vS0], %[vP0], %[t], 8\n\t"
+      "v_bfe_i32 %[vS1], %[vP1], %[t], 8\n\t"
+      "v_subrev_u32 %[vT0], m0, %[vL2]\n\t"                   // rel0 = 2 lane - rbeg
+      "v_add_u32 %[vT1], 1, %[vT0]\n\t"                       // rel1
+      "v_cmp_gt_u32 %[act0], %[span], %[vT0]\n\t"
+      "v_cmp_gt_u32 %[act1], %[span], %[vT1]\n\t"
+      "v_add_u32 %[vA0], %[vH0], %[vS0]\n\t"
+      "v_add_u32 %[vA1], %[vH1], %[vS1]\n\t"
+      "v_max_i32 %[vA0], %[vA0], %[vE0]\n\t"
+      "v_max_i32 %[vA1], %[vA1], %[vE1]\n\t"
+      "v_cndmask_b32 %[vA0], %[vNEG], %[vA0], %[act0]\n\t"
+      "v_cndmask_b32 %[vA1], %[vNEG], %[vA1], %[act1]\n\t"
+      "v_sub_u32 %[vG0], %[vA0], %[vNegC]\n\t"                // g of the even column
+      "v_sub_u32 %[vG], %[vA1], %[vNegC]\n\t"
+      "v_add_u32 %[vG], %[eins], %[vG]\n\t"                   // g of the odd column
+      "v_lshl_or_b32 %[vK], %[vA0], 7, %[vL2]\n\t"
+      "v_lshl_or_b32 %[vS0], %[vA1], 7, %[vL2]\n\t"
+      "v_or_b32 %[vS0], 1, %[vS0]\n\t"
+      "v_max_i32 %[vG], %[vG], %[vG0]\n\t"                    // the lane's two columns folded
+      "v_max_i32 %[vK], %[vK], %[vS0]\n\t"                    // a << 7 | column: row maximum and its LAST column
+      "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t"
+      "s_max_i32 %[h1], %[h1raw], 0\n\t"                      // SWUtil.scala:137-138
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_cmp_eq_u32 %[h1], 0\n\t"
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_addc_u32 %[t3], %[beg], 0\n\t"                       // nb0 = beg + (h1 == 0)
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32 %[vh1], %[h1]\n\t"
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  // prefix over the columns of the lanes below
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t"
+      "v_add3_u32 %[vS0], %[vPp], %[vNegC], %[nkc]\n\t"       // F of the even column
+      "v_max_i32 %[vS1], %[vPp], %[vG0]\n\t"
+      "v_add3_u32 %[vS1], %[vS1], %[vNegC], %[nkc1]\n\t"      // F of the odd column
+      "v_max_i32 %[vA0], %[vA0], %[vS0]\n\t"                  // H even (>= 0 wherever the cell is in the band)
+      "v_max_i32 %[vA1], %[vA1], %[vS1]\n\t"                  // H odd
+      "v_cmp_gt_i32 vcc, 1, %[vA0]\n\t"
+      "s_and_b64 %[z0], vcc, %[act0]\n\t"                     // zero cells of the band, even columns
+      "v_cmp_gt_i32 vcc, 1, %[vA1]\n\t"
+      "s_and_b64 %[z1], vcc, %[act1]\n\t"                     // ... odd columns
+      "v_subrev_u32 %[vE0], %[edel], %[vE0]\n\t"
+      "v_subrev_u32 %[vS0], %[oedel], %[vA0]\n\t"
+      "v_max3_i32 %[vE0], %[vE0], %[vS0], 0\n\t"
+      "v_cndmask_b32 %[vE0], 0, %[vE0], %[act0]\n\t"          // E(i+1,j); eh[end].e = 0
+      "v_subrev_u32 %[vE1], %[edel], %[vE1]\n\t"
+      "v_subrev_u32 %[vS1], %[oedel], %[vA1]\n\t"
+      "v_max3_i32 %[vE1], %[vE1], %[vS1], 0\n\t"
+      "v_cndmask_b32 %[vE1], 0, %[vE1], %[act1]\n\t"
+      "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  // eh[j].h = H(i,j-1): even column <- odd of the lane below
+      "v_cmp_eq_u32 vcc, 0, %[vT0]\n\t"
+      "v_cndmask_b32 %[vH0], %[vH0], %[vh1], vcc\n\t"         // eh[beg].h = h1   SWUtil.scala:153
+      "v_cmp_eq_u32 vcc, 0, %[vT1]\n\t"
+      "v_cndmask_b32 %[vH1], %[vA0], %[vh1], vcc\n\t"         // odd column <- even of the same lane
+      // SWUtil.scala:177-182
+      "s_cmp_lg_u32 %[end], %[qlen]\n\t"
+      "s_cbranch_scc1 L_nogs_%=\n\t"
+      "s_lshr_b32 %[t1], %[t2], 1\n\t"                        // t2 = end - base: lane, and which of the lane's columns
+      "s_and_b32 %[t2], %[t2], 1\n\t"
+      "v_readlane_b32 %[t4], %[vH0], %[t1]\n\t"
+      "v_readlane_b32 %[t1], %[vH1], %[t1]\n\t"
+      "s_cmp_eq_u32 %[t2], 0\n\t"
+      "s_cselect_b32 %[t1], %[t4], %[t1]\n\t"
+      "s_cmp_le_i32 %[gs], %[t1]\n\t"
+      "s_cselect_b32 %[maxie], %[i], %[maxie]\n\t"
+      "s_max_i32 %[gs], %[gs], %[t1]\n\t"
+      "L_nogs_%=:\n\t"
+      "s_cmp_lt_i32 %[mkey], 128\n\t"
+      "s_cbranch_scc1 L_done_%=\n\t"                          // m == 0
+      "s_lshr_b32 %[m], %[mkey], 7\n\t"
+      "s_and_b32 %[mj], %[mkey], 127\n\t"
+      "s_add_i32 %[mja], %[mj], %[base]\n\t"
+      "s_cmp_gt_i32 %[m], %[mx]\n\t"
+      "s_cbranch_scc0 L_noimp_%=\n\t"
+      "s_sub_i32 %[t1], %[mja], %[i]\n\t"
+      "s_abs_i32 %[t1], %[t1]\n\t"
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t"
+      "s_mov_b32 %[mx], %[m]\n\t"
+      "s_mov_b32 %[maxi], %[i]\n\t"
+      "s_mov_b32 %[maxj], %[mja]\n\t"
+      "L_trim_%=:\n\t"                                        // band trimming, SWUtil.scala:202-214, on the even / odd zero masks
+      "s_or_b64 %[u64], %[z0], %[z1]\n\t"
+      "s_cmp_eq_u64 %[u64], 0\n\t"
+      "s_cbranch_scc1 L_nozero_%=\n\t"
+      // last zero left of mj: even columns 2l < mj <=> l < (mj+1)>>1; odd columns 2l+1 < mj <=> l < mj>>1
+      "s_add_i32 %[t5], %[mj], 1\n\t"
+      "s_lshr_b32 %[t6], %[t5], 1\n\t"                        // (mj+1)>>1
+      "s_bfm_b64 %[u64], %[t6], 0\n\t"
+      "s_and_b64 %[u64], %[u64], %[z0]\n\t"
+      "s_flbit_i32_b64 %[t1], %[u64]\n\t"                     // -1: none, else 63 - lane
+      "s_lshr_b32 %[t4], %[mj], 1\n\t"                        // mj>>1
+      "s_bfm_b64 %[u64], %[t4], 0\n\t"
+      "s_and_b64 %[u64], %[u64], %[z1]\n\t"
+      "s_flbit_i32_b64 %[t2], %[u64]\n\t"
+      // column of each candidate + 2, or a value below every real one: even 2(63 - t1) + 2 = 128 - 2 t1; odd 2(63 - t2) + 3 = 129 - 2 t2
+      "s_lshl_b32 %[m], %[t1], 1\n\t"
+      "s_sub_i32 %[m], 128, %[m]\n\t"
+      "s_cmp_lt_i32 %[t1], 0\n\t"
+      "s_cselect_b32 %[m], -1, %[m]\n\t"
+      "s_lshl_b32 %[t1], %[t2], 1\n\t"
+      "s_sub_i32 %[t1], 129, %[t1]\n\t"
+      "s_cmp_lt_i32 %[t2], 0\n\t"
+      "s_cselect_b32 %[t1], -1, %[t1]\n\t"
+      "s_max_i32 %[m], %[m], %[t1]\n\t"                       // cl + 2, or -1
+      "s_add_i32 %[t1], %[m], %[base]\n\t"
+      "s_cmp_lt_i32 %[m], 0\n\t"
+      "s_cselect_b32 %[beg], %[t3], %[t1]\n\t"                // beg = base + cl + 2, or nb0
+      // first zero right of mj: even columns 2l > mj <=> l >= (mj+2)>>1; odd columns 2l+1 > mj <=> l >= (mj+1)>>1 = t6
+      "s_and_b32 %[t5], %[t5], 1\n\t"                         // (mj+1) & 1
+      "s_add_i32 %[t4], %[t6], %[t5]\n\t"                     // se = (mj+2)>>1 (at most 64: shifted in two steps)
+      "s_lshr_b64 %[u64], %[z0], %[t6]\n\t"
+      "s_lshr_b64 %[u64], %[u64], %[t5]\n\t"
+      "s_ff1_i32_b64 %[t1], %[u64]\n\t"
+      "s_lshr_b64 %[u64], %[z1], %[t6]\n\t"
+      "s_ff1_i32_b64 %[t2], %[u64]\n\t"
+      "s_add_i32 %[m], %[t4], %[t1]\n\t"
+      "s_lshl_b32 %[m], %[m], 1\n\t"                          // 2 (se + fe)
+      "s_cmp_lt_i32 %[t1], 0\n\t"
+      "s_cselect_b32 %[m], 0x100000, %[m]\n\t"
+      "s_add_i32 %[t1], %[t6], %[t2]\n\t"
+      "s_lshl_b32 %[t1], %[t1], 1\n\t"
+      "s_add_i32 %[t1], %[t1], 1\n\t"                         // 2 (so + fo) + 1
+      "s_cmp_lt_i32 %[t2], 0\n\t"
+      "s_cselect_b32 %[t1], 0x100000, %[t1]\n\t"
+      "s_min_i32 %[m], %[m], %[t1]\n\t"                       // cr, or 0x100000
+      "s_add_i32 %[t1], %[m], %[base]\n\t"
+      "s_add_i32 %[t1], %[t1], 1\n\t"
+      "s_add_i32 %[t2], %[end], 1\n\t"
+      "s_cmp_lt_i32 %[m], 0x100000\n\t"
+      "s_cselect_b32 %[end], %[t1], %[t2]\n\t"                // end = base + cr + 1, or end + 1
+      "s_branch L_next_%=\n\t"
+      "L_nozero_%=:\n\t"
+      "s_mov_b32 %[beg], %[t3]\n\t"
+      "s_add_i32 %[end], %[end], 1\n\t"
+      "L_next_%=:\n\t"
+      "s_add_i32 %[i], %[i], 1\n\t"
+      "s_cmp_lt_i32 %[i], %[rowend]\n\t"
+      "s_cbranch_scc1 L_row_%=\n\t"
+      "s_mov_b32 %[reason], 1\n\t"
+      "s_branch L_out_%=\n\t"
+      "L_noimp_%=:\n\t"                                       // SWUtil.scala:194-199 / native/ksw.c:455-461
+      "s_cmp_lt_i32 %[zdrop], 1\n\t"
+      "s_cbranch_scc1 L_trim_%=\n\t"
+      "s_sub_i32 %[t1], %[i], %[maxi]\n\t"
+      "s_sub_i32 %[t2], %[mja], %[maxj]\n\t"
+      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"
+      "s_sub_i32 %[t2], %[mx], %[m]\n\t"
+      "s_cmp_gt_i32 %[t1], 0\n\t"
+      "s_cbranch_scc0 L_zneg_%=\n\t"
+      "s_mul_i32 %[t4], %[t1], %[zpos]\n\t"
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t"
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t"
+      "s_cbranch_scc1 L_done_%=\n\t"
+      "s_branch L_trim_%=\n\t"
+      "L_zneg_%=:\n\t"
+      "s_cmp_eq_u32 %[zneg], 0\n\t"
+      "s_cbranch_scc1 L_trim_%=\n\t"
+      "s_mul_i32 %[t4], %[t1], %[eins]\n\t"
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t"
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t"
+      "s_cbranch_scc1 L_done_%=\n\t"
+      "s_branch L_trim_%=\n\t"
+      "L_tail_%=:\n\t"
+      "s_mul_i32 %[t1], %[i], %[edel]\n\t"
+      "s_sub_i32 %[t1], %[u0], %[t1]\n\t"
+      "s_max_i32 %[t1], %[t1], %[qa]\n\t"
+      "s_cmp_le_i32 %[t1], %[mx]\n\t"
+      "s_cbranch_scc0 L_rowb_%=\n\t"
+      "s_cmp_lt_i32 %[t1], %[gs]\n\t"
+      "s_cbranch_scc0 L_rowb_%=\n\t"
+      "L_done_%=:\n\t"
+      "s_mov_b32 %[reason], 0\n\t"
+      "s_branch L_out_%=\n\t"
+      "L_slow_%=:\n\t"
+      "s_mov_b32 %[reason], 3\n\t"
+      "L_out_%=:\n\t"
+      : [vH0] "+v"(vH0), [vE0] "+v"(vE0), [vH1] "+v"(vH1), [vE1] "+v"(vE1), [vPp] "+v"(vPp), [i] "+s"(s_i), [beg] "+s"(s_beg),
+        [end] "+s"(s_end), [h1raw] "+s"(s_h1raw), [mx] "+s"(s_mx), [maxi] "+s"(s_maxi), [maxj] "+s"(s_maxj), [maxie] "+s"(s_maxie),
+        [gs] "+s"(s_gs), [moff] "+s"(s_moff), [reason] "=&s"(reason), [vS0] "=&v"(vS0), [vS1] "=&v"(vS1), [vA0] "=&v"(vA0),
+        [vA1] "=&v"(vA1), [vG0] "=&v"(vG0), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [vT1] "=&v"(vT1), [vh1] "=&v"(vh1),
+        [t] "=&s"(t), [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja),
+        [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [t5] "=&s"(t5), [t6] "=&s"(t6), [act0] "=&s"(act0),
+        [act1] "=&s"(act1), [z0] "=&s"(z0), [z1] "=&s"(z1), [u64] "=&s"(u64)
+      : [vP0] "v"(vP0), [vP1] "v"(vP1), [vL2] "v"(vL2), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end),
+        [qlen] "s"(qLen), [base] "s"(s_base), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc),
+        [nkc1] "s"(s_nkc1), [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [u0] "s"(u0),
+        [qa] "s"(qa), [narrow1] "s"(ROWS_NARROW + 1)
+      : "vcc", "scc", "memory");  // (M0 is written too)
+  st.H0 = vH0; st.E0 = vE0; st.H1 = vH1; st.E1 = vE1;
+  st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.mx = s_mx; st.max_i = s_maxi; st.max_j = s_maxj;
+  st.max_ie = s_maxie; st.gscore = s_gs; st.max_off = s_moff;
+  return reason;
+}
+
 // SWExtend on the adaptive window, for flanks of up to 255 bases (WINDOW) or 127 (no window: the band always fits two columns per
 // lane, and the layout still changes with the band).  *overflow = 1: a band wider than 128 columns, the task is not for this build.
 template <bool WINDOW, class QC>
@@ -440,7 +684,17 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
         continue;
       }
     } else {
-      r = rows_cpp<2>(st, lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, 0x7fffffff);
+#if BPSW_EXT_ROWS_ASM
+      if (st.i >= tLen) break;
+      if ((st.i >> 6) != ts_chunk) {
+        ts_chunk = st.i >> 6;
+        const int at = (ts_chunk << 6) + lane;
+        vTS = at < tLen ? (int)ts[at] : 0;
+      }
+      r = rows2_asm(st, lane, qLen, min(tLen, (ts_chunk + 1) << 6), vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa);
+      if (r == ROWS_SLOW)
+#endif
+        r = rows_cpp<2>(st, lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
       if (r == ROWS_OVERFLOW) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
       if (r == ROWS_OTHER_MODE) {  // the band fits one column per lane again: window at its left end
         const int nb = st.beg;
