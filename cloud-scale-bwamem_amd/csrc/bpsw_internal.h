@@ -233,15 +233,34 @@ struct PinnedBuffer {
 // Readers (every call that launches kernels over the resident reference) hold the gate for the duration of the call; a load /
 // unload holds it exclusively while it frees or reallocates the buffers, so that no thread can sit between taking the device
 // pointer and launching while another context replaces the reference (one context per task thread share one reference).
-// Reader-preferring: a nested read never waits for a queued writer, only for an active one.
+// Writers are not starved: a queued writer (bpsw_ref_load / unload / bns_load) keeps NEW readers out, so that a stream of
+// overlapping calls from 20-32 task threads cannot hold `readers` above zero for ever; a NESTED read of a thread that already
+// holds the gate (a call that takes a snapshot inside another) is still admitted, or it would deadlock against that writer.
+inline thread_local int t_ref_read_depth = 0;
 struct RefGate {
   std::mutex m;
   std::condition_variable cv;
-  int readers = 0;
+  int readers = 0, writers_waiting = 0;
   bool writing = false;
-  void read_lock() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !writing; }); ++readers; }
-  void read_unlock() { std::lock_guard<std::mutex> lk(m); if (--readers == 0) cv.notify_all(); }
-  void write_lock() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !writing && readers == 0; }); writing = true; }
+  void read_lock() {
+    std::unique_lock<std::mutex> lk(m);
+    if (t_ref_read_depth == 0) cv.wait(lk, [&] { return !writing && writers_waiting == 0; });
+    else cv.wait(lk, [&] { return !writing; });
+    ++readers;
+    ++t_ref_read_depth;
+  }
+  void read_unlock() {
+    std::lock_guard<std::mutex> lk(m);
+    --t_ref_read_depth;
+    if (--readers == 0) cv.notify_all();
+  }
+  void write_lock() {
+    std::unique_lock<std::mutex> lk(m);
+    ++writers_waiting;
+    cv.wait(lk, [&] { return !writing && readers == 0; });
+    --writers_waiting;
+    writing = true;
+  }
   void write_unlock() { { std::lock_guard<std::mutex> lk(m); writing = false; } cv.notify_all(); }
 };
 struct RefHold {  // RAII read side of the gate; movable

@@ -783,7 +783,9 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
       HIP_TRY(hipMemsetAsync(d_list, 0, sizeof(int), s));
       HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu, d_queue, nullptr, s,
                                 d_pre, true, KernelEvents(), true, d_list, -255));
-      HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, std::min(n_tasks, c->num_cu), (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu,
+      // (sized like a normal launch: how many tasks the first one defers is unknown here -- all of them when the gap costs rule the
+      // register sweeps out --, an empty list returns at once and the persistent queue lets surplus waves leave immediately)
+      HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu,
                                 d_queue, nullptr, s, d_pre, true, KernelEvents(), false, d_list));
     } else {
       HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu, d_queue, nullptr, s,
