@@ -11,7 +11,8 @@ from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles")
+P = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")   # PROFILES_OUT: summarise on the GPU box (the raw CSVs of a 12-pass step are too large to pull back)
+os.makedirs(P, exist_ok=True)
 
 
 def short(name):
