@@ -200,16 +200,177 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
   return ret;
 }
 
+// top of a row at or past the query end: the tail-row test (the rows before it run the instantiation without)
+#define ROWS_TAIL_TOP "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_tail_t_%=\n\t"
+
 // ---- the one-column loop in assembly ---------------------------------------------------------------------------------------
 // Sweeps rows i .. row_end-1 of the window layout COLS == 1 (lane l holds column base + l), the common path only.  Leaves with
 //   ROWS_DONE  the call is over            ROWS_MORE  i == row_end (the caller reloads the target chunk or ends the call)
-//   ROWS_SLOW  row i is one the loop does not serve (an N row, column `end` beyond the window, an empty band): the row has not
+//   ROWS_SLOW  row i is one the loop does not serve (column `end` beyond the window, an empty band; an N row is kept out of
+//              [i, row_end) by the caller, rows_asm_end): the row has not
 //              been touched (the band clamp, which is idempotent, may have been applied) -- rows_cpp<1> sweeps it.
 // vTS: 8 * target base of rows (i & ~63) + lane.  Register use: see the operand list.  DPP reads need two wait states behind the
 // VALU write of their operand, v_readlane / v_writelane with a scalar lane select none when a SALU instruction wrote it.
+#define ROWS1_TEXT(TOP, SFX) \
+      "L_row" SFX "_%=:\n\t" TOP "L_rowb" SFX "_%=:\n\t" \
+      "v_readlane_b32 %[t], %[vTS], %[i]\n\t"  /* 8 * target base of row i (lane i & 63) */ \
+      "s_sub_i32 %[t1], %[i], %[w]\n\t" \
+      "s_max_i32 %[beg], %[beg], %[t1]\n\t"  /* beg = max(beg, i - w)            SWUtil.scala:140-142 */ \
+      "s_add_i32 %[t1], %[i], %[w1]\n\t" \
+      "s_min_i32 %[end], %[end], %[t1]\n\t" \
+      "s_min_i32 %[end], %[end], %[qlen]\n\t"  /* end = min(end, i + w + 1, qLen) */ \
+      "s_sub_i32 %[t2], %[end], %[base]\n\t" \
+      "s_cmp_gt_i32 %[t2], 63\n\t" \
+      "s_cbranch_scc1 L_slow" SFX "_%=\n\t"  /* column `end` beyond the window */ \
+      "s_sub_i32 %[span], %[end], %[beg]\n\t" \
+      "s_cmp_lt_i32 %[span], 1\n\t" \
+      "s_cbranch_scc1 L_slow" SFX "_%=\n\t"  /* an empty band */ \
+      "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg, the band's left end in window coordinates (in M0: v_writelane takes one SGPR + M0) */ \
+      "v_bfe_i32 %[vS], %[vP], %[t], 8\n\t" \
+      "v_subrev_u32 %[vT0], m0, %[vLane]\n\t"  /* rel = lane - rbeg */ \
+      "v_cmp_gt_u32 %[act], %[span], %[vT0]\n\t"  /* act = rel < span (unsigned) */ \
+      "v_add_u32 %[vA], %[vH], %[vS]\n\t" \
+      "v_max_i32 %[vA], %[vA], %[vE]\n\t" \
+      "v_cndmask_b32 %[vA], %[vNEG], %[vA], %[act]\n\t"  /* a = max(H(i-1,j-1) + s, E) or "no cell" */ \
+      "v_sub_u32 %[vG], %[vA], %[vNegC]\n\t"  /* g = a + j*eIns */ \
+      "v_lshl_or_b32 %[vK], %[vA], 7, %[vLane]\n\t"  /* a << 7 | column: the row maximum and its LAST column in one scan */ \
+      "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t"  /* (scalar work in the wait states of the scans) */ \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_max_i32 %[h1], %[h1raw], 0\n\t"  /* h1 = max(0, h0 - oDel - eDel*(i+1))   SWUtil.scala:137-138 */ \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_cmp_eq_u32 %[h1], 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_addc_u32 %[t3], %[beg], 0\n\t"  /* nb0 = beg + (h1 == 0) */ \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "s_nop 1\n\t" \
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* exclusive prefix of g */ \
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      "v_add3_u32 %[vS], %[vPp], %[vNegC], %[nkc]\n\t"  /* F = Pex - (j-1)*eIns - oeIns */ \
+      "v_max_i32 %[vT0], %[vA], %[vS]\n\t"  /* H (>= 0 wherever the cell is in the band: E never goes below 0) */ \
+      "v_cmp_gt_i32 vcc, 1, %[vT0]\n\t"  /* H == 0 */ \
+      "v_subrev_u32 %[vE], %[edel], %[vE]\n\t" \
+      "v_subrev_u32 %[vS], %[oedel], %[vT0]\n\t" \
+      "v_max3_i32 %[vE], %[vE], %[vS], 0\n\t"  /* E(i+1,j) = max(E - eDel, H - oeDel, 0) */ \
+      "v_cndmask_b32 %[vE], 0, %[vE], %[act]\n\t"  /* eh[end].e = 0 */ \
+      "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* eh[j].h = H(i,j-1) */ \
+      "s_and_b64 %[z], vcc, %[act]\n\t"  /* the zero cells of the band */ \
+      "v_writelane_b32 %[vH], %[h1], m0\n\t"  /* eh[beg].h = h1                        SWUtil.scala:153 */ \
+      /* SWUtil.scala:177-182: j after the column loop is end (the band is not empty); h1 there is eh[end].h */ \
+      "s_cmp_lg_u32 %[end], %[qlen]\n\t" \
+      "s_cbranch_scc1 L_nogs" SFX "_%=\n\t" \
+      "s_nop 0\n\t" \
+      "v_readlane_b32 %[t1], %[vH], %[t2]\n\t"  /* lane end - base */ \
+      "s_cmp_le_i32 %[gs], %[t1]\n\t" \
+      "s_cselect_b32 %[maxie], %[i], %[maxie]\n\t" \
+      "s_max_i32 %[gs], %[gs], %[t1]\n\t" \
+      "L_nogs" SFX "_%=:\n\t" \
+      "s_cmp_lt_i32 %[mkey], 128\n\t" \
+      "s_cbranch_scc1 L_done" SFX "_%=\n\t"  /* m == 0                                SWUtil.scala:184-185 */ \
+      "s_lshr_b32 %[m], %[mkey], 7\n\t" \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_add_i32 %[mja], %[mj], %[base]\n\t" \
+      "s_cmp_gt_i32 %[m], %[mx]\n\t" \
+      "s_cbranch_scc0 L_noimp" SFX "_%=\n\t" \
+      "s_sub_i32 %[t1], %[mja], %[i]\n\t"  /* SWUtil.scala:187-193 */ \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t" \
+      "s_mov_b32 %[mx], %[m]\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_mov_b32 %[maxj], %[mja]\n\t" \
+      "L_trim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214 */ \
+      "s_cmp_eq_u64 %[z], 0\n\t" \
+      "s_cbranch_scc1 L_nozero" SFX "_%=\n\t" \
+      "s_bfm_b64 %[u64], %[mj], 0\n\t" \
+      "s_and_b64 %[u64], %[u64], %[z]\n\t" \
+      "s_flbit_i32_b64 %[t1], %[u64]\n\t"  /* last zero left of mj (leading-zero count, -1: none) */ \
+      "s_lshr_b64 %[u64], %[z], %[mj]\n\t" \
+      "s_lshr_b64 %[u64], %[u64], 1\n\t" \
+      "s_ff1_i32_b64 %[t2], %[u64]\n\t"  /* first zero right of mj (-1: none) */ \
+      "s_sub_i32 %[t4], %[b65], %[t1]\n\t" \
+      "s_cmp_lt_i32 %[t1], 0\n\t" \
+      "s_cselect_b32 %[beg], %[t3], %[t4]\n\t" \
+      "s_add_i32 %[t4], %[mja], %[t2]\n\t" \
+      "s_add_i32 %[t4], %[t4], 2\n\t" \
+      "s_add_i32 %[t1], %[end], 1\n\t" \
+      "s_cmp_lt_i32 %[t2], 0\n\t" \
+      "s_cselect_b32 %[end], %[t1], %[t4]\n\t" \
+      "s_branch L_next" SFX "_%=\n\t" \
+      "L_nozero" SFX "_%=:\n\t" \
+      "s_mov_b32 %[beg], %[t3]\n\t" \
+      "s_add_i32 %[end], %[end], 1\n\t" \
+      "L_next" SFX "_%=:\n\t" \
+      "s_add_i32 %[i], %[i], 1\n\t" \
+      "s_cmp_lt_i32 %[i], %[rowend]\n\t" \
+      "s_cbranch_scc1 L_row" SFX "_%=\n\t" \
+      "s_mov_b32 %[reason], 1\n\t"  /* ROWS_MORE */ \
+      "s_branch L_out" SFX "_%=\n\t" \
+      "L_noimp" SFX "_%=:\n\t"  /* SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse) */ \
+      "s_cmp_lt_i32 %[zdrop], 1\n\t" \
+      "s_cbranch_scc1 L_trim" SFX "_%=\n\t" \
+      "s_sub_i32 %[t1], %[i], %[maxi]\n\t" \
+      "s_sub_i32 %[t2], %[mja], %[maxj]\n\t" \
+      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* k */ \
+      "s_sub_i32 %[t2], %[mx], %[m]\n\t"  /* X */ \
+      "s_cmp_gt_i32 %[t1], 0\n\t" \
+      "s_cbranch_scc0 L_zneg" SFX "_%=\n\t" \
+      "s_mul_i32 %[t4], %[t1], %[zpos]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cbranch_scc1 L_done" SFX "_%=\n\t" \
+      "s_branch L_trim" SFX "_%=\n\t" \
+      "L_zneg" SFX "_%=:\n\t" \
+      "s_cmp_eq_u32 %[zneg], 0\n\t" \
+      "s_cbranch_scc1 L_trim" SFX "_%=\n\t" \
+      "s_mul_i32 %[t4], %[t1], %[eins]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cbranch_scc1 L_done" SFX "_%=\n\t" \
+      "s_branch L_trim" SFX "_%=\n\t" \
+      "L_tail" SFX "_%=:\n\t"  /* tail_row_bound: U = max(u0 - i*eDel, qa); over once U <= max and U < gscore */ \
+      "s_mul_i32 %[t1], %[i], %[edel]\n\t" \
+      "s_sub_i32 %[t1], %[u0], %[t1]\n\t" \
+      "s_max_i32 %[t1], %[t1], %[qa]\n\t" \
+      "s_cmp_le_i32 %[t1], %[mx]\n\t" \
+      "s_cbranch_scc0 L_rowb" SFX "_%=\n\t" \
+      "s_cmp_lt_i32 %[t1], %[gs]\n\t" \
+      "s_cbranch_scc0 L_rowb" SFX "_%=\n\t" \
+      "L_done" SFX "_%=:\n\t" \
+      "s_mov_b32 %[reason], 0\n\t"  /* ROWS_DONE */ \
+      "s_branch L_out" SFX "_%=\n\t" \
+      "L_slow" SFX "_%=:\n\t" \
+      "s_mov_b32 %[reason], 3\n\t"  /* ROWS_SLOW */ \
+      "L_out" SFX "_%=:\n\t"
+// both instantiations in one statement (two statements under a branch make the compiler route the scalar state through VGPRs)
+#define ROWS1_ASM \
+  asm volatile( \
+      "s_cmp_eq_u32 %[tailrows], 0\n\t" \
+      "s_cbranch_scc1 L_rowb_n_%=\n\t" \
+      ROWS1_TEXT(ROWS_TAIL_TOP, "_t") \
+      "s_branch L_end_%=\n\t" \
+      ROWS1_TEXT("", "_n") \
+      "L_end_%=:\n\t" \
+      : [vH] "+v"(vH), [vE] "+v"(vE), [vPp] "+v"(vPp), [i] "+s"(s_i), [beg] "+s"(s_beg), [end] "+s"(s_end), [h1raw] "+s"(s_h1raw), \
+        [mx] "+s"(s_mx), [maxi] "+s"(s_maxi), [maxj] "+s"(s_maxj), [maxie] "+s"(s_maxie), [gs] "+s"(s_gs), [moff] "+s"(s_moff), \
+        [reason] "=&s"(reason), [vS] "=&v"(vS), [vA] "=&v"(vA), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [t] "=&s"(t), \
+        [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja), \
+        [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [act] "=&s"(act), [z] "=&s"(z), [u64] "=&s"(u64) \
+      : [vP] "v"(vP), [vLane] "v"(lane), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end), [qlen] "s"(qLen), \
+        [base] "s"(s_base), [b65] "s"(s_b65), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
+        [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), [qa] "s"(qa) \
+      : "vcc", "scc", "memory");  /* (M0 is written too: the compiler never keeps a value in it across statements on gfx9) */
 __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int qLen, const int row_end, const int vTS, const int w,
                                          const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
-                                         const int i_tail, const int u0, const int qa) {
+                                         const int i_tail, const int u0, const int qa, const bool tail_rows) {
   int vH = st.H0, vE = st.E0;
   const int vP = st.plo0;
   const int vNegC = -(lane * eIns);     // g(k) = a(k) + k*eIns = a - vNegC;  F(j) = Pex(j) + vNegC + (eIns - oeIns)
@@ -225,159 +386,9 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
   int vS, vA, vG, vK, vT0;
   int t, h1, span, mkey, m, mj, mja, t1, t2, t3, t4;
   unsigned long long act, z, u64;
-  asm volatile(
-      "L_row_%=:\n\t"
-      "s_cmp_ge_i32 %[i], %[itail]\n\t"
-      "s_cbranch_scc1 L_tail_%=\n\t"
-      "L_rowb_%=:\n\t"
-      "v_readlane_b32 %[t], %[vTS], %[i]\n\t"                 // 8 * target base of row i (lane i & 63)
-      "s_sub_i32 %[t1], %[i], %[w]\n\t"
-      "s_max_i32 %[beg], %[beg], %[t1]\n\t"                   // beg = max(beg, i - w)            SWUtil.scala:140-142
-      "s_add_i32 %[t1], %[i], %[w1]\n\t"
-      "s_min_i32 %[end], %[end], %[t1]\n\t"
-      "s_min_i32 %[end], %[end], %[qlen]\n\t"                 // end = min(end, i + w + 1, qLen)
-      "s_sub_i32 %[t2], %[end], %[base]\n\t"
-      "s_cmp_gt_i32 %[t2], 63\n\t"
-      "s_cbranch_scc1 L_slow_%=\n\t"                          // column `end` beyond the window
-      "s_cmp_eq_u32 %[t], 32\n\t"
-      "s_cbranch_scc1 L_slow_%=\n\t"                          // an N row
-      "s_sub_i32 %[span], %[end], %[beg]\n\t"
-      "s_cmp_lt_i32 %[span], 1\n\t"
-      "s_cbranch_scc1 L_slow_%=\n\t"                          // an empty band
-      "s_sub_i32 m0, %[beg], %[base]\n\t"                     // rbeg, the band's left end in window coordinates (in M0: v_writelane takes one SGPR + M0)
-      "v_bfe_i32 %[vS], %[vP], %[t], 8\n\t"
-      "v_subrev_u32 %[vT0], m0, %[vLane]\n\t"                 // rel = lane - rbeg
-      "v_cmp_gt_u32 %[act], %[span], %[vT0]\n\t"              // act = rel < span (unsigned)
-      "v_add_u32 %[vA], %[vH], %[vS]\n\t"
-      "v_max_i32 %[vA], %[vA], %[vE]\n\t"
-      "v_cndmask_b32 %[vA], %[vNEG], %[vA], %[act]\n\t"       // a = max(H(i-1,j-1) + s, E) or "no cell"
-      "v_sub_u32 %[vG], %[vA], %[vNegC]\n\t"                  // g = a + j*eIns
-      "v_lshl_or_b32 %[vK], %[vA], 7, %[vLane]\n\t"           // a << 7 | column: the row maximum and its LAST column in one scan
-      "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t"             // (scalar work in the wait states of the scans)
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "s_max_i32 %[h1], %[h1raw], 0\n\t"                      // h1 = max(0, h0 - oDel - eDel*(i+1))   SWUtil.scala:137-138
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "s_cmp_eq_u32 %[h1], 0\n\t"
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "s_addc_u32 %[t3], %[beg], 0\n\t"                       // nb0 = beg + (h1 == 0)
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  // exclusive prefix of g
-      "v_readlane_b32 %[mkey], %[vK], 63\n\t"
-      "v_add3_u32 %[vS], %[vPp], %[vNegC], %[nkc]\n\t"        // F = Pex - (j-1)*eIns - oeIns
-      "v_max_i32 %[vT0], %[vA], %[vS]\n\t"                    // H (>= 0 wherever the cell is in the band: E never goes below 0)
-      "v_cmp_gt_i32 vcc, 1, %[vT0]\n\t"                       // H == 0
-      "v_subrev_u32 %[vE], %[edel], %[vE]\n\t"
-      "v_subrev_u32 %[vS], %[oedel], %[vT0]\n\t"
-      "v_max3_i32 %[vE], %[vE], %[vS], 0\n\t"                 // E(i+1,j) = max(E - eDel, H - oeDel, 0)
-      "v_cndmask_b32 %[vE], 0, %[vE], %[act]\n\t"             // eh[end].e = 0
-      "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  // eh[j].h = H(i,j-1)
-      "s_and_b64 %[z], vcc, %[act]\n\t"                       // the zero cells of the band
-      "v_writelane_b32 %[vH], %[h1], m0\n\t"                  // eh[beg].h = h1                        SWUtil.scala:153
-      // SWUtil.scala:177-182: j after the column loop is end (the band is not empty); h1 there is eh[end].h
-      "s_cmp_lg_u32 %[end], %[qlen]\n\t"
-      "s_cbranch_scc1 L_nogs_%=\n\t"
-      "s_nop 0\n\t"
-      "v_readlane_b32 %[t1], %[vH], %[t2]\n\t"                // lane end - base
-      "s_cmp_le_i32 %[gs], %[t1]\n\t"
-      "s_cselect_b32 %[maxie], %[i], %[maxie]\n\t"
-      "s_max_i32 %[gs], %[gs], %[t1]\n\t"
-      "L_nogs_%=:\n\t"
-      "s_cmp_lt_i32 %[mkey], 128\n\t"
-      "s_cbranch_scc1 L_done_%=\n\t"                          // m == 0                                SWUtil.scala:184-185
-      "s_lshr_b32 %[m], %[mkey], 7\n\t"
-      "s_and_b32 %[mj], %[mkey], 127\n\t"
-      "s_add_i32 %[mja], %[mj], %[base]\n\t"
-      "s_cmp_gt_i32 %[m], %[mx]\n\t"
-      "s_cbranch_scc0 L_noimp_%=\n\t"
-      "s_sub_i32 %[t1], %[mja], %[i]\n\t"                     // SWUtil.scala:187-193
-      "s_abs_i32 %[t1], %[t1]\n\t"
-      "s_max_i32 %[moff], %[moff], %[t1]\n\t"
-      "s_mov_b32 %[mx], %[m]\n\t"
-      "s_mov_b32 %[maxi], %[i]\n\t"
-      "s_mov_b32 %[maxj], %[mja]\n\t"
-      "L_trim_%=:\n\t"                                        // band trimming, SWUtil.scala:202-214
-      "s_cmp_eq_u64 %[z], 0\n\t"
-      "s_cbranch_scc1 L_nozero_%=\n\t"
-      "s_bfm_b64 %[u64], %[mj], 0\n\t"
-      "s_and_b64 %[u64], %[u64], %[z]\n\t"
-      "s_flbit_i32_b64 %[t1], %[u64]\n\t"                     // last zero left of mj (leading-zero count, -1: none)
-      "s_lshr_b64 %[u64], %[z], %[mj]\n\t"
-      "s_lshr_b64 %[u64], %[u64], 1\n\t"
-      "s_ff1_i32_b64 %[t2], %[u64]\n\t"                       // first zero right of mj (-1: none)
-      "s_sub_i32 %[t4], %[b65], %[t1]\n\t"
-      "s_cmp_lt_i32 %[t1], 0\n\t"
-      "s_cselect_b32 %[beg], %[t3], %[t4]\n\t"
-      "s_add_i32 %[t4], %[mja], %[t2]\n\t"
-      "s_add_i32 %[t4], %[t4], 2\n\t"
-      "s_add_i32 %[t1], %[end], 1\n\t"
-      "s_cmp_lt_i32 %[t2], 0\n\t"
-      "s_cselect_b32 %[end], %[t1], %[t4]\n\t"
-      "s_branch L_next_%=\n\t"
-      "L_nozero_%=:\n\t"
-      "s_mov_b32 %[beg], %[t3]\n\t"
-      "s_add_i32 %[end], %[end], 1\n\t"
-      "L_next_%=:\n\t"
-      "s_add_i32 %[i], %[i], 1\n\t"
-      "s_cmp_lt_i32 %[i], %[rowend]\n\t"
-      "s_cbranch_scc1 L_row_%=\n\t"
-      "s_mov_b32 %[reason], 1\n\t"                            // ROWS_MORE
-      "s_branch L_out_%=\n\t"
-      "L_noimp_%=:\n\t"                                       // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
-      "s_cmp_lt_i32 %[zdrop], 1\n\t"
-      "s_cbranch_scc1 L_trim_%=\n\t"
-      "s_sub_i32 %[t1], %[i], %[maxi]\n\t"
-      "s_sub_i32 %[t2], %[mja], %[maxj]\n\t"
-      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"                     // k
-      "s_sub_i32 %[t2], %[mx], %[m]\n\t"                      // X
-      "s_cmp_gt_i32 %[t1], 0\n\t"
-      "s_cbranch_scc0 L_zneg_%=\n\t"
-      "s_mul_i32 %[t4], %[t1], %[zpos]\n\t"
-      "s_add_i32 %[t4], %[t4], %[t2]\n\t"
-      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t"
-      "s_cbranch_scc1 L_done_%=\n\t"
-      "s_branch L_trim_%=\n\t"
-      "L_zneg_%=:\n\t"
-      "s_cmp_eq_u32 %[zneg], 0\n\t"
-      "s_cbranch_scc1 L_trim_%=\n\t"
-      "s_mul_i32 %[t4], %[t1], %[eins]\n\t"
-      "s_add_i32 %[t4], %[t4], %[t2]\n\t"
-      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t"
-      "s_cbranch_scc1 L_done_%=\n\t"
-      "s_branch L_trim_%=\n\t"
-      "L_tail_%=:\n\t"                                        // tail_row_bound: U = max(u0 - i*eDel, qa); over once U <= max and U < gscore
-      "s_mul_i32 %[t1], %[i], %[edel]\n\t"
-      "s_sub_i32 %[t1], %[u0], %[t1]\n\t"
-      "s_max_i32 %[t1], %[t1], %[qa]\n\t"
-      "s_cmp_le_i32 %[t1], %[mx]\n\t"
-      "s_cbranch_scc0 L_rowb_%=\n\t"
-      "s_cmp_lt_i32 %[t1], %[gs]\n\t"
-      "s_cbranch_scc0 L_rowb_%=\n\t"
-      "L_done_%=:\n\t"
-      "s_mov_b32 %[reason], 0\n\t"                            // ROWS_DONE
-      "s_branch L_out_%=\n\t"
-      "L_slow_%=:\n\t"
-      "s_mov_b32 %[reason], 3\n\t"                            // ROWS_SLOW
-      "L_out_%=:\n\t"
-      : [vH] "+v"(vH), [vE] "+v"(vE), [vPp] "+v"(vPp), [i] "+s"(s_i), [beg] "+s"(s_beg), [end] "+s"(s_end), [h1raw] "+s"(s_h1raw),
-        [mx] "+s"(s_mx), [maxi] "+s"(s_maxi), [maxj] "+s"(s_maxj), [maxie] "+s"(s_maxie), [gs] "+s"(s_gs), [moff] "+s"(s_moff),
-        [reason] "=&s"(reason), [vS] "=&v"(vS), [vA] "=&v"(vA), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [t] "=&s"(t),
-        [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja),
-        [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [act] "=&s"(act), [z] "=&s"(z), [u64] "=&s"(u64)
-      : [vP] "v"(vP), [vLane] "v"(lane), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end), [qlen] "s"(qLen),
-        [base] "s"(s_base), [b65] "s"(s_b65), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc),
-        [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [u0] "s"(u0), [qa] "s"(qa)
-      : "vcc", "scc", "memory");  // (M0 is written too: the compiler never keeps a value in it across statements on gfx9)
+  // (the loop exists twice in the statement: the rows below the query end need no tail-row test at their top)
+  const int s_tailrows = uni((int)tail_rows);
+  ROWS1_ASM
   st.H0 = vH; st.E0 = vE;
   st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.mx = s_mx; st.max_i = s_maxi; st.max_j = s_maxj;
   st.max_ie = s_maxie; st.gscore = s_gs; st.max_off = s_moff;
@@ -387,9 +398,231 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
 // ---- the two-column loop in assembly ---------------------------------------------------------------------------------------
 // The same for the layout COLS == 2 (lane l holds columns base + 2l in H0 / E0 and base + 2l + 1 in H1 / E1).  It also leaves with
 // ROWS_SLOW when the band has become narrow enough for one column per lane (rows_cpp<2> then reports ROWS_OTHER_MODE).
+#define ROWS2_TEXT(TOP, SFX) \
+      "L_row" SFX "_%=:\n\t" TOP "L_rowb" SFX "_%=:\n\t" \
+      "v_readlane_b32 %[t], %[vTS], %[i]\n\t" \
+      "s_sub_i32 %[t1], %[i], %[w]\n\t" \
+      "s_max_i32 %[beg], %[beg], %[t1]\n\t"  /* SWUtil.scala:140-142 */ \
+      "s_add_i32 %[t1], %[i], %[w1]\n\t" \
+      "s_min_i32 %[end], %[end], %[t1]\n\t" \
+      "s_min_i32 %[end], %[end], %[qlen]\n\t" \
+      "s_sub_i32 %[t2], %[end], %[base]\n\t" \
+      "s_cmp_gt_i32 %[t2], 127\n\t" \
+      "s_cbranch_scc1 L_slow" SFX "_%=\n\t"  /* column `end` beyond the window */ \
+      "s_sub_i32 %[span], %[end], %[beg]\n\t" \
+      "s_cmp_lt_i32 %[span], %[narrow1]\n\t" \
+      "s_cbranch_scc1 L_slow" SFX "_%=\n\t"  /* an empty band, or one that fits one column per lane again */ \
+      "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
+      "v_bfe_i32 %[vS0], %[vP0], %[t], 8\n\t" \
+      "v_bfe_i32 %[vS1], %[vP1], %[t], 8\n\t" \
+      "v_subrev_u32 %[vT0], m0, %[vL2]\n\t"  /* rel0 = 2 lane - rbeg */ \
+      "v_add_u32 %[vT1], 1, %[vT0]\n\t"  /* rel1 */ \
+      "v_cmp_gt_u32 %[act0], %[span], %[vT0]\n\t" \
+      "v_cmp_gt_u32 %[act1], %[span], %[vT1]\n\t" \
+      "v_add_u32 %[vA0], %[vH0], %[vS0]\n\t" \
+      "v_add_u32 %[vA1], %[vH1], %[vS1]\n\t" \
+      "v_max_i32 %[vA0], %[vA0], %[vE0]\n\t" \
+      "v_max_i32 %[vA1], %[vA1], %[vE1]\n\t" \
+      "v_cndmask_b32 %[vA0], %[vNEG], %[vA0], %[act0]\n\t" \
+      "v_cndmask_b32 %[vA1], %[vNEG], %[vA1], %[act1]\n\t" \
+      "v_sub_u32 %[vG0], %[vA0], %[vNegC]\n\t"  /* g of the even column */ \
+      "v_sub_u32 %[vG], %[vA1], %[vNegC]\n\t" \
+      "v_add_u32 %[vG], %[eins], %[vG]\n\t"  /* g of the odd column */ \
+      "v_lshl_or_b32 %[vK], %[vA0], 7, %[vL2]\n\t" \
+      "v_lshl_or_b32 %[vS0], %[vA1], 7, %[vL2]\n\t" \
+      "v_or_b32 %[vS0], 1, %[vS0]\n\t" \
+      "v_max_i32 %[vG], %[vG], %[vG0]\n\t"  /* the lane's two columns folded */ \
+      "v_max_i32 %[vK], %[vK], %[vS0]\n\t"  /* a << 7 | column: row maximum and its LAST column */ \
+      "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t" \
+      "s_max_i32 %[h1], %[h1raw], 0\n\t"  /* SWUtil.scala:137-138 */ \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_cmp_eq_u32 %[h1], 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_addc_u32 %[t3], %[beg], 0\n\t"  /* nb0 = beg + (h1 == 0) */ \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_mov_b32 %[vh1], %[h1]\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "s_nop 1\n\t" \
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* prefix over the columns of the lanes below */ \
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      "v_add3_u32 %[vS0], %[vPp], %[vNegC], %[nkc]\n\t"  /* F of the even column */ \
+      "v_max_i32 %[vS1], %[vPp], %[vG0]\n\t" \
+      "v_add3_u32 %[vS1], %[vS1], %[vNegC], %[nkc1]\n\t"  /* F of the odd column */ \
+      "v_max_i32 %[vA0], %[vA0], %[vS0]\n\t"  /* H even (>= 0 wherever the cell is in the band) */ \
+      "v_max_i32 %[vA1], %[vA1], %[vS1]\n\t"  /* H odd */ \
+      "v_cmp_gt_i32 vcc, 1, %[vA0]\n\t" \
+      "s_and_b64 %[z0], vcc, %[act0]\n\t"  /* zero cells of the band, even columns */ \
+      "v_cmp_gt_i32 vcc, 1, %[vA1]\n\t" \
+      "s_and_b64 %[z1], vcc, %[act1]\n\t"  /* ... odd columns */ \
+      "v_subrev_u32 %[vE0], %[edel], %[vE0]\n\t" \
+      "v_subrev_u32 %[vS0], %[oedel], %[vA0]\n\t" \
+      "v_max3_i32 %[vE0], %[vE0], %[vS0], 0\n\t" \
+      "v_cndmask_b32 %[vE0], 0, %[vE0], %[act0]\n\t"  /* E(i+1,j); eh[end].e = 0 */ \
+      "v_subrev_u32 %[vE1], %[edel], %[vE1]\n\t" \
+      "v_subrev_u32 %[vS1], %[oedel], %[vA1]\n\t" \
+      "v_max3_i32 %[vE1], %[vE1], %[vS1], 0\n\t" \
+      "v_cndmask_b32 %[vE1], 0, %[vE1], %[act1]\n\t" \
+      "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* eh[j].h = H(i,j-1): even column <- odd of the lane below */ \
+      "v_cmp_eq_u32 vcc, 0, %[vT0]\n\t" \
+      "v_cndmask_b32 %[vH0], %[vH0], %[vh1], vcc\n\t"  /* eh[beg].h = h1   SWUtil.scala:153 */ \
+      "v_cmp_eq_u32 vcc, 0, %[vT1]\n\t" \
+      "v_cndmask_b32 %[vH1], %[vA0], %[vh1], vcc\n\t"  /* odd column <- even of the same lane */ \
+      /* SWUtil.scala:177-182 */ \
+      "s_cmp_lg_u32 %[end], %[qlen]\n\t" \
+      "s_cbranch_scc1 L_nogs" SFX "_%=\n\t" \
+      "s_lshr_b32 %[t1], %[t2], 1\n\t"  /* t2 = end - base: lane, and which of the lane's columns */ \
+      "s_and_b32 %[t2], %[t2], 1\n\t" \
+      "v_readlane_b32 %[t4], %[vH0], %[t1]\n\t" \
+      "v_readlane_b32 %[t1], %[vH1], %[t1]\n\t" \
+      "s_cmp_eq_u32 %[t2], 0\n\t" \
+      "s_cselect_b32 %[t1], %[t4], %[t1]\n\t" \
+      "s_cmp_le_i32 %[gs], %[t1]\n\t" \
+      "s_cselect_b32 %[maxie], %[i], %[maxie]\n\t" \
+      "s_max_i32 %[gs], %[gs], %[t1]\n\t" \
+      "L_nogs" SFX "_%=:\n\t" \
+      "s_cmp_lt_i32 %[mkey], 128\n\t" \
+      "s_cbranch_scc1 L_done" SFX "_%=\n\t"  /* m == 0 */ \
+      "s_lshr_b32 %[m], %[mkey], 7\n\t" \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_add_i32 %[mja], %[mj], %[base]\n\t" \
+      "s_cmp_gt_i32 %[m], %[mx]\n\t" \
+      "s_cbranch_scc0 L_noimp" SFX "_%=\n\t" \
+      "s_sub_i32 %[t1], %[mja], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t" \
+      "s_mov_b32 %[mx], %[m]\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_mov_b32 %[maxj], %[mja]\n\t" \
+      "L_trim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214, on the even / odd zero masks */ \
+      "s_or_b64 %[u64], %[z0], %[z1]\n\t" \
+      "s_cmp_eq_u64 %[u64], 0\n\t" \
+      "s_cbranch_scc1 L_nozero" SFX "_%=\n\t" \
+      /* last zero left of mj: even columns 2l < mj <=> l < (mj+1)>>1; odd columns 2l+1 < mj <=> l < mj>>1 */ \
+      "s_add_i32 %[t5], %[mj], 1\n\t" \
+      "s_lshr_b32 %[t6], %[t5], 1\n\t"  /* (mj+1)>>1 */ \
+      "s_bfm_b64 %[u64], %[t6], 0\n\t" \
+      "s_and_b64 %[u64], %[u64], %[z0]\n\t" \
+      "s_flbit_i32_b64 %[t1], %[u64]\n\t"  /* -1: none, else 63 - lane */ \
+      "s_lshr_b32 %[t4], %[mj], 1\n\t"  /* mj>>1 */ \
+      "s_bfm_b64 %[u64], %[t4], 0\n\t" \
+      "s_and_b64 %[u64], %[u64], %[z1]\n\t" \
+      "s_flbit_i32_b64 %[t2], %[u64]\n\t" \
+      /* column of each candidate + 2, or a value below every real one: even 2(63 - t1) + 2 = 128 - 2 t1; odd 2(63 - t2) + 3 = 129 - 2 t2 */ \
+      "s_lshl_b32 %[m], %[t1], 1\n\t" \
+      "s_sub_i32 %[m], 128, %[m]\n\t" \
+      "s_cmp_lt_i32 %[t1], 0\n\t" \
+      "s_cselect_b32 %[m], -1, %[m]\n\t" \
+      "s_lshl_b32 %[t1], %[t2], 1\n\t" \
+      "s_sub_i32 %[t1], 129, %[t1]\n\t" \
+      "s_cmp_lt_i32 %[t2], 0\n\t" \
+      "s_cselect_b32 %[t1], -1, %[t1]\n\t" \
+      "s_max_i32 %[m], %[m], %[t1]\n\t"  /* cl + 2, or -1 */ \
+      "s_add_i32 %[t1], %[m], %[base]\n\t" \
+      "s_cmp_lt_i32 %[m], 0\n\t" \
+      "s_cselect_b32 %[beg], %[t3], %[t1]\n\t"  /* beg = base + cl + 2, or nb0 */ \
+      /* first zero right of mj: even columns 2l > mj <=> l >= (mj+2)>>1; odd columns 2l+1 > mj <=> l >= (mj+1)>>1 = t6 */ \
+      "s_and_b32 %[t5], %[t5], 1\n\t"  /* (mj+1) & 1 */ \
+      "s_add_i32 %[t4], %[t6], %[t5]\n\t"  /* se = (mj+2)>>1 (at most 64: shifted in two steps) */ \
+      "s_lshr_b64 %[u64], %[z0], %[t6]\n\t" \
+      "s_lshr_b64 %[u64], %[u64], %[t5]\n\t" \
+      "s_ff1_i32_b64 %[t1], %[u64]\n\t" \
+      "s_lshr_b64 %[u64], %[z1], %[t6]\n\t" \
+      "s_ff1_i32_b64 %[t2], %[u64]\n\t" \
+      "s_add_i32 %[m], %[t4], %[t1]\n\t" \
+      "s_lshl_b32 %[m], %[m], 1\n\t"  /* 2 (se + fe) */ \
+      "s_cmp_lt_i32 %[t1], 0\n\t" \
+      "s_cselect_b32 %[m], 0x100000, %[m]\n\t" \
+      "s_add_i32 %[t1], %[t6], %[t2]\n\t" \
+      "s_lshl_b32 %[t1], %[t1], 1\n\t" \
+      "s_add_i32 %[t1], %[t1], 1\n\t"  /* 2 (so + fo) + 1 */ \
+      "s_cmp_lt_i32 %[t2], 0\n\t" \
+      "s_cselect_b32 %[t1], 0x100000, %[t1]\n\t" \
+      "s_min_i32 %[m], %[m], %[t1]\n\t"  /* cr, or 0x100000 */ \
+      "s_add_i32 %[t1], %[m], %[base]\n\t" \
+      "s_add_i32 %[t1], %[t1], 1\n\t" \
+      "s_add_i32 %[t2], %[end], 1\n\t" \
+      "s_cmp_lt_i32 %[m], 0x100000\n\t" \
+      "s_cselect_b32 %[end], %[t1], %[t2]\n\t"  /* end = base + cr + 1, or end + 1 */ \
+      "s_branch L_next" SFX "_%=\n\t" \
+      "L_nozero" SFX "_%=:\n\t" \
+      "s_mov_b32 %[beg], %[t3]\n\t" \
+      "s_add_i32 %[end], %[end], 1\n\t" \
+      "L_next" SFX "_%=:\n\t" \
+      "s_add_i32 %[i], %[i], 1\n\t" \
+      "s_cmp_lt_i32 %[i], %[rowend]\n\t" \
+      "s_cbranch_scc1 L_row" SFX "_%=\n\t" \
+      "s_mov_b32 %[reason], 1\n\t" \
+      "s_branch L_out" SFX "_%=\n\t" \
+      "L_noimp" SFX "_%=:\n\t"  /* SWUtil.scala:194-199 / native/ksw.c:455-461 */ \
+      "s_cmp_lt_i32 %[zdrop], 1\n\t" \
+      "s_cbranch_scc1 L_trim" SFX "_%=\n\t" \
+      "s_sub_i32 %[t1], %[i], %[maxi]\n\t" \
+      "s_sub_i32 %[t2], %[mja], %[maxj]\n\t" \
+      "s_sub_i32 %[t1], %[t1], %[t2]\n\t" \
+      "s_sub_i32 %[t2], %[mx], %[m]\n\t" \
+      "s_cmp_gt_i32 %[t1], 0\n\t" \
+      "s_cbranch_scc0 L_zneg" SFX "_%=\n\t" \
+      "s_mul_i32 %[t4], %[t1], %[zpos]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cbranch_scc1 L_done" SFX "_%=\n\t" \
+      "s_branch L_trim" SFX "_%=\n\t" \
+      "L_zneg" SFX "_%=:\n\t" \
+      "s_cmp_eq_u32 %[zneg], 0\n\t" \
+      "s_cbranch_scc1 L_trim" SFX "_%=\n\t" \
+      "s_mul_i32 %[t4], %[t1], %[eins]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cbranch_scc1 L_done" SFX "_%=\n\t" \
+      "s_branch L_trim" SFX "_%=\n\t" \
+      "L_tail" SFX "_%=:\n\t" \
+      "s_mul_i32 %[t1], %[i], %[edel]\n\t" \
+      "s_sub_i32 %[t1], %[u0], %[t1]\n\t" \
+      "s_max_i32 %[t1], %[t1], %[qa]\n\t" \
+      "s_cmp_le_i32 %[t1], %[mx]\n\t" \
+      "s_cbranch_scc0 L_rowb" SFX "_%=\n\t" \
+      "s_cmp_lt_i32 %[t1], %[gs]\n\t" \
+      "s_cbranch_scc0 L_rowb" SFX "_%=\n\t" \
+      "L_done" SFX "_%=:\n\t" \
+      "s_mov_b32 %[reason], 0\n\t" \
+      "s_branch L_out" SFX "_%=\n\t" \
+      "L_slow" SFX "_%=:\n\t" \
+      "s_mov_b32 %[reason], 3\n\t" \
+      "L_out" SFX "_%=:\n\t"
+// both instantiations in one statement (two statements under a branch make the compiler route the scalar state through VGPRs)
+#define ROWS2_ASM \
+  asm volatile( \
+      "s_cmp_eq_u32 %[tailrows], 0\n\t" \
+      "s_cbranch_scc1 L_rowb_n_%=\n\t" \
+      ROWS2_TEXT(ROWS_TAIL_TOP, "_t") \
+      "s_branch L_end_%=\n\t" \
+      ROWS2_TEXT("", "_n") \
+      "L_end_%=:\n\t" \
+      : [vH0] "+v"(vH0), [vE0] "+v"(vE0), [vH1] "+v"(vH1), [vE1] "+v"(vE1), [vPp] "+v"(vPp), [i] "+s"(s_i), [beg] "+s"(s_beg), \
+        [end] "+s"(s_end), [h1raw] "+s"(s_h1raw), [mx] "+s"(s_mx), [maxi] "+s"(s_maxi), [maxj] "+s"(s_maxj), [maxie] "+s"(s_maxie), \
+        [gs] "+s"(s_gs), [moff] "+s"(s_moff), [reason] "=&s"(reason), [vS0] "=&v"(vS0), [vS1] "=&v"(vS1), [vA0] "=&v"(vA0), \
+        [vA1] "=&v"(vA1), [vG0] "=&v"(vG0), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [vT1] "=&v"(vT1), [vh1] "=&v"(vh1), \
+        [t] "=&s"(t), [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja), \
+        [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [t5] "=&s"(t5), [t6] "=&s"(t6), [act0] "=&s"(act0), \
+        [act1] "=&s"(act1), [z0] "=&s"(z0), [z1] "=&s"(z1), [u64] "=&s"(u64) \
+      : [vP0] "v"(vP0), [vP1] "v"(vP1), [vL2] "v"(vL2), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end), \
+        [qlen] "s"(qLen), [base] "s"(s_base), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
+        [nkc1] "s"(s_nkc1), [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), \
+        [qa] "s"(qa), [narrow1] "s"(ROWS_NARROW + 1) \
+      : "vcc", "scc", "memory");  /* (M0 is written too) */
 __device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int qLen, const int row_end, const int vTS, const int w,
                                          const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
-                                         const int i_tail, const int u0, const int qa) {
+                                         const int i_tail, const int u0, const int qa, const bool tail_rows) {
   int vH0 = st.H0, vE0 = st.E0, vH1 = st.H1, vE1 = st.E1;
   const int vP0 = st.plo0, vP1 = st.plo1;
   const int vL2 = 2 * lane;               // the lane's even column, in window coordinates
@@ -404,228 +637,31 @@ __device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int
   int vS0, vS1, vA0, vA1, vG0, vG, vK, vT0, vT1, vh1;
   int t, h1, span, mkey, m, mj, mja, t1, t2, t3, t4, t5, t6;
   unsigned long long act0, act1, z0, z1, u64;
-  asm volatile(
-      "L_row_%=:\n\t"
-      "s_cmp_ge_i32 %[i], %[itail]\n\t"
-      "s_cbranch_scc1 L_tail_%=\n\t"
-      "L_rowb_%=:\n\t"
-      "v_readlane_b32 %[t], %[vTS], %[i]\n\t"
-      "s_sub_i32 %[t1], %[i], %[w]\n\t"
-      "s_max_i32 %[beg], %[beg], %[t1]\n\t"                   // SWUtil.scala:140-142
-      "s_add_i32 %[t1], %[i], %[w1]\n\t"
-      "s_min_i32 %[end], %[end], %[t1]\n\t"
-      "s_min_i32 %[end], %[end], %[qlen]\n\t"
-      "s_sub_i32 %[t2], %[end], %[base]\n\t"
-      "s_cmp_gt_i32 %[t2], 127\n\t"
-      "s_cbranch_scc1 L_slow_%=\n\t"                          // column `end` beyond the window
-      "s_cmp_eq_u32 %[t], 32\n\t"
-      "s_cbranch_scc1 L_slow_%=\n\t"                          // an N row
-      "s_sub_i32 %[span], %[end], %[beg]\n\t"
-      "s_cmp_lt_i32 %[span], %[narrow1]\n\t"
-      "s_cbranch_scc1 L_slow_%=\n\t"                          // an empty band, or one that fits one column per lane again
-      "s_sub_i32 m0, %[beg], %[base]\n\t"                     // rbeg
-      "v_bfe_i32 %[vS0], %[vP0], %[t], 8\n\t"
-      "v_bfe_i32 %[vS1], %[vP1], %[t], 8\n\t"
-      "v_subrev_u32 %[vT0], m0, %[vL2]\n\t"                   // rel0 = 2 lane - rbeg
-      "v_add_u32 %[vT1], 1, %[vT0]\n\t"                       // rel1
-      "v_cmp_gt_u32 %[act0], %[span], %[vT0]\n\t"
-      "v_cmp_gt_u32 %[act1], %[span], %[vT1]\n\t"
-      "v_add_u32 %[vA0], %[vH0], %[vS0]\n\t"
-      "v_add_u32 %[vA1], %[vH1], %[vS1]\n\t"
-      "v_max_i32 %[vA0], %[vA0], %[vE0]\n\t"
-      "v_max_i32 %[vA1], %[vA1], %[vE1]\n\t"
-      "v_cndmask_b32 %[vA0], %[vNEG], %[vA0], %[act0]\n\t"
-      "v_cndmask_b32 %[vA1], %[vNEG], %[vA1], %[act1]\n\t"
-      "v_sub_u32 %[vG0], %[vA0], %[vNegC]\n\t"                // g of the even column
-      "v_sub_u32 %[vG], %[vA1], %[vNegC]\n\t"
-      "v_add_u32 %[vG], %[eins], %[vG]\n\t"                   // g of the odd column
-      "v_lshl_or_b32 %[vK], %[vA0], 7, %[vL2]\n\t"
-      "v_lshl_or_b32 %[vS0], %[vA1], 7, %[vL2]\n\t"
-      "v_or_b32 %[vS0], 1, %[vS0]\n\t"
-      "v_max_i32 %[vG], %[vG], %[vG0]\n\t"                    // the lane's two columns folded
-      "v_max_i32 %[vK], %[vK], %[vS0]\n\t"                    // a << 7 | column: row maximum and its LAST column
-      "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t"
-      "s_max_i32 %[h1], %[h1raw], 0\n\t"                      // SWUtil.scala:137-138
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "s_cmp_eq_u32 %[h1], 0\n\t"
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "s_addc_u32 %[t3], %[beg], 0\n\t"                       // nb0 = beg + (h1 == 0)
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_mov_b32 %[vh1], %[h1]\n\t"
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  // prefix over the columns of the lanes below
-      "v_readlane_b32 %[mkey], %[vK], 63\n\t"
-      "v_add3_u32 %[vS0], %[vPp], %[vNegC], %[nkc]\n\t"       // F of the even column
-      "v_max_i32 %[vS1], %[vPp], %[vG0]\n\t"
-      "v_add3_u32 %[vS1], %[vS1], %[vNegC], %[nkc1]\n\t"      // F of the odd column
-      "v_max_i32 %[vA0], %[vA0], %[vS0]\n\t"                  // H even (>= 0 wherever the cell is in the band)
-      "v_max_i32 %[vA1], %[vA1], %[vS1]\n\t"                  // H odd
-      "v_cmp_gt_i32 vcc, 1, %[vA0]\n\t"
-      "s_and_b64 %[z0], vcc, %[act0]\n\t"                     // zero cells of the band, even columns
-      "v_cmp_gt_i32 vcc, 1, %[vA1]\n\t"
-      "s_and_b64 %[z1], vcc, %[act1]\n\t"                     // ... odd columns
-      "v_subrev_u32 %[vE0], %[edel], %[vE0]\n\t"
-      "v_subrev_u32 %[vS0], %[oedel], %[vA0]\n\t"
-      "v_max3_i32 %[vE0], %[vE0], %[vS0], 0\n\t"
-      "v_cndmask_b32 %[vE0], 0, %[vE0], %[act0]\n\t"          // E(i+1,j); eh[end].e = 0
-      "v_subrev_u32 %[vE1], %[edel], %[vE1]\n\t"
-      "v_subrev_u32 %[vS1], %[oedel], %[vA1]\n\t"
-      "v_max3_i32 %[vE1], %[vE1], %[vS1], 0\n\t"
-      "v_cndmask_b32 %[vE1], 0, %[vE1], %[act1]\n\t"
-      "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  // eh[j].h = H(i,j-1): even column <- odd of the lane below
-      "v_cmp_eq_u32 vcc, 0, %[vT0]\n\t"
-      "v_cndmask_b32 %[vH0], %[vH0], %[vh1], vcc\n\t"         // eh[beg].h = h1   SWUtil.scala:153
-      "v_cmp_eq_u32 vcc, 0, %[vT1]\n\t"
-      "v_cndmask_b32 %[vH1], %[vA0], %[vh1], vcc\n\t"         // odd column <- even of the same lane
-      // SWUtil.scala:177-182
-      "s_cmp_lg_u32 %[end], %[qlen]\n\t"
-      "s_cbranch_scc1 L_nogs_%=\n\t"
-      "s_lshr_b32 %[t1], %[t2], 1\n\t"                        // t2 = end - base: lane, and which of the lane's columns
-      "s_and_b32 %[t2], %[t2], 1\n\t"
-      "v_readlane_b32 %[t4], %[vH0], %[t1]\n\t"
-      "v_readlane_b32 %[t1], %[vH1], %[t1]\n\t"
-      "s_cmp_eq_u32 %[t2], 0\n\t"
-      "s_cselect_b32 %[t1], %[t4], %[t1]\n\t"
-      "s_cmp_le_i32 %[gs], %[t1]\n\t"
-      "s_cselect_b32 %[maxie], %[i], %[maxie]\n\t"
-      "s_max_i32 %[gs], %[gs], %[t1]\n\t"
-      "L_nogs_%=:\n\t"
-      "s_cmp_lt_i32 %[mkey], 128\n\t"
-      "s_cbranch_scc1 L_done_%=\n\t"                          // m == 0
-      "s_lshr_b32 %[m], %[mkey], 7\n\t"
-      "s_and_b32 %[mj], %[mkey], 127\n\t"
-      "s_add_i32 %[mja], %[mj], %[base]\n\t"
-      "s_cmp_gt_i32 %[m], %[mx]\n\t"
-      "s_cbranch_scc0 L_noimp_%=\n\t"
-      "s_sub_i32 %[t1], %[mja], %[i]\n\t"
-      "s_abs_i32 %[t1], %[t1]\n\t"
-      "s_max_i32 %[moff], %[moff], %[t1]\n\t"
-      "s_mov_b32 %[mx], %[m]\n\t"
-      "s_mov_b32 %[maxi], %[i]\n\t"
-      "s_mov_b32 %[maxj], %[mja]\n\t"
-      "L_trim_%=:\n\t"                                        // band trimming, SWUtil.scala:202-214, on the even / odd zero masks
-      "s_or_b64 %[u64], %[z0], %[z1]\n\t"
-      "s_cmp_eq_u64 %[u64], 0\n\t"
-      "s_cbranch_scc1 L_nozero_%=\n\t"
-      // last zero left of mj: even columns 2l < mj <=> l < (mj+1)>>1; odd columns 2l+1 < mj <=> l < mj>>1
-      "s_add_i32 %[t5], %[mj], 1\n\t"
-      "s_lshr_b32 %[t6], %[t5], 1\n\t"                        // (mj+1)>>1
-      "s_bfm_b64 %[u64], %[t6], 0\n\t"
-      "s_and_b64 %[u64], %[u64], %[z0]\n\t"
-      "s_flbit_i32_b64 %[t1], %[u64]\n\t"                     // -1: none, else 63 - lane
-      "s_lshr_b32 %[t4], %[mj], 1\n\t"                        // mj>>1
-      "s_bfm_b64 %[u64], %[t4], 0\n\t"
-      "s_and_b64 %[u64], %[u64], %[z1]\n\t"
-      "s_flbit_i32_b64 %[t2], %[u64]\n\t"
-      // column of each candidate + 2, or a value below every real one: even 2(63 - t1) + 2 = 128 - 2 t1; odd 2(63 - t2) + 3 = 129 - 2 t2
-      "s_lshl_b32 %[m], %[t1], 1\n\t"
-      "s_sub_i32 %[m], 128, %[m]\n\t"
-      "s_cmp_lt_i32 %[t1], 0\n\t"
-      "s_cselect_b32 %[m], -1, %[m]\n\t"
-      "s_lshl_b32 %[t1], %[t2], 1\n\t"
-      "s_sub_i32 %[t1], 129, %[t1]\n\t"
-      "s_cmp_lt_i32 %[t2], 0\n\t"
-      "s_cselect_b32 %[t1], -1, %[t1]\n\t"
-      "s_max_i32 %[m], %[m], %[t1]\n\t"                       // cl + 2, or -1
-      "s_add_i32 %[t1], %[m], %[base]\n\t"
-      "s_cmp_lt_i32 %[m], 0\n\t"
-      "s_cselect_b32 %[beg], %[t3], %[t1]\n\t"                // beg = base + cl + 2, or nb0
-      // first zero right of mj: even columns 2l > mj <=> l >= (mj+2)>>1; odd columns 2l+1 > mj <=> l >= (mj+1)>>1 = t6
-      "s_and_b32 %[t5], %[t5], 1\n\t"                         // (mj+1) & 1
-      "s_add_i32 %[t4], %[t6], %[t5]\n\t"                     // se = (mj+2)>>1 (at most 64: shifted in two steps)
-      "s_lshr_b64 %[u64], %[z0], %[t6]\n\t"
-      "s_lshr_b64 %[u64], %[u64], %[t5]\n\t"
-      "s_ff1_i32_b64 %[t1], %[u64]\n\t"
-      "s_lshr_b64 %[u64], %[z1], %[t6]\n\t"
-      "s_ff1_i32_b64 %[t2], %[u64]\n\t"
-      "s_add_i32 %[m], %[t4], %[t1]\n\t"
-      "s_lshl_b32 %[m], %[m], 1\n\t"                          // 2 (se + fe)
-      "s_cmp_lt_i32 %[t1], 0\n\t"
-      "s_cselect_b32 %[m], 0x100000, %[m]\n\t"
-      "s_add_i32 %[t1], %[t6], %[t2]\n\t"
-      "s_lshl_b32 %[t1], %[t1], 1\n\t"
-      "s_add_i32 %[t1], %[t1], 1\n\t"                         // 2 (so + fo) + 1
-      "s_cmp_lt_i32 %[t2], 0\n\t"
-      "s_cselect_b32 %[t1], 0x100000, %[t1]\n\t"
-      "s_min_i32 %[m], %[m], %[t1]\n\t"                       // cr, or 0x100000
-      "s_add_i32 %[t1], %[m], %[base]\n\t"
-      "s_add_i32 %[t1], %[t1], 1\n\t"
-      "s_add_i32 %[t2], %[end], 1\n\t"
-      "s_cmp_lt_i32 %[m], 0x100000\n\t"
-      "s_cselect_b32 %[end], %[t1], %[t2]\n\t"                // end = base + cr + 1, or end + 1
-      "s_branch L_next_%=\n\t"
-      "L_nozero_%=:\n\t"
-      "s_mov_b32 %[beg], %[t3]\n\t"
-      "s_add_i32 %[end], %[end], 1\n\t"
-      "L_next_%=:\n\t"
-      "s_add_i32 %[i], %[i], 1\n\t"
-      "s_cmp_lt_i32 %[i], %[rowend]\n\t"
-      "s_cbranch_scc1 L_row_%=\n\t"
-      "s_mov_b32 %[reason], 1\n\t"
-      "s_branch L_out_%=\n\t"
-      "L_noimp_%=:\n\t"                                       // SWUtil.scala:194-199 / native/ksw.c:455-461
-      "s_cmp_lt_i32 %[zdrop], 1\n\t"
-      "s_cbranch_scc1 L_trim_%=\n\t"
-      "s_sub_i32 %[t1], %[i], %[maxi]\n\t"
-      "s_sub_i32 %[t2], %[mja], %[maxj]\n\t"
-      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"
-      "s_sub_i32 %[t2], %[mx], %[m]\n\t"
-      "s_cmp_gt_i32 %[t1], 0\n\t"
-      "s_cbranch_scc0 L_zneg_%=\n\t"
-      "s_mul_i32 %[t4], %[t1], %[zpos]\n\t"
-      "s_add_i32 %[t4], %[t4], %[t2]\n\t"
-      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t"
-      "s_cbranch_scc1 L_done_%=\n\t"
-      "s_branch L_trim_%=\n\t"
-      "L_zneg_%=:\n\t"
-      "s_cmp_eq_u32 %[zneg], 0\n\t"
-      "s_cbranch_scc1 L_trim_%=\n\t"
-      "s_mul_i32 %[t4], %[t1], %[eins]\n\t"
-      "s_add_i32 %[t4], %[t4], %[t2]\n\t"
-      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t"
-      "s_cbranch_scc1 L_done_%=\n\t"
-      "s_branch L_trim_%=\n\t"
-      "L_tail_%=:\n\t"
-      "s_mul_i32 %[t1], %[i], %[edel]\n\t"
-      "s_sub_i32 %[t1], %[u0], %[t1]\n\t"
-      "s_max_i32 %[t1], %[t1], %[qa]\n\t"
-      "s_cmp_le_i32 %[t1], %[mx]\n\t"
-      "s_cbranch_scc0 L_rowb_%=\n\t"
-      "s_cmp_lt_i32 %[t1], %[gs]\n\t"
-      "s_cbranch_scc0 L_rowb_%=\n\t"
-      "L_done_%=:\n\t"
-      "s_mov_b32 %[reason], 0\n\t"
-      "s_branch L_out_%=\n\t"
-      "L_slow_%=:\n\t"
-      "s_mov_b32 %[reason], 3\n\t"
-      "L_out_%=:\n\t"
-      : [vH0] "+v"(vH0), [vE0] "+v"(vE0), [vH1] "+v"(vH1), [vE1] "+v"(vE1), [vPp] "+v"(vPp), [i] "+s"(s_i), [beg] "+s"(s_beg),
-        [end] "+s"(s_end), [h1raw] "+s"(s_h1raw), [mx] "+s"(s_mx), [maxi] "+s"(s_maxi), [maxj] "+s"(s_maxj), [maxie] "+s"(s_maxie),
-        [gs] "+s"(s_gs), [moff] "+s"(s_moff), [reason] "=&s"(reason), [vS0] "=&v"(vS0), [vS1] "=&v"(vS1), [vA0] "=&v"(vA0),
-        [vA1] "=&v"(vA1), [vG0] "=&v"(vG0), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [vT1] "=&v"(vT1), [vh1] "=&v"(vh1),
-        [t] "=&s"(t), [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja),
-        [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [t5] "=&s"(t5), [t6] "=&s"(t6), [act0] "=&s"(act0),
-        [act1] "=&s"(act1), [z0] "=&s"(z0), [z1] "=&s"(z1), [u64] "=&s"(u64)
-      : [vP0] "v"(vP0), [vP1] "v"(vP1), [vL2] "v"(vL2), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end),
-        [qlen] "s"(qLen), [base] "s"(s_base), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc),
-        [nkc1] "s"(s_nkc1), [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [u0] "s"(u0),
-        [qa] "s"(qa), [narrow1] "s"(ROWS_NARROW + 1)
-      : "vcc", "scc", "memory");  // (M0 is written too)
+  // (the loop exists twice in the statement: the rows below the query end need no tail-row test at their top)
+  const int s_tailrows = uni((int)tail_rows);
+  ROWS2_ASM
   st.H0 = vH0; st.E0 = vE0; st.H1 = vH1; st.E1 = vE1;
   st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.mx = s_mx; st.max_i = s_maxi; st.max_j = s_maxj;
   st.max_ie = s_maxie; st.gscore = s_gs; st.max_off = s_moff;
   return reason;
+}
+
+// Where the assembly loop may run to from row i: the end of the 64-row target chunk it has in a register (reloaded here when i has
+// left it), the last target row, the first N row (the loops have no N-row path: a mask of the chunk's N rows replaces a test per row),
+// and the first row at the query end when i is still before it (the instantiation without the tail-row test serves those rows).
+__device__ __forceinline__ int rows_asm_end(const int i, const int tLen, const int i_tail, const uint8_t* __restrict__ ts, const int lane,
+                                            int* vTS, int* ts_chunk, unsigned long long* n_rows) {
+  if ((i >> 6) != *ts_chunk) {  // 8 * target base of the 64 rows around row i, one per lane
+    *ts_chunk = i >> 6;
+    const int at = (*ts_chunk << 6) + lane;
+    *vTS = at < tLen ? (int)ts[at] : 0;
+    *n_rows = __builtin_amdgcn_ballot_w64(*vTS == 32);
+  }
+  int end = min(tLen, (*ts_chunk + 1) << 6);
+  const unsigned long long ahead = *n_rows >> (i & 63);
+  if (ahead) end = min(end, i + (int)__builtin_ctzll(ahead));
+  if (i < i_tail) end = min(end, i_tail);
+  return uni(end);
 }
 
 // SWExtend on the adaptive window, for flanks of up to 255 bases (WINDOW) or 127 (no window: the band always fits two columns per
@@ -657,17 +693,15 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
   const int i_tail = amax > 0 ? qLen : 0x7fffffff;
   const int u0 = h0 + qLen * amax - oDel + (qLen - 1) * eDel, qa = qLen * amax;  // tail_row_bound(i) = max(u0 - i*eDel, qa)
   int vTS = 0, ts_chunk = -1;
+  unsigned long long n_rows = 0ull;  // the N rows of the target chunk in vTS
   for (;;) {
     int r;
     if (cols == 1) {
 #if BPSW_EXT_ROWS_ASM
       if (st.i >= tLen) break;
-      if ((st.i >> 6) != ts_chunk) {  // 8 * target base of the 64 rows around row i, one per lane
-        ts_chunk = st.i >> 6;
-        const int at = (ts_chunk << 6) + lane;
-        vTS = at < tLen ? (int)ts[at] : 0;
-      }
-      r = rows1_asm(st, lane, qLen, min(tLen, (ts_chunk + 1) << 6), vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa);
+      r = ROWS_SLOW;
+      if (const int row_end = rows_asm_end(st.i, tLen, i_tail, ts, lane, &vTS, &ts_chunk, &n_rows); row_end > st.i)
+        r = rows1_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail);
       if (r == ROWS_SLOW)
 #endif
         r = rows_cpp<1>(st, lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
@@ -686,12 +720,9 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
     } else {
 #if BPSW_EXT_ROWS_ASM
       if (st.i >= tLen) break;
-      if ((st.i >> 6) != ts_chunk) {
-        ts_chunk = st.i >> 6;
-        const int at = (ts_chunk << 6) + lane;
-        vTS = at < tLen ? (int)ts[at] : 0;
-      }
-      r = rows2_asm(st, lane, qLen, min(tLen, (ts_chunk + 1) << 6), vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa);
+      r = ROWS_SLOW;
+      if (const int row_end = rows_asm_end(st.i, tLen, i_tail, ts, lane, &vTS, &ts_chunk, &n_rows); row_end > st.i)
+        r = rows2_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail);
       if (r == ROWS_SLOW)
 #endif
         r = rows_cpp<2>(st, lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
