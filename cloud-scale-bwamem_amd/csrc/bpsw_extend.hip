@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
                                                                      const ExtPrepass* __restrict__ pre,
                                                                      int* __restrict__ defer, const int short_qmax,
                                                                      uint8_t* __restrict__ qflag, uint4* __restrict__ qcarry,
-                                                                     const int quad_qmax) {
+                                                                     const int quad_qmax, const uint8_t* __restrict__ sift_flag,
+                                                                     const uint4* __restrict__ sift_recs) {
   extern __shared__ __align__(16) unsigned char smem[];
   // the full kernel behind a SHORT launch: its task list and count are what the host listed plus what that launch deferred
   const int n_tasks = (!SHORT && defer) ? uni(defer[0]) : n_tasks_arg;
@@ -140,6 +141,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
     }
     const int task = task_list ? uni(task_list[ticket]) : ticket;  // n_tasks counts the entries of task_list when given
     ++ticket;
+    // what the sift kernel (bpsw_extend_sift.hip: the shortcuts, one task per lane) left for this task: 1 = its record is written,
+    // 2 = a record per side in sift_recs, 0 = nothing
+    int sifted = 0;
+    if (SHORT == 1 && !COORD && sift_flag) {
+      sifted = uni((int)sift_flag[task]);
+      if (sifted == 1) continue;
+    }
     const uint32_t* rec = wire + 8 + (COORD ? 10 : 8) * (size_t)task;  // MemChainToAlignBatched.scala:95-117
     const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
     // coordinate batch: the seed's start in the doubled reference and its length (in the slot of the redundant 16-bit idx)
@@ -196,8 +204,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
                                                          hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
       };
       bool exact_v;
-      if constexpr (COORD) exact_v = reg_path && shortcuts(LdsShiftT{ts}, tstage);
-      else exact_v = shortcuts(tnib, rLen);
+      if constexpr (COORD) {
+        exact_v = reg_path && shortcuts(LdsShiftT{ts}, tstage);
+      } else {
+        int judged = 0;  // 1: the sift kernel found that no form holds, 2: that one does for this start score
+        if (SHORT == 1 && sifted == 2) {
+          const uint4 sr = sift_recs[2 * (size_t)task + side];
+          const int kind = uni((int)(sr.x & 0xffu)), hmin = uni((int)sr.x >> 8);
+          if (kind == 1) judged = 1;
+          else if (kind == 2 && hInit >= hmin) {
+            judged = 2;
+            r.max = hInit + uni(lo16(sr.y)); r.gscore = hInit + uni(hi16(sr.y));
+            r.qle = uni(lo16(sr.z)); r.tle = uni(hi16(sr.z)); r.gtle = uni(lo16(sr.w)); r.max_off = uni(hi16(sr.w));
+          }
+        }
+        exact_v = judged ? judged == 2 : shortcuts(tnib, rLen);
+      }
       // wave-uniform by construction (the shortcuts decide on wave reductions), but not to the compiler: without this the DP below
       // sits in what it takes for divergent control flow and its whole scalar state is kept in vector registers
       const bool exact = uni(exact_v ? 1 : 0) != 0;
@@ -334,7 +356,8 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev, bool short_kernel, int* d_defer,
-                             int short_qmax, uint8_t* d_qflag, uint4* d_qcarry, int quad_qmax) {
+                             int short_qmax, uint8_t* d_qflag, uint4* d_qcarry, int quad_qmax, const uint8_t* d_sift_flag,
+                             const uint4* d_sift_recs) {
   if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
   const int variant = !short_kernel ? 0 : ((short_qmax < 0 ? -short_qmax : short_qmax) <= 127 ? 1 : 2);
@@ -384,7 +407,8 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
 #define BPSW_EXT_GO(CO, SH)                                                                                                     \
   BPSW_LAUNCH(kev, (ext_kernel<CO, SH>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap, rcap, \
-              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_qflag, d_qcarry, quad_qmax)
+              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_qflag, d_qcarry, quad_qmax, \
+              d_sift_flag, d_sift_recs)
   if (variant == 1) {
     if (coord) BPSW_EXT_GO(true, 1); else BPSW_EXT_GO(false, 1);
   } else if (variant == 2) {

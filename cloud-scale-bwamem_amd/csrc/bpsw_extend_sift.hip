@@ -1,0 +1,422 @@
+// bpsw_extend_sift.hip -- the exact shortcuts of the extension (bpsw_extend_core.h: flank_closed_form with its single-gap
+// certificate and two-gap-open tests, flank_start_gap_form), evaluated one TASK per LANE in front of ext_kernel.
+//
+// Why: three quarters of the tasks of low-error reads are resolved by the shortcuts on both sides, and ext_kernel spends a whole
+// wavefront on each of them -- 64 lanes for a flank of ~65 bases, two DPP scans per 64 columns and shift of the certificate, several
+// hundred wave-instructions per task that is never swept.  The shortcuts decide on the main diagonal's few mismatches, so they are
+// word-parallel work on the nibble stream itself: eight bases per XOR.  Here a wavefront copies the nibble streams of 64 consecutive
+// tasks into LDS with coalesced loads (they lie back to back in the wire batch; a batch laid out otherwise is left to ext_kernel),
+// every lane takes one task and runs the same decisions in 32-bit integer arithmetic on funnel-shifted words of its stream.
+//
+// What it hands on (per task, `flag`):  1 = both sides resolved, the result record is written, ext_kernel skips the task;
+// 2 = a record per side for ext_kernel: "no form holds" (sweep at once) or "resolved when hInit >= hmin, with these results
+// relative to hInit" -- every form is linear in the start score, and the right side's start score is the left side's result, which
+// only ext_kernel knows when the left side needs the DP;  0 = not examined: ext_kernel does it all.
+// A side that this kernel does not judge (an N in either flank) is marked "not examined" and evaluated by ext_kernel's own
+// wave-wide code: the decisions are the same either way, never a guess.
+// Restrictions (the launch checks them): wire format 1, a matrix whose sixteen base-vs-base entries are a on the diagonal and one
+// value a - dm off it (sc.exact_a > 0 says the first, `dm` is passed in), flanks up to 127 bases.
+//
+// The single-gap certificate without scans.  With one mismatch score every term of bpsw_extend_core.h's conditions is a multiple of
+// dm: along a shifted diagonal a column GAINS dm where the main diagonal mismatches and the shifted one matches, LOSES dm where the
+// main one matches and the shifted one does not, and G(y) - min_{z<y} G(z) = dm * r(y) with r(y) = c(y) + max(0, r(y-1)).  So
+// W(y) = max(0, r(y)) is a counter that goes up at a gain and down (not below 0) at a loss, gains are among the <= 3 deficit columns
+// of the flank, and the conditions can only fail at a handful of columns: at a gain (insertion: dm (W + 1) >= T), at the end of the
+// range, and -- deletion, where the comparison is with the main diagonal d rows further down, tail(x) = A(min(x+d, n-1)) - A(x) --
+// wherever dm W(x) - tail(x) can rise: at x = 0, at a deficit column p, at p - d (p enters the tail), and in the last d columns (the
+// tail gets shorter).  Between such columns only the number of losses matters, and only up to W: a popcount over words, nearly
+// always one word.  Same decisions as the scans (tests/test_extend_gpu.py, tools/soak_cert2.py compare the verdicts side by side).
+// Cites: the forms follow SWUtil.scala:61-230 / MemChainToAlignBatched.scala:789-883 exactly as bpsw_extend_core.h derives them;
+// the chaining of the two sides mirrors ext_kernel (bpsw_extend.hip).
+#include "bpsw_extend_core.h"
+
+namespace bpsw {
+namespace {
+
+constexpr int SIFT_RAW_WORDS = 4096;  // nibble words of 64 consecutive tasks a wavefront stages (16 KB; 2x150 bp tasks average ~41)
+
+__device__ __forceinline__ int s_lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
+__device__ __forceinline__ int s_hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
+
+// this lane's task: its nibble stream in LDS (first base in the top nibble of word 0) and where the two flanks of one side start
+struct SiftSeq {
+  const uint32_t* raw;
+  int qs, ts;
+  // the eight bases from base k of the stream on
+  __device__ __forceinline__ uint32_t at8(int k) const {
+    const int wi = k >> 3;
+    const unsigned long long v = ((unsigned long long)raw[wi] << 32) | raw[wi + 1];
+    return (uint32_t)((v << ((k & 7) << 2)) >> 32);
+  }
+  __device__ __forceinline__ uint32_t q8(int k) const { return at8(qs + k); }
+  __device__ __forceinline__ uint32_t t8(int k) const { return at8(ts + k); }
+  __device__ __forceinline__ int at1(int k) const { return (int)((raw[k >> 3] >> (28 - 4 * (k & 7))) & 0xFu); }
+  __device__ __forceinline__ int qn(int k) const { return at1(qs + k); }
+  __device__ __forceinline__ int tn(int k) const { return at1(ts + k); }
+};
+
+// the top `cnt` nibbles of a word (cnt >= 1; 8 and more: all of it)
+__device__ __forceinline__ uint32_t top_nibbles(int cnt) { return cnt >= 8 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (32 - 4 * cnt); }
+// one flag (bit 0 of its nibble) per nibble in which two words of codes 0..3 differ
+__device__ __forceinline__ uint32_t differ(uint32_t x, uint32_t y) {
+  const uint32_t v = x ^ y;
+  return (v | (v >> 1)) & 0x11111111u;
+}
+
+enum { SIFT_UNSEEN = 0, SIFT_FAIL = 1, SIFT_FORM = 2 };
+struct SideRec {
+  int kind, hmin;                                   // SIFT_FORM: the side is resolved when its start score is >= hmin
+  int max_rel, g_rel, qle, tle, gtle, max_off;      // max - hInit, gscore - hInit, and the rest of ExtRes
+};
+
+struct SiftParams {
+  int a, dm;                 // match score, a - (mismatch score)
+  int oDel, eDel, oIns, eIns, zdrop, certify, wBand;
+};
+
+// how many of the columns lo..hi have q[y + dq] != t[y + dt]; stops counting at `cap` (lo <= hi)
+__device__ int sift_count_differ(const SiftSeq& s, const int lo, const int hi, const int dq, const int dt, const int cap) {
+  int cnt = 0;
+  for (int k = lo; k <= hi && cnt < cap; k += 8) cnt += __popc(differ(s.q8(k + dq), s.t8(k + dt)) & top_nibbles(hi + 1 - k));
+  return cnt;
+}
+__device__ __forceinline__ bool sift_equal_run(const SiftSeq& s, const int lo, const int hi, const int dq, const int dt) {
+  return sift_count_differ(s, lo, hi, dq, dt, 1) == 0;
+}
+
+// single_gap_certificate of bpsw_extend_core.h for a flank without N whose main diagonal mismatches in columns p0 < p1 < p2 (the
+// first k of them, k <= 3; D = k dm): see the head of this file.  W is only ever above 0 in a short run of columns behind a gain,
+// so the columns are walked one by one there and nowhere else; where W = 0 the deletion condition is -tail(x) < T, which depends
+// on the deficit columns alone.
+__device__ bool sift_single_gap_certificate(const SiftSeq& s, const int n, const int tLen, const SiftParams& P, const int k,
+                                            const int p0, const int p1, const int p2) {
+  const int a = P.a, dm = P.dm, D = k * dm;
+  const auto deficits_in = [&](const int lo, const int hi) {  // deficit columns in lo..hi
+    return (int)(k > 0 && p0 >= lo && p0 <= hi) + (int)(k > 1 && p1 >= lo && p1 <= hi) + (int)(k > 2 && p2 >= lo && p2 <= hi);
+  };
+  const auto col = [&](const int i) { return i == 0 ? p0 : (i == 1 ? p1 : p2); };
+  const int dI = (D - P.oIns) / P.eIns, dD = (D - P.oDel) / P.eDel;
+  // the gains of every shift at once: flag d-1 (from the top nibble) of gi[i] is CLEAR when q[p_i + d] == t[p_i], of gd[i] when
+  // t[p_i + d] == q[p_i], d = 1..8 (bases past a flank's end compare as whatever follows it: such a column is never asked for)
+  uint32_t gi[3], gd[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    gi[i] = gd[i] = 0x11111111u;
+    if (i < k) {
+      const int p = col(i);
+      if (dI >= 1) gi[i] = differ(s.q8(p + 1), (uint32_t)s.tn(p) * 0x11111111u);
+      if (dD >= 1) gd[i] = differ(s.t8(p + 1), (uint32_t)s.qn(p) * 0x11111111u);
+    }
+  }
+  const auto gain = [&](const uint32_t g, const int d, const bool ins, const int p) {
+    if (d <= 8) return ((g >> (32 - 4 * d)) & 1u) == 0u;
+    return ins ? s.qn(p + d) == s.tn(p) : s.tn(p + d) == s.qn(p);
+  };
+  // ---- one insertion of d query bases, then the diagonal shifted right by d -------------------------------------------------------
+  for (int d = 1; d <= dI && d < n; ++d) {
+    const int xl = n - 1 - d, T = P.oIns + d * P.eIns;
+    const int tail_main = a * d - dm * deficits_in(xl + 1, n - 1);  // A(n-1) - A(xl)
+    int W = 0, x = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = col(i);
+      if (i < k && p <= xl) {
+        while (W > 0 && x < p) { if (s.qn(x + d) != s.tn(x)) --W; ++x; }  // losses
+        if (gain(gi[i], d, true, p)) {
+          if (dm * (W + 1) >= T) return false;
+          ++W;
+        }
+        x = p + 1;
+      }
+    }
+    while (W > 0 && x <= xl) { if (s.qn(x + d) != s.tn(x)) --W; ++x; }
+    if (dm * W - tail_main > T) return false;  // (W = W(xl): the walk ended at xl, or at 0 before it)
+  }
+  // ---- one deletion of d target bases, then the diagonal shifted down by d --------------------------------------------------------
+  for (int d = 1; d <= dD; ++d) {
+    const int T = P.oDel + d * P.eDel;
+    const int xmax = min(n - 1, tLen - d - 1);  // the columns whose shifted cell exists
+    if (xmax < 0) continue;
+    const auto tail = [&](const int x) {  // A(min(x+d, n-1)) - A(x)
+      const int z = min(x + d, n - 1);
+      return a * (z - x) - dm * deficits_in(x + 1, z);
+    };
+    // where W = 0: -tail(x) < T for every column; -tail rises only where a deficit column enters the tail (x = p - d), and in the
+    // last d columns (the tail gets shorter) up to the last column or the one before a deficit column leaves it
+    if (dm * min(k, d) >= T) {  // (else no window of d columns holds enough deficit)
+      if (-tail(0) >= T || -tail(xmax) >= T) return false;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (i < k) {
+          const int p = col(i);
+          if (p - d >= 0 && p - d <= xmax && -tail(p - d) >= T) return false;
+          if (p - 1 >= 0 && p - 1 <= xmax && -tail(p - 1) >= T) return false;
+        }
+      }
+    }
+    // where W > 0: behind a gain, column by column
+    int W = 0, x = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = col(i);
+      if (i < k && p <= xmax) {
+        while (W > 0 && x < p) {
+          if (s.tn(x + d) != s.qn(x)) --W;
+          if (W > 0 && dm * W - tail(x) >= T) return false;
+          ++x;
+        }
+        if (gain(gd[i], d, false, p)) ++W;
+        if (W > 0 && dm * W - tail(p) >= T) return false;
+        x = p + 1;
+      }
+    }
+    while (W > 0 && x <= xmax) {
+      if (s.tn(x + d) != s.qn(x)) --W;
+      if (W > 0 && dm * W - tail(x) >= T) return false;
+      ++x;
+    }
+  }
+  return true;
+}
+
+// flank_closed_form + flank_start_gap_form of bpsw_extend_core.h for one side, with everything that depends on the start score
+// factored out (hmin, *_rel).  n = qLen (1..127), tLen = the target flank's length; the sequences hold no N.
+__device__ SideRec sift_side(const SiftSeq& s, const int n, const int tLen, const SiftParams& P) {
+  SideRec rec = {SIFT_FAIL, 0, 0, 0, 0, 0, 0, 0};
+  const int a = P.a, dm = P.dm;
+  const int oe_min = min(P.oIns + P.eIns, P.oDel + P.eDel);
+  const bool family = a == 1 && P.eIns == 1 && P.eDel == 1 && P.oIns + P.eIns == P.oDel + P.eDel && oe_min >= 2;
+  // ---- flank_closed_form --------------------------------------------------------------------------------------------------------
+  if (tLen >= n) {
+    const bool two_opens = P.certify >= 2 && family;  // (n <= 128 always here)
+    const int limit = P.certify ? (two_opens ? 2 * oe_min + 2 : 2 * oe_min) : oe_min;
+    int D = 0, best_rel = 0, best_i = -1, k = 0;
+    int p_last = -1, p_prev = -1, p_prev2 = -1;
+    bool open = true;  // the form can still hold
+    for (int j = 0; j < n && open; j += 8) {
+      uint32_t m = differ(s.q8(j), s.t8(j)) & top_nibbles(n - j);
+      while (m) {  // the (very few) diagonal cells that are not a match
+        const int i = __clz((int)m) >> 2;
+        m &= ~(0x10000000u >> (4 * i));
+        const int pos = j + i;
+        const int v = pos * a - D;  // m(pos-1) - h0: the last row before this deficit
+        if (pos >= 1 && v > best_rel) { best_rel = v; best_i = pos - 1; }
+        D += dm;
+        p_prev2 = p_prev; p_prev = p_last; p_last = pos;
+        ++k;
+        if (D >= limit) { open = false; break; }
+      }
+    }
+    if (open && P.zdrop > 0 && D > P.zdrop) open = false;
+    if (open && D >= oe_min && k > 3) {  // (a mismatch score so mild that four deficit columns stay below two gap opens)
+      rec.kind = SIFT_UNSEEN;
+      return rec;
+    }
+    if (open && D >= 2 * oe_min) {  // two gap opens: tests 1 and 2 of flank_closed_form
+      const auto is_match = [&](const int ti, const int qi) {
+        return ti >= 0 && qi >= 0 && ti < tLen && qi < n && s.tn(ti) == s.qn(qi);
+      };
+      for (int L = 2; L <= 2 + (D - 2 * oe_min) && open; ++L) {
+        if (is_match(p_last, p_last + L)) {
+          bool m1 = p_prev < 0, m2 = p_prev2 < 0;
+          for (int sft = 1; sft <= L; ++sft) { m1 = m1 || is_match(p_prev, p_prev + sft); m2 = m2 || is_match(p_prev2, p_prev2 + sft); }
+          if (m1 && m2) open = false;
+        }
+        if (open && is_match(n - 1 + L, n - 1)) {
+          bool m0 = false, m1 = p_prev < 0, m2 = p_prev2 < 0;
+          for (int sft = 1; sft <= L; ++sft) {
+            m0 = m0 || is_match(p_last + sft, p_last); m1 = m1 || is_match(p_prev + sft, p_prev); m2 = m2 || is_match(p_prev2 + sft, p_prev2);
+          }
+          if (m0 && m1 && m2) open = false;
+        }
+      }
+    }
+    if (open && D >= oe_min) {
+      // ascending deficit columns
+      const int q0 = k == 1 ? p_last : (k == 2 ? p_prev : p_prev2), q1 = k == 2 ? p_last : p_prev, q2 = p_last;
+      if (!sift_single_gap_certificate(s, n, tLen, P, k, q0, q1, q2)) open = false;
+    }
+    if (open) {
+      const int g_rel = n * a - D;
+      if (g_rel > best_rel) { best_rel = g_rel; best_i = n - 1; }
+      rec.kind = SIFT_FORM; rec.hmin = D + 1;
+      rec.max_rel = best_rel; rec.g_rel = g_rel; rec.qle = best_i + 1; rec.tle = best_i + 1; rec.gtle = n; rec.max_off = 0;
+      return rec;
+    }
+  }
+  // ---- flank_start_gap_form -----------------------------------------------------------------------------------------------------
+  if (P.certify < 3 || !family) return rec;
+  const int oe = P.oIns + P.eIns;
+  if (P.wBand < 4 || (P.zdrop > 0 && P.zdrop < oe) || n < oe + 3) return rec;
+  bool ins = tLen >= n - 1, del = tLen >= n + 1, del2 = tLen >= n + 2;
+  if (!ins && !del) return rec;
+  // the shifted diagonals: t[j] == q[j+1] (j <= n-2), t[j+1] == q[j], t[j+2] == q[j] (j <= n-1)
+  if (ins) ins = sift_equal_run(s, 0, n - 2, 1, 0);
+  if (del) del = sift_equal_run(s, 0, n - 1, 0, 1);
+  if (!ins && !del) return rec;
+  if (del2) del2 = sift_equal_run(s, 0, n - 1, 0, 2);
+  if (ins && (del || del2)) return rec;
+  // the main diagonal must never get back above h0: S(j) = a(j+1) - dm * (mismatches up to j) <= 0 for every j < min(n, tLen);
+  // S peaks on the last base of a run of matches
+  {
+    const int nt = min(n, tLen);
+    int mm = 0;
+    for (int j = 0; j < nt; j += 8) {
+      uint32_t m = differ(s.q8(j), s.t8(j)) & top_nibbles(nt - j);
+      while (m) {
+        const int i = __clz((int)m) >> 2;
+        m &= ~(0x10000000u >> (4 * i));
+        const int pos = j + i;
+        if (pos * a - dm * mm > 0) return rec;  // S(pos - 1)
+        ++mm;
+      }
+    }
+    if (nt * a - dm * mm > 0) return rec;
+  }
+  if (del) {
+    const int s0 = s.tn(0) == s.qn(0) ? a : a - dm;
+    if (s0 + oe + 1 <= 0) return rec;
+    if (s.tn(0) == s.qn(1) || s.tn(0) == s.qn(2)) return rec;  // n >= 5 here
+    const int g_rel = -oe + a * n;
+    rec.kind = SIFT_FORM; rec.hmin = max(2 * oe + 1, a - s0 + 1);  // h0 >= 2 oe + 1 and h0 + s0 > a
+    rec.max_rel = g_rel; rec.g_rel = g_rel; rec.qle = n; rec.tle = n + 1; rec.gtle = n + 1; rec.max_off = 1;
+    return rec;
+  }
+  const int g_rel = -oe + a * (n - 1);
+  rec.kind = SIFT_FORM; rec.hmin = 2 * oe + 1;
+  rec.max_rel = g_rel; rec.g_rel = g_rel; rec.qle = n; rec.tle = n - 1; rec.gtle = n - 1; rec.max_off = 1;
+  return rec;
+}
+
+__device__ __forceinline__ uint4 pack_rec(const SideRec& r) {
+  return make_uint4(((uint32_t)r.kind & 0xffu) | ((uint32_t)r.hmin << 8), ((uint32_t)r.max_rel & 0xffffu) | ((uint32_t)r.g_rel << 16),
+                    ((uint32_t)r.qle & 0xffffu) | ((uint32_t)r.tle << 16), ((uint32_t)r.gtle & 0xffffu) | ((uint32_t)r.max_off << 16));
+}
+
+// one wavefront per workgroup, 64 consecutive tasks
+__global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict__ wire, const int n_tasks, int16_t* __restrict__ out,
+                                                      const ExtScoring sc, const int dm, const int qmax, uint8_t* __restrict__ flag,
+                                                      uint4* __restrict__ recs) {
+  __shared__ uint32_t raw[SIFT_RAW_WORDS + 4];
+  const int lane = threadIdx.x;
+  const int task = (int)blockIdx.x * 64 + lane;
+  const bool live = task < n_tasks;
+  const uint32_t hdr0 = wire[0], hdr1 = wire[1];
+  SiftParams P;
+  P.oDel = (int8_t)(hdr0 & 0xff); P.eDel = (int8_t)((hdr0 >> 8) & 0xff);
+  P.oIns = (int8_t)((hdr0 >> 16) & 0xff); P.eIns = (int8_t)((hdr0 >> 24) & 0xff);
+  const int penClip5 = (int8_t)(hdr1 & 0xff), penClip3 = (int8_t)((hdr1 >> 8) & 0xff);
+  P.wBand = (int8_t)((hdr1 >> 16) & 0xff);
+  P.zdrop = sc.zdrop; P.certify = sc.certify; P.dm = dm;
+  const int oe_min = min(P.oIns + P.eIns, P.oDel + P.eDel);
+  P.a = (oe_min > 0 && P.wBand >= 2) ? sc.exact_a : 0;
+
+  const uint32_t* rec = wire + 8 + 8 * (size_t)(live ? task : n_tasks - 1);
+  const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4];
+  const int lq = s_lo16(r0), lr = s_hi16(r0), rq = s_lo16(r1), rr = s_hi16(r1);
+  const int pos = (int)rec[2];
+  const int nwords = (lq + lr + rq + rr + 7) >> 3;
+  // the streams of the wave's tasks lie back to back in the batch (MemChainToAlignBatched.scala:125-170 appends them in task order):
+  // one coalesced copy brings them into LDS.  Anything else -- or longer tasks than the buffer holds -- is left to ext_kernel.
+  const int base = uni(pos);
+  const int span = wave_max(pos + nwords) - base;
+  const bool fits = __builtin_amdgcn_ballot_w64(pos < base) == 0ull && span <= SIFT_RAW_WORDS;
+  if (P.a <= 0 || !fits) {
+    if (live) flag[task] = 0;
+    return;
+  }
+  uint32_t n_codes = 0u;  // codes above 3 (N) anywhere in the wave's streams?  (mostly none: then no lane looks for them again)
+  {
+    const uint32_t* __restrict__ src = wire + (size_t)base;
+    int i = lane;
+    for (; i + 192 < span; i += 256) {  // four loads in flight per lane
+      const uint32_t v0 = src[i], v1 = src[i + 64], v2 = src[i + 128], v3 = src[i + 192];
+      raw[i] = v0; raw[i + 64] = v1; raw[i + 128] = v2; raw[i + 192] = v3;
+      n_codes |= (v0 | v1 | v2 | v3) & 0xCCCCCCCCu;
+    }
+    for (; i < span; i += 64) { const uint32_t v = src[i]; raw[i] = v; n_codes |= v & 0xCCCCCCCCu; }
+  }
+  const bool any_n = __builtin_amdgcn_ballot_w64(n_codes != 0u) != 0ull;
+  if (lane < 4) raw[span + lane] = 0u;
+  __syncthreads();
+  if (!live) return;
+  if (lq > qmax || rq > qmax) {  // not a task the 48-VGPR build of ext_kernel takes
+    flag[task] = 0;
+    return;
+  }
+  const int regScore0 = s_lo16(r3), qBeg = s_hi16(r3), h0 = s_lo16(r4);
+  const int idx = (int)rec[7];
+
+  const auto judge = [&](const int side) {
+    const int qLen = side ? rq : lq, rLen = side ? rr : lr;
+    SideRec r = {SIFT_UNSEEN, 0, 0, 0, 0, 0, 0, 0};
+    if (qLen <= 0) return r;
+    const SiftSeq s = {raw + (pos - base), side ? lq : 0, side ? lq + rq + lr : lq + rq};
+    if (any_n) {  // a code above 3 (N) anywhere in the two flanks: the side is left to ext_kernel
+      uint32_t n_seen = 0u;
+      for (int j = 0; j < qLen; j += 8) n_seen |= s.q8(j) & top_nibbles(qLen - j) & 0xCCCCCCCCu;
+      for (int j = 0; j < rLen; j += 8) n_seen |= s.t8(j) & top_nibbles(rLen - j) & 0xCCCCCCCCu;
+      if (n_seen) return r;
+    }
+    return sift_side(s, qLen, rLen, P);
+  };
+  const SideRec sr0 = judge(0), sr1 = judge(1);
+
+  // extension(), MemChainToAlignBatched.scala:789-883, for sides that are resolved (as ext_kernel chains them)
+  int regScore = regScore0;
+  int outQBeg = 0, outRBeg = 0, outQEnd = rq, outREnd = 0, trueScore = regScore0, score = -1;
+  bool done = true;
+  const auto chain = [&](const int side, const SideRec& r) {
+    const int qLen = side ? rq : lq;
+    if (qLen <= 0 || !done) return;
+    const int hInit = side ? regScore : h0;
+    if (r.kind != SIFT_FORM || hInit < r.hmin) { done = false; return; }
+    const int penClip = side ? penClip3 : penClip5;
+    const int sc0 = regScore;
+    const int rmax = hInit + r.max_rel, gscore = hInit + r.g_rel;
+    regScore = rmax;
+    score = regScore;
+    const bool local = gscore <= 0 || gscore <= regScore - penClip;
+    if (side == 0) {
+      outQBeg = local ? qBeg - r.qle : 0;
+      outRBeg = local ? -r.tle : -r.gtle;
+      trueScore = local ? regScore : gscore;
+    } else {
+      outQEnd = local ? r.qle : rq;
+      outREnd = local ? r.tle : r.gtle;
+      trueScore += (local ? regScore : gscore) - sc0;
+    }
+  };
+  chain(0, sr0);
+  chain(1, sr1);
+  if (done) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)sc.out_stride * (size_t)task);
+    o[0] = (uint32_t)idx;
+    o[1] = ((uint32_t)outQBeg & 0xffffu) | ((uint32_t)outQEnd << 16);
+    o[2] = ((uint32_t)outRBeg & 0xffffu) | ((uint32_t)outREnd << 16);
+    o[3] = ((uint32_t)score & 0xffffu) | ((uint32_t)trueScore << 16);
+    o[4] = (uint32_t)P.wBand & 0xffffu;
+    if (sc.side_how) {
+      if (lq > 0) sc.side_how[2 * (size_t)task] = 1;
+      if (rq > 0) sc.side_how[2 * (size_t)task + 1] = 1;
+    }
+    flag[task] = 1;
+    return;
+  }
+  // a form that did not hold for the start score this kernel could see is judged again by ext_kernel (another form may hold)
+  recs[2 * (size_t)task] = pack_rec(sr0);
+  recs[2 * (size_t)task + 1] = pack_rec(sr1);
+  flag[task] = 2;
+}
+
+}  // namespace
+
+hipError_t launch_ext_sift_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int dm, int qmax,
+                                  uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev) {
+  if (n_tasks <= 0) return hipSuccess;
+  const int blocks = (n_tasks + 63) / 64;
+  BPSW_LAUNCH(kev, ext_sift_kernel, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs);
+  return hipGetLastError();
+}
+
+}  // namespace bpsw

@@ -120,6 +120,15 @@ int exact_match_score(const int8_t mat[25]) {
 // The exact shortcuts of the extension (bpsw_extend_core.h) as the context's mask allows them: bit 0 closed form for near-exact
 // flanks, 1 single-gap certificate, 2 two gap opens, 3 one-base gap at the start of a flank, 4 tail-row bound; the environment
 // switches (BPSW_EXT_EXACT / CERT / CERT2 / GAP1 / TAIL = 0) and the scoring matrix can only take shortcuts away.
+int sift_uniform_dm(const int8_t mat[25], int exact_a) {
+  if (exact_a <= 0) return 0;
+  const int mm = mat[1];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (i != j && mat[5 * i + j] != mm) return 0;
+  return exact_a - mm > 0 ? exact_a - mm : 0;
+}
+
 void apply_shortcuts(int mask, const int8_t mat[25], int* exact_a, int* certify, int* tail_bound) {
   *exact_a = (mask & 1) ? exact_match_score(mat) : 0;
   int lvl = *exact_a > 0 ? certify_level(mat) : 0;
@@ -389,7 +398,7 @@ void bpsw_destroy(bpsw_ctx_t* c) {
   if (c->pend_sw.active && c->pend_sw.s) (void)hipStreamSynchronize(c->pend_sw.s);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
-  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release(); c->d_quad.release();
+  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release(); c->d_quad.release(); c->d_sift.release();
   c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();
   rescue_scratch_free(c->rescue_scratch);
   for (int i = 0; i < 8; ++i)
@@ -403,7 +412,7 @@ int bpsw_device_of(const bpsw_ctx_t* c) { return c ? c->device : -1; }
 int bpsw_set_ext_shortcuts(bpsw_ctx_t* c, int mask) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
   std::lock_guard<std::mutex> g(c->mu);
-  c->shortcut_mask = mask < 0 ? 31 : (mask & 31);
+  c->shortcut_mask = mask < 0 ? 63 : (mask & 63);
   apply_shortcuts(c->shortcut_mask, c->ext_mat, &c->ext_sc.exact_a, &c->ext_sc.certify, &c->ext_sc.tail_bound);
   return BPSW_OK;
 }
@@ -596,6 +605,13 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     quad_fresh = true;  // cleared on the launch stream, in front of ext_kernel (a hipMemset on the null stream is not ordered with it)
   }
   const size_t quad_carry_off = (size_t)c->quad_cap_n;
+  // The sift kernel in front of the 48-VGPR build for flanks up to 127 bases (bpsw_extend_sift.hip): format-1 batches whose matrix
+  // has one mismatch score.  BPSW_EXT_SIFT=0 switches it off (A/B runs).
+  static const bool sift_on = !(getenv("BPSW_EXT_SIFT") && atoi(getenv("BPSW_EXT_SIFT")) == 0);
+  const int sift_dm = sift_uniform_dm(c->ext_mat, c->ext_sc.exact_a);
+  const bool use_sift = sift_on && (c->shortcut_mask & 32) && use_short && !any_mid && !coord && !use_quad && sift_dm > 0;
+  const size_t sift_rec_off = ((size_t)n + 15) & ~(size_t)15;
+  if (use_sift) HIP_TRY(c->d_sift.reserve(sift_rec_off + 32 * (size_t)n));
   const bool staged = wire == (const uint8_t*)c->h_stage_in.ptr;
   if (staged && stage_bytes > c->h_stage_in.cap) return fail(BPSW_ERR_ARG, "extend_commit: the staged batch is larger than what bpsw_extend_stage was asked for");
   HIP_TRY(c->h_stage_in.reserve(stage_bytes));
@@ -640,8 +656,15 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         uint4* d_qcarry = use_quad ? (uint4*)((char*)c->d_quad.ptr + quad_carry_off) : nullptr;
         // the flags are zero when ext_kernel starts: the quad kernel leaves them so, a new buffer is cleared here
         if (quad_fresh) HIP_TRY(hipMemsetAsync(c->d_quad.ptr, 0, c->d_quad.cap, s));
+        uint8_t* d_sflag = use_sift ? (uint8_t*)c->d_sift.ptr : nullptr;
+        uint4* d_srecs = use_sift ? (uint4*)((char*)c->d_sift.ptr + sift_rec_off) : nullptr;
+        if (use_sift) {  // the kernel time of the call starts with it
+          KernelEvents sev;
+          sev.start = kev.start; kev.start = nullptr;
+          HIP_TRY(launch_ext_sift_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, sift_dm, 127, d_sflag, d_srecs, s, sev));
+        }
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 255), mr_short, c->num_cu, d_queue, nullptr, s,
-                                  nullptr, false, kev, true, d_list, any_mid ? 255 : 127, d_quad, d_qcarry, 128));
+                                  nullptr, false, kev, true, d_list, any_mid ? 255 : 127, d_quad, d_qcarry, 128, d_sflag, d_srecs));
         if (use_quad) {
           // behind it on the stream: the flanks it handed over (how many, only the device knows: a third of the tasks sizes the grid)
           KernelEvents qev;

@@ -81,7 +81,8 @@ int bpsw_set_ext_scoring(bpsw_ctx_t *ctx, const int8_t mat[25], int zdrop, int z
 
 /* Which of the kernel's EXACT shortcuts may replace the DP of an extension flank (results are identical either
  * way, this is an A/B and test switch): bit 0 closed form for near-exact flanks, bit 1 single-gap certificate, bit 2 its
- * two-gap-open extension, bit 3 one-base gap at the start of a flank, bit 4 tail-row bound.  mask < 0 or 31: all (default).
+ * two-gap-open extension, bit 3 one-base gap at the start of a flank, bit 4 tail-row bound, bit 5 evaluate those forms in the
+ * one-task-per-lane sift kernel in front of the extension kernel (where, not which).  mask < 0 or 63: all (default).
  * Applies to bpsw_extend_batch* and bpsw_chain2aln_batch on this context. */
 int bpsw_set_ext_shortcuts(bpsw_ctx_t *ctx, int mask);
 

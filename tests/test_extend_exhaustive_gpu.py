@@ -40,8 +40,8 @@ def _mat(b, nscore):
 
 SCORINGS = [(po.default_mat(), 6), (_mat(1, -1), 1), (_mat(2, -3), 3), (_mat(6, -1), 2)]   # (matrix, gap open); gap extension 1
 ZDROPS = [(100, po.ZDROP_SCALA), (3, po.ZDROP_SCALA), (3, po.ZDROP_BWA)]
-LEVELS_FULL = 31
-LEVELS_REDUCED = [0, 1, 1 | 16, 1 | 2 | 16, 1 | 2 | 4 | 16]   # pure DP; closed form only; + tail bound; + certificate; + two gap opens (no start-gap form)
+LEVELS_FULL = 63
+LEVELS_REDUCED = [0, 1, 1 | 16, 1 | 2 | 16, 1 | 2 | 4 | 16, 31, 1 | 32, 1 | 2 | 4 | 16 | 32]   # pure DP; closed form only; + tail bound; + certificate; + two gap opens (no start-gap form); all forms in ext_kernel alone; the sift kernel at two levels
 
 
 def test_every_short_flank_at_every_shortcut_level():

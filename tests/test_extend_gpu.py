@@ -351,3 +351,48 @@ def test_launch_plans_of_the_split_kernel(ctx, orc, mid_share, w):
     soa.w = w
     for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
         _check(ctx, orc, soa, zmode=zmode)
+
+
+@pytest.mark.parametrize("sub,indel,n_rate", [(0.005, 0.0005, 0.0), (0.01, 0.001, 0.0), (0.02, 0.004, 0.002), (0.05, 0.01, 0.0)])
+def test_sift_kernel_changes_where_the_shortcuts_run_not_what_they_decide(ctx, orc, sub, indel, n_rate):
+    """csrc/bpsw_extend_sift.hip evaluates the exact shortcuts one task per lane in front of ext_kernel (bit 5 of
+    bpsw_set_ext_shortcuts): results AND the per-side verdicts (shortcut / DP swept) equal those of ext_kernel alone, at every
+    certificate level; tasks with N bases, empty sides, flanks above the sift's 127 bases and custom gap costs ride along"""
+    rng = np.random.default_rng(int(sub * 1e4) + 5)
+    soa = synth.ext_tasks(6000, read_len=150, sub_rate=sub, indel_rate=indel, seed=900 + int(sub * 1e4))
+    if n_rate:
+        pool = soa.pool.copy()
+        pool[rng.random(pool.size) < n_rate] = 4
+        soa.pool = pool
+    wire = bpsw_hip.wire_pack(soa)
+    want, _ = orc.wire_extend(wire)
+    try:
+        for level in (1, 1 | 2, 1 | 2 | 4, 31):
+            ctx.set_ext_shortcuts(level)
+            out0, how0 = ctx.extend_batch_classify(wire)
+            ctx.set_ext_shortcuts(level | 32)
+            out1, how1 = ctx.extend_batch_classify(wire)
+            assert np.array_equal(out0, want) and np.array_equal(out1, want), level
+            assert np.array_equal(how0, how1), level
+        assert sub > 0.02 or (how1 == 1).sum() > 0.3 * (how1 != 0).sum()      # the batch does exercise the forms
+    finally:
+        ctx.set_ext_shortcuts(-1)
+    # other gap costs / a matrix with another mismatch score (dm = 4) / one with two mismatch scores (no sift: same results)
+    for (mat, o, e) in ((po.default_mat(), 4, 2), (_uniform_mat(1, 3), 5, 1), (_two_score_mat(), 6, 1)):
+        soa.o_del = soa.o_ins = o
+        soa.e_del = soa.e_ins = e
+        _check(ctx, orc, soa, mat=mat)
+
+
+def _uniform_mat(a, b):
+    m = np.full((5, 5), -1, np.int8)
+    m[:4, :4] = -b
+    for i in range(4):
+        m[i, i] = a
+    return m.reshape(-1)
+
+
+def _two_score_mat():
+    m = _uniform_mat(1, 4).reshape(5, 5)
+    m[0, 2] = m[2, 0] = -2      # transitions cheaper than transversions
+    return m.reshape(-1)

@@ -110,6 +110,9 @@ def run(rounds=20, per=4000, time_limit=None, log=print):
     after `time_limit` seconds.  Returns (task runs compared, differences).  tests/test_soak_gpu.py runs a one-minute slice."""
     import time
     ctx, orc = bpsw_hip.Context(0), po.Oracle()
+    # the same forms evaluated by ext_kernel alone (no sift kernel, csrc/bpsw_extend_sift.hip): the verdicts per side must agree
+    ctx_wave = bpsw_hip.Context(0)
+    ctx_wave.set_ext_shortcuts(31)
     t_start = time.time()
     total = bad_total = 0
     for rd in range(rounds):
@@ -132,16 +135,21 @@ def run(rounds=20, per=4000, time_limit=None, log=print):
             for zmode, zdrop in ((0, 100), (1, 100), (1, 16), (0, 0)):
                 mat = MATS[(rd + zmode + zdrop) % len(MATS)]
                 ctx.set_ext_scoring(mat, zdrop, zmode)
-                got = ctx.extend_batch(wire).reshape(-1, 10)
+                got, how = ctx.extend_batch_classify(wire)
+                got = got.reshape(-1, 10)
+                ctx_wave.set_ext_scoring(mat, zdrop, zmode)
+                got_w, how_w = ctx_wave.extend_batch_classify(wire)
                 want, _ = orc.wire_extend(wire, mat, zdrop, zmode)
                 want = want.reshape(-1, 10)
-                bad = np.nonzero((got != want).any(axis=1))[0]
+                bad = np.nonzero((got != want).any(axis=1) | (got_w.reshape(-1, 10) != want).any(axis=1) | (how != how_w).any(axis=1))[0]
                 total += soa.n
                 if bad.size:
                     bad_total += bad.size
-                    log(f"round {rd} gaps {(od, ed, oi, ei)} w {w} z {zmode}/{zdrop}: {bad.size} differ; task {bad[0]} got {got[bad[0]]} want {want[bad[0]]}")
+                    log(f"round {rd} gaps {(od, ed, oi, ei)} w {w} z {zmode}/{zdrop}: {bad.size} differ; task {bad[0]} got {got[bad[0]]} want {want[bad[0]]} "
+                        f"verdicts with / without the sift kernel {how[bad[0]]} / {how_w[bad[0]]}")
         log(f"round {rd} tasks so far {total} bad {bad_total}")
     ctx.close()
+    ctx_wave.close()
     return total, bad_total
 
 
