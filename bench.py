@@ -292,8 +292,7 @@ def coordinate_batches_breakdown(W, cfg_no, rank, F, fd, wires, groups, structs,
     reps = max(2, passes // 2)
     F.run(items)                       # warm-up pass
     t0 = time.perf_counter()
-    for _ in range(reps):
-        F.run(items)
+    F.run(items, reps)
     dt = time.perf_counter() - t0
     # a sample of these outputs against the oracle on the byte form of the same tasks
     orc = po.Oracle()
@@ -477,14 +476,16 @@ def main():
         torch.cuda.synchronize(dev)
 
     passes = W["passes"]
-    for _ in range(args.warmup * passes):
-        F.run(items)
+    if args.warmup > 0:
+        F.run(items, args.warmup * passes)
     F.reset_stats()
     barrier()
     cpu0 = os.times()
     t0 = time.perf_counter()
-    for _ in range(args.steps * passes):
-        F.run(items)                 # every call of the pass complete, results in host memory
+    # the K steps in one go: the feeder threads go round the passes without waiting for each other, as the task threads of an
+    # executor would (rounds 1-2 put a barrier behind every pass -- with configs[1]'s 32 batches per pass on 32 threads every pass
+    # was one burst of calls, all staging and copying at once, and the device sat idle between bursts: DESIGN.md 5.2)
+    F.run(items, args.steps * passes)   # every call complete, results in host memory
     barrier()
     elapsed = time.perf_counter() - t0
     cpu1 = os.times()

@@ -24,6 +24,7 @@ class Feeder:
         self.syn.bpsw_feeder_create.restype = C.c_void_p
         self.syn.bpsw_feeder_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         self.syn.bpsw_feeder_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.syn.bpsw_feeder_run_repeats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         self.syn.bpsw_feeder_destroy.argtypes = [C.c_void_p]
         self.syn.bpsw_feeder_destroy.restype = None
         self.ctxs = [Context(device) for _ in range(n_threads)]
@@ -38,9 +39,10 @@ class Feeder:
             raise BpswError("bpsw_feeder_create failed")
         self.n_threads = n_threads
 
-    def run(self, items) -> None:
-        """items: a ctypes array of FeedItem (make_items); every item is run once, the call returns when all are done"""
-        rc = self.syn.bpsw_feeder_run(self.h, items, len(items))
+    def run(self, items, repeats: int = 1) -> None:
+        """items: a ctypes array of FeedItem (make_items); every item is run `repeats` times -- the threads go round the items
+        without a barrier between the rounds, never two calls on one item at a time -- the call returns when all are done"""
+        rc = self.syn.bpsw_feeder_run_repeats(self.h, items, len(items), int(repeats))
         if rc != 0:
             raise BpswError(f"a feeder call failed with code {rc}")
 

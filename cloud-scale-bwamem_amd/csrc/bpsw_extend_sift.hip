@@ -84,36 +84,21 @@ __device__ __forceinline__ bool sift_equal_run(const SiftSeq& s, const int lo, c
   return sift_count_differ(s, lo, hi, dq, dt, 1) == 0;
 }
 
-// single_gap_certificate of bpsw_extend_core.h for a flank without N whose main diagonal mismatches in columns p0 < p1 < p2 (the
-// first k of them, k <= 3; D = k dm): see the head of this file.  W is only ever above 0 in a short run of columns behind a gain,
-// so the columns are walked one by one there and nowhere else; where W = 0 the deletion condition is -tail(x) < T, which depends
-// on the deficit columns alone.
-__device__ bool sift_single_gap_certificate(const SiftSeq& s, const int n, const int tLen, const SiftParams& P, const int k,
-                                            const int p0, const int p1, const int p2) {
-  const int a = P.a, dm = P.dm, D = k * dm;
+// One shift of single_gap_certificate (bpsw_extend_core.h) for a flank without N whose main diagonal mismatches in columns
+// p0 < p1 < p2 (the first k of them, k <= 3; D = k dm): see the head of this file.  `ins`: one insertion of d query bases, then the
+// diagonal shifted right by d; else one deletion of d target bases, then the diagonal shifted down by d.  W is only ever above 0 in
+// a short run of columns behind a gain, so the columns are walked one by one there and nowhere else; where W = 0 the deletion
+// condition is -tail(x) < T, which depends on the deficit columns alone.  The shifts of a flank are independent: the kernel spreads
+// (flank, shift) pairs over the lanes of the wavefront.
+__device__ bool sift_certificate_shift(const SiftSeq& s, const int n, const int tLen, const SiftParams& P, const int k, const int p0,
+                                       const int p1, const int p2, const bool ins, const int d) {
+  const int a = P.a, dm = P.dm;
   const auto deficits_in = [&](const int lo, const int hi) {  // deficit columns in lo..hi
     return (int)(k > 0 && p0 >= lo && p0 <= hi) + (int)(k > 1 && p1 >= lo && p1 <= hi) + (int)(k > 2 && p2 >= lo && p2 <= hi);
   };
   const auto col = [&](const int i) { return i == 0 ? p0 : (i == 1 ? p1 : p2); };
-  const int dI = (D - P.oIns) / P.eIns, dD = (D - P.oDel) / P.eDel;
-  // the gains of every shift at once: flag d-1 (from the top nibble) of gi[i] is CLEAR when q[p_i + d] == t[p_i], of gd[i] when
-  // t[p_i + d] == q[p_i], d = 1..8 (bases past a flank's end compare as whatever follows it: such a column is never asked for)
-  uint32_t gi[3], gd[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    gi[i] = gd[i] = 0x11111111u;
-    if (i < k) {
-      const int p = col(i);
-      if (dI >= 1) gi[i] = differ(s.q8(p + 1), (uint32_t)s.tn(p) * 0x11111111u);
-      if (dD >= 1) gd[i] = differ(s.t8(p + 1), (uint32_t)s.qn(p) * 0x11111111u);
-    }
-  }
-  const auto gain = [&](const uint32_t g, const int d, const bool ins, const int p) {
-    if (d <= 8) return ((g >> (32 - 4 * d)) & 1u) == 0u;
-    return ins ? s.qn(p + d) == s.tn(p) : s.tn(p + d) == s.qn(p);
-  };
-  // ---- one insertion of d query bases, then the diagonal shifted right by d -------------------------------------------------------
-  for (int d = 1; d <= dI && d < n; ++d) {
+  if (ins) {
+    if (d >= n) return true;
     const int xl = n - 1 - d, T = P.oIns + d * P.eIns;
     const int tail_main = a * d - dm * deficits_in(xl + 1, n - 1);  // A(n-1) - A(xl)
     int W = 0, x = 0;
@@ -122,7 +107,7 @@ __device__ bool sift_single_gap_certificate(const SiftSeq& s, const int n, const
       const int p = col(i);
       if (i < k && p <= xl) {
         while (W > 0 && x < p) { if (s.qn(x + d) != s.tn(x)) --W; ++x; }  // losses
-        if (gain(gi[i], d, true, p)) {
+        if (s.qn(p + d) == s.tn(p)) {                                      // a gain
           if (dm * (W + 1) >= T) return false;
           ++W;
         }
@@ -130,132 +115,132 @@ __device__ bool sift_single_gap_certificate(const SiftSeq& s, const int n, const
       }
     }
     while (W > 0 && x <= xl) { if (s.qn(x + d) != s.tn(x)) --W; ++x; }
-    if (dm * W - tail_main > T) return false;  // (W = W(xl): the walk ended at xl, or at 0 before it)
+    return dm * W - tail_main <= T;  // (W = W(xl): the walk ended at xl, or at 0 before it)
   }
-  // ---- one deletion of d target bases, then the diagonal shifted down by d --------------------------------------------------------
-  for (int d = 1; d <= dD; ++d) {
-    const int T = P.oDel + d * P.eDel;
-    const int xmax = min(n - 1, tLen - d - 1);  // the columns whose shifted cell exists
-    if (xmax < 0) continue;
-    const auto tail = [&](const int x) {  // A(min(x+d, n-1)) - A(x)
-      const int z = min(x + d, n - 1);
-      return a * (z - x) - dm * deficits_in(x + 1, z);
-    };
-    // where W = 0: -tail(x) < T for every column; -tail rises only where a deficit column enters the tail (x = p - d), and in the
-    // last d columns (the tail gets shorter) up to the last column or the one before a deficit column leaves it
-    if (dm * min(k, d) >= T) {  // (else no window of d columns holds enough deficit)
-      if (-tail(0) >= T || -tail(xmax) >= T) return false;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        if (i < k) {
-          const int p = col(i);
-          if (p - d >= 0 && p - d <= xmax && -tail(p - d) >= T) return false;
-          if (p - 1 >= 0 && p - 1 <= xmax && -tail(p - 1) >= T) return false;
-        }
-      }
-    }
-    // where W > 0: behind a gain, column by column
-    int W = 0, x = 0;
+  const int T = P.oDel + d * P.eDel;
+  const int xmax = min(n - 1, tLen - d - 1);  // the columns whose shifted cell exists
+  if (xmax < 0) return true;
+  const auto tail = [&](const int x) {  // A(min(x+d, n-1)) - A(x)
+    const int z = min(x + d, n - 1);
+    return a * (z - x) - dm * deficits_in(x + 1, z);
+  };
+  // where W = 0: -tail(x) < T for every column; -tail rises only where a deficit column enters the tail (x = p - d), and in the
+  // last d columns (the tail gets shorter) up to the last column or the one before a deficit column leaves it
+  if (dm * min(k, d) >= T) {  // (else no window of d columns holds enough deficit)
+    if (-tail(0) >= T || -tail(xmax) >= T) return false;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int p = col(i);
-      if (i < k && p <= xmax) {
-        while (W > 0 && x < p) {
-          if (s.tn(x + d) != s.qn(x)) --W;
-          if (W > 0 && dm * W - tail(x) >= T) return false;
-          ++x;
-        }
-        if (gain(gd[i], d, false, p)) ++W;
-        if (W > 0 && dm * W - tail(p) >= T) return false;
-        x = p + 1;
+      if (i < k) {
+        const int p = col(i);
+        if (p - d >= 0 && p - d <= xmax && -tail(p - d) >= T) return false;
+        if (p - 1 >= 0 && p - 1 <= xmax && -tail(p - 1) >= T) return false;
       }
     }
-    while (W > 0 && x <= xmax) {
-      if (s.tn(x + d) != s.qn(x)) --W;
-      if (W > 0 && dm * W - tail(x) >= T) return false;
-      ++x;
+  }
+  // where W > 0: behind a gain, column by column
+  int W = 0, x = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p = col(i);
+    if (i < k && p <= xmax) {
+      while (W > 0 && x < p) {
+        if (s.tn(x + d) != s.qn(x)) --W;
+        if (W > 0 && dm * W - tail(x) >= T) return false;
+        ++x;
+      }
+      if (s.tn(p + d) == s.qn(p)) ++W;
+      if (W > 0 && dm * W - tail(p) >= T) return false;
+      x = p + 1;
     }
+  }
+  while (W > 0 && x <= xmax) {
+    if (s.tn(x + d) != s.qn(x)) --W;
+    if (W > 0 && dm * W - tail(x) >= T) return false;
+    ++x;
   }
   return true;
 }
 
-// flank_closed_form + flank_start_gap_form of bpsw_extend_core.h for one side, with everything that depends on the start score
-// factored out (hmin, *_rel).  n = qLen (1..127), tLen = the target flank's length; the sequences hold no N.
-__device__ SideRec sift_side(const SiftSeq& s, const int n, const int tLen, const SiftParams& P) {
-  SideRec rec = {SIFT_FAIL, 0, 0, 0, 0, 0, 0, 0};
+enum { CF_HOLDS = 0, CF_IF_CERTIFIED = 1, CF_FAILS = 2, CF_UNSEEN = 3 };
+constexpr int SIFT_MAX_SHIFTS = 16;  // shifts per direction the certificate lanes take (default scoring: 9); more: left to ext_kernel
+
+// flank_closed_form of bpsw_extend_core.h for one side up to its certificate, with everything that depends on the start score
+// factored out (hmin, *_rel).  n = qLen (1..127), tLen = the target flank's length; the sequences hold no N.  CF_IF_CERTIFIED: `rec`
+// is the result provided every shift 1..dI (insertion) and 1..dD (deletion) passes sift_certificate_shift for the deficit columns
+// p[0..k).
+__device__ int sift_closed_form(const SiftSeq& s, const int n, const int tLen, const SiftParams& P, SideRec* rec, int* k_out, int* p,
+                                int* dI, int* dD) {
+  if (tLen < n) return CF_FAILS;
   const int a = P.a, dm = P.dm;
   const int oe_min = min(P.oIns + P.eIns, P.oDel + P.eDel);
   const bool family = a == 1 && P.eIns == 1 && P.eDel == 1 && P.oIns + P.eIns == P.oDel + P.eDel && oe_min >= 2;
-  // ---- flank_closed_form --------------------------------------------------------------------------------------------------------
-  if (tLen >= n) {
-    const bool two_opens = P.certify >= 2 && family;  // (n <= 128 always here)
-    const int limit = P.certify ? (two_opens ? 2 * oe_min + 2 : 2 * oe_min) : oe_min;
-    int D = 0, best_rel = 0, best_i = -1, k = 0;
-    int p_last = -1, p_prev = -1, p_prev2 = -1;
-    bool open = true;  // the form can still hold
-    for (int j = 0; j < n && open; j += 8) {
-      uint32_t m = differ(s.q8(j), s.t8(j)) & top_nibbles(n - j);
-      while (m) {  // the (very few) diagonal cells that are not a match
-        const int i = __clz((int)m) >> 2;
-        m &= ~(0x10000000u >> (4 * i));
-        const int pos = j + i;
-        const int v = pos * a - D;  // m(pos-1) - h0: the last row before this deficit
-        if (pos >= 1 && v > best_rel) { best_rel = v; best_i = pos - 1; }
-        D += dm;
-        p_prev2 = p_prev; p_prev = p_last; p_last = pos;
-        ++k;
-        if (D >= limit) { open = false; break; }
-      }
-    }
-    if (open && P.zdrop > 0 && D > P.zdrop) open = false;
-    if (open && D >= oe_min && k > 3) {  // (a mismatch score so mild that four deficit columns stay below two gap opens)
-      rec.kind = SIFT_UNSEEN;
-      return rec;
-    }
-    if (open && D >= 2 * oe_min) {  // two gap opens: tests 1 and 2 of flank_closed_form
-      const auto is_match = [&](const int ti, const int qi) {
-        return ti >= 0 && qi >= 0 && ti < tLen && qi < n && s.tn(ti) == s.qn(qi);
-      };
-      for (int L = 2; L <= 2 + (D - 2 * oe_min) && open; ++L) {
-        if (is_match(p_last, p_last + L)) {
-          bool m1 = p_prev < 0, m2 = p_prev2 < 0;
-          for (int sft = 1; sft <= L; ++sft) { m1 = m1 || is_match(p_prev, p_prev + sft); m2 = m2 || is_match(p_prev2, p_prev2 + sft); }
-          if (m1 && m2) open = false;
-        }
-        if (open && is_match(n - 1 + L, n - 1)) {
-          bool m0 = false, m1 = p_prev < 0, m2 = p_prev2 < 0;
-          for (int sft = 1; sft <= L; ++sft) {
-            m0 = m0 || is_match(p_last + sft, p_last); m1 = m1 || is_match(p_prev + sft, p_prev); m2 = m2 || is_match(p_prev2 + sft, p_prev2);
-          }
-          if (m0 && m1 && m2) open = false;
-        }
-      }
-    }
-    if (open && D >= oe_min) {
-      // ascending deficit columns
-      const int q0 = k == 1 ? p_last : (k == 2 ? p_prev : p_prev2), q1 = k == 2 ? p_last : p_prev, q2 = p_last;
-      if (!sift_single_gap_certificate(s, n, tLen, P, k, q0, q1, q2)) open = false;
-    }
-    if (open) {
-      const int g_rel = n * a - D;
-      if (g_rel > best_rel) { best_rel = g_rel; best_i = n - 1; }
-      rec.kind = SIFT_FORM; rec.hmin = D + 1;
-      rec.max_rel = best_rel; rec.g_rel = g_rel; rec.qle = best_i + 1; rec.tle = best_i + 1; rec.gtle = n; rec.max_off = 0;
-      return rec;
+  const bool two_opens = P.certify >= 2 && family;  // (n <= 128 always here)
+  const int limit = P.certify ? (two_opens ? 2 * oe_min + 2 : 2 * oe_min) : oe_min;
+  int D = 0, best_rel = 0, best_i = -1, k = 0;
+  int p_last = -1, p_prev = -1, p_prev2 = -1;
+  for (int j = 0; j < n; j += 8) {
+    uint32_t m = differ(s.q8(j), s.t8(j)) & top_nibbles(n - j);
+    while (m) {  // the (very few) diagonal cells that are not a match
+      const int i = __clz((int)m) >> 2;
+      m &= ~(0x10000000u >> (4 * i));
+      const int pos = j + i;
+      const int v = pos * a - D;  // m(pos-1) - h0: the last row before this deficit
+      if (pos >= 1 && v > best_rel) { best_rel = v; best_i = pos - 1; }
+      D += dm;
+      p_prev2 = p_prev; p_prev = p_last; p_last = pos;
+      ++k;
+      if (D >= limit) return CF_FAILS;
     }
   }
-  // ---- flank_start_gap_form -----------------------------------------------------------------------------------------------------
-  if (P.certify < 3 || !family) return rec;
+  if (P.zdrop > 0 && D > P.zdrop) return CF_FAILS;
+  *dI = D >= oe_min ? max(0, (D - P.oIns) / P.eIns) : 0;  // (a deficit below the dearer of the two gap opens: no shift of that kind)
+  *dD = D >= oe_min ? max(0, (D - P.oDel) / P.eDel) : 0;
+  // (a mismatch score so mild that four deficit columns stay below two gap opens, or gap costs that ask for very long shifts)
+  if (D >= oe_min && (k > 3 || *dI > SIFT_MAX_SHIFTS || *dD > SIFT_MAX_SHIFTS)) return CF_UNSEEN;
+  if (D >= 2 * oe_min) {  // two gap opens: tests 1 and 2 of flank_closed_form
+    const auto is_match = [&](const int ti, const int qi) {
+      return ti >= 0 && qi >= 0 && ti < tLen && qi < n && s.tn(ti) == s.qn(qi);
+    };
+    for (int L = 2; L <= 2 + (D - 2 * oe_min); ++L) {
+      if (is_match(p_last, p_last + L)) {
+        bool m1 = p_prev < 0, m2 = p_prev2 < 0;
+        for (int sft = 1; sft <= L; ++sft) { m1 = m1 || is_match(p_prev, p_prev + sft); m2 = m2 || is_match(p_prev2, p_prev2 + sft); }
+        if (m1 && m2) return CF_FAILS;
+      }
+      if (is_match(n - 1 + L, n - 1)) {
+        bool m0 = false, m1 = p_prev < 0, m2 = p_prev2 < 0;
+        for (int sft = 1; sft <= L; ++sft) {
+          m0 = m0 || is_match(p_last + sft, p_last); m1 = m1 || is_match(p_prev + sft, p_prev); m2 = m2 || is_match(p_prev2 + sft, p_prev2);
+        }
+        if (m0 && m1 && m2) return CF_FAILS;
+      }
+    }
+  }
+  const int g_rel = n * a - D;
+  if (g_rel > best_rel) { best_rel = g_rel; best_i = n - 1; }
+  rec->kind = SIFT_FORM; rec->hmin = D + 1;
+  rec->max_rel = best_rel; rec->g_rel = g_rel; rec->qle = best_i + 1; rec->tle = best_i + 1; rec->gtle = n; rec->max_off = 0;
+  if (D < oe_min) return CF_HOLDS;
+  *k_out = k;  // ascending deficit columns
+  p[0] = k == 1 ? p_last : (k == 2 ? p_prev : p_prev2); p[1] = k == 2 ? p_last : p_prev; p[2] = p_last;
+  return CF_IF_CERTIFIED;
+}
+
+// flank_start_gap_form of bpsw_extend_core.h (tried when the closed form does not hold); false: no form holds
+__device__ bool sift_start_gap_form(const SiftSeq& s, const int n, const int tLen, const SiftParams& P, SideRec* rec) {
+  const int a = P.a, dm = P.dm;
   const int oe = P.oIns + P.eIns;
-  if (P.wBand < 4 || (P.zdrop > 0 && P.zdrop < oe) || n < oe + 3) return rec;
+  const bool family = a == 1 && P.eIns == 1 && P.eDel == 1 && oe == P.oDel + P.eDel && oe >= 2;
+  if (P.certify < 3 || !family) return false;
+  if (P.wBand < 4 || (P.zdrop > 0 && P.zdrop < oe) || n < oe + 3) return false;
   bool ins = tLen >= n - 1, del = tLen >= n + 1, del2 = tLen >= n + 2;
-  if (!ins && !del) return rec;
+  if (!ins && !del) return false;
   // the shifted diagonals: t[j] == q[j+1] (j <= n-2), t[j+1] == q[j], t[j+2] == q[j] (j <= n-1)
   if (ins) ins = sift_equal_run(s, 0, n - 2, 1, 0);
   if (del) del = sift_equal_run(s, 0, n - 1, 0, 1);
-  if (!ins && !del) return rec;
+  if (!ins && !del) return false;
   if (del2) del2 = sift_equal_run(s, 0, n - 1, 0, 2);
-  if (ins && (del || del2)) return rec;
+  if (ins && (del || del2)) return false;
   // the main diagonal must never get back above h0: S(j) = a(j+1) - dm * (mismatches up to j) <= 0 for every j < min(n, tLen);
   // S peaks on the last base of a run of matches
   {
@@ -267,25 +252,25 @@ __device__ SideRec sift_side(const SiftSeq& s, const int n, const int tLen, cons
         const int i = __clz((int)m) >> 2;
         m &= ~(0x10000000u >> (4 * i));
         const int pos = j + i;
-        if (pos * a - dm * mm > 0) return rec;  // S(pos - 1)
+        if (pos * a - dm * mm > 0) return false;  // S(pos - 1)
         ++mm;
       }
     }
-    if (nt * a - dm * mm > 0) return rec;
+    if (nt * a - dm * mm > 0) return false;
   }
   if (del) {
     const int s0 = s.tn(0) == s.qn(0) ? a : a - dm;
-    if (s0 + oe + 1 <= 0) return rec;
-    if (s.tn(0) == s.qn(1) || s.tn(0) == s.qn(2)) return rec;  // n >= 5 here
+    if (s0 + oe + 1 <= 0) return false;
+    if (s.tn(0) == s.qn(1) || s.tn(0) == s.qn(2)) return false;  // n >= 5 here
     const int g_rel = -oe + a * n;
-    rec.kind = SIFT_FORM; rec.hmin = max(2 * oe + 1, a - s0 + 1);  // h0 >= 2 oe + 1 and h0 + s0 > a
-    rec.max_rel = g_rel; rec.g_rel = g_rel; rec.qle = n; rec.tle = n + 1; rec.gtle = n + 1; rec.max_off = 1;
-    return rec;
+    rec->kind = SIFT_FORM; rec->hmin = max(2 * oe + 1, a - s0 + 1);  // h0 >= 2 oe + 1 and h0 + s0 > a
+    rec->max_rel = g_rel; rec->g_rel = g_rel; rec->qle = n; rec->tle = n + 1; rec->gtle = n + 1; rec->max_off = 1;
+    return true;
   }
   const int g_rel = -oe + a * (n - 1);
-  rec.kind = SIFT_FORM; rec.hmin = 2 * oe + 1;
-  rec.max_rel = g_rel; rec.g_rel = g_rel; rec.qle = n; rec.tle = n - 1; rec.gtle = n - 1; rec.max_off = 1;
-  return rec;
+  rec->kind = SIFT_FORM; rec->hmin = 2 * oe + 1;
+  rec->max_rel = g_rel; rec->g_rel = g_rel; rec->qle = n; rec->tle = n - 1; rec->gtle = n - 1; rec->max_off = 1;
+  return true;
 }
 
 __device__ __forceinline__ uint4 pack_rec(const SideRec& r) {
@@ -298,6 +283,8 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
                                                       const ExtScoring sc, const int dm, const int qmax, uint8_t* __restrict__ flag,
                                                       uint4* __restrict__ recs) {
   __shared__ uint32_t raw[SIFT_RAW_WORDS + 4];
+  __shared__ int items[128 * 8];   // the flanks whose closed form waits for its certificate: stream offset, qs, ts, n | tLen << 8, k, p0, p1, p2
+  __shared__ int item_fail[128];
   const int lane = threadIdx.x;
   const int task = (int)blockIdx.x * 64 + lane;
   const bool live = task < n_tasks;
@@ -336,31 +323,83 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
     }
     for (; i < span; i += 64) { const uint32_t v = src[i]; raw[i] = v; n_codes |= v & 0xCCCCCCCCu; }
   }
-  const bool any_n = __builtin_amdgcn_ballot_w64(n_codes != 0u) != 0ull;
   if (lane < 4) raw[span + lane] = 0u;
+  item_fail[lane] = 0; item_fail[64 + lane] = 0;
+  const bool any_n = __builtin_amdgcn_ballot_w64(n_codes != 0u) != 0ull;
   __syncthreads();
-  if (!live) return;
-  if (lq > qmax || rq > qmax) {  // not a task the 48-VGPR build of ext_kernel takes
-    flag[task] = 0;
-    return;
-  }
+  const bool mine = live && lq <= qmax && rq <= qmax;  // else not a task the 48-VGPR build of ext_kernel takes
   const int regScore0 = s_lo16(r3), qBeg = s_hi16(r3), h0 = s_lo16(r4);
   const int idx = (int)rec[7];
+  const uint32_t* my_raw = raw + (pos - base);
 
-  const auto judge = [&](const int side) {
+  // ---- 1: the closed form of both sides up to its certificate; the flanks that need one queue up in LDS ---------------------------
+  int n_items = 0, max_shifts = 0;
+  SideRec sr0 = {SIFT_UNSEEN, 0, 0, 0, 0, 0, 0, 0}, sr1 = sr0;
+  int st0 = CF_UNSEEN, st1 = CF_UNSEEN, item0 = -1, item1 = -1;  // CF_* per side
+  const auto closed = [&](const int side, SideRec* r, int* st, int* item) {
     const int qLen = side ? rq : lq, rLen = side ? rr : lr;
-    SideRec r = {SIFT_UNSEEN, 0, 0, 0, 0, 0, 0, 0};
-    if (qLen <= 0) return r;
-    const SiftSeq s = {raw + (pos - base), side ? lq : 0, side ? lq + rq + lr : lq + rq};
-    if (any_n) {  // a code above 3 (N) anywhere in the two flanks: the side is left to ext_kernel
+    const SiftSeq s = {my_raw, side ? lq : 0, side ? lq + rq + lr : lq + rq};
+    int k = 0, p[3] = {0, 0, 0}, dI = 0, dD = 0;
+    *st = CF_UNSEEN;
+    if (mine && qLen > 0) {
       uint32_t n_seen = 0u;
-      for (int j = 0; j < qLen; j += 8) n_seen |= s.q8(j) & top_nibbles(qLen - j) & 0xCCCCCCCCu;
-      for (int j = 0; j < rLen; j += 8) n_seen |= s.t8(j) & top_nibbles(rLen - j) & 0xCCCCCCCCu;
-      if (n_seen) return r;
+      if (any_n) {  // a code above 3 (N) anywhere in the two flanks: the side is left to ext_kernel
+        for (int j = 0; j < qLen; j += 8) n_seen |= s.q8(j) & top_nibbles(qLen - j) & 0xCCCCCCCCu;
+        for (int j = 0; j < rLen; j += 8) n_seen |= s.t8(j) & top_nibbles(rLen - j) & 0xCCCCCCCCu;
+      }
+      if (!n_seen) *st = sift_closed_form(s, qLen, rLen, P, r, &k, p, &dI, &dD);
     }
-    return sift_side(s, qLen, rLen, P);
+    const bool need = *st == CF_IF_CERTIFIED;
+    const unsigned long long needs = __builtin_amdgcn_ballot_w64(need);
+    if (need) {
+      const int it = n_items + __popcll(needs & ((1ull << lane) - 1ull));
+      *item = it;
+      int* e = items + 8 * it;
+      e[0] = pos - base; e[1] = s.qs; e[2] = s.ts; e[3] = qLen | (rLen << 8); e[4] = k; e[5] = p[0]; e[6] = p[1]; e[7] = p[2];
+    }
+    n_items += __popcll(needs);
+    max_shifts = max(max_shifts, wave_max(need ? dI + dD : 0));
   };
-  const SideRec sr0 = judge(0), sr1 = judge(1);
+  closed(0, &sr0, &st0, &item0);
+  closed(1, &sr1, &st1, &item1);
+  __syncthreads();
+
+  // ---- 2: the certificates, one (flank, shift) pair per lane ------------------------------------------------------------------------
+  for (int slot0 = 0; slot0 < n_items * max_shifts; slot0 += 64) {
+    const int slot = slot0 + lane;
+    if (slot < n_items * max_shifts) {
+      const int it = slot / max_shifts, sub = slot - it * max_shifts;
+      const int* e = items + 8 * it;
+      const SiftSeq s = {raw + e[0], e[1], e[2]};
+      const int n = e[3] & 0xff, tLen = e[3] >> 8, k = e[4];
+      const int D = k * dm, dI = max(0, (D - P.oIns) / P.eIns), dD = max(0, (D - P.oDel) / P.eDel);
+      bool ok = true;
+      if (sub < dI) ok = sift_certificate_shift(s, n, tLen, P, k, e[5], e[6], e[7], true, sub + 1);
+      else if (sub - dI < dD) ok = sift_certificate_shift(s, n, tLen, P, k, e[5], e[6], e[7], false, sub - dI + 1);
+      if (!ok) item_fail[it] = 1;
+    }
+  }
+  __syncthreads();
+  if (!mine) {
+    if (live) flag[task] = 0;
+    return;
+  }
+
+  // ---- 3: the start-gap form where the closed form does not hold; extension() over the sides that are resolved ---------------------
+  const auto settle = [&](const int side, SideRec* r, int st, const int item) {
+    const int qLen = side ? rq : lq, rLen = side ? rr : lr;
+    if (qLen <= 0) return;
+    if (st == CF_IF_CERTIFIED) st = item_fail[item] ? CF_FAILS : CF_HOLDS;
+    if (st == CF_FAILS) {
+      const SiftSeq s = {my_raw, side ? lq : 0, side ? lq + rq + lr : lq + rq};
+      r->kind = SIFT_FAIL;
+      (void)sift_start_gap_form(s, qLen, rLen, P, r);
+    } else if (st == CF_UNSEEN) {
+      r->kind = SIFT_UNSEEN;
+    }
+  };
+  settle(0, &sr0, st0, item0);
+  settle(1, &sr1, st1, item1);
 
   // extension(), MemChainToAlignBatched.scala:789-883, for sides that are resolved (as ext_kernel chains them)
   int regScore = regScore0;

@@ -47,7 +47,9 @@ struct bpsw_feeder {
   bool quit = false;
   bpsw_feed_item_t* items = nullptr;
   int n_items = 0;
-  std::atomic<int> next{0};
+  long long n_tickets = 0;                       // n_items * repeats: ticket i runs item i % n_items
+  std::vector<std::atomic<unsigned char>> busy;  // per item: a call on it is in flight (its output buffers are in use)
+  std::atomic<long long> next{0};
   std::atomic<int> first_rc{0};
 };
 
@@ -67,16 +69,22 @@ static void feeder_worker(bpsw_feeder* F, int t) {
       seen = F->epoch;
     }
     for (;;) {
-      const int i = F->next.fetch_add(1, std::memory_order_relaxed);
-      if (i >= F->n_items) break;
+      const long long ticket = F->next.fetch_add(1, std::memory_order_relaxed);
+      if (ticket >= F->n_tickets) break;
+      const int i = (int)(ticket % F->n_items);
       bpsw_feed_item_t& it = F->items[i];
+      // an item of the next repeat while a slow thread still runs it: wait for that call (its result buffers are the same)
+      unsigned char idle = 0;
+      while (!F->busy[(size_t)i].compare_exchange_weak(idle, 1, std::memory_order_acquire)) { idle = 0; sched_yield(); }
       const double t0 = now_ms();
       if (it.kind == 0) it.rc = F->f_ext(F->ctxs[(size_t)t], (const uint8_t*)it.in, it.in_bytes, (int16_t*)it.out, (size_t)it.out_cap);
       else it.rc = F->f_grp(F->ctxs[(size_t)t], F->opt, it.in, F->mode, (int32_t*)it.out, it.out2, it.out_cap, &it.out_total);
       it.ms = now_ms() - t0;
-      if (it.rc != 0) {
+      const int rc = it.rc;
+      F->busy[(size_t)i].store(0, std::memory_order_release);
+      if (rc != 0) {
         int zero = 0;
-        F->first_rc.compare_exchange_strong(zero, it.rc);
+        F->first_rc.compare_exchange_strong(zero, rc);
       }
     }
     {
@@ -110,14 +118,19 @@ bpsw_feeder* bpsw_feeder_create(int n_threads, void** ctxs, void* fn_extend, voi
   return F;
 }
 
-// Runs every item once (dynamic assignment: the next free thread takes the next item) and returns when all are done.
-// Returns the first non-zero return code of a call, or 0.
-int bpsw_feeder_run(bpsw_feeder* F, bpsw_feed_item_t* items, int n_items) {
-  if (!F || n_items < 0) return -1;
+// Runs every item `repeats` times (dynamic assignment: the next free thread takes the next item; after the last item the first
+// one again, with no barrier in between -- task threads of an executor do not wait for each other -- but never two calls on one
+// item at a time) and returns when all are done.  Returns the first non-zero return code of a call, or 0.
+int bpsw_feeder_run_repeats(bpsw_feeder* F, bpsw_feed_item_t* items, int n_items, int repeats) {
+  if (!F || n_items < 0 || repeats < 0) return -1;
+  if (n_items == 0 || repeats == 0) return 0;
   {
     std::lock_guard<std::mutex> lk(F->mu);
     F->items = items;
     F->n_items = n_items;
+    F->n_tickets = (long long)n_items * repeats;
+    if (F->busy.size() < (size_t)n_items) F->busy = std::vector<std::atomic<unsigned char>>((size_t)n_items);
+    for (int i = 0; i < n_items; ++i) F->busy[(size_t)i].store(0);
     F->next.store(0);
     F->first_rc.store(0);
     F->running = (int)F->threads.size();
@@ -128,6 +141,8 @@ int bpsw_feeder_run(bpsw_feeder* F, bpsw_feed_item_t* items, int n_items) {
   F->cv_done.wait(lk, [&] { return F->running == 0; });
   return F->first_rc.load();
 }
+
+int bpsw_feeder_run(bpsw_feeder* F, bpsw_feed_item_t* items, int n_items) { return bpsw_feeder_run_repeats(F, items, n_items, 1); }
 
 void bpsw_feeder_destroy(bpsw_feeder* F) {
   if (!F) return;
