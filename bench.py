@@ -2,9 +2,10 @@
 """bench.py -- reads aligned/sec through the MI355X batched Smith-Waterman path, measured the way SURVEY.md 8(d) defines it:
 wall clock of the HOST-BUFFER C ABI calls the two JNI symbols make, H2D / D2H and the whole boundary-1 host layer included.
 
-One step = the hot path over 12 582 912 synthetic read pairs: twelve passes over a set of 1 048 576 DISTINCT pairs (2.3 GB of
-host inputs, far beyond any cache, so a pass never finds its data warm; twelve so that the driver's 20 steps time more than
-three seconds and its GPU-busy samples see the device at work).  Default workload: BASELINE.json configs[2], 2x150 bp, 1 % substitutions, 0.1 % indels, 10 % of the pairs need mate
+One step = the hot path over 16 777 216 synthetic read pairs: sixteen passes over a set of 1 048 576 DISTINCT pairs (2.3 GB of
+host inputs, far beyond any cache, so a pass never finds its data warm; sixteen so that the driver's 20 steps time more than
+three seconds and its GPU-busy samples see the device at work).  The feeder threads go round the passes without a barrier: each
+takes the next call when it has finished one, as the task threads of an executor do.  Default workload: BASELINE.json configs[2], 2x150 bp, 1 % substitutions, 0.1 % indels, 10 % of the pairs need mate
 rescue.  Per pass:
   * boundary 2: one bpsw_extend_batch call per wire batch of 32 768 reads (the reference's -bSWExtSize 32768, run_test.sh:7;
     the call behind MemChainToAlignBatched.scala:175-176), host wire bytes in, host int16 results out;
@@ -52,7 +53,7 @@ WORKLOADS = {
     3: dict(label="configs[2]: 10M-pair-shaped stream of pair-end 2x150bp synthetic reads (1% sub, 0.1% indel) vs a chr21-sized "
                   "coordinate space, batched seed extension + batched pair-end SW rescue (10% of pairs)",
             metric="pair-end 2x150bp reads aligned/sec", read_len=150, sub=0.01, indel=0.001, tail_frac=0.0, tail_sub=0.2,
-            tail_indel=0.02, p_resc=0.10, mate_sub=0.02, mate_indel=0.002, paired=True, ext_batches=64, groups=256, passes=12),
+            tail_indel=0.02, p_resc=0.10, mate_sub=0.02, mate_indel=0.002, paired=True, ext_batches=64, groups=256, passes=16),
     2: dict(label="configs[1]: single-end 150bp synthetic reads (1% sub, 0.1% indel), HIP seed extension only",
             metric="single-end 150bp reads aligned/sec", read_len=150, sub=0.01, indel=0.001, tail_frac=0.0, tail_sub=0.2,
             tail_indel=0.02, p_resc=0.0, mate_sub=0.0, mate_indel=0.0, paired=False, ext_batches=32, groups=0, passes=32),

@@ -20,7 +20,8 @@ for fn in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
         ops.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy_" + r.get("Direction", "?"), "copy"))
 ops.sort()
 t0, t1 = ops[0][0], max(o[1] for o in ops)
-lo, hi = t0 + 0.3 * (t1 - t0), t0 + 0.9 * (t1 - t0)   # the timed steps (the start is warm-up and input generation)
+starts = sorted(o[0] for o in ops if not o[2].startswith("copy"))
+lo, hi = starts[int(0.25 * len(starts))], starts[int(0.9 * len(starts))]   # well inside the timed steps (the start is warm-up)
 span = hi - lo
 kinds = collections.defaultdict(lambda: [0, 0.0, 0.0])   # count, summed duration inside the window, summed full duration
 for s, e, k, q in ops:
