@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
     // what the sift kernel (bpsw_extend_sift.hip: the shortcuts, one task per lane) left for this task: 1 = its record is written,
     // 2 = a record per side in sift_recs, 0 = nothing
     int sifted = 0;
-    if (SHORT == 1 && !COORD && sift_flag) {
+    if (SHORT == 1 && sift_flag) {
       sifted = uni((int)sift_flag[task]);
       if (sifted == 1) continue;
     }
@@ -204,22 +204,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
                                                          hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
       };
       bool exact_v;
-      if constexpr (COORD) {
-        exact_v = reg_path && shortcuts(LdsShiftT{ts}, tstage);
-      } else {
-        int judged = 0;  // 1: the sift kernel found that no form holds, 2: that one does for this start score
-        if (SHORT == 1 && sifted == 2) {
-          const uint4 sr = sift_recs[2 * (size_t)task + side];
-          const int kind = uni((int)(sr.x & 0xffu)), hmin = uni((int)sr.x >> 8);
-          if (kind == 1) judged = 1;
-          else if (kind == 2 && hInit >= hmin) {
-            judged = 2;
-            r.max = hInit + uni(lo16(sr.y)); r.gscore = hInit + uni(hi16(sr.y));
-            r.qle = uni(lo16(sr.z)); r.tle = uni(hi16(sr.z)); r.gtle = uni(lo16(sr.w)); r.max_off = uni(hi16(sr.w));
-          }
+      int judged = 0;  // 1: the sift kernel found that no form holds, 2: that one does for this start score
+      if (SHORT == 1 && sifted == 2) {
+        const uint4 sr = sift_recs[2 * (size_t)task + side];
+        const int kind = uni((int)(sr.x & 0xffu)), hmin = uni((int)sr.x >> 8);
+        if (kind == 1) judged = 1;
+        else if (kind == 2 && hInit >= hmin) {
+          judged = 2;
+          r.max = hInit + uni(lo16(sr.y)); r.gscore = hInit + uni(hi16(sr.y));
+          r.qle = uni(lo16(sr.z)); r.tle = uni(hi16(sr.z)); r.gtle = uni(lo16(sr.w)); r.max_off = uni(hi16(sr.w));
         }
-        exact_v = judged ? judged == 2 : shortcuts(tnib, rLen);
       }
+      if (judged) exact_v = judged == 2;
+      else if constexpr (COORD) exact_v = reg_path && shortcuts(LdsShiftT{ts}, tstage);
+      else exact_v = shortcuts(tnib, rLen);
       // wave-uniform by construction (the shortcuts decide on wave reductions), but not to the compiler: without this the DP below
       // sits in what it takes for divergent control flow and its whole scalar state is kept in vector registers
       const bool exact = uni(exact_v ? 1 : 0) != 0;

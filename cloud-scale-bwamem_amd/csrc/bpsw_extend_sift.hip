@@ -38,21 +38,25 @@ constexpr int SIFT_RAW_WORDS = 4096;  // nibble words of 64 consecutive tasks a 
 __device__ __forceinline__ int s_lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 __device__ __forceinline__ int s_hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
 
-// this lane's task: its nibble stream in LDS (first base in the top nibble of word 0) and where the two flanks of one side start
+// one side of a task: the nibble streams (LDS; first base in the top nibble of word 0) that hold its query and its target flank, and
+// where each starts.  A wire batch of format 1 keeps both in the task's one stream; a coordinate batch has the target flank in a
+// block of its own, expanded from the 2-bit reference.
 struct SiftSeq {
-  const uint32_t* raw;
-  int qs, ts;
-  // the eight bases from base k of the stream on
-  __device__ __forceinline__ uint32_t at8(int k) const {
+  const uint32_t* qraw;
+  int qs;
+  const uint32_t* traw;
+  int ts;
+  // the eight bases from base k of a stream on
+  static __device__ __forceinline__ uint32_t at8(const uint32_t* raw, int k) {
     const int wi = k >> 3;
     const unsigned long long v = ((unsigned long long)raw[wi] << 32) | raw[wi + 1];
     return (uint32_t)((v << ((k & 7) << 2)) >> 32);
   }
-  __device__ __forceinline__ uint32_t q8(int k) const { return at8(qs + k); }
-  __device__ __forceinline__ uint32_t t8(int k) const { return at8(ts + k); }
-  __device__ __forceinline__ int at1(int k) const { return (int)((raw[k >> 3] >> (28 - 4 * (k & 7))) & 0xFu); }
-  __device__ __forceinline__ int qn(int k) const { return at1(qs + k); }
-  __device__ __forceinline__ int tn(int k) const { return at1(ts + k); }
+  static __device__ __forceinline__ int at1(const uint32_t* raw, int k) { return (int)((raw[k >> 3] >> (28 - 4 * (k & 7))) & 0xFu); }
+  __device__ __forceinline__ uint32_t q8(int k) const { return at8(qraw, qs + k); }
+  __device__ __forceinline__ uint32_t t8(int k) const { return at8(traw, ts + k); }
+  __device__ __forceinline__ int qn(int k) const { return at1(qraw, qs + k); }
+  __device__ __forceinline__ int tn(int k) const { return at1(traw, ts + k); }
 };
 
 // the top `cnt` nibbles of a word (cnt >= 1; 8 and more: all of it)
@@ -61,6 +65,43 @@ __device__ __forceinline__ uint32_t top_nibbles(int cnt) { return cnt >= 8 ? 0xF
 __device__ __forceinline__ uint32_t differ(uint32_t x, uint32_t y) {
   const uint32_t v = x ^ y;
   return (v | (v >> 1)) & 0x11111111u;
+}
+
+// the eight bases k .. k+7 of the 2-bit reference (four bases per byte, first base in the top bits: util/BNTSeqUtil.scala:56-73) as 16
+// bits, first base on top; the buffer is 256-byte aligned and padded (bpsw_ref_load), bases outside 0 .. l_pac-1 read as anything
+__device__ __forceinline__ uint32_t pac_bases8(const uint8_t* __restrict__ pac, const long long k) {
+  const long long A = k >> 4;
+  const uint32_t* __restrict__ p32 = reinterpret_cast<const uint32_t*>(pac);
+  const uint32_t d0 = A >= 0 ? p32[A] : 0u, d1 = A + 1 >= 0 ? p32[A + 1] : 0u;
+  const unsigned long long v = ((unsigned long long)__builtin_bswap32(d0) << 32) | __builtin_bswap32(d1);
+  return (uint32_t)((v << (((int)k & 15) << 1)) >> 48);
+}
+// 16 bits of eight 2-bit codes -> eight nibbles, order kept
+__device__ __forceinline__ uint32_t spread_codes(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  return (x | (x << 2)) & 0x33333333u;
+}
+// the order of eight 2-bit codes reversed
+__device__ __forceinline__ uint32_t reverse_codes(uint32_t x) {
+  const uint32_t y = __brev(x) >> 16;
+  return ((y & 0x5555u) << 1) | ((y >> 1) & 0x5555u);
+}
+// the target flank of a coordinate task (bnsGetSeq of MemChainToAlignBatched.scala:363 with the left flank reversed, :511-517): base i
+// is position pos + step * i of the doubled reference, positions >= l_pac being the reverse strand, complemented.  A flank lies on
+// one strand (scan_wire), so the 2-bit stream is read forwards or backwards, eight bases at a time.
+__device__ __forceinline__ void sift_stage_pac(uint32_t* __restrict__ dst, const uint8_t* __restrict__ pac, const long long l_pac,
+                                               const long long pos, const int step, const int nbases) {
+  const bool rev = pos >= l_pac;
+  const long long k0 = rev ? (l_pac << 1) - 1 - pos : pos;
+  const bool up = rev ? step < 0 : step > 0;
+  const int nw = (nbases + 7) >> 3;
+  for (int w = 0; w < nw; ++w) {
+    uint32_t x = up ? pac_bases8(pac, k0 + 8 * w) : reverse_codes(pac_bases8(pac, k0 - 8 * w - 7));
+    if (rev) x ^= 0xFFFFu;
+    dst[w] = spread_codes(x);
+  }
+  dst[nw] = 0u;
 }
 
 enum { SIFT_UNSEEN = 0, SIFT_FAIL = 1, SIFT_FORM = 2 };
@@ -278,12 +319,16 @@ __device__ __forceinline__ uint4 pack_rec(const SideRec& r) {
                     ((uint32_t)r.qle & 0xffffu) | ((uint32_t)r.tle << 16), ((uint32_t)r.gtle & 0xffffu) | ((uint32_t)r.max_off << 16));
 }
 
+constexpr int SIFT_T_WORDS = 21;  // a coordinate task's staged target flank: 127 + SIFT_MAX_SHIFTS + 4 bases and a spare word, odd (LDS banks)
+
 // one wavefront per workgroup, 64 consecutive tasks
+template <bool COORD>
 __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict__ wire, const int n_tasks, int16_t* __restrict__ out,
                                                       const ExtScoring sc, const int dm, const int qmax, uint8_t* __restrict__ flag,
                                                       uint4* __restrict__ recs) {
-  __shared__ uint32_t raw[SIFT_RAW_WORDS + 4];
-  __shared__ int items[128 * 8];   // the flanks whose closed form waits for its certificate: stream offset, qs, ts, n | tLen << 8, k, p0, p1, p2
+  __shared__ uint32_t raw[SIFT_RAW_WORDS + 4 + (COORD ? 2 * 64 * SIFT_T_WORDS : 0)];
+  constexpr int T_BASE = SIFT_RAW_WORDS + 4;  // COORD: the target flank of (side, lane) at T_BASE + (side * 64 + lane) * SIFT_T_WORDS
+  __shared__ int items[128 * 8];   // the flanks whose closed form waits for its certificate: query stream, qs | ts << 8, target stream, n | tLen << 8, k, p0, p1, p2
   __shared__ int item_fail[128];
   const int lane = threadIdx.x;
   const int task = (int)blockIdx.x * 64 + lane;
@@ -298,11 +343,11 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
   const int oe_min = min(P.oIns + P.eIns, P.oDel + P.eDel);
   P.a = (oe_min > 0 && P.wBand >= 2) ? sc.exact_a : 0;
 
-  const uint32_t* rec = wire + 8 + 8 * (size_t)(live ? task : n_tasks - 1);
+  const uint32_t* rec = wire + 8 + (COORD ? 10 : 8) * (size_t)(live ? task : n_tasks - 1);
   const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4];
   const int lq = s_lo16(r0), lr = s_hi16(r0), rq = s_lo16(r1), rr = s_hi16(r1);
   const int pos = (int)rec[2];
-  const int nwords = (lq + lr + rq + rr + 7) >> 3;
+  const int nwords = COORD ? (lq + rq + 7) >> 3 : (lq + lr + rq + rr + 7) >> 3;  // a coordinate task's stream holds the query flanks only
   // the streams of the wave's tasks lie back to back in the batch (MemChainToAlignBatched.scala:125-170 appends them in task order):
   // one coalesced copy brings them into LDS.  Anything else -- or longer tasks than the buffer holds -- is left to ext_kernel.
   const int base = uni(pos);
@@ -331,21 +376,41 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
   const int regScore0 = s_lo16(r3), qBeg = s_hi16(r3), h0 = s_lo16(r4);
   const int idx = (int)rec[7];
   const uint32_t* my_raw = raw + (pos - base);
+  // what a side's forms see of its target flank: all of it, or -- a coordinate batch -- what ext_kernel stages (bpsw_extend.hip)
+  const auto t_len = [&](const int side) {
+    const int qLen = side ? rq : lq, rLen = side ? rr : lr;
+    return COORD ? min(rLen, qLen + (P.wBand << 1) + 2) : rLen;
+  };
+  const auto side_seq = [&](const int side) {
+    if constexpr (COORD) return SiftSeq{my_raw, side ? lq : 0, raw + T_BASE + (side * 64 + lane) * SIFT_T_WORDS, 0};
+    else return SiftSeq{my_raw, side ? lq : 0, my_raw, side ? lq + rq + lr : lq + rq};
+  };
+  if constexpr (COORD) {  // the target flanks from the device-resident reference (the 2-bit reference holds no N)
+    const long long seedRb = (long long)(((unsigned long long)rec[9] << 32) | rec[8]);
+    const int seedLen = s_hi16(r4);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int qLen = side ? rq : lq;
+      if (mine && qLen > 0)
+        sift_stage_pac(raw + T_BASE + (side * 64 + lane) * SIFT_T_WORDS, sc.pac, sc.l_pac, side ? seedRb + seedLen : seedRb - 1, side ? 1 : -1,
+                       min(t_len(side), qLen + SIFT_MAX_SHIFTS + 4));
+    }
+  }
 
   // ---- 1: the closed form of both sides up to its certificate; the flanks that need one queue up in LDS ---------------------------
   int n_items = 0, max_shifts = 0;
   SideRec sr0 = {SIFT_UNSEEN, 0, 0, 0, 0, 0, 0, 0}, sr1 = sr0;
   int st0 = CF_UNSEEN, st1 = CF_UNSEEN, item0 = -1, item1 = -1;  // CF_* per side
   const auto closed = [&](const int side, SideRec* r, int* st, int* item) {
-    const int qLen = side ? rq : lq, rLen = side ? rr : lr;
-    const SiftSeq s = {my_raw, side ? lq : 0, side ? lq + rq + lr : lq + rq};
+    const int qLen = side ? rq : lq, rLen = t_len(side);
+    const SiftSeq s = side_seq(side);
     int k = 0, p[3] = {0, 0, 0}, dI = 0, dD = 0;
     *st = CF_UNSEEN;
     if (mine && qLen > 0) {
       uint32_t n_seen = 0u;
       if (any_n) {  // a code above 3 (N) anywhere in the two flanks: the side is left to ext_kernel
         for (int j = 0; j < qLen; j += 8) n_seen |= s.q8(j) & top_nibbles(qLen - j) & 0xCCCCCCCCu;
-        for (int j = 0; j < rLen; j += 8) n_seen |= s.t8(j) & top_nibbles(rLen - j) & 0xCCCCCCCCu;
+        if (!COORD) for (int j = 0; j < rLen; j += 8) n_seen |= s.t8(j) & top_nibbles(rLen - j) & 0xCCCCCCCCu;
       }
       if (!n_seen) *st = sift_closed_form(s, qLen, rLen, P, r, &k, p, &dI, &dD);
     }
@@ -355,7 +420,7 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
       const int it = n_items + __popcll(needs & ((1ull << lane) - 1ull));
       *item = it;
       int* e = items + 8 * it;
-      e[0] = pos - base; e[1] = s.qs; e[2] = s.ts; e[3] = qLen | (rLen << 8); e[4] = k; e[5] = p[0]; e[6] = p[1]; e[7] = p[2];
+      e[0] = (int)(s.qraw - raw); e[1] = s.qs | (s.ts << 8); e[2] = (int)(s.traw - raw); e[3] = qLen | (rLen << 8); e[4] = k; e[5] = p[0]; e[6] = p[1]; e[7] = p[2];
     }
     n_items += __popcll(needs);
     max_shifts = max(max_shifts, wave_max(need ? dI + dD : 0));
@@ -370,7 +435,7 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
     if (slot < n_items * max_shifts) {
       const int it = slot / max_shifts, sub = slot - it * max_shifts;
       const int* e = items + 8 * it;
-      const SiftSeq s = {raw + e[0], e[1], e[2]};
+      const SiftSeq s = {raw + e[0], e[1] & 0xff, raw + e[2], e[1] >> 8};
       const int n = e[3] & 0xff, tLen = e[3] >> 8, k = e[4];
       const int D = k * dm, dI = max(0, (D - P.oIns) / P.eIns), dD = max(0, (D - P.oDel) / P.eDel);
       bool ok = true;
@@ -387,11 +452,11 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
 
   // ---- 3: the start-gap form where the closed form does not hold; extension() over the sides that are resolved ---------------------
   const auto settle = [&](const int side, SideRec* r, int st, const int item) {
-    const int qLen = side ? rq : lq, rLen = side ? rr : lr;
+    const int qLen = side ? rq : lq, rLen = t_len(side);
     if (qLen <= 0) return;
     if (st == CF_IF_CERTIFIED) st = item_fail[item] ? CF_FAILS : CF_HOLDS;
     if (st == CF_FAILS) {
-      const SiftSeq s = {my_raw, side ? lq : 0, side ? lq + rq + lr : lq + rq};
+      const SiftSeq s = side_seq(side);
       r->kind = SIFT_FAIL;
       (void)sift_start_gap_form(s, qLen, rLen, P, r);
     } else if (st == CF_UNSEEN) {
@@ -454,7 +519,8 @@ hipError_t launch_ext_sift_kernel(const uint32_t* d_wire, int n_tasks, int16_t* 
                                   uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev) {
   if (n_tasks <= 0) return hipSuccess;
   const int blocks = (n_tasks + 63) / 64;
-  BPSW_LAUNCH(kev, ext_sift_kernel, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs);
+  if (sc.pac) BPSW_LAUNCH(kev, ext_sift_kernel<true>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs);
+  else BPSW_LAUNCH(kev, ext_sift_kernel<false>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs);
   return hipGetLastError();
 }
 

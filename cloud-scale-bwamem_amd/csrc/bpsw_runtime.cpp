@@ -605,11 +605,11 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     quad_fresh = true;  // cleared on the launch stream, in front of ext_kernel (a hipMemset on the null stream is not ordered with it)
   }
   const size_t quad_carry_off = (size_t)c->quad_cap_n;
-  // The sift kernel in front of the 48-VGPR build for flanks up to 127 bases (bpsw_extend_sift.hip): format-1 batches whose matrix
-  // has one mismatch score.  BPSW_EXT_SIFT=0 switches it off (A/B runs).
+  // The sift kernel in front of the 48-VGPR build for flanks up to 127 bases (bpsw_extend_sift.hip): batches whose matrix
+  // has one mismatch score (both wire formats).  BPSW_EXT_SIFT=0 switches it off (A/B runs).
   static const bool sift_on = !(getenv("BPSW_EXT_SIFT") && atoi(getenv("BPSW_EXT_SIFT")) == 0);
   const int sift_dm = sift_uniform_dm(c->ext_mat, c->ext_sc.exact_a);
-  const bool use_sift = sift_on && (c->shortcut_mask & 32) && use_short && !any_mid && !coord && !use_quad && sift_dm > 0;
+  const bool use_sift = sift_on && (c->shortcut_mask & 32) && use_short && !any_mid && !use_quad && sift_dm > 0;
   const size_t sift_rec_off = ((size_t)n + 15) & ~(size_t)15;
   if (use_sift) HIP_TRY(c->d_sift.reserve(sift_rec_off + 32 * (size_t)n));
   const bool staged = wire == (const uint8_t*)c->h_stage_in.ptr;

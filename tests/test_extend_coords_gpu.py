@@ -147,3 +147,27 @@ def test_reference_backed_c_generator_both_forms_agree(refctx, orc):
         if lr:
             assert np.array_equal(np.asarray(orc.bns_get_seq(l_pac, pac, rb - lr, rb))[::-1], by.pool[int(by.left_r_off[t]): int(by.left_r_off[t]) + lr])
     assert wire_c.size < 0.7 * wire_b.size
+
+
+@pytest.mark.parametrize("sub,indel", [(0.01, 0.001), (0.03, 0.006)])
+def test_sift_kernel_on_coordinate_batches(refctx, orc, sub, indel):
+    """csrc/bpsw_extend_sift.hip reads the target flanks of a coordinate batch from the 2-bit reference (both strands, the left
+    flank backwards): same results and the same per-side verdicts as ext_kernel alone, equal to the oracle on the byte form"""
+    l_pac = 2_000_003
+    pac = synth.hash_pac(l_pac, seed=191)
+    refctx.ref_load(pac, l_pac)
+    by, co = synth.ext_tasks_ref(5000, pac, l_pac, read_len=150, sub_rate=sub, indel_rate=indel, seed=192 + int(sub * 1000))
+    assert (co.seed_rbeg >= l_pac).any() and (co.seed_rbeg < l_pac).any()
+    wire_c = bpsw_hip.wire_coords_pack(co)
+    want, _ = orc.wire_extend(bpsw_hip.wire_pack(by))
+    try:
+        for level in (1, 1 | 2 | 4, 31):
+            refctx.set_ext_shortcuts(level)
+            out0, how0 = refctx.extend_batch_classify(wire_c)
+            refctx.set_ext_shortcuts(level | 32)
+            out1, how1 = refctx.extend_batch_classify(wire_c)
+            assert np.array_equal(out0, want) and np.array_equal(out1, want), level
+            assert np.array_equal(how0, how1), level
+        assert (how1 == 1).sum() > 0.2 * (how1 != 0).sum()
+    finally:
+        refctx.set_ext_shortcuts(-1)

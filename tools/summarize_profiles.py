@@ -19,7 +19,7 @@ def short(name):
     m = re.search(r"ext_kernel<\w+, (\d)>", name)   # <COORD, SHORT>: 0 = the full kernel (listed / deferred tasks), 1 / 2 = the 48-VGPR builds
     if m:
         return "extend_full" if m.group(1) == "0" else "extend"
-    for k, v in (("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("swp_kernel", "swalign2"), ("sw4_kernel", "swalign2"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
+    for k, v in (("ext_sift", "extend_sift"), ("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("swp_kernel", "swalign2"), ("sw4_kernel", "swalign2"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
                  ("reg2aln", "reg2aln"), ("chain2aln", "chain2aln"), ("ext_quad", "extend_quad"), ("global_kernel", "global")):
         if k in name:
             return v
@@ -87,11 +87,15 @@ for k in ("extend", "swalign2", "ext_prepass", "sw_prepass"):
     if "SQ_INSTS_VALU" in per[k] and "SQ_INSTS_SALU" in per[k]:
         issue[k] = {"valu": int(sum(per[k]["SQ_INSTS_VALU"]) / len(per[k]["SQ_INSTS_VALU"])),
                     "salu": int(sum(per[k]["SQ_INSTS_SALU"]) / len(per[k]["SQ_INSTS_SALU"]))}
-# per bpsw_extend_batch CALL: the 48-VGPR launch plus the full-kernel launch behind it (listed / deferred tasks), when there is one
-if "extend" in issue and "SQ_INSTS_VALU" in per["extend_full"]:
+# per bpsw_extend_batch CALL: the 48-VGPR launch plus the sift kernel in front of it and the full-kernel launch behind it (listed /
+# deferred tasks), when there are any
+if "extend" in issue and ("SQ_INSTS_VALU" in per["extend_full"] or "SQ_INSTS_VALU" in per["extend_sift"]):
     calls = len(per["extend"]["SQ_INSTS_VALU"])
-    issue["extend_per_call"] = {"valu": int((sum(per["extend"]["SQ_INSTS_VALU"]) + sum(per["extend_full"]["SQ_INSTS_VALU"])) / calls),
-                                "salu": int((sum(per["extend"]["SQ_INSTS_SALU"]) + sum(per["extend_full"]["SQ_INSTS_SALU"])) / calls)}
-issue["note"] = f"wave-instructions per launch (SQ_INSTS_VALU, SQ_INSTS_SALU) from profiles/{tag}_pmc_counters.csv; extend_per_call = both extension launches of a call"
+    tot = lambda c: sum(sum(per[k].get(c, [])) for k in ("extend", "extend_full", "extend_sift"))
+    issue["extend_per_call"] = {"valu": int(tot("SQ_INSTS_VALU") / calls), "salu": int(tot("SQ_INSTS_SALU") / calls)}
+    if "SQ_INSTS_VALU" in per["extend_sift"]:
+        issue["extend_sift"] = {"valu": int(sum(per["extend_sift"]["SQ_INSTS_VALU"]) / len(per["extend_sift"]["SQ_INSTS_VALU"])),
+                                "salu": int(sum(per["extend_sift"]["SQ_INSTS_SALU"]) / len(per["extend_sift"]["SQ_INSTS_SALU"]))}
+issue["note"] = f"wave-instructions per launch (SQ_INSTS_VALU, SQ_INSTS_SALU) from profiles/{tag}_pmc_counters.csv; extend_per_call = all extension launches of a call (sift + 48-VGPR + full kernel)"
 json.dump(issue, open(os.path.join(P, "pmc_issue.json"), "w"), indent=1)
 print(issue)
