@@ -608,8 +608,11 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // The sift kernel in front of the 48-VGPR build for flanks up to 127 bases (bpsw_extend_sift.hip): batches whose matrix
   // has one mismatch score (both wire formats).  BPSW_EXT_SIFT=0 switches it off (A/B runs).
   static const bool sift_on = !(getenv("BPSW_EXT_SIFT") && atoi(getenv("BPSW_EXT_SIFT")) == 0);
+  // a lone small call is latency: the extra launch costs it 60-70 us and saves nothing it would notice (tests/small_call_table.py:
+  // 61 tasks 0.108 -> 0.171 ms, 4 088 tasks 0.267 -> 0.298, 32 768 tasks 0.76 either way); BPSW_EXT_SIFT_MIN moves the threshold
+  static const int sift_min = getenv("BPSW_EXT_SIFT_MIN") ? atoi(getenv("BPSW_EXT_SIFT_MIN")) : 8192;
   const int sift_dm = sift_uniform_dm(c->ext_mat, c->ext_sc.exact_a);
-  const bool use_sift = sift_on && (c->shortcut_mask & 32) && use_short && !any_mid && !use_quad && sift_dm > 0;
+  const bool use_sift = sift_on && n >= sift_min && (c->shortcut_mask & 32) && use_short && !any_mid && !use_quad && sift_dm > 0;
   const size_t sift_rec_off = ((size_t)n + 15) & ~(size_t)15;
   if (use_sift) HIP_TRY(c->d_sift.reserve(sift_rec_off + 32 * (size_t)n));
   const bool staged = wire == (const uint8_t*)c->h_stage_in.ptr;

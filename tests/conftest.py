@@ -8,6 +8,8 @@ import pytest
 # the library's stream pool is clamped to the process's HIP hardware queues (default 4): the multi-threaded tests want what an
 # executor is told to set; must be in the environment before the HIP runtime initialises
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+# the sift kernel (csrc/bpsw_extend_sift.hip) normally serves batches of 8 192 and more tasks: the tests want it on every batch
+os.environ.setdefault("BPSW_EXT_SIFT_MIN", "0")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "cloud-scale-bwamem_amd")

@@ -6,6 +6,8 @@ tests match more often than by chance.  Usage on a GPU box: python tools/soak_ce
 import os
 import sys
 
+os.environ.setdefault("BPSW_EXT_SIFT_MIN", "0")   # the sift kernel on every batch, whatever its size
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("cloud-scale-bwamem_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
