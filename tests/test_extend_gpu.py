@@ -396,3 +396,35 @@ def _two_score_mat():
     m = _uniform_mat(1, 4).reshape(5, 5)
     m[0, 2] = m[2, 0] = -2      # transitions cheaper than transversions
     return m.reshape(-1)
+
+
+def test_sift_kernel_leaves_what_it_cannot_stage_to_the_extension_kernel(ctx, orc):
+    """the sift kernel copies the nibble streams of 64 consecutive tasks as one run: a batch whose task table is not in stream order
+    (legal: every record carries its own offset), or with tasks too long for its buffer between short ones, must come out the same"""
+    soa = synth.ext_tasks(5000, read_len=150, sub_rate=0.01, indel_rate=0.001, seed=4711)
+    wire = bpsw_hip.wire_pack(soa)
+    want, _ = orc.wire_extend(wire)
+    assert np.array_equal(ctx.extend_batch(wire), want)
+    n = int(np.frombuffer(wire[8:12].tobytes(), "<i4")[0])
+    rng = np.random.default_rng(4712)
+    # (a) the records shuffled, the streams where they were; idx (the last word of a record) travels with its record
+    perm = rng.permutation(n)
+    shuffled = wire.copy()
+    table = wire[32: 32 + 32 * n].reshape(n, 32)
+    shuffled[32: 32 + 32 * n] = table[perm].reshape(-1)
+    want_s, _ = orc.wire_extend(shuffled)
+    assert np.array_equal(want_s.reshape(n, 10), want.reshape(n, 10)[perm])
+    assert np.array_equal(ctx.extend_batch(shuffled), want_s)
+    # (b) only every 64th pair of records swapped: most waves still stage, the others must notice
+    part = wire.copy()
+    t2 = table.copy()
+    for i in range(10, n - 70, 64):
+        t2[[i, i + 37]] = t2[[i + 37, i]]
+    part[32: 32 + 32 * n] = t2.reshape(-1)
+    want_p, _ = orc.wire_extend(part)
+    assert np.array_equal(ctx.extend_batch(part), want_p)
+    # (c) long tasks (flanks of 250 bases with their 500-base targets) sprinkled in: runs of 64 tasks that outgrow the buffer
+    long_soa = synth.ext_tasks(4000, read_len=600, sub_rate=0.01, indel_rate=0.001, seed=4713)
+    wl = bpsw_hip.wire_pack(long_soa)
+    want_l, _ = orc.wire_extend(wl)
+    assert np.array_equal(ctx.extend_batch(wl), want_l)
