@@ -73,6 +73,21 @@ for k in ("extend", "swalign2"):
     else:
         traffic[k] = d["fetch_size_x2_plus_write_size"]
     detail[k] = d
+# an extension CALL launches the sift kernel in front of the extension kernel and the full kernel behind it (bpsw_extend.hip): the
+# call's traffic is the sum (the sift kernel reads the whole wire batch once more), scaled to launches of the extension kernel
+def _bytes(k):
+    r32, r64, r128, wr = mean(k, "TCC_EA0_RDREQ_32B_sum"), mean(k, "TCC_EA0_RDREQ_64B_sum"), mean(k, "TCC_EA0_RDREQ_128B_sum"), mean(k, "WRITE_SIZE")
+    if None in (r32, r64, r128, wr):
+        return None
+    return 32 * r32 + 64 * r64 + 128 * r128 + wr * 1024
+if "extend" in traffic and _bytes("extend") is not None:
+    n_ext = len(per["extend"]["WRITE_SIZE"])
+    parts = {"extension_kernel": int(_bytes("extend"))}
+    for k, name in (("extend_sift", "sift_kernel"), ("extend_full", "full_kernel")):
+        if _bytes(k) is not None:
+            parts[name] = int(_bytes(k) * len(per[k]["WRITE_SIZE"]) / n_ext)
+    detail["extend"]["per_call_by_kernel"] = parts
+    traffic["extend"] = int(sum(parts.values()))
 traffic["detail"] = detail
 traffic["note"] = ("fabric-side bytes per launch from separate rocprofv3 --pmc passes under the bench command "
                    f"(profiles/{tag}_pmc_counters.csv).  Reads by request size, 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B: FETCH_SIZE "
