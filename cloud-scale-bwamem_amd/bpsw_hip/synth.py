@@ -210,7 +210,7 @@ def window_bases(bases: np.ndarray, l_pac: int, rb: int, re: int) -> np.ndarray:
 def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE + 3, l_pac: int = 46_709_983,
                  p_resc: float = 0.10, all_orientations: bool = False, sub_rate: float = 0.02, indel_rate: float = 0.002,
                  p_multi_anchor: float = 0.10, p_wrong_mate: float = 0.05, max_matesw: int = 100, pen_unpaired: int = 17,
-                 ref_bases: np.ndarray | None = None, positions=None):
+                 ref_bases: np.ndarray | None = None, positions=None, p_decoy_anchor: float = 0.0):
     """Synthetic pair-end group (FR library, insert ~ N(400, 50^2)) in the flat layout of include/bpsw.h.
 
     Each pair has an anchor on one end; with probability p_resc the mate has no consistent hit, so the
@@ -218,6 +218,8 @@ def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE
     With ref_bases (the unpacked forward strand of a reference of length l_pac -- anything that answers ref_bases[a:b], e.g.
     PacBases) reads and windows are cut from that reference, so the same group can be submitted with bytes or, after ref_load,
     with coordinates only.  positions: forward start of the first len(positions) pairs (the rest are drawn at random).
+    p_decoy_anchor: an end gets, in front of its true hit, a better-scoring hit at an unrelated locus -- the rescue from it finds
+    nothing, so the true hit's rescue is still needed afterwards (the replay's second round, csrc/bpsw_rescue.cpp).
     """
     from . import RescueGroupSoA, ALNREG_DTYPE
     rng = np.random.default_rng(seed)
@@ -281,6 +283,8 @@ def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE
                 ends_regs[i].append(mk_reg(true_rb[i], L - int(rng.integers(0, 8))))
                 if rng.random() < p_multi_anchor:  # a near-duplicate anchor a few bases away (overlapping hit)
                     ends_regs[i].append(mk_reg(true_rb[i] + int(rng.integers(1, 4)), ends_regs[i][0][4] - int(rng.integers(0, pen_unpaired))))
+                if rng.random() < p_decoy_anchor:  # a decoy that sorts in front of the true hit
+                    ends_regs[i].append(mk_reg(int(rng.integers(0, 2 * l_pac - L)), ends_regs[i][0][4] + 1 + int(rng.integers(0, 5))))
                 if rng.random() < 0.15:  # a weak, far-away secondary hit below the anchor threshold
                     ends_regs[i].append(mk_reg(int(rng.integers(0, 2 * l_pac - L)), ends_regs[i][0][4] - pen_unpaired - 5, 10, L - 20))
             elif rng.random() < p_wrong_mate:

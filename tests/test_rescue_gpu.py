@@ -40,3 +40,29 @@ def test_speculation_stats(ctx):
     after = ctx.stats()
     assert after.sw_speculated > before.sw_speculated
     assert after.sw_jobs - before.sw_jobs >= after.sw_speculated - before.sw_speculated
+
+
+@pytest.mark.parametrize("mode", [po.RESCUE_C, po.RESCUE_SCALA])
+def test_lean_speculation_second_round(ctx, orc, mode):
+    """csrc/bpsw_rescue.cpp launches only the first anchor of an end that has a job and lets the replay ask for the later anchors'
+    jobs when they turn out to be needed: with near-duplicate anchors (the first rescue succeeds) nothing is wasted and no second
+    round runs; with a decoy in front of the true hit (its rescue finds nothing) the second round must run -- same results as the
+    reference's sequential walk (native/bwamem_pair.c:115-156) either way"""
+    opt = bpsw_hip.default_opt()
+    g = synth.rescue_group(300, seed=41, p_resc=0.4, p_multi_anchor=0.6)
+    s0 = ctx.stats()
+    got_cnt, got = ctx.matesw_group(opt, g, mode)
+    s1 = ctx.stats()
+    want_cnt, want, _, _ = orc.matesw_group(orc.default_opt(), g, mode)
+    assert np.array_equal(got_cnt, want_cnt)
+    region_fields_equal(got, want)
+    assert s1.sw_wasted == s0.sw_wasted and s1.sw_replayed_rounds == s0.sw_replayed_rounds
+    g = synth.rescue_group(300, seed=42, p_resc=0.5, p_multi_anchor=0.3, p_decoy_anchor=0.5)
+    got_cnt, got = ctx.matesw_group(opt, g, mode)
+    s2 = ctx.stats()
+    want_cnt, want, n_sw, _ = orc.matesw_group(orc.default_opt(), g, mode)
+    assert np.array_equal(got_cnt, want_cnt)
+    region_fields_equal(got, want)
+    assert s2.sw_replayed_rounds > s1.sw_replayed_rounds          # the decoys' rescues failed: the true hits' jobs came second
+    assert s2.sw_jobs - s1.sw_jobs == n_sw                         # and exactly the jobs the sequential walk runs were computed
+    assert got.shape[0] > g.regs.shape[0]
