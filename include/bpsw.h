@@ -398,7 +398,9 @@ int bpsw_approx_mapq_se(const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, cons
 int bpsw_mem_pair(const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, int64_t l_pac, const bpsw_pestat_t pes[4], int32_t n0,
                   const bpsw_alnreg_t *regs0, int32_t n1, const bpsw_alnreg_t *regs1, int64_t id, int32_t out5[5]);
 int bpsw_sort_dedup(int32_t n, bpsw_alnreg_t *regs, float mask_level_redun, int mode);
-/* memPeStat (worker2/MemSamPe.scala:117-260 == mem_pestat, native/bwamem_pair.c:50-112): the insert-size statistics the driver
+/* HARNESS ONLY -- outside both boundaries (the driver's job), kept because the tests and tools that build worker2
+ * inputs need the pes[] the driver would have computed; a maintainer wiring the library into the aligner does not bind it.
+ * memPeStat (worker2/MemSamPe.scala:117-260 == mem_pestat, native/bwamem_pair.c:50-112): the insert-size statistics the driver
  * computes between worker1 and worker2, from the region lists of n_pairs pairs in (pair, end, j) order.  Nothing is printed. */
 int bpsw_pe_stat(const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, int64_t l_pac, int32_t n_pairs, const int32_t *reg_cnt,
                  const bpsw_alnreg_t *regs, bpsw_pestat_t pes[4]);
