@@ -3,6 +3,7 @@
 of the closed form and the single-gap certificate, repeats, restarts, long deletions), many seeds and gap-cost sets.
 Usage on a GPU box: python tools/soak_extend.py [n_rounds] [tasks_per_round]"""
 import os
+os.environ.setdefault("BPSW_EXT_SIFT_MIN", "0")   # the sift kernel on every batch, whatever its size
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

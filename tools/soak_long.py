@@ -5,6 +5,7 @@ flanks at 0..20 % substitutions and 0..5 % indels, long insertions / deletions (
 (wide bands), unrelated sequence after a good stretch (z-drop), band widths 3..127 and their doubles in the retry (200, 254), several
 gap-cost sets, both z-drop parses.  Usage on a GPU box: python tools/soak_long.py [rounds] [tasks_per_round]"""
 import os
+os.environ.setdefault("BPSW_EXT_SIFT_MIN", "0")   # the sift kernel on every batch, whatever its size
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
