@@ -81,7 +81,7 @@ def test_every_short_flank_at_every_shortcut_level():
     for c in ctxs.values():
         c.close()
     assert bad == 0, f"{bad} of {runs} task runs differ; first: {first_bad}"
-    assert runs > 95_000_000
+    assert runs > 195_000_000
 
 
 _tls_orc = {}
