@@ -551,7 +551,9 @@ __device__ __forceinline__ void swp_step(PkCols<C>& S, const PkConst& K, const i
   u16x2 diag = pk(din), f = pk(fin), key = pk(kin);
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    const u16x2 m = pk_subs(diag + pk(s[c]), K.biasv);                 // max(H(i-1,j-1) + s, 0)
+    // (one 32-bit add for both halves: H <= 255 and a biased score byte <= 255 never carry into the other half, and a plain
+    // v_add_u32 issues at twice the rate of v_pk_add_u16)
+    const u16x2 m = pk_subs(pk((int)((unsigned)unpk(diag) + (unsigned)s[c])), K.biasv);   // max(H(i-1,j-1) + s, 0)
     const u16x2 h = pk_max(pk_max(m, pk(S.E[c])), f);
     diag = pk(S.Hp[c]);
     S.Hp[c] = unpk(h);
