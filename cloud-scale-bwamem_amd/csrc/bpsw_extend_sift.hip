@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
   }
 
   // ---- 1: the closed form of both sides up to its certificate; the flanks that need one queue up in LDS ---------------------------
-  int n_items = 0, max_shifts = 0;
+  int n_items = 0, max_di = 0, max_dd = 0;
   SideRec sr0 = {SIFT_UNSEEN, 0, 0, 0, 0, 0, 0, 0}, sr1 = sr0;
   int st0 = CF_UNSEEN, st1 = CF_UNSEEN, item0 = -1, item1 = -1;  // CF_* per side
   const auto closed = [&](const int side, SideRec* r, int* st, int* item) {
@@ -423,25 +423,30 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
       e[0] = (int)(s.qraw - raw); e[1] = s.qs | (s.ts << 8); e[2] = (int)(s.traw - raw); e[3] = qLen | (rLen << 8); e[4] = k; e[5] = p[0]; e[6] = p[1]; e[7] = p[2];
     }
     n_items += __popcll(needs);
-    max_shifts = max(max_shifts, wave_max(need ? dI + dD : 0));
+    max_di = max(max_di, wave_max(need ? dI : 0));
+    max_dd = max(max_dd, wave_max(need ? dD : 0));
   };
   closed(0, &sr0, &st0, &item0);
   closed(1, &sr1, &st1, &item1);
   __syncthreads();
 
-  // ---- 2: the certificates, one (flank, shift) pair per lane ------------------------------------------------------------------------
-  for (int slot0 = 0; slot0 < n_items * max_shifts; slot0 += 64) {
-    const int slot = slot0 + lane;
-    if (slot < n_items * max_shifts) {
-      const int it = slot / max_shifts, sub = slot - it * max_shifts;
-      const int* e = items + 8 * it;
-      const SiftSeq s = {raw + e[0], e[1] & 0xff, raw + e[2], e[1] >> 8};
-      const int n = e[3] & 0xff, tLen = e[3] >> 8, k = e[4];
-      const int D = k * dm, dI = max(0, (D - P.oIns) / P.eIns), dD = max(0, (D - P.oDel) / P.eDel);
-      bool ok = true;
-      if (sub < dI) ok = sift_certificate_shift(s, n, tLen, P, k, e[5], e[6], e[7], true, sub + 1);
-      else if (sub - dI < dD) ok = sift_certificate_shift(s, n, tLen, P, k, e[5], e[6], e[7], false, sub - dI + 1);
-      if (!ok) item_fail[it] = 1;
+  // ---- 2: the certificates, one (flank, shift) pair per lane; the insertion shifts first, then the deletion shifts (the two
+  // kinds share no code: mixed in one round every lane would wait through both) ------------------------------------------------
+#pragma unroll
+  for (int kind = 0; kind < 2; ++kind) {
+    const int per = kind ? max_dd : max_di;  // shifts per flank in this pass (the largest any queued flank needs)
+    for (int slot0 = 0; slot0 < n_items * per; slot0 += 64) {
+      const int slot = slot0 + lane;
+      if (slot < n_items * per) {
+        const int it = slot / per, d = slot - it * per + 1;
+        const int* e = items + 8 * it;
+        const int k = e[4], D = k * dm;
+        const int mine_d = kind ? max(0, (D - P.oDel) / P.eDel) : max(0, (D - P.oIns) / P.eIns);
+        if (d <= mine_d) {
+          const SiftSeq s = {raw + e[0], e[1] & 0xff, raw + e[2], e[1] >> 8};
+          if (!sift_certificate_shift(s, e[3] & 0xff, e[3] >> 8, P, k, e[5], e[6], e[7], kind == 0, d)) item_fail[it] = 1;
+        }
+      }
     }
   }
   __syncthreads();
