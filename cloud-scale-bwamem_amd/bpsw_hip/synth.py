@@ -283,7 +283,7 @@ def rescue_group(n_pairs: int, read_len: int = 150, seed: int = CONFIG_SEED_BASE
                 ends_regs[i].append(mk_reg(true_rb[i], L - int(rng.integers(0, 8))))
                 if rng.random() < p_multi_anchor:  # a near-duplicate anchor a few bases away (overlapping hit)
                     ends_regs[i].append(mk_reg(true_rb[i] + int(rng.integers(1, 4)), ends_regs[i][0][4] - int(rng.integers(0, pen_unpaired))))
-                if rng.random() < p_decoy_anchor:  # a decoy that sorts in front of the true hit
+                if p_decoy_anchor > 0 and rng.random() < p_decoy_anchor:  # a decoy that sorts in front of the true hit (no draw when off: the streams of the golden fixtures stay as they were)
                     ends_regs[i].append(mk_reg(int(rng.integers(0, 2 * l_pac - L)), ends_regs[i][0][4] + 1 + int(rng.integers(0, 5))))
                 if rng.random() < 0.15:  # a weak, far-away secondary hit below the anchor threshold
                     ends_regs[i].append(mk_reg(int(rng.integers(0, 2 * l_pac - L)), ends_regs[i][0][4] - pen_unpaired - 5, 10, L - 20))
