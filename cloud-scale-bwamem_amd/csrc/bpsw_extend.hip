@@ -14,7 +14,8 @@
 // (valid because oIns >= 0, checked on the host).  Row maximum + LAST arg-max (SWUtil.scala:158-161) ride on a second scan; the
 // band trimming loops (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
 // Before any DP a flank goes through the exact shortcuts (closed forms, certificates: bpsw_extend_core.h), which resolve most
-// flanks of low-error reads.  Three builds (ext_kernel<COORD, SHORT>): two 48-VGPR ones at eight waves per SIMD for flanks up to
+// flanks of low-error reads -- for large batches of short flanks in a kernel of their own in front of this one (bpsw_extend_sift.hip:
+// one task per lane), which leaves a flag and a verdict per side here (sift_flag, sift_recs).  Three builds (ext_kernel<COORD, SHORT>): two 48-VGPR ones at eight waves per SIMD for flanks up to
 // 127 / 255 bases, and the full one (slot sweeps for wide-band retries, an LDS-row sweep for flanks above 255 bases) for what
 // the host lists or the window build defers.
 #include <stdlib.h>
