@@ -100,7 +100,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
   unsigned char* base = smem + (size_t)wave * lds_per_wave;
   int2* eh = reinterpret_cast<int2*>(base);
   int8_t* qp = reinterpret_cast<int8_t*>(base + 8 * (size_t)(qcap + 2));
-  uint8_t* ts = SHORT ? base : reinterpret_cast<uint8_t*>(qp + 5 * (size_t)qcap);  // SHORT: the target bytes are all the LDS a wave has
+  uint8_t* ts = SHORT ? base : reinterpret_cast<uint8_t*>(qp + 5 * (size_t)qcap);  // SHORT: the target bytes, then the query profile of the call
+  // (SHORT) the query profile of the adaptive sweep (bpsw_extend_rows.h, ProfLds): qcap + 1 words, qcap + 1 bytes behind the target bytes
+  int* prof_w = reinterpret_cast<int*>(base + (((size_t)rcap + 15) & ~(size_t)15));
+  const ProfLds pl = {prof_w, reinterpret_cast<int8_t*>(prof_w + qcap + 1),
+                      (unsigned)(uintptr_t)((__attribute__((address_space(3))) int*)prof_w)};
 
   // header, MemChainToAlignBatched.scala:78-84 (signed bytes)
   const uint32_t hdr0 = wire[0], hdr1 = wire[1];
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
           int ov = 0;
 #if BPSW_EXT_ADAPTIVE
-          r = sw_extend_adaptive<SHORT == 2>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+          r = sw_extend_adaptive<SHORT == 2>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, pl, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
 #else
           r = sw_extend_reg_short<SHORT == 2>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
 #endif
@@ -366,7 +370,8 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
   rcap = (rcap + 63) & ~63;
-  const size_t per_wave = short_kernel ? (((size_t)rcap + 15) & ~(size_t)15) : ext_lds_per_wave(qcap, rcap);
+  // short kernels: the target bytes, then the call's query profile (qcap + 1 words and bytes: ProfLds, bpsw_extend_rows.h)
+  const size_t per_wave = short_kernel ? (((size_t)rcap + 15) & ~(size_t)15) + ((5 * ((size_t)qcap + 1) + 15) & ~(size_t)15) : ext_lds_per_wave(qcap, rcap);
   const size_t lds = per_wave * WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device

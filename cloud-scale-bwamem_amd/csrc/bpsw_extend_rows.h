@@ -25,6 +25,9 @@ namespace {
 #ifndef BPSW_EXT_ADAPTIVE
 #define BPSW_EXT_ADAPTIVE 1
 #endif
+#ifndef BPSW_EXT_ROWS_FAST
+#define BPSW_EXT_ROWS_FAST 1  // 0: every row of the assembly loops on their general form (A/B runs)
+#endif
 #ifndef BPSW_EXT_ROWS_ASM
 #define BPSW_EXT_ROWS_ASM 1  // 0: the C++ form of the one-column loop everywhere (A/B runs, and the reference the tests compare with)
 #endif
@@ -34,24 +37,37 @@ struct RowState {
   int i, beg, end, h1raw, mx, max_i, max_j, max_ie, gscore, max_off;
   int base;            // first column of the window
   int H0, E0, H1, E1;  // one column per lane: column base + lane in H0 / E0; two: columns base + 2 lane, base + 2 lane + 1
-  int plo0, plo1, phi2;
+  int plo0, plo1;      // the lane's profile words: the scores of its column(s) against target A, C, G, T, one byte each
 };
 enum { ROWS_DONE = 0, ROWS_MORE = 1, ROWS_OTHER_MODE = 2, ROWS_SLOW = 3, ROWS_OVERFLOW = 4 };
 constexpr int ROWS_NARROW = 52;  // a band of at most this many columns goes (back) to one column per lane; wider than 63 must leave it
 
-template <int COLS, class QC>
-__device__ __forceinline__ void rows_load_profile(RowState& st, const QC& qcode, const MatRows& mat, const int qLen, const int lane) {
-  st.phi2 = 0;
-#pragma unroll
-  for (int s = 0; s < COLS; ++s) {
-    const int j = st.base + COLS * lane + s;
-    const int code = (j >= 0 && j < qLen) ? qcode(j) : 4;
+// The query profile of a call lives in LDS (round 4): prof[j] = the scores of query base j against target A, C, G, T (one byte
+// each: the word a lane holds for its column), profn[j] = its score against a target N; entry qLen stands for every column past
+// the query end (code 4).  A window move -- in rows_cpp or inside the assembly loops -- is then two ds_bpermute and one LDS read
+// instead of a nibble fetch from the wire batch per lane.
+struct ProfLds {
+  int* prof;        // qLen + 1 words
+  int8_t* profn;    // qLen + 1 bytes
+  unsigned addr;    // LDS byte address of prof (for the assembly loops' ds_read)
+};
+template <class QC>
+__device__ __forceinline__ void rows_build_profile(const ProfLds& pl, const QC& qcode, const MatRows& mat, const int qLen, const int lane) {
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j <= qLen; j += 64) {
+    const int code = j < qLen ? qcode(j) : 4;
     const int sh = 8 * code;
-    const int p = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
-                        (((mat.row[3] >> sh) & 0xff) << 24));
-    if (s == 0) st.plo0 = p; else st.plo1 = p;
-    st.phi2 |= (int)((mat.row[4] >> sh) & 0xff) << (8 * s);
+    pl.prof[j] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
+                       (((mat.row[3] >> sh) & 0xff) << 24));
+    pl.profn[j] = (int8_t)((mat.row[4] >> sh) & 0xff);
   }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int COLS>
+__device__ __forceinline__ void rows_load_profile(RowState& st, const ProfLds& pl, const int qLen, const int lane) {
+  const int j0 = min(st.base + COLS * lane, qLen);
+  st.plo0 = pl.prof[j0];
+  if (COLS == 2) st.plo1 = pl.prof[min(j0 + 1, qLen)];
 }
 
 // The C++ form of the sweep over a window, COLS columns per lane (1: 64 columns, 2: 128), for at most max_rows rows.  It serves
@@ -61,9 +77,9 @@ __device__ __forceinline__ void rows_load_profile(RowState& st, const QC& qcode,
 //   ROWS_OTHER_MODE  COLS == 1: the next row's band does not fit 64 columns; COLS == 2: it fits ROWS_NARROW columns again
 //   ROWS_OVERFLOW    COLS == 2: the next row's band does not fit 128 columns (the task goes to the full kernel)
 // In the last two cases the row has not been touched.
-template <int COLS, class QC>
-__device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int tLen, const QC& qcode, const uint8_t* __restrict__ ts,
-                        const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
+template <int COLS>
+__device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int tLen, const ProfLds& pl, const uint8_t* __restrict__ ts,
+                        const int oDel, const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
                         const int zmode, const int h0, const int amax, int max_rows) {
   const int oeDel = oDel + eDel, oeIns = oIns + eIns;
   const int jE0 = COLS * lane * eIns - oeIns;  // j*eIns - oeIns of the lane's first column, j counted from the window's origin
@@ -102,7 +118,7 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       }
       base = nb;
       st.base = base;
-      rows_load_profile<COLS>(st, qcode, mat, qLen, lane);
+      rows_load_profile<COLS>(st, pl, qLen, lane);
     }
     beg = nbeg; end = nend;
     const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base
@@ -113,8 +129,8 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
     const unsigned spanA = (unsigned)smax2(span, 0);
     int scv0, scv1 = 0;
     if (__builtin_expect(tsv == 32, 0)) {  // an N row
-      scv0 = __builtin_amdgcn_sbfe(st.phi2, 0u, 8u);
-      scv1 = __builtin_amdgcn_sbfe(st.phi2, 8u, 8u);
+      scv0 = (int)pl.profn[min(base + col0, qLen)];
+      if (COLS == 2) scv1 = (int)pl.profn[min(base + col1, qLen)];
       asm volatile("" : "+v"(scv0), "+v"(scv1));  // keeps the branch: two selects per row otherwise
     } else {
       scv0 = __builtin_amdgcn_sbfe(st.plo0, (unsigned)tsv, 8u);
@@ -350,48 +366,247 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "L_slow" SFX "_%=:\n\t" \
       "s_mov_b32 %[reason], 3\n\t"  /* ROWS_SLOW */ \
       "L_out" SFX "_%=:\n\t"
-// both instantiations in one statement (two statements under a branch make the compiler route the scalar state through VGPRs)
+// ---- the one-column loop, FAST form (round 4) ---------------------------------------------------------------------------------
+// What a row costs is the NUMBER of its instructions -- vector, scalar or branch alike ~2.2 cycles of the SIMD once three or more
+// waves share it, s_nop free (tools/ubench/gen_rowloop_price.py, profiles/r04_rowloop_price_*.txt) -- so the common rows run a loop
+// that holds only what they need, under preconditions the caller establishes per entry instead of tests per row:
+//   * the window has room: end - base <= 63 on entry and row_end <= i + (base + 63 - end) + 1 (end grows by at most one per row);
+//   * the band clamp cannot bind: end <= min(i + w + 1, qLen) on entry (then it never binds again: end grows by at most one per
+//     row) and row_end <= beg + w + 1 (beg never decreases), so beg = max(beg, i - w) is the identity;
+//   * the rows are all above the query end (no tail-row test) and all in ONE phase of h1 = max(0, h0 - oDel - eDel (i + 1)):
+//     LIVE (h1 > 0 on every row: h1 = h1raw after the decrement, nb0 = beg) or DEAD (h1 == 0: no h1 at all -- H is clamped at 0
+//     so that the lane left of the band hands the band's first column its eh[beg].h = 0 through the shift, nb0 = beg + 1).
+// Also: the band mask is one s_bfm_b64; "improved" is one compare of the scan key against mx << 7 | 127 (mxhi) and comes before
+// the m == 0 test, which only a row that did not improve needs; gscore / max_ie live in one key (H << 16 | i, signed max: a later
+// row wins a tie, SWUtil.scala:178-181); the zero test of the trimming is the SCC of the s_and_b64 that builds the mask.
+// 58 instructions on the common path (a row that improves, no zero cell in the band) against 87.
+#define ROWS1F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO) \
+      "L_frow" SFX "_%=:\n\t" \
+      "v_readlane_b32 %[t], %[vTS], %[i]\n\t"  /* 8 * target base of row i */ \
+      "s_sub_i32 %[span], %[end], %[beg]\n\t" \
+      "s_cmp_lt_i32 %[span], 1\n\t" \
+      "s_cbranch_scc1 L_fslow_%=\n\t"  /* an empty band */ \
+      "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
+      "s_bfm_b64 %[act], %[span], m0\n\t"  /* the lanes of the band */ \
+      "v_bfe_i32 %[vS], %[vP], %[t], 8\n\t" \
+      "v_add_u32 %[vA], %[vH], %[vS]\n\t" \
+      "v_max_i32 %[vA], %[vA], %[vE]\n\t" \
+      "v_cndmask_b32 %[vA], %[vNEG], %[vA], %[act]\n\t"  /* a = max(H(i-1,j-1) + s, E) or "no cell" */ \
+      "v_sub_u32 %[vG], %[vA], %[vNegC]\n\t"  /* g = a + j*eIns */ \
+      "v_lshl_or_b32 %[vK], %[vA], 7, %[vLane]\n\t"  /* a << 7 | column */ \
+      H1STEP \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "s_nop 1\n\t" \
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* exclusive prefix of g */ \
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      "v_add3_u32 %[vS], %[vPp], %[vNegC], %[nkc]\n\t"  /* F = Pex - (j-1)*eIns - oeIns */ \
+      HMAX  /* H */ \
+      "v_cmp_gt_i32 vcc, 1, %[vT0]\n\t"  /* H == 0 */ \
+      "v_subrev_u32 %[vE], %[edel], %[vE]\n\t" \
+      "v_subrev_u32 %[vS], %[oedel], %[vT0]\n\t" \
+      "v_max3_i32 %[vE], %[vE], %[vS], 0\n\t"  /* E(i+1,j) */ \
+      "v_cndmask_b32 %[vE], 0, %[vE], %[act]\n\t"  /* eh[end].e = 0 */ \
+      HSHIFT  /* eh[j].h = H(i,j-1), eh[beg].h = h1 */ \
+      /* SWUtil.scala:177-182 */ \
+      "s_cmp_lg_u32 %[end], %[qlen]\n\t" \
+      "s_cbranch_scc1 L_fnogs" SFX "_%=\n\t" \
+      "v_lshl_or_b32 %[vS], %[vH], 16, %[i]\n\t"  /* H(i,j-1) << 16 | i */ \
+      "s_sub_i32 %[t2], %[end], %[base]\n\t" \
+      "v_readlane_b32 %[t1], %[vS], %[t2]\n\t"  /* lane end - base: H(i, qLen-1) */ \
+      "s_max_i32 %[gskey], %[gskey], %[t1]\n\t" \
+      "L_fnogs" SFX "_%=:\n\t" \
+      "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
+      "s_cbranch_scc0 L_fnoimp" SFX "_%=\n\t" \
+      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
+      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t" \
+      "L_ftrim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214 */ \
+      "s_and_b64 %[z], vcc, %[act]\n\t"  /* the zero cells of the band; SCC = there are some */ \
+      "s_cbranch_scc1 L_fzero" SFX "_%=\n\t" \
+      NB0_NOZERO \
+      "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
+      "s_addc_u32 %[end], %[end], 0\n\t"  /* end = min(end + 1, qLen) */ \
+      "L_fnext" SFX "_%=:\n\t" \
+      "s_add_i32 %[i], %[i], 1\n\t" \
+      "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
+      "s_cbranch_scc1 L_frow" SFX "_%=\n\t" \
+      /* row i is the first one this run may not sweep as it is: out of rows (the caller looks), or out of window */ \
+      "L_fbound" SFX "_%=:\n\t" \
+      "s_cmp_ge_i32 %[i], %[hardend]\n\t" \
+      "s_cbranch_scc1 L_fmore_%=\n\t" \
+      "s_sub_i32 %[t1], %[end], %[base]\n\t" \
+      "s_cmp_lt_i32 %[t1], 64\n\t" \
+      "s_cbranch_scc1 L_froom" SFX "_%=\n\t" \
+      /* column `end` would fall outside the window: move the window up to the band's left end (as rows_cpp does) */ \
+      "s_sub_i32 %[t2], %[beg], %[base]\n\t"  /* lanes to move down */ \
+      "s_sub_i32 %[t1], %[end], %[beg]\n\t" \
+      "s_cmp_gt_i32 %[t1], 63\n\t" \
+      "s_cbranch_scc1 L_fslow_%=\n\t"  /* a band of 64 columns: not for this layout */ \
+      "v_add_lshl_u32 %[vT0], %[vLane], %[t2], 2\n\t"  /* byte address of the source lane; lanes past 63 wrap (don't-cares) */ \
+      "v_add_u32 %[vS], %[beg], %[vLane]\n\t" \
+      "v_min_i32 %[vS], %[vS], %[qlen]\n\t" \
+      "v_lshl_add_u32 %[vS], %[vS], 2, %[profaddr]\n\t"  /* the profile word of column beg + lane (entry qLen: past the query) */ \
+      "ds_bpermute_b32 %[vH], %[vT0], %[vH]\n\t" \
+      "ds_bpermute_b32 %[vE], %[vT0], %[vE]\n\t" \
+      "ds_read_b32 %[vP], %[vS]\n\t" \
+      "s_mov_b32 %[base], %[beg]\n\t" \
+      "s_add_i32 %[b65], %[beg], 65\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\t" \
+      "L_froom" SFX "_%=:\n\t"  /* t1 = end - base <= 63: 64 - t1 rows can run before `end` can leave the window */ \
+      "s_sub_i32 %[t1], 64, %[t1]\n\t" \
+      "s_add_i32 %[fastend], %[i], %[t1]\n\t" \
+      "s_min_i32 %[fastend], %[fastend], %[hardend]\n\t" \
+      "s_branch L_frow" SFX "_%=\n\t" \
+      "L_fzero" SFX "_%=:\n\t" \
+      "s_add_i32 %[mja], %[mj], %[base]\n\t" \
+      "s_bfm_b64 %[u64], %[mj], 0\n\t" \
+      "s_and_b64 %[u64], %[u64], %[z]\n\t" \
+      "s_flbit_i32_b64 %[t1], %[u64]\n\t"  /* last zero left of mj */ \
+      "s_lshr_b64 %[u64], %[z], %[mj]\n\t" \
+      "s_lshr_b64 %[u64], %[u64], 1\n\t" \
+      "s_ff1_i32_b64 %[t2], %[u64]\n\t"  /* first zero right of mj */ \
+      "s_sub_i32 %[t4], %[b65], %[t1]\n\t" \
+      NB0_ZERO \
+      "s_cmp_lt_i32 %[t1], 0\n\t" \
+      "s_cselect_b32 %[beg], %[t3], %[t4]\n\t" \
+      "s_add_i32 %[t4], %[mja], %[t2]\n\t" \
+      "s_add_i32 %[t4], %[t4], 2\n\t" \
+      "s_add_i32 %[t1], %[end], 1\n\t" \
+      "s_min_i32 %[t1], %[t1], %[qlen]\n\t" \
+      "s_cmp_lt_i32 %[t2], 0\n\t" \
+      "s_cselect_b32 %[end], %[t1], %[t4]\n\t" \
+      "s_branch L_fnext" SFX "_%=\n\t" \
+      "L_fnoimp" SFX "_%=:\n\t" \
+      "s_cmp_lt_i32 %[mkey], 128\n\t" \
+      "s_cbranch_scc1 L_fdone_%=\n\t"  /* m == 0                                SWUtil.scala:184-185 */ \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_cmp_lt_i32 %[zdrop], 1\n\t" \
+      "s_cbranch_scc1 L_ftrim" SFX "_%=\n\t" \
+      /* SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse): k = (i - max_i) - (mj - max_j), X = max - m */ \
+      "s_add_i32 %[mja], %[mj], %[base]\n\t" \
+      "s_sub_i32 %[t1], %[i], %[maxi]\n\t" \
+      "s_sub_i32 %[t2], %[mja], %[maxj]\n\t" \
+      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* k */ \
+      "s_lshr_b32 %[m], %[mkey], 7\n\t" \
+      "s_lshr_b32 %[t2], %[mxhi], 7\n\t" \
+      "s_sub_i32 %[t2], %[t2], %[m]\n\t"  /* X */ \
+      "s_cmp_gt_i32 %[t1], 0\n\t" \
+      "s_cbranch_scc0 L_fzneg" SFX "_%=\n\t" \
+      "s_mul_i32 %[t4], %[t1], %[zpos]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cbranch_scc1 L_fdone_%=\n\t" \
+      "s_branch L_ftrim" SFX "_%=\n\t" \
+      "L_fzneg" SFX "_%=:\n\t" \
+      "s_cmp_eq_u32 %[zneg], 0\n\t" \
+      "s_cbranch_scc1 L_ftrim" SFX "_%=\n\t" \
+      "s_mul_i32 %[t4], %[t1], %[eins]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cbranch_scc1 L_fdone_%=\n\t" \
+      "s_branch L_ftrim" SFX "_%=\n\t"
+#define ROWS1F_LIVE \
+  ROWS1F_TEXT("_l", "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", "v_max_i32 %[vT0], %[vA], %[vS]\n\t", \
+              "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %[vH], %[h1raw], m0\n\t", \
+              "", "s_mov_b32 %[t3], %[beg]\n\t")
+#define ROWS1F_DEAD \
+  ROWS1F_TEXT("_d", "s_nop 0\n\t", "v_max3_i32 %[vT0], %[vA], %[vS], 0\n\t", \
+              "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t", \
+              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t")
+// all the instantiations in one statement (two statements under a branch make the compiler route the scalar state through VGPRs):
+// sel 0 = the general loop (ROWS1_TEXT, with or without the tail-row test), 1 = the fast loop in its LIVE phase, 2 = DEAD.
+// Every read-write operand is early-clobber: an input that happens to hold the same value (end and qLen on row 0) must not share
+// its register.
 #define ROWS1_ASM \
   asm volatile( \
+      "s_cmp_eq_u32 %[sel], 1\n\t" \
+      "s_cbranch_scc1 L_fbound_l_%=\n\t" \
+      "s_cmp_eq_u32 %[sel], 2\n\t" \
+      "s_cbranch_scc1 L_fbound_d_%=\n\t" \
       "s_cmp_eq_u32 %[tailrows], 0\n\t" \
       "s_cbranch_scc1 L_rowb_n_%=\n\t" \
       ROWS1_TEXT(ROWS_TAIL_TOP, "_t") \
       "s_branch L_end_%=\n\t" \
       ROWS1_TEXT("", "_n") \
+      "s_branch L_end_%=\n\t" \
+      ROWS1F_LIVE \
+      ROWS1F_DEAD \
+      "L_fmore_%=:\n\t" \
+      "s_mov_b32 %[reason], 1\n\t"  /* ROWS_MORE */ \
+      "s_branch L_out_%=\n\t" \
+      "L_fdone_%=:\n\t" \
+      "s_mov_b32 %[reason], 0\n\t"  /* ROWS_DONE */ \
+      "s_branch L_out_%=\n\t" \
+      "L_fslow_%=:\n\t" \
+      "s_mov_b32 %[reason], 3\n\t"  /* ROWS_SLOW */ \
+      "L_out_%=:\n\t" \
       "L_end_%=:\n\t" \
-      : [vH] "+v"(vH), [vE] "+v"(vE), [vPp] "+v"(vPp), [i] "+s"(s_i), [beg] "+s"(s_beg), [end] "+s"(s_end), [h1raw] "+s"(s_h1raw), \
-        [mx] "+s"(s_mx), [maxi] "+s"(s_maxi), [maxj] "+s"(s_maxj), [maxie] "+s"(s_maxie), [gs] "+s"(s_gs), [moff] "+s"(s_moff), \
-        [reason] "=&s"(reason), [vS] "=&v"(vS), [vA] "=&v"(vA), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [t] "=&s"(t), \
+      : [vH] "+&v"(vH), [vE] "+&v"(vE), [vPp] "+&v"(vPp), [i] "+&s"(s_i), [beg] "+&s"(s_beg), [end] "+&s"(s_end), [h1raw] "+&s"(s_h1raw), \
+        [mx] "+&s"(s_mx), [maxi] "+&s"(s_maxi), [maxj] "+&s"(s_maxj), [maxie] "+&s"(s_maxie), [gs] "+&s"(s_gs), [moff] "+&s"(s_moff), \
+        [mxhi] "+&s"(s_mxhi), [gskey] "+&s"(s_gskey), [base] "+&s"(s_base), [b65] "+&s"(s_b65), [vP] "+&v"(vP), \
+        [reason] "=&s"(reason), [fastend] "=&s"(s_fastend), [vS] "=&v"(vS), [vA] "=&v"(vA), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [t] "=&s"(t), \
         [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja), \
         [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [act] "=&s"(act), [z] "=&s"(z), [u64] "=&s"(u64) \
-      : [vP] "v"(vP), [vLane] "v"(lane), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end), [qlen] "s"(qLen), \
-        [base] "s"(s_base), [b65] "s"(s_b65), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
-        [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), [qa] "s"(qa) \
+      : [vLane] "v"(lane), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end), [qlen] "s"(qLen), \
+        [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
+        [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), [qa] "s"(qa), \
+        [sel] "s"(s_sel), [hardend] "s"(s_hardend), [profaddr] "s"(s_profaddr) \
       : "vcc", "scc", "memory");  /* (M0 is written too: the compiler never keeps a value in it across statements on gfx9) */
+// sel: 0 the general loop over [i, row_end), 1 / 2 the fast loop (LIVE / DEAD phase of h1) over [i, fast_end) under the preconditions
+// listed at ROWS1F_TEXT, which the caller (sw_extend_adaptive) establishes
 __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int qLen, const int row_end, const int vTS, const int w,
                                          const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
-                                         const int i_tail, const int u0, const int qa, const bool tail_rows) {
+                                         const int i_tail, const int u0, const int qa, const bool tail_rows, const int sel, const int hard_end,
+                                         const unsigned prof_addr) {
   int vH = st.H0, vE = st.E0;
-  const int vP = st.plo0;
+  int vP = st.plo0;
   const int vNegC = -(lane * eIns);     // g(k) = a(k) + k*eIns = a - vNegC;  F(j) = Pex(j) + vNegC + (eIns - oeIns)
   int vPp = NEG;                        // the exclusive prefix: lane 0 keeps "nothing to the left"
   int vNEG = NEG_A;
   int s_i = st.i, s_beg = st.beg, s_end = st.end, s_h1raw = st.h1raw, s_mx = st.mx, s_maxi = st.max_i, s_maxj = st.max_j;
   int s_maxie = st.max_ie, s_gs = st.gscore, s_moff = st.max_off;
-  const int s_base = st.base, s_b65 = st.base + 65, s_w1 = w + 1, s_nkc = eIns - oeIns;
+  // the fast loop's forms of max and (gscore, max_ie): mx << 7 | 127 against the scan key; gscore << 16 | max_ie under a signed max
+  // ((-1, -1), "never reached the query end", is -1; a row index fits 16 bits: target flanks are a few hundred rows)
+  int s_mxhi = (st.mx << 7) | 127, s_gskey = (int)(((unsigned)st.gscore << 16) | ((unsigned)st.max_ie & 0xffffu));
+  int s_base = st.base, s_b65 = st.base + 65;  // (the fast loop moves the window itself)
+  const int s_w1 = w + 1, s_nkc = eIns - oeIns;
   // z-drop of a row that did not improve: k = (i - max_i) - (mj - max_j), X = max - m.  k > 0: X + k * zpos > zdrop with zpos = eIns
   // (Scala parse: its B || C is C) or -eDel (BWA parse: B); k <= 0: the BWA parse alone tests X + k * eIns (zdrop_stop)
   const int s_zpos = uni(zmode == BPSW_ZDROP_SCALA ? eIns : -eDel), s_zneg = uni(zmode == BPSW_ZDROP_SCALA ? 0 : 1);
-  int reason;
+  int reason, s_fastend;
   int vS, vA, vG, vK, vT0;
   int t, h1, span, mkey, m, mj, mja, t1, t2, t3, t4;
   unsigned long long act, z, u64;
-  // (the loop exists twice in the statement: the rows below the query end need no tail-row test at their top)
-  const int s_tailrows = uni((int)tail_rows);
+  // (the general loop exists twice in the statement: the rows below the query end need no tail-row test at their top)
+  const int s_tailrows = uni((int)tail_rows), s_sel = uni(sel), s_hardend = uni(hard_end), s_profaddr = uni((int)prof_addr);
   ROWS1_ASM
-  st.H0 = vH; st.E0 = vE;
-  st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.mx = s_mx; st.max_i = s_maxi; st.max_j = s_maxj;
-  st.max_ie = s_maxie; st.gscore = s_gs; st.max_off = s_moff;
+  st.H0 = vH; st.E0 = vE; st.plo0 = vP; st.base = s_base;
+  st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.max_i = s_maxi; st.max_j = s_maxj; st.max_off = s_moff;
+  if (s_sel) {
+    st.mx = s_mxhi >> 7; st.gscore = s_gskey >> 16; st.max_ie = (int)(short)(s_gskey & 0xffff);
+  } else {
+    st.mx = s_mx; st.max_ie = s_maxie; st.gscore = s_gs;
+  }
   return reason;
 }
 
@@ -668,7 +883,7 @@ __device__ __forceinline__ int rows_asm_end(const int i, const int tLen, const i
 // lane, and the layout still changes with the band).  *overflow = 1: a band wider than 128 columns, the task is not for this build.
 template <bool WINDOW, class QC>
 __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int tLen, const QC& qcode, const uint8_t* __restrict__ ts,
-                                     const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w,
+                                     const ProfLds& pl, const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w,
                                      const int zdrop, const int zmode, const int h0, const int amax, int* __restrict__ overflow) {
   const int oeIns = oIns + eIns, oeDel = oDel + eDel;
   RowState st;
@@ -679,12 +894,13 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
   int cols = min(qLen, w + 1) <= 63 ? 1 : 2;
   if (min(qLen, w + 1) > 127) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
   st.H1 = 0; st.E1 = 0; st.plo1 = 0;
+  rows_build_profile(pl, qcode, mat, qLen, lane);
   if (cols == 1) {
-    rows_load_profile<1>(st, qcode, mat, qLen, lane);
+    rows_load_profile<1>(st, pl, qLen, lane);
     st.H0 = lane == 0 ? h0 : max(0, h0 - oeIns - (lane - 1) * eIns);  // row -1, SWUtil.scala:97-104
     st.E0 = 0;
   } else {
-    rows_load_profile<2>(st, qcode, mat, qLen, lane);
+    rows_load_profile<2>(st, pl, qLen, lane);
     const int j0 = 2 * lane, j1 = 2 * lane + 1;
     st.H0 = j0 == 0 ? h0 : max(0, h0 - oeIns - (j0 - 1) * eIns);
     st.H1 = max(0, h0 - oeIns - (j1 - 1) * eIns);
@@ -692,6 +908,8 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
   }
   const int i_tail = amax > 0 ? qLen : 0x7fffffff;
   const int u0 = h0 + qLen * amax - oDel + (qLen - 1) * eDel, qa = qLen * amax;  // tail_row_bound(i) = max(u0 - i*eDel, qa)
+  // the first row whose h1 = max(0, h0 - oDel - eDel (i + 1)) is zero (SWUtil.scala:137-138): ceil((h0 - oDel) / eDel) - 1, at least 0
+  const int i_h1z = uni(h0 - oDel > 0 ? (h0 - oDel + eDel - 1) / eDel - 1 : 0);
   int vTS = 0, ts_chunk = -1;
   unsigned long long n_rows = 0ull;  // the N rows of the target chunk in vTS
   for (;;) {
@@ -700,11 +918,21 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
 #if BPSW_EXT_ROWS_ASM
       if (st.i >= tLen) break;
       r = ROWS_SLOW;
-      if (const int row_end = rows_asm_end(st.i, tLen, i_tail, ts, lane, &vTS, &ts_chunk, &n_rows); row_end > st.i)
-        r = rows1_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail);
+      if (const int row_end = rows_asm_end(st.i, tLen, i_tail, ts, lane, &vTS, &ts_chunk, &n_rows); row_end > st.i) {
+        // the band clamp of row i (SWUtil.scala:140-142; idempotent), then how far the fast loop may run (ROWS1F_TEXT): while the
+        // left clamp cannot bind, inside one phase of h1 (it looks after the window itself)
+        st.beg = smax2(st.beg, st.i - w);
+        st.end = smin2(smin2(st.end, st.i + w + 1), qLen);
+        const bool live = st.i < i_h1z;
+        int hard_end = smin2(row_end, st.beg + w + 1);
+        if (live) hard_end = smin2(hard_end, i_h1z);
+        const int sel = uni((BPSW_EXT_ROWS_FAST && st.i < i_tail && hard_end > st.i) ? (live ? 1 : 2) : 0);
+        r = rows1_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail, sel, hard_end, pl.addr);
+        if (r == ROWS_MORE) continue;
+      }
       if (r == ROWS_SLOW)
 #endif
-        r = rows_cpp<1>(st, lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
+        r = rows_cpp<1>(st, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
       if (r == ROWS_OTHER_MODE) {  // the band outgrew 64 columns: two columns per lane, window at the band's left end
         const int nb = st.beg & ~1;
         if (st.end - nb > 127) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
@@ -713,7 +941,7 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
         const int e0v = __builtin_amdgcn_ds_bpermute(src0, st.E0), e1v = __builtin_amdgcn_ds_bpermute(src1, st.E0);
         st.H0 = h0v; st.H1 = h1v; st.E0 = e0v; st.E1 = e1v;
         st.base = nb;
-        rows_load_profile<2>(st, qcode, mat, qLen, lane);
+        rows_load_profile<2>(st, pl, qLen, lane);
         cols = 2;
         continue;
       }
@@ -725,7 +953,7 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
         r = rows2_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail);
       if (r == ROWS_SLOW)
 #endif
-        r = rows_cpp<2>(st, lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
+        r = rows_cpp<2>(st, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
       if (r == ROWS_OVERFLOW) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
       if (r == ROWS_OTHER_MODE) {  // the band fits one column per lane again: window at its left end
         const int nb = st.beg;
@@ -736,7 +964,7 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
         st.H0 = (col & 1) ? hb : ha;
         st.E0 = (col & 1) ? eb : ea;
         st.base = nb;
-        rows_load_profile<1>(st, qcode, mat, qLen, lane);
+        rows_load_profile<1>(st, pl, qLen, lane);
         cols = 1;
         ts_chunk = -1;
         continue;

@@ -3,7 +3,7 @@
 set -e
 SUB=${SUB:-0.05}; INDEL=${INDEL:-0.01}; MASK=${MASK:-0}; NTASK=${NTASK:-16384}
 out=$1; shift
-mkdir -p $out
+mkdir -p $out; out=$(cd $out && pwd)
 cd /tmp && export TMPDIR=/tmp
 for L in "$@"; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $out/pmc_$L -o r -- python3 $GRAFT_REPO_ROOT/tools/ext_row_cost.py $L $SUB $INDEL $MASK $NTASK > $out/row_$L.log 2>&1
