@@ -101,9 +101,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
   int2* eh = reinterpret_cast<int2*>(base);
   int8_t* qp = reinterpret_cast<int8_t*>(base + 8 * (size_t)(qcap + 2));
   uint8_t* ts = SHORT ? base : reinterpret_cast<uint8_t*>(qp + 5 * (size_t)qcap);  // SHORT: the target bytes, then the query profile of the call
-  // (SHORT) the query profile of the adaptive sweep (bpsw_extend_rows.h, ProfLds): qcap + 1 words, qcap + 1 bytes behind the target bytes
+  // (SHORT) the query profile of the adaptive sweep (bpsw_extend_rows.h, ProfLds): qcap + 2 words, qcap + 2 bytes behind the target bytes
   int* prof_w = reinterpret_cast<int*>(base + (((size_t)rcap + 15) & ~(size_t)15));
-  const ProfLds pl = {prof_w, reinterpret_cast<int8_t*>(prof_w + qcap + 1),
+  const ProfLds pl = {prof_w, reinterpret_cast<int8_t*>(prof_w + qcap + 2),
                       (unsigned)(uintptr_t)((__attribute__((address_space(3))) int*)prof_w)};
 
   // header, MemChainToAlignBatched.scala:78-84 (signed bytes)
@@ -370,8 +370,8 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
   rcap = (rcap + 63) & ~63;
-  // short kernels: the target bytes, then the call's query profile (qcap + 1 words and bytes: ProfLds, bpsw_extend_rows.h)
-  const size_t per_wave = short_kernel ? (((size_t)rcap + 15) & ~(size_t)15) + ((5 * ((size_t)qcap + 1) + 15) & ~(size_t)15) : ext_lds_per_wave(qcap, rcap);
+  // short kernels: the target bytes, then the call's query profile (qcap + 2 words and bytes: ProfLds, bpsw_extend_rows.h)
+  const size_t per_wave = short_kernel ? (((size_t)rcap + 15) & ~(size_t)15) + ((5 * ((size_t)qcap + 2) + 15) & ~(size_t)15) : ext_lds_per_wave(qcap, rcap);
   const size_t lds = per_wave * WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device

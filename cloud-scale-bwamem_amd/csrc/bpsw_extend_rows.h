@@ -43,18 +43,18 @@ enum { ROWS_DONE = 0, ROWS_MORE = 1, ROWS_OTHER_MODE = 2, ROWS_SLOW = 3, ROWS_OV
 constexpr int ROWS_NARROW = 52;  // a band of at most this many columns goes (back) to one column per lane; wider than 63 must leave it
 
 // The query profile of a call lives in LDS (round 4): prof[j] = the scores of query base j against target A, C, G, T (one byte
-// each: the word a lane holds for its column), profn[j] = its score against a target N; entry qLen stands for every column past
-// the query end (code 4).  A window move -- in rows_cpp or inside the assembly loops -- is then two ds_bpermute and one LDS read
+// each: the word a lane holds for its column), profn[j] = its score against a target N; entries qLen and qLen + 1 stand for every column
+// past the query end (code 4; two of them, so that a lane may read the words of two neighbouring columns from any clamped index).  A window move -- in rows_cpp or inside the assembly loops -- is then two ds_bpermute and one LDS read
 // instead of a nibble fetch from the wire batch per lane.
 struct ProfLds {
-  int* prof;        // qLen + 1 words
-  int8_t* profn;    // qLen + 1 bytes
+  int* prof;        // qLen + 2 words
+  int8_t* profn;    // qLen + 2 bytes
   unsigned addr;    // LDS byte address of prof (for the assembly loops' ds_read)
 };
 template <class QC>
 __device__ __forceinline__ void rows_build_profile(const ProfLds& pl, const QC& qcode, const MatRows& mat, const int qLen, const int lane) {
   __builtin_amdgcn_wave_barrier();
-  for (int j = lane; j <= qLen; j += 64) {
+  for (int j = lane; j <= qLen + 1; j += 64) {
     const int code = j < qLen ? qcode(j) : 4;
     const int sh = 8 * code;
     pl.prof[j] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
@@ -380,7 +380,7 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
 // the m == 0 test, which only a row that did not improve needs; gscore / max_ie live in one key (H << 16 | i, signed max: a later
 // row wins a tie, SWUtil.scala:178-181); the zero test of the trimming is the SCC of the s_and_b64 that builds the mask.
 // 58 instructions on the common path (a row that improves, no zero cell in the band) against 87.
-#define ROWS1F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO) \
+#define ROWS1F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH) \
       "L_frow" SFX "_%=:\n\t" \
       "v_readlane_b32 %[t], %[vTS], %[i]\n\t"  /* 8 * target base of row i */ \
       "s_sub_i32 %[span], %[end], %[beg]\n\t" \
@@ -452,8 +452,37 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "s_cbranch_scc1 L_frow" SFX "_%=\n\t" \
       /* row i is the first one this run may not sweep as it is: out of rows (the caller looks), or out of window */ \
       "L_fbound" SFX "_%=:\n\t" \
-      "s_cmp_ge_i32 %[i], %[hardend]\n\t" \
+      "s_add_i32 %[t1], %[beg], %[w1]\n\t"  /* rows up to beg + w: the left clamp cannot bind */ \
+      "s_min_i32 %[hardend], %[rowend], %[t1]\n\t" \
+      "s_min_i32 %[hardend], %[hardend], %[itail]\n\t" \
+      PHASE_MIN \
+      "s_cmp_lt_i32 %[i], %[hardend]\n\t" \
+      "s_cbranch_scc1 L_fwin" SFX "_%=\n\t" \
+      /* no row to run: the end of the target chunk, the query end, the end of the phase, or the clamp */ \
+      "s_cmp_ge_i32 %[i], %[rowend]\n\t" \
+      "s_cbranch_scc1 L_fchunk" SFX "_%=\n\t" \
+      "s_cmp_ge_i32 %[i], %[itail]\n\t" \
+      "s_cbranch_scc1 L_ftotail_%=\n\t" \
+      PHASE_SWITCH \
+      "s_branch L_ftogen_%=\n\t" \
+      "L_fchunk" SFX "_%=:\n\t"  /* the next 64 target rows, when row i starts a chunk that holds no N */ \
+      "s_cmp_ge_i32 %[i], %[tlen]\n\t" \
       "s_cbranch_scc1 L_fmore_%=\n\t" \
+      "s_and_b32 %[t1], %[i], 63\n\t" \
+      "s_cmp_lg_u32 %[t1], 0\n\t" \
+      "s_cbranch_scc1 L_fmore_%=\n\t"  /* an N row ahead: the caller's */ \
+      "s_add_i32 %[t1], %[tsaddr], %[i]\n\t" \
+      "v_add_u32 %[vT0], %[t1], %[vLane]\n\t" \
+      "ds_read_u8 %[vTS], %[vT0]\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\t" \
+      "v_cmp_eq_u32 vcc, 32, %[vTS]\n\t" \
+      "s_nop 4\n\t" \
+      "s_cmp_lg_u64 vcc, 0\n\t" \
+      "s_cbranch_scc1 L_fmore_%=\n\t"  /* an N row in the chunk (or stale bytes past the target's end that look like one): the caller's */ \
+      "s_add_i32 %[rowend], %[i], 64\n\t" \
+      "s_min_i32 %[rowend], %[rowend], %[tlen]\n\t" \
+      "s_branch L_fbound" SFX "_%=\n\t" \
+      "L_fwin" SFX "_%=:\n\t" \
       "s_sub_i32 %[t1], %[end], %[base]\n\t" \
       "s_cmp_lt_i32 %[t1], 64\n\t" \
       "s_cbranch_scc1 L_froom" SFX "_%=\n\t" \
@@ -528,17 +557,19 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
 #define ROWS1F_LIVE \
   ROWS1F_TEXT("_l", "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", "v_max_i32 %[vT0], %[vA], %[vS]\n\t", \
               "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %[vH], %[h1raw], m0\n\t", \
-              "", "s_mov_b32 %[t3], %[beg]\n\t")
+              "", "s_mov_b32 %[t3], %[beg]\n\t", "s_min_i32 %[hardend], %[hardend], %[ih1z]\n\t", \
+              "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_fbound_d_%=\n\t")
 #define ROWS1F_DEAD \
   ROWS1F_TEXT("_d", "s_nop 0\n\t", "v_max3_i32 %[vT0], %[vA], %[vS], 0\n\t", \
               "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t", \
-              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t")
+              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "")
 // all the instantiations in one statement (two statements under a branch make the compiler route the scalar state through VGPRs):
 // sel 0 = the general loop (ROWS1_TEXT, with or without the tail-row test), 1 = the fast loop in its LIVE phase, 2 = DEAD.
 // Every read-write operand is early-clobber: an input that happens to hold the same value (end and qLen on row 0) must not share
 // its register.
 #define ROWS1_ASM \
   asm volatile( \
+      "s_mov_b32 %[form], %[sel]\n\t" \
       "s_cmp_eq_u32 %[sel], 1\n\t" \
       "s_cbranch_scc1 L_fbound_l_%=\n\t" \
       "s_cmp_eq_u32 %[sel], 2\n\t" \
@@ -551,6 +582,18 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "s_branch L_end_%=\n\t" \
       ROWS1F_LIVE \
       ROWS1F_DEAD \
+      "L_ftotail_%=:\n\t"  /* the rows at and past the query end: the general loop with the tail-row test, in its own form of the state */ \
+      "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
+      "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
+      "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
+      "s_mov_b32 %[form], 0\n\t" \
+      "s_branch L_row_t_%=\n\t" \
+      "L_ftogen_%=:\n\t"  /* the left clamp may bind from here on: the general loop */ \
+      "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
+      "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
+      "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
+      "s_mov_b32 %[form], 0\n\t" \
+      "s_branch L_row_n_%=\n\t" \
       "L_fmore_%=:\n\t" \
       "s_mov_b32 %[reason], 1\n\t"  /* ROWS_MORE */ \
       "s_branch L_out_%=\n\t" \
@@ -564,20 +607,20 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       : [vH] "+&v"(vH), [vE] "+&v"(vE), [vPp] "+&v"(vPp), [i] "+&s"(s_i), [beg] "+&s"(s_beg), [end] "+&s"(s_end), [h1raw] "+&s"(s_h1raw), \
         [mx] "+&s"(s_mx), [maxi] "+&s"(s_maxi), [maxj] "+&s"(s_maxj), [maxie] "+&s"(s_maxie), [gs] "+&s"(s_gs), [moff] "+&s"(s_moff), \
         [mxhi] "+&s"(s_mxhi), [gskey] "+&s"(s_gskey), [base] "+&s"(s_base), [b65] "+&s"(s_b65), [vP] "+&v"(vP), \
-        [reason] "=&s"(reason), [fastend] "=&s"(s_fastend), [vS] "=&v"(vS), [vA] "=&v"(vA), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [t] "=&s"(t), \
+        [rowend] "+&s"(s_rowend), [vTS] "+&v"(vTS), [reason] "=&s"(reason), [fastend] "=&s"(s_fastend), [hardend] "=&s"(s_hardend), [form] "=&s"(s_form), [vS] "=&v"(vS), [vA] "=&v"(vA), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [t] "=&s"(t), \
         [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja), \
         [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [act] "=&s"(act), [z] "=&s"(z), [u64] "=&s"(u64) \
-      : [vLane] "v"(lane), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end), [qlen] "s"(qLen), \
+      : [vLane] "v"(lane), [vNegC] "v"(vNegC), [vNEG] "v"(vNEG), [qlen] "s"(qLen), [tlen] "s"(s_tlen), [tsaddr] "s"(s_tsaddr), [ih1z] "s"(s_ih1z), \
         [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
         [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), [qa] "s"(qa), \
-        [sel] "s"(s_sel), [hardend] "s"(s_hardend), [profaddr] "s"(s_profaddr) \
+        [sel] "s"(s_sel), [profaddr] "s"(s_profaddr) \
       : "vcc", "scc", "memory");  /* (M0 is written too: the compiler never keeps a value in it across statements on gfx9) */
 // sel: 0 the general loop over [i, row_end), 1 / 2 the fast loop (LIVE / DEAD phase of h1) over [i, fast_end) under the preconditions
 // listed at ROWS1F_TEXT, which the caller (sw_extend_adaptive) establishes
-__device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int qLen, const int row_end, const int vTS, const int w,
+__device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int qLen, const int row_end, int& vTS, const int w,
                                          const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
-                                         const int i_tail, const int u0, const int qa, const bool tail_rows, const int sel, const int hard_end,
-                                         const unsigned prof_addr) {
+                                         const int i_tail, const int u0, const int qa, const bool tail_rows, const int sel, const int tLen,
+                                         const int i_h1z, const unsigned ts_addr, const unsigned prof_addr) {
   int vH = st.H0, vE = st.E0;
   int vP = st.plo0;
   const int vNegC = -(lane * eIns);     // g(k) = a(k) + k*eIns = a - vNegC;  F(j) = Pex(j) + vNegC + (eIns - oeIns)
@@ -593,16 +636,18 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
   // z-drop of a row that did not improve: k = (i - max_i) - (mj - max_j), X = max - m.  k > 0: X + k * zpos > zdrop with zpos = eIns
   // (Scala parse: its B || C is C) or -eDel (BWA parse: B); k <= 0: the BWA parse alone tests X + k * eIns (zdrop_stop)
   const int s_zpos = uni(zmode == BPSW_ZDROP_SCALA ? eIns : -eDel), s_zneg = uni(zmode == BPSW_ZDROP_SCALA ? 0 : 1);
-  int reason, s_fastend;
+  int reason, s_fastend, s_hardend, s_form;
+  int s_rowend = row_end;  // (the fast loop fetches the next chunk of target rows itself)
   int vS, vA, vG, vK, vT0;
   int t, h1, span, mkey, m, mj, mja, t1, t2, t3, t4;
   unsigned long long act, z, u64;
   // (the general loop exists twice in the statement: the rows below the query end need no tail-row test at their top)
-  const int s_tailrows = uni((int)tail_rows), s_sel = uni(sel), s_hardend = uni(hard_end), s_profaddr = uni((int)prof_addr);
+  const int s_tailrows = uni((int)tail_rows), s_sel = uni(sel), s_profaddr = uni((int)prof_addr), s_tlen = uni(tLen),
+            s_ih1z = uni(i_h1z), s_tsaddr = uni((int)ts_addr);
   ROWS1_ASM
   st.H0 = vH; st.E0 = vE; st.plo0 = vP; st.base = s_base;
   st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.max_i = s_maxi; st.max_j = s_maxj; st.max_off = s_moff;
-  if (s_sel) {
+  if (s_form) {  // the statement ended in the fast loop: its forms of max and (gscore, max_ie)
     st.mx = s_mxhi >> 7; st.gscore = s_gskey >> 16; st.max_ie = (int)(short)(s_gskey & 0xffff);
   } else {
     st.mx = s_mx; st.max_ie = s_maxie; st.gscore = s_gs;
@@ -814,50 +859,352 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
       "L_slow" SFX "_%=:\n\t" \
       "s_mov_b32 %[reason], 3\n\t" \
       "L_out" SFX "_%=:\n\t"
-// both instantiations in one statement (two statements under a branch make the compiler route the scalar state through VGPRs)
+// ---- the two-column loop, FAST form (round 4): as ROWS1F_TEXT -- same preconditions, the window of 128 columns -----------------
+// In the DEAD phase of h1 the clamp of H at 0 replaces the whole injection of eh[beg].h (a move, two compares and two selects):
+// the column left of the band hands on a 0 by itself -- to an even column through the lane shift (the odd column of the lane
+// below), to an odd column as the even column of its own lane.  gscore reads column qLen - 1 out of the shifted row, whose lane and
+// parity in the window (gsl, gsp) only change when the window moves.
+#define ROWS2F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH) \
+      "L_g2row" SFX "_%=:\n\t" \
+      "v_readlane_b32 %[t], %[vTS], %[i]\n\t" \
+      "s_sub_i32 %[span], %[end], %[beg]\n\t" \
+      "s_cmp_lt_i32 %[span], %[narrow1]\n\t" \
+      "s_cbranch_scc1 L_fslow_%=\n\t"  /* an empty band, or one that fits one column per lane again */ \
+      "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
+      "v_bfe_i32 %[vS0], %[vP0], %[t], 8\n\t" \
+      "v_bfe_i32 %[vS1], %[vP1], %[t], 8\n\t" \
+      "v_subrev_u32 %[vT0], m0, %[vL2]\n\t"  /* rel0 = 2 lane - rbeg */ \
+      "v_add_u32 %[vT1], 1, %[vT0]\n\t"  /* rel1 */ \
+      "v_cmp_gt_u32 %[act0], %[span], %[vT0]\n\t" \
+      "v_cmp_gt_u32 %[act1], %[span], %[vT1]\n\t" \
+      "v_add_u32 %[vA0], %[vH0], %[vS0]\n\t" \
+      "v_add_u32 %[vA1], %[vH1], %[vS1]\n\t" \
+      "v_max_i32 %[vA0], %[vA0], %[vE0]\n\t" \
+      "v_max_i32 %[vA1], %[vA1], %[vE1]\n\t" \
+      "v_cndmask_b32 %[vA0], %[vNEG], %[vA0], %[act0]\n\t" \
+      "v_cndmask_b32 %[vA1], %[vNEG], %[vA1], %[act1]\n\t" \
+      "v_sub_u32 %[vG0], %[vA0], %[vNegC]\n\t"  /* g of the even column */ \
+      "v_sub_u32 %[vG], %[vA1], %[vNegC1]\n\t"  /* g of the odd column (vNegC1 = vNegC - eIns) */ \
+      "v_lshl_or_b32 %[vK], %[vA0], 7, %[vL2]\n\t" \
+      "v_lshl_or_b32 %[vS0], %[vA1], 7, %[vL2p1]\n\t" \
+      "v_max_i32 %[vG], %[vG], %[vG0]\n\t"  /* the lane's two columns folded */ \
+      "v_max_i32 %[vK], %[vK], %[vS0]\n\t"  /* a << 7 | column: row maximum and its LAST column */ \
+      H1STEP \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "s_nop 1\n\t" \
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* prefix over the columns of the lanes below */ \
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      "v_add3_u32 %[vS0], %[vPp], %[vNegC], %[nkc]\n\t"  /* F of the even column */ \
+      "v_max_i32 %[vS1], %[vPp], %[vG0]\n\t" \
+      "v_add3_u32 %[vS1], %[vS1], %[vNegC], %[nkc1]\n\t"  /* F of the odd column */ \
+      HMAX  /* H even, H odd */ \
+      "v_cmp_gt_i32 vcc, 1, %[vA0]\n\t" \
+      "s_and_b64 %[z0], vcc, %[act0]\n\t"  /* zero cells of the band, even columns */ \
+      "v_cmp_gt_i32 vcc, 1, %[vA1]\n\t" \
+      "s_and_b64 %[z1], vcc, %[act1]\n\t"  /* ... odd columns */ \
+      "v_subrev_u32 %[vE0], %[edel], %[vE0]\n\t" \
+      "v_subrev_u32 %[vS0], %[oedel], %[vA0]\n\t" \
+      "v_max3_i32 %[vE0], %[vE0], %[vS0], 0\n\t" \
+      "v_cndmask_b32 %[vE0], 0, %[vE0], %[act0]\n\t"  /* E(i+1,j); eh[end].e = 0 */ \
+      "v_subrev_u32 %[vE1], %[edel], %[vE1]\n\t" \
+      "v_subrev_u32 %[vS1], %[oedel], %[vA1]\n\t" \
+      "v_max3_i32 %[vE1], %[vE1], %[vS1], 0\n\t" \
+      "v_cndmask_b32 %[vE1], 0, %[vE1], %[act1]\n\t" \
+      HSHIFT  /* eh[j].h = H(i,j-1): even column <- odd of the lane below, odd column <- even of the same lane; eh[beg].h = h1 */ \
+      /* SWUtil.scala:177-182 */ \
+      "s_cmp_lg_u32 %[end], %[qlen]\n\t" \
+      "s_cbranch_scc1 L_g2nogs" SFX "_%=\n\t" \
+      "s_cmp_eq_u32 %[gsp], 0\n\t" \
+      "s_cbranch_scc0 L_g2gsodd" SFX "_%=\n\t" \
+      "v_lshl_or_b32 %[vS0], %[vH0], 16, %[i]\n\t"  /* H(i, qLen-1) << 16 | i */ \
+      "s_nop 0\n\t" \
+      "v_readlane_b32 %[t1], %[vS0], %[gsl]\n\t" \
+      "s_max_i32 %[gskey], %[gskey], %[t1]\n\t" \
+      "s_branch L_g2nogs" SFX "_%=\n\t" \
+      "L_g2gsodd" SFX "_%=:\n\t" \
+      "v_lshl_or_b32 %[vS0], %[vH1], 16, %[i]\n\t" \
+      "s_nop 0\n\t" \
+      "v_readlane_b32 %[t1], %[vS0], %[gsl]\n\t" \
+      "s_max_i32 %[gskey], %[gskey], %[t1]\n\t" \
+      "L_g2nogs" SFX "_%=:\n\t" \
+      "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
+      "s_cbranch_scc0 L_g2noimp" SFX "_%=\n\t" \
+      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
+      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t" \
+      "L_g2trim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214 */ \
+      "s_or_b64 %[u64], %[z0], %[z1]\n\t"  /* SCC = the band has a zero cell */ \
+      "s_cbranch_scc1 L_g2zero" SFX "_%=\n\t" \
+      NB0_NOZERO \
+      "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
+      "s_addc_u32 %[end], %[end], 0\n\t"  /* end = min(end + 1, qLen) */ \
+      "L_g2next" SFX "_%=:\n\t" \
+      "s_add_i32 %[i], %[i], 1\n\t" \
+      "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
+      "s_cbranch_scc1 L_g2row" SFX "_%=\n\t" \
+      /* row i is the first one this run may not sweep as it is: out of rows (the caller looks), or out of window */ \
+      "L_g2bound" SFX "_%=:\n\t" \
+      "s_add_i32 %[t1], %[beg], %[w1]\n\t"  /* rows up to beg + w: the left clamp cannot bind */ \
+      "s_min_i32 %[hardend], %[rowend], %[t1]\n\t" \
+      "s_min_i32 %[hardend], %[hardend], %[itail]\n\t" \
+      PHASE_MIN \
+      "s_cmp_lt_i32 %[i], %[hardend]\n\t" \
+      "s_cbranch_scc1 L_g2win" SFX "_%=\n\t" \
+      /* no row to run: the end of the target chunk, the query end, the end of the phase, or the clamp */ \
+      "s_cmp_ge_i32 %[i], %[rowend]\n\t" \
+      "s_cbranch_scc1 L_g2chunk" SFX "_%=\n\t" \
+      "s_cmp_ge_i32 %[i], %[itail]\n\t" \
+      "s_cbranch_scc1 L_ftotail_%=\n\t" \
+      PHASE_SWITCH \
+      "s_branch L_ftogen_%=\n\t" \
+      "L_g2chunk" SFX "_%=:\n\t"  /* the next 64 target rows, when row i starts a chunk that holds no N */ \
+      "s_cmp_ge_i32 %[i], %[tlen]\n\t" \
+      "s_cbranch_scc1 L_fmore_%=\n\t" \
+      "s_and_b32 %[t1], %[i], 63\n\t" \
+      "s_cmp_lg_u32 %[t1], 0\n\t" \
+      "s_cbranch_scc1 L_fmore_%=\n\t"  /* an N row ahead: the caller's */ \
+      "s_add_i32 %[t1], %[tsaddr], %[i]\n\t" \
+      "v_add_u32 %[vT0], %[t1], %[vLane]\n\t" \
+      "ds_read_u8 %[vTS], %[vT0]\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\t" \
+      "v_cmp_eq_u32 vcc, 32, %[vTS]\n\t" \
+      "s_nop 4\n\t" \
+      "s_cmp_lg_u64 vcc, 0\n\t" \
+      "s_cbranch_scc1 L_fmore_%=\n\t"  /* an N row in the chunk (or stale bytes past the target's end that look like one): the caller's */ \
+      "s_add_i32 %[rowend], %[i], 64\n\t" \
+      "s_min_i32 %[rowend], %[rowend], %[tlen]\n\t" \
+      "s_branch L_g2bound" SFX "_%=\n\t" \
+      "L_g2win" SFX "_%=:\n\t" \
+      "s_sub_i32 %[t1], %[end], %[base]\n\t" \
+      "s_cmp_lt_i32 %[t1], 128\n\t" \
+      "s_cbranch_scc1 L_g2room" SFX "_%=\n\t" \
+      /* column `end` would fall outside the window: move the window up to the band's left end, an even column (as rows_cpp does) */ \
+      "s_and_b32 %[t2], %[beg], -2\n\t"  /* the new base */ \
+      "s_sub_i32 %[t1], %[end], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t1], 127\n\t" \
+      "s_cbranch_scc1 L_fslow_%=\n\t"  /* a band wider than the window: the caller reports the overflow */ \
+      "s_sub_i32 %[t4], %[t2], %[base]\n\t" \
+      "s_lshr_b32 %[t4], %[t4], 1\n\t"  /* lanes to move down */ \
+      "v_add_lshl_u32 %[vT0], %[vLane], %[t4], 2\n\t"  /* byte address of the source lane; lanes past 63 wrap (don't-cares) */ \
+      "v_add_u32 %[vS0], %[t2], %[vL2]\n\t" \
+      "v_min_i32 %[vS0], %[vS0], %[qlen]\n\t" \
+      "v_lshl_add_u32 %[vS0], %[vS0], 2, %[profaddr]\n\t"  /* the profile words of columns nb + 2 lane, + 1 (entries qLen, qLen + 1: past the query) */ \
+      "ds_bpermute_b32 %[vH0], %[vT0], %[vH0]\n\t" \
+      "ds_bpermute_b32 %[vE0], %[vT0], %[vE0]\n\t" \
+      "ds_bpermute_b32 %[vH1], %[vT0], %[vH1]\n\t" \
+      "ds_bpermute_b32 %[vE1], %[vT0], %[vE1]\n\t" \
+      "ds_read_b32 %[vP0], %[vS0]\n\t" \
+      "ds_read_b32 %[vP1], %[vS0] offset:4\n\t" \
+      "s_mov_b32 %[base], %[t2]\n\t" \
+      "s_sub_i32 %[t2], %[qlen], %[base]\n\t" \
+      "s_lshr_b32 %[gsl], %[t2], 1\n\t" \
+      "s_and_b32 %[gsp], %[t2], 1\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\t" \
+      "L_g2room" SFX "_%=:\n\t"  /* t1 = end - base <= 127: 128 - t1 rows can run before `end` can leave the window */ \
+      "s_sub_i32 %[t1], 128, %[t1]\n\t" \
+      "s_add_i32 %[fastend], %[i], %[t1]\n\t" \
+      "s_min_i32 %[fastend], %[fastend], %[hardend]\n\t" \
+      "s_branch L_g2row" SFX "_%=\n\t" \
+      "L_g2zero" SFX "_%=:\n\t"  /* on the even / odd zero masks (as ROWS2_TEXT) */ \
+      /* last zero left of mj: even columns 2l < mj <=> l < (mj+1)>>1; odd columns 2l+1 < mj <=> l < mj>>1 */ \
+      "s_add_i32 %[t5], %[mj], 1\n\t" \
+      "s_lshr_b32 %[t6], %[t5], 1\n\t"  /* (mj+1)>>1 */ \
+      "s_bfm_b64 %[u64], %[t6], 0\n\t" \
+      "s_and_b64 %[u64], %[u64], %[z0]\n\t" \
+      "s_flbit_i32_b64 %[t1], %[u64]\n\t"  /* -1: none, else 63 - lane */ \
+      "s_lshr_b32 %[t4], %[mj], 1\n\t"  /* mj>>1 */ \
+      "s_bfm_b64 %[u64], %[t4], 0\n\t" \
+      "s_and_b64 %[u64], %[u64], %[z1]\n\t" \
+      "s_flbit_i32_b64 %[t2], %[u64]\n\t" \
+      "s_lshl_b32 %[m], %[t1], 1\n\t" \
+      "s_sub_i32 %[m], 128, %[m]\n\t" \
+      "s_cmp_lt_i32 %[t1], 0\n\t" \
+      "s_cselect_b32 %[m], -1, %[m]\n\t" \
+      "s_lshl_b32 %[t1], %[t2], 1\n\t" \
+      "s_sub_i32 %[t1], 129, %[t1]\n\t" \
+      "s_cmp_lt_i32 %[t2], 0\n\t" \
+      "s_cselect_b32 %[t1], -1, %[t1]\n\t" \
+      "s_max_i32 %[m], %[m], %[t1]\n\t"  /* cl + 2, or -1 */ \
+      "s_add_i32 %[t1], %[m], %[base]\n\t" \
+      NB0_ZERO \
+      "s_cmp_lt_i32 %[m], 0\n\t" \
+      "s_cselect_b32 %[beg], %[t3], %[t1]\n\t"  /* beg = base + cl + 2, or nb0 */ \
+      /* first zero right of mj: even columns 2l > mj <=> l >= (mj+2)>>1; odd columns 2l+1 > mj <=> l >= (mj+1)>>1 = t6 */ \
+      "s_and_b32 %[t5], %[t5], 1\n\t"  /* (mj+1) & 1 */ \
+      "s_add_i32 %[t4], %[t6], %[t5]\n\t"  /* se = (mj+2)>>1 (at most 64: shifted in two steps) */ \
+      "s_lshr_b64 %[u64], %[z0], %[t6]\n\t" \
+      "s_lshr_b64 %[u64], %[u64], %[t5]\n\t" \
+      "s_ff1_i32_b64 %[t1], %[u64]\n\t" \
+      "s_lshr_b64 %[u64], %[z1], %[t6]\n\t" \
+      "s_ff1_i32_b64 %[t2], %[u64]\n\t" \
+      "s_add_i32 %[m], %[t4], %[t1]\n\t" \
+      "s_lshl_b32 %[m], %[m], 1\n\t"  /* 2 (se + fe) */ \
+      "s_cmp_lt_i32 %[t1], 0\n\t" \
+      "s_cselect_b32 %[m], 0x100000, %[m]\n\t" \
+      "s_add_i32 %[t1], %[t6], %[t2]\n\t" \
+      "s_lshl_b32 %[t1], %[t1], 1\n\t" \
+      "s_add_i32 %[t1], %[t1], 1\n\t"  /* 2 (so + fo) + 1 */ \
+      "s_cmp_lt_i32 %[t2], 0\n\t" \
+      "s_cselect_b32 %[t1], 0x100000, %[t1]\n\t" \
+      "s_min_i32 %[m], %[m], %[t1]\n\t"  /* cr, or 0x100000 */ \
+      "s_add_i32 %[t1], %[m], %[base]\n\t" \
+      "s_add_i32 %[t1], %[t1], 1\n\t" \
+      "s_add_i32 %[t2], %[end], 1\n\t" \
+      "s_min_i32 %[t2], %[t2], %[qlen]\n\t" \
+      "s_cmp_lt_i32 %[m], 0x100000\n\t" \
+      "s_cselect_b32 %[end], %[t1], %[t2]\n\t"  /* end = base + cr + 1, or min(end + 1, qLen) */ \
+      "s_branch L_g2next" SFX "_%=\n\t" \
+      "L_g2noimp" SFX "_%=:\n\t" \
+      "s_cmp_lt_i32 %[mkey], 128\n\t" \
+      "s_cbranch_scc1 L_fdone_%=\n\t"  /* m == 0                                SWUtil.scala:184-185 */ \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_cmp_lt_i32 %[zdrop], 1\n\t" \
+      "s_cbranch_scc1 L_g2trim" SFX "_%=\n\t" \
+      /* SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse): k = (i - max_i) - (mj - max_j), X = max - m */ \
+      "s_add_i32 %[mja], %[mj], %[base]\n\t" \
+      "s_sub_i32 %[t1], %[i], %[maxi]\n\t" \
+      "s_sub_i32 %[t2], %[mja], %[maxj]\n\t" \
+      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* k */ \
+      "s_lshr_b32 %[m], %[mkey], 7\n\t" \
+      "s_lshr_b32 %[t2], %[mxhi], 7\n\t" \
+      "s_sub_i32 %[t2], %[t2], %[m]\n\t"  /* X */ \
+      "s_cmp_gt_i32 %[t1], 0\n\t" \
+      "s_cbranch_scc0 L_g2zneg" SFX "_%=\n\t" \
+      "s_mul_i32 %[t4], %[t1], %[zpos]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cbranch_scc1 L_fdone_%=\n\t" \
+      "s_branch L_g2trim" SFX "_%=\n\t" \
+      "L_g2zneg" SFX "_%=:\n\t" \
+      "s_cmp_eq_u32 %[zneg], 0\n\t" \
+      "s_cbranch_scc1 L_g2trim" SFX "_%=\n\t" \
+      "s_mul_i32 %[t4], %[t1], %[eins]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cbranch_scc1 L_fdone_%=\n\t" \
+      "s_branch L_g2trim" SFX "_%=\n\t"
+#define ROWS2F_LIVE \
+  ROWS2F_TEXT("_l", "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", \
+              "v_max_i32 %[vA0], %[vA0], %[vS0]\n\tv_max_i32 %[vA1], %[vA1], %[vS1]\n\t", \
+              "v_mov_b32 %[vh1], %[h1raw]\n\t" \
+              "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+              "v_cmp_eq_u32 vcc, 0, %[vT0]\n\t" \
+              "v_cndmask_b32 %[vH0], %[vH0], %[vh1], vcc\n\t" \
+              "v_cmp_eq_u32 vcc, 0, %[vT1]\n\t" \
+              "v_cndmask_b32 %[vH1], %[vA0], %[vh1], vcc\n\t", \
+              "", "s_mov_b32 %[t3], %[beg]\n\t", "s_min_i32 %[hardend], %[hardend], %[ih1z]\n\t", \
+              "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_g2bound_d_%=\n\t")
+#define ROWS2F_DEAD \
+  ROWS2F_TEXT("_d", "", \
+              "v_max3_i32 %[vA0], %[vA0], %[vS0], 0\n\tv_max3_i32 %[vA1], %[vA1], %[vS1], 0\n\t", \
+              "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+              "v_mov_b32 %[vH1], %[vA0]\n\t", \
+              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "")
+// all the instantiations in one statement, as ROWS1_ASM: sel 0 = the general loop, 1 = the fast loop in its LIVE phase, 2 = DEAD
 #define ROWS2_ASM \
   asm volatile( \
+      "s_mov_b32 %[form], %[sel]\n\t" \
+      "s_cmp_eq_u32 %[sel], 1\n\t" \
+      "s_cbranch_scc1 L_g2bound_l_%=\n\t" \
+      "s_cmp_eq_u32 %[sel], 2\n\t" \
+      "s_cbranch_scc1 L_g2bound_d_%=\n\t" \
       "s_cmp_eq_u32 %[tailrows], 0\n\t" \
       "s_cbranch_scc1 L_rowb_n_%=\n\t" \
       ROWS2_TEXT(ROWS_TAIL_TOP, "_t") \
       "s_branch L_end_%=\n\t" \
       ROWS2_TEXT("", "_n") \
+      "s_branch L_end_%=\n\t" \
+      ROWS2F_LIVE \
+      ROWS2F_DEAD \
+      "L_ftotail_%=:\n\t"  /* the rows at and past the query end: the general loop with the tail-row test, in its own form of the state */ \
+      "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
+      "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
+      "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
+      "s_mov_b32 %[form], 0\n\t" \
+      "s_branch L_row_t_%=\n\t" \
+      "L_ftogen_%=:\n\t"  /* the left clamp may bind from here on: the general loop */ \
+      "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
+      "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
+      "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
+      "s_mov_b32 %[form], 0\n\t" \
+      "s_branch L_row_n_%=\n\t" \
+      "L_fmore_%=:\n\t" \
+      "s_mov_b32 %[reason], 1\n\t"  /* ROWS_MORE */ \
+      "s_branch L_end_%=\n\t" \
+      "L_fdone_%=:\n\t" \
+      "s_mov_b32 %[reason], 0\n\t"  /* ROWS_DONE */ \
+      "s_branch L_end_%=\n\t" \
+      "L_fslow_%=:\n\t" \
+      "s_mov_b32 %[reason], 3\n\t"  /* ROWS_SLOW */ \
       "L_end_%=:\n\t" \
-      : [vH0] "+v"(vH0), [vE0] "+v"(vE0), [vH1] "+v"(vH1), [vE1] "+v"(vE1), [vPp] "+v"(vPp), [i] "+s"(s_i), [beg] "+s"(s_beg), \
-        [end] "+s"(s_end), [h1raw] "+s"(s_h1raw), [mx] "+s"(s_mx), [maxi] "+s"(s_maxi), [maxj] "+s"(s_maxj), [maxie] "+s"(s_maxie), \
-        [gs] "+s"(s_gs), [moff] "+s"(s_moff), [reason] "=&s"(reason), [vS0] "=&v"(vS0), [vS1] "=&v"(vS1), [vA0] "=&v"(vA0), \
+      : [vH0] "+&v"(vH0), [vE0] "+&v"(vE0), [vH1] "+&v"(vH1), [vE1] "+&v"(vE1), [vPp] "+&v"(vPp), [i] "+&s"(s_i), [beg] "+&s"(s_beg), \
+        [end] "+&s"(s_end), [h1raw] "+&s"(s_h1raw), [mx] "+&s"(s_mx), [maxi] "+&s"(s_maxi), [maxj] "+&s"(s_maxj), [maxie] "+&s"(s_maxie), \
+        [gs] "+&s"(s_gs), [moff] "+&s"(s_moff), [mxhi] "+&s"(s_mxhi), [gskey] "+&s"(s_gskey), [base] "+&s"(s_base), [gsl] "+&s"(s_gsl), \
+        [gsp] "+&s"(s_gsp), [vP0] "+&v"(vP0), [vP1] "+&v"(vP1), \
+        [rowend] "+&s"(s_rowend), [vTS] "+&v"(vTS), [reason] "=&s"(reason), [fastend] "=&s"(s_fastend), [hardend] "=&s"(s_hardend), [form] "=&s"(s_form), [vS0] "=&v"(vS0), [vS1] "=&v"(vS1), [vA0] "=&v"(vA0), \
         [vA1] "=&v"(vA1), [vG0] "=&v"(vG0), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [vT1] "=&v"(vT1), [vh1] "=&v"(vh1), \
         [t] "=&s"(t), [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja), \
         [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [t5] "=&s"(t5), [t6] "=&s"(t6), [act0] "=&s"(act0), \
         [act1] "=&s"(act1), [z0] "=&s"(z0), [z1] "=&s"(z1), [u64] "=&s"(u64) \
-      : [vP0] "v"(vP0), [vP1] "v"(vP1), [vL2] "v"(vL2), [vNegC] "v"(vNegC), [vTS] "v"(vTS), [vNEG] "v"(vNEG), [rowend] "s"(row_end), \
-        [qlen] "s"(qLen), [base] "s"(s_base), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
+      : [vL2] "v"(vL2), [vL2p1] "v"(vL2p1), [vLane] "v"(lane), [vNegC] "v"(vNegC), [vNegC1] "v"(vNegC1), [vNEG] "v"(vNEG), \
+        [qlen] "s"(qLen), [tlen] "s"(s_tlen), [tsaddr] "s"(s_tsaddr), [ih1z] "s"(s_ih1z), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
         [nkc1] "s"(s_nkc1), [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), \
-        [qa] "s"(qa), [narrow1] "s"(ROWS_NARROW + 1) \
+        [qa] "s"(qa), [narrow1] "s"(ROWS_NARROW + 1), [sel] "s"(s_sel), [profaddr] "s"(s_profaddr) \
       : "vcc", "scc", "memory");  /* (M0 is written too) */
-__device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int qLen, const int row_end, const int vTS, const int w,
+__device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int qLen, const int row_end, int& vTS, const int w,
                                          const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
-                                         const int i_tail, const int u0, const int qa, const bool tail_rows) {
+                                         const int i_tail, const int u0, const int qa, const bool tail_rows, const int sel, const int tLen,
+                                         const int i_h1z, const unsigned ts_addr, const unsigned prof_addr) {
   int vH0 = st.H0, vE0 = st.E0, vH1 = st.H1, vE1 = st.E1;
-  const int vP0 = st.plo0, vP1 = st.plo1;
-  const int vL2 = 2 * lane;               // the lane's even column, in window coordinates
+  int vP0 = st.plo0, vP1 = st.plo1;
+  const int vL2 = 2 * lane, vL2p1 = 2 * lane + 1;  // the lane's columns, in window coordinates
   const int vNegC = -(2 * lane * eIns);   // g(k) = a(k) + k*eIns;  F(j) = Pex(j) - (j-1)*eIns - oeIns
+  const int vNegC1 = vNegC - eIns;
   int vPp = NEG;
   int vNEG = NEG_A;
   int s_i = st.i, s_beg = st.beg, s_end = st.end, s_h1raw = st.h1raw, s_mx = st.mx, s_maxi = st.max_i, s_maxj = st.max_j;
   int s_maxie = st.max_ie, s_gs = st.gscore, s_moff = st.max_off;
-  const int s_base = st.base, s_w1 = w + 1, s_nkc = eIns - oeIns, s_nkc1 = -oeIns;
+  int s_mxhi = (st.mx << 7) | 127, s_gskey = (int)(((unsigned)st.gscore << 16) | ((unsigned)st.max_ie & 0xffffu));  // (see rows1_asm)
+  int s_base = st.base, s_gsl = (qLen - st.base) >> 1, s_gsp = (qLen - st.base) & 1;  // column qLen of the shifted row: lane, parity
+  const int s_w1 = w + 1, s_nkc = eIns - oeIns, s_nkc1 = -oeIns;
   const int s_zpos = uni(zmode == BPSW_ZDROP_SCALA ? eIns : -eDel), s_zneg = uni(zmode == BPSW_ZDROP_SCALA ? 0 : 1);
-  int reason;
+  int reason, s_fastend, s_hardend, s_form;
+  int s_rowend = row_end;
   int vS0, vS1, vA0, vA1, vG0, vG, vK, vT0, vT1, vh1;
   int t, h1, span, mkey, m, mj, mja, t1, t2, t3, t4, t5, t6;
   unsigned long long act0, act1, z0, z1, u64;
-  // (the loop exists twice in the statement: the rows below the query end need no tail-row test at their top)
-  const int s_tailrows = uni((int)tail_rows);
+  // (the general loop exists twice in the statement: the rows below the query end need no tail-row test at their top)
+  const int s_tailrows = uni((int)tail_rows), s_sel = uni(sel), s_profaddr = uni((int)prof_addr), s_tlen = uni(tLen),
+            s_ih1z = uni(i_h1z), s_tsaddr = uni((int)ts_addr);
   ROWS2_ASM
-  st.H0 = vH0; st.E0 = vE0; st.H1 = vH1; st.E1 = vE1;
-  st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.mx = s_mx; st.max_i = s_maxi; st.max_j = s_maxj;
-  st.max_ie = s_maxie; st.gscore = s_gs; st.max_off = s_moff;
+  st.H0 = vH0; st.E0 = vE0; st.H1 = vH1; st.E1 = vE1; st.plo0 = vP0; st.plo1 = vP1; st.base = s_base;
+  st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.max_i = s_maxi; st.max_j = s_maxj; st.max_off = s_moff;
+  if (s_form) {
+    st.mx = s_mxhi >> 7; st.gscore = s_gskey >> 16; st.max_ie = (int)(short)(s_gskey & 0xffff);
+  } else {
+    st.mx = s_mx; st.max_ie = s_maxie; st.gscore = s_gs;
+  }
   return reason;
 }
 
@@ -886,6 +1233,9 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
                                      const ProfLds& pl, const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w,
                                      const int zdrop, const int zmode, const int h0, const int amax, int* __restrict__ overflow) {
   const int oeIns = oIns + eIns, oeDel = oDel + eDel;
+#if defined(BPSW_DIAG_SKIP) && BPSW_DIAG_SKIP == 1  // instruction-count experiments only: the call returns before any setup
+  return ExtRes{h0, 0, 0, 0, 0, 0};
+#endif
   RowState st;
   st.i = 0; st.beg = 0; st.end = qLen; st.h1raw = h0 - oDel;
   st.mx = h0; st.max_i = -1; st.max_j = -1; st.max_ie = -1; st.gscore = -1; st.max_off = 0;  // SWUtil.scala:118-125
@@ -912,6 +1262,10 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
   const int i_h1z = uni(h0 - oDel > 0 ? (h0 - oDel + eDel - 1) / eDel - 1 : 0);
   int vTS = 0, ts_chunk = -1;
   unsigned long long n_rows = 0ull;  // the N rows of the target chunk in vTS
+  const unsigned ts_addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const uint8_t*)ts);  // for the loops' own chunk reload
+#if defined(BPSW_DIAG_SKIP) && BPSW_DIAG_SKIP == 2  // ... after the setup, before the first row
+  return ExtRes{h0 + st.H0 * 0, 0, 0, 0, 0, 0};
+#endif
   for (;;) {
     int r;
     if (cols == 1) {
@@ -920,14 +1274,13 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
       r = ROWS_SLOW;
       if (const int row_end = rows_asm_end(st.i, tLen, i_tail, ts, lane, &vTS, &ts_chunk, &n_rows); row_end > st.i) {
         // the band clamp of row i (SWUtil.scala:140-142; idempotent), then how far the fast loop may run (ROWS1F_TEXT): while the
-        // left clamp cannot bind, inside one phase of h1 (it looks after the window itself)
+        // left clamp cannot bind (it looks after the window, the target chunks, the change of h1's phase and the hand-over to the
+        // general loop at the query end itself)
         st.beg = smax2(st.beg, st.i - w);
         st.end = smin2(smin2(st.end, st.i + w + 1), qLen);
         const bool live = st.i < i_h1z;
-        int hard_end = smin2(row_end, st.beg + w + 1);
-        if (live) hard_end = smin2(hard_end, i_h1z);
-        const int sel = uni((BPSW_EXT_ROWS_FAST && st.i < i_tail && hard_end > st.i) ? (live ? 1 : 2) : 0);
-        r = rows1_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail, sel, hard_end, pl.addr);
+        const int sel = uni((BPSW_EXT_ROWS_FAST && st.i < i_tail && st.beg + w + 1 > st.i) ? (live ? 1 : 2) : 0);
+        r = rows1_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail, sel, tLen, i_h1z, ts_addr, pl.addr);
         if (r == ROWS_MORE) continue;
       }
       if (r == ROWS_SLOW)
@@ -949,8 +1302,14 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
 #if BPSW_EXT_ROWS_ASM
       if (st.i >= tLen) break;
       r = ROWS_SLOW;
-      if (const int row_end = rows_asm_end(st.i, tLen, i_tail, ts, lane, &vTS, &ts_chunk, &n_rows); row_end > st.i)
-        r = rows2_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail);
+      if (const int row_end = rows_asm_end(st.i, tLen, i_tail, ts, lane, &vTS, &ts_chunk, &n_rows); row_end > st.i) {
+        st.beg = smax2(st.beg, st.i - w);  // (as for the one-column loop above)
+        st.end = smin2(smin2(st.end, st.i + w + 1), qLen);
+        const bool live = st.i < i_h1z;
+        const int sel = uni((BPSW_EXT_ROWS_FAST && st.i < i_tail && st.beg + w + 1 > st.i) ? (live ? 1 : 2) : 0);
+        r = rows2_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail, sel, tLen, i_h1z, ts_addr, pl.addr);
+        if (r == ROWS_MORE) continue;
+      }
       if (r == ROWS_SLOW)
 #endif
         r = rows_cpp<2>(st, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
