@@ -380,8 +380,24 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
 // the m == 0 test, which only a row that did not improve needs; gscore / max_ie live in one key (H << 16 | i, signed max: a later
 // row wins a tie, SWUtil.scala:178-181); the zero test of the trimming is the SCC of the s_and_b64 that builds the mask.
 // 58 instructions on the common path (a row that improves, no zero cell in the band) against 87.
-#define ROWS1F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH) \
+#define ROWSF_TAILTEST(SFX) \
+      /* a row at or past the query end: tail_row_bound -- U = max(u0 - i eDel, qa); the call is over once U <= max and U < gscore */ \
+      /* (in the loop's own forms: U << 7 | 127 <= mxhi; (U + 1) << 16 <= gskey) */ \
+      "s_mul_i32 %[t1], %[i], %[edel]\n\t" \
+      "s_sub_i32 %[t1], %[u0], %[t1]\n\t" \
+      "s_max_i32 %[t1], %[t1], %[qa]\n\t" \
+      "s_lshl_b32 %[t2], %[t1], 7\n\t" \
+      "s_or_b32 %[t2], %[t2], 127\n\t" \
+      "s_cmp_le_i32 %[t2], %[mxhi]\n\t" \
+      "s_cbranch_scc0 L_ttgo" SFX "_%=\n\t" \
+      "s_add_i32 %[t1], %[t1], 1\n\t" \
+      "s_lshl_b32 %[t1], %[t1], 16\n\t" \
+      "s_cmp_le_i32 %[t1], %[gskey]\n\t" \
+      "s_cbranch_scc1 L_fdone_%=\n\t" \
+      "L_ttgo" SFX "_%=:\n\t"
+#define ROWS1F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
       "L_frow" SFX "_%=:\n\t" \
+      TAILTOP \
       "v_readlane_b32 %[t], %[vTS], %[i]\n\t"  /* 8 * target base of row i */ \
       "s_sub_i32 %[span], %[end], %[beg]\n\t" \
       "s_cmp_lt_i32 %[span], 1\n\t" \
@@ -454,15 +470,14 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "L_fbound" SFX "_%=:\n\t" \
       "s_add_i32 %[t1], %[beg], %[w1]\n\t"  /* rows up to beg + w: the left clamp cannot bind */ \
       "s_min_i32 %[hardend], %[rowend], %[t1]\n\t" \
-      "s_min_i32 %[hardend], %[hardend], %[itail]\n\t" \
+      TAIL_MIN \
       PHASE_MIN \
       "s_cmp_lt_i32 %[i], %[hardend]\n\t" \
       "s_cbranch_scc1 L_fwin" SFX "_%=\n\t" \
       /* no row to run: the end of the target chunk, the query end, the end of the phase, or the clamp */ \
       "s_cmp_ge_i32 %[i], %[rowend]\n\t" \
       "s_cbranch_scc1 L_fchunk" SFX "_%=\n\t" \
-      "s_cmp_ge_i32 %[i], %[itail]\n\t" \
-      "s_cbranch_scc1 L_ftotail_%=\n\t" \
+      TAIL_SWITCH \
       PHASE_SWITCH \
       "s_branch L_ftogen_%=\n\t" \
       "L_fchunk" SFX "_%=:\n\t"  /* the next 64 target rows, when row i starts a chunk that holds no N */ \
@@ -529,21 +544,24 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "s_cmp_lt_i32 %[mkey], 128\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t"  /* m == 0                                SWUtil.scala:184-185 */ \
       "s_and_b32 %[mj], %[mkey], 127\n\t" \
-      "s_cmp_lt_i32 %[zdrop], 1\n\t" \
-      "s_cbranch_scc1 L_ftrim" SFX "_%=\n\t" \
-      /* SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse): k = (i - max_i) - (mj - max_j), X = max - m */ \
+      /* SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse): k = (i - max_i) - (mj - max_j), X = max - m.  First a */ \
+      /* test every stop passes -- X + k * eIns > zdrop (Scala: that IS its test once k > 0) / X > zdrop (BWA: both its tests take */ \
+      /* something off X) -- which nearly every row fails; zlim = zdrop, or a value no score reaches when the z-drop is off */ \
       "s_add_i32 %[mja], %[mj], %[base]\n\t" \
       "s_sub_i32 %[t1], %[i], %[maxi]\n\t" \
       "s_sub_i32 %[t2], %[mja], %[maxj]\n\t" \
       "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* k */ \
-      "s_lshr_b32 %[m], %[mkey], 7\n\t" \
-      "s_lshr_b32 %[t2], %[mxhi], 7\n\t" \
-      "s_sub_i32 %[t2], %[t2], %[m]\n\t"  /* X */ \
+      "s_sub_i32 %[t2], %[mxhi], %[mkey]\n\t" \
+      "s_lshr_b32 %[t2], %[t2], 7\n\t"  /* X (the low 7 bits of mxhi are all ones: no borrow from the column) */ \
+      "s_mul_i32 %[t4], %[t1], %[zc1]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zlim]\n\t" \
+      "s_cbranch_scc0 L_ftrim" SFX "_%=\n\t" \
       "s_cmp_gt_i32 %[t1], 0\n\t" \
       "s_cbranch_scc0 L_fzneg" SFX "_%=\n\t" \
       "s_mul_i32 %[t4], %[t1], %[zpos]\n\t" \
       "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
-      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zlim]\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t" \
       "s_branch L_ftrim" SFX "_%=\n\t" \
       "L_fzneg" SFX "_%=:\n\t" \
@@ -551,18 +569,24 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "s_cbranch_scc1 L_ftrim" SFX "_%=\n\t" \
       "s_mul_i32 %[t4], %[t1], %[eins]\n\t" \
       "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
-      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zlim]\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t" \
       "s_branch L_ftrim" SFX "_%=\n\t"
-#define ROWS1F_LIVE \
-  ROWS1F_TEXT("_l", "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", "v_max_i32 %[vT0], %[vA], %[vS]\n\t", \
+#define ROWS1F_LIVE_(SFX, DEADSFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
+  ROWS1F_TEXT(SFX, "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", "v_max_i32 %[vT0], %[vA], %[vS]\n\t", \
               "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %[vH], %[h1raw], m0\n\t", \
               "", "s_mov_b32 %[t3], %[beg]\n\t", "s_min_i32 %[hardend], %[hardend], %[ih1z]\n\t", \
-              "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_fbound_d_%=\n\t")
-#define ROWS1F_DEAD \
-  ROWS1F_TEXT("_d", "s_nop 0\n\t", "v_max3_i32 %[vT0], %[vA], %[vS], 0\n\t", \
+              "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_fbound" DEADSFX "_%=\n\t", TAIL_MIN, TAIL_SWITCH, TAILTOP)
+#define ROWS1F_DEAD_(SFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
+  ROWS1F_TEXT(SFX, "s_nop 0\n\t", "v_max3_i32 %[vT0], %[vA], %[vS], 0\n\t", \
               "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t", \
-              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "")
+              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "", TAIL_MIN, TAIL_SWITCH, TAILTOP)
+#define ROWSF_TAILMIN "s_min_i32 %[hardend], %[hardend], %[itail]\n\t"
+#define ROWS1F_ALL \
+  ROWS1F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_lt_%=\n\t", "") \
+  ROWS1F_DEAD_("_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_dt_%=\n\t", "") \
+  ROWS1F_LIVE_("_lt", "_dt", "", "", ROWSF_TAILTEST("_lt")) \
+  ROWS1F_DEAD_("_dt", "", "", ROWSF_TAILTEST("_dt"))
 // all the instantiations in one statement (two statements under a branch make the compiler route the scalar state through VGPRs):
 // sel 0 = the general loop (ROWS1_TEXT, with or without the tail-row test), 1 = the fast loop in its LIVE phase, 2 = DEAD.
 // Every read-write operand is early-clobber: an input that happens to hold the same value (end and qLen on row 0) must not share
@@ -574,14 +598,17 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "s_cbranch_scc1 L_fbound_l_%=\n\t" \
       "s_cmp_eq_u32 %[sel], 2\n\t" \
       "s_cbranch_scc1 L_fbound_d_%=\n\t" \
+      "s_cmp_eq_u32 %[sel], 3\n\t" \
+      "s_cbranch_scc1 L_fbound_lt_%=\n\t" \
+      "s_cmp_eq_u32 %[sel], 4\n\t" \
+      "s_cbranch_scc1 L_fbound_dt_%=\n\t" \
       "s_cmp_eq_u32 %[tailrows], 0\n\t" \
       "s_cbranch_scc1 L_rowb_n_%=\n\t" \
       ROWS1_TEXT(ROWS_TAIL_TOP, "_t") \
       "s_branch L_end_%=\n\t" \
       ROWS1_TEXT("", "_n") \
       "s_branch L_end_%=\n\t" \
-      ROWS1F_LIVE \
-      ROWS1F_DEAD \
+      ROWS1F_ALL \
       "L_ftotail_%=:\n\t"  /* the rows at and past the query end: the general loop with the tail-row test, in its own form of the state */ \
       "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
       "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
@@ -593,7 +620,7 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
       "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
       "s_mov_b32 %[form], 0\n\t" \
-      "s_branch L_row_n_%=\n\t" \
+      "s_branch L_row_t_%=\n\t"  /* (the instantiation with the tail-row test: it may run past the query end) */ \
       "L_fmore_%=:\n\t" \
       "s_mov_b32 %[reason], 1\n\t"  /* ROWS_MORE */ \
       "s_branch L_out_%=\n\t" \
@@ -613,7 +640,7 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       : [vLane] "v"(lane), [vNegC] "v"(vNegC), [vNEG] "v"(vNEG), [qlen] "s"(qLen), [tlen] "s"(s_tlen), [tsaddr] "s"(s_tsaddr), [ih1z] "s"(s_ih1z), \
         [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
         [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), [qa] "s"(qa), \
-        [sel] "s"(s_sel), [profaddr] "s"(s_profaddr) \
+        [sel] "s"(s_sel), [profaddr] "s"(s_profaddr), [zc1] "s"(s_zc1), [zlim] "s"(s_zlim) \
       : "vcc", "scc", "memory");  /* (M0 is written too: the compiler never keeps a value in it across statements on gfx9) */
 // sel: 0 the general loop over [i, row_end), 1 / 2 the fast loop (LIVE / DEAD phase of h1) over [i, fast_end) under the preconditions
 // listed at ROWS1F_TEXT, which the caller (sw_extend_adaptive) establishes
@@ -636,6 +663,7 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
   // z-drop of a row that did not improve: k = (i - max_i) - (mj - max_j), X = max - m.  k > 0: X + k * zpos > zdrop with zpos = eIns
   // (Scala parse: its B || C is C) or -eDel (BWA parse: B); k <= 0: the BWA parse alone tests X + k * eIns (zdrop_stop)
   const int s_zpos = uni(zmode == BPSW_ZDROP_SCALA ? eIns : -eDel), s_zneg = uni(zmode == BPSW_ZDROP_SCALA ? 0 : 1);
+  const int s_zc1 = uni(zmode == BPSW_ZDROP_SCALA ? eIns : 0), s_zlim = uni(zdrop > 0 ? zdrop : 0x3fffffff);  // the fast loops' first z-drop test
   int reason, s_fastend, s_hardend, s_form;
   int s_rowend = row_end;  // (the fast loop fetches the next chunk of target rows itself)
   int vS, vA, vG, vK, vT0;
@@ -864,19 +892,25 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
 // the column left of the band hands on a 0 by itself -- to an even column through the lane shift (the odd column of the lane
 // below), to an odd column as the even column of its own lane.  gscore reads column qLen - 1 out of the shifted row, whose lane and
 // parity in the window (gsl, gsp) only change when the window moves.
-#define ROWS2F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH) \
+#define ROWS2F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH, BAND_EXTRA, SAME_BAND, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
+      /* the band's set-up: only when the band has changed (in the LIVE phase a row without a zero cell leaves beg where it is, and */ \
+      /* end as well once it has reached the query end -- most rows of a flank whose score is high) */ \
       "L_g2row" SFX "_%=:\n\t" \
-      "v_readlane_b32 %[t], %[vTS], %[i]\n\t" \
       "s_sub_i32 %[span], %[end], %[beg]\n\t" \
       "s_cmp_lt_i32 %[span], %[narrow1]\n\t" \
       "s_cbranch_scc1 L_fslow_%=\n\t"  /* an empty band, or one that fits one column per lane again */ \
       "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
-      "v_bfe_i32 %[vS0], %[vP0], %[t], 8\n\t" \
-      "v_bfe_i32 %[vS1], %[vP1], %[t], 8\n\t" \
       "v_subrev_u32 %[vT0], m0, %[vL2]\n\t"  /* rel0 = 2 lane - rbeg */ \
       "v_add_u32 %[vT1], 1, %[vT0]\n\t"  /* rel1 */ \
       "v_cmp_gt_u32 %[act0], %[span], %[vT0]\n\t" \
       "v_cmp_gt_u32 %[act1], %[span], %[vT1]\n\t" \
+      BAND_EXTRA \
+      "L_g2body" SFX "_%=:\n\t" \
+      TAILTOP \
+      "v_readlane_b32 %[t], %[vTS], %[i]\n\t" \
+      "s_nop 1\n\t" \
+      "v_bfe_i32 %[vS0], %[vP0], %[t], 8\n\t" \
+      "v_bfe_i32 %[vS1], %[vP1], %[t], 8\n\t" \
       "v_add_u32 %[vA0], %[vH0], %[vS0]\n\t" \
       "v_add_u32 %[vA1], %[vH1], %[vS1]\n\t" \
       "v_max_i32 %[vA0], %[vA0], %[vE0]\n\t" \
@@ -957,6 +991,7 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
       "s_or_b64 %[u64], %[z0], %[z1]\n\t"  /* SCC = the band has a zero cell */ \
       "s_cbranch_scc1 L_g2zero" SFX "_%=\n\t" \
       NB0_NOZERO \
+      SAME_BAND \
       "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
       "s_addc_u32 %[end], %[end], 0\n\t"  /* end = min(end + 1, qLen) */ \
       "L_g2next" SFX "_%=:\n\t" \
@@ -967,15 +1002,14 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
       "L_g2bound" SFX "_%=:\n\t" \
       "s_add_i32 %[t1], %[beg], %[w1]\n\t"  /* rows up to beg + w: the left clamp cannot bind */ \
       "s_min_i32 %[hardend], %[rowend], %[t1]\n\t" \
-      "s_min_i32 %[hardend], %[hardend], %[itail]\n\t" \
+      TAIL_MIN \
       PHASE_MIN \
       "s_cmp_lt_i32 %[i], %[hardend]\n\t" \
       "s_cbranch_scc1 L_g2win" SFX "_%=\n\t" \
       /* no row to run: the end of the target chunk, the query end, the end of the phase, or the clamp */ \
       "s_cmp_ge_i32 %[i], %[rowend]\n\t" \
       "s_cbranch_scc1 L_g2chunk" SFX "_%=\n\t" \
-      "s_cmp_ge_i32 %[i], %[itail]\n\t" \
-      "s_cbranch_scc1 L_ftotail_%=\n\t" \
+      TAIL_SWITCH \
       PHASE_SWITCH \
       "s_branch L_ftogen_%=\n\t" \
       "L_g2chunk" SFX "_%=:\n\t"  /* the next 64 target rows, when row i starts a chunk that holds no N */ \
@@ -1079,21 +1113,24 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
       "s_cmp_lt_i32 %[mkey], 128\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t"  /* m == 0                                SWUtil.scala:184-185 */ \
       "s_and_b32 %[mj], %[mkey], 127\n\t" \
-      "s_cmp_lt_i32 %[zdrop], 1\n\t" \
-      "s_cbranch_scc1 L_g2trim" SFX "_%=\n\t" \
-      /* SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse): k = (i - max_i) - (mj - max_j), X = max - m */ \
+      /* SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse): k = (i - max_i) - (mj - max_j), X = max - m.  First a */ \
+      /* test every stop passes -- X + k * eIns > zdrop (Scala: that IS its test once k > 0) / X > zdrop (BWA: both its tests take */ \
+      /* something off X) -- which nearly every row fails; zlim = zdrop, or a value no score reaches when the z-drop is off */ \
       "s_add_i32 %[mja], %[mj], %[base]\n\t" \
       "s_sub_i32 %[t1], %[i], %[maxi]\n\t" \
       "s_sub_i32 %[t2], %[mja], %[maxj]\n\t" \
       "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* k */ \
-      "s_lshr_b32 %[m], %[mkey], 7\n\t" \
-      "s_lshr_b32 %[t2], %[mxhi], 7\n\t" \
-      "s_sub_i32 %[t2], %[t2], %[m]\n\t"  /* X */ \
+      "s_sub_i32 %[t2], %[mxhi], %[mkey]\n\t" \
+      "s_lshr_b32 %[t2], %[t2], 7\n\t"  /* X (the low 7 bits of mxhi are all ones: no borrow from the column) */ \
+      "s_mul_i32 %[t4], %[t1], %[zc1]\n\t" \
+      "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zlim]\n\t" \
+      "s_cbranch_scc0 L_g2trim" SFX "_%=\n\t" \
       "s_cmp_gt_i32 %[t1], 0\n\t" \
       "s_cbranch_scc0 L_g2zneg" SFX "_%=\n\t" \
       "s_mul_i32 %[t4], %[t1], %[zpos]\n\t" \
       "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
-      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zlim]\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t" \
       "s_branch L_g2trim" SFX "_%=\n\t" \
       "L_g2zneg" SFX "_%=:\n\t" \
@@ -1101,26 +1138,39 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
       "s_cbranch_scc1 L_g2trim" SFX "_%=\n\t" \
       "s_mul_i32 %[t4], %[t1], %[eins]\n\t" \
       "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
-      "s_cmp_gt_i32 %[t4], %[zdrop]\n\t" \
+      "s_cmp_gt_i32 %[t4], %[zlim]\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t" \
       "s_branch L_g2trim" SFX "_%=\n\t"
-#define ROWS2F_LIVE \
-  ROWS2F_TEXT("_l", "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", \
+#define ROWS2F_LIVE_(SFX, DEADSFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
+  ROWS2F_TEXT(SFX, "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", \
               "v_max_i32 %[vA0], %[vA0], %[vS0]\n\tv_max_i32 %[vA1], %[vA1], %[vS1]\n\t", \
               "v_mov_b32 %[vh1], %[h1raw]\n\t" \
               "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-              "v_cmp_eq_u32 vcc, 0, %[vT0]\n\t" \
-              "v_cndmask_b32 %[vH0], %[vH0], %[vh1], vcc\n\t" \
-              "v_cmp_eq_u32 vcc, 0, %[vT1]\n\t" \
-              "v_cndmask_b32 %[vH1], %[vA0], %[vh1], vcc\n\t", \
+              "v_cndmask_b32 %[vH1], %[vA0], %[vh1], %[inj1]\n\t" \
+              "v_cndmask_b32 %[vH0], %[vH0], %[vh1], %[inj0]\n\t", \
               "", "s_mov_b32 %[t3], %[beg]\n\t", "s_min_i32 %[hardend], %[hardend], %[ih1z]\n\t", \
-              "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_g2bound_d_%=\n\t")
-#define ROWS2F_DEAD \
-  ROWS2F_TEXT("_d", "", \
+              "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_g2bound" DEADSFX "_%=\n\t", \
+              /* the lanes that take eh[beg].h = h1: column beg is an even or an odd one */ \
+              "v_cmp_eq_u32 %[inj0], 0, %[vT0]\n\tv_cmp_eq_u32 %[inj1], 0, %[vT1]\n\t", \
+              /* end at the query end, beg untouched: the next row's band is this row's */ \
+              "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
+              "s_cbranch_scc1 L_g2grow" SFX "_%=\n\t" \
+              "s_add_i32 %[i], %[i], 1\n\t" \
+              "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
+              "s_cbranch_scc1 L_g2body" SFX "_%=\n\t" \
+              "s_branch L_g2bound" SFX "_%=\n\t" \
+              "L_g2grow" SFX "_%=:\n\t", TAIL_MIN, TAIL_SWITCH, TAILTOP)
+#define ROWS2F_DEAD_(SFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
+  ROWS2F_TEXT(SFX, "", \
               "v_max3_i32 %[vA0], %[vA0], %[vS0], 0\n\tv_max3_i32 %[vA1], %[vA1], %[vS1], 0\n\t", \
               "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
               "v_mov_b32 %[vH1], %[vA0]\n\t", \
-              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "")
+              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "", "", "", TAIL_MIN, TAIL_SWITCH, TAILTOP)
+#define ROWS2F_ALL \
+  ROWS2F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_g2bound_lt_%=\n\t", "") \
+  ROWS2F_DEAD_("_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_g2bound_dt_%=\n\t", "") \
+  ROWS2F_LIVE_("_lt", "_dt", "", "", ROWSF_TAILTEST("_lt2")) \
+  ROWS2F_DEAD_("_dt", "", "", ROWSF_TAILTEST("_dt2"))
 // all the instantiations in one statement, as ROWS1_ASM: sel 0 = the general loop, 1 = the fast loop in its LIVE phase, 2 = DEAD
 #define ROWS2_ASM \
   asm volatile( \
@@ -1129,14 +1179,17 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
       "s_cbranch_scc1 L_g2bound_l_%=\n\t" \
       "s_cmp_eq_u32 %[sel], 2\n\t" \
       "s_cbranch_scc1 L_g2bound_d_%=\n\t" \
+      "s_cmp_eq_u32 %[sel], 3\n\t" \
+      "s_cbranch_scc1 L_g2bound_lt_%=\n\t" \
+      "s_cmp_eq_u32 %[sel], 4\n\t" \
+      "s_cbranch_scc1 L_g2bound_dt_%=\n\t" \
       "s_cmp_eq_u32 %[tailrows], 0\n\t" \
       "s_cbranch_scc1 L_rowb_n_%=\n\t" \
       ROWS2_TEXT(ROWS_TAIL_TOP, "_t") \
       "s_branch L_end_%=\n\t" \
       ROWS2_TEXT("", "_n") \
       "s_branch L_end_%=\n\t" \
-      ROWS2F_LIVE \
-      ROWS2F_DEAD \
+      ROWS2F_ALL \
       "L_ftotail_%=:\n\t"  /* the rows at and past the query end: the general loop with the tail-row test, in its own form of the state */ \
       "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
       "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
@@ -1148,7 +1201,7 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
       "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
       "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
       "s_mov_b32 %[form], 0\n\t" \
-      "s_branch L_row_n_%=\n\t" \
+      "s_branch L_row_t_%=\n\t"  /* (the instantiation with the tail-row test: it may run past the query end) */ \
       "L_fmore_%=:\n\t" \
       "s_mov_b32 %[reason], 1\n\t"  /* ROWS_MORE */ \
       "s_branch L_end_%=\n\t" \
@@ -1166,11 +1219,11 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
         [vA1] "=&v"(vA1), [vG0] "=&v"(vG0), [vG] "=&v"(vG), [vK] "=&v"(vK), [vT0] "=&v"(vT0), [vT1] "=&v"(vT1), [vh1] "=&v"(vh1), \
         [t] "=&s"(t), [h1] "=&s"(h1), [span] "=&s"(span), [mkey] "=&s"(mkey), [m] "=&s"(m), [mj] "=&s"(mj), [mja] "=&s"(mja), \
         [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [t5] "=&s"(t5), [t6] "=&s"(t6), [act0] "=&s"(act0), \
-        [act1] "=&s"(act1), [z0] "=&s"(z0), [z1] "=&s"(z1), [u64] "=&s"(u64) \
+        [act1] "=&s"(act1), [z0] "=&s"(z0), [z1] "=&s"(z1), [u64] "=&s"(u64), [inj0] "=&s"(inj0), [inj1] "=&s"(inj1) \
       : [vL2] "v"(vL2), [vL2p1] "v"(vL2p1), [vLane] "v"(lane), [vNegC] "v"(vNegC), [vNegC1] "v"(vNegC1), [vNEG] "v"(vNEG), \
         [qlen] "s"(qLen), [tlen] "s"(s_tlen), [tsaddr] "s"(s_tsaddr), [ih1z] "s"(s_ih1z), [w] "s"(w), [w1] "s"(s_w1), [edel] "s"(eDel), [oedel] "s"(oeDel), [nkc] "s"(s_nkc), \
         [nkc1] "s"(s_nkc1), [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), \
-        [qa] "s"(qa), [narrow1] "s"(ROWS_NARROW + 1), [sel] "s"(s_sel), [profaddr] "s"(s_profaddr) \
+        [qa] "s"(qa), [narrow1] "s"(ROWS_NARROW + 1), [sel] "s"(s_sel), [profaddr] "s"(s_profaddr), [zc1] "s"(s_zc1), [zlim] "s"(s_zlim) \
       : "vcc", "scc", "memory");  /* (M0 is written too) */
 __device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int qLen, const int row_end, int& vTS, const int w,
                                          const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
@@ -1189,11 +1242,12 @@ __device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int
   int s_base = st.base, s_gsl = (qLen - st.base) >> 1, s_gsp = (qLen - st.base) & 1;  // column qLen of the shifted row: lane, parity
   const int s_w1 = w + 1, s_nkc = eIns - oeIns, s_nkc1 = -oeIns;
   const int s_zpos = uni(zmode == BPSW_ZDROP_SCALA ? eIns : -eDel), s_zneg = uni(zmode == BPSW_ZDROP_SCALA ? 0 : 1);
+  const int s_zc1 = uni(zmode == BPSW_ZDROP_SCALA ? eIns : 0), s_zlim = uni(zdrop > 0 ? zdrop : 0x3fffffff);  // the fast loops' first z-drop test
   int reason, s_fastend, s_hardend, s_form;
   int s_rowend = row_end;
   int vS0, vS1, vA0, vA1, vG0, vG, vK, vT0, vT1, vh1;
   int t, h1, span, mkey, m, mj, mja, t1, t2, t3, t4, t5, t6;
-  unsigned long long act0, act1, z0, z1, u64;
+  unsigned long long act0, act1, z0, z1, u64, inj0, inj1;
   // (the general loop exists twice in the statement: the rows below the query end need no tail-row test at their top)
   const int s_tailrows = uni((int)tail_rows), s_sel = uni(sel), s_profaddr = uni((int)prof_addr), s_tlen = uni(tLen),
             s_ih1z = uni(i_h1z), s_tsaddr = uni((int)ts_addr);
@@ -1210,7 +1264,8 @@ __device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int
 
 // Where the assembly loop may run to from row i: the end of the 64-row target chunk it has in a register (reloaded here when i has
 // left it), the last target row, the first N row (the loops have no N-row path: a mask of the chunk's N rows replaces a test per row),
-// and the first row at the query end when i is still before it (the instantiation without the tail-row test serves those rows).
+// (and, for the general loop, the caller adds the first row at the query end when i is still before it: the instantiation without
+// the tail-row test serves those rows).
 __device__ __forceinline__ int rows_asm_end(const int i, const int tLen, const int i_tail, const uint8_t* __restrict__ ts, const int lane,
                                             int* vTS, int* ts_chunk, unsigned long long* n_rows) {
   if ((i >> 6) != *ts_chunk) {  // 8 * target base of the 64 rows around row i, one per lane
@@ -1222,7 +1277,7 @@ __device__ __forceinline__ int rows_asm_end(const int i, const int tLen, const i
   int end = min(tLen, (*ts_chunk + 1) << 6);
   const unsigned long long ahead = *n_rows >> (i & 63);
   if (ahead) end = min(end, i + (int)__builtin_ctzll(ahead));
-  if (i < i_tail) end = min(end, i_tail);
+  // (the caller caps this at the query end for the general loop without the tail-row test; the fast loops change over themselves)
   return uni(end);
 }
 
@@ -1279,8 +1334,10 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
         st.beg = smax2(st.beg, st.i - w);
         st.end = smin2(smin2(st.end, st.i + w + 1), qLen);
         const bool live = st.i < i_h1z;
-        const int sel = uni((BPSW_EXT_ROWS_FAST && st.i < i_tail && st.beg + w + 1 > st.i) ? (live ? 1 : 2) : 0);
-        r = rows1_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail, sel, tLen, i_h1z, ts_addr, pl.addr);
+        // (the tail rows' bound U <= u0, qa must fit the loops' 16-bit forms of gscore)
+        const bool tail = st.i >= i_tail;
+        const int sel = uni((BPSW_EXT_ROWS_FAST && st.beg + w + 1 > st.i && (!tail || (u0 < 30000 && qa < 30000))) ? (live ? 1 : 2) + (tail ? 2 : 0) : 0);
+        r = rows1_asm(st, lane, qLen, (sel == 0 && !tail) ? smin2(row_end, i_tail) : row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail, sel, tLen, i_h1z, ts_addr, pl.addr);
         if (r == ROWS_MORE) continue;
       }
       if (r == ROWS_SLOW)
@@ -1306,8 +1363,10 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
         st.beg = smax2(st.beg, st.i - w);  // (as for the one-column loop above)
         st.end = smin2(smin2(st.end, st.i + w + 1), qLen);
         const bool live = st.i < i_h1z;
-        const int sel = uni((BPSW_EXT_ROWS_FAST && st.i < i_tail && st.beg + w + 1 > st.i) ? (live ? 1 : 2) : 0);
-        r = rows2_asm(st, lane, qLen, row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail, sel, tLen, i_h1z, ts_addr, pl.addr);
+        // (the tail rows' bound U <= u0, qa must fit the loops' 16-bit forms of gscore)
+        const bool tail = st.i >= i_tail;
+        const int sel = uni((BPSW_EXT_ROWS_FAST && st.beg + w + 1 > st.i && (!tail || (u0 < 30000 && qa < 30000))) ? (live ? 1 : 2) + (tail ? 2 : 0) : 0);
+        r = rows2_asm(st, lane, qLen, (sel == 0 && !tail) ? smin2(row_end, i_tail) : row_end, vTS, w, eDel, oeDel, oeIns, eIns, zdrop, zmode, i_tail, u0, qa, st.i >= i_tail, sel, tLen, i_h1z, ts_addr, pl.addr);
         if (r == ROWS_MORE) continue;
       }
       if (r == ROWS_SLOW)

@@ -765,7 +765,10 @@ constexpr int PK_KEY_PAD = 128;        // steps past the last target row: pipe d
 constexpr int PK_KEYS_LDS_MAX = 1536;  // rows; 4 waves x (1536 + 128) words = 26 KB per workgroup
 template <int C, bool KL>
 // (five waves per SIMD for up to three columns per lane: 91 VGPRs without a spill instead of 97; more columns keep four)
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? 5 : 4) void swp_kernel(const SwJobsDev jobs, const SwScoring sc, const int bias,
+#ifndef BPSW_SWP_WAVES
+#define BPSW_SWP_WAVES 5
+#endif
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) void swp_kernel(const SwJobsDev jobs, const SwScoring sc, const int bias,
                                                                      int32_t* __restrict__ out,
                                                                      uint32_t* __restrict__ scratch,
                                                                      const int scratch_per_job,
