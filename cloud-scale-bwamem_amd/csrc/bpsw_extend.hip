@@ -17,7 +17,7 @@
 // flanks of low-error reads -- for large batches of short flanks in a kernel of their own in front of this one (bpsw_extend_sift.hip:
 // one task per lane), which leaves a flag and a verdict per side here (sift_flag, sift_recs).  Three builds (ext_kernel<COORD, SHORT>): two 48-VGPR ones at eight waves per SIMD for flanks up to
 // 127 / 255 bases, and the full one (slot sweeps for wide-band retries, an LDS-row sweep for flanks above 255 bases) for what
-// the host lists or the window build defers.
+// the host lists or the short build defers.
 #include <stdlib.h>
 
 #include <atomic>
@@ -63,15 +63,17 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 #endif
 // COORD: a coordinate batch (include/bpsw.h, "wire format 2") -- 40-byte task records, query flanks only, the target flanks are
 // read from the device-resident reference (bnsGetSeq of MemChainToAlignBatched.scala:363 moves to the device).
-// SHORT: the kernel for tasks whose two query flanks have at most `short_qmax` bases (127: every task of 2x150 bp reads but a few;
-// 255: also nearly every task of 2x250 bp reads).  It carries only the lean sweeps (one / two columns per lane, the sliding
-// window) and the shortcuts, needs 48 VGPRs instead of 87 and no LDS but the target bytes, so eight of its waves share a SIMD: a
-// wave of this kernel is bound by the latency of its row (1 200 cycles alone on a SIMD), and the rows of more waves fill each
-// other's gaps.  It skips longer tasks: the host, which has seen every record (scan_wire), lists those for the full kernel.  A
-// task that turns out to need what this kernel lacks -- a band wider than the 128-column window, on its first row (the doubled
-// band of a retry) or later -- is DEFERRED: appended to the same list (defer[0] = entries so far, defer[1..] = task indices),
-// which the full kernel, launched behind this one on the stream, reads its task count from.
-// SHORT: 0 the full kernel; 1 flanks up to 127 bases (no window: the leanest build, what 2x150 bp batches run on); 2 up to 255
+// SHORT = 1: the kernel for tasks whose two query flanks have at most `short_qmax` bases (255: nearly every task of 2x150 and 2x250 bp
+// reads).  It carries only the adaptive sweep (bpsw_extend_rows.h: one / two columns per lane on a window that follows the band,
+// row loops in assembly) and the shortcuts, needs 64 VGPRs instead of 87 and little LDS (the target bytes and the call's query
+// profile), so eight of its waves share a SIMD.  It skips longer tasks: the host, which has seen every record (scan_wire), lists
+// those for the full kernel.  A task that turns out to need what this kernel lacks -- a band wider than the 128-column window, on
+// its first row (the doubled band of a retry) or later: only possible with a flank of 128 bases or more -- is DEFERRED: appended to
+// the same list (defer[0] = entries so far, defer[1..] = task indices), which the full kernel, launched behind this one on the
+// stream, reads its task count from.  (Rounds 2-3 had two such builds, one for flanks up to 127 bases without the window; since
+// the adaptive sweep of round 3 they were the same code, and round 4 made them one: 2x150 bp batches no longer send their few
+// flanks of 128-131 bases through a full-kernel launch of their own.)
+// SHORT = 0: the full kernel (slot sweeps for wide bands, an LDS-row sweep for flanks above 255 bases).
 template <bool COORD, int SHORT>
 #ifndef BPSW_EXT_SHORT_WAVES_PER_SIMD
 #define BPSW_EXT_SHORT_WAVES_PER_SIMD 8
@@ -84,8 +86,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
                                                                      const int* __restrict__ task_list_arg,
                                                                      const ExtPrepass* __restrict__ pre,
                                                                      int* __restrict__ defer, const int short_qmax,
-                                                                     uint8_t* __restrict__ qflag, uint4* __restrict__ qcarry,
-                                                                     const int quad_qmax, const uint8_t* __restrict__ sift_flag,
+                                                                     const uint8_t* __restrict__ sift_flag,
                                                                      const uint4* __restrict__ sift_recs) {
   extern __shared__ __align__(16) unsigned char smem[];
   // the full kernel behind a SHORT launch: its task list and count are what the host listed plus what that launch deferred
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
     // what the sift kernel (bpsw_extend_sift.hip: the shortcuts, one task per lane) left for this task: 1 = its record is written,
     // 2 = a record per side in sift_recs, 0 = nothing
     int sifted = 0;
-    if (SHORT == 1 && sift_flag) {
+    if (SHORT && sift_flag) {
       sifted = uni((int)sift_flag[task]);
       if (sifted == 1) continue;
     }
@@ -162,12 +163,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
     // short_qmax < 0 (the asynchronous device entry, where no host has seen the records): nobody has listed the tasks this build
     // cannot take -- a flank above -short_qmax bases, or any task when the gap costs rule out the register sweeps -- so it defers
     // them itself; short_qmax > 0: the host has listed them for the full kernel
-    bool deferred = false, handed = false;
+    bool deferred = false;
     if (SHORT) {
       const int qm = short_qmax < 0 ? -short_qmax : short_qmax;
-      const bool too_long = lq > qm || rq > qm || (SHORT == 2 && short_qmax < 0 && oIns + eIns <= 0);
+      const bool too_long = lq > qm || rq > qm || (short_qmax < 0 && oIns + eIns <= 0);
       if (too_long) {
-        if (SHORT == 2 && short_qmax < 0) {
+        if (short_qmax < 0) {
           if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
         }
         continue;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
       };
       bool exact_v;
       int judged = 0;  // 1: the sift kernel found that no form holds, 2: that one does for this start score
-      if (SHORT == 1 && sifted == 2) {
+      if (SHORT && sifted == 2) {
         const uint4 sr = sift_recs[2 * (size_t)task + side];
         const int kind = uni((int)(sr.x & 0xffu)), hmin = uni((int)sr.x >> 8);
         if (kind == 1) judged = 1;
@@ -226,15 +227,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
       // wave-uniform by construction (the shortcuts decide on wave reductions), but not to the compiler: without this the DP below
       // sits in what it takes for divergent control flow and its whole scalar state is kept in vector registers
       const bool exact = uni(exact_v ? 1 : 0) != 0;
-      // A flank that needs the DP goes to the quad kernel (bpsw_extend_quad.hip: four flanks per wavefront), with what extension()
-      // has computed so far, when it -- and, from the left flank, the right one as well -- fits that kernel's columns.
-      if (SHORT && qflag && !exact && qLen <= quad_qmax && (side || rq <= quad_qmax)) {
-        if (side) store_lane0_b128(qcarry + task, make_uint4(((uint32_t)regScore & 0xffffu) | ((uint32_t)outQBeg << 16),
-                                                             ((uint32_t)outRBeg & 0xffffu) | ((uint32_t)trueScore << 16), (uint32_t)awMax, 0u));
-        store_lane0_b8(qflag + task, 1 + side);  // a plain store: no list, no atomic (bpsw_extend_quad.hip)
-        handed = true;
-        break;
-      }
       if (sc.side_how && lane == 0) sc.side_how[2 * (size_t)task + side] = exact ? 1 : 2;  // diagnostics only
       if (exact) {
         awSide = wBand;
@@ -260,9 +252,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
           int ov = 0;
 #if BPSW_EXT_ADAPTIVE
-          r = sw_extend_adaptive<SHORT == 2>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, pl, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+          r = sw_extend_adaptive(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, pl, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
 #else
-          r = sw_extend_reg_short<SHORT == 2>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+          r = sw_extend_reg_short<true>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
 #endif
           if (uni(ov)) { deferred = true; break; }
         } else if (reg_path) {
@@ -277,7 +269,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
         regScore = uni(r.max);
         if (regScore == prev || r.max_off < (awSide >> 1) + (awSide >> 2)) break;
       }
-      if (SHORT == 2 && deferred) break;
+      if (SHORT && deferred) break;
       score = regScore;
       awMax = max(awMax, awSide);
       const bool local = r.gscore <= 0 || r.gscore <= regScore - penClip;  // local extension vs reaching the query end
@@ -291,8 +283,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
         trueScore += (local ? regScore : r.gscore) - sc0;
       }
     }
-    if (SHORT && handed) continue;  // the quad kernel finishes the task and writes its record
-    if (SHORT == 2 && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
+    if (SHORT && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
+      // (a launch without a list serves flanks of at most 127 bases only, whose bands always fit the 128-column window: a band that
+      // does not fit there is a bug in the row loops, and must not pass for a result)
+      if (!defer) __builtin_trap();
       if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
       continue;
     }
@@ -359,14 +353,12 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev, bool short_kernel, int* d_defer,
-                             int short_qmax, uint8_t* d_qflag, uint4* d_qcarry, int quad_qmax, const uint8_t* d_sift_flag,
-                             const uint4* d_sift_recs) {
+                             int short_qmax, const uint8_t* d_sift_flag, const uint4* d_sift_recs) {
   if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
-  const int variant = !short_kernel ? 0 : ((short_qmax < 0 ? -short_qmax : short_qmax) <= 127 ? 1 : 2);
+  const int variant = short_kernel ? 1 : 0;
   const void* fn = variant == 0 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 0>) : reinterpret_cast<const void*>(ext_kernel<false, 0>))
-                 : variant == 1 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 1>) : reinterpret_cast<const void*>(ext_kernel<false, 1>))
-                                : (coord ? reinterpret_cast<const void*>(ext_kernel<true, 2>) : reinterpret_cast<const void*>(ext_kernel<false, 2>));
+                                : (coord ? reinterpret_cast<const void*>(ext_kernel<true, 1>) : reinterpret_cast<const void*>(ext_kernel<false, 1>));
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
   rcap = (rcap + 63) & ~63;
@@ -375,7 +367,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   const size_t lds = per_wave * WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device
-  static std::atomic<size_t> attr_set_v[6][64];
+  static std::atomic<size_t> attr_set_v[4][64];
   std::atomic<size_t>* attr_set = attr_set_v[(coord ? 1 : 0) + 2 * variant];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -413,12 +405,9 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
 #define BPSW_EXT_GO(CO, SH)                                                                                                     \
   BPSW_LAUNCH(kev, (ext_kernel<CO, SH>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap, rcap, \
-              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_qflag, d_qcarry, quad_qmax, \
-              d_sift_flag, d_sift_recs)
+              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_sift_flag, d_sift_recs)
   if (variant == 1) {
     if (coord) BPSW_EXT_GO(true, 1); else BPSW_EXT_GO(false, 1);
-  } else if (variant == 2) {
-    if (coord) BPSW_EXT_GO(true, 2); else BPSW_EXT_GO(false, 2);
   } else {
     if (coord) BPSW_EXT_GO(true, 0); else BPSW_EXT_GO(false, 0);
   }

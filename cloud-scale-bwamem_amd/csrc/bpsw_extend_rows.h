@@ -1281,9 +1281,9 @@ __device__ __forceinline__ int rows_asm_end(const int i, const int tLen, const i
   return uni(end);
 }
 
-// SWExtend on the adaptive window, for flanks of up to 255 bases (WINDOW) or 127 (no window: the band always fits two columns per
-// lane, and the layout still changes with the band).  *overflow = 1: a band wider than 128 columns, the task is not for this build.
-template <bool WINDOW, class QC>
+// SWExtend on the adaptive window, for flanks of up to 255 bases.  *overflow = 1: a band wider than 128 columns, the task is not for
+// this build (flanks of at most 127 bases never get there).
+template <class QC>
 __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int tLen, const QC& qcode, const uint8_t* __restrict__ ts,
                                      const ProfLds& pl, const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w,
                                      const int zdrop, const int zmode, const int h0, const int amax, int* __restrict__ overflow) {
@@ -1390,7 +1390,6 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
     }
     if (r == ROWS_DONE) break;
   }
-  (void)WINDOW;
   ExtRes res;
   res.max = st.mx; res.qle = st.max_j + 1; res.tle = st.max_i + 1; res.gtle = st.max_ie + 1; res.gscore = st.gscore; res.max_off = st.max_off;
   return res;

@@ -88,7 +88,10 @@ constexpr int SIFT_T_WORDS = 21;  // a coordinate task's staged target flank: 12
 template <bool COORD>
 __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict__ wire, const int n_tasks, int16_t* __restrict__ out,
                                                       const ExtScoring sc, const int dm, const int qmax, uint8_t* __restrict__ flag,
-                                                      uint4* __restrict__ recs) {
+                                                      uint4* __restrict__ recs, const ExtPrepass* __restrict__ pre) {
+  // asynchronous entry (bpsw_extend_batch_device): the table scan ran just before on the same stream and nobody has read it back
+  // yet -- a malformed batch is left untouched (ext_kernel behind this launch does the same and never looks at the flags)
+  if (pre && pre->error != 0) return;
   __shared__ uint32_t raw[SIFT_RAW_WORDS + 4 + (COORD ? 2 * 64 * SIFT_T_WORDS : 0)];
   constexpr int T_BASE = SIFT_RAW_WORDS + 4;  // COORD: the target flank of (side, lane) at T_BASE + (side * 64 + lane) * SIFT_T_WORDS
   __shared__ int items[128 * 8];   // the flanks whose closed form waits for its certificate: query stream, qs | ts << 8, target stream, n | tLen << 8, k, p0, p1, p2
@@ -257,11 +260,11 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
 }  // namespace
 
 hipError_t launch_ext_sift_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int dm, int qmax,
-                                  uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev) {
+                                  uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev, const ExtPrepass* d_pre_check) {
   if (n_tasks <= 0) return hipSuccess;
   const int blocks = (n_tasks + 63) / 64;
-  if (sc.pac) BPSW_LAUNCH(kev, ext_sift_kernel<true>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs);
-  else BPSW_LAUNCH(kev, ext_sift_kernel<false>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs);
+  if (sc.pac) BPSW_LAUNCH(kev, ext_sift_kernel<true>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs, d_pre_check);
+  else BPSW_LAUNCH(kev, ext_sift_kernel<false>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs, d_pre_check);
   return hipGetLastError();
 }
 

@@ -84,21 +84,15 @@ size_t ext_lds_per_wave(int qcap, int rcap);
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false, KernelEvents kev = KernelEvents(),
-                             bool short_kernel = false, int* d_defer = nullptr, int short_qmax = 127, uint8_t* d_qflag = nullptr,
-                             uint4* d_qcarry = nullptr, int quad_qmax = 0, const uint8_t* d_sift_flag = nullptr,
-                             const uint4* d_sift_recs = nullptr);
+                             bool short_kernel = false, int* d_defer = nullptr, int short_qmax = 255,
+                             const uint8_t* d_sift_flag = nullptr, const uint4* d_sift_recs = nullptr);
 // The sift kernel (bpsw_extend_sift.hip): the exact shortcuts of every task of a format-1 batch, one task per lane, in front of
 // the 48-VGPR ext_kernel, which reads d_flag[task] (1: record written, skip; 2: d_recs[2 task + side] holds the verdict per side).
 // dm = a - (the one mismatch score of the matrix), sift_uniform_dm(); qmax = the longest flank the 48-VGPR build takes.
 hipError_t launch_ext_sift_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int dm, int qmax,
-                                  uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev = KernelEvents());
+                                  uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev = KernelEvents(),
+                                  const ExtPrepass* d_pre_check = nullptr);
 int sift_uniform_dm(const int8_t mat[25], int exact_a);  // > 0 when all twelve base-vs-other-base entries equal exact_a - dm, else 0
-// d_qflag / d_qcarry (48-VGPR builds only): the flanks that need the DP and have at most quad_qmax bases are handed to the quad
-// kernel (bpsw_extend_quad.hip) instead of being swept here: d_qflag[task] = 1 + side (zero at launch; the quad kernel puts it back),
-// d_qcarry[task] = the state of extension() after a resolved left flank.
-hipError_t launch_ext_quad_kernel(int s_cols, const uint32_t* d_wire, size_t wire_words, uint8_t* d_qflag, const uint4* d_carry,
-                                  int n_hint, int n_tasks, int16_t* d_out, const ExtScoring& sc, int num_cu, int* d_counter,
-                                  hipStream_t s, KernelEvents kev = KernelEvents());
 // ---- local SW (boundary 1) ---------------------------------------------------------------------
 struct SwScoring {
   MatRows mat;
@@ -366,8 +360,6 @@ struct bpsw_ctx {
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
   bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
   bpsw::DeviceBuffer d_sift;  // the sift kernel's verdicts (bpsw_extend_sift.hip): [flag byte per task | two 16-byte records per task]
-  int quad_cap_n = 0;         // tasks the flag region of d_quad is sized for
-  bpsw::DeviceBuffer d_quad;  // the quad kernel's hand-over flags and carry records (bpsw_extend_quad.hip): [flag byte per task | carry]
   // asynchronous device entries: a launch whose table scan has not been read back yet (resolved by finish_pending)
   struct PendingExt { bool active = false; const void* d_wire = nullptr; size_t wire_bytes = 0; int n_tasks = 0; void* d_out = nullptr;
                       hipStream_t s = nullptr; int qcap = 0, rcap = 0; } pend_ext;

@@ -398,7 +398,7 @@ void bpsw_destroy(bpsw_ctx_t* c) {
   if (c->pend_sw.active && c->pend_sw.s) (void)hipStreamSynchronize(c->pend_sw.s);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
-  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release(); c->d_quad.release(); c->d_sift.release();
+  c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release(); c->d_sift.release();
   c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();
   rescue_scratch_free(c->rescue_scratch);
   for (int i = 0; i < 8; ++i)
@@ -556,22 +556,17 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   std::vector<int>& mid_tasks = c->ext_mid_tasks;
   int rc = scan_wire(wire, wire_bytes, l_pac, &n, &mq, &mr, &coord, &long_tasks, &mid_tasks, &mr_short, &n_mid);
   if (rc != BPSW_OK) return rc;
-  // A batch with few mid tasks (2x150 bp reads: the flanks of 128-131 bases) runs the build without the window, whose rows cost
-  // 4 % less, and lists its mid tasks for the full kernel like the long ones; a batch of mostly mid tasks (2x250 bp) runs the
-  // window build, which defers on the device.
-  static const long window_share = getenv("BPSW_EXT_WINDOW_SHARE") ? atol(getenv("BPSW_EXT_WINDOW_SHARE")) : 16;  // A/B switch
-  const bool window_build = (size_t)window_share * (size_t)n_mid > (size_t)n;
-  if (!window_build && n_mid > 0) {
-    long_tasks.insert(long_tasks.end(), mid_tasks.begin(), mid_tasks.end());
-    n_mid = 0;
-  }
+  // "mid" tasks (a query flank of 128-255 bases) run on the short kernel like the others; only they can meet a band wider than its
+  // 128-column window, in which case the kernel defers them to the full kernel on the device (bpsw_extend.hip)
+  (void)mid_tasks;
   const bool any_mid = n_mid > 0;
-  // Launch plan: the 48-VGPR kernel over the whole batch (it skips the long tasks) and the full kernel over the list of long
-  // ones -- or the full kernel alone when most tasks are long (2x250 bp reads) or the split is switched off (BPSW_EXT_SPLIT=0)
+  // Launch plan: the short kernel over the whole batch (it skips the long tasks: a flank above 255 bases) and the full kernel over
+  // the list of long ones plus what the short kernel defers -- or the full kernel alone when most tasks are long or the split is
+  // switched off (BPSW_EXT_SPLIT=0)
   static const bool split_on = !(getenv("BPSW_EXT_SPLIT") && atoi(getenv("BPSW_EXT_SPLIT")) == 0);
   const int n_long = (int)long_tasks.size();
   const bool use_short = split_on && 2 * (size_t)n_long <= (size_t)n;
-  const bool use_full = !use_short || n_long > 0 || any_mid;  // any_mid: the 48-VGPR kernel may defer tasks from the device
+  const bool use_full = !use_short || n_long > 0 || any_mid;  // any_mid: the short kernel may defer tasks from the device
   // behind the wire bytes: the full kernel's list as [count, task indices...]; the host stages its own entries and the count, the
   // 48-VGPR kernel appends (room for every task)
   const size_t list_off = (wire_bytes + 15) & ~(size_t)15;
@@ -588,31 +583,16 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   bool zc_slots = false;
   HIP_TRY(c->d_wire.reserve(dev_bytes));
   HIP_TRY(c->d_out.reserve(out_bytes));
-  // The quad kernel (bpsw_extend_quad.hip: four flanks per wavefront) can take the flanks whose shortcuts fail from the 48-VGPR
-  // kernel: a flag byte per task + carry records in a buffer of the context.  Opt-in (BPSW_EXT_QUAD=1): it sweeps a DP row in 80
-  // instructions instead of 134, but nearly all of them are half-rate vector instructions, and on the bench it runs at parity
-  // with the one-task-per-wave sweeps at best.
-  static const int quad_mode = getenv("BPSW_EXT_QUAD") ? atoi(getenv("BPSW_EXT_QUAD")) : 0;
-  static const bool quad_hint_all = getenv("BPSW_QUAD_HINT_ALL") && atoi(getenv("BPSW_QUAD_HINT_ALL")) != 0;  // size the quad grid for every task (diagnostics)
-  const bool use_quad = quad_mode != 0 && use_short && !side_how_blocks_quad(side_how);
-  // layout [one flag byte per task | carry records], the flags sized for the largest batch seen (quad_cap_n), NOT for this batch:
-  // a flag byte must never lie where an earlier, smaller batch kept its carry records
-  bool quad_fresh = false;
-  if (use_quad && n > c->quad_cap_n) {
-    const size_t cap_n = (((size_t)n + (size_t)n / 2 + 4096) + 63) & ~(size_t)63;
-    HIP_TRY(c->d_quad.reserve(cap_n + 16 * cap_n));
-    c->quad_cap_n = (int)cap_n;
-    quad_fresh = true;  // cleared on the launch stream, in front of ext_kernel (a hipMemset on the null stream is not ordered with it)
-  }
-  const size_t quad_carry_off = (size_t)c->quad_cap_n;
-  // The sift kernel in front of the 48-VGPR build for flanks up to 127 bases (bpsw_extend_sift.hip): batches whose matrix
-  // has one mismatch score (both wire formats).  BPSW_EXT_SIFT=0 switches it off (A/B runs).
+  // The sift kernel in front of the short kernel (bpsw_extend_sift.hip: it examines the tasks whose flanks have at most 127 bases):
+  // batches whose matrix has one mismatch score (both wire formats) and of whose tasks at most one in sixteen has a longer flank
+  // (2x150 bp reads: the flanks of 128-131 bases; a batch of 2x250 bp reads would pay the launch for nothing).
+  // BPSW_EXT_SIFT=0 switches it off (A/B runs).
   static const bool sift_on = !(getenv("BPSW_EXT_SIFT") && atoi(getenv("BPSW_EXT_SIFT")) == 0);
   // a lone small call is latency: the extra launch costs it 60-70 us and saves nothing it would notice (tests/small_call_table.py:
   // 61 tasks 0.108 -> 0.171 ms, 4 088 tasks 0.267 -> 0.298, 32 768 tasks 0.76 either way); BPSW_EXT_SIFT_MIN moves the threshold
   static const int sift_min = getenv("BPSW_EXT_SIFT_MIN") ? atoi(getenv("BPSW_EXT_SIFT_MIN")) : 8192;
   const int sift_dm = sift_uniform_dm(c->ext_mat, c->ext_sc.exact_a);
-  const bool use_sift = sift_on && n >= sift_min && (c->shortcut_mask & 32) && use_short && !any_mid && !use_quad && sift_dm > 0;
+  const bool use_sift = sift_on && n >= sift_min && (c->shortcut_mask & 32) && use_short && 16 * (size_t)n_mid <= (size_t)n && sift_dm > 0;
   const size_t sift_rec_off = ((size_t)n + 15) & ~(size_t)15;
   if (use_sift) HIP_TRY(c->d_sift.reserve(sift_rec_off + 32 * (size_t)n));
   const bool staged = wire == (const uint8_t*)c->h_stage_in.ptr;
@@ -654,11 +634,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       int* d_list = with_list ? (int*)((char*)c->d_wire.ptr + list_off) : nullptr;
       if (use_short) {
         KernelEvents kev;
-        kev.start = c->ev[1]; kev.stop = (use_full || use_quad) ? nullptr : c->ev[2];
-        uint8_t* d_quad = use_quad ? (uint8_t*)c->d_quad.ptr : nullptr;
-        uint4* d_qcarry = use_quad ? (uint4*)((char*)c->d_quad.ptr + quad_carry_off) : nullptr;
-        // the flags are zero when ext_kernel starts: the quad kernel leaves them so, a new buffer is cleared here
-        if (quad_fresh) HIP_TRY(hipMemsetAsync(c->d_quad.ptr, 0, c->d_quad.cap, s));
+        kev.start = c->ev[1]; kev.stop = use_full ? nullptr : c->ev[2];
         uint8_t* d_sflag = use_sift ? (uint8_t*)c->d_sift.ptr : nullptr;
         uint4* d_srecs = use_sift ? (uint4*)((char*)c->d_sift.ptr + sift_rec_off) : nullptr;
         if (use_sift) {  // the kernel time of the call starts with it
@@ -667,14 +643,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
           HIP_TRY(launch_ext_sift_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, sift_dm, 127, d_sflag, d_srecs, s, sev));
         }
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 255), mr_short, c->num_cu, d_queue, nullptr, s,
-                                  nullptr, false, kev, true, d_list, any_mid ? 255 : 127, d_quad, d_qcarry, 128, d_sflag, d_srecs));
-        if (use_quad) {
-          // behind it on the stream: the flanks it handed over (how many, only the device knows: a third of the tasks sizes the grid)
-          KernelEvents qev;
-          qev.stop = use_full ? nullptr : c->ev[2];
-          HIP_TRY(launch_ext_quad_kernel(8, (const uint32_t*)c->d_wire.ptr, wire_bytes >> 2, d_quad, d_qcarry, quad_hint_all ? n : n / 3 + 16, n, k_out, sc,
-                                         c->num_cu, (int*)((char*)c->d_pre.ptr + 192), s, qev));
-        }
+                                  nullptr, false, kev, true, d_list, 255, d_sflag, d_srecs));
       }
       if (use_full) {
         KernelEvents kev;
@@ -803,12 +772,28 @@ int bpsw_extend_batch_device(bpsw_ctx_t* c, const void* d_wire, size_t wire_byte
     static const bool split_on = !(getenv("BPSW_EXT_SPLIT") && atoi(getenv("BPSW_EXT_SPLIT")) == 0);
     int* d_queue = (int*)((char*)c->d_pre.ptr + 128);
     if (split_on) {
-      // the 48-VGPR window build over every task, deferring on the device what it cannot take (nobody has seen the records
+      // the short kernel over every task, deferring on the device what it cannot take (nobody has seen the records
       // here), and the full kernel behind it for that list; both check the scan and leave a bad batch untouched
       int* d_list = (int*)c->d_ext_lists.ptr;
       HIP_TRY(hipMemsetAsync(d_list, 0, sizeof(int), s));
+      // the sift kernel in front, as on the host-buffer path (extend_batch_impl): large batches of a context whose verified calls
+      // have shown reads of the 2x150 bp kind (nobody has seen this batch's records: a batch of longer flanks pays a launch that
+      // examines nothing)
+      static const bool sift_on = !(getenv("BPSW_EXT_SIFT") && atoi(getenv("BPSW_EXT_SIFT")) == 0);
+      static const int sift_min = getenv("BPSW_EXT_SIFT_MIN") ? atoi(getenv("BPSW_EXT_SIFT_MIN")) : 8192;
+      const int sift_dm = sift_uniform_dm(c->ext_mat, c->ext_sc.exact_a);
+      const bool use_sift = sift_on && n_tasks >= sift_min && (c->shortcut_mask & 32) && sift_dm > 0 && c->ext_geom_q > 0 && c->ext_geom_q <= 140;
+      const size_t sift_rec_off = ((size_t)n_tasks + 15) & ~(size_t)15;
+      uint8_t* d_sflag = nullptr;
+      uint4* d_srecs = nullptr;
+      if (use_sift) {
+        HIP_TRY(c->d_sift.reserve(sift_rec_off + 32 * (size_t)n_tasks));
+        d_sflag = (uint8_t*)c->d_sift.ptr;
+        d_srecs = (uint4*)((char*)c->d_sift.ptr + sift_rec_off);
+        HIP_TRY(launch_ext_sift_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, sift_dm, 127, d_sflag, d_srecs, s, KernelEvents(), d_pre));
+      }
       HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu, d_queue, nullptr, s,
-                                d_pre, true, KernelEvents(), true, d_list, -255));
+                                d_pre, true, KernelEvents(), true, d_list, -255, d_sflag, d_srecs));
       // (sized like a normal launch: how many tasks the first one defers is unknown here -- all of them when the gap costs rule the
       // register sweeps out --, an empty list returns at once and the persistent queue lets surplus waves leave immediately)
       HIP_TRY(launch_ext_kernel((const uint32_t*)d_wire, n_tasks, (int16_t*)d_out, c->ext_sc, qcap, rcap, c->num_cu,
