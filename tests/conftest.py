@@ -9,7 +9,9 @@ import pytest
 # executor is told to set; must be in the environment before the HIP runtime initialises
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 # the sift kernel (csrc/bpsw_extend_sift.hip) normally serves batches of 8 192 and more tasks: the tests want it on every batch
-os.environ.setdefault("BPSW_EXT_SIFT_MIN", "0")
+# (tests/test_production_defaults_gpu.py runs a slice of the suite once more with the library's own threshold)
+if not os.environ.get("BPSW_TEST_PRODUCTION_DEFAULTS"):
+    os.environ.setdefault("BPSW_EXT_SIFT_MIN", "0")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "cloud-scale-bwamem_amd")

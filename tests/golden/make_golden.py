@@ -293,6 +293,59 @@ np.savez_compressed(os.path.join(HERE, "mem_reg2aln.npz"), l_pac=int(sum(contigs
                     read_len=np.array(jl, np.int32), read_off=np.array(jo, np.int64), read_pool=tb.read_pool, regs=rg, alns=alns,
                     cigar=cig, md=md)
 
+# ---- whole extension tasks through the reference's ksw_extend2 (ref_extend_batch, oracle/ref_shim.c: the extension() control of
+# MemChainToAlignBatched.scala:789-883 around native/ksw.c:379-476): two-sided tasks with their band retries, for the kernels' own
+# row loops to be held against reference OUTPUTS (tests/test_golden_gpu.py) -- 150 and 250 bp, 1-20 % error, bands 5 / 70 / 100 / 127.
+# (own generator: the shared one above must keep its sequence for the other files)
+sets, fields = [], ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "left_q_off", "left_r_off", "right_q_off", "right_r_off",
+                    "reg_score", "q_beg", "h0", "idx")
+ext_kw = {}
+for si, (rl, sub, indel, w, zd) in enumerate(((150, 0.01, 0.001, 100, 100), (150, 0.05, 0.01, 100, 100), (150, 0.10, 0.02, 70, 100),
+                                               (150, 0.20, 0.02, 5, 100), (150, 0.02, 0.05, 5, 100), (250, 0.08, 0.02, 100, 100),
+                                               (250, 0.20, 0.02, 127, 100), (250, 0.05, 0.05, 5, 20), (250, 0.03, 0.004, 127, 0))):
+    soa = synth.ext_tasks(90, read_len=rl, sub_rate=sub, indel_rate=indel, n_rate=0.002, seed=synth.CONFIG_SEED_BASE + 4000 + si)
+    soa.w = w
+    out = ref.extend_batch(soa, mat, zdrop=zd)
+    for f in fields:
+        ext_kw[f"s{si}_{f}"] = getattr(soa, f)
+    ext_kw[f"s{si}_pool"] = soa.pool
+    ext_kw[f"s{si}_out"] = out
+    sets.append((rl, int(round(sub * 1000)), int(round(indel * 1000)), w, zd, soa.n))
+# one more set, built by hand: right-side flanks of ~200 bases with ONE indel of 60-95 bases behind 40 matching ones -- at band 100 an
+# alignment that ends 75 or more columns off the diagonal makes extension() run ksw_extend2 again with the band doubled to 200
+import bpsw_hip  # noqa: E402
+rg2 = np.random.default_rng(20261004)
+pool, fl = [], {k: [] for k in fields}
+for k in range(48):
+    core = rg2.integers(0, 4, 200).astype(np.uint8)
+    gap = int(rg2.integers(60, 96))
+    extra = rg2.integers(0, 4, gap).astype(np.uint8)
+    if k % 2 == 0:   # the target has `gap` bases more (a deletion in the read)
+        q, t = core, np.concatenate([core[:40], extra, core[40:]])
+    else:            # the read has them (an insertion)
+        q, t = np.concatenate([core[:40], extra, core[40:200 - gap if gap < 90 else 110]]), core
+    t = np.concatenate([t, rg2.integers(0, 4, 60).astype(np.uint8)])
+    for j in rg2.integers(0, len(q), 2):
+        q[j] = (q[j] + 1) & 3
+    fl["left_qlen"].append(0); fl["left_rlen"].append(0); fl["left_q_off"].append(0); fl["left_r_off"].append(0)
+    fl["right_qlen"].append(len(q)); fl["right_rlen"].append(len(t))
+    fl["right_q_off"].append(len(pool)); pool.extend(q.tolist())
+    fl["right_r_off"].append(len(pool)); pool.extend(t.tolist())
+    h = int(rg2.integers(90, 140))   # (the alignment must survive the gap: its score at the gap exceeds the gap's cost)
+    fl["reg_score"].append(h); fl["h0"].append(h); fl["q_beg"].append(0); fl["idx"].append(k)
+si = len(sets)
+soa = bpsw_hip.ExtTaskSoA(pool=np.array(pool + [0] * 16, np.uint8), **{k: np.array(v, np.int64 if k.endswith("_off") else np.int32) for k, v in fl.items()})
+soa.w = 100
+out = ref.extend_batch(soa, mat, zdrop=100)
+for f in fields:
+    ext_kw[f"s{si}_{f}"] = getattr(soa, f)
+ext_kw[f"s{si}_pool"] = soa.pool
+ext_kw[f"s{si}_out"] = out
+sets.append((200, 10, 0, 100, 100, soa.n))
+np.savez_compressed(os.path.join(HERE, "ref_extension_tasks.npz"), sets=np.array(sets, np.int32), **ext_kw,
+                    note="ref_extend_batch: per set s<i>_*: ExtTaskSoA fields + out[n,7] = qBeg,qEnd,rBeg,rEnd,score,trueScore,width; "
+                         "sets rows = read_len, sub permille, indel permille, w, zdrop, n; scoring 1/-4/6/1/6/1, clip 5/5, BWA z-drop parse")
+
 if CHECK:
     if _mismatch:
         print("golden fixtures differ from what this script generates now:", ", ".join(_mismatch))

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import bpsw_hip
 import pyoracle as po
 import scala_text
 from conftest import region_fields_equal
@@ -164,6 +165,28 @@ def test_chain2aln_vs_mem_chain2aln_golden(orc):
     for f in regs.dtype.names:
         assert np.array_equal(regs[f], z["out_regs"][f]), f
     assert n_ext > 300 and len(regs) < len(b.seed_len)       # extensions ran; contained seeds were skipped
+
+
+def _ref_task_sets():
+    z = np.load(os.path.join(G, "ref_extension_tasks.npz"))
+    fields = ("left_qlen", "left_rlen", "right_qlen", "right_rlen", "left_q_off", "left_r_off", "right_q_off", "right_r_off",
+              "reg_score", "q_beg", "h0", "idx")
+    for si, (rl, sub, indel, w, zd, n) in enumerate(z["sets"].tolist()):
+        soa = bpsw_hip.ExtTaskSoA(pool=z[f"s{si}_pool"], **{f: z[f"s{si}_{f}"] for f in fields})
+        soa.w = int(w)
+        yield si, soa, int(zd), z[f"s{si}_out"]
+
+
+def test_extension_tasks_vs_reference_golden(orc):
+    """whole two-sided extension tasks, band retries included: the oracle (BWA z-drop parse) against ref_extend_batch's outputs"""
+    import bpsw_hip
+    retried = 0
+    for si, soa, zd, want in _ref_task_sets():
+        got, _ = orc.wire_extend(bpsw_hip.wire_pack(soa), zdrop=zd, zdrop_mode=po.ZDROP_BWA)
+        got = np.asarray(got).reshape(-1, 10)
+        assert np.array_equal(got[:, 2:9].astype(np.int32), want), si
+        retried += int((want[:, 6] > soa.w).sum())
+    assert retried > 100   # the doubled band is exercised
 
 
 def test_committed_fixtures_are_what_the_committed_script_generates():

@@ -79,6 +79,25 @@ def test_extend_kernel_vs_ksw_extend2_golden(ctx):
     assert checked > 300
 
 
+@pytest.mark.parametrize("mask", [0, 31, 63])
+def test_extension_tasks_vs_reference_golden(ctx, mask):
+    """Whole two-sided extension tasks -- band retries, bands 5 / 70 / 100 / 127, 150 and 250 bp, the hand-built long indels that
+    double the band to 200 -- through bpsw_extend_batch against the outputs of the reference's own ksw_extend2 under its
+    extension() control (tests/golden/ref_extension_tasks.npz, ref_extend_batch): the assembly row loops, the window moves, the
+    deferral to the full kernel and the shortcuts (none / all but the sift kernel / all) meet reference outputs directly."""
+    from test_golden import _ref_task_sets
+    ctx.set_ext_shortcuts(mask)
+    try:
+        for si, soa, zd, want in _ref_task_sets():
+            ctx.set_ext_scoring(po.default_mat(), zd, bpsw_hip.ZDROP_BWA)
+            got = ctx.extend_batch(bpsw_hip.wire_pack(soa)).reshape(-1, 10)
+            assert np.array_equal(got[:, 2:9].astype(np.int32), want), (mask, si)
+            assert np.array_equal(got[:, 0].astype(np.int32) & 0xffff, soa.idx & 0xffff)
+    finally:
+        ctx.set_ext_scoring(po.default_mat(), 100, bpsw_hip.ZDROP_SCALA)
+        ctx.set_ext_shortcuts(-1)
+
+
 @pytest.mark.parametrize("tag", ["fr", "all4"])
 def test_group_rescue_vs_mem_group_matesw_golden(ctx, tag):
     z = np.load(os.path.join(G, f"mem_group_matesw_{tag}.npz"))

@@ -1,0 +1,23 @@
+"""The extension parity tests once more with the library's PRODUCTION defaults: the rest of the suite runs with BPSW_EXT_SIFT_MIN=0
+(tests/conftest.py), which puts the sift kernel in front of every batch; here the variable is unset, so batches below 8 192 tasks go
+straight to the extension kernel and larger ones take the sift kernel, as in an executor (csrc/bpsw_runtime.cpp).  One child process,
+run to its end before this one continues."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_extension_suite_with_production_sift_threshold():
+    if os.environ.get("BPSW_TEST_PRODUCTION_DEFAULTS"):
+        pytest.skip("already running with the production defaults")
+    env = dict(os.environ, BPSW_TEST_PRODUCTION_DEFAULTS="1")
+    env.pop("BPSW_EXT_SIFT_MIN", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(HERE, "test_extend_gpu.py"),
+                        os.path.join(HERE, "test_golden_gpu.py"), os.path.join(HERE, "test_extend_coords_gpu.py")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
