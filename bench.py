@@ -639,8 +639,37 @@ def main():
         if rank == 0 and world == 1 and wires and groups:
             # what the JNI shim adds around the C ABI calls the timed region makes (fake JNIEnv: a JVM exists on neither box)
             try:
-                from bpsw_hip import jnishim
-                extras["jni_shim_fake_env"] = jnishim.shim_rate(wires[0], ntasks[0], groups[0], reps=5)
+                from bpsw_hip import jnishim, synth
+                js = jnishim.shim_rate(wires[0], ntasks[0], groups[0], reps=5)
+                # the flat entry with the windows named by coordinates needs a group drawn from a reference: a small one of its own
+                try:
+                    l_pac_s = 2_000_003
+                    pac_s, bases_s = synth.random_pac(l_pac_s, seed=synth.CONFIG_SEED_BASE + 91)
+                    g_ref = synth.rescue_group(1024, seed=synth.CONFIG_SEED_BASE + 92, l_pac=l_pac_s, p_resc=W["p_resc"], ref_bases=bases_s)
+                    js["mateSWFlatJNI_coordinates"] = jnishim.shim_rate(wires[0], ntasks[0], g_ref, reps=5, pac=pac_s)["mateSWFlatJNI_coordinates"]
+                except Exception as e:  # noqa: BLE001
+                    js["mateSWFlatJNI_coordinates"] = {"error": repr(e)}
+                # what a Scala caller could reach THROUGH the shim with the bench's number of task threads: a unit of 32 768 reads is one
+                # extension call and four rescue calls; per thread it takes the calls' loaded latencies (measured in the timed region)
+                # plus the marshalling measured here -- an estimate, never above the device-bound `value`
+                try:
+                    ext_shim = (js["swExtendFPGAJNI"]["marshal_in_us"] + js["swExtendFPGAJNI"]["marshal_out_us"]) * 1e-3
+                    ext_ms = host_ms["extend"]["mean"] + ext_shim
+                    grp_ms = host_ms["matesw_group"]["mean"] if host_ms.get("matesw_group") else 0.0
+                    est = {}
+                    for key in ("mateSWJNI", "mateSWFlatJNI", "mateSWFlatJNI_coordinates"):
+                        if key not in js or "marshal_in_us" not in js[key]:
+                            continue
+                        scale = PAIRS_PER_GROUP / max(js[key]["pairs_per_call"], 1)   # (the coordinate group is smaller: per-pair cost scaled)
+                        shim_ms = (js[key]["marshal_in_us"] + js[key]["marshal_out_us"]) * 1e-3 * scale
+                        unit_ms = ext_ms + (READS_PER_EXT_BATCH // (2 * PAIRS_PER_GROUP)) * (grp_ms + shim_ms) if W["paired"] else ext_ms
+                        est[key] = round(min(value, n_threads * READS_PER_EXT_BATCH / (unit_ms * 1e-3)), 1)
+                    js["through_shim_reads_per_s_est"] = dict(est, threads=n_threads,
+                                                              note="min(value, threads x 32768 reads / (loaded call latencies of one extension call and four rescue calls + "
+                                                                   "their marshalling through the fake JNIEnv)); mateSWJNI = the reference's object-array contract as it is")
+                except Exception as e:  # noqa: BLE001
+                    js["through_shim_reads_per_s_est"] = {"error": repr(e)}
+                extras["jni_shim_fake_env"] = js
             except Exception as e:  # noqa: BLE001
                 extras["jni_shim_fake_env"] = {"error": repr(e)}
         if rank == 0 and world == 1 and not args.no_tail and args.config == 3:

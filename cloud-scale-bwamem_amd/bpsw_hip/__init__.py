@@ -41,6 +41,7 @@ JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI",   # new entry for SURVEY.md 8f.3
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI",            # new entries for SURVEY.md 8f.1 / 8f.4
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI",
+    "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWFlatJNI",         # boundary 1 with primitive arrays (round 4)
 ]
 
 

@@ -6,6 +6,7 @@
 //   Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld            replaces native/jni_hello_world.c:23-26
 //   Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI    NEW: the whole round loop of
 //                                                                  memChainToAlnBatched in one call, primitive arrays only
+//   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWFlatJNI          NEW (round 4): boundary 1 with primitive arrays in and one long[] out
 //   Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI             NEW (needs one line of Scala, see
 //                                                                  INTEGRATION.md): puts the 2-bit reference on every
 //                                                                  visible device; mateSWJNI then accepts RefSWType
@@ -228,7 +229,7 @@ struct BytePool {
 // What a mateSWJNI call builds for bpsw_matesw_group, kept per thread and reused: a call of 4 096 pairs moves ~10 MB through these,
 // and allocating (and zero-filling) them afresh on every call was a measurable part of the shim.
 struct MateScratch {
-  std::vector<int32_t> seq_len, reg_cnt, ref_cnt, out_cnt;
+  std::vector<int32_t> seq_len, reg_cnt, ref_cnt, out_cnt, tmp_cnt;
   std::vector<int64_t> seq_off, at, base, ref_rb, ref_re, ref_len, ref_off;
   std::vector<long> where;
   std::vector<bpsw_alnreg_t> regs, tmp, out;
@@ -492,6 +493,165 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       jni::SetObjectArrayElement(env, ret, (jsize)at, m);
       jni::PopLocalFrame(env, nullptr);
     }
+  t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)total};
+  return ret;
+}
+
+// ---- boundary 1 with flat arrays (round 4) -------------------------------------------------------------------------------------
+// mateSWJNI's contract (native/jni_mate_sw.c:239-518, 560-591) costs one GetObjectArrayElement and ~13 Get<Type>Field per region on
+// the way in and an AllocObject pair per region on the way out: 96 % of a 4 096-pair call (breakdown.jni_shim_fake_env).  This entry
+// takes what memSamPeGroupJNIPrepare (worker2/MemSamPe.scala:1895-2000) holds in its loops as primitive arrays -- the same values in
+// the same (k, i, j) order, no objects -- and returns one long[]; the Scala edit is in INTEGRATION.md section 1e.
+// Scala side (jni/MateSWJNI.scala):
+//   @native def mateSWFlatJNI(optInts: Array[Int], maskLevelRedun: Float, mat: Array[Byte], pacLen: Long, pes: Array[Double],
+//                             groupSize: Int, seqLen: Array[Int], seqs: Array[Byte], regCnt: Array[Int], regLongs: Array[Long],
+//                             regInts: Array[Int], refCnt: Array[Int], refRb: Array[Long], refRe: Array[Long], refLen: Array[Long],
+//                             refBytes: Array[Byte]): Array[Long]
+// optInts  = (a, b, oDel, eDel, oIns, eIns, penUnpaired, penClip5, penClip3, w, zdrop, T, flag, minSeedLen, maxIns, maxMatesw);
+// pes      = per orientation (low, high, failed, avg, std): 20 doubles;
+// seqLen / regCnt / refCnt are indexed 2k+i (refCnt = refSizeArray, MemSamPe.scala:1944-1947); seqs = the reads' codes back to back;
+// regLongs = (rBeg, rEnd, hash), regInts = (qBeg, qEnd, score, trueScore, sub, csub, subNum, width, seedCov, secondary) per region in
+//            (k, i, j) order; refRb / refRe / refLen hold 4 entries (the orientations) per (k, i, j < refCnt) row in the same order
+//            (-1, -1, 0 = failed orientation, MemSamPe.scala:1863-1868); refBytes = the windows of positive length back to back in
+//            that order.  refLen == null and refBytes == null: the windows are named by (rBeg, rEnd) alone and read from the
+//            reference loaded with loadPacJNI -- then nothing but the reads' own bytes travels.
+// Returns long[2 G + 8 R']: the region counts per end, then per region after the rescue, in (k, i, rank) order, 8 longs:
+//   rBeg, rEnd, hash, qBeg | qEnd << 32, score | trueScore << 32, sub | csub << 32, subNum | width << 32, seedCov | secondary << 32
+// (the low halves are the 32 low bits of the first field).
+JNIEXPORT jlongArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWFlatJNI(
+    JNIEnv* env, jobject, jintArray optInts, jfloat maskLevelRedun, jbyteArray matArr, jlong pacLen, jdoubleArray pesArr, jint groupSize,
+    jintArray seqLenArr, jbyteArray seqsArr, jintArray regCntArr, jlongArray regLongsArr, jintArray regIntsArr, jintArray refCntArr,
+    jlongArray refRbArr, jlongArray refReArr, jlongArray refLenArr, jbyteArray refBytesArr) {
+  const jsize ends_j = 2 * groupSize;
+  if (!optInts || !matArr || !pesArr || !seqLenArr || !seqsArr || !regCntArr || !regLongsArr || !regIntsArr || !refCntArr || !refRbArr ||
+      !refReArr || groupSize < 0 || (refLenArr == nullptr) != (refBytesArr == nullptr) || jni::GetArrayLength(env, optInts) < 16 ||
+      jni::GetArrayLength(env, matArr) < 25 || jni::GetArrayLength(env, pesArr) < 20 || jni::GetArrayLength(env, seqLenArr) < ends_j ||
+      jni::GetArrayLength(env, regCntArr) < ends_j || jni::GetArrayLength(env, refCntArr) < ends_j) {
+    throw_runtime(env, "bPSW: mateSWFlatJNI: bad arguments");
+    return nullptr;
+  }
+  const double t0 = now_us();
+  bpsw_opt_t opt;
+  bpsw_opt_default(&opt);
+  {
+    jint oi[16];
+    jni::GetIntArrayRegion(env, optInts, 0, 16, oi);
+    int32_t* dst[16] = {&opt.a, &opt.b, &opt.o_del, &opt.e_del, &opt.o_ins, &opt.e_ins, &opt.pen_unpaired, &opt.pen_clip5,
+                        &opt.pen_clip3, &opt.w, &opt.zdrop, &opt.T, &opt.flag, &opt.min_seed_len, &opt.max_ins, &opt.max_matesw};
+    for (int i = 0; i < 16; ++i) *dst[i] = oi[i];
+    opt.mask_level_redun = maskLevelRedun;
+    jni::GetByteArrayRegion(env, matArr, 0, 25, reinterpret_cast<jbyte*>(opt.mat));
+  }
+  bpsw_rescue_group_t g;
+  memset(&g, 0, sizeof g);
+  g.group_size = groupSize;
+  g.l_pac = pacLen;
+  {
+    jdouble pe[20];
+    jni::GetDoubleArrayRegion(env, pesArr, 0, 20, pe);
+    for (int r = 0; r < 4; ++r) {
+      g.pes[r].low = (int32_t)pe[5 * r]; g.pes[r].high = (int32_t)pe[5 * r + 1]; g.pes[r].failed = (int32_t)pe[5 * r + 2];
+      g.pes[r].avg = pe[5 * r + 3]; g.pes[r].std = pe[5 * r + 4];
+    }
+  }
+  const size_t ends = (size_t)ends_j;
+  MateScratch& ms = t_ms;
+  std::vector<int32_t>&seq_len = ms.seq_len, &reg_cnt = ms.reg_cnt, &ref_cnt = ms.ref_cnt;
+  std::vector<int64_t>&seq_off = ms.seq_off, &ref_rb = ms.ref_rb, &ref_re = ms.ref_re, &ref_len = ms.ref_len, &ref_off = ms.ref_off;
+  seq_len.resize(ends + 1); reg_cnt.resize(ends + 1); ref_cnt.resize(ends + 1); seq_off.resize(ends + 1);
+  if (ends) {
+    jni::GetIntArrayRegion(env, seqLenArr, 0, ends_j, seq_len.data());
+    jni::GetIntArrayRegion(env, regCntArr, 0, ends_j, reg_cnt.data());
+    jni::GetIntArrayRegion(env, refCntArr, 0, ends_j, ref_cnt.data());
+  }
+  int64_t seq_bytes = 0, n_regs = 0, rows = 0;
+  for (size_t e = 0; e < ends; ++e) {
+    if (seq_len[e] < 0 || reg_cnt[e] < 0 || ref_cnt[e] < 0) { throw_runtime(env, "bPSW: mateSWFlatJNI: negative length or count"); return nullptr; }
+    seq_off[e] = seq_bytes; seq_bytes += seq_len[e]; n_regs += reg_cnt[e]; rows += ref_cnt[e];
+  }
+  if ((int64_t)jni::GetArrayLength(env, seqsArr) < seq_bytes || (int64_t)jni::GetArrayLength(env, regLongsArr) < 3 * n_regs ||
+      (int64_t)jni::GetArrayLength(env, regIntsArr) < 10 * n_regs || (int64_t)jni::GetArrayLength(env, refRbArr) < 4 * rows ||
+      (int64_t)jni::GetArrayLength(env, refReArr) < 4 * rows || (refLenArr && (int64_t)jni::GetArrayLength(env, refLenArr) < 4 * rows)) {
+    throw_runtime(env, "bPSW: mateSWFlatJNI: an array is shorter than its table says");
+    return nullptr;
+  }
+  BytePool &seq_pool = ms.seq_pool, &ref_pool = ms.ref_pool;
+  seq_pool.clear(); ref_pool.clear();
+  if (seq_bytes) jni::GetByteArrayRegion(env, seqsArr, 0, (jsize)seq_bytes, reinterpret_cast<jbyte*>(seq_pool.grow((size_t)seq_bytes)));
+  memset(seq_pool.grow(16), 0, 16);
+  std::vector<bpsw_alnreg_t>& regs = ms.regs;
+  regs.resize((size_t)n_regs + 1);
+  {
+    std::vector<int64_t>& rl = ms.at;    // (scratch vectors of the object-array entry, reused)
+    std::vector<int32_t>& ri = ms.out_cnt;
+    rl.resize((size_t)(3 * n_regs) + 1); ri.resize((size_t)(10 * n_regs) + 1);
+    if (n_regs) {
+      jni::GetLongArrayRegion(env, regLongsArr, 0, (jsize)(3 * n_regs), reinterpret_cast<jlong*>(rl.data()));
+      jni::GetIntArrayRegion(env, regIntsArr, 0, (jsize)(10 * n_regs), ri.data());
+    }
+    for (int64_t j = 0; j < n_regs; ++j) {
+      bpsw_alnreg_t& a = regs[(size_t)j];
+      const int32_t* v = ri.data() + 10 * j;
+      a.rb = rl[(size_t)(3 * j)]; a.re = rl[(size_t)(3 * j + 1)]; a.hash = (uint64_t)rl[(size_t)(3 * j + 2)];
+      a.qb = v[0]; a.qe = v[1]; a.score = v[2]; a.truesc = v[3]; a.sub = v[4]; a.csub = v[5]; a.sub_n = v[6]; a.w = v[7]; a.seedcov = v[8];
+      a.secondary = v[9];
+    }
+  }
+  ref_rb.resize((size_t)(4 * rows) + 1); ref_re.resize((size_t)(4 * rows) + 1);
+  if (rows) {
+    jni::GetLongArrayRegion(env, refRbArr, 0, (jsize)(4 * rows), reinterpret_cast<jlong*>(ref_rb.data()));
+    jni::GetLongArrayRegion(env, refReArr, 0, (jsize)(4 * rows), reinterpret_cast<jlong*>(ref_re.data()));
+  }
+  if (refLenArr) {
+    ref_len.resize((size_t)(4 * rows) + 1); ref_off.resize((size_t)(4 * rows) + 1);
+    if (rows) jni::GetLongArrayRegion(env, refLenArr, 0, (jsize)(4 * rows), reinterpret_cast<jlong*>(ref_len.data()));
+    int64_t ref_bytes = 0;
+    for (int64_t x = 0; x < 4 * rows; ++x) {
+      if (ref_len[(size_t)x] < 0) { throw_runtime(env, "bPSW: mateSWFlatJNI: negative window length"); return nullptr; }
+      ref_off[(size_t)x] = ref_bytes;
+      ref_bytes += ref_len[(size_t)x];
+    }
+    if ((int64_t)jni::GetArrayLength(env, refBytesArr) < ref_bytes) { throw_runtime(env, "bPSW: mateSWFlatJNI: refBytes shorter than refLen says"); return nullptr; }
+    if (ref_bytes) jni::GetByteArrayRegion(env, refBytesArr, 0, (jsize)ref_bytes, reinterpret_cast<jbyte*>(ref_pool.grow((size_t)ref_bytes)));
+    memset(ref_pool.grow(16), 0, 16);
+    g.ref_len = ref_len.data(); g.ref_off = ref_off.data(); g.ref_pool = ref_pool.p; g.ref_pool_bytes = ref_pool.n;
+  }
+  g.seq_len = seq_len.data(); g.seq_off = seq_off.data(); g.seq_pool = seq_pool.p; g.seq_pool_bytes = seq_pool.n;
+  g.reg_cnt = reg_cnt.data(); g.regs = regs.data(); g.ref_cnt = ref_cnt.data(); g.ref_rb = ref_rb.data(); g.ref_re = ref_re.data();
+
+  bpsw_ctx_t* ctx = thread_context(env);
+  if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
+  std::vector<int32_t>& out_cnt = ms.tmp_cnt;
+  std::vector<bpsw_alnreg_t>& out = ms.out;
+  out_cnt.resize(ends ? ends : 1);
+  out.resize((size_t)n_regs + (size_t)rows + 16);
+  int64_t total = 0;
+  const double t1 = now_us();
+  const char* compat = getenv("BPSW_MATESW_COMPAT");
+  const int mode = (compat && strcmp(compat, "scala") == 0) ? BPSW_RESCUE_SCALA : BPSW_RESCUE_C;
+  int rc = bpsw_matesw_group(ctx, &opt, &g, mode, out_cnt.data(), out.data(), (int64_t)out.size(), &total);
+  if (rc == BPSW_ERR_CAPACITY) {
+    out.resize((size_t)total);
+    rc = bpsw_matesw_group(ctx, &opt, &g, mode, out_cnt.data(), out.data(), (int64_t)out.size(), &total);
+  }
+  if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: mateSWFlatJNI: ") + bpsw_last_error()); return nullptr; }
+
+  const double t2 = now_us();
+  const int64_t n_out = (int64_t)ends + 8 * total;
+  if (n_out > 0x7fffffffLL) { throw_runtime(env, "bPSW: mateSWFlatJNI: result exceeds a Java array; use a smaller group"); return nullptr; }
+  std::vector<int64_t>& res = ms.base;
+  res.resize((size_t)n_out + 1);
+  for (size_t e = 0; e < ends; ++e) res[e] = out_cnt[e];
+  const auto pack = [](int32_t lo, int32_t hi) { return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo); };
+  for (int64_t j = 0; j < total; ++j) {
+    const bpsw_alnreg_t& r = out[(size_t)j];
+    int64_t* o = res.data() + ends + 8 * j;
+    o[0] = r.rb; o[1] = r.re; o[2] = (int64_t)r.hash; o[3] = pack(r.qb, r.qe); o[4] = pack(r.score, r.truesc); o[5] = pack(r.sub, r.csub);
+    o[6] = pack(r.sub_n, r.w); o[7] = pack(r.seedcov, r.secondary);
+  }
+  jlongArray ret = jni::NewLongArray(env, (jsize)n_out);
+  if (!ret) return nullptr;  // OutOfMemoryError already pending
+  if (n_out) jni::SetLongArrayRegion(env, ret, 0, (jsize)n_out, reinterpret_cast<const jlong*>(res.data()));
   t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)total};
   return ret;
 }

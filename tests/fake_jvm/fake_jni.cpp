@@ -390,6 +390,82 @@ int fake_jvm_matesw(const char* lib, int partition, const int32_t opt_ints[16], 
   return 0;
 }
 
+// mateSWFlatJNI (round 4): what the flattened memSamPeGroupJNIPrepare of INTEGRATION.md 1e hands over -- primitive arrays only.
+// Same inputs and outputs as fake_jvm_matesw (the object-array entry), so a test can hold the two against each other.
+int fake_jvm_matesw_flat(const char* lib, int partition, const int32_t opt_ints[16], float mask_level_redun, const int8_t mat[25],
+                         int64_t l_pac, const double* pes /*4x5*/, int group_size, const int32_t* seq_len, const int64_t* seq_off,
+                         const uint8_t* seq_pool, const int32_t* reg_cnt, const FlatReg* regs, const int32_t* ref_cnt, const int64_t* ref_rb,
+                         const int64_t* ref_re, const int64_t* ref_len, const int64_t* ref_off, const uint8_t* ref_pool, int32_t* out_cnt,
+                         FlatReg* out_regs, int64_t out_cap, int64_t* out_total, char* err, int errcap, const uint8_t* pac /* may be null */) {
+  Jvm vm;
+  g_vm = &vm;
+  vm.partition = partition;
+  Env e;
+  FObj* self = vm.alloc("cs/ucla/edu/bwaspark/jni/MateSWJNI");
+  if (pac) {
+    typedef jint (*LoadFn)(JNIEnv*, jobject, jbyteArray, jlong);
+    LoadFn load = (LoadFn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI", err, (size_t)errcap);
+    if (!load) return -1;
+    const jint nd = load(&e.env, J(self), (jbyteArray)J(byte_array(pac, (size_t)((l_pac + 3) / 4))), (jlong)l_pac);
+    if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+    if (nd < 1) { snprintf(err, (size_t)errcap, "loadPacJNI loaded no device"); return -1; }
+  }
+  typedef jlongArray (*Fn)(JNIEnv*, jobject, jintArray, jfloat, jbyteArray, jlong, jdoubleArray, jint, jintArray, jbyteArray, jintArray,
+                           jlongArray, jintArray, jintArray, jlongArray, jlongArray, jlongArray, jbyteArray);
+  Fn fn = (Fn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWFlatJNI", err, (size_t)errcap);
+  if (!fn) return -1;
+  const size_t ends = 2 * (size_t)group_size;
+  std::vector<uint8_t> seqs;
+  int64_t n_regs = 0, rows = 0;
+  for (size_t e2 = 0; e2 < ends; ++e2) {
+    seqs.insert(seqs.end(), seq_pool + seq_off[e2], seq_pool + seq_off[e2] + seq_len[e2]);
+    n_regs += reg_cnt[e2]; rows += ref_cnt[e2];
+  }
+  std::vector<int64_t> rl((size_t)(3 * n_regs)), lens;
+  std::vector<int32_t> ri((size_t)(10 * n_regs));
+  for (int64_t j = 0; j < n_regs; ++j) {
+    const FlatReg& r = regs[j];
+    rl[(size_t)(3 * j)] = r.rb; rl[(size_t)(3 * j + 1)] = r.re; rl[(size_t)(3 * j + 2)] = (int64_t)r.hash;
+    int32_t* v = ri.data() + 10 * j;
+    v[0] = r.qb; v[1] = r.qe; v[2] = r.score; v[3] = r.truesc; v[4] = r.sub; v[5] = r.csub; v[6] = r.sub_n; v[7] = r.w; v[8] = r.seedcov;
+    v[9] = r.secondary;
+  }
+  std::vector<uint8_t> windows;
+  if (!pac) {
+    lens.assign(ref_len, ref_len + 4 * rows);
+    for (int64_t x = 0; x < 4 * rows; ++x) {
+      if (lens[(size_t)x] < 0) lens[(size_t)x] = 0;
+      if (lens[(size_t)x] > 0) windows.insert(windows.end(), ref_pool + ref_off[x], ref_pool + ref_off[x] + lens[(size_t)x]);
+    }
+  }
+  jlongArray r = fn(&e.env, J(self), (jintArray)J(int_array(opt_ints, 16)), mask_level_redun,
+                    (jbyteArray)J(byte_array(reinterpret_cast<const uint8_t*>(mat), 25)), (jlong)l_pac, (jdoubleArray)J(double_array(pes, 20)),
+                    group_size, (jintArray)J(int_array(seq_len, ends)), (jbyteArray)J(byte_array(seqs.data(), seqs.size())),
+                    (jintArray)J(int_array(reg_cnt, ends)), (jlongArray)J(long_array(rl.data(), rl.size())),
+                    (jintArray)J(int_array(ri.data(), ri.size())), (jintArray)J(int_array(ref_cnt, ends)),
+                    (jlongArray)J(long_array(ref_rb, (size_t)(4 * rows))), (jlongArray)J(long_array(ref_re, (size_t)(4 * rows))),
+                    pac ? nullptr : (jlongArray)J(long_array(lens.data(), lens.size())),
+                    pac ? nullptr : (jbyteArray)J(byte_array(windows.data(), windows.size())));
+  if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+  if (!r) { snprintf(err, (size_t)errcap, "null result"); return -1; }
+  const std::vector<int64_t>& la = O(r)->la;
+  if (la.size() < ends || (la.size() - ends) % 8) { snprintf(err, (size_t)errcap, "malformed result array"); return -1; }
+  *out_total = (int64_t)((la.size() - ends) / 8);
+  if (*out_total > out_cap) { snprintf(err, (size_t)errcap, "out_cap too small"); return -1; }
+  int64_t sum = 0;
+  for (size_t e2 = 0; e2 < ends; ++e2) { out_cnt[e2] = (int32_t)la[e2]; sum += la[e2]; }
+  if (sum != *out_total) { snprintf(err, (size_t)errcap, "counts do not add up to the regions returned"); return -1; }
+  for (int64_t j = 0; j < *out_total; ++j) {
+    const int64_t* o = la.data() + ends + 8 * j;
+    FlatReg& q = out_regs[j];
+    q.rb = o[0]; q.re = o[1]; q.hash = (uint64_t)o[2];
+    q.qb = (int32_t)(uint32_t)o[3]; q.qe = (int32_t)(o[3] >> 32); q.score = (int32_t)(uint32_t)o[4]; q.truesc = (int32_t)(o[4] >> 32);
+    q.sub = (int32_t)(uint32_t)o[5]; q.csub = (int32_t)(o[5] >> 32); q.sub_n = (int32_t)(uint32_t)o[6]; q.w = (int32_t)(o[6] >> 32);
+    q.seedcov = (int32_t)(uint32_t)o[7]; q.secondary = (int32_t)(o[7] >> 32);
+  }
+  return 0;
+}
+
 // loadPacJNI, then chainToAlnJNI with primitive arrays (reads back to back).  out receives the returned
 // long[] (n counts, then 8 longs per region); *out_n its length.
 int fake_jvm_chain2aln(const char* lib, int partition, const uint8_t* pac, int64_t l_pac, const int32_t opt_ints[10],

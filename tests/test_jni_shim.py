@@ -102,6 +102,36 @@ def test_matesw_through_jni_with_reference_on_device(fake, ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("allo", [False, True])
+def test_matesw_flat_entry_equals_the_object_array_entry(fake, ctx, allo):
+    """mateSWFlatJNI (round 4: primitive arrays in, one long[] out) against mateSWJNI on the same group, and against the C ABI"""
+    g = synth.rescue_group(160, seed=811, p_resc=0.4, all_orientations=allo)
+    want_cnt, want = ctx.matesw_group(bpsw_hip.default_opt(), g)
+    rc, cnt_o, regs_o, frames, msg = _matesw(fake, g, partition=2)
+    assert rc == 0, msg
+    rc, cnt_f, regs_f, msg = jnishim.matesw_flat(fake, g, partition=2)
+    assert rc == 0, msg
+    assert np.array_equal(cnt_f, cnt_o) and np.array_equal(cnt_f, want_cnt)
+    region_fields_equal(regs_f, regs_o)
+    region_fields_equal(regs_f, want)
+    assert np.array_equal(regs_f["hash"], regs_o["hash"])
+
+
+@pytest.mark.gpu
+def test_matesw_flat_entry_with_reference_on_device(fake, ctx):
+    """the flat entry with refLen = refBytes = null: windows by (rBeg, rEnd) from the reference loaded with loadPacJNI"""
+    l_pac = 300_007
+    pac, bases = synth.random_pac(l_pac, seed=53)
+    g = synth.rescue_group(150, seed=54, l_pac=l_pac, p_resc=0.4, ref_bases=bases)
+    want_cnt, want = ctx.matesw_group(bpsw_hip.default_opt(), g)          # windows shipped as bytes
+    rc, cnt, regs, msg = jnishim.matesw_flat(fake, g, partition=1, pac=pac)
+    assert rc == 0, msg
+    assert np.array_equal(cnt, want_cnt)
+    region_fields_equal(regs, want)
+    assert regs.shape[0] > g.regs.shape[0]
+
+
+@pytest.mark.gpu
 def test_chain2aln_through_jni_matches_c_abi(fake, ctx):
     """SURVEY.md 8f.3 through the JNI surface: loadPacJNI + chainToAlnJNI (primitive arrays only)"""
     l_pac = 300_007
