@@ -17,4 +17,13 @@ W = bench.WORKLOADS[3]
 soa = bench.make_ext_soa(W, 3, 0, 0)
 wire = bpsw_hip.wire_pack(soa)
 grp = bench.make_group(W, 3, 0, 0)
-print(json.dumps(jnishim.shim_rate(wire, soa.n, grp, reps=int(sys.argv[1]) if len(sys.argv) > 1 else 7)))
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+res = jnishim.shim_rate(wire, soa.n, grp, reps=reps)
+# the flat entry with the windows named by coordinates: a group drawn from a reference of its own (4 096 pairs as well)
+from bpsw_hip import synth  # noqa: E402
+l_pac = 4_000_003
+pac, bases = synth.random_pac(l_pac, seed=synth.CONFIG_SEED_BASE + 91)
+g_ref = synth.rescue_group(4096, seed=synth.CONFIG_SEED_BASE + 92, l_pac=l_pac, p_resc=W["p_resc"], ref_bases=bases)
+r2 = jnishim.shim_rate(wire, soa.n, g_ref, reps=reps, pac=pac)
+res["reference_backed_group"] = {k: r2[k] for k in ("mateSWJNI", "mateSWFlatJNI", "mateSWFlatJNI_coordinates") if k in r2}
+print(json.dumps(res))
