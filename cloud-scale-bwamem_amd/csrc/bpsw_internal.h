@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -237,22 +238,40 @@ struct PinnedBuffer {
 // Writers are not starved: a queued writer (bpsw_ref_load / unload / bns_load) keeps NEW readers out, so that a stream of
 // overlapping calls from 20-32 task threads cannot hold `readers` above zero for ever; a NESTED read of a thread that already
 // holds the gate (a call that takes a snapshot inside another) is still admitted, or it would deadlock against that writer.
-inline thread_local int t_ref_read_depth = 0;
+// The nesting depth is counted PER GATE and per thread (a thread that reads device A's reference is not "nested" on device B's
+// gate), in a small thread-local table; a hold must be released by the thread that took it (RefHold asserts it).
+struct RefGate;
+struct RefDepthSlot { const RefGate* gate; int depth; };
+inline thread_local RefDepthSlot t_ref_depth[8] = {};
+inline int* ref_depth_of(const RefGate* g) {
+  RefDepthSlot* free_slot = nullptr;
+  for (RefDepthSlot& s : t_ref_depth) {
+    if (s.gate == g) return &s.depth;
+    if (!free_slot && s.depth == 0) free_slot = &s;
+  }
+  if (!free_slot) abort();  // a thread inside more than eight devices' gates at once: not something this library does
+  free_slot->gate = g;
+  free_slot->depth = 0;
+  return &free_slot->depth;
+}
 struct RefGate {
   std::mutex m;
   std::condition_variable cv;
   int readers = 0, writers_waiting = 0;
   bool writing = false;
   void read_lock() {
+    int* depth = ref_depth_of(this);
     std::unique_lock<std::mutex> lk(m);
-    if (t_ref_read_depth == 0) cv.wait(lk, [&] { return !writing && writers_waiting == 0; });
+    if (*depth == 0) cv.wait(lk, [&] { return !writing && writers_waiting == 0; });
     else cv.wait(lk, [&] { return !writing; });
     ++readers;
-    ++t_ref_read_depth;
+    ++*depth;
   }
   void read_unlock() {
+    int* depth = ref_depth_of(this);
+    if (*depth <= 0) abort();  // released on another thread than the one that took it: the writer preference would silently go
     std::lock_guard<std::mutex> lk(m);
-    --t_ref_read_depth;
+    --*depth;
     if (--readers == 0) cv.notify_all();
   }
   void write_lock() {
@@ -264,7 +283,7 @@ struct RefGate {
   }
   void write_unlock() { { std::lock_guard<std::mutex> lk(m); writing = false; } cv.notify_all(); }
 };
-struct RefHold {  // RAII read side of the gate; movable
+struct RefHold {  // RAII read side of the gate; movable within the thread that took it
   RefGate* g = nullptr;
   RefHold() = default;
   explicit RefHold(RefGate* gate) : g(gate) { if (g) g->read_lock(); }
@@ -359,6 +378,7 @@ struct bpsw_ctx {
   int8_t ext_mat[25];
   // persistent arenas (grow-only; no hipMalloc on the steady-state path)
   bpsw::DeviceBuffer d_wire, d_out, d_pre, d_sw_in, d_sw_out, d_sw_scratch, d_gl_z, d_ext_lists;
+  size_t staged_bytes = 0;    // what the last bpsw_extend_stage was asked for (0: nothing staged / already committed)
   bpsw::DeviceBuffer d_sift;  // the sift kernel's verdicts (bpsw_extend_sift.hip): [flag byte per task | two 16-byte records per task]
   // asynchronous device entries: a launch whose table scan has not been read back yet (resolved by finish_pending)
   struct PendingExt { bool active = false; const void* d_wire = nullptr; size_t wire_bytes = 0; int n_tasks = 0; void* d_out = nullptr;

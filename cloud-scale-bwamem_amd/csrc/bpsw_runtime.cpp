@@ -242,9 +242,15 @@ int stream_pool_cap() {
     // started without the variable is told once, because it runs at a fraction of the rate it could.
     const char* q = getenv("GPU_MAX_HW_QUEUES");
     const int queues = q && atoi(q) > 0 ? atoi(q) : 4;
-    if (v > queues) {
-      if (!q) fprintf(stderr, "bPSW: GPU_MAX_HW_QUEUES is not set: the HIP runtime gives this process 4 hardware queues, so only 4 calls run on the "
-                              "GPU at a time; start the executor with GPU_MAX_HW_QUEUES=20 (two executors per GPU: 10 each)\n");
+    // (the library reads the ENVIRONMENT, not what the runtime picked up: the variable must be exported before the process starts --
+    // a JVM or a Python that sets it after HIP has initialised gets a pool larger than its queues.  BPSW_STREAM_POOL_FORCE=1 keeps the
+    // requested size whatever the variable says.)
+    const char* force = getenv("BPSW_STREAM_POOL_FORCE");
+    if (v > queues && !(force && atoi(force) != 0)) {
+      fprintf(stderr, "bPSW: stream pool clamped from %d (%s) to %d: %s, so only that many calls run on the GPU at a time; start the "
+                      "executor with GPU_MAX_HW_QUEUES=20 (two executors per GPU: 10 each), or set BPSW_STREAM_POOL_FORCE=1 to keep %d\n",
+              v, e ? "BPSW_STREAM_POOL" : "the default", queues,
+              q ? "GPU_MAX_HW_QUEUES gives this process fewer hardware queues" : "GPU_MAX_HW_QUEUES is not set and the HIP runtime's default is 4 hardware queues", v);
       v = queues;
     }
     return v;
@@ -520,14 +526,24 @@ int bpsw_extend_stage(bpsw_ctx_t* c, size_t bytes, uint8_t** buf) {
   { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
   // room for the batch and for the task list the launch plan may stage behind it (at most one int per 32-byte record)
   HIP_TRY(c->h_stage_in.reserve(bytes + bytes / 8 + 4096));
+  c->staged_bytes = bytes;
   *buf = (uint8_t*)c->h_stage_in.ptr;
   return BPSW_OK;
 }
 
 int bpsw_extend_commit(bpsw_ctx_t* c, size_t wire_bytes, const int16_t** out, size_t* out_len) {
   if (!c || !out) return fail(BPSW_ERR_ARG, "extend_commit: null argument");
-  if (!c->h_stage_in.ptr) return fail(BPSW_ERR_ARG, "extend_commit: nothing staged (call bpsw_extend_stage first)");
-  const int rc = extend_batch_impl(c, (const uint8_t*)c->h_stage_in.ptr, wire_bytes, nullptr, 0, nullptr, out);
+  const uint8_t* staged = nullptr;
+  {  // the staging block and what bpsw_extend_stage was asked for, read under the context's lock; a commit of more bytes than were
+     // staged would let the table scan read past the pinned block
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->h_stage_in.ptr || c->staged_bytes == 0) return fail(BPSW_ERR_ARG, "extend_commit: nothing staged (call bpsw_extend_stage first)");
+    if (wire_bytes > c->staged_bytes || wire_bytes > c->h_stage_in.cap)
+      return fail(BPSW_ERR_ARG, "extend_commit: more bytes than bpsw_extend_stage was asked for");
+    staged = (const uint8_t*)c->h_stage_in.ptr;
+    c->staged_bytes = 0;  // one commit per stage
+  }
+  const int rc = extend_batch_impl(c, staged, wire_bytes, nullptr, 0, nullptr, out);
   if (rc == BPSW_OK && out_len) *out_len = *out ? 10 * (size_t)rd32((const uint8_t*)c->h_stage_in.ptr, 8) : 0;
   return rc;
 }

@@ -100,7 +100,8 @@ int bpsw_extend_batch(bpsw_ctx_t *ctx, const uint8_t *wire, size_t wire_bytes, i
  * src/main/jni_fpga/sw_extend_fpga.c:146-155).  bpsw_extend_stage returns the context's pinned staging block with room for
  * `bytes`; the caller writes the wire batch there and calls bpsw_extend_commit, which runs the batch without copying it again
  * and returns a VIEW of the 10*n int16 results where the kernel wrote them (*out, *out_len int16; valid until the next call on
- * the context; n == 0 gives *out == NULL).  One thread per context, as everywhere. */
+ * the context; n == 0 gives *out == NULL).  One commit per stage, of at most the `bytes` that were staged (BPSW_ERR_ARG otherwise: the
+ * table scan never reads past the pinned block).  One thread per context, as everywhere. */
 int bpsw_extend_stage(bpsw_ctx_t *ctx, size_t bytes, uint8_t **buf);
 int bpsw_extend_commit(bpsw_ctx_t *ctx, size_t wire_bytes, const int16_t **out, size_t *out_len);
 
