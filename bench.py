@@ -46,7 +46,8 @@ PAIRS_PER_GROUP = int(os.environ.get("BENCH_GROUP_PAIRS", "4096"))   # boundary-
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT_VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9   # MI355X_MICROARCH.md ("Terms", "Wave scheduling", cycles table): 256 CUs x 4 SIMD-32 x 2.4 GHz --
                                             # a wave64 VALU instruction issues over 2 cycles, 7.86e13 int32 lane-ops/s
-PROFILE_TAG = "r03"              # the committed rocprofv3 summaries this round's line is cross-checked against (profiles/r03_*)
+PROFILE_TAG = "r04"              # the committed rocprofv3 summaries this round's line is cross-checked against (profiles/r04_*)
+PROTOCOL = "r03b"                # what a step IS: changes whenever values stop being comparable with earlier rounds (see `protocol` in the line)
 
 # SURVEY.md 8(d) workloads, keyed by the survey's config number
 WORKLOADS = {
@@ -551,14 +552,14 @@ def main():
     trace_avg = {}
     try:
         import csv
-        # `extend`: a call's launches back to back on its stream -- the sift kernel, the 48-VGPR extension kernel, the full kernel for
+        # `extend`: a call's launches back to back on its stream -- the sift kernel, the short extension kernel, the full kernel for
         # listed / deferred tasks (format-1 batches: the `false` instantiations) -- summed per call, as the library's events see them
         ext_total_ns, ext_calls = 0.0, 0
         for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_stats_bench.csv"))):
             nm = r["Name"]
             if "ext_sift_kernel<false>" in nm or "ext_kernel<false" in nm:
                 ext_total_ns += float(r["TotalDurationNs"])
-                if "ext_kernel<false, 1>" in nm or "ext_kernel<false, 2>" in nm:
+                if "ext_kernel<false, 1>" in nm:
                     ext_calls += int(r["Calls"])
             elif per_kernel["swalign2"][3] in nm and "swalign2" not in trace_avg:
                 trace_avg["swalign2"] = round(float(r["AverageNs"]) * 1e-6, 4)
@@ -567,6 +568,14 @@ def main():
     except Exception:
         trace_avg = {}
     step_s_all = elapsed / args.steps
+    # where the dominant kernel's wave-cycles go (committed SQ counters of this command, profiles/<tag>_sq_activity.json)
+    sq_activity = None
+    try:
+        sa = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_sq_activity.json")))
+        sq_activity = {k: {q: sa[k][q] for q in ("active_valu", "active_sca", "wait_inst_any", "wait_any") if q in sa[k]} for k in ("extend", "swalign2") if k in sa}
+        sq_activity["note"] = f"fractions of SQ_WAVE_CYCLES, from the committed profiles/{PROFILE_TAG}_sq_activity.json (rocprofv3 --pmc pass of this command)"
+    except Exception:  # noqa: BLE001
+        sq_activity = None
     both = {}
     for k, (b, ms, n_l, _) in per_kernel.items():
         if n_l:
@@ -707,19 +716,24 @@ def main():
                      "aggregate_GBps": round(algo_bytes_step / step_s_all / 1e9, 3),
                      "aggregate_frac_of_hbm_peak": round(algo_bytes_step / step_s_all / 1e9 / HBM_PEAK_GBPS, 6),
                      "launch_overlap": round(summed_kernel_s / step_s_all, 2),
+                     "issue": sq_activity,
                      "note": "launch duration = HIP events attached to the kernel's dispatch on its launch stream inside the library, averaged over "
                              "the timed region; launches of different host threads overlap on the device (launch_overlap = summed launch durations / "
                              "step time), so a launch's duration is the time it spends SHARING the GPU: aggregate_GBps = algorithmic bytes of a step / "
                              "step time is the figure to cross-check ms_per_step with.  The rescue kernel reads its jobs (table, mates, windows) from pinned "
                              "HOST memory over PCIe (zero-copy) and writes its results there: its bytes are PCIe reads, not HBM traffic.  The events see "
                              "about 0.06 ms of dispatch latency per launch that a kernel trace does not.  `extend` is what an extension call launches back "
-                             "to back on its stream -- the sift kernel (shortcuts, one task per lane), the 48-VGPR extension kernel, the full kernel for the "
+                             "to back on its stream -- the sift kernel (shortcuts, one task per lane), the short extension kernel, the full kernel for the "
                              "few listed tasks -- timed from the first dispatch to the end of the last; its avg_launch_ms_kernel_trace is the sum of those "
                              "kernels' durations per call, the gaps between them (waiting for wave slots) not included.  avg_launch_ms_kernel_trace is the rocprofv3 "
                              f"--kernel-trace --stats average of this command committed under profiles/{PROFILE_TAG}_kernel_stats_bench.csv.  These kernels are "
                              "integer DP with hundreds of operations per byte: the HBM fraction is ~1e-3 by construction (SURVEY.md 8d), what binds is the "
                              "vector pipe (frac_of_issue_rate)"},
         "gcups": gcups, "frac_of_valu_ceiling": valu, "frac_of_issue_rate": issue_frac,
+        "protocol": {"id": PROTOCOL, "passes_per_step": passes, "barrier_between_passes": False, "feeder": "bpsw_feeder_run_repeats (next free thread takes the next call)",
+                     "profile_figures": f"per-launch instruction / traffic / trace figures come from the COMMITTED profiles/{PROFILE_TAG}_* of this command, not from this run",
+                     "comparable_with": "BENCH_r03 (same protocol); BENCH_r01 / r02 used 3 resp. 8 passes per step with a barrier behind every pass and priced the "
+                                        "VALU ceiling at SIMD-16: their `value` is comparable only through ms per read, their fractions are not"},
         "kernels": {"extend": {"avg_ms": round(ext_avg_ms, 4), "launches": ext_launches, "bytes_per_launch": int(ext_bytes),
                                "h2d_ms_avg": round(st["ext_h2d_ms"] / max(ext_launches, 1), 4), "d2h_ms_avg": round(st["ext_d2h_ms"] / max(ext_launches, 1), 4)},
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes),

@@ -16,11 +16,11 @@ os.makedirs(P, exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"ext_kernel<\w+, (\d)>", name)   # <COORD, SHORT>: 0 = the full kernel (listed / deferred tasks), 1 / 2 = the 48-VGPR builds
+    m = re.search(r"ext_kernel<\w+, (\d)>", name)   # <COORD, SHORT>: 0 = the full kernel (listed / deferred tasks), 1 = the short kernel
     if m:
         return "extend_full" if m.group(1) == "0" else "extend"
     for k, v in (("ext_sift", "extend_sift"), ("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("swp_kernel", "swalign2"), ("sw4_kernel", "swalign2"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
-                 ("reg2aln", "reg2aln"), ("chain2aln", "chain2aln"), ("ext_quad", "extend_quad"), ("global_kernel", "global")):
+                 ("reg2aln", "reg2aln"), ("chain2aln", "chain2aln"), ("global_kernel", "global")):
         if k in name:
             return v
     return name[:40]
@@ -37,7 +37,7 @@ if stats:
     print("kernel stats:", [(short(r["Name"]), r["Calls"], r["AverageNs"]) for r in rows[:4]])
 
 per = defaultdict(lambda: defaultdict(list))
-for sub in ("fetch", "write", "sq", "rdreq", "wrreq", "rdsrc"):
+for sub in ("fetch", "write", "sq", "sqact", "rdreq", "wrreq", "rdsrc"):
     for fn in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fn)):
             per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -114,3 +114,29 @@ if "extend" in issue and ("SQ_INSTS_VALU" in per["extend_full"] or "SQ_INSTS_VAL
 issue["note"] = f"wave-instructions per launch (SQ_INSTS_VALU, SQ_INSTS_SALU) from profiles/{tag}_pmc_counters.csv; extend_per_call = all extension launches of a call (sift + 48-VGPR + full kernel)"
 json.dump(issue, open(os.path.join(P, "pmc_issue.json"), "w"), indent=1)
 print(issue)
+
+# where the wave-cycles of each kernel go under the bench's own sharing of the device (SQ_WAVE_CYCLES, SQ_WAIT_* and SQ_ACTIVE_INST_*
+# count quad-cycles, MI355X_MICROARCH.md; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES): fractions of the wave-cycles
+act = {}
+for k in ("extend", "extend_sift", "extend_full", "swalign2"):
+    wc = mean(k, "SQ_WAVE_CYCLES")
+    if not wc:
+        continue
+    act[k] = {name: round(mean(k, c) / wc, 4) for c, name in (("SQ_ACTIVE_INST_ANY", "active_any"), ("SQ_ACTIVE_INST_VALU", "active_valu"),
+                                                              ("SQ_ACTIVE_INST_SCA", "active_sca"), ("SQ_ACTIVE_INST_LDS", "active_lds"),
+                                                              ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_WAIT_INST_LDS", "wait_inst_lds"),
+                                                              ("SQ_WAIT_ANY", "wait_any")) if mean(k, c) is not None}
+    act[k]["wave_quad_cycles_per_launch"] = int(wc)
+    act[k]["launches"] = len(per[k]["SQ_WAVE_CYCLES"])
+if act:
+    act["note"] = ("fractions of SQ_WAVE_CYCLES per kernel under the bench command (rocprofv3 --pmc, one pass; the launches share the device "
+                   "with each other as in the timed region): active = an instruction of the wave is issuing, wait_inst_any = ready but not "
+                   "issued (the pipe or the arbiter is busy), wait_any = parked (dependencies, waitcnt, instruction fetch)")
+    json.dump(act, open(os.path.join(P, f"{tag}_sq_activity.json"), "w"), indent=1)
+    with open(os.path.join(P, f"{tag}_sq_activity.csv"), "w") as f:
+        f.write("kernel,quantity,value\n")
+        for k, d in act.items():
+            if isinstance(d, dict):
+                for q, v in d.items():
+                    f.write(f"{k},{q},{v}\n")
+    print(act)
