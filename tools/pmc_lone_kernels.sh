@@ -41,8 +41,5 @@ for tag in ("ext_rows", "ext_batch", "swalign2"):
         fr = {c.replace("SQ_", "").lower(): round(mean[c] / wc, 3) for c in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS",
                                                                        "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY") if c in mean}
         ins = {c.replace("SQ_INSTS_", "").lower(): round(mean[c] / 1e6, 2) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS") if c in mean}
-        busy = mean.get("SQ_BUSY_CYCLES")
-        tot = sum(mean.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH"))
-        print(f"{tag:10s} {k:28s} launches {len(v['SQ_WAVE_CYCLES'])}  {fr}  M-instr/launch {ins}"
-              + (f"  instr per SIMD-cycle {tot / (busy / 8 * 4 * 32):.3f} (SQ_BUSY_CYCLES is summed over 8 XCDs; 32 CUs x 4 SIMDs each)" if busy else ""))
+        print(f"{tag:10s} {k:28s} launches {len(v['SQ_WAVE_CYCLES'])}  {fr}  M-instr/launch {ins}")
 PY
