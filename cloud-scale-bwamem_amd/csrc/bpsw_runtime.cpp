@@ -667,7 +667,11 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         // behind the 48-VGPR kernel: the list it completed on the device (what it may have deferred is unknown to the host
         // -- a subset of the mid tasks, normally a small one: a quarter of them sizes the grid; an empty list costs a launch that
         // returns at once)
-        const int grid_tasks = !use_short ? n : n_long + (n_mid + 3) / 4 + (any_mid ? 4 : 0);
+        // (a batch with few mid tasks -- 2x150 bp reads: the flanks of 128-131 bases -- defers next to nothing: one workgroup, whose
+        // four persistent waves take whatever the list holds, gets its wave slots sooner than a grid sized for a quarter of them, and
+        // the call holds its stream for that long)
+        const bool few_mid = 16 * (size_t)n_mid <= (size_t)n;
+        const int grid_tasks = !use_short ? n : n_long + (few_mid ? 0 : (n_mid + 3) / 4) + (any_mid ? 4 : 0);
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, grid_tasks, k_out, sc, mq, mr, c->num_cu, d_queue, nullptr, s,
                                   nullptr, false, kev, false, use_short ? d_list : nullptr));
       }
