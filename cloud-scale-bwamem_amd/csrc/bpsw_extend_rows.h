@@ -396,14 +396,18 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "s_cbranch_scc1 L_fdone_%=\n\t" \
       "L_ttgo" SFX "_%=:\n\t"
 #define ROWS1F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
+      /* the band's set-up, only when the band is not simply last row's (LIVE: unchanged at the query end) or last row's moved up by */ \
+      /* one lane (DEAD: the mask is shifted in place) */ \
       "L_frow" SFX "_%=:\n\t" \
-      TAILTOP \
-      "v_readlane_b32 %[t], %[vTS], %[i]\n\t"  /* 8 * target base of row i */ \
       "s_sub_i32 %[span], %[end], %[beg]\n\t" \
       "s_cmp_lt_i32 %[span], 1\n\t" \
       "s_cbranch_scc1 L_fslow_%=\n\t"  /* an empty band */ \
       "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
       "s_bfm_b64 %[act], %[span], m0\n\t"  /* the lanes of the band */ \
+      "L_fbody" SFX "_%=:\n\t" \
+      TAILTOP \
+      "v_readlane_b32 %[t], %[vTS], %[i]\n\t"  /* 8 * target base of row i */ \
+      "s_nop 1\n\t" \
       "v_bfe_i32 %[vS], %[vP], %[t], 8\n\t" \
       "v_add_u32 %[vA], %[vH], %[vS]\n\t" \
       "v_max_i32 %[vA], %[vA], %[vE]\n\t" \
@@ -459,9 +463,7 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
       "L_ftrim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214 */ \
       "s_and_b64 %[z], vcc, %[act]\n\t"  /* the zero cells of the band; SCC = there are some */ \
       "s_cbranch_scc1 L_fzero" SFX "_%=\n\t" \
-      NB0_NOZERO \
-      "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
-      "s_addc_u32 %[end], %[end], 0\n\t"  /* end = min(end + 1, qLen) */ \
+      NB0_NOZERO  /* beg, end and the band mask of the next row; falls through when the set-up has to run */ \
       "L_fnext" SFX "_%=:\n\t" \
       "s_add_i32 %[i], %[i], 1\n\t" \
       "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
@@ -575,12 +577,36 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
 #define ROWS1F_LIVE_(SFX, DEADSFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
   ROWS1F_TEXT(SFX, "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", "v_max_i32 %[vT0], %[vA], %[vS]\n\t", \
               "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %[vH], %[h1raw], m0\n\t", \
-              "", "s_mov_b32 %[t3], %[beg]\n\t", "s_min_i32 %[hardend], %[hardend], %[ih1z]\n\t", \
+              /* beg stays; end at the query end: the next row's band is this row's */ \
+              "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
+              "s_cbranch_scc1 L_fgrow" SFX "_%=\n\t" \
+              "s_add_i32 %[i], %[i], 1\n\t" \
+              "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
+              "s_cbranch_scc1 L_fbody" SFX "_%=\n\t" \
+              "s_branch L_fbound" SFX "_%=\n\t" \
+              "L_fgrow" SFX "_%=:\n\t" \
+              "s_add_i32 %[end], %[end], 1\n\t", \
+              "s_mov_b32 %[t3], %[beg]\n\t", "s_min_i32 %[hardend], %[hardend], %[ih1z]\n\t", \
               "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_fbound" DEADSFX "_%=\n\t", TAIL_MIN, TAIL_SWITCH, TAILTOP)
 #define ROWS1F_DEAD_(SFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
   ROWS1F_TEXT(SFX, "s_nop 0\n\t", "v_max3_i32 %[vT0], %[vA], %[vS], 0\n\t", \
               "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t", \
-              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "", TAIL_MIN, TAIL_SWITCH, TAILTOP)
+              /* beg + 1, and end + 1 below the query end: the band moves up by one lane (or loses its first column) -- the mask follows */ \
+              "s_add_i32 %[beg], %[beg], 1\n\t" \
+              "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
+              "s_cbranch_scc0 L_fatq" SFX "_%=\n\t" \
+              "s_add_i32 %[end], %[end], 1\n\t" \
+              "s_lshl_b64 %[act], %[act], 1\n\t" \
+              "L_fsh" SFX "_%=:\n\t" \
+              "s_add_i32 %[i], %[i], 1\n\t" \
+              "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
+              "s_cbranch_scc1 L_fbody" SFX "_%=\n\t" \
+              "s_branch L_fbound" SFX "_%=\n\t" \
+              "L_fatq" SFX "_%=:\n\t" \
+              "s_lshl_b64 %[u64], %[act], 1\n\t" \
+              "s_and_b64 %[act], %[act], %[u64]\n\t" \
+              "s_cbranch_scc1 L_fsh" SFX "_%=\n\t",  /* (an empty band: through the set-up, which leaves the loop) */ \
+              "s_add_i32 %[t3], %[beg], 1\n\t", "", "", TAIL_MIN, TAIL_SWITCH, TAILTOP)
 #define ROWSF_TAILMIN "s_min_i32 %[hardend], %[hardend], %[itail]\n\t"
 #define ROWS1F_ALL \
   ROWS1F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_lt_%=\n\t", "") \
