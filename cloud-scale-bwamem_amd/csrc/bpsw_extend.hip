@@ -25,6 +25,9 @@
 #include "bpsw_extend_core.h"
 #include "bpsw_extend_rows.h"
 
+#include "bpsw_diag_waves.h"
+BPSW_DIAG_WAVES_DEFINE(ext)
+
 namespace bpsw {
 namespace {
 
@@ -87,8 +90,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
                                                                      const ExtPrepass* __restrict__ pre,
                                                                      int* __restrict__ defer, const int short_qmax,
                                                                      const uint8_t* __restrict__ sift_flag,
-                                                                     const uint4* __restrict__ sift_recs) {
+                                                                     const uint4* __restrict__ sift_recs,
+                                                                     int* __restrict__ defer_post,
+                                                                     const int* __restrict__ todo_list) {
   extern __shared__ __align__(16) unsigned char smem[];
+  BPSW_DIAG_WAVE_BEGIN();
+  BPSW_DIAG_TASKS_DECL();
   // the full kernel behind a SHORT launch: its task list and count are what the host listed plus what that launch deferred
   const int n_tasks = (!SHORT && defer) ? uni(defer[0]) : n_tasks_arg;
   const int* __restrict__ task_list = (!SHORT && defer) ? defer + 1 : task_list_arg;
@@ -128,24 +135,44 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
   // sixth of the atomics.  Every dequeue is a device-scope atomic that goes to the memory side (the XCDs' L2s are not coherent
   // with each other): at one per task the queue alone was as much fabric traffic as the tasks' own bytes.
   const int total_waves = (int)gridDim.x * WAVES_PER_BLOCK;
-  int ticket = 0, ticket_end = 0, take = chunk > 0 ? chunk : max(1, min(guide_cap, n_tasks / (2 * total_waves)));
+  // Behind the sift kernel (SHORT): the tickets are the entries of its to-do list -- the tasks it did not finish, next_task[2] of
+  // them from the front of the list and, taken first, next_task[3] from its back: the ones with the longest sweeps ahead.  One
+  // ticket at a time: every ticket is a task with a sweep to do (a wave holds the counter for one atomic per ~25 us), and a
+  // launch ends with the last tickets taken -- with eight at a time from the whole batch (the guided dequeue below, whose chunk
+  // size is one chunk old when it is used), half of the waves had left 155 us before the last one of a 430 us launch
+  // (tools/wave_placement.py, profiles/r04_wave_placement.txt).
+  const bool listed = SHORT && todo_list != nullptr;
+  const int n_heavy = listed ? uni(next_task[3]) : 0;
+  const int n_tix = listed ? uni(next_task[2]) + n_heavy : n_tasks;
+  int ticket = 0, ticket_end = 0, take = listed ? 1 : chunk > 0 ? chunk : max(1, min(guide_cap, n_tix / (2 * total_waves)));
   for (;;) {
     if (ticket == ticket_end) {
       ticket = dequeue_task(next_task, take);
-      ticket_end = min(ticket + take, n_tasks);
-      if (chunk == 0) take = max(1, min(guide_cap, (n_tasks - ticket_end) / (2 * total_waves)));
-      if (ticket >= n_tasks) {
+      ticket_end = min(ticket + take, n_tix);
+      if (chunk == 0 && !listed) take = max(1, min(guide_cap, (n_tix - ticket_end) / (2 * total_waves)));
+      if (ticket >= n_tix) {
         // The last wave to leave puts the queue back to zero for the next launch on this context: next_task[1] counts the waves
         // that have taken their last ticket.  Saves the fill kernel that used to zero the head before every launch.
         const int gone = dequeue_task(next_task + 1);
-        if (gone == (int)gridDim.x * WAVES_PER_BLOCK - 1 && lane == 0) {
-          next_task[0] = 0;
-          next_task[1] = 0;
+        if (gone == (int)gridDim.x * WAVES_PER_BLOCK - 1) {
+          // (SHORT) the host launches the full kernel only when this launch left it something (bpsw_runtime.cpp): the length of
+          // the list, next to the results.  Every other wave's pushes returned before it counted itself out above, and
+          // the count is read where the atomics were performed (the XCDs' L2s are not coherent with each other).
+          if (SHORT && defer_post) {
+            const int listed = dequeue_task(defer, 0);
+            if (lane == 0) *defer_post = listed;
+          }
+          if (lane == 0) {
+            next_task[0] = 0;
+            next_task[1] = 0;
+            if (listed) { next_task[2] = 0; next_task[3] = 0; }
+          }
         }
         break;
       }
     }
-    const int task = task_list ? uni(task_list[ticket]) : ticket;  // n_tasks counts the entries of task_list when given
+    const int task = listed ? uni(todo_list[ticket < n_heavy ? n_tasks - 1 - ticket : ticket - n_heavy])
+                            : task_list ? uni(task_list[ticket]) : ticket;  // n_tasks counts the entries of task_list when given
     ++ticket;
     // what the sift kernel (bpsw_extend_sift.hip: the shortcuts, one task per lane) left for this task: 1 = its record is written,
     // 2 = a record per side in sift_recs, 0 = nothing
@@ -154,6 +181,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
       sifted = uni((int)sift_flag[task]);
       if (sifted == 1) continue;
     }
+    BPSW_DIAG_TASK_BEGIN(task);
     const uint32_t* rec = wire + 8 + (COORD ? 10 : 8) * (size_t)task;  // MemChainToAlignBatched.scala:95-117
     const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
     // coordinate batch: the seed's start in the doubled reference and its length (in the slot of the redundant 16-bit idx)
@@ -299,7 +327,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
       o[3] = ((uint32_t)score & 0xffffu) | ((uint32_t)trueScore << 16);
       o[4] = (uint32_t)width & 0xffffu;
     }
+    BPSW_DIAG_TASK_END();
   }
+  BPSW_DIAG_WAVE_END_TASKS(SHORT ? 1 : 0, next_task, lane);
 }
 
 // ---- table scan: validates the batch and finds the LDS capacities the main launch needs --------
@@ -353,7 +383,7 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev, bool short_kernel, int* d_defer,
-                             int short_qmax, const uint8_t* d_sift_flag, const uint4* d_sift_recs) {
+                             int short_qmax, const uint8_t* d_sift_flag, const uint4* d_sift_recs, int* d_defer_post, const int* d_todo_list) {
   if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
   const int variant = short_kernel ? 1 : 0;
@@ -405,7 +435,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
 #define BPSW_EXT_GO(CO, SH)                                                                                                     \
   BPSW_LAUNCH(kev, (ext_kernel<CO, SH>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap, rcap, \
-              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_sift_flag, d_sift_recs)
+              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_sift_flag, d_sift_recs, d_defer_post, d_todo_list)
   if (variant == 1) {
     if (coord) BPSW_EXT_GO(true, 1); else BPSW_EXT_GO(false, 1);
   } else {

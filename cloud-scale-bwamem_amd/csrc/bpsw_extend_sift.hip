@@ -88,7 +88,8 @@ constexpr int SIFT_T_WORDS = 21;  // a coordinate task's staged target flank: 12
 template <bool COORD>
 __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict__ wire, const int n_tasks, int16_t* __restrict__ out,
                                                       const ExtScoring sc, const int dm, const int qmax, uint8_t* __restrict__ flag,
-                                                      uint4* __restrict__ recs, const ExtPrepass* __restrict__ pre) {
+                                                      uint4* __restrict__ recs, const ExtPrepass* __restrict__ pre,
+                                                      int* __restrict__ todo_count, int* __restrict__ todo_list, const int heavy_min) {
   // asynchronous entry (bpsw_extend_batch_device): the table scan ran just before on the same stream and nobody has read it back
   // yet -- a malformed batch is left untouched (ext_kernel behind this launch does the same and never looks at the flags)
   if (pre && pre->error != 0) return;
@@ -119,8 +120,27 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
   const int base = uni(pos);
   const int span = wave_max(pos + nwords) - base;
   const bool fits = __builtin_amdgcn_ballot_w64(pos < base) == 0ull && span <= SIFT_RAW_WORDS;
+  // The tasks this kernel leaves to ext_kernel go on its to-do list (one atomic per wave and class): todo_count[0] of them from
+  // the front of todo_list, and -- the ones with the longest sweeps ahead, which ext_kernel takes first: a launch ends with the
+  // last task taken -- todo_count[1] from its back.
+  const auto todo = [&](const bool mine_todo, const bool heavy) {
+    if (!todo_list) return;
+#pragma unroll
+    for (int cls = 0; cls < 2; ++cls) {
+      const bool in = mine_todo && (heavy == (cls == 1));
+      const unsigned long long v = __builtin_amdgcn_ballot_w64(in);
+      if (v) {
+        const int first = __builtin_ctzll(v);
+        int at = 0;
+        if (lane == first) at = atomicAdd(todo_count + cls, __popcll(v));
+        at = __builtin_amdgcn_readlane(at, first) + __popcll(v & ((1ull << lane) - 1ull));
+        if (in) todo_list[cls ? n_tasks - 1 - at : at] = task;
+      }
+    }
+  };
   if (P.a <= 0 || !fits) {
     if (live) flag[task] = 0;
+    todo(live, false);
     return;
   }
   uint32_t n_codes = 0u;  // codes above 3 (N) anywhere in the wave's streams?  (mostly none: then no lane looks for them again)
@@ -216,11 +236,6 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
     }
   }
   __syncthreads();
-  if (!mine) {
-    if (live) flag[task] = 0;
-    return;
-  }
-
   // ---- 3: the start-gap form where the closed form does not hold; extension() over the sides that are resolved ---------------------
   const auto settle = [&](const int side, SideRec* r, int st, const int item) {
     const int qLen = side ? rq : lq, rLen = t_len(side);
@@ -234,37 +249,47 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
       r->kind = SIFT_UNSEEN;
     }
   };
-  settle(0, &sr0, st0, item0);
-  settle(1, &sr1, st1, item1);
-
-  // extension() over the sides that are resolved (sift_chain, bpsw_extend_sift_core.h)
-  const SiftTask T = {lq, rq, regScore0, qBeg, h0, idx, penClip5, penClip3, P.wBand};
-  uint32_t rec_out[5];
-  if (sift_chain(T, sr0, sr1, rec_out)) {
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)sc.out_stride * (size_t)task);
+  int fl = 0;          // what ext_kernel finds in flag[task]: 0 nothing, 1 the record is written, 2 a verdict per side in recs
+  bool heavy = false;  // a long sweep ahead
+  if (!mine) {
+    heavy = live && heavy_min > 0;      // a flank of 128 bases or more, left to ext_kernel whole
+  } else {
+    settle(0, &sr0, st0, item0);
+    settle(1, &sr1, st1, item1);
+    // extension() over the sides that are resolved (sift_chain, bpsw_extend_sift_core.h)
+    const SiftTask T = {lq, rq, regScore0, qBeg, h0, idx, penClip5, penClip3, P.wBand};
+    uint32_t rec_out[5];
+    if (sift_chain(T, sr0, sr1, rec_out)) {
+      uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)sc.out_stride * (size_t)task);
 #pragma unroll
-    for (int w = 0; w < 5; ++w) o[w] = rec_out[w];
-    if (sc.side_how) {
-      if (lq > 0) sc.side_how[2 * (size_t)task] = 1;
-      if (rq > 0) sc.side_how[2 * (size_t)task + 1] = 1;
+      for (int w = 0; w < 5; ++w) o[w] = rec_out[w];
+      if (sc.side_how) {
+        if (lq > 0) sc.side_how[2 * (size_t)task] = 1;
+        if (rq > 0) sc.side_how[2 * (size_t)task + 1] = 1;
+      }
+      fl = 1;
+    } else {
+      // a form that did not hold for the start score this kernel could see is judged again by ext_kernel (another form may hold)
+      recs[2 * (size_t)task] = pack_rec(sr0);
+      recs[2 * (size_t)task + 1] = pack_rec(sr1);
+      fl = 2;
+      // the rows its sweeps may take: the bases of the flanks no form resolved
+      heavy = heavy_min > 0 && (sr0.kind != SIFT_FORM ? lq : 0) + (sr1.kind != SIFT_FORM ? rq : 0) >= heavy_min;
     }
-    flag[task] = 1;
-    return;
   }
-  // a form that did not hold for the start score this kernel could see is judged again by ext_kernel (another form may hold)
-  recs[2 * (size_t)task] = pack_rec(sr0);
-  recs[2 * (size_t)task + 1] = pack_rec(sr1);
-  flag[task] = 2;
+  todo(live && fl != 1, heavy);
+  if (live) flag[task] = (uint8_t)fl;
 }
 
 }  // namespace
 
 hipError_t launch_ext_sift_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int dm, int qmax,
-                                  uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev, const ExtPrepass* d_pre_check) {
+                                  uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev, const ExtPrepass* d_pre_check,
+                                  int* d_todo_count, int* d_todo_list, int heavy_min) {
   if (n_tasks <= 0) return hipSuccess;
   const int blocks = (n_tasks + 63) / 64;
-  if (sc.pac) BPSW_LAUNCH(kev, ext_sift_kernel<true>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs, d_pre_check);
-  else BPSW_LAUNCH(kev, ext_sift_kernel<false>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs, d_pre_check);
+  if (sc.pac) BPSW_LAUNCH(kev, ext_sift_kernel<true>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs, d_pre_check, d_todo_count, d_todo_list, heavy_min);
+  else BPSW_LAUNCH(kev, ext_sift_kernel<false>, dim3(blocks), dim3(64), 0, s, d_wire, n_tasks, d_out, sc, dm, qmax, d_flag, d_recs, d_pre_check, d_todo_count, d_todo_list, heavy_min);
   return hipGetLastError();
 }
 

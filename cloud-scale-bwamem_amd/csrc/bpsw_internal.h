@@ -86,13 +86,20 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false, KernelEvents kev = KernelEvents(),
                              bool short_kernel = false, int* d_defer = nullptr, int short_qmax = 255,
-                             const uint8_t* d_sift_flag = nullptr, const uint4* d_sift_recs = nullptr);
+                             const uint8_t* d_sift_flag = nullptr, const uint4* d_sift_recs = nullptr, int* d_defer_post = nullptr,
+                             const int* d_todo_list = nullptr);
 // The sift kernel (bpsw_extend_sift.hip): the exact shortcuts of every task of a format-1 batch, one task per lane, in front of
 // the 48-VGPR ext_kernel, which reads d_flag[task] (1: record written, skip; 2: d_recs[2 task + side] holds the verdict per side).
 // dm = a - (the one mismatch score of the matrix), sift_uniform_dm(); qmax = the longest flank the 48-VGPR build takes.
 hipError_t launch_ext_sift_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int dm, int qmax,
                                   uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev = KernelEvents(),
-                                  const ExtPrepass* d_pre_check = nullptr);
+                                  const ExtPrepass* d_pre_check = nullptr, int* d_todo_count = nullptr, int* d_todo_list = nullptr,
+                                  int heavy_min = 0);
+// (d_todo_list, n_tasks words: the tasks the sift kernel leaves to ext_kernel -- d_todo_count[0] of them from the front, and from
+// the back the d_todo_count[1] with the longest sweeps ahead: flanks of heavy_min bases or more in all that no form resolved, or
+// a flank the sift does not examine.  launch_ext_kernel with the same list takes its tickets from it, the back first.  The
+// counts are the third and fourth word of the queue heads, d_counter[2..3]: zero between launches, ext_kernel's last wave puts
+// them back.)
 int sift_uniform_dm(const int8_t mat[25], int exact_a);  // > 0 when all twelve base-vs-other-base entries equal exact_a - dm, else 0
 // ---- local SW (boundary 1) ---------------------------------------------------------------------
 struct SwScoring {

@@ -594,11 +594,19 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   if (n == 0) return BPSW_OK;
   { int prc = finish_pending(c); if (prc != BPSW_OK) return prc; }
   const size_t out_bytes = 20 * (size_t)n;
+  // The full kernel behind the short one, when the host has listed nothing for it (no flank above 255 bases) and few tasks could
+  // end up on its list at all (2x150 bp reads: the flanks of 128-131 bases): launched only when the short kernel did defer
+  // something -- its last wave posts the length of the list behind the results, the call looks after its wait and, if need be,
+  // launches the full kernel and waits again.  An empty launch held the stream for 0.1-0.18 ms of a 1.6 ms call
+  // (profiles/r03_trace_overlap.txt).  BPSW_EXT_LAZY_FULL=0: always launch it.
+  static const bool lazy_on = !(getenv("BPSW_EXT_LAZY_FULL") && atoi(getenv("BPSW_EXT_LAZY_FULL")) == 0);
+  const bool lazy_full = lazy_on && !side_how && use_short && use_full && n_long == 0 && 16 * (size_t)n_mid <= (size_t)n;
+  const size_t out_post_bytes = out_bytes + (lazy_full ? 4 : 0);
   // (32-byte result slots in the pinned buffer were tried: the 16 + 4 byte stores of a record then cost two write sectors each,
   // more fabric writes than back-to-back 20-byte records that merge in L2, and the host-side gather cost more than the memcpy)
   bool zc_slots = false;
   HIP_TRY(c->d_wire.reserve(dev_bytes));
-  HIP_TRY(c->d_out.reserve(out_bytes));
+  HIP_TRY(c->d_out.reserve(out_post_bytes));
   // The sift kernel in front of the short kernel (bpsw_extend_sift.hip: it examines the tasks whose flanks have at most 127 bases):
   // batches whose matrix has one mismatch score (both wire formats) and of whose tasks at most one in sixteen has a longer flank
   // (2x150 bp reads: the flanks of 128-131 bases; a batch of 2x250 bp reads would pay the launch for nothing).
@@ -610,11 +618,19 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   const int sift_dm = sift_uniform_dm(c->ext_mat, c->ext_sc.exact_a);
   const bool use_sift = sift_on && n >= sift_min && (c->shortcut_mask & 32) && use_short && 16 * (size_t)n_mid <= (size_t)n && sift_dm > 0;
   const size_t sift_rec_off = ((size_t)n + 15) & ~(size_t)15;
-  if (use_sift) HIP_TRY(c->d_sift.reserve(sift_rec_off + 32 * (size_t)n));
+  // the sift kernel lists what it leaves to the short kernel, which takes its tickets from the list (bpsw_extend.hip): the tasks
+  // whose unresolved flanks add up to heavy_min bases or more (and the ones the sift does not examine: a flank of 128 bases or
+  // more) first.  BPSW_EXT_TODO=0: no list, the short kernel walks the batch; BPSW_EXT_HEAVY_MIN=0: one class.
+  static const bool todo_on = !(getenv("BPSW_EXT_TODO") && atoi(getenv("BPSW_EXT_TODO")) == 0);
+  static const int heavy_min = getenv("BPSW_EXT_HEAVY_MIN") ? atoi(getenv("BPSW_EXT_HEAVY_MIN")) : 96;
+  const bool use_todo = use_sift && todo_on;
+  const size_t todo_off = sift_rec_off + 32 * (size_t)n;
+  if (use_sift) HIP_TRY(c->d_sift.reserve(todo_off + (use_todo ? 4 * (size_t)n : 0)));
   const bool staged = wire == (const uint8_t*)c->h_stage_in.ptr;
   if (staged && stage_bytes > c->h_stage_in.cap) return fail(BPSW_ERR_ARG, "extend_commit: the staged batch is larger than what bpsw_extend_stage was asked for");
   HIP_TRY(c->h_stage_in.reserve(stage_bytes));
-  HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_bytes));
+  HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_post_bytes));
+  if (lazy_full) *(volatile int*)((char*)c->h_stage_out.ptr + out_bytes) = 0;
   const double t_in = wall_ms();
   if (!staged) memcpy(c->h_stage_in.ptr, wire, wire_bytes);
   if (with_list) {  // rides on the same copy
@@ -636,10 +652,12 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     // device memory and copied back
     const bool zc_out = (zerocopy_mask() & 1) != 0;
     int16_t* k_out = zc_out ? (int16_t*)c->h_stage_out.ptr : (int16_t*)c->d_out.ptr;
+    ExtScoring c_sc_full = c->ext_sc;  // what a late launch of the full kernel gets (lazy_full)
     {
       ExtScoring sc = c->ext_sc;
       if (zc_slots) sc.out_stride = 16;
       if (coord) { sc.pac = d_pac; sc.l_pac = l_pac; }
+      c_sc_full = sc;
       if (side_how) {  // diagnostics: the kernel notes per side whether a shortcut or the DP produced the result
         HIP_TRY(c->d_ext_lists.reserve(2 * (size_t)n + 16));
         HIP_TRY(hipMemsetAsync(c->d_ext_lists.ptr, 0, 2 * (size_t)n, s));
@@ -650,18 +668,20 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       int* d_list = with_list ? (int*)((char*)c->d_wire.ptr + list_off) : nullptr;
       if (use_short) {
         KernelEvents kev;
-        kev.start = c->ev[1]; kev.stop = use_full ? nullptr : c->ev[2];
+        kev.start = c->ev[1]; kev.stop = (use_full && !lazy_full) ? nullptr : c->ev[2];
         uint8_t* d_sflag = use_sift ? (uint8_t*)c->d_sift.ptr : nullptr;
         uint4* d_srecs = use_sift ? (uint4*)((char*)c->d_sift.ptr + sift_rec_off) : nullptr;
+        int* d_todo = use_todo ? (int*)((char*)c->d_sift.ptr + todo_off) : nullptr;
         if (use_sift) {  // the kernel time of the call starts with it
           KernelEvents sev;
           sev.start = kev.start; kev.start = nullptr;
-          HIP_TRY(launch_ext_sift_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, sift_dm, 127, d_sflag, d_srecs, s, sev));
+          HIP_TRY(launch_ext_sift_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, sift_dm, 127, d_sflag, d_srecs, s, sev, nullptr,
+                                         use_todo ? d_queue + 2 : nullptr, d_todo, heavy_min));
         }
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 255), mr_short, c->num_cu, d_queue, nullptr, s,
-                                  nullptr, false, kev, true, d_list, 255, d_sflag, d_srecs));
+                                  nullptr, false, kev, true, d_list, 255, d_sflag, d_srecs, lazy_full ? (int*)(k_out + 10 * (size_t)n) : nullptr, d_todo));
       }
-      if (use_full) {
+      if (use_full && !lazy_full) {
         KernelEvents kev;
         kev.start = use_short ? nullptr : c->ev[1]; kev.stop = c->ev[2];
         // behind the 48-VGPR kernel: the list it completed on the device (what it may have deferred is unknown to the host
@@ -680,9 +700,20 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     if (!on_dispatch) HIP_TRY(hipEventRecord(c->ev[2], s));
     const bool kernel_is_last = on_dispatch && zc_out && !side_how;  // then the call waits for the kernel's own stop event
     kernel_was_last = kernel_is_last;
-    if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
+    if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_post_bytes, hipMemcpyDeviceToHost, s));
     if (!kernel_is_last) HIP_TRY(hipEventRecord(c->ev[3], s));
     HIP_TRY(wait_event(c, kernel_is_last ? c->ev[2] : c->ev[3], 0));  // the last operation of the call on this stream
+    if (lazy_full && *(volatile int*)((char*)c->h_stage_out.ptr + out_bytes) > 0) {  // the short kernel left a list: the full kernel, now
+      KernelEvents kev;
+      kev.stop = c->ev[2];
+      const int listed = *(volatile int*)((char*)c->h_stage_out.ptr + out_bytes);
+      HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, listed, k_out, c_sc_full, mq, mr, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), nullptr, s,
+                                nullptr, false, kev, false, (int*)((char*)c->d_wire.ptr + list_off)));
+      if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
+      if (!kernel_is_last) HIP_TRY(hipEventRecord(c->ev[3], s));
+      HIP_TRY(wait_event(c, kernel_is_last ? c->ev[2] : c->ev[3], 0));
+      c->stats.ext_full_relaunches++;
+    }
     t_dev1 = wall_ms();
     c->stats.ext_wait_ms += lease.wait_ms;
   }

@@ -18,6 +18,9 @@
 #include "bpsw_internal.h"
 #include "bpsw_wave.h"
 
+#include "bpsw_diag_waves.h"
+BPSW_DIAG_WAVES_DEFINE(sw)
+
 namespace bpsw {
 namespace {
 
@@ -776,6 +779,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
   __shared__ uint32_t tbuf_all[WAVES_PER_BLOCK][PK_TBUF + PK_G];
   __shared__ uint8_t mate_all[WAVES_PER_BLOCK][2][PK_MATE_LDS];
   extern __shared__ uint32_t key_rows[];
+  BPSW_DIAG_WAVE_BEGIN();
   if (pre && (pre->error != 0 || pre->max_qlen > (PK_LAST + 1) * C || ((pre->max_tlen + 63) & ~63) > scratch_per_job)) return;
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
@@ -872,6 +876,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
     }
     __builtin_amdgcn_wave_barrier();
   }
+  BPSW_DIAG_WAVE_END(3, out, lane);
 }
 
 // validates the job table and finds the longest mate / window

@@ -429,6 +429,7 @@ typedef struct {
   double ext_host_in_ms, ext_wait_ms, ext_dev_ms, ext_host_out_ms;
   double grp_plan_ms, grp_pack_ms, grp_wait_ms, grp_dev_ms, grp_replay_ms, grp_out_ms;
   uint64_t grp_calls, grp_pairs;
+  uint64_t ext_full_relaunches; /* extension calls whose short kernel deferred tasks, so that the full kernel was launched behind it after all */
 } bpsw_stats_t;
 int bpsw_get_stats(bpsw_ctx_t *ctx, bpsw_stats_t *out);
 int bpsw_reset_stats(bpsw_ctx_t *ctx);

@@ -1,5 +1,7 @@
 """Parity of the HIP extension kernel (boundary 2) with the oracle's restatement of the Scala extension()
 (MemChainToAlignBatched.scala:789-883 over SWUtil.scala:61-230).  Bit-exact: int16 results compared with ==."""
+import os
+
 import numpy as np
 import pytest
 
@@ -351,6 +353,41 @@ def test_launch_plans_of_the_split_kernel(ctx, orc, mid_share, w):
     soa.w = w
     for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
         _check(ctx, orc, soa, zmode=zmode)
+
+
+@pytest.mark.parametrize("w,must_defer", [(100, False), (70, True), (127, True)])
+def test_full_kernel_is_launched_late_when_the_short_kernel_deferred(ctx, orc, w, must_defer):
+    """bpsw_runtime.cpp (lazy_full): a batch without flanks above 255 bases and with few of 128-255 gets the full kernel only if
+    the short kernel put something on its list -- the count comes back with the results, the call launches the full kernel behind
+    and waits again.  Same results as the oracle whether the second launch happens or not; bpsw_stats_t counts the second launches."""
+    rng = np.random.default_rng(77 + w)
+    tasks = []
+    for t in range(2400):
+        if rng.random() < 0.04:
+            n1, n2 = int(rng.integers(128, 256)), int(rng.integers(1, 128))
+        else:
+            n1, n2 = int(rng.integers(1, 128)), int(rng.integers(1, 128))
+        if rng.random() < 0.5:
+            n1, n2 = n2, n1
+        sub = float(rng.choice([0.0, 0.02, 0.08, 0.2]))
+        indel = float(rng.choice([0.0, 0.01, 0.04]))
+        lq, lr = _flank(rng, n1, sub, indel)
+        rq, rr = _flank(rng, n2, sub, indel)
+        tasks.append((lq, lr, rq, rr, int(rng.choice([19, 30, 60, 120])), n1))
+    soa = _manual_tasks(tasks)
+    soa.w = w
+    before = ctx.stats().ext_full_relaunches
+    for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
+        _check(ctx, orc, soa, zmode=zmode)
+    late = ctx.stats().ext_full_relaunches - before
+    if must_defer and os.environ.get("BPSW_EXT_LAZY_FULL", "1") != "0":
+        assert late > 0   # w = 70 / 127: the doubled band of a retry outgrows the 128-column window
+    # a batch with nothing between 128 and 255 bases never has a list
+    short = _manual_tasks([t for t in tasks if max(len(t[0]), len(t[2])) < 128])
+    short.w = w
+    before = ctx.stats().ext_full_relaunches
+    _check(ctx, orc, short)
+    assert ctx.stats().ext_full_relaunches == before
 
 
 @pytest.mark.parametrize("sub,indel,n_rate", [(0.005, 0.0005, 0.0), (0.01, 0.001, 0.0), (0.02, 0.004, 0.002), (0.05, 0.01, 0.0)])
