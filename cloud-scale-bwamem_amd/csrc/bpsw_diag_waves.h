@@ -47,6 +47,10 @@ constexpr unsigned DIAG_WAVE_CAP = 1u << 21;
 #define BPSW_DIAG_TASK_BEGIN(TASK) do { diag_last = (unsigned)(TASK); diag_tt0 = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define BPSW_DIAG_TASK_END() do { diag_last_dur = (unsigned)(__builtin_amdgcn_s_memrealtime() - diag_tt0); ++diag_n; diag_max = diag_last_dur > diag_max ? diag_last_dur : diag_max; } while (0)
 #define BPSW_DIAG_WAVE_END_TASKS(KIND, TAG, LANE) diag_wave_end(diag_t0, KIND, TAG, LANE, make_uint4(diag_last, diag_last_dur, diag_n, diag_max))
+// rescue kernel: four words of the wave's (last) job pair
+#define BPSW_DIAG_DUO_DECL() unsigned diag_d0 = 0u, diag_d1 = 0u, diag_d2 = 0u, diag_d3 = 0u
+#define BPSW_DIAG_DUO_SET(A, B, CC, DD) do { diag_d0 = (unsigned)(A); diag_d1 = (unsigned)(B); diag_d2 = (unsigned)(CC); diag_d3 = (unsigned)(DD); } while (0)
+#define BPSW_DIAG_WAVE_END_DUO(KIND, TAG, LANE) diag_wave_end(diag_t0, KIND, TAG, LANE, make_uint4(diag_d0, diag_d1, diag_d2, diag_d3))
 }  // namespace bpsw
 #else
 #define BPSW_DIAG_WAVES_DEFINE(NAME)
@@ -56,4 +60,7 @@ constexpr unsigned DIAG_WAVE_CAP = 1u << 21;
 #define BPSW_DIAG_TASK_BEGIN(TASK)
 #define BPSW_DIAG_TASK_END()
 #define BPSW_DIAG_WAVE_END_TASKS(KIND, TAG, LANE)
+#define BPSW_DIAG_DUO_DECL()
+#define BPSW_DIAG_DUO_SET(A, B, CC, DD)
+#define BPSW_DIAG_WAVE_END_DUO(KIND, TAG, LANE)
 #endif

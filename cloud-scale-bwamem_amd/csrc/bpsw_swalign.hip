@@ -780,6 +780,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
   __shared__ uint8_t mate_all[WAVES_PER_BLOCK][2][PK_MATE_LDS];
   extern __shared__ uint32_t key_rows[];
   BPSW_DIAG_WAVE_BEGIN();
+  BPSW_DIAG_DUO_DECL();
   if (pre && (pre->error != 0 || pre->max_qlen > (PK_LAST + 1) * C || ((pre->max_tlen + 63) & ~63) > scratch_per_job)) return;
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
@@ -853,6 +854,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
       qCols2[g] = on2[g] ? qe[g] + 1 : 0;
       stop2[g] = min(score[g] & 0xffff, maxScore);
     }
+    BPSW_DIAG_DUO_SET((on[0] ? J.tLen[0] : 0) | ((on[1] ? J.tLen[1] : 0) << 16), (on[0] ? f[0].n_rows : 0) | ((on[1] ? f[1].n_rows : 0) << 16),
+                      (on2[0] ? te[0] + 1 : 0) | ((on2[1] ? te[1] + 1 : 0) << 16), (on[0] ? score[0] : 0) | ((on[1] ? score[1] : 0) << 16));
     if (on2[0] | on2[1]) {
       PkRes r[2];
       __builtin_amdgcn_wave_barrier();
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
     }
     __builtin_amdgcn_wave_barrier();
   }
-  BPSW_DIAG_WAVE_END(3, out, lane);
+  BPSW_DIAG_WAVE_END_DUO(3, out, lane);
 }
 
 // validates the job table and finds the longest mate / window

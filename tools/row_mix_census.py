@@ -45,6 +45,7 @@ SIFT_FORM = 2  # bpsw_extend_sift_core.h: SIFT_UNSEEN 0, SIFT_FAIL 1, SIFT_FORM 
 
 
 def sweep(q, t, h0, w, stats, end_bonus):
+    global span_hist
     """one SWExtend call; returns (max, qle, tle, gtle, gscore, max_off) and bins its rows"""
     oD, eD, oI, eI = soa.o_del, soa.e_del, soa.o_ins, soa.e_ins
     qlen, tlen = len(q), len(t)
@@ -70,6 +71,7 @@ def sweep(q, t, h0, w, stats, end_bonus):
             if U <= mx and U < gscore:
                 break
         span = end - beg
+        span_hist[min(span, 255) // 8] += 1
         key = ("cols2" if span > 63 else "cols1", "live" if h1 > 0 else "dead", "atend" if end == qlen else "inner", "tail" if i >= qlen else "body")
         if span > 0:
             js = np.arange(beg, end)
@@ -109,6 +111,7 @@ def sweep(q, t, h0, w, stats, end_bonus):
 
 
 stats = collections.Counter()
+span_hist = collections.Counter()
 sides_dp = sides_all = rows = 0
 rng = np.random.default_rng(1)
 pick = rng.permutation(n)[:n_want]
@@ -137,3 +140,7 @@ for k, v in stats.most_common(24):
     print(f"  {100 * v / tot:5.1f} %  {' '.join(k)}")
 for dim, names in ((0, ("cols1", "cols2")), (1, ("live", "dead")), (2, ("atend", "inner")), (3, ("tail", "body")), (4, ("zero", "nozero")), (5, ("imp", "noimp"))):
     print("  ", {nm: round(100 * sum(v for k, v in stats.items() if k[dim] == nm) / tot, 1) for nm in names})
+
+tot_s = sum(span_hist.values())
+acc = 0
+print("band width of the swept rows (columns, cumulative share): " + " ".join(f"<={8 * k + 7}:{(acc := acc + span_hist[k]) / tot_s:.3f}" for k in sorted(span_hist)))

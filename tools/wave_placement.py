@@ -78,6 +78,23 @@ for s in samples:
 occ /= occ.sum()
 print("share of SIMD-time with k resident waves, k = 0..11+: " + " ".join(f"{v:.3f}" for v in occ))
 
+# rescue kernel: what the waves' job pairs looked like, and how a wave's lifetime follows from it
+sw = kind == 3
+if sw.any():
+    tl0, tl1 = x_last[sw] & 0xffff, x_last[sw] >> 16
+    r0, r1 = x_last_dur[sw] & 0xffff, x_last_dur[sw] >> 16
+    p0, p1 = x_n[sw] & 0xffff, x_n[sw] >> 16
+    life = (t1 - t0)[sw] * 1e-2
+    both = (tl0 > 0) & (tl1 > 0)
+    pc = lambda v: " ".join(f"{np.percentile(v, q):.0f}" for q in (1, 10, 50, 90, 99))
+    print(f"rescue job pairs: window rows p1/10/50/90/99: {pc(np.concatenate([tl0[tl0 > 0], tl1[tl1 > 0]]))}; rows the first pass swept: {pc(np.concatenate([r0[tl0 > 0], r1[tl1 > 0]]))}; "
+          f"rows of the second pass (0 = none): {pc(np.concatenate([p0[tl0 > 0], p1[tl1 > 0]]))}; jobs with a second pass {np.mean(np.concatenate([p0[tl0 > 0], p1[tl1 > 0]]) > 0):.3f}")
+    steps = np.maximum(r0, r1) + np.maximum(p0, p1)      # the pair advances together: a pass takes as many steps as its longer job
+    ideal = (r0 + r1 + p0 + p1) / 2.0
+    print(f"   steps of a pair (max of the two jobs per pass) mean {steps.mean():.0f}, half the sum of its jobs' rows {ideal.mean():.0f}: pairing costs {steps.mean() / ideal.mean() - 1:.3f}; "
+          f"lifetime us per step {np.median(life[steps > 0] / steps[steps > 0]):.3f}; corr(lifetime, steps) {np.corrcoef(life, steps)[0, 1]:.3f}")
+    print(f"   steps p1/10/50/90/99: {pc(steps)}; lifetime us: {pc(life)}")
+
 names = {0: "ext_kernel<.,0> (full)", 1: "ext_kernel<.,1> (short)", 3: "swp_kernel"}
 for k in sorted(set(kind.tolist())):
     sel = kind == k
