@@ -78,8 +78,12 @@ int make_sw_scoring(const bpsw_opt_t* opt, SwScoring* sc) {
 
 struct JobResult {
   Reg2AlnOut k;
-  std::vector<uint32_t> cigar;
-  std::string md;
+  size_t cig_at = 0, md_at = 0;  // its CIGAR words / MD bytes in JobResults::cig / ::md (k.n_cigar, k.md_len of them)
+};
+struct JobResults {  // one allocation per kind and call, not two per job
+  std::vector<JobResult> r;
+  std::vector<uint32_t> cig;
+  std::vector<char> md;
 };
 
 // One launch of reg2aln_kernel over `n` mapped jobs (regs[j] with rb, re >= 0); caller holds c->mu and has set the device.
@@ -155,9 +159,11 @@ int launch_jobs(bpsw_ctx* c, const SwScoring& sc, const bpsw_opt_t* opt, int fla
 // All jobs of a call, re-submitting the few whose CIGAR or MD did not fit the first, small, per-job room.
 int run_jobs(bpsw_ctx* c, const SwScoring& sc, const bpsw_opt_t* opt, int flavour, const BnsView& bns, const std::vector<int32_t>& read_len,
              const std::vector<int64_t>& read_off, const uint8_t* read_pool, size_t read_pool_bytes,
-             const std::vector<bpsw_alnreg_t>& regs, std::vector<JobResult>* res) {
+             const std::vector<bpsw_alnreg_t>& regs, JobResults* res) {
   const int n = (int)regs.size();
-  res->assign((size_t)n, JobResult());
+  res->r.assign((size_t)n, JobResult());
+  res->cig.clear(); res->md.clear();
+  res->cig.reserve(4 * (size_t)n); res->md.reserve(16 * (size_t)n);
   std::vector<int> todo((size_t)n);
   for (int j = 0; j < n; ++j) todo[(size_t)j] = j;
   int max_cigar = 16, max_md = 64;
@@ -175,14 +181,15 @@ int run_jobs(bpsw_ctx* c, const SwScoring& sc, const bpsw_opt_t* opt, int flavou
     if (rc != BPSW_OK) return rc;
     std::vector<int> again;
     for (int t = 0; t < m; ++t) {
-      JobResult& r = (*res)[(size_t)todo[(size_t)t]];
+      JobResult& r = res->r[(size_t)todo[(size_t)t]];
       r.k = out[(size_t)t];
       const bool fits = r.k.n_cigar <= max_cigar && r.k.md_len <= max_md;
       if (!fits && r.k.status == 0 && max_cigar < KERNEL_CIG_CAP + 2) { again.push_back(todo[(size_t)t]); continue; }
       if (!fits && r.k.status == 0) r.k.status = BPSW_ALN_OVERFLOW;
       if (r.k.status == 0 || r.k.status == BPSW_ALN_NOCIGAR) {
-        r.cigar.assign(cig.begin() + (size_t)t * (size_t)max_cigar, cig.begin() + (size_t)t * (size_t)max_cigar + (size_t)std::max(r.k.n_cigar, 0));
-        r.md.assign((const char*)md.data() + (size_t)t * (size_t)max_md, (size_t)std::max(r.k.md_len, 0));
+        r.cig_at = res->cig.size(); r.md_at = res->md.size();
+        res->cig.insert(res->cig.end(), cig.begin() + (size_t)t * (size_t)max_cigar, cig.begin() + (size_t)t * (size_t)max_cigar + (size_t)std::max(r.k.n_cigar, 0));
+        res->md.insert(res->md.end(), (const char*)md.data() + (size_t)t * (size_t)max_md, (const char*)md.data() + (size_t)t * (size_t)max_md + (size_t)std::max(r.k.md_len, 0));
       }
     }
     todo.swap(again);
@@ -211,7 +218,8 @@ void mark_primary(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, std::vector<bps
     return signed_hash ? (int64_t)x.hash < (int64_t)y.hash : x.hash < y.hash;  // hash64 is a bijection: no ties
   });
   const int gap = std::max(o.a + o.b, std::max(o.o_del + o.e_del, o.o_ins + o.e_ins));
-  std::vector<int> prim((size_t)n + 1, 0);  // the Scala's zero-filled z array, MP:46
+  static thread_local std::vector<int> prim;
+  prim.assign((size_t)n + 1, 0);  // the Scala's zero-filled z array, MP:46
   int np = 0;
   prim[(size_t)np++] = 0;
   for (int i = 1; i < n; ++i) {
@@ -273,7 +281,8 @@ struct PairScore { int score, sub, n_sub, z[2]; };
 PairScore mem_pair(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, long long l_pac, const bpsw_pestat_t pes[4],
                    const std::vector<bpsw_alnreg_t> a[2], int64_t id) {
   typedef std::pair<uint64_t, uint64_t> Key;  // (x, y), ordered like pair64_lt
-  std::vector<Key> v, u;
+  static thread_local std::vector<Key> v, u;
+  v.clear(); u.clear();
   for (int r = 0; r < 2; ++r)
     for (size_t i = 0; i < a[r].size(); ++i) {
       const bpsw_alnreg_t& e = a[r][i];
@@ -323,8 +332,8 @@ PairScore mem_pair(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, long long l_pa
 // ---- plan / emit -------------------------------------------------------------------------------------------------------
 struct Aln {  // a mem_aln_t under construction
   bpsw_aln_t a;
-  const std::vector<uint32_t>* cigar = nullptr;
-  const std::string* md = nullptr;
+  const uint32_t* cigar = nullptr;  // a.n_cigar words
+  const char* md = nullptr;         // a.md_len bytes
 };
 
 struct EndPlan {
@@ -337,30 +346,53 @@ struct PairPlan {
   EndPlan end[2];
 };
 
-void put_num(std::string& s, long long v) {
+// The text of a call is written straight into the caller's buffer (round 3 built a std::string and copied it: push_back by
+// push_back, 2.3 GB/s and a 3 MB memcpy per 4 096 pairs).  Past the capacity it only counts, so that *out_needed comes out right.
+struct Text {
+  char* buf;
+  size_t cap, n = 0;
+  Text(char* b, size_t c) : buf(b), cap(b ? c : 0) {}
+  size_t size() const { return n; }
+  char* grow(size_t len) {  // len more bytes, to be written by the caller; nullptr when they do not fit (they still count)
+    char* p = n + len <= cap ? buf + n : nullptr;
+    n += len;
+    return p;
+  }
+  void push_back(char c) { if (n < cap) buf[n] = c; ++n; }
+  void append(const char* p, size_t len) { char* d = grow(len); if (d) memcpy(d, p, len); }
+  Text& operator+=(const char* z) { append(z, strlen(z)); return *this; }
+  Text& operator+=(const std::string& z) { append(z.data(), z.size()); return *this; }
+};
+
+const char kDigitPairs[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+
+void put_num(Text& s, long long v) {
   char b[24];
-  int n = 0;
+  int n = 24;
   const bool neg = v < 0;
   unsigned long long x = neg ? (unsigned long long)(-v) : (unsigned long long)v;
-  do { b[n++] = (char)('0' + x % 10); x /= 10; } while (x);
-  if (neg) s.push_back('-');
-  while (n) s.push_back(b[--n]);
+  while (x >= 100) { const unsigned r = (unsigned)(x % 100); x /= 100; b[--n] = kDigitPairs[2 * r + 1]; b[--n] = kDigitPairs[2 * r]; }
+  if (x >= 10) { b[--n] = kDigitPairs[2 * x + 1]; b[--n] = kDigitPairs[2 * x]; }
+  else b[--n] = (char)('0' + x);
+  if (neg) b[--n] = '-';
+  s.append(b + n, (size_t)(24 - n));
 }
 
 int ref_len_of(const Aln& p) {  // getRlen, R2S:146-160
   int l = 0;
   if (p.a.n_cigar > 0 && p.cigar)
-    for (int k = 0; k < p.a.n_cigar; ++k) { const int op = (int)((*p.cigar)[(size_t)k] & 0xf); if (op == 0 || op == 2) l += (int)((*p.cigar)[(size_t)k] >> 4); }
+    for (int k = 0; k < p.a.n_cigar; ++k) { const int op = (int)(p.cigar[(size_t)k] & 0xf); if (op == 0 || op == 2) l += (int)(p.cigar[(size_t)k] >> 4); }
   return l;
 }
 
-void put_contig(std::string& s, const BnsView& bns, int rid) {
+void put_contig(Text& s, const BnsView& bns, int rid) {
   if ((size_t)rid < bns.name.size() && !bns.name[(size_t)rid].empty()) s += bns.name[(size_t)rid];
   else { s += "ctg"; put_num(s, rid + 1); }
 }
 
 // memAlnToSAM, R2S:328-560 (C: native/bwamem.c:726-838; the Scala leaves the comment field out, R2S:546-556)
-void aln_to_sam(const BnsView& bns, int flavour, std::string& s, const char* name, size_t name_len, int l_seq, const uint8_t* seq,
+void aln_to_sam(const BnsView& bns, int flavour, Text& s, const char* name, size_t name_len, int l_seq, const uint8_t* seq,
                 const uint8_t* qual, const Aln* list, const size_t n_list, int which, const Aln* mate_in) {
   Aln p = list[(size_t)which];
   Aln m;
@@ -383,9 +415,9 @@ void aln_to_sam(const BnsView& bns, int flavour, std::string& s, const char* nam
     put_num(s, p.a.mapq); s.push_back('\t');
     if (p.a.n_cigar > 0) {
       for (int i = 0; i < p.a.n_cigar; ++i) {
-        int c = (int)((*p.cigar)[(size_t)i] & 0xf);
+        int c = (int)(p.cigar[(size_t)i] & 0xf);
         if (c == 3 || c == 4) c = which ? 4 : 3;  // hard clipping for supplementary alignments
-        put_num(s, (*p.cigar)[(size_t)i] >> 4); s.push_back("MIDSH"[c]);
+        put_num(s, p.cigar[(size_t)i] >> 4); s.push_back("MIDSH"[c]);
       }
     } else s.push_back('*');
   } else s += "*\t0\t0\t*";
@@ -407,31 +439,33 @@ void aln_to_sam(const BnsView& bns, int flavour, std::string& s, const char* nam
   } else {
     int qb = 0, qe = l_seq;
     const int nc = p.a.n_cigar;
-    const bool clip_first = nc > 0 && (((*p.cigar)[0] & 0xf) == 4 || ((*p.cigar)[0] & 0xf) == 3);
-    const bool clip_last = nc > 0 && (((*p.cigar)[(size_t)nc - 1] & 0xf) == 4 || ((*p.cigar)[(size_t)nc - 1] & 0xf) == 3);
+    const bool clip_first = nc > 0 && ((p.cigar[0] & 0xf) == 4 || (p.cigar[0] & 0xf) == 3);
+    const bool clip_last = nc > 0 && ((p.cigar[(size_t)nc - 1] & 0xf) == 4 || (p.cigar[(size_t)nc - 1] & 0xf) == 3);
     if (!p.a.is_rev) {
-      if (which && clip_first) qb += (int)((*p.cigar)[0] >> 4);
-      if (which && clip_last) qe -= (int)((*p.cigar)[(size_t)nc - 1] >> 4);
-      const size_t n = (size_t)std::max(0, qe - qb), at = s.size();
-      s.resize(at + n + 1 + (qual ? n : 1));  // bases, tab, qualities: written in place
-      char* d = &s[at];
-      for (size_t i = 0; i < n; ++i) d[i] = "ACGTN"[seq[(size_t)qb + i] > 4 ? 4 : seq[(size_t)qb + i]];
-      d[n] = '\t';
-      if (qual) memcpy(d + n + 1, qual + qb, n); else d[n + 1] = '*';
+      if (which && clip_first) qb += (int)(p.cigar[0] >> 4);
+      if (which && clip_last) qe -= (int)(p.cigar[(size_t)nc - 1] >> 4);
+      const size_t n = (size_t)std::max(0, qe - qb);
+      char* d = s.grow(n + 1 + (qual ? n : 1));  // bases, tab, qualities: written in place
+      if (d) {
+        for (size_t i = 0; i < n; ++i) d[i] = "ACGTN"[seq[(size_t)qb + i] > 4 ? 4 : seq[(size_t)qb + i]];
+        d[n] = '\t';
+        if (qual) memcpy(d + n + 1, qual + qb, n); else d[n + 1] = '*';
+      }
     } else {
-      if (which && clip_first) qe -= (int)((*p.cigar)[0] >> 4);
-      if (which && clip_last) qb += (int)((*p.cigar)[(size_t)nc - 1] >> 4);
-      const size_t n = (size_t)std::max(0, qe - qb), at = s.size();
-      s.resize(at + n + 1 + (qual ? n : 1));
-      char* d = &s[at];
-      for (size_t i = 0; i < n; ++i) d[i] = "TGCAN"[seq[(size_t)qe - 1 - i] > 4 ? 4 : seq[(size_t)qe - 1 - i]];
-      d[n] = '\t';
-      if (qual) for (size_t i = 0; i < n; ++i) d[n + 1 + i] = (char)qual[(size_t)qe - 1 - i]; else d[n + 1] = '*';
+      if (which && clip_first) qe -= (int)(p.cigar[0] >> 4);
+      if (which && clip_last) qb += (int)(p.cigar[(size_t)nc - 1] >> 4);
+      const size_t n = (size_t)std::max(0, qe - qb);
+      char* d = s.grow(n + 1 + (qual ? n : 1));
+      if (d) {
+        for (size_t i = 0; i < n; ++i) d[i] = "TGCAN"[seq[(size_t)qe - 1 - i] > 4 ? 4 : seq[(size_t)qe - 1 - i]];
+        d[n] = '\t';
+        if (qual) for (size_t i = 0; i < n; ++i) d[n + 1 + i] = (char)qual[(size_t)qe - 1 - i]; else d[n + 1] = '*';
+      }
     }
   }
   if (p.a.n_cigar > 0) {
     s += "\tNM:i:"; put_num(s, p.a.NM);
-    s += "\tMD:Z:"; if (p.md) s += *p.md;
+    s += "\tMD:Z:"; if (p.md && p.a.md_len > 0) s.append(p.md, (size_t)p.a.md_len);
   }
   if (p.a.score >= 0) { s += "\tAS:i:"; put_num(s, p.a.score); }
   if (p.a.sub >= 0) { s += "\tXS:i:"; put_num(s, p.a.sub); }
@@ -446,7 +480,7 @@ void aln_to_sam(const BnsView& bns, int flavour, std::string& s, const char* nam
         put_contig(s, bns, r.a.rid); s.push_back(',');
         put_num(s, r.a.pos + 1); s.push_back(',');
         s.push_back("+-"[r.a.is_rev ? 1 : 0]); s.push_back(',');
-        for (int k = 0; k < r.a.n_cigar; ++k) { put_num(s, (*r.cigar)[(size_t)k] >> 4); s.push_back("MIDSH"[(*r.cigar)[(size_t)k] & 0xf]); }
+        for (int k = 0; k < r.a.n_cigar; ++k) { put_num(s, r.cigar[(size_t)k] >> 4); s.push_back("MIDSH"[r.cigar[(size_t)k] & 0xf]); }
         s.push_back(','); put_num(s, r.a.mapq);
         s.push_back(','); put_num(s, r.a.NM);
         s.push_back(';');
@@ -456,14 +490,14 @@ void aln_to_sam(const BnsView& bns, int flavour, std::string& s, const char* nam
   s.push_back('\n');
 }
 
-const std::vector<uint32_t> kNoCigar;
-const std::string kNoMd;
+const uint32_t kNoCigar[1] = {0};
+const char kNoMd[1] = {0};
 
 // the mem_aln_t of memRegToAln: kernel result + the fields that need no sequence (R2S:188-192, :306-310)
-Aln make_aln(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, const bpsw_alnreg_t* ar, const JobResult* jr) {
+Aln make_aln(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, const bpsw_alnreg_t* ar, const JobResult* jr, const JobResults& R) {
   Aln x;
   memset(&x.a, 0, sizeof x.a);
-  x.cigar = &kNoCigar; x.md = &kNoMd;
+  x.cigar = kNoCigar; x.md = kNoMd;
   if (!ar || ar->rb < 0 || ar->re < 0 || !jr) { x.a.rid = -1; x.a.pos = -1; x.a.flag |= 0x4; return x; }
   x.a.mapq = ar->secondary < 0 ? approx_mapq(o, t, *ar) : 0;
   if (ar->secondary >= 0) x.a.flag |= 0x100;
@@ -473,7 +507,7 @@ Aln make_aln(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, const bpsw_alnreg_t*
   x.a.n_cigar = jr->k.n_cigar; x.a.md_len = jr->k.md_len;
   x.a.score = ar->score;
   x.a.sub = ar->sub > ar->csub ? ar->sub : ar->csub;
-  x.cigar = &jr->cigar; x.md = &jr->md;
+  x.cigar = R.cig.data() + jr->cig_at; x.md = R.md.data() + jr->md_at;
   return x;
 }
 
@@ -550,12 +584,13 @@ int bpsw_reg2aln_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt
   if (rc != BPSW_OK) return rc;
   memset(out_cigar, 0, 4 * (size_t)n * (size_t)j->max_cigar);
   memset(out_md, 0, (size_t)n * (size_t)j->max_md);
-  for (int t = 0; t < n; ++t) { Aln u = make_aln(*opt, *topt, nullptr, nullptr); out[t] = u.a; }
+  const JobResults none;
+  for (int t = 0; t < n; ++t) { Aln u = make_aln(*opt, *topt, nullptr, nullptr, none); out[t] = u.a; }
   for (int x = 0; x < m; ++x) {
     const int t = mapped[(size_t)x];
     JobResult jr;
     jr.k = k[(size_t)x];
-    Aln u = make_aln(*opt, *topt, &j->regs[t], &jr);
+    Aln u = make_aln(*opt, *topt, &j->regs[t], &jr, none);  // (the fields only: CIGAR and MD are copied from the launch's arrays below)
     out[t] = u.a;
     if (jr.k.status == BPSW_ALN_XREF) continue;
     if (jr.k.n_cigar <= j->max_cigar) memcpy(out_cigar + (size_t)t * (size_t)j->max_cigar, cig.data() + (size_t)x * (size_t)j->max_cigar, 4 * (size_t)std::max(jr.k.n_cigar, 0));
@@ -594,11 +629,22 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
   // ---- plan -----------------------------------------------------------------------------------------------------------
   c->last_tail_ms = 0.f; c->last_tail_jobs = 0; c->last_tail_resubmitted = 0;
   const double t_plan = now_ms();
-  std::vector<std::vector<bpsw_alnreg_t> > regs((size_t)(2 * G));
-  std::vector<PairPlan> plan((size_t)G);
-  std::vector<int32_t> job_len;
-  std::vector<int64_t> job_off;
-  std::vector<bpsw_alnreg_t> job_reg;
+  struct PlanScratch {
+    std::vector<std::vector<bpsw_alnreg_t> > regs;
+    std::vector<PairPlan> plan;
+    std::vector<int32_t> job_len;
+    std::vector<int64_t> job_off;
+    std::vector<bpsw_alnreg_t> job_reg;
+  };
+  static thread_local PlanScratch scratch;  // 2 G + G vectors, re-filled in place: their heap blocks are reused from call to call
+  std::vector<std::vector<bpsw_alnreg_t> >& regs = scratch.regs;
+  std::vector<PairPlan>& plan = scratch.plan;
+  std::vector<int32_t>& job_len = scratch.job_len;
+  std::vector<int64_t>& job_off = scratch.job_off;
+  std::vector<bpsw_alnreg_t>& job_reg = scratch.job_reg;
+  if (regs.size() < (size_t)(2 * G)) regs.resize((size_t)(2 * G));
+  if (plan.size() < (size_t)G) plan.resize((size_t)G);
+  job_len.clear(); job_off.clear(); job_reg.clear();
   auto add_job = [&](int read, const bpsw_alnreg_t& ar) -> int {
     if (ar.rb < 0 || ar.re < 0) return -1;  // the unmapped record, R2S:175-180
     job_len.push_back(g->read_len[read]); job_off.push_back(g->read_off[read]); job_reg.push_back(ar);
@@ -607,6 +653,8 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
   size_t at = 0;
   for (int k = 0; k < G; ++k) {
     PairPlan& P = plan[(size_t)k];
+    P.paired = false; P.z[0] = P.z[1] = 0; P.q_se[0] = P.q_se[1] = 0; P.extra_flag = 1;
+    for (int i = 0; i < 2; ++i) { P.end[i].h_job = -1; P.end[i].se_jobs.clear(); }
     std::vector<bpsw_alnreg_t>* a = &regs[(size_t)(2 * k)];
     for (int i = 0; i < 2; ++i) {
       a[i].assign(g->regs + at, g->regs + at + (size_t)g->reg_cnt[2 * k + i]);
@@ -659,9 +707,11 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
   }
 
   // ---- device -----------------------------------------------------------------------------------------------------------
-  std::vector<JobResult> res;
+  static thread_local JobResults results;  // (the scratch of a call is kept per calling thread: no allocation in the steady state)
+  JobResults& R = results;
+  std::vector<JobResult>& res = R.r;
   const double t_dev = now_ms();
-  rc = run_jobs(c, sc, opt, t.flavour, bns, job_len, job_off, g->read_pool, g->read_pool_bytes, job_reg, &res);
+  rc = run_jobs(c, sc, opt, t.flavour, bns, job_len, job_off, g->read_pool, g->read_pool_bytes, job_reg, &R);
   if (rc != BPSW_OK) return rc;
   for (size_t j = 0; j < res.size(); ++j)
     if (res[j].k.status == BPSW_ALN_XREF || res[j].k.status == BPSW_ALN_OVERFLOW)
@@ -670,8 +720,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
 
   // ---- emit ---------------------------------------------------------------------------------------------------------------
   const double t_emit = now_ms();
-  std::string text;
-  text.reserve((size_t)G * 700);
+  Text text(out_text, text_cap);
   for (int k = 0; k < G; ++k) {
     const PairPlan& P = plan[(size_t)k];
     const std::vector<bpsw_alnreg_t>* a = &regs[(size_t)(2 * k)];
@@ -683,7 +732,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
     if (P.paired) {
       for (int i = 0; i < 2; ++i) {
         const int jb = P.end[i].h_job;
-        h[i] = make_aln(o, t, &a[i][(size_t)P.z[i]], jb >= 0 ? &res[(size_t)jb] : nullptr);
+        h[i] = make_aln(o, t, &a[i][(size_t)P.z[i]], jb >= 0 ? &res[(size_t)jb] : nullptr, R);
         h[i].a.mapq = P.q_se[i];
         h[i].a.flag |= (i ? 0x80 : 0x40) | P.extra_flag;
       }
@@ -696,7 +745,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
     int extra_flag = 1;
     for (int i = 0; i < 2; ++i) {
       const int jb = P.end[i].h_job;
-      h[i] = make_aln(o, t, jb >= 0 ? &a[i][0] : nullptr, jb >= 0 ? &res[(size_t)jb] : nullptr);
+      h[i] = make_aln(o, t, jb >= 0 ? &a[i][0] : nullptr, jb >= 0 ? &res[(size_t)jb] : nullptr, R);
     }
     if (!(o.flag & BPSW_MEM_F_NOPAIRING) && h[0].a.rid == h[1].a.rid && h[0].a.rid >= 0) {  // PE:1571-1594
       long long dist;
@@ -710,7 +759,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
       for (size_t x = 0; x < P.end[i].se_jobs.size(); ++x) {
         const int j = P.end[i].se_jobs[x].first, jb = P.end[i].se_jobs[x].second;
         const bpsw_alnreg_t& p = a[i][(size_t)j];
-        Aln q = make_aln(o, t, &p, jb >= 0 ? &res[(size_t)jb] : nullptr);
+        Aln q = make_aln(o, t, &p, jb >= 0 ? &res[(size_t)jb] : nullptr, R);
         q.a.flag |= xf;
         if (p.secondary >= 0) q.a.sub = -1;  // don't output the sub-optimal score
         if (j && p.secondary < 0) q.a.flag |= (o.flag & BPSW_MEM_F_NO_MULTI) ? 0x10000 : 0x800;  // supplementary
@@ -718,7 +767,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
         aa.push_back(q);
       }
       if (aa.empty()) {
-        Aln u = make_aln(o, t, nullptr, nullptr);
+        Aln u = make_aln(o, t, nullptr, nullptr, R);
         u.a.flag |= xf;
         aa.push_back(u);
         aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa.data(), aa.size(), 0, &h[1 - i]);
@@ -736,7 +785,6 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
   c->tail_host_ms[0] = t_dev - t_plan; c->tail_host_ms[1] = t_emit - t_dev; c->tail_host_ms[2] = now_ms() - t_emit;
   if (out_needed) *out_needed = text.size();
   if (!out_text || text.size() > text_cap) return fail(BPSW_ERR_CAPACITY, "sam_pe: text buffer too small (see *out_needed)");
-  memcpy(out_text, text.data(), text.size());
   return BPSW_OK;
 }
 

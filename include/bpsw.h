@@ -373,7 +373,8 @@ int bpsw_reg2aln_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_tail_o
 /* The tail over a group of pairs.  Arrays are indexed 2k+i (pair k, end i); regions in (k, i, j) order as
  * bpsw_matesw_group leaves them.  id0: pair id of the first pair (the reference hashes id0 + k).
  * Output: out_text receives the SAM lines (read 2k+i: out_text[out_off[2k+i] .. out_off[2k+i+1]); a read with
- * supplementary hits has several lines); BPSW_ERR_CAPACITY with *out_needed set when text_cap is too small.
+ * supplementary hits has several lines); BPSW_ERR_CAPACITY with *out_needed set when text_cap is too small (out_text then
+ * holds a part of the text, nothing is written past text_cap, out_off is complete: call again with *out_needed bytes).
  * out_regs (optional, same size as regs): the region lists as the tail leaves them (sorted, sub/sub_n/secondary/hash). */
 typedef struct {
   int32_t group_size;

@@ -48,6 +48,29 @@ def test_reg2aln_vs_reference_golden(ctx):
     assert np.array_equal(cig, z["cigar"]) and np.array_equal(md, z["md"])
 
 
+def test_sam_pe_text_buffer_too_small_reports_the_size_and_a_second_call_gives_the_text(ctx, orc):
+    """bpsw_sam_pe_batch writes straight into the caller's buffer: past its capacity it only counts (BPSW_ERR_CAPACITY, *out_needed,
+    a complete out_off), and nothing is written beyond text_cap (what is below it is a part of the text, not specified further)"""
+    import ctypes as C
+    from bpsw_hip import _pairs_struct, _ptr
+    pac, g = synthetic_group(orc, 200, 4242, read_len=150, sub_rate=0.02, indel_rate=0.004, p_span=0.05)
+    _load_ref(ctx, pac, g)
+    opt, topt = bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(bpsw_hip.TAIL_SCALA)
+    want, _ = ctx.sam_pe_batch(opt, topt, g)
+    full = b"".join(want)
+    st, keep, regs = _pairs_struct(g)
+    off = np.zeros(2 * g.group_size + 1, np.int64)
+    need = C.c_size_t(0)
+    for cap in (0, 1, 777, len(full) - 1):
+        buf = np.full(cap + 64, 0xAB, np.uint8)
+        rc = ctx.lib.bpsw_sam_pe_batch(ctx.h, C.byref(opt), C.byref(topt), C.byref(st), _ptr(buf), cap, _ptr(off), C.byref(need), None)
+        assert rc == -3 and need.value == len(full) and int(off[-1]) == len(full)
+        assert (buf[cap:] == 0xAB).all()
+    buf = np.zeros(len(full), np.uint8)
+    rc = ctx.lib.bpsw_sam_pe_batch(ctx.h, C.byref(opt), C.byref(topt), C.byref(st), _ptr(buf), len(full), _ptr(off), C.byref(need), None)
+    assert rc == 0 and buf.tobytes() == full
+
+
 @pytest.mark.parametrize("flavour", [bpsw_hip.TAIL_SCALA, bpsw_hip.TAIL_C])
 @pytest.mark.parametrize("L,es,ei,flag", [(150, 0.01, 0.002, 0), (150, 0.05, 0.02, bpsw_hip.MEM_F_ALL), (250, 0.08, 0.02, 0),
                                           (100, 0.02, 0.005, bpsw_hip.MEM_F_NO_MULTI | bpsw_hip.MEM_F_ALL), (150, 0.02, 0.004, bpsw_hip.MEM_F_NOPAIRING)])
