@@ -321,37 +321,46 @@ def coordinate_batches_breakdown(W, cfg_no, rank, F, fd, wires, groups, structs,
 
 
 def device_resident_breakdown(W, cfg_no, rank, wires, ntasks, dev, local_rank, reps):
-    """the round-1 measurement, kept as a breakdown: four wire batches + the rescue jobs of the same 65 536 pairs already in
-    HBM, issued through the asynchronous device entries on five contexts; kernels only (no H2D/D2H, no boundary-1 host layer)"""
+    """inputs already in HBM: sixteen wire batches + the rescue jobs of the same 262 144 pairs (in four launches), issued through
+    the asynchronous device entries on twenty contexts; kernels only (no H2D/D2H, no boundary-1 host layer).  (Rounds 1-3 issued four
+    batches and one rescue launch at a time -- five launch chains in flight against the host path's twenty: a lower rate than
+    `value` for want of concurrency, not because of the entries.)"""
     import torch
     import bpsw_hip
     from bpsw_hip import synth
-    nb = min(4, len(wires))
+    nb = min(16, len(wires))
+    n_sw = 4
     pairs = nb * READS_PER_EXT_BATCH // 2
-    ctxs = [bpsw_hip.Context(local_rank) for _ in range(nb + 1)]
+    ctxs = [bpsw_hip.Context(local_rank) for _ in range(nb + n_sw)]
     opt = bpsw_hip.default_opt()
     xtra = bpsw_hip.KSW_XSUBO | bpsw_hip.KSW_XSTART | bpsw_hip.KSW_XBYTE | 19
     d_wires = [torch.from_numpy(w).to(dev) for w in wires[:nb]]
     d_outs = [torch.zeros(10 * n, dtype=torch.int16, device=dev) for n in ntasks[:nb]]
     n_jobs = int(pairs * 0.11) if W["paired"] else 0
-    sj = d_sw_out = None
+    sjs = []
+    keep = []
     if n_jobs:
-        jobs = synth.sw_jobs(n_jobs, read_len=W["read_len"], win_min=400, win_max=400, sub_rate=W["mate_sub"], indel_rate=W["mate_indel"],
-                             unrelated_frac=0.05, decoy_frac=0.1, rev_frac=1.0, seed=ext_seed(cfg_no, rank, 0) + 100)
-        d_jobs = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in jobs.items()}
-        d_sw_out = torch.zeros((n_jobs, 7), dtype=torch.int32, device=dev)
-        sj = bpsw_hip.SwJobs()
-        sj.n, sj.xtra = n_jobs, xtra
-        for k in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool"):
-            setattr(sj, k, d_jobs[k].data_ptr())
-        sj.q_pool_bytes, sj.t_pool_bytes = d_jobs["q_pool"].numel(), d_jobs["t_pool"].numel()
+        per = n_jobs // n_sw
+        for q in range(n_sw):
+            jobs = synth.sw_jobs(per, read_len=W["read_len"], win_min=400, win_max=400, sub_rate=W["mate_sub"], indel_rate=W["mate_indel"],
+                                 unrelated_frac=0.05, decoy_frac=0.1, rev_frac=1.0, seed=ext_seed(cfg_no, rank, 0) + 100 + q)
+            d_jobs = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in jobs.items()}
+            d_sw_out = torch.zeros((per, 7), dtype=torch.int32, device=dev)
+            sj = bpsw_hip.SwJobs()
+            sj.n, sj.xtra = per, xtra
+            for k in ("q_len", "t_len", "q_off", "t_off", "q_rev", "q_pool", "t_pool"):
+                setattr(sj, k, d_jobs[k].data_ptr())
+            sj.q_pool_bytes, sj.t_pool_bytes = d_jobs["q_pool"].numel(), d_jobs["t_pool"].numel()
+            sjs.append((sj, d_sw_out))
+            keep.append(d_jobs)
+        n_jobs = per * n_sw
     torch.cuda.synchronize(dev)
 
     def step():
         for cx, w, n, dw, do in zip(ctxs, wires[:nb], ntasks[:nb], d_wires, d_outs):
             cx.extend_batch_device(dw.data_ptr(), int(w.size), n, do.data_ptr(), 0)
-        if sj is not None:
-            ctxs[-1].swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
+        for q, (sj, d_sw_out) in enumerate(sjs):
+            ctxs[nb + q].swalign2_batch_device(opt, sj, d_sw_out.data_ptr(), 0)
 
     def wait():
         for cx in ctxs:
