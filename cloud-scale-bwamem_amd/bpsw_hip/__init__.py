@@ -623,7 +623,8 @@ ALN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("flag", "<i4"), ("is_rev"
 
 
 class TailOpt(C.Structure):  # bpsw_tail_opt_t
-    _fields_ = [("mask_level", C.c_float), ("mapq_coef_len", C.c_float), ("mapq_coef_fac", C.c_int32), ("flavour", C.c_int32)]
+    _fields_ = [("mask_level", C.c_float), ("mapq_coef_len", C.c_float), ("mapq_coef_fac", C.c_int32), ("flavour", C.c_int32),
+                ("rg_id", C.c_char * 64)]
 
 
 class Reg2AlnJobs(C.Structure):  # bpsw_reg2aln_jobs_t

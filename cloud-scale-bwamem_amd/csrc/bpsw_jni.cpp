@@ -830,6 +830,8 @@ JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJN
   jni::GetByteArrayRegion(env, matArr, 0, 25, reinterpret_cast<jbyte*>(opt.mat));
   const char* compat = getenv("BPSW_TAIL_COMPAT");
   topt.flavour = (compat && (compat[0] == 'c' || compat[0] == 'C')) ? BPSW_TAIL_C : BPSW_TAIL_SCALA;
+  // the read group of the run (samHeader.bwaReadGroupID, FastMap.scala:109-114: fixed by the -R line before any worker starts)
+  if (const char* rg = getenv("BPSW_READ_GROUP_ID")) strncpy(topt.rg_id, rg, sizeof(topt.rg_id) - 1);
   const jsize n2 = jni::GetArrayLength(env, readLenArr);
   const jsize G = n2 / 2;
   if ((n2 & 1) || jni::GetArrayLength(env, regCntArr) != n2 || jni::GetArrayLength(env, nameLenArr) != G ||

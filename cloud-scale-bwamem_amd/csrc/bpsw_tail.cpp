@@ -393,7 +393,7 @@ void put_contig(Text& s, const BnsView& bns, int rid) {
 
 // memAlnToSAM, R2S:328-560 (C: native/bwamem.c:726-838; the Scala leaves the comment field out, R2S:546-556)
 void aln_to_sam(const BnsView& bns, int flavour, Text& s, const char* name, size_t name_len, int l_seq, const uint8_t* seq,
-                const uint8_t* qual, const Aln* list, const size_t n_list, int which, const Aln* mate_in) {
+                const uint8_t* qual, const Aln* list, const size_t n_list, int which, const Aln* mate_in, const char* rg_id) {
   Aln p = list[(size_t)which];
   Aln m;
   const bool has_m = mate_in != nullptr;
@@ -469,6 +469,7 @@ void aln_to_sam(const BnsView& bns, int flavour, Text& s, const char* name, size
   }
   if (p.a.score >= 0) { s += "\tAS:i:"; put_num(s, p.a.score); }
   if (p.a.sub >= 0) { s += "\tXS:i:"; put_num(s, p.a.sub); }
+  if (rg_id && rg_id[0]) { s += "\tRG:Z:"; s.append(rg_id, strnlen(rg_id, sizeof(((bpsw_tail_opt_t*)nullptr)->rg_id))); }  // R2S:496-500, native/bwamem.c:815
   if (!(p.a.flag & 0x100)) {
     bool others = false;
     for (size_t i = 0; i < n_list; ++i) if ((int)i != which && !(list[i].a.flag & 0x100)) { others = true; break; }
@@ -520,6 +521,7 @@ void bpsw_tail_opt_default(bpsw_tail_opt_t* t) {  // datatype/MemOptType.scala:4
   t->mapq_coef_len = 50.f;
   t->mapq_coef_fac = (int)log(50.0);
   t->flavour = BPSW_TAIL_SCALA;
+  memset(t->rg_id, 0, sizeof t->rg_id);
 }
 
 int bpsw_bns_load(bpsw_ctx_t* c, int32_t n_seqs, const int64_t* offset, const int32_t* len, const char* names) {
@@ -738,7 +740,7 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
       }
       for (int i = 0; i < 2; ++i) {
         out_off[2 * k + i] = (int64_t)text.size();
-        aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], &h[i], 1, 0, &h[1 - i]);
+        aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], &h[i], 1, 0, &h[1 - i], t.rg_id);
       }
       continue;
     }
@@ -770,10 +772,10 @@ int bpsw_sam_pe_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_tail_opt_
         Aln u = make_aln(o, t, nullptr, nullptr, R);
         u.a.flag |= xf;
         aa.push_back(u);
-        aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa.data(), aa.size(), 0, &h[1 - i]);
+        aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa.data(), aa.size(), 0, &h[1 - i], t.rg_id);
       } else {
         for (size_t x = 0; x < aa.size(); ++x)
-          aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa.data(), aa.size(), (int)x, &h[1 - i]);
+          aln_to_sam(bns, t.flavour, text, name, name_len, g->read_len[2 * k + i], seq[i], qual[i], aa.data(), aa.size(), (int)x, &h[1 - i], t.rg_id);
       }
     }
   }

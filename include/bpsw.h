@@ -337,6 +337,8 @@ typedef struct { /* the MemOptType fields only the tail reads (datatype/MemOptTy
   float mask_level, mapq_coef_len;
   int32_t mapq_coef_fac;
   int32_t flavour;
+  char rg_id[64]; /* read-group ID ("" = none): every SAM line gets \tRG:Z:<id> behind XS (worker2/MemRegToADAMSAM.scala:496-500 ==
+                     native/bwamem.c:815; the ID is what SAMHeader.bwaSetReadGroup / bwa_set_rg cut out of the -R line) */
 } bpsw_tail_opt_t;
 void bpsw_tail_opt_default(bpsw_tail_opt_t *t);
 

@@ -166,6 +166,7 @@ typedef struct {
   float mask_level, mapq_coef_len; /* MemOptType.scala:47,51 */
   int32_t mapq_coef_fac;           /* :52 */
   int32_t pad_;
+  char rg_id[64];                  /* SAMHeader.bwaReadGroupID ("" = none): \tRG:Z:<id> behind XS, MemRegToADAMSAM.scala:496-500 */
 } orc_tail_opt_t;
 void orc_tail_opt_default(orc_tail_opt_t *t);
 

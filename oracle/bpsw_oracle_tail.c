@@ -36,6 +36,7 @@ void orc_tail_opt_default(orc_tail_opt_t *t) { /* MemOptType.scala:47-52 */
   t->mapq_coef_len = 50.f;
   t->mapq_coef_fac = (int)log(50.0);
   t->pad_ = 0;
+  memset(t->rg_id, 0, sizeof t->rg_id);
 }
 
 /* MemMarkPrimarySe.scala:111-122 == hash_64, native/utils.h */
@@ -495,7 +496,7 @@ static int get_rlen(const full_aln_t *p) { /* R2S:146-160 */
 
 /* memAlnToSAM, R2S:328-560 (== mem_aln2sam, native/bwamem.c:726-838, without the comment field the Scala drops :546-556) */
 static void aln2sam(const bns_view_t *bns, int flavour, sbuf_t *str, const char *name, size_t name_len, int l_seq, const uint8_t *seq,
-                    const char *qual, int n, const full_aln_t *list, int which, const full_aln_t *m_) {
+                    const char *qual, int n, const full_aln_t *list, int which, const full_aln_t *m_, const char *rg_id) {
   int i;
   full_aln_t *p = (full_aln_t *)malloc(sizeof(full_aln_t)), *m = NULL;
   *p = list[which];
@@ -565,6 +566,7 @@ static void aln2sam(const bns_view_t *bns, int flavour, sbuf_t *str, const char 
   }
   if (p->a.score >= 0) { sb_puts(str, "\tAS:i:"); sb_putl(str, p->a.score); }
   if (p->a.sub >= 0) { sb_puts(str, "\tXS:i:"); sb_putl(str, p->a.sub); }
+  if (rg_id && rg_id[0]) { sb_puts(str, "\tRG:Z:"); sb_puts(str, rg_id); } /* R2S:496-500 (samHeader.bwaReadGroupID), native/bwamem.c:815 */
   if (!(p->a.flag & 0x100)) {
     for (i = 0; i < n; ++i) if (i != which && !(list[i].a.flag & 0x100)) break;
     if (i < n) {
@@ -622,10 +624,10 @@ static void reg2sam_se(tail_env_t *E, sbuf_t *str, const char *name, size_t name
     full_aln_t *t = (full_aln_t *)malloc(sizeof(full_aln_t));
     reg2aln_full(E, l_seq, seq, NULL, t);
     t->a.flag |= extra_flag;
-    aln2sam(E->bns, E->flavour, str, name, name_len, l_seq, seq, qual, 1, t, 0, m);
+    aln2sam(E->bns, E->flavour, str, name, name_len, l_seq, seq, qual, 1, t, 0, m, E->t->rg_id);
     free(t);
   } else {
-    for (k = 0; k < na; ++k) aln2sam(E->bns, E->flavour, str, name, name_len, l_seq, seq, qual, na, aa, k, m);
+    for (k = 0; k < na; ++k) aln2sam(E->bns, E->flavour, str, name, name_len, l_seq, seq, qual, na, aa, k, m, E->t->rg_id);
   }
   free(aa);
 }
@@ -674,8 +676,8 @@ static void sam_pe_one(tail_env_t *E, const orc_pestat_t pes[4], int64_t id, con
     }
     reg2aln_full(E, l_seq[0], seq[0], &a[0][z[0]], &h[0]); h[0].a.mapq = q_se[0]; h[0].a.flag |= 0x40 | extra_flag;
     reg2aln_full(E, l_seq[1], seq[1], &a[1][z[1]], &h[1]); h[1].a.mapq = q_se[1]; h[1].a.flag |= 0x80 | extra_flag;
-    aln2sam(E->bns, E->flavour, &out[0], name, name_len, l_seq[0], seq[0], qual[0], 1, &h[0], 0, &h[1]);
-    aln2sam(E->bns, E->flavour, &out[1], name, name_len, l_seq[1], seq[1], qual[1], 1, &h[1], 0, &h[0]);
+    aln2sam(E->bns, E->flavour, &out[0], name, name_len, l_seq[0], seq[0], qual[0], 1, &h[0], 0, &h[1], E->t->rg_id);
+    aln2sam(E->bns, E->flavour, &out[1], name, name_len, l_seq[1], seq[1], qual[1], 1, &h[1], 0, &h[0], E->t->rg_id);
     free(h);
     return;
   }

@@ -355,7 +355,8 @@ ALN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("flag", "<i4"), ("is_rev"
 
 
 class TailOpt(C.Structure):
-    _fields_ = [("mask_level", C.c_float), ("mapq_coef_len", C.c_float), ("mapq_coef_fac", C.c_int32), ("pad_", C.c_int32)]
+    _fields_ = [("mask_level", C.c_float), ("mapq_coef_len", C.c_float), ("mapq_coef_fac", C.c_int32), ("pad_", C.c_int32),
+                ("rg_id", C.c_char * 64)]
 
 
 def _ints_of(opt: Opt):
@@ -494,8 +495,9 @@ def _ref_reg2aln_batch(self, opt, topt, pac, l_pac, ann_off, ann_len, read_len, 
 
 
 def _ref_sam_pe_batch(self, opt, topt, pac, g, no_rescue=True):
-    """mem_sam_pe (native/bwamem_pair.c:361-453) per pair -> list of 2G SAM texts"""
+    """mem_sam_pe (native/bwamem_pair.c:361-453) per pair -> list of 2G SAM texts (topt.rg_id -> the reference's bwa_rg_id)"""
     pac = np.ascontiguousarray(pac, np.uint8)
+    self.lib.ref_set_rg_id(C.c_char_p(bytes(topt.rg_id)))
     ints = _ints_of(opt)
     if no_rescue:
         ints[12] |= MEM_F_NO_RESCUE

@@ -324,6 +324,14 @@ void ref_reg2aln_batch(const int32_t ints[16], const int8_t mat[25], const float
   shim_bns_free(bns); free(o);
 }
 
+/* the reference keeps the read-group ID in a global (native/bwa.c:16, filled by bwa_set_rg :340-373 from the -R line; mem_aln2sam
+ * prints it, native/bwamem.c:815): set it ("" = none) before ref_sam_pe_batch */
+extern char bwa_rg_id[256];
+void ref_set_rg_id(const char *id) {
+  memset(bwa_rg_id, 0, 256);
+  if (id) strncpy(bwa_rg_id, id, 255);
+}
+
 /* mem_sam_pe (native/bwamem_pair.c:361-453) for a group of pairs; the caller sets MEM_F_NO_RESCUE (0x20) in ints[12] when the
  * region lists are already rescued.  Text of read 2k+i in out_text[out_off[2k+i] .. out_off[2k+i+1]); out_cnt/out_regs (optional)
  * receive the region lists as mem_sam_pe leaves them.  returns total text bytes or -(needed). */

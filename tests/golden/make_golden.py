@@ -253,21 +253,24 @@ def regions_of(batch, opt):
     return np.array(out_cnt, np.int32), np.concatenate(out)
 
 
-for stem, n_pairs, es, ei, flag, seed in (("mem_sam_pe", 160, 0.02, 0.006, 0, 20261008),
-                                          ("mem_sam_pe_all", 90, 0.03, 0.01, po.MEM_F_ALL, 20261009)):
+for stem, n_pairs, es, ei, flag, seed, rg_id in (("mem_sam_pe", 160, 0.02, 0.006, 0, 20261008, b""),
+                                                 ("mem_sam_pe_all", 90, 0.03, 0.01, po.MEM_F_ALL, 20261009, b""),
+                                                 ("mem_sam_pe_rg", 60, 0.03, 0.01, po.MEM_F_ALL, 20261011, b"lane7.A")):  # -R "@RG\tID:lane7.A\t..."
     tb, names, quals, pes = synth.tail_pairs(n_pairs, bases4, ann_off4, ann_len4, dups4, sub_rate=es, indel_rate=ei, seed=seed)
     rc, rg = regions_of(tb, opt4)
     g4 = bpsw_hip.make_tail_group(tb, names, quals, pes, rc, rg, ann_off4, ann_len4, ann_names4, id0=4242)
     o = po.Oracle().default_opt()
     o.flag = flag
+    topt4.rg_id = rg_id
     texts = ref.sam_pe_batch(o, topt4, pac4, g4)
+    topt4.rg_id = b""
     t_off = np.zeros(len(texts) + 1, np.int64)
     t_off[1:] = np.cumsum([len(t) for t in texts])
     np.savez_compressed(os.path.join(HERE, stem + ".npz"), l_pac=g4.l_pac, pac=pac4, id0=g4.id0, flag=flag, pes=np.array(pes, np.float64),
                         read_len=g4.read_len, read_off=g4.read_off, read_pool=g4.read_pool, qual_pool=g4.qual_pool,
                         name_off=g4.name_off, name_pool=g4.name_pool, reg_cnt=g4.reg_cnt, regs=g4.regs, ann_off=g4.ann_off,
                         ann_len=g4.ann_len, ann_name_off=g4.ann_name_off, ann_name_pool=g4.ann_name_pool,
-                        text=np.frombuffer(b"".join(texts), np.uint8), text_off=t_off)
+                        text=np.frombuffer(b"".join(texts), np.uint8), text_off=t_off, **({"rg_id": np.frombuffer(rg_id, np.uint8)} if rg_id else {}))
 
 # mem_reg2aln on every region of 250 pairs (primary and secondary alike), plus the unmapped record
 tb, names, quals, pes = synth.tail_pairs(250, bases4, ann_off4, ann_len4, dups4, sub_rate=0.03, indel_rate=0.01, p_span=0.08, seed=20261010)

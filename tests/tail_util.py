@@ -20,6 +20,7 @@ def load_sam_pe_golden(stem):
                               ann_name_off=z["ann_name_off"], ann_name_pool=z["ann_name_pool"])
     text, off = z["text"].tobytes(), z["text_off"]
     want = [text[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+    g.rg_id = z["rg_id"].tobytes() if "rg_id" in z.files else b""   # the -R read-group ID the reference ran with
     return z["pac"], g, int(z["flag"]), want
 
 

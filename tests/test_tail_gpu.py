@@ -22,13 +22,15 @@ def _load_ref(ctx, pac, g):
     ctx.bns_load(g.ann_off, g.ann_len, names)
 
 
-@pytest.mark.parametrize("stem", ["mem_sam_pe", "mem_sam_pe_all"])
+@pytest.mark.parametrize("stem", ["mem_sam_pe", "mem_sam_pe_all", "mem_sam_pe_rg"])
 def test_sam_pe_vs_reference_golden_text(ctx, stem):
     pac, g, flag, want = load_sam_pe_golden(stem)
     _load_ref(ctx, pac, g)
     opt = bpsw_hip.default_opt()
     opt.flag = flag
-    got, _ = ctx.sam_pe_batch(opt, bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C), g)
+    topt = bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C)
+    topt.rg_id = g.rg_id        # "mem_sam_pe_rg": the reference ran with -R "@RG\tID:lane7.A..." (RG:Z:lane7.A behind XS on every line)
+    got, _ = ctx.sam_pe_batch(opt, topt, g)
     assert got == want          # the reference's mem_sam_pe output, byte for byte
     ms, n_jobs = ctx.last_tail_kernel()
     assert n_jobs > 0 and ms > 0
@@ -79,8 +81,12 @@ def test_sam_pe_vs_oracle(ctx, orc, flavour, L, es, ei, flag):
     _load_ref(ctx, pac, g)
     opt, oopt = bpsw_hip.default_opt(), orc.default_opt()
     opt.flag = oopt.flag = flag
-    want, want_regs, n_jobs = orc.sam_pe_batch(oopt, orc.default_tail_opt(), pac, g, flavour=flavour)
-    got, got_regs = ctx.sam_pe_batch(opt, bpsw_hip.default_tail_opt(flavour), g)
+    otopt, topt = orc.default_tail_opt(), bpsw_hip.default_tail_opt(flavour)
+    if flag & bpsw_hip.MEM_F_ALL:       # two of the cases run with a read group: RG:Z:<id> behind XS on every line (R2S:496-500)
+        otopt.rg_id = topt.rg_id = b"run12.lane3"
+    want, want_regs, n_jobs = orc.sam_pe_batch(oopt, otopt, pac, g, flavour=flavour)
+    got, got_regs = ctx.sam_pe_batch(opt, topt, g)
+    assert all((b"\tRG:Z:run12.lane3" in w) == bool(flag & bpsw_hip.MEM_F_ALL) for w in want)
     bad = [i for i in range(len(want)) if want[i] != got[i]]
     assert not bad, (len(bad), want[bad[0]], got[bad[0]])
     assert want_regs.tobytes() == got_regs.tobytes()
