@@ -582,7 +582,12 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   static const bool split_on = !(getenv("BPSW_EXT_SPLIT") && atoi(getenv("BPSW_EXT_SPLIT")) == 0);
   const int n_long = (int)long_tasks.size();
   const bool use_short = split_on && 2 * (size_t)n_long <= (size_t)n;
-  const bool use_full = !use_short || n_long > 0 || any_mid;  // any_mid: the short kernel may defer tasks from the device
+  // Many tasks with a flank of 128-255 bases (2x250 bp reads): the short kernel that sweeps an outgrown band itself (ext_kernel<., 2>,
+  // bpsw_extend.hip) -- nothing is deferred, the full kernel is only launched for what the host listed.  BPSW_EXT_INLINE_WIDE=0: the
+  // deferring build for every batch (A/B).
+  static const bool inline_wide_on = !(getenv("BPSW_EXT_INLINE_WIDE") && atoi(getenv("BPSW_EXT_INLINE_WIDE")) == 0);
+  const bool inline_wide = inline_wide_on && use_short && 16 * (size_t)n_mid > (size_t)n;
+  const bool use_full = !use_short || n_long > 0 || (any_mid && !inline_wide);  // any_mid: the short kernel may defer tasks from the device
   // behind the wire bytes: the full kernel's list as [count, task indices...]; the host stages its own entries and the count, the
   // 48-VGPR kernel appends (room for every task)
   const size_t list_off = (wire_bytes + 15) & ~(size_t)15;
@@ -679,7 +684,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
                                          use_todo ? d_queue + 2 : nullptr, d_todo, heavy_min));
         }
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 255), mr_short, c->num_cu, d_queue, nullptr, s,
-                                  nullptr, false, kev, true, d_list, 255, d_sflag, d_srecs, lazy_full ? (int*)(k_out + 10 * (size_t)n) : nullptr, d_todo));
+                                  nullptr, false, kev, true, d_list, 255, d_sflag, d_srecs, lazy_full ? (int*)(k_out + 10 * (size_t)n) : nullptr, d_todo, inline_wide));
       }
       if (use_full && !lazy_full) {
         KernelEvents kev;
@@ -691,7 +696,8 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         // four persistent waves take whatever the list holds, gets its wave slots sooner than a grid sized for a quarter of them, and
         // the call holds its stream for that long)
         const bool few_mid = 16 * (size_t)n_mid <= (size_t)n;
-        const int grid_tasks = !use_short ? n : n_long + (few_mid ? 0 : (n_mid + 3) / 4) + (any_mid ? 4 : 0);
+        const bool may_defer = any_mid && !inline_wide;
+        const int grid_tasks = !use_short ? n : n_long + (may_defer ? (few_mid ? 0 : (n_mid + 3) / 4) + 4 : 0);
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, grid_tasks, k_out, sc, mq, mr, c->num_cu, d_queue, nullptr, s,
                                   nullptr, false, kev, false, use_short ? d_list : nullptr));
       }

@@ -355,6 +355,33 @@ def test_launch_plans_of_the_split_kernel(ctx, orc, mid_share, w):
         _check(ctx, orc, soa, zmode=zmode)
 
 
+@pytest.mark.parametrize("w", [70, 100, 127])
+def test_many_long_flanks_are_swept_where_they_are(ctx, orc, w):
+    """bpsw_extend.hip, ext_kernel<., 2>: a batch in which more than one task in sixteen has a flank of 128-255 bases (2x250 bp reads)
+    runs on the short kernel that sweeps a band wider than its window itself, with the full kernel's slot sweep for that side and
+    band -- no list, no second launch.  Retries that double the band to 140 / 200 / 254 columns, both parses, against the oracle."""
+    rng = np.random.default_rng(500 + w)
+    tasks = []
+    for t in range(1200):
+        if rng.random() < 0.5:
+            n1, n2 = int(rng.integers(128, 256)), int(rng.integers(1, 256))
+        else:
+            n1, n2 = int(rng.integers(1, 128)), int(rng.integers(1, 128))
+        if rng.random() < 0.5:
+            n1, n2 = n2, n1
+        sub = float(rng.choice([0.0, 0.02, 0.08, 0.2]))
+        indel = float(rng.choice([0.0, 0.01, 0.04]))
+        lq, lr = _flank(rng, n1, sub, indel)
+        rq, rr = _flank(rng, n2, sub, indel)
+        tasks.append((lq, lr, rq, rr, int(rng.choice([19, 30, 60, 120, 200])), n1))
+    soa = _manual_tasks(tasks)
+    soa.w = w
+    before = ctx.stats().ext_full_relaunches
+    for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
+        _check(ctx, orc, soa, zmode=zmode)
+    assert ctx.stats().ext_full_relaunches == before
+
+
 @pytest.mark.parametrize("w,must_defer", [(100, False), (70, True), (127, True)])
 def test_full_kernel_is_launched_late_when_the_short_kernel_deferred(ctx, orc, w, must_defer):
     """bpsw_runtime.cpp (lazy_full): a batch without flanks above 255 bases and with few of 128-255 gets the full kernel only if
