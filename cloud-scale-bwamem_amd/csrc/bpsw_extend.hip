@@ -79,7 +79,7 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 // SHORT = 2: the short kernel for batches in which MANY tasks may outgrow the window (2x250 bp reads: one task in five has a flank of
 // 128+ bases): a band that does not fit is swept right here, by the full kernel's slot sweep for THIS side and band -- no list, no
 // second launch, and nothing the wave has already computed (the other side, the first band) is computed again.  Round 4: the full
-// kernel's launch behind such a batch was 31 % of the call's kernel time (profiles/r04_cfg5_kernel_stats.csv), half of it
+// kernel's launch behind such a batch was 31 % of the call's kernel time (profiles/r04_cfg5_kernel_stats_before_inline_wide.csv), half of it
 // recomputation, most of the rest a tail of few long tasks.  Built for eight waves per SIMD like SHORT = 1: the slot sweep then
 // spills 34 VGPRs (it is the rare path), and the 2x250 bp step runs 4 % faster than with the 96 VGPRs the sweep would like (2.08 /
 // 2.15 / 2.17 x 10^7 reads/s at 5 / 6 / 8 waves per SIMD: beside the rescue kernel's waves, residency does count).  The extension
