@@ -561,14 +561,14 @@ def main():
     trace_avg = {}
     try:
         import csv
-        # `extend`: a call's launches back to back on its stream -- the sift kernel, the short extension kernel, the full kernel for
-        # listed / deferred tasks (format-1 batches: the `false` instantiations) -- summed per call, as the library's events see them
+        # `extend`: a call's launches back to back on its stream -- the sift kernel, the short extension kernel, the full kernel (only
+        # behind a launch with listed / deferred tasks) (format-1 batches: the `false` instantiations) -- summed per call, as the library's events see them
         ext_total_ns, ext_calls = 0.0, 0
         for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_stats_bench.csv"))):
             nm = r["Name"]
             if "ext_sift_kernel<false>" in nm or "ext_kernel<false" in nm:
                 ext_total_ns += float(r["TotalDurationNs"])
-                if "ext_kernel<false, 1>" in nm:
+                if "ext_kernel<false, 1>" in nm or "ext_kernel<false, 2>" in nm:   # the short kernel (2: the build that sweeps wide bands itself)
                     ext_calls += int(r["Calls"])
             elif per_kernel["swalign2"][3] in nm and "swalign2" not in trace_avg:
                 trace_avg["swalign2"] = round(float(r["AverageNs"]) * 1e-6, 4)
@@ -732,8 +732,8 @@ def main():
                              "step time is the figure to cross-check ms_per_step with.  The rescue kernel reads its jobs (table, mates, windows) from pinned "
                              "HOST memory over PCIe (zero-copy) and writes its results there: its bytes are PCIe reads, not HBM traffic.  The events see "
                              "about 0.06 ms of dispatch latency per launch that a kernel trace does not.  `extend` is what an extension call launches back "
-                             "to back on its stream -- the sift kernel (shortcuts, one task per lane), the short extension kernel, the full kernel for the "
-                             "few listed tasks -- timed from the first dispatch to the end of the last; its avg_launch_ms_kernel_trace is the sum of those "
+                             "to back on its stream -- the sift kernel (shortcuts, one task per lane), the short extension kernel and, only behind a launch that "
+                             "deferred a task, the full kernel -- timed from the first dispatch to the end of the last; its avg_launch_ms_kernel_trace is the sum of those "
                              "kernels' durations per call, the gaps between them (waiting for wave slots) not included.  avg_launch_ms_kernel_trace is the rocprofv3 "
                              f"--kernel-trace --stats average of this command committed under profiles/{PROFILE_TAG}_kernel_stats_bench.csv.  These kernels are "
                              "integer DP with hundreds of operations per byte: the HBM fraction is ~1e-3 by construction (SURVEY.md 8d), what binds is the "
