@@ -10,6 +10,9 @@
 // PE = worker2/MemSamPe.scala, R2S = worker2/MemRegToADAMSAM.scala, MP = worker2/MemMarkPrimarySe.scala.
 #include <math.h>
 #include <string.h>
+#if defined(__x86_64__)
+#include <tmmintrin.h>  // pshufb: the base / quality columns of a SAM line, 16 characters at a time (host pass only)
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -241,6 +244,14 @@ void mark_primary(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, std::vector<bps
   }
 }
 
+// log(l) for the alignment lengths memApproxMapqSe meets (one call per alignment: the same doubles as log(), computed once)
+inline double log_of_len(int l) {
+  static thread_local double tab[1024];
+  if (l <= 0 || l >= 1024) return log((double)l);
+  if (tab[l] == 0.0 && l != 1) tab[l] = log((double)l);
+  return tab[l];
+}
+
 // memApproxMapqSe, R2S:568-604 (C: native/bwamem.c:845-872)
 int approx_mapq(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, const bpsw_alnreg_t& a) {
   int sub = a.sub > 0 ? a.sub : o.min_seed_len * o.a;
@@ -254,8 +265,8 @@ int approx_mapq(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, const bpsw_alnreg
     mapq = 0;
   } else if (t.mapq_coef_len > 0) {
     double tmp;
-    if (t.flavour == BPSW_TAIL_C) tmp = l < t.mapq_coef_len ? 1. : t.mapq_coef_fac / log((double)l);
-    else tmp = l > t.mapq_coef_len ? t.mapq_coef_fac / log((double)l) : 1.;  // R2S:586: differs from the C at l == mapQCoefLen
+    if (t.flavour == BPSW_TAIL_C) tmp = l < t.mapq_coef_len ? 1. : t.mapq_coef_fac / log_of_len(l);
+    else tmp = l > t.mapq_coef_len ? t.mapq_coef_fac / log_of_len(l) : 1.;  // R2S:586: differs from the C at l == mapQCoefLen
     tmp *= identity * identity;
     mapq = (int)(6.02 * (a.score - sub) / o.a * tmp * tmp + .499);
   } else {
@@ -276,6 +287,24 @@ int infer_dir(long long l_pac, long long b1, long long b2, long long* dist) {  /
 }
 
 struct PairScore { int score, sub, n_sub, z[2]; };
+
+// The insert-size term of memPair's score depends on the orientation's statistics and the INTEGER distance only: an erfc and a
+// log per candidate pair were half of the plan phase.  One table per orientation and calling thread over [low, high] (memPair
+// never asks outside it), rebuilt when the statistics change; the same doubles as the expression computes.
+inline double pair_penalty(const bpsw_pestat_t& pe, int dir, long long dist) {
+  struct Tab { double avg = 0., std = 0.; long long low = 0, high = -1; std::vector<double> val; std::vector<uint8_t> have; };
+  static thread_local Tab tabs[4];
+  const auto direct = [&]() { const double ns = ((double)dist - pe.avg) / pe.std; return .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)); };
+  if (dist < pe.low || dist > pe.high || (long long)pe.high - (long long)pe.low > (1 << 16)) return direct();
+  Tab& T = tabs[dir & 3];
+  if (T.avg != pe.avg || T.std != pe.std || T.low != pe.low || T.high != pe.high) {
+    T.avg = pe.avg; T.std = pe.std; T.low = pe.low; T.high = pe.high;
+    T.val.assign((size_t)(pe.high - pe.low + 1), 0.); T.have.assign(T.val.size(), 0);
+  }
+  const size_t at = (size_t)(dist - pe.low);
+  if (!T.have[at]) { T.val[at] = direct(); T.have[at] = 1; }
+  return T.val[at];
+}
 
 // memPair, PE:462-572 (C: native/bwamem_pair.c:298-357)
 PairScore mem_pair(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, long long l_pac, const bpsw_pestat_t pes[4],
@@ -303,8 +332,8 @@ PairScore mem_pair(const bpsw_opt_t& o, const bpsw_tail_opt_t& t, long long l_pa
         const long long dist = (long long)v[(size_t)i].first - (long long)v[(size_t)k].first;
         if (dist > pes[dir].high) break;
         if (dist < pes[dir].low) continue;
-        const double ns = (dist - pes[dir].avg) / pes[dir].std;
-        int q = (int)((double)((v[(size_t)i].second >> 32) + (v[(size_t)k].second >> 32)) + .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * o.a + .499);
+        const double pen = pair_penalty(pes[dir], dir, dist);  // .721 * log(2 * erfc(|ns| / sqrt 2)), ns = (dist - avg) / std
+        int q = (int)((double)((v[(size_t)i].second >> 32) + (v[(size_t)k].second >> 32)) + pen * o.a + .499);
         if (q < 0) q = 0;
         const uint64_t y = (uint64_t)k << 32 | (uint64_t)i;
         u.push_back(Key((uint64_t)q << 32 | (hash64(y ^ idsh) & 0xffffffffULL), y));
@@ -391,6 +420,55 @@ void put_contig(Text& s, const BnsView& bns, int rid) {
   else { s += "ctg"; put_num(s, rid + 1); }
 }
 
+// The SEQ and QUAL columns: 2 x read length of the ~390 bytes of a line.  codes[0..n) -> "ACGTN" (forward) or the reverse
+// complement "TGCAN" read backwards; quals copied or reversed.  With SSSE3 sixteen characters per pshufb, else byte by byte.
+void put_bases_scalar(char* d, const uint8_t* seq, size_t n, bool rev) {
+  if (!rev) for (size_t i = 0; i < n; ++i) d[i] = "ACGTN"[seq[i] > 4 ? 4 : seq[i]];
+  else for (size_t i = 0; i < n; ++i) d[i] = "TGCAN"[seq[n - 1 - i] > 4 ? 4 : seq[n - 1 - i]];
+}
+void put_reversed_scalar(char* d, const uint8_t* q, size_t n) {
+  for (size_t i = 0; i < n; ++i) d[i] = (char)q[n - 1 - i];
+}
+#if defined(__x86_64__)
+__attribute__((target("ssse3"))) void put_bases_ssse3(char* d, const uint8_t* seq, size_t n, bool rev) {
+  const __m128i four = _mm_set1_epi8(4);
+  const __m128i flip = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+  const __m128i tab = rev ? _mm_setr_epi8('T', 'G', 'C', 'A', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N')
+                          : _mm_setr_epi8('A', 'C', 'G', 'T', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N');
+  size_t i = 0;
+  for (; i + 16 <= n; i += 16) {
+    __m128i v = _mm_loadu_si128((const __m128i*)(rev ? seq + (n - 16 - i) : seq + i));
+    if (rev) v = _mm_shuffle_epi8(v, flip);
+    v = _mm_min_epu8(v, four);  // codes above 4 print as N
+    _mm_storeu_si128((__m128i*)(d + i), _mm_shuffle_epi8(tab, v));
+  }
+  if (!rev) put_bases_scalar(d + i, seq + i, n - i, false);
+  else put_bases_scalar(d + i, seq, n - i, true);   // the n - i bases left are the FIRST ones of the read
+}
+__attribute__((target("ssse3"))) void put_reversed_ssse3(char* d, const uint8_t* q, size_t n) {
+  const __m128i flip = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+  size_t i = 0;
+  for (; i + 16 <= n; i += 16)
+    _mm_storeu_si128((__m128i*)(d + i), _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(q + (n - 16 - i))), flip));
+  put_reversed_scalar(d + i, q, n - i);
+}
+const bool kHaveSsse3 = __builtin_cpu_supports("ssse3");
+#else
+const bool kHaveSsse3 = false;
+#endif
+inline void put_bases(char* d, const uint8_t* seq, size_t n, bool rev) {
+#if defined(__x86_64__)
+  if (kHaveSsse3) return put_bases_ssse3(d, seq, n, rev);
+#endif
+  put_bases_scalar(d, seq, n, rev);
+}
+inline void put_reversed(char* d, const uint8_t* q, size_t n) {
+#if defined(__x86_64__)
+  if (kHaveSsse3) return put_reversed_ssse3(d, q, n);
+#endif
+  put_reversed_scalar(d, q, n);
+}
+
 // memAlnToSAM, R2S:328-560 (C: native/bwamem.c:726-838; the Scala leaves the comment field out, R2S:546-556)
 void aln_to_sam(const BnsView& bns, int flavour, Text& s, const char* name, size_t name_len, int l_seq, const uint8_t* seq,
                 const uint8_t* qual, const Aln* list, const size_t n_list, int which, const Aln* mate_in, const char* rg_id) {
@@ -447,7 +525,7 @@ void aln_to_sam(const BnsView& bns, int flavour, Text& s, const char* name, size
       const size_t n = (size_t)std::max(0, qe - qb);
       char* d = s.grow(n + 1 + (qual ? n : 1));  // bases, tab, qualities: written in place
       if (d) {
-        for (size_t i = 0; i < n; ++i) d[i] = "ACGTN"[seq[(size_t)qb + i] > 4 ? 4 : seq[(size_t)qb + i]];
+        put_bases(d, seq + qb, n, false);
         d[n] = '\t';
         if (qual) memcpy(d + n + 1, qual + qb, n); else d[n + 1] = '*';
       }
@@ -457,9 +535,9 @@ void aln_to_sam(const BnsView& bns, int flavour, Text& s, const char* name, size
       const size_t n = (size_t)std::max(0, qe - qb);
       char* d = s.grow(n + 1 + (qual ? n : 1));
       if (d) {
-        for (size_t i = 0; i < n; ++i) d[i] = "TGCAN"[seq[(size_t)qe - 1 - i] > 4 ? 4 : seq[(size_t)qe - 1 - i]];
+        put_bases(d, seq + qb, n, true);   // bases qe-1 down to qb, complemented
         d[n] = '\t';
-        if (qual) for (size_t i = 0; i < n; ++i) d[n + 1 + i] = (char)qual[(size_t)qe - 1 - i]; else d[n + 1] = '*';
+        if (qual) put_reversed(d + n + 1, qual + qb, n); else d[n + 1] = '*';
       }
     }
   }
