@@ -93,6 +93,11 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
   // asynchronous entry (bpsw_extend_batch_device): the table scan ran just before on the same stream and nobody has read it back
   // yet -- a malformed batch is left untouched (ext_kernel behind this launch does the same and never looks at the flags)
   if (pre && pre->error != 0) return;
+  // (wave priorities: bpsw_swalign.hip, swp_kernel)
+#ifndef BPSW_SIFT_PRIO
+#define BPSW_SIFT_PRIO 2
+#endif
+  if (BPSW_SIFT_PRIO) __builtin_amdgcn_s_setprio(BPSW_SIFT_PRIO);
   __shared__ uint32_t raw[SIFT_RAW_WORDS + 4 + (COORD ? 2 * 64 * SIFT_T_WORDS : 0)];
   constexpr int T_BASE = SIFT_RAW_WORDS + 4;  // COORD: the target flank of (side, lane) at T_BASE + (side * 64 + lane) * SIFT_T_WORDS
   __shared__ int items[128 * 8];   // the flanks whose closed form waits for its certificate: query stream, qs | ts << 8, target stream, n | tLen << 8, k, p0, p1, p2

@@ -781,6 +781,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
   extern __shared__ uint32_t key_rows[];
   BPSW_DIAG_WAVE_BEGIN();
   BPSW_DIAG_DUO_DECL();
+  // Shortest launches first: a rescue launch is a quarter of an extension call's work and there are four times as many of them, and
+  // the host's threads wait for each -- its waves go before the extension kernel's (priority 0) on the SIMDs they share, the sift
+  // kernel's (priority 2: the short first launch of an extension call) before both.  Measured on the bench step: the device phase
+  // of a rescue call 0.554 -> 0.512 ms, of an extension call 1.05 -> 1.09 ms, the step +3 % (1.99 -> 2.05 x 10^8 reads/s; priorities
+  // 2 / 3 and a raised priority for the extension kernel's last tickets: the same).  -DBPSW_SWP_PRIO=0 / -DBPSW_SIFT_PRIO=0: off.
+#ifndef BPSW_SWP_PRIO
+#define BPSW_SWP_PRIO 1
+#endif
+  if (BPSW_SWP_PRIO) __builtin_amdgcn_s_setprio(BPSW_SWP_PRIO);
   if (pre && (pre->error != 0 || pre->max_qlen > (PK_LAST + 1) * C || ((pre->max_tlen + 63) & ~63) > scratch_per_job)) return;
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
