@@ -318,7 +318,7 @@ extern "C" {
 
 const char* bpsw_last_error(void) { return g_err.c_str(); }
 const char* bpsw_version(void) {
-  return "bPSW-hip 0.2 (gfx950)";
+  return "bPSW-hip 0.4 (gfx950)";  // 0.4 = round 4: bpsw_stats_t and bpsw_tail_opt_t grew (ext_full_relaunches, rg_id): rebuild callers against include/bpsw.h
 }
 
 int bpsw_device_count(void) {

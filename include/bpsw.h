@@ -73,7 +73,8 @@ int bpsw_device_of(const bpsw_ctx_t *ctx);
 int bpsw_device_slots(void);                  /* number of entries; 0 = no usable device */
 int bpsw_device_for_partition(int partition); /* HIP device index of that entry, -1 = no usable device / negative partition */
 const char *bpsw_last_error(void); /* thread-local text of the last failing call */
-const char *bpsw_version(void);
+const char *bpsw_version(void); /* "bPSW-hip <major.minor> (gfx950)": structs of this header only ever grow at their end, and the minor
+                                   number changes when one does (0.4: bpsw_stats_t::ext_full_relaunches, bpsw_tail_opt_t::rg_id) */
 
 /* ---- scoring that boundary 2 does not transmit (zdrop, mat) ------------------ */
 /* defaults: MemOptType (datatype/MemOptType.scala:28-73): a=1 b=4 N=-1, zdrop=100, Scala z-drop parse */
