@@ -342,6 +342,10 @@ struct StreamLease {
   StreamLease& operator=(const StreamLease&) = delete;
 };
 double wall_ms();
+// rescue launches (sw_stage_run) between their launch and the end of their wait, per device: the extension path shapes its bulk copies
+// by it (extend_batch_impl)
+int sw_launches_in_flight(int device);
+void sw_launch_in_flight(int device, int delta);
 hipError_t wait_event(bpsw_ctx* c, hipEvent_t ev, int kind);  // kind 0: extension call, 1: SW call (separate duration estimates)
 int zerocopy_mask();  // BPSW_ZEROCOPY, see bpsw_runtime.cpp
 bool spin_wait();  // BPSW_SPIN_WAIT=1: busy-wait for the device instead of sleeping on a blocking event

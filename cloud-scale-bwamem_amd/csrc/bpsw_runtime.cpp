@@ -644,14 +644,29 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     if (n_long) memcpy(hl + 1, long_tasks.data(), 4 * (size_t)n_long);
   }
   const double t_staged = wall_ms();
-  double t_dev0, t_dev1;
+  double t_dev0, t_dev1, copy_first_ms = 0.;
   bool kernel_was_last = false;
   {
+    // The copy of the wire batch.  While rescue launches are in flight on this device (bpsw_sw_runtime.cpp counts them) it is a
+    // blocking hipMemcpy BEFORE the call takes a pooled stream: the pooled streams are non-blocking, so it waits for nobody's
+    // kernels; the stream is then held for the kernels only (the streams are what the calls queue for: DESIGN.md 5.2), and -- all
+    // such copies going through the legacy stream -- one bulk copy crosses PCIe at a time instead of several beside the rescue
+    // kernels' zero-copy reads.  configs[2]: the device phase of an extension call 1.07 -> 0.93 ms, the step +2.7 % (2.03 -> 2.09 x
+    // 10^8 reads/s).  With no rescue launch about (an extension-only stream of batches moves 55 GB/s: the link's rate) the copy stays
+    // on the call's own stream, where several are in flight: one at a time is 43 GB/s (3.2 instead of 4.0 x 10^8 reads/s on
+    // configs[1]).  BPSW_EXT_H2D_FIRST=0 / 1: never / always.
+    static const int h2d_first = getenv("BPSW_EXT_H2D_FIRST") ? atoi(getenv("BPSW_EXT_H2D_FIRST")) : -1;
+    const bool copy_first = h2d_first == 1 || (h2d_first < 0 && sw_launches_in_flight(c->device) > 0);
+    if (copy_first) {
+      const double t_c0 = wall_ms();
+      HIP_TRY(hipMemcpy(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice));
+      copy_first_ms = wall_ms() - t_c0;  // (booked as the call's H2D time below)
+    }
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
     hipStream_t s = lease.s;
     t_dev0 = wall_ms();
     HIP_TRY(hipEventRecord(c->ev[0], s));
-    HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, s));
+    if (!copy_first) HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, s));
     bool on_dispatch = false;  // ev[1] / ev[2] ride on the kernel's own dispatch (KernelEvents, bpsw_internal.h)
     // results: written by the kernel straight into the pinned staging buffer (20 B per task, posted PCIe writes), or into
     // device memory and copied back
@@ -741,8 +756,8 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
   if (!kernel_was_last) (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n; c->stats.ext_wire_bytes += wire_bytes;
-  c->stats.ext_h2d_ms += a; c->stats.ext_kernel_ms += b; c->stats.ext_d2h_ms += d;
-  c->stats.ext_host_in_ms += t_staged - t_in; c->stats.ext_dev_ms += t_dev1 - t_dev0; c->stats.ext_host_out_ms += t_out - t_dev1;
+  c->stats.ext_h2d_ms += a + copy_first_ms; c->stats.ext_kernel_ms += b; c->stats.ext_d2h_ms += d;
+  c->stats.ext_host_in_ms += t_staged - t_in; c->stats.ext_dev_ms += t_dev1 - t_dev0 + copy_first_ms; c->stats.ext_host_out_ms += t_out - t_dev1;
   c->last_ext_ms = b;
   c->have_ext_ev = false;
   return BPSW_OK;

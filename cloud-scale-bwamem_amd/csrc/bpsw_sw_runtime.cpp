@@ -1,6 +1,8 @@
 // bpsw_sw_runtime.cpp -- C ABI entry points for the local-SW (mate rescue) jobs.
 #include <string.h>
 
+#include <atomic>
+
 #include "bpsw_internal.h"
 
 using namespace bpsw;
@@ -63,6 +65,10 @@ int sw_stage_begin(bpsw_ctx* c, int n, size_t q_pool_bytes, size_t t_pool_bytes,
 
 // One launch over a batch staged by sw_stage_begin (and filled by the caller): H2D (or the kernel reads the pinned block
 // itself), kernel, D2H.  *results = 7 int32 per job in the pinned result buffer, valid until the next call on the context.
+static std::atomic<int> g_sw_in_flight[64];
+int sw_launches_in_flight(int device) { return g_sw_in_flight[device >= 0 && device < 64 ? device : 0].load(std::memory_order_relaxed); }
+void sw_launch_in_flight(int device, int delta) { g_sw_in_flight[device >= 0 && device < 64 ? device : 0].fetch_add(delta, std::memory_order_relaxed); }
+
 int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st, int mq, int mt, bool pac_mode, const int32_t** results) {
   SwScoring sc;
   int rc = make_scoring(opt, xtra, &sc);
@@ -101,6 +107,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     dev.packed = (const uint32_t*)(d + st.o_packed);
   }
   {
+    struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
     hipStream_t s = lease.s;
     const double t_dev0 = wall_ms();
