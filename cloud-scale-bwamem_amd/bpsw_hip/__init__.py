@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_device_slots", "bpsw_device_for_partition", "bpsw_last_error", "bpsw_version",
     "bpsw_set_ext_scoring", "bpsw_set_ext_shortcuts", "bpsw_extend_batch", "bpsw_extend_stage", "bpsw_extend_commit", "bpsw_extend_batch_classify", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack", "bpsw_wire_coords_size", "bpsw_wire_coords_pack",
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
-    "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms",
+    "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms", "bpsw_ring_stats",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
     "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_worker2_batch", "bpsw_last_tail_times",
     "bpsw_mark_primary_se", "bpsw_approx_mapq_se", "bpsw_mem_pair", "bpsw_sort_dedup", "bpsw_pe_stat",
@@ -123,7 +123,7 @@ class Stats(C.Structure):  # bpsw_stats_t
                [(n, C.c_double) for n in ("ext_h2d_ms", "ext_kernel_ms", "ext_d2h_ms", "sw_h2d_ms", "sw_kernel_ms",
                                           "sw_d2h_ms", "sw_host_ms", "ext_host_in_ms", "ext_wait_ms", "ext_dev_ms",
                                           "ext_host_out_ms", "grp_plan_ms", "grp_pack_ms", "grp_wait_ms", "grp_dev_ms",
-                                          "grp_replay_ms", "grp_out_ms")] + [("grp_calls", C.c_uint64), ("grp_pairs", C.c_uint64), ("ext_full_relaunches", C.c_uint64)]
+                                          "grp_replay_ms", "grp_out_ms")] + [("grp_calls", C.c_uint64), ("grp_pairs", C.c_uint64), ("ext_full_relaunches", C.c_uint64), ("sw_ring_calls", C.c_uint64)]
 
 
 _lib = None
@@ -173,6 +173,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.bpsw_reset_stats.argtypes = [C.c_void_p]
     lib.bpsw_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.bpsw_ring_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.bpsw_chain2aln_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(Chains), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.POINTER(C.c_int64)]
     lib.bpsw_ref_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -492,6 +493,12 @@ class Context:
         _chk(self.lib, self.lib.bpsw_chain2aln_batch(self.h, C.byref(opt), C.byref(st), zdrop_mode, flags, _ptr(out_cnt), _ptr(out), cap,
                                                     C.byref(total)), "bpsw_chain2aln_batch")
         return out_cnt[: b.n_reads], out[: total.value]
+
+    def ring_stats(self):
+        """(epochs, submitted, carried) of the device's submission ring (include/bpsw.h: bpsw_ring_stats)"""
+        e, s, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _chk(self.lib, self.lib.bpsw_ring_stats(self.h, C.byref(e), C.byref(s), C.byref(c)), "bpsw_ring_stats")
+        return int(e.value), int(s.value), int(c.value)
 
     def stats(self) -> Stats:
         s = Stats()

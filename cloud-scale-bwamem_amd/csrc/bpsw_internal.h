@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "bpsw.h"
+#include "bpsw_ring.h"
 
 struct bpsw_ctx;
 
@@ -142,6 +143,21 @@ int sw_resident_waves(int num_cu);
 // d_pre_check: as for launch_ext_kernel (the launch is sized for max_qlen / max_tlen speculatively).
 hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* d_out,
                             uint32_t* d_scratch, int num_cu, hipStream_t s, const SwPrepass* d_pre_check = nullptr, KernelEvents kev = KernelEvents());
+
+// The resident form of the packed rescue kernel behind the per-device submission ring (bpsw_ring.h, bpsw_ring.cpp):
+// sw_ring_class: 3 or 5 (the kernel's columns per lane) when a batch with these longest sequences and this scoring can go through
+// the ring (*bias_out = the packed kernel's score bias), 0 when it needs a launch of its own.
+int sw_ring_class(const SwScoring& sc, int max_qlen, int max_tlen, int* bias_out);
+hipError_t launch_swp_resident(int c_class, const RingArgs& A, int blocks, hipStream_t s);
+
+// host side of the ring (bpsw_ring.cpp).  BPSW_RING=0 sends every call through a launch of its own, as before round 5.
+bool ring_enabled();
+int ring_submit(int device, int c_class, int num_cu, const RingDesc& desc);
+int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, double* est_ms);
+double ring_ticks_per_ms(int device, int c_class);
+void ring_pause(int device);   // close the device's open epochs, wait for their kernels, keep the rings locked ...
+void ring_resume(int device);  // ... until here (bpsw_ref_load / unload: a device-wide synchronisation in between)
+void ring_get_stats(int device, uint64_t* epochs, uint64_t* submitted, uint64_t* carried);
 
 // ---- global alignment + CIGAR -------------------------------------------------
 struct GlobalJobsDev {  // all device pointers
@@ -411,6 +427,7 @@ struct bpsw_ctx {
   int shortcut_mask = 63;  // bpsw_set_ext_shortcuts
   std::vector<int> ext_long_tasks, ext_mid_tasks;  // scratch of bpsw_extend_batch: the tasks of the current batch that go to the full kernel / have a flank of 128-255 bases
   double wait_est_ms[2] = {0., 0.};  // wait_event: running average of the device-phase waits (extension, SW)
+  uint32_t ring_seq = 0;             // completion values of this context's ring submissions (RingDone at h_pre + 448)
   void* rescue_scratch = nullptr;  // bpsw_rescue.cpp: vectors reused across bpsw_matesw_group calls (freed by rescue_scratch_free)
   bpsw_stats_t stats;
   float last_ext_ms = 0.f, last_sw_ms = 0.f;

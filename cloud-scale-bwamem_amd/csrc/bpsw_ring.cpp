@@ -1,0 +1,296 @@
+// bpsw_ring.cpp -- host side of the per-device submission ring (bpsw_ring.h): services, epochs, submission, waiting.
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <atomic>
+
+#include "bpsw_internal.h"
+
+namespace bpsw {
+
+namespace {
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+
+struct RingService {
+  std::recursive_mutex mu;  // (recursive: bpsw_ref_load pauses the rings and may free the old reference, which pauses them again)
+  int pause_depth = 0;
+  int device = 0, c_class = 0;
+  bool inited = false, running = false, broken = false;
+  uint32_t epoch = 0, published = 0, capacity = 0;
+  uint32_t carry_from = 0, carry_n = 0;  // descriptors of a closed epoch the device did not consume
+  RingHostCtl* H = nullptr;
+  RingDesc* h_desc = nullptr;
+  void* h_block = nullptr;
+  void* d_block = nullptr;
+  RingDevCtl* D = nullptr;
+  RingDesc* d_desc = nullptr;
+  RingCtr* ctr = nullptr;
+  size_t d_zero_bytes = 0;  // control block + counters: cleared at every epoch start
+  hipStream_t stream = nullptr;
+  int blocks = 0;
+  unsigned long long ticks_per_us = 100;
+  // statistics (under mu)
+  uint64_t epochs = 0, submitted = 0, carried = 0;
+};
+
+// one service per device and ring class (3: mates up to 171 bases, 5: up to 256)
+RingService g_rings[64][2];
+RingService& service(int device, int c_class) { return g_rings[device >= 0 && device < 64 ? device : 0][c_class == 3 ? 0 : 1]; }
+
+int hip_fail_ring(hipError_t e, const char* what) { return fail(BPSW_ERR_DEVICE, std::string("ring: ") + what + ": " + hipGetErrorString(e)); }
+#define RING_TRY(expr)                                      \
+  do {                                                      \
+    hipError_t e_ = (expr);                                 \
+    if (e_ != hipSuccess) return hip_fail_ring(e_, #expr);  \
+  } while (0)
+
+// (caller holds S.mu and has set the device)
+int init_service(RingService& S, int device, int c_class, int num_cu) {
+  S.device = device; S.c_class = c_class;
+  int cap = env_int("BPSW_RING_CAPACITY", 16384);
+  cap = cap < 64 ? 64 : (cap > (1 << 20) ? (1 << 20) : cap);
+  S.capacity = (uint32_t)cap;
+  const size_t h_bytes = sizeof(RingHostCtl) + sizeof(RingDesc) * (size_t)cap;
+  RING_TRY(hipHostMalloc(&S.h_block, h_bytes, hipHostMallocDefault));
+  memset(S.h_block, 0, h_bytes);
+  S.H = (RingHostCtl*)S.h_block;
+  S.h_desc = (RingDesc*)((char*)S.h_block + sizeof(RingHostCtl));
+  S.d_zero_bytes = sizeof(RingDevCtl) + sizeof(RingCtr) * (size_t)cap;
+  RING_TRY(hipMalloc(&S.d_block, S.d_zero_bytes + sizeof(RingDesc) * (size_t)cap));
+  S.D = (RingDevCtl*)S.d_block;
+  S.ctr = (RingCtr*)((char*)S.d_block + sizeof(RingDevCtl));
+  S.d_desc = (RingDesc*)((char*)S.d_block + S.d_zero_bytes);
+  RING_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) S.ticks_per_us = (unsigned long long)(khz / 1000 > 0 ? khz / 1000 : 1);
+  // Worker workgroups per CU (four wavefronts each).  The resident grid holds its wave slots for as long as the epoch lives, so it
+  // is sized to leave room for the other kernels' waves on every SIMD: 3 workgroups = 3 waves of <= 96 VGPRs per SIMD leave 224 of
+  // the 512 VGPRs, three waves of the 64-VGPR extension kernel.
+  const double per_cu = getenv("BPSW_RING_WG_PER_CU") ? atof(getenv("BPSW_RING_WG_PER_CU")) : (c_class == 3 ? 3.0 : 2.0);
+  int blocks = (int)(num_cu * (per_cu > 0.0 ? per_cu : 1.0));
+  S.blocks = blocks < 2 ? 2 : blocks;
+  S.inited = true;
+  return BPSW_OK;
+}
+
+// (caller holds S.mu and has set the device)  Starts the next epoch, carrying over what the closed one left unconsumed.
+int start_epoch(RingService& S) {
+  if (S.broken) return fail(BPSW_ERR_DEVICE, "ring: the submission ring of this device failed earlier");
+  ++S.epoch;
+  if (S.epoch >= 0xffffffu) S.epoch = 1;
+  if (S.carry_n && S.carry_from) memmove(S.h_desc, S.h_desc + S.carry_from, sizeof(RingDesc) * (size_t)S.carry_n);
+  S.carried += S.carry_n;
+  S.published = S.carry_n;
+  S.carry_from = S.carry_n = 0;
+  S.H->close_req = 0;
+  S.H->state = ring_state(S.epoch, 0, RING_OPEN);
+  std::atomic_thread_fence(std::memory_order_release);
+  S.H->tail = S.published;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  RingArgs A;
+  A.H = S.H; A.h_desc = S.h_desc; A.D = S.D; A.d_desc = S.d_desc; A.ctr = S.ctr;
+  A.epoch = S.epoch; A.capacity = S.capacity;
+  A.sleep_ticks_us = S.ticks_per_us;
+  A.idle_ticks = (unsigned long long)env_int("BPSW_RING_IDLE_US", 2000) * S.ticks_per_us;
+  A.worker_idle_ticks = (unsigned long long)env_int("BPSW_RING_WORKER_IDLE_US", 50000) * S.ticks_per_us;
+  hipError_t e = hipMemsetAsync(S.d_block, 0, S.d_zero_bytes, S.stream);  // behind the previous epoch's kernel, in stream order
+  if (e == hipSuccess) e = launch_swp_resident(S.c_class, A, S.blocks, S.stream);
+  if (e != hipSuccess) { S.broken = true; return hip_fail_ring(e, "epoch launch"); }
+  S.running = true;
+  ++S.epochs;
+  return BPSW_OK;
+}
+
+// the device's state word of the current epoch with CLOSING resolved (the device commits or withdraws within microseconds)
+uint64_t resolved_state(RingService& S) {
+  const double t0 = wall_ms();
+  for (;;) {
+    const uint64_t s = S.H->state;
+    if (ring_state_epoch(s) != S.epoch || ring_state_phase(s) != RING_CLOSING) return s;
+    if (wall_ms() - t0 > 200.0) return s;  // a device that never resolves: the caller's watchdog reports it
+    sched_yield();
+  }
+}
+
+// (caller holds S.mu)  Notes a closed epoch: what it consumed, what has to be carried over.
+void note_closed(RingService& S, uint64_t s) {
+  const uint32_t consumed = ring_state_consumed(s);
+  S.running = false;
+  S.carry_from = consumed;
+  S.carry_n = S.published > consumed ? S.published - consumed : 0;
+}
+
+int wait_closed(RingService& S, double limit_ms) {
+  const double t0 = wall_ms();
+  for (;;) {
+    const uint64_t s = S.H->state;
+    if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) { note_closed(S, s); return BPSW_OK; }
+    if (wall_ms() - t0 > limit_ms) { S.broken = true; return fail(BPSW_ERR_DEVICE, "ring: the resident kernel did not close its epoch"); }
+    timespec ts = {0, 20000};
+    nanosleep(&ts, nullptr);
+  }
+}
+
+int timeout_ms() {
+  static const int v = env_int("BPSW_RING_TIMEOUT_MS", 20000);
+  return v;
+}
+
+}  // namespace
+
+bool ring_enabled() {
+  static const bool on = env_int("BPSW_RING", 1) != 0;
+  return on;
+}
+
+// Appends one descriptor to the ring of (device, class); starts an epoch when none is open.  The caller then waits on its completion
+// record (ring_wait).  Caller has set the device.
+int ring_submit(int device, int c_class, int num_cu, const RingDesc& desc) {
+  RingService& S = service(device, c_class);
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  if (!S.inited) { const int rc = init_service(S, device, c_class, num_cu); if (rc != BPSW_OK) return rc; }
+  for (;;) {
+    if (S.running) {  // an epoch that closed by itself (idle) since the last submission
+      const uint64_t s = S.H->state;
+      if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) note_closed(S, s);
+    }
+    if (!S.running) { const int rc = start_epoch(S); if (rc != BPSW_OK) return rc; }
+    if (S.published < S.capacity) break;
+    // the epoch's ring is used up: the poller closes it once it has consumed the last descriptor
+    const int rc = wait_closed(S, (double)timeout_ms());
+    if (rc != BPSW_OK) return rc;
+  }
+  S.h_desc[S.published] = desc;
+  std::atomic_thread_fence(std::memory_order_release);
+  S.H->tail = ++S.published;
+  std::atomic_thread_fence(std::memory_order_seq_cst);  // W(tail) ; fence ; R(state) against the poller's W(state) ; fence ; R(tail)
+  ++S.submitted;
+  const uint64_t s = resolved_state(S);
+  if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) {
+    note_closed(S, s);
+    if (S.carry_n) return start_epoch(S);  // this descriptor (at least) was not consumed: it opens the next epoch
+  }
+  return BPSW_OK;
+}
+
+// A waiting caller's slow path: if the epoch closed with descriptors unconsumed and nobody has restarted it, do so; report a device
+// error on the ring's stream.  Caller has set the device.
+int ring_poke(int device, int c_class) {
+  RingService& S = service(device, c_class);
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  if (!S.inited) return BPSW_OK;
+  if (S.broken) return fail(BPSW_ERR_DEVICE, "ring: the submission ring of this device failed");
+  if (S.running) {
+    const uint64_t s = resolved_state(S);
+    if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) note_closed(S, s);
+  }
+  if (!S.running && S.carry_n) return start_epoch(S);
+  const hipError_t q = hipStreamQuery(S.stream);
+  if (q != hipSuccess && q != hipErrorNotReady) { S.broken = true; return hip_fail_ring(q, "resident kernel"); }
+  return BPSW_OK;
+}
+
+// Waits until the completion record shows `value`.  est_ms: running average of this caller's waits of the kind (updated).
+int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, double* est_ms) {
+  const double t0 = wall_ms();
+  double est = est_ms ? *est_ms : 0.;
+  if (!spin_wait() && est > 0.15) {
+    const double nap_us = est * 700.0 - 60.0;  // 70 % of the estimate, less the kernel's default timer slack (wait_event)
+    if (nap_us > 20.0) {
+      timespec ts = {0, (long)(nap_us * 1000.0)};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  int polls = 0;
+  double next_poke = 2.0;
+  while (done->value != value) {
+    const double waited = wall_ms() - t0;
+    if (spin_wait() || (++polls < 64 && waited < est * 1.3 + 0.05)) {
+      sched_yield();
+    } else {
+      timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+    if (waited > next_poke) {
+      const int rc = ring_poke(device, c_class);
+      if (rc != BPSW_OK) return rc;
+      next_poke = waited * 2.0;
+      if (waited > (double)timeout_ms()) {
+        RingService& S = service(device, c_class);
+        std::lock_guard<std::recursive_mutex> lk(S.mu);
+        S.broken = true;
+        return fail(BPSW_ERR_DEVICE, "ring: watchdog: a submitted batch was not completed within BPSW_RING_TIMEOUT_MS");
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const double took = wall_ms() - t0;
+  if (est_ms) *est_ms = est <= 0. ? took : 0.75 * est + 0.25 * took;
+  return BPSW_OK;
+}
+
+double ring_ticks_per_ms(int device, int c_class) { return 1000.0 * (double)service(device, c_class).ticks_per_us; }
+
+// Closes the open epochs of a device and waits for their kernels to end; the rings stay locked until ring_resume, so that a
+// device-wide synchronisation in between (bpsw_ref_load / unload) cannot be held up by an epoch other threads keep feeding.
+void ring_pause(int device) {
+  for (int k = 0; k < 2; ++k) {
+    RingService& S = g_rings[device >= 0 && device < 64 ? device : 0][k];
+    S.mu.lock();
+    ++S.pause_depth;
+    if (!S.inited || !S.running) continue;
+    S.H->close_req = S.epoch;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    (void)wait_closed(S, 2000.0);
+    (void)hipStreamSynchronize(S.stream);
+  }
+}
+void ring_resume(int device) {
+  for (int k = 0; k < 2; ++k) {
+    RingService& S = g_rings[device >= 0 && device < 64 ? device : 0][k];
+    if (--S.pause_depth == 0 && S.inited && !S.running && S.carry_n && !S.broken) (void)start_epoch(S);
+    S.mu.unlock();
+  }
+}
+
+void ring_get_stats(int device, uint64_t* epochs, uint64_t* submitted, uint64_t* carried) {
+  uint64_t e = 0, s = 0, c = 0;
+  for (int k = 0; k < 2; ++k) {
+    RingService& S = g_rings[device >= 0 && device < 64 ? device : 0][k];
+    std::lock_guard<std::recursive_mutex> lk(S.mu);
+    e += S.epochs; s += S.submitted; c += S.carried;
+  }
+  if (epochs) *epochs = e;
+  if (submitted) *submitted = s;
+  if (carried) *carried = c;
+}
+
+// Process exit / library unload: ask every open epoch to close and give it a moment -- plain memory traffic only, the HIP runtime
+// may already be shutting down.  (Left alone an epoch closes by itself BPSW_RING_IDLE_US after its last descriptor.)
+__attribute__((destructor)) static void ring_shutdown() {
+  bool any = false;
+  for (auto& dev : g_rings)
+    for (RingService& S : dev)
+      if (S.inited && S.running && S.H) { S.H->close_req = S.epoch; any = true; }
+  if (!any) return;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  const double t0 = wall_ms();
+  for (auto& dev : g_rings)
+    for (RingService& S : dev) {
+      if (!(S.inited && S.running && S.H)) continue;
+      while (wall_ms() - t0 < 50.0) {
+        const uint64_t s = S.H->state;
+        if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) break;
+        sched_yield();
+      }
+    }
+}
+
+}  // namespace bpsw

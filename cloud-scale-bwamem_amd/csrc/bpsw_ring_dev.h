@@ -1,0 +1,154 @@
+// bpsw_ring_dev.h -- device side of the submission ring (bpsw_ring.h): the poller wavefront and the workers' claim / completion
+// steps, shared by the resident kernels.  Every loop in here ends by itself: the poller after `idle_ticks` without a new descriptor
+// (or at once on close_req), a worker on `quit` or after `worker_idle_ticks` without work.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "bpsw_ring.h"
+
+namespace bpsw {
+
+#define RING_SYS __HIP_MEMORY_SCOPE_SYSTEM
+#define RING_DEV __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ uint32_t ring_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// The poller: ONE wavefront of the epoch's kernel.  Mirrors newly published descriptors from pinned host memory into device
+// memory (one 256-byte load per descriptor), publishes the count to the workers, and runs the closing handshake.
+__device__ inline void ring_poller(const RingArgs& A, const int lane) {
+  uint32_t consumed = 0;
+  unsigned long long last = wall_clock64();
+  // progress watch: with units outstanding, `cur` or the current descriptor's hand-out count must move; if neither has for two
+  // seconds (no worker alive: cannot happen by construction) the epoch is closed anyway -- the kernel must end, the waiting
+  // callers' watchdog reports the rest
+  unsigned long long last_progress = last;
+  uint32_t seen_cur = 0, seen_next = 0;
+  uint32_t* h_tail = (uint32_t*)&A.H->tail;
+  uint32_t* h_close = (uint32_t*)&A.H->close_req;
+  unsigned long long* h_state = (unsigned long long*)&A.H->state;
+  const auto state_word = [&](const uint32_t c, const unsigned long long phase) {
+    return ((unsigned long long)(A.epoch & 0xffffffu) << 40) | ((unsigned long long)c << 8) | phase;
+  };
+  for (;;) {
+    uint32_t t = ring_uni(__hip_atomic_load(h_tail, __ATOMIC_ACQUIRE, RING_SYS));
+    const uint32_t close_req = ring_uni(__hip_atomic_load(h_close, __ATOMIC_RELAXED, RING_SYS));
+    if (t > A.capacity) t = A.capacity;
+    const unsigned long long now = wall_clock64();
+    if (t > consumed) {
+      for (uint32_t d = consumed; d < t; ++d) {
+        const uint32_t w = __hip_atomic_load((uint32_t*)&A.h_desc[d].w[lane], __ATOMIC_RELAXED, RING_SYS);
+        __hip_atomic_store(&A.d_desc[d].w[lane], w, __ATOMIC_RELAXED, RING_DEV);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every lane's words before the count
+      if (lane == 0) {
+        __hip_atomic_store(&A.D->tail, t, __ATOMIC_RELEASE, RING_DEV);
+        __hip_atomic_store((unsigned long long*)&A.H->heartbeat, now, __ATOMIC_RELAXED, RING_SYS);
+      }
+      consumed = t;
+      last = now;
+      continue;
+    }
+    const uint32_t cur = ring_uni(__hip_atomic_load(&A.D->cur, __ATOMIC_RELAXED, RING_DEV));
+    bool stalled = false;
+    if (cur < consumed) {  // units still to hand out: not idle
+      last = now;
+      const uint32_t nxt = ring_uni(__hip_atomic_load(&A.ctr[cur].next, __ATOMIC_RELAXED, RING_DEV));
+      if (cur != seen_cur || nxt != seen_next) { seen_cur = cur; seen_next = nxt; last_progress = now; }
+      stalled = now - last_progress > 2000000ull * A.sleep_ticks_us;
+    } else {
+      last_progress = now;
+    }
+    const bool asked = (close_req != 0 && close_req == A.epoch) || stalled;
+    const bool full = consumed >= A.capacity;
+    if (asked || full || now - last > A.idle_ticks) {
+      // two-phase close (bpsw_ring.h): announce, look at the tail again, then either withdraw or commit
+      if (lane == 0) __hip_atomic_store(h_state, state_word(consumed, RING_CLOSING), __ATOMIC_SEQ_CST, RING_SYS);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+      uint32_t t2 = ring_uni(__hip_atomic_load(h_tail, __ATOMIC_SEQ_CST, RING_SYS));
+      for (int look = 0; look < 3 && t2 <= consumed; ++look) {  // margin: three more looks about a microsecond apart
+        __builtin_amdgcn_s_sleep(32);
+        t2 = ring_uni(__hip_atomic_load(h_tail, __ATOMIC_SEQ_CST, RING_SYS));
+      }
+      if (t2 > A.capacity) t2 = A.capacity;
+      if (t2 > consumed && !asked && !full) {  // somebody published meanwhile: stay open and serve it
+        if (lane == 0) __hip_atomic_store(h_state, state_word(consumed, RING_OPEN), __ATOMIC_SEQ_CST, RING_SYS);
+        last = now;
+        continue;
+      }
+      if (lane == 0) {
+        __hip_atomic_store(h_state, state_word(consumed, RING_CLOSED), __ATOMIC_SEQ_CST, RING_SYS);
+        __hip_atomic_store((uint32_t*)&A.H->workers_seen, __hip_atomic_load(&A.D->workers, __ATOMIC_RELAXED, RING_DEV), __ATOMIC_RELAXED, RING_SYS);
+        __hip_atomic_store(&A.D->quit, 1u, __ATOMIC_RELEASE, RING_DEV);
+      }
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+struct RingWorker {
+  uint32_t d = 0;  // first descriptor this wave has not seen drained
+  bool idle = false, counted = false;
+  unsigned long long idle_since = 0;
+};
+
+// The next unit of work for this wavefront: descriptor W.d, unit `unit`; `word` = this lane's word of the descriptor (field k
+// of it: readlane(word, k)).  false: leave the kernel.
+__device__ inline bool ring_next_unit(const RingArgs& A, const int lane, RingWorker& W, uint32_t& unit, uint32_t& word) {
+  for (;;) {
+    const uint32_t cur = ring_uni(__hip_atomic_load(&A.D->cur, __ATOMIC_RELAXED, RING_DEV));
+    if (cur > W.d) W.d = cur;
+    uint32_t tail = ring_uni(__hip_atomic_load(&A.D->tail, __ATOMIC_ACQUIRE, RING_DEV));
+    if (W.d >= tail) {
+      if (ring_uni(__hip_atomic_load(&A.D->quit, __ATOMIC_ACQUIRE, RING_DEV)) != 0u) {
+        tail = ring_uni(__hip_atomic_load(&A.D->tail, __ATOMIC_ACQUIRE, RING_DEV));  // the last count is published before quit
+        if (W.d >= tail) return false;
+        continue;
+      }
+      const unsigned long long now = wall_clock64();
+      if (!W.idle) { W.idle = true; W.idle_since = now; }
+      else if (now - W.idle_since > A.worker_idle_ticks) return false;
+      __builtin_amdgcn_s_sleep(24);  // ~0.6 us
+      continue;
+    }
+    W.idle = false;
+    uint32_t k = 0;
+    if (lane == 0) k = __hip_atomic_fetch_add(&A.ctr[W.d].next, 1u, __ATOMIC_RELAXED, RING_DEV);
+    k = ring_uni(k);
+    word = __hip_atomic_load(&A.d_desc[W.d].w[lane], __ATOMIC_RELAXED, RING_DEV);
+    const uint32_t n_units = (uint32_t)__builtin_amdgcn_readlane((int)word, 0);
+    if (k < n_units) {
+      unit = k;
+      if (lane == 0) {
+        if (k == 0u) __hip_atomic_store((unsigned long long*)&A.ctr[W.d].t0, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, RING_DEV);
+        if (!W.counted) __hip_atomic_fetch_add(&A.D->workers, 1u, __ATOMIC_RELAXED, RING_DEV);
+      }
+      W.counted = true;
+      return true;
+    }
+    if (lane == 0) __hip_atomic_fetch_max(&A.D->cur, W.d + 1u, __ATOMIC_RELAXED, RING_DEV);
+    W.d += 1u;
+  }
+}
+
+// After a unit's results have been stored (by lane 0): count it, and -- the last unit of its descriptor -- write the caller's
+// completion record.  `word` as ring_next_unit returned it.
+__device__ inline void ring_unit_done(const RingArgs& A, const int lane, const RingWorker& W, const uint32_t word) {
+  const uint32_t n_units = (uint32_t)__builtin_amdgcn_readlane((int)word, 0);
+  const uint32_t done_value = (uint32_t)__builtin_amdgcn_readlane((int)word, 1);
+  const unsigned long long done_ptr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)word, 3) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)word, 2);
+  if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // this unit's results, in host memory, before the count
+    const uint32_t before = __hip_atomic_fetch_add(&A.ctr[W.d].done, 1u, __ATOMIC_ACQ_REL, RING_DEV);
+    if (before + 1u == n_units) {
+      RingDone* r = (RingDone*)done_ptr;
+      const unsigned long long t0 = __hip_atomic_load((unsigned long long*)&A.ctr[W.d].t0, __ATOMIC_RELAXED, RING_DEV);
+      __hip_atomic_store((unsigned long long*)&r->t_first, t0, __ATOMIC_RELAXED, RING_SYS);
+      __hip_atomic_store((unsigned long long*)&r->t_done, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, RING_SYS);
+      __hip_atomic_store((uint32_t*)&r->value, done_value, __ATOMIC_RELEASE, RING_SYS);
+    }
+  }
+}
+
+}  // namespace bpsw

@@ -31,11 +31,20 @@ static int hip_fail(hipError_t e, const char* what) {
     if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
   } while (0)
 
+// hipFree / hipHostFree wait for everything on the device -- which, with a resident kernel of the submission ring that other threads keep
+// feeding, is for as long as they keep coming: the open epochs are closed first (a few hundred microseconds) and the rings held until
+// the memory is gone.
+struct RingPauseForFree {
+  int dev = 0;
+  RingPauseForFree() { if (hipGetDevice(&dev) != hipSuccess) dev = 0; ring_pause(dev); }
+  ~RingPauseForFree() { ring_resume(dev); }
+};
+
 hipError_t DeviceBuffer::reserve(size_t bytes) {
   if (bytes <= cap) return hipSuccess;
   size_t want = cap ? cap : 1 << 20;
   while (want < bytes) want <<= 1;
-  if (ptr) (void)hipFree(ptr);
+  if (ptr) { RingPauseForFree paused; (void)hipFree(ptr); }
   ptr = nullptr;
   cap = 0;
   hipError_t e = hipMalloc(&ptr, want);
@@ -43,7 +52,7 @@ hipError_t DeviceBuffer::reserve(size_t bytes) {
   return e;
 }
 void DeviceBuffer::release() {
-  if (ptr) (void)hipFree(ptr);
+  if (ptr) { RingPauseForFree paused; (void)hipFree(ptr); }
   ptr = nullptr;
   cap = 0;
 }
@@ -51,7 +60,7 @@ hipError_t PinnedBuffer::reserve(size_t bytes) {
   if (bytes <= cap) return hipSuccess;
   size_t want = cap ? cap : 1 << 20;
   while (want < bytes) want <<= 1;
-  if (ptr) (void)hipHostFree(ptr);
+  if (ptr) { RingPauseForFree paused; (void)hipHostFree(ptr); }
   ptr = nullptr;
   cap = 0;
   // (coarse-grained pinned memory, hipHostMallocNonCoherent, was tried for the zero-copy reads of the SW kernel: no difference)
@@ -60,7 +69,7 @@ hipError_t PinnedBuffer::reserve(size_t bytes) {
   return e;
 }
 void PinnedBuffer::release() {
-  if (ptr) (void)hipHostFree(ptr);
+  if (ptr) { RingPauseForFree paused; (void)hipHostFree(ptr); }
   ptr = nullptr;
   cap = 0;
 }
@@ -318,7 +327,7 @@ extern "C" {
 
 const char* bpsw_last_error(void) { return g_err.c_str(); }
 const char* bpsw_version(void) {
-  return "bPSW-hip 0.4 (gfx950)";  // 0.4 = round 4: bpsw_stats_t and bpsw_tail_opt_t grew (ext_full_relaunches, rg_id): rebuild callers against include/bpsw.h
+  return "bPSW-hip 0.5 (gfx950)";  // 0.5 = round 5: bpsw_stats_t grew (sw_ring_calls): rebuild callers against include/bpsw.h
 }
 
 int bpsw_device_count(void) {
@@ -389,6 +398,7 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   if (e == hipSuccess) e = c->d_pre.reserve(512);
   if (e == hipSuccess) e = hipMemset(c->d_pre.ptr, 0, 512);  // scan records and the self-resetting queue heads of ext_kernel
   if (e == hipSuccess) e = c->h_pre.reserve(512);
+  if (e == hipSuccess) memset(c->h_pre.ptr, 0, 512);  // (+448: the completion record of this context's ring submissions)
   if (e != hipSuccess) {
     bpsw_destroy(c);
     return hip_fail(e, "bpsw_create");

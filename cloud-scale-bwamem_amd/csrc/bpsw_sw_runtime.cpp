@@ -106,6 +106,45 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     }
     dev.packed = (const uint32_t*)(d + st.o_packed);
   }
+  // The submission ring (bpsw_ring.h): the batch becomes one descriptor of the device's resident rescue kernel -- no stream, no launch,
+  // no event; the call waits on a completion record in its own pinned block.  Batches the resident kernel cannot take (a scoring the
+  // packed kernel does not cover, mates above 256 bases, windows longer than its key rows) and BPSW_RING=0 go through a launch.
+  int ring_bias = 0;
+  const int ring_class = (ring_enabled() && zc_in && zc_out) ? sw_ring_class(sc, mq, mt, &ring_bias) : 0;
+  if (ring_class) {
+    struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
+    RingDesc desc;
+    memset(&desc, 0, sizeof desc);
+    RingDescHead head;
+    memset(&head, 0, sizeof head);
+    RingDone* done = (RingDone*)((char*)c->h_pre.ptr + 448);
+    if (++c->ring_seq == 0) ++c->ring_seq;
+    head.n_units = (uint32_t)((n + 1) / 2);
+    head.done_value = c->ring_seq;
+    head.done_ptr = (uint64_t)(uintptr_t)done;
+    SwRingPayload pl;
+    memset(&pl, 0, sizeof pl);
+    pl.packed = (uint64_t)(uintptr_t)dev.packed; pl.q_pool = (uint64_t)(uintptr_t)dev.q_pool; pl.t_pool = (uint64_t)(uintptr_t)dev.t_pool;
+    pl.pac = (uint64_t)(uintptr_t)dev.pac; pl.l_pac = dev.l_pac; pl.out = (uint64_t)(uintptr_t)k_out;
+    pl.n_jobs = n; pl.bias = ring_bias;
+    for (int r = 0; r < 5; ++r) pl.mat_row[r] = sc.mat.row[r];
+    pl.a = sc.a; pl.b = sc.b; pl.o_del = sc.o_del; pl.e_del = sc.e_del; pl.o_ins = sc.o_ins; pl.e_ins = sc.e_ins; pl.xtra = sc.xtra;
+    memcpy(desc.w, &head, sizeof head);
+    memcpy(desc.w + sizeof(RingDescHead) / 4, &pl, sizeof pl);
+    const double t_dev0 = wall_ms();
+    rc = ring_submit(c->device, ring_class, c->num_cu, desc);
+    if (rc != BPSW_OK) return rc;
+    rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[1]);
+    if (rc != BPSW_OK) return rc;
+    const float span_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, ring_class));
+    c->stats.grp_dev_ms += wall_ms() - t_dev0;
+    c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)n; c->stats.sw_ring_calls++;
+    c->stats.sw_kernel_ms += span_ms;  // first unit taken -> last unit finished, on the device's clock
+    c->last_sw_ms = span_ms;
+    c->have_sw_ev = false;
+    *results = (const int32_t*)c->h_stage_out.ptr;
+    return BPSW_OK;
+  }
   {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
@@ -313,6 +352,9 @@ int bpsw_ref_load(bpsw_ctx_t* c, const uint8_t* pac, int64_t l_pac) {
   RefWriteHold wr(&r.gate);  // no call may be between its snapshot and its last wait
   std::lock_guard<std::mutex> gr(r.mu);
   const size_t bytes = (size_t)((l_pac + 3) >> 2);
+  // the resident kernels of the submission rings end their epochs first (other threads' calls that do not read the reference could
+  // keep one alive for as long as they keep coming); the rings are locked until the reference has been replaced
+  struct RingPause { int d; explicit RingPause(int dev) : d(dev) { ring_pause(d); } ~RingPause() { ring_resume(d); } } ring_paused(c->device);
   HIP_TRY(hipDeviceSynchronize());  // nothing in flight may still read the previous reference
   HIP_TRY(r.buf.reserve(bytes + 16));
   HIP_TRY(hipMemcpy(r.buf.ptr, pac, bytes, hipMemcpyHostToDevice));
@@ -328,6 +370,7 @@ int bpsw_ref_unload(bpsw_ctx_t* c) {
   DeviceRef& r = device_ref(c->device);
   RefWriteHold wr(&r.gate);
   std::lock_guard<std::mutex> gr(r.mu);
+  struct RingPause { int d; explicit RingPause(int dev) : d(dev) { ring_pause(d); } ~RingPause() { ring_resume(d); } } ring_paused(c->device);
   HIP_TRY(hipDeviceSynchronize());
   r.buf.release();
   r.l_pac = 0;
@@ -581,6 +624,12 @@ int bpsw_global_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_global_jo
   memcpy(out_score, ho + o_score, 4 * (size_t)n);
   memcpy(out_ncigar, ho + o_nc, 4 * (size_t)n);
   memcpy(out_cigar, ho + o_cig, 4 * (size_t)n * (size_t)j->max_cigar);
+  return BPSW_OK;
+}
+
+int bpsw_ring_stats(bpsw_ctx_t* c, uint64_t* epochs, uint64_t* submitted, uint64_t* carried) {
+  if (!c) return fail(BPSW_ERR_ARG, "null context");
+  ring_get_stats(c->device, epochs, submitted, carried);
   return BPSW_OK;
 }
 

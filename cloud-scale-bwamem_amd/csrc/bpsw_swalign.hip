@@ -18,6 +18,8 @@
 #include "bpsw_internal.h"
 #include "bpsw_wave.h"
 
+#include "bpsw_ring_dev.h"
+
 #include "bpsw_diag_waves.h"
 BPSW_DIAG_WAVES_DEFINE(sw)
 
@@ -759,13 +761,112 @@ __device__ void swp_pass(const int lane, const Duo& J, const int (&on)[2], const
   }
 }
 
+constexpr int PK_MATE_LDS = 320;       // bytes per staged mate: (PK_LAST + 1) * C <= 285 columns for C <= 5
+constexpr int PK_KEY_PAD = 128;        // steps past the last target row: pipe depth (<= 56) + group rounding + the tail lanes
+constexpr int PK_KEYS_LDS_MAX = 1536;  // rows; 4 waves x (1536 + 128) words = 26 KB per workgroup
+
+struct DuoDiag { unsigned d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u; };  // what the wave log keeps of a job pair (diagnostics builds)
+
+// One pair of jobs (2 duo, 2 duo + 1) of a job table by one wavefront: both passes, the second best, the result records.
+// Shared by the per-call launch (swp_kernel) and the resident kernel behind the submission ring (swp_resident_kernel).
+template <int C>
+__device__ __forceinline__ void swp_do_duo(const SwJobsDev& jobs, const SwScoring& sc, const int bias, int32_t* __restrict__ out,
+                                           const int duo, const int lane, uint32_t* __restrict__ tbuf, uint32_t* __restrict__ keys,
+                                           uint8_t (*mate_lds)[PK_MATE_LDS], DuoDiag& diag) {
+  const int maxScore = 255 - abs(sc.b);  // SWUtil.scala:423
+  const int xtra = sc.xtra;
+  const int minScore = (xtra & BPSW_KSW_XSUBO) ? (xtra & 0xffff) : 0x10000;  // SWUtil.scala:434-437
+  const int endScore0 = (xtra & BPSW_KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
+  Duo J;
+  int job[2], on[2], qCols[2], zero2[2] = {0, 0}, stop1[2], D[2];
+  // both job records with one load when the table came as records (in the host path it sits in pinned host memory, where
+  // every load instruction is a PCIe request of its own): lanes 0-7 hold job 2*duo, lanes 8-15 job 2*duo + 1
+  uint32_t recw = 0;
+  if (jobs.packed && lane < 16 && 2 * duo + (lane >> 3) < jobs.n) recw = jobs.packed[16 * (size_t)duo + lane];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    job[g] = 2 * duo + g;
+    on[g] = job[g] < jobs.n ? 1 : 0;
+    const int jj = on[g] ? job[g] : 0;
+    long long qoff, toff;
+    if (jobs.packed) {
+      const auto field = [&](const int k) { return (unsigned)__builtin_amdgcn_readlane((int)recw, 8 * g + k); };
+      qoff = (long long)(((unsigned long long)field(1) << 32) | field(0));
+      toff = (long long)(((unsigned long long)field(3) << 32) | field(2));
+      J.qLenRaw[g] = (int)field(4); J.tLen[g] = (int)field(5); J.qrev[g] = (int)field(6);
+    } else {
+      J.qLenRaw[g] = uni(jobs.q_len[jj]);
+      J.tLen[g] = uni(jobs.t_len[jj]);
+      J.qrev[g] = uni((int)jobs.q_rev[jj]);
+      qoff = jobs.q_off[jj];
+      toff = jobs.t_off[jj];
+    }
+    // the mate goes to LDS once, 64 consecutive bytes per load: both passes build their column profiles from it (they used
+    // to read it from the pool byte by strided byte, C loads per pass over the same lines)
+    uint8_t* mate = mate_lds[g];
+    const uint8_t* src = jobs.q_pool + qoff;
+    const int ncopy = on[g] ? min(J.qLenRaw[g], PK_MATE_LDS) : 0;
+    for (int k = lane; k < ncopy; k += 64) mate[k] = src[k];
+    J.q[g] = mate;
+    J.tbytes[g] = jobs.t_pool ? jobs.t_pool + toff : nullptr;
+    J.rb[g] = toff;
+    qCols[g] = J.qLenRaw[g];
+    stop1[g] = min(endScore0, maxScore);  // SWUtil.scala:537
+  }
+  __builtin_amdgcn_wave_barrier();
+  PkRes f[2];
+  swp_pass<C>(lane, J, on, qCols, false, zero2, zero2, jobs.pac, jobs.l_pac, sc, bias, stop1, tbuf, keys, D, f);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the keys written by the tail lanes -> all lanes
+  int score[2], te[2], qe[2], score2[2], te2[2], tb[2], qb[2], on2[2], qCols2[2], stop2[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    score[g] = f[g].max >= maxScore ? 255 : f[g].max;  // SWUtil.scala:544
+    te[g] = f[g].max_i;
+    qe[g] = -1; score2[g] = -1; te2[g] = -1; tb[g] = -1; qb[g] = -1;
+    if (on[g] && score[g] != 255) {  // SWUtil.scala:549-567
+      qe[g] = f[g].max_j;
+      const int tmp = (score[g] + sc.a - 1) / sc.a;
+      second_best(lane, keys, 16 * g, D[g], f[g].n_rows, minScore, te[g] - tmp, te[g] + tmp, score2[g], te2[g]);
+    }
+    // SWUtil.scala:586-598
+    const bool want_start = (xtra & BPSW_KSW_XSTART) && !((xtra & BPSW_KSW_XSUBO) && score[g] < (xtra & 0xffff));
+    on2[g] = (on[g] && want_start && qe[g] >= 0 && te[g] >= 0) ? 1 : 0;
+    qCols2[g] = on2[g] ? qe[g] + 1 : 0;
+    stop2[g] = min(score[g] & 0xffff, maxScore);
+  }
+  diag.d0 = (unsigned)((on[0] ? J.tLen[0] : 0) | ((on[1] ? J.tLen[1] : 0) << 16));
+  diag.d1 = (unsigned)((on[0] ? f[0].n_rows : 0) | ((on[1] ? f[1].n_rows : 0) << 16));
+  diag.d2 = (unsigned)((on2[0] ? te[0] + 1 : 0) | ((on2[1] ? te[1] + 1 : 0) << 16));
+  diag.d3 = (unsigned)((on[0] ? score[0] : 0) | ((on[1] ? score[1] : 0) << 16));
+  if (on2[0] | on2[1]) {
+    PkRes r[2];
+    __builtin_amdgcn_wave_barrier();
+    swp_pass<C>(lane, J, on2, qCols2, true, qe, te, jobs.pac, jobs.l_pac, sc, bias, stop2, tbuf, keys, D, r);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if (on2[g]) {
+        const int rscore = r[g].max >= maxScore ? 255 : r[g].max;
+        if (score[g] == rscore) { tb[g] = te[g] - r[g].max_i; qb[g] = qe[g] - r[g].max_j; }
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if (on[g]) {
+        int32_t* o = out + 7 * (size_t)job[g];
+        o[0] = score[g]; o[1] = te[g]; o[2] = qe[g]; o[3] = score2[g]; o[4] = te2[g]; o[5] = tb[g]; o[6] = qb[g];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // KL: the packed row keys (one word per step and wave, written by the booking lanes, read once by second_best) stay in LDS --
 // scratch_per_job + PK_KEY_PAD words per wave of dynamic shared memory -- instead of making a round trip through HBM, which was
 // 4.5x the kernel's compulsory traffic (profiles/pmc_traffic.json, round 1).  The launcher picks KL for windows up to
 // PK_KEYS_LDS_MAX rows (every 2x150 / 2x250 bp rescue window); longer windows keep the scratch rows in HBM.
-constexpr int PK_MATE_LDS = 320;       // bytes per staged mate: (PK_LAST + 1) * C <= 285 columns for C <= 5
-constexpr int PK_KEY_PAD = 128;        // steps past the last target row: pipe depth (<= 56) + group rounding + the tail lanes
-constexpr int PK_KEYS_LDS_MAX = 1536;  // rows; 4 waves x (1536 + 128) words = 26 KB per workgroup
 template <int C, bool KL>
 // (five waves per SIMD for up to three columns per lane: 91 VGPRs without a spill instead of 97; more columns keep four)
 #ifndef BPSW_SWP_WAVES
@@ -781,7 +882,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
   extern __shared__ uint32_t key_rows[];
   BPSW_DIAG_WAVE_BEGIN();
   BPSW_DIAG_DUO_DECL();
-  // Shortest launches first: a rescue launch is a quarter of an extension call's work and there are four times as many of them, and
+  // Shortest launches first: a rescue launch is a quarter of an extension call's work and there are four times as many, and
   // the host's threads wait for each -- its waves go before the extension kernel's (priority 0) on the SIMDs they share, the sift
   // kernel's (priority 2: the short first launch of an extension call) before both.  Measured on the bench step: the device phase
   // of a rescue call 0.554 -> 0.512 ms, of an extension call 1.05 -> 1.09 ms, the step +3 % (1.99 -> 2.05 x 10^8 reads/s; priorities
@@ -797,98 +898,58 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
   uint32_t* tbuf = tbuf_all[wave];
   // packed row keys, one word per step: <= max_tlen + 70 words
   uint32_t* keys = KL ? key_rows + (size_t)wave * (size_t)(scratch_per_job + PK_KEY_PAD) : scratch + (size_t)slot * 4 * (size_t)scratch_per_job;
-  const int maxScore = 255 - abs(sc.b);  // SWUtil.scala:423
-  const int xtra = sc.xtra;
   const int stride = gridDim.x * WAVES_PER_BLOCK;
-  const int minScore = (xtra & BPSW_KSW_XSUBO) ? (xtra & 0xffff) : 0x10000;  // SWUtil.scala:434-437
-  const int endScore0 = (xtra & BPSW_KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
   const int nduo = (jobs.n + 1) >> 1;
-
-  for (int duo = slot; duo < nduo; duo += stride) {
-    Duo J;
-    int job[2], on[2], qCols[2], zero2[2] = {0, 0}, stop1[2], D[2];
-    // both job records with one load when the table came as records (in the host path it sits in pinned host memory, where
-    // every load instruction is a PCIe request of its own): lanes 0-7 hold job 2*duo, lanes 8-15 job 2*duo + 1
-    uint32_t recw = 0;
-    if (jobs.packed && lane < 16 && 2 * duo + (lane >> 3) < jobs.n) recw = jobs.packed[16 * (size_t)duo + lane];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      job[g] = 2 * duo + g;
-      on[g] = job[g] < jobs.n ? 1 : 0;
-      const int jj = on[g] ? job[g] : 0;
-      long long qoff, toff;
-      if (jobs.packed) {
-        const auto field = [&](const int k) { return (unsigned)__builtin_amdgcn_readlane((int)recw, 8 * g + k); };
-        qoff = (long long)(((unsigned long long)field(1) << 32) | field(0));
-        toff = (long long)(((unsigned long long)field(3) << 32) | field(2));
-        J.qLenRaw[g] = (int)field(4); J.tLen[g] = (int)field(5); J.qrev[g] = (int)field(6);
-      } else {
-        J.qLenRaw[g] = uni(jobs.q_len[jj]);
-        J.tLen[g] = uni(jobs.t_len[jj]);
-        J.qrev[g] = uni((int)jobs.q_rev[jj]);
-        qoff = jobs.q_off[jj];
-        toff = jobs.t_off[jj];
-      }
-      // the mate goes to LDS once, 64 consecutive bytes per load: both passes build their column profiles from it (they used
-      // to read it from the pool byte by strided byte, C loads per pass over the same lines)
-      uint8_t* mate = mate_all[wave][g];
-      const uint8_t* src = jobs.q_pool + qoff;
-      const int ncopy = on[g] ? min(J.qLenRaw[g], PK_MATE_LDS) : 0;
-      for (int k = lane; k < ncopy; k += 64) mate[k] = src[k];
-      J.q[g] = mate;
-      J.tbytes[g] = jobs.t_pool ? jobs.t_pool + toff : nullptr;
-      J.rb[g] = toff;
-      qCols[g] = J.qLenRaw[g];
-      stop1[g] = min(endScore0, maxScore);  // SWUtil.scala:537
-    }
-    __builtin_amdgcn_wave_barrier();
-    PkRes f[2];
-    swp_pass<C>(lane, J, on, qCols, false, zero2, zero2, jobs.pac, jobs.l_pac, sc, bias, stop1, tbuf, keys, D, f);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the keys written by the tail lanes -> all lanes
-    int score[2], te[2], qe[2], score2[2], te2[2], tb[2], qb[2], on2[2], qCols2[2], stop2[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      score[g] = f[g].max >= maxScore ? 255 : f[g].max;  // SWUtil.scala:544
-      te[g] = f[g].max_i;
-      qe[g] = -1; score2[g] = -1; te2[g] = -1; tb[g] = -1; qb[g] = -1;
-      if (on[g] && score[g] != 255) {  // SWUtil.scala:549-567
-        qe[g] = f[g].max_j;
-        const int tmp = (score[g] + sc.a - 1) / sc.a;
-        second_best(lane, keys, 16 * g, D[g], f[g].n_rows, minScore, te[g] - tmp, te[g] + tmp, score2[g], te2[g]);
-      }
-      // SWUtil.scala:586-598
-      const bool want_start = (xtra & BPSW_KSW_XSTART) && !((xtra & BPSW_KSW_XSUBO) && score[g] < (xtra & 0xffff));
-      on2[g] = (on[g] && want_start && qe[g] >= 0 && te[g] >= 0) ? 1 : 0;
-      qCols2[g] = on2[g] ? qe[g] + 1 : 0;
-      stop2[g] = min(score[g] & 0xffff, maxScore);
-    }
-    BPSW_DIAG_DUO_SET((on[0] ? J.tLen[0] : 0) | ((on[1] ? J.tLen[1] : 0) << 16), (on[0] ? f[0].n_rows : 0) | ((on[1] ? f[1].n_rows : 0) << 16),
-                      (on2[0] ? te[0] + 1 : 0) | ((on2[1] ? te[1] + 1 : 0) << 16), (on[0] ? score[0] : 0) | ((on[1] ? score[1] : 0) << 16));
-    if (on2[0] | on2[1]) {
-      PkRes r[2];
-      __builtin_amdgcn_wave_barrier();
-      swp_pass<C>(lane, J, on2, qCols2, true, qe, te, jobs.pac, jobs.l_pac, sc, bias, stop2, tbuf, keys, D, r);
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        if (on2[g]) {
-          const int rscore = r[g].max >= maxScore ? 255 : r[g].max;
-          if (score[g] == rscore) { tb[g] = te[g] - r[g].max_i; qb[g] = qe[g] - r[g].max_j; }
-        }
-      }
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        if (on[g]) {
-          int32_t* o = out + 7 * (size_t)job[g];
-          o[0] = score[g]; o[1] = te[g]; o[2] = qe[g]; o[3] = score2[g]; o[4] = te2[g]; o[5] = tb[g]; o[6] = qb[g];
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+  DuoDiag diag;
+  for (int duo = slot; duo < nduo; duo += stride) swp_do_duo<C>(jobs, sc, bias, out, duo, lane, tbuf, keys, mate_all[wave], diag);
+  BPSW_DIAG_DUO_SET(diag.d0, diag.d1, diag.d2, diag.d3);
   BPSW_DIAG_WAVE_END_DUO(3, out, lane);
+}
+
+// The resident form (bpsw_ring.h): the same job pairs, taken one at a time from the descriptors task threads append to the device's
+// submission ring instead of from one launch's table.  Wavefront 0 of workgroup 0 is the ring's poller; every other wavefront is a
+// worker.  The row keys always stay in LDS: `key_rows_cap` rows per wave, fixed for the epoch -- the host sends a call whose longest
+// window has more rows through a launch of its own (swp_kernel).
+template <int C>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) void swp_resident_kernel(const RingArgs A, const int key_rows_cap) {
+  __shared__ uint32_t tbuf_all[WAVES_PER_BLOCK][PK_TBUF + PK_G];
+  __shared__ uint8_t mate_all[WAVES_PER_BLOCK][2][PK_MATE_LDS];
+  extern __shared__ uint32_t key_rows[];
+  if (BPSW_SWP_PRIO) __builtin_amdgcn_s_setprio(BPSW_SWP_PRIO);
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  if (blockIdx.x == 0 && wave == 0) {
+    ring_poller(A, lane);
+    return;
+  }
+  uint32_t* tbuf = tbuf_all[wave];
+  uint32_t* keys = key_rows + (size_t)wave * (size_t)(key_rows_cap + PK_KEY_PAD);
+  RingWorker W;
+  DuoDiag diag;
+  for (;;) {
+    uint32_t unit = 0, word = 0;
+    if (!ring_next_unit(A, lane, W, unit, word)) break;
+    const auto f32 = [&](const int k) { return (uint32_t)__builtin_amdgcn_readlane((int)word, k); };
+    const auto f64 = [&](const int k) { return ((unsigned long long)f32(k + 1) << 32) | (unsigned long long)f32(k); };
+    // the payload (SwRingPayload, words 8..) as the arguments a launch would have got
+    SwJobsDev jobs;
+    jobs.n = (int)f32(20);
+    jobs.q_len = nullptr; jobs.t_len = nullptr; jobs.q_off = nullptr; jobs.t_off = nullptr; jobs.q_rev = nullptr;
+    jobs.packed = (const uint32_t*)f64(8);
+    jobs.q_pool = (const uint8_t*)f64(10);
+    jobs.t_pool = (const uint8_t*)f64(12);
+    jobs.pac = (const uint8_t*)f64(14);
+    jobs.l_pac = (long long)f64(16);
+    int32_t* out = (int32_t*)f64(18);
+    const int bias = (int)f32(21);
+    SwScoring sc;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) sc.mat.row[r] = f64(22 + 2 * r);
+    sc.a = (int)f32(32); sc.b = (int)f32(33); sc.o_del = (int)f32(34); sc.e_del = (int)f32(35);
+    sc.o_ins = (int)f32(36); sc.e_ins = (int)f32(37); sc.xtra = (int)f32(38);
+    swp_do_duo<C>(jobs, sc, bias, out, (int)unit, lane, tbuf, keys, mate_all[wave], diag);
+    ring_unit_done(A, lane, W, word);
+  }
 }
 
 // validates the job table and finds the longest mate / window
@@ -1054,6 +1115,34 @@ hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_
   if (c <= 6) return launch_c<6>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check, kev);
   if (c <= 8) return launch_c<8>(jobs, sc, d_out, d_scratch, per_wave, blocks, s, d_pre_check, kev);
   return hipErrorInvalidValue;
+}
+
+
+// ---- the resident form behind the submission ring (bpsw_ring.h) -------------------------------------------------------
+// Rows of packed keys a worker wave keeps in LDS, fixed for an epoch of class c (columns per lane): the windows of 2x150 bp pairs
+// have 500-700 rows, those of 2x250 bp pairs up to ~1200; a call with a longer window takes a launch of its own.
+int swp_resident_key_rows(int c_class) { return c_class <= 3 ? 1024 : PK_KEYS_LDS_MAX; }
+
+// The ring class of a batch (= the packed kernel's columns per lane, 1..5), or 0 when it has to be launched on its own: a scoring the
+// packed kernel cannot take, mates above 256 bases, windows longer than the resident kernel's key rows.
+int sw_ring_class(const SwScoring& sc, int max_qlen, int max_tlen, int* bias_out) {
+  const int bias = sw_pack_bias(sc);
+  if (bias < 0 || max_qlen > 256 || max_qlen < 1) return 0;
+  const int pc = (max_qlen + PK_LAST) / (PK_LAST + 1);
+  const int c_class = pc <= 3 ? 3 : 5;  // two resident kernels at most per device: mates up to 171 bases, and up to 256
+  const int per_job = (int)(sw_scratch_bytes_per_wave(max_tlen) / 16);
+  if (per_job > swp_resident_key_rows(c_class)) return 0;
+  *bias_out = bias;
+  return c_class;
+}
+
+hipError_t launch_swp_resident(int c_class, const RingArgs& A, int blocks, hipStream_t s) {
+  const int cap = swp_resident_key_rows(c_class);
+  const size_t lds = sizeof(uint32_t) * WAVES_PER_BLOCK * (size_t)(cap + PK_KEY_PAD);
+  if (c_class == 3) hipLaunchKernelGGL((swp_resident_kernel<3>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, A, cap);
+  else if (c_class == 5) hipLaunchKernelGGL((swp_resident_kernel<5>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, A, cap);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 
 }  // namespace bpsw

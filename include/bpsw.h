@@ -74,7 +74,7 @@ int bpsw_device_slots(void);                  /* number of entries; 0 = no usabl
 int bpsw_device_for_partition(int partition); /* HIP device index of that entry, -1 = no usable device / negative partition */
 const char *bpsw_last_error(void); /* thread-local text of the last failing call */
 const char *bpsw_version(void); /* "bPSW-hip <major.minor> (gfx950)": structs of this header only ever grow at their end, and the minor
-                                   number changes when one does (0.4: bpsw_stats_t::ext_full_relaunches, bpsw_tail_opt_t::rg_id) */
+                                   number changes when one does (0.4: bpsw_stats_t::ext_full_relaunches, bpsw_tail_opt_t::rg_id; 0.5: bpsw_stats_t::sw_ring_calls) */
 
 /* ---- scoring that boundary 2 does not transmit (zdrop, mat) ------------------ */
 /* defaults: MemOptType (datatype/MemOptType.scala:28-73): a=1 b=4 N=-1, zdrop=100, Scala z-drop parse */
@@ -434,6 +434,8 @@ typedef struct {
   double grp_plan_ms, grp_pack_ms, grp_wait_ms, grp_dev_ms, grp_replay_ms, grp_out_ms;
   uint64_t grp_calls, grp_pairs;
   uint64_t ext_full_relaunches; /* extension calls whose short kernel deferred tasks, so that the full kernel was launched behind it after all */
+  uint64_t sw_ring_calls;       /* SW batches that went through the device's submission ring (resident kernel) instead of a launch of their own;
+                                   for those sw_kernel_ms is the batch's span on the device clock: first job pair taken -> last one finished */
 } bpsw_stats_t;
 int bpsw_get_stats(bpsw_ctx_t *ctx, bpsw_stats_t *out);
 int bpsw_reset_stats(bpsw_ctx_t *ctx);
@@ -441,6 +443,11 @@ int bpsw_reset_stats(bpsw_ctx_t *ctx);
  * hipEvents on the launch stream.  Synchronises the stream and resolves the asynchronous device entries: their deferred
  * errors are returned here. */
 int bpsw_last_kernel_ms(bpsw_ctx_t *ctx, float *ext_ms, float *sw_ms);
+/* The submission ring of the context's device (round 5; csrc/bpsw_ring.h): the SW batches of bpsw_swalign2_batch / bpsw_matesw_group /
+ * mateSWJNI of ALL contexts of a device are descriptors of one resident kernel instead of launches of their own.  epochs = launches of
+ * that kernel (it ends by itself BPSW_RING_IDLE_US after its last batch), submitted = batches appended, carried = batches a closing
+ * epoch handed to its successor.  Diagnostics; any pointer may be null. */
+int bpsw_ring_stats(bpsw_ctx_t *ctx, uint64_t *epochs, uint64_t *submitted, uint64_t *carried);
 
 #ifdef __cplusplus
 }

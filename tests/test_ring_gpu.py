@@ -1,0 +1,175 @@
+"""The per-device submission ring behind the SW entry points (csrc/bpsw_ring.h, round 5): batches of every size from many task
+threads become descriptors of ONE resident kernel.  What the reference gives to compare with is the call's contract -- one
+synchronous call per group whatever its size (native/jni_mate_sw.c:534, default group size 10: commandline/BWAMEMCommand.scala:28) --
+so the tests are: the results do not depend on the ring (bit-exact against the oracle under 32 threads of mixed sizes), epochs end and
+restart (idle, ring used up, bpsw_ref_load in between, contexts destroyed while the kernel is resident), and nothing hangs."""
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import bpsw_hip
+from bpsw_hip import synth
+import pyoracle as po
+from conftest import region_fields_equal
+
+pytestmark = pytest.mark.gpu
+
+XTRA = po.KSW_XSUBO | po.KSW_XSTART | po.KSW_XBYTE | 19
+RING_ON = os.environ.get("BPSW_RING", "1") != "0"
+
+
+def _want(orc, jobs):
+    return orc.sw_align2_jobs(orc.default_opt(), XTRA, **jobs)[0]
+
+
+def test_batches_go_through_the_ring(ctx, orc):
+    jobs = synth.sw_jobs(300, seed=501)
+    before = ctx.stats().sw_ring_calls
+    e0, s0, _ = ctx.ring_stats()
+    got = ctx.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs)
+    assert np.array_equal(got, _want(orc, jobs))
+    if RING_ON:
+        assert ctx.stats().sw_ring_calls == before + 1
+        e1, s1, _ = ctx.ring_stats()
+        assert s1 == s0 + 1 and e1 >= max(e0, 1)
+
+
+@pytest.mark.parametrize("n_jobs", [1, 2, 3, 7, 64, 65])
+def test_small_and_odd_batches(ctx, orc, n_jobs):
+    jobs = synth.sw_jobs(n_jobs, seed=510 + n_jobs)
+    assert np.array_equal(ctx.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs), _want(orc, jobs))
+
+
+def test_250_base_mates_use_the_second_class(ctx, orc):
+    jobs = synth.sw_jobs(200, read_len=250, win_min=700, win_max=1100, sub_rate=0.06, indel_rate=0.01, seed=520)
+    assert np.array_equal(ctx.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs), _want(orc, jobs))
+
+
+def test_32_threads_mixed_sizes_bit_exact(orc):
+    sizes = [1, 4, 10, 33, 150, 700, 2500]
+    cases = []
+    for k, n in enumerate(sizes):
+        jobs = synth.sw_jobs(n, seed=530 + k)
+        cases.append((jobs, _want(orc, jobs)))
+    groups = []
+    for k, (gs, p) in enumerate(((10, 0.5), (64, 0.4), (600, 0.2))):
+        g = synth.rescue_group(gs, seed=540 + k, p_resc=p)
+        wcnt, wregs, _, _ = orc.matesw_group(orc.default_opt(), g, po.RESCUE_C)
+        groups.append((g, wcnt, wregs))
+    errors = []
+
+    def worker(tid):
+        try:
+            c = bpsw_hip.Context(0)
+            opt = bpsw_hip.default_opt()
+            for it in range(12):
+                k = (tid * 5 + it * 3) % (len(cases) + len(groups))
+                if k < len(cases):
+                    jobs, want = cases[k]
+                    assert np.array_equal(c.swalign2_batch(opt, XTRA, **jobs), want), ("jobs", k)
+                else:
+                    g, wcnt, wregs = groups[k - len(cases)]
+                    cnt, regs = c.matesw_group(opt, g)
+                    assert np.array_equal(cnt, wcnt), ("group", k)
+                    region_fields_equal(regs, wregs)
+            c.close()   # destroyed while the kernel the other threads feed is resident
+        except BaseException as e:   # noqa: BLE001 - reported to the main thread
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(32)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not any(t.is_alive() for t in threads), "a caller is still waiting on the ring"
+    assert not errors, errors[:4]
+
+
+def test_idle_epoch_ends_and_the_next_call_restarts_it(ctx, orc):
+    if not RING_ON:
+        pytest.skip("BPSW_RING=0")
+    jobs = synth.sw_jobs(40, seed=550)
+    want = _want(orc, jobs)
+    opt = bpsw_hip.default_opt()
+    assert np.array_equal(ctx.swalign2_batch(opt, XTRA, **jobs), want)
+    e0, _, _ = ctx.ring_stats()
+    time.sleep(0.25)   # far beyond BPSW_RING_IDLE_US: the epoch has closed and its kernel has left the device
+    import torch
+    t0 = time.time()
+    torch.cuda.synchronize()   # a device-wide wait returns: no resident wave is left behind
+    assert time.time() - t0 < 1.0
+    assert np.array_equal(ctx.swalign2_batch(opt, XTRA, **jobs), want)
+    e1, _, _ = ctx.ring_stats()
+    assert e1 == e0 + 1
+
+
+def test_ref_load_between_calls_pauses_the_ring(orc):
+    """bpsw_ref_load synchronises the device: it closes the open epoch first, and window-by-coordinate jobs afterwards read the
+    NEW reference."""
+    l_pac = 300_007
+    c = bpsw_hip.Context(0)
+    opt = bpsw_hip.default_opt()
+    jobs = synth.sw_jobs(80, seed=560)
+    want = _want(orc, jobs)
+    for seed in (561, 562):
+        pac, bases = synth.random_pac(l_pac, seed=seed)
+        assert np.array_equal(c.swalign2_batch(opt, XTRA, **jobs), want)   # an epoch is open now
+        c.ref_load(pac, l_pac)
+        g = synth.rescue_group(120, seed=563, l_pac=l_pac, p_resc=0.4, ref_bases=bases)
+        import dataclasses
+        gc = dataclasses.replace(g, ref_pool=None, ref_len=None, ref_off=None)
+        wcnt, wregs, _, _ = orc.matesw_group(orc.default_opt(), g, po.RESCUE_C)
+        cnt, regs = c.matesw_group(opt, gc)
+        assert np.array_equal(cnt, wcnt)
+        region_fields_equal(regs, wregs)
+    c.ref_unload()
+    c.close()
+
+
+_ROLLOVER = r"""
+import os, sys, threading
+import numpy as np
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {orc!r})
+import bpsw_hip
+from bpsw_hip import synth
+import pyoracle as po
+XTRA = po.KSW_XSUBO | po.KSW_XSTART | po.KSW_XBYTE | 19
+orc = po.Oracle()
+jobs = synth.sw_jobs(6, seed=570)
+want = orc.sw_align2_jobs(orc.default_opt(), XTRA, **jobs)[0]
+errs = []
+def worker(t):
+    try:
+        c = bpsw_hip.Context(0)
+        for _ in range(150):
+            assert np.array_equal(c.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs), want)
+        c.close()
+    except BaseException as e:
+        errs.append(repr(e))
+ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+[t.start() for t in ts]; [t.join(300) for t in ts]
+assert not errs, errs[:2]
+c = bpsw_hip.Context(0)
+e, s, carried = c.ring_stats()
+print("RING", e, s, carried)
+assert s == 8 * 150 and e >= s // 64, (e, s)
+c.close()
+"""
+
+
+def test_ring_used_up_rolls_over_to_the_next_epoch():
+    """A tiny ring (64 descriptors per epoch): 1 200 calls from eight threads cross eighteen epoch boundaries; calls that were
+    published while an epoch closed are carried into the next one."""
+    if not RING_ON:
+        pytest.skip("BPSW_RING=0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BPSW_RING_CAPACITY="64")
+    src = _ROLLOVER.format(pkg=os.path.join(root, "cloud-scale-bwamem_amd"), orc=os.path.join(root, "oracle"))
+    r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RING" in r.stdout
