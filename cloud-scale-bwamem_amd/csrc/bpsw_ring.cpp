@@ -67,7 +67,15 @@ int init_service(RingService& S, int device, int c_class, int num_cu) {
   S.D = (RingDevCtl*)S.d_block;
   S.ctr = (RingCtr*)((char*)S.d_block + sizeof(RingDevCtl));
   S.d_desc = (RingDesc*)((char*)S.d_block + S.d_zero_bytes);
-  RING_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  // The epoch's kernel sits on its hardware queue for as long as it lives: a stream that shared the queue would wait behind it for
+  // the whole epoch (the runtime maps a process's streams onto GPU_MAX_HW_QUEUES queues PER PRIORITY LEVEL, round robin).  A stream of
+  // the highest priority takes its queue from a pool no other stream of this library uses.
+  {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+    if (greatest != least) RING_TRY(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, greatest));
+    else RING_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  }
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) S.ticks_per_us = (unsigned long long)(khz / 1000 > 0 ? khz / 1000 : 1);
   // Worker workgroups per CU (four wavefronts each).  The resident grid holds its wave slots for as long as the epoch lives, so it
@@ -120,8 +128,19 @@ uint64_t resolved_state(RingService& S) {
 }
 
 // (caller holds S.mu)  Notes a closed epoch: what it consumed, what has to be carried over.
+bool ring_debug() {
+  static const bool on = env_int("BPSW_RING_DEBUG", 0) != 0;
+  return on;
+}
 void note_closed(RingService& S, uint64_t s) {
   const uint32_t consumed = ring_state_consumed(s);
+  if (ring_debug())
+  {
+    const double nu = S.H->diag_units ? (double)S.H->diag_units : 1.0;
+    fprintf(stderr, "bPSW ring[%d/%d]: epoch %u closed: consumed %u of %u published, %u worker waves took a unit, %d workgroups; diag: %llu units, "
+            "taken %.1f us after publication on average, %.1f us per unit\n", S.device, S.c_class, S.epoch, consumed, S.published, (unsigned)S.H->workers_seen,
+            S.blocks, (unsigned long long)S.H->diag_units, (double)S.H->diag_claim_ticks / nu / (double)S.ticks_per_us, (double)S.H->diag_unit_ticks / nu / (double)S.ticks_per_us);
+  }
   S.running = false;
   S.carry_from = consumed;
   S.carry_n = S.published > consumed ? S.published - consumed : 0;

@@ -49,22 +49,31 @@ struct RingHostCtl {
   volatile uint64_t state;      // device (the host initialises it to OPEN before the launch)
   volatile uint64_t heartbeat;  // device: the poller's clock at its last pass (diagnostics)
   volatile uint32_t workers_seen;  // device: worker wavefronts that took at least one unit in this epoch (diagnostics)
-  uint32_t pad1[27];
+  uint32_t pad1a;
+  volatile uint64_t diag_claim_ticks, diag_unit_ticks, diag_units;  // copies of RingDevCtl's at the epoch's close
+  uint32_t pad1[20];
 };
 static_assert(sizeof(RingHostCtl) == 256, "ring control block layout");
 
-// Control block in device memory: three hot words on lines of their own.
+// Control block in device memory.  The three words a waiting worker looks at share sixteen bytes: ONE load per look.
 struct RingDevCtl {
-  uint32_t tail;  uint32_t pad0[31];   // poller -> workers: descriptors mirrored into d_desc
-  uint32_t cur;   uint32_t pad1[31];   // workers: first descriptor that may still have units to hand out
-  uint32_t quit;  uint32_t pad2[31];   // poller: the epoch is closed
+  uint32_t tail;   // poller -> workers: descriptors mirrored into d_desc
+  uint32_t cur;    // workers: first descriptor that may still have units to hand out
+  uint32_t quit;   // poller: the epoch is closed
+  uint32_t pad0[29];
   uint32_t workers; uint32_t pad3[31];
+  // diagnostics builds (-DBPSW_RING_DIAG): ticks between a descriptor's publication and each of its units being taken; ticks a unit took
+  unsigned long long diag_claim_ticks, diag_unit_ticks, diag_units, diag_pad[13];
 };
 struct RingCtr {  // per descriptor, device memory, zero at epoch start
-  uint32_t next;  // units handed out
-  uint32_t done;  // units finished
-  uint64_t t0;    // device clock when unit 0 was taken
+  uint32_t next;     // units handed out
+  uint32_t n_units;  // the descriptor's unit count (the poller's copy: a worker sees "handed out" with one load, without an atomic)
+  uint32_t done;     // units finished
+  uint32_t pad;
+  uint64_t t0;       // device clock when unit 0 was taken
+  uint64_t t_pub;    // device clock when the poller published the descriptor
 };
+static_assert(sizeof(RingCtr) == 32, "ring counters");
 
 // A descriptor: 64 words.  Words 0-7 are the ring's, the rest is the kernel class's payload.
 struct RingDescHead {

@@ -199,7 +199,7 @@ int zerocopy_mask() {
 // restores hipEventSynchronize.
 hipError_t wait_event(bpsw_ctx* c, hipEvent_t ev, int kind) {
   if (spin_wait()) return hipEventSynchronize(ev);
-  double& est = c->wait_est_ms[kind & 1];
+  double& est = c->wait_est_ms[kind & 3];
   const double t0 = wall_ms();
   if (est > 0.15) {
     const double nap_us = est * 700.0 - 60.0;  // 70 % of the estimate, less the kernel's default timer slack

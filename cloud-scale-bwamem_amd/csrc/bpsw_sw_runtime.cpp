@@ -1,4 +1,5 @@
 // bpsw_sw_runtime.cpp -- C ABI entry points for the local-SW (mate rescue) jobs.
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -113,6 +114,23 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
   const int ring_class = (ring_enabled() && zc_in && zc_out) ? sw_ring_class(sc, mq, mt, &ring_bias) : 0;
   if (ring_class) {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
+    const double t_dev0 = wall_ms();
+    // Where the workers read the batch from.  Reading it from the pinned block (zero-copy, what a launch of its own does) costs a job
+    // pair about eight dependent round trips over PCIe, and the link does not take thousands of waves doing that at once: with more
+    // than ~2 500 job pairs in flight every one of them slows down, with 4 000 the total rate FALLS (32 threads of rescue calls alone:
+    // 4.2 ms per call instead of 0.5).  The resident kernel keeps every worker busy, so its batches come by copy engine -- one bulk
+    // transfer into the context's device arena, waited for before the descriptor is published -- and the workers read HBM.  Small
+    // batches (BPSW_RING_ZC_BYTES, default 16 KB) stay zero-copy: the copy's latency would be most of their call.
+    static const size_t ring_zc_bytes = getenv("BPSW_RING_ZC_BYTES") ? (size_t)atoll(getenv("BPSW_RING_ZC_BYTES")) : 16384;
+    if (st.total > ring_zc_bytes) {
+      HIP_TRY(c->d_sw_in.reserve(st.total));
+      uint8_t* dd = (uint8_t*)c->d_sw_in.ptr;
+      HIP_TRY(hipMemcpyAsync(dd, h, st.total, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+      HIP_TRY(wait_event(c, c->ev[0], 2));
+      dev.q_pool = dd + st.o_qpool; dev.t_pool = pac_mode ? nullptr : dd + st.o_tpool; dev.packed = (const uint32_t*)(dd + st.o_packed);
+      c->stats.sw_h2d_ms += wall_ms() - t_dev0;  // (wall time of the copy as the caller saw it)
+    }
     RingDesc desc;
     memset(&desc, 0, sizeof desc);
     RingDescHead head;
@@ -131,7 +149,6 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     pl.a = sc.a; pl.b = sc.b; pl.o_del = sc.o_del; pl.e_del = sc.e_del; pl.o_ins = sc.o_ins; pl.e_ins = sc.e_ins; pl.xtra = sc.xtra;
     memcpy(desc.w, &head, sizeof head);
     memcpy(desc.w + sizeof(RingDescHead) / 4, &pl, sizeof pl);
-    const double t_dev0 = wall_ms();
     rc = ring_submit(c->device, ring_class, c->num_cu, desc);
     if (rc != BPSW_OK) return rc;
     rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[1]);

@@ -851,14 +851,20 @@ __device__ __forceinline__ void swp_do_duo(const SwJobsDev& jobs, const SwScorin
       }
     }
   }
-  if (lane == 0) {
+  {
+    // both result records (jobs 2 duo and 2 duo + 1 are neighbours in `out`) with ONE store instruction, a field per lane: one
+    // 56-byte write instead of fourteen four-byte ones -- the records go to the caller's pinned block over PCIe, where every store
+    // instruction of a lane is a packet of its own
+    int v = 0;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      if (on[g]) {
-        int32_t* o = out + 7 * (size_t)job[g];
-        o[0] = score[g]; o[1] = te[g]; o[2] = qe[g]; o[3] = score2[g]; o[4] = te2[g]; o[5] = tb[g]; o[6] = qb[g];
-      }
+      const int f[7] = {score[g], te[g], qe[g], score2[g], te2[g], tb[g], qb[g]};
+#pragma unroll
+      for (int k = 0; k < 7; ++k) v = lane == 7 * g + k ? f[k] : v;
     }
+    // (a system-scope store: written through to host memory now, not when the kernel ends -- the resident form publishes a unit
+    // after waiting for its stores, bpsw_ring_dev.h; a plain store may sit in the L2 until a write-back)
+    if (lane < 7 * (on[0] + on[1])) __hip_atomic_store(out + 7 * (size_t)job[0] + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -915,7 +921,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, C <= 3 ? BPSW_SWP_WAVES : 4) 
   __shared__ uint32_t tbuf_all[WAVES_PER_BLOCK][PK_TBUF + PK_G];
   __shared__ uint8_t mate_all[WAVES_PER_BLOCK][2][PK_MATE_LDS];
   extern __shared__ uint32_t key_rows[];
-  if (BPSW_SWP_PRIO) __builtin_amdgcn_s_setprio(BPSW_SWP_PRIO);
+#ifndef BPSW_RING_PRIO
+#define BPSW_RING_PRIO BPSW_SWP_PRIO
+#endif
+  if (BPSW_RING_PRIO) __builtin_amdgcn_s_setprio(BPSW_RING_PRIO);
   const int lane = threadIdx.x & 63;
   const int wave = uni((int)(threadIdx.x >> 6));
   if (blockIdx.x == 0 && wave == 0) {
