@@ -503,6 +503,7 @@ def main():
     cpu_busy = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / elapsed   # host CPUs busy during the timed region (this rank)
     st = F.stats_sum()
     call_ms = {"extend": [it.ms for it in items if it.kind == 0], "matesw_group": [it.ms for it in items if it.kind == 1]}
+    call_cpu_ms = {"extend": [it.cpu_ms for it in items if it.kind == 0], "matesw_group": [it.cpu_ms for it in items if it.kind == 1]}
     grp_totals = [0] * len(groups)
     for it, (kind, i) in zip(items, order):
         if kind == 1:
@@ -749,6 +750,11 @@ def main():
                                  "jobs": int(st["sw_jobs"]), "replay_rounds": int(st["sw_replayed_rounds"]), "wasted_jobs": int(st["sw_wasted"]),
                                  "h2d_ms_avg": round(st["sw_h2d_ms"] / max(sw_launches, 1), 4), "d2h_ms_avg": round(st["sw_d2h_ms"] / max(sw_launches, 1), 4)}},
         "host": {"cpus_busy": round(cpu_busy, 2), "cpu_quota": cpu_quota(), "call_ms": host_ms,
+                 # CPU time of the calling thread inside a call (CLOCK_THREAD_CPUTIME_ID around the last timed call on every item): what a
+                 # read costs the executor's CPU quota on this path
+                 "call_cpu_ms": {k: round(float(np.mean(v)), 4) if v else None for k, v in call_cpu_ms.items()},
+                 "cpu_s_per_Mreads": round(cpu_busy * elapsed / (reads_per_step * args.steps / 1e6), 5),
+                 "dram_bytes_per_read_est": round((passes * (3 * sum(int(w.size) for w in wires) + 2 * 20 * sum(ntasks)) + 3 * (pcie_bytes_per_step - passes * (sum(int(w.size) for w in wires) + 20 * sum(ntasks)))) / max(reads_per_step, 1), 1),
                  "phase_ms_per_call": {"extend": {k: round(st["ext_" + k + "_ms"] / max(ext_launches, 1), 4) for k in ("host_in", "wait", "dev", "host_out")},
                                        "matesw_group": {k: round(st["grp_" + k + "_ms"] / max(int(st["grp_calls"]), 1), 4)
                                                         for k in ("plan", "pack", "wait", "dev", "replay", "out")}}, "pcie_bytes_per_step": int(pcie_bytes_per_step),

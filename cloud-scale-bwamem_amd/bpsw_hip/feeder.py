@@ -12,7 +12,7 @@ from .synth import _load as _load_synth
 
 class FeedItem(C.Structure):
     _fields_ = [("kind", C.c_int32), ("rc", C.c_int32), ("inp", C.c_void_p), ("in_bytes", C.c_size_t), ("out", C.c_void_p),
-                ("out2", C.c_void_p), ("out_cap", C.c_int64), ("out_total", C.c_int64), ("ms", C.c_double)]
+                ("out2", C.c_void_p), ("out_cap", C.c_int64), ("out_total", C.c_int64), ("ms", C.c_double), ("cpu_ms", C.c_double)]
 
 
 class Feeder:

@@ -27,6 +27,7 @@ typedef struct {
   int64_t out_cap;
   int64_t out_total;  // kind 1: regions written (output)
   double ms;          // wall time of the call (output)
+  double cpu_ms;      // CPU time the calling thread spent in the call (CLOCK_THREAD_CPUTIME_ID; output)
 } bpsw_feed_item_t;
 
 typedef int (*extend_fn)(void* ctx, const uint8_t* wire, size_t bytes, int16_t* out, size_t out_len);
@@ -59,6 +60,12 @@ static double now_ms() {
   return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
 }
 
+static double thread_cpu_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+  return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
 static void feeder_worker(bpsw_feeder* F, int t) {
   uint64_t seen = 0;
   for (;;) {
@@ -76,10 +83,11 @@ static void feeder_worker(bpsw_feeder* F, int t) {
       // an item of the next repeat while a slow thread still runs it: wait for that call (its result buffers are the same)
       unsigned char idle = 0;
       while (!F->busy[(size_t)i].compare_exchange_weak(idle, 1, std::memory_order_acquire)) { idle = 0; sched_yield(); }
-      const double t0 = now_ms();
+      const double t0 = now_ms(), c0 = thread_cpu_ms();
       if (it.kind == 0) it.rc = F->f_ext(F->ctxs[(size_t)t], (const uint8_t*)it.in, it.in_bytes, (int16_t*)it.out, (size_t)it.out_cap);
       else it.rc = F->f_grp(F->ctxs[(size_t)t], F->opt, it.in, F->mode, (int32_t*)it.out, it.out2, it.out_cap, &it.out_total);
       it.ms = now_ms() - t0;
+      it.cpu_ms = thread_cpu_ms() - c0;
       const int rc = it.rc;
       F->busy[(size_t)i].store(0, std::memory_order_release);
       if (rc != 0) {

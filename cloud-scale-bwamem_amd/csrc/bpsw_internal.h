@@ -362,6 +362,8 @@ double wall_ms();
 // by it (extend_batch_impl)
 int sw_launches_in_flight(int device);
 void sw_launch_in_flight(int device, int delta);
+void wait_nap(double est_ms);                                        // the sleep before the first look (BPSW_WAIT_MODE, bpsw_runtime.cpp)
+void wait_poll_pause(int polls, double waited_ms, double est_ms);    // between two looks
 hipError_t wait_event(bpsw_ctx* c, hipEvent_t ev, int kind);  // kind 0: extension call, 1: SW call (separate duration estimates)
 int zerocopy_mask();  // BPSW_ZEROCOPY, see bpsw_runtime.cpp
 bool spin_wait();  // BPSW_SPIN_WAIT=1: busy-wait for the device instead of sleeping on a blocking event

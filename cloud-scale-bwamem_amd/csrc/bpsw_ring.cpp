@@ -78,10 +78,12 @@ int init_service(RingService& S, int device, int c_class, int num_cu) {
   }
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) S.ticks_per_us = (unsigned long long)(khz / 1000 > 0 ? khz / 1000 : 1);
-  // Worker workgroups per CU (four wavefronts each).  The resident grid holds its wave slots for as long as the epoch lives, so it
-  // is sized to leave room for the other kernels' waves on every SIMD: 3 workgroups = 3 waves of <= 96 VGPRs per SIMD leave 224 of
-  // the 512 VGPRs, three waves of the 64-VGPR extension kernel.
-  const double per_cu = getenv("BPSW_RING_WG_PER_CU") ? atof(getenv("BPSW_RING_WG_PER_CU")) : (c_class == 3 ? 3.0 : 2.0);
+  // Worker workgroups per CU (four wavefronts each).  The resident grid holds its wave slots for as long as the epoch lives, and more
+  // workers are not more throughput: the device is shared with the extension kernels, and what a worker more takes from them costs the
+  // step more than a batch's units waiting a little for a free worker.  Measured on the bench (configs[2], 32 threads): 0.5 / 0.75 / 1 /
+  // 1.25 / 1.5 / 2 / 3 workgroups per CU = 1.63 / 2.34 / 2.35 / 2.26 / 2.20 / 2.05 / 1.70 x 10^8 reads/s; configs[4] (mates of 250
+  // bases, the second class; the step is the extension's): 0.5 / 1 / 2 = 2.28 / 2.12 / 1.96 x 10^7.
+  const double per_cu = getenv("BPSW_RING_WG_PER_CU") ? atof(getenv("BPSW_RING_WG_PER_CU")) : (c_class == 3 ? 1.0 : 0.5);
   int blocks = (int)(num_cu * (per_cu > 0.0 ? per_cu : 1.0));
   S.blocks = blocks < 2 ? 2 : blocks;
   S.inited = true;
@@ -220,23 +222,13 @@ int ring_poke(int device, int c_class) {
 int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, double* est_ms) {
   const double t0 = wall_ms();
   double est = est_ms ? *est_ms : 0.;
-  if (!spin_wait() && est > 0.15) {
-    const double nap_us = est * 700.0 - 60.0;  // 70 % of the estimate, less the kernel's default timer slack (wait_event)
-    if (nap_us > 20.0) {
-      timespec ts = {0, (long)(nap_us * 1000.0)};
-      nanosleep(&ts, nullptr);
-    }
-  }
+  if (!spin_wait()) wait_nap(est);
   int polls = 0;
   double next_poke = 2.0;
   while (done->value != value) {
     const double waited = wall_ms() - t0;
-    if (spin_wait() || (++polls < 64 && waited < est * 1.3 + 0.05)) {
-      sched_yield();
-    } else {
-      timespec ts = {0, 20000};
-      nanosleep(&ts, nullptr);
-    }
+    if (spin_wait()) sched_yield();
+    else wait_poll_pause(++polls, waited, est);
     if (waited > next_poke) {
       const int rc = ring_poke(device, c_class);
       if (rc != BPSW_OK) return rc;
