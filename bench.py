@@ -177,7 +177,11 @@ def cpu_baseline(W, cfg_no, rank, xtra):
         ref = po.Ref()
         mat = po.default_mat()
         ropt = po.Oracle().default_opt()
-        cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+        quota = cpu_quota()
+        # `cores`: the CPUs the box really gives this process -- its cgroup quota when there is one (16 on a one-GPU box whose affinity
+        # mask shows 64), else the affinity mask; the sample runs one thread per CPU of the mask all the same, the quota decides what they get
+        cores = max(1, int(round(quota))) if quota else threads
 
         def unit(_):
             ref.extend_batch(soa, mat)
@@ -187,21 +191,20 @@ def cpu_baseline(W, cfg_no, rank, xtra):
         one = time.perf_counter()
         unit(0)
         one = time.perf_counter() - one
-        reps = max(1, int(round(4.0 / max(one, 1e-3))))          # ~4 s of wall per thread
+        reps = max(1, int(round(4.0 * cores / threads / max(one, 1e-3))))          # ~4 s of wall in all
         t0 = time.perf_counter()
         cpu_t0 = os.times()
-        with ThreadPoolExecutor(cores) as ex:                     # ctypes releases the GIL inside the C loops
-            list(ex.map(unit, range(cores * reps)))
+        with ThreadPoolExecutor(threads) as ex:                     # ctypes releases the GIL inside the C loops
+            list(ex.map(unit, range(threads * reps)))
         dt = time.perf_counter() - t0
         cpu_s = os.times()
-        quota = cpu_quota()
         return {
-            "value": round(cores * reps * unit_reads / dt, 1), "unit": "reads/s", "cores": cores, "kind": "reference",
-            "threads": cores, "cpu_quota": quota, "cpus_busy": round(((cpu_s.user - cpu_t0.user) + (cpu_s.system - cpu_t0.system)) / dt, 1),
-            "cores_note": "`cores` is the number of THREADS used (one per CPU of the affinity mask, at most 64); the box limits the process to "
-                          "`cpu_quota` CPUs worth of time (cgroup cpu.max; null = no quota readable), and `cpus_busy` is what the threads actually got",
-            "sample": f"{cores * reps} units of {unit_reads} reads ({soa.n} extension tasks + {n_grp} rescue groups of {PAIRS_PER_GROUP} pairs) "
-                      f"in {dt:.2f}s on {cores} threads; reference C kernels (scalar ksw_extend2 under the builder's batch loop, "
+            "value": round(threads * reps * unit_reads / dt, 1), "unit": "reads/s", "cores": cores, "kind": "reference",
+            "threads": threads, "cpu_quota": quota, "cpus_busy": round(((cpu_s.user - cpu_t0.user) + (cpu_s.system - cpu_t0.system)) / dt, 1),
+            "cores_note": "`cores` is the CPU quota of the box (cgroup cpu.max; the affinity mask when none is readable), `threads` what the sample ran on "
+                          "(one per CPU of the affinity mask, at most 64), `cpus_busy` what the threads actually got",
+            "sample": f"{threads * reps} units of {unit_reads} reads ({soa.n} extension tasks + {n_grp} rescue groups of {PAIRS_PER_GROUP} pairs) "
+                      f"in {dt:.2f}s on {threads} threads; reference C kernels (scalar ksw_extend2 under the builder's batch loop, "
                       f"mem_group_matesw with SSE2 ksw_align2) from oracle/_ref, no JVM; 1 thread alone: {unit_reads / one:.0f} reads/s",
         }
     import bpsw_hip
@@ -408,6 +411,54 @@ def tail_breakdown(ctx, opt, n_pairs: int = 4096):
             "sam_bytes": int(sum(len(t) for t in texts)), "note": "host buffers in, SAM text out; not part of `value`"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: the N ranks as children of torch.distributed.run on 127.0.0.1 (this process never
+    initialises the GPU; the children inherit stdout, so rank 0's JSON line is this command's line).  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_main(args, W):
+    """BENCH_STUB=1: the launch / rendezvous / reduction skeleton of main() with a sleep for a workload and no GPU call -- what the CPU
+    tests run to check that `--gpus N` really is N ranks (tests/test_multigpu_cpu.py).  Its line is marked `stub` and is not a measurement."""
+    import torch  # noqa: F401
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("BENCH_BACKEND", "gloo")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.02 * (rank + 1) * max(args.steps, 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ranks_seen = world
+    if world > 1:
+        elapsed, ranks_seen = reduce_over_ranks(elapsed, "cpu")
+    if ranks_seen != args.gpus:
+        print(f"bench: {ranks_seen} ranks took part, --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(3)
+    reads_per_step = READS_PER_EXT_BATCH * W["ext_batches"] * W["passes"]
+    if rank == 0:
+        print(json.dumps({"metric": W["metric"], "value": whole_job_rate(reads_per_step, args.steps, world, elapsed), "unit": "reads/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+                          "scaling": "weak", "ranks_seen": ranks_seen, "stub": True, "data": "none (BENCH_STUB=1: launch skeleton only)"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -420,7 +471,24 @@ def main():
     ap.add_argument("--no-tail", action="store_true", help="skip the worker2-tail breakdown entry")
     ap.add_argument("--no-extras", action="store_true", help="skip every breakdown outside the timed region")
     args = ap.parse_args()
-    W = WORKLOADS[args.config]
+    W = dict(WORKLOADS[args.config])
+    shrink = max(1, int(os.environ.get("BENCH_SHRINK", "1")))   # rehearsals (tests): 1/k of the batches, groups and passes; the line says so and is not the metric
+    if shrink > 1:
+        W["ext_batches"] = max(1, W["ext_batches"] // shrink)
+        W["groups"] = W["groups"] // shrink if W["groups"] else 0
+        W["passes"] = max(1, W["passes"] // shrink)
+
+    # ---- N ranks: one process per GPU (the reference's parallelism is mapPartitions over Spark partitions,
+    # FastMap.scala:266-293).  Under a launcher (WORLD_SIZE set) the world must be what --gpus says; without one, --gpus N > 1 starts
+    # the N ranks itself -- before anything in this process has touched the GPU -- and passes rank 0's line through.
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    if world_env is not None and int(world_env) != args.gpus:
+        print(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("BENCH_STUB") == "1":
+        return stub_main(args, W)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -511,9 +579,12 @@ def main():
     ranks_seen = world
     if distributed:
         elapsed, ranks_seen = reduce_over_ranks(elapsed, dev if backend == "nccl" else "cpu")
+    if ranks_seen != args.gpus:
+        print(f"bench: {ranks_seen} ranks took part in the timed region, --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(3)
 
     reads_per_pass = READS_PER_EXT_BATCH * W["ext_batches"]
-    assert only or not W["paired"] or reads_per_pass // 2 == PAIRS_PER_GROUP * W["groups"] or PAIRS_PER_GROUP != 4096
+    assert only or shrink > 1 or not W["paired"] or reads_per_pass // 2 == PAIRS_PER_GROUP * W["groups"] or PAIRS_PER_GROUP != 4096
     reads_per_step = reads_per_pass * passes
     pairs_per_step = reads_per_step // 2 if W["paired"] else 0
     value = whole_job_rate(reads_per_step, args.steps, world, elapsed)
@@ -713,7 +784,7 @@ def main():
                    "timed_region": "host buffers in, host buffers out: bpsw_extend_batch per wire batch + bpsw_matesw_group per group "
                                    "(H2D, kernels, D2H, speculate/replay, sort/dedup all inside)",
                    "host_threads_per_gpu": n_threads, "numa_node": numa_node, "feeder_cpus": len(share),
-                   "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "ranks_seen": ranks_seen,
+                   "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "ranks_seen": ranks_seen, "shrink": shrink,
                    "parallelism": f"partition->device x{world} (no collective)", "input_generation_s": round(t_gen, 1)},
         "verified": verified,
         "roofline": {"bound": "hbm", "kernel": dominant, "dominant_by": dominant_by, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
                                                                      const uint8_t* __restrict__ sift_flag,
                                                                      const uint4* __restrict__ sift_recs,
                                                                      int* __restrict__ defer_post,
-                                                                     const int* __restrict__ todo_list) {
+                                                                     const int* __restrict__ todo_list, const int inject_defer) {
   extern __shared__ __align__(16) unsigned char smem[];
   BPSW_DIAG_WAVE_BEGIN();
   BPSW_DIAG_TASKS_DECL();
@@ -155,8 +155,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
   // size is one chunk old when it is used), half of the waves had left 155 us before the last one of a 430 us launch
   // (tools/wave_placement.py, profiles/r04_wave_placement.txt).
   const bool listed = SHORT && todo_list != nullptr;
-  const int n_heavy = listed ? uni(next_task[3]) : 0;
-  const int n_tix = listed ? uni(next_task[2]) + n_heavy : n_tasks;
+  // (clamped: the counts come from the sift kernel of this call; whatever went wrong before, no ticket indexes outside the list)
+  const int n_heavy = listed ? min(uni(next_task[3]), n_tasks) : 0;
+  const int n_tix = listed ? min(uni(next_task[2]) + n_heavy, n_tasks) : n_tasks;
   int ticket = 0, ticket_end = 0, take = listed ? 1 : chunk > 0 ? chunk : max(1, min(guide_cap, n_tix / (2 * total_waves)));
   for (;;) {
     if (ticket == ticket_end) {
@@ -205,6 +206,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
     // cannot take -- a flank above -short_qmax bases, or any task when the gap costs rule out the register sweeps -- so it defers
     // them itself; short_qmax > 0: the host has listed them for the full kernel
     bool deferred = false;
+    // (test hook, BPSW_EXT_INJECT_DEFER=k: every k-th task of a deferring launch takes the way of a band that outgrew the window)
+    if (SHORT == 1 && inject_defer > 0 && task % inject_defer == 0) deferred = true;
     if (SHORT) {
       const int qm = short_qmax < 0 ? -short_qmax : short_qmax;
       const bool too_long = lq > qm || rq > qm || (short_qmax < 0 && oIns + eIns <= 0);
@@ -332,9 +335,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
       }
     }
     if (SHORT == 1 && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
-      // (a launch without a list serves flanks of at most 127 bases only, whose bands always fit the 128-column window: a band that
-      // does not fit there is a bug in the row loops, and must not pass for a result)
-      if (!defer) __builtin_trap();
+      // (every deferring launch has a list: launch_ext_kernel refuses one without.  A batch whose flanks all have at most 127 bases
+      // is not expected to defer anything -- their bands fit the 128-column window -- but if a row loop ever said otherwise, the
+      // task goes to the full kernel like any other deferred one instead of trapping the executor's process: round 4 trapped)
+      if (!defer) continue;
       if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
       continue;
     }
@@ -406,6 +410,9 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
                              int short_qmax, const uint8_t* d_sift_flag, const uint4* d_sift_recs, int* d_defer_post, const int* d_todo_list,
                              bool inline_wide) {
   if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
+  if (short_kernel && !inline_wide && !d_defer) return hipErrorInvalidValue;  // the deferring build needs somewhere to defer to
+  static const int inject_env = getenv("BPSW_EXT_INJECT_DEFER") ? atoi(getenv("BPSW_EXT_INJECT_DEFER")) : 0;  // test hook (tests/test_extend_gpu.py)
+  const int inject_defer = short_kernel && !inline_wide ? inject_env : 0;
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
   const int variant = short_kernel ? (inline_wide ? 2 : 1) : 0;
   const void* fn = variant == 0 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 0>) : reinterpret_cast<const void*>(ext_kernel<false, 0>))
@@ -459,7 +466,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   static const int guide_cap = [] { const int v = getenv("BPSW_EXT_GUIDE_CAP") ? atoi(getenv("BPSW_EXT_GUIDE_CAP")) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
 #define BPSW_EXT_GO(CO, SH)                                                                                                     \
   BPSW_LAUNCH(kev, (ext_kernel<CO, SH>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, d_wire, n_tasks, d_out, sc, qcap, rcap, \
-              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_sift_flag, d_sift_recs, d_defer_post, d_todo_list)
+              (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_sift_flag, d_sift_recs, d_defer_post, d_todo_list, inject_defer)
   if (variant == 1) {
     if (coord) BPSW_EXT_GO(true, 1); else BPSW_EXT_GO(false, 1);
   } else if (variant == 2) {

@@ -621,11 +621,14 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // deferring build for every batch (A/B).
   static const bool inline_wide_on = !(getenv("BPSW_EXT_INLINE_WIDE") && atoi(getenv("BPSW_EXT_INLINE_WIDE")) == 0);
   const bool inline_wide = inline_wide_on && use_short && 16 * (size_t)n_mid > (size_t)n;
-  const bool use_full = !use_short || n_long > 0 || (any_mid && !inline_wide);  // any_mid: the short kernel may defer tasks from the device
+  const bool expect_full = !use_short || n_long > 0 || (any_mid && !inline_wide);  // any_mid: the short kernel may defer tasks from the device
   // behind the wire bytes: the full kernel's list as [count, task indices...]; the host stages its own entries and the count, the
   // 48-VGPR kernel appends (room for every task)
   const size_t list_off = (wire_bytes + 15) & ~(size_t)15;
-  const bool with_list = use_short && use_full;
+  // The deferring short kernel ALWAYS has a list to defer to (round 4 gave it none when no task could be expected to defer, and
+  // trapped if one did): a batch without mid tasks posts an empty list like any other, and the full kernel is launched behind it
+  // only when it is not (lazy_full below) -- or unconditionally where the late launch is off (classify entry, BPSW_EXT_LAZY_FULL=0).
+  const bool with_list = use_short && !inline_wide ? true : (use_short && expect_full);
   const size_t stage_bytes = with_list ? list_off + 4 * (1 + (size_t)n_long) : wire_bytes;
   const size_t dev_bytes = with_list ? list_off + 4 * (1 + (size_t)n) : wire_bytes;
   if (!out_view && (!out || out_len < 10 * (size_t)n)) return fail(BPSW_ERR_CAPACITY, "extend: result buffer smaller than 10*n int16");
@@ -639,7 +642,8 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // launches the full kernel and waits again.  An empty launch held the stream for 0.1-0.18 ms of a 1.6 ms call
   // (profiles/r03_trace_overlap.txt).  BPSW_EXT_LAZY_FULL=0: always launch it.
   static const bool lazy_on = !(getenv("BPSW_EXT_LAZY_FULL") && atoi(getenv("BPSW_EXT_LAZY_FULL")) == 0);
-  const bool lazy_full = lazy_on && !side_how && use_short && use_full && n_long == 0 && 16 * (size_t)n_mid <= (size_t)n;
+  const bool lazy_full = lazy_on && !side_how && use_short && with_list && n_long == 0 && 16 * (size_t)n_mid <= (size_t)n;
+  const bool use_full = expect_full || (with_list && !lazy_full);
   const size_t out_post_bytes = out_bytes + (lazy_full ? 4 : 0);
   // (32-byte result slots in the pinned buffer were tried: the 16 + 4 byte stores of a record then cost two write sectors each,
   // more fabric writes than back-to-back 20-byte records that merge in L2, and the host-side gather cost more than the memcpy)
@@ -726,14 +730,22 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         uint8_t* d_sflag = use_sift ? (uint8_t*)c->d_sift.ptr : nullptr;
         uint4* d_srecs = use_sift ? (uint4*)((char*)c->d_sift.ptr + sift_rec_off) : nullptr;
         int* d_todo = use_todo ? (int*)((char*)c->d_sift.ptr + todo_off) : nullptr;
+        // (should anything fail between the sift kernel, which fills the to-do counters d_queue[2..3], and the short kernel, whose last
+        // wave puts them back to zero, they are cleared here: the next call's sift kernel adds to what it finds)
+        struct TodoGuard {
+          int* q; hipStream_t s; bool armed;
+          ~TodoGuard() { if (armed) { (void)hipMemsetAsync(q, 0, 4 * sizeof(int), s); (void)hipStreamSynchronize(s); } }
+        } todo_guard{d_queue, s, false};
         if (use_sift) {  // the kernel time of the call starts with it
           KernelEvents sev;
           sev.start = kev.start; kev.start = nullptr;
+          todo_guard.armed = use_todo;
           HIP_TRY(launch_ext_sift_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, sift_dm, 127, d_sflag, d_srecs, s, sev, nullptr,
                                          use_todo ? d_queue + 2 : nullptr, d_todo, heavy_min));
         }
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 255), mr_short, c->num_cu, d_queue, nullptr, s,
                                   nullptr, false, kev, true, d_list, 255, d_sflag, d_srecs, lazy_full ? (int*)(k_out + 10 * (size_t)n) : nullptr, d_todo, inline_wide));
+        todo_guard.armed = false;
       }
       if (use_full && !lazy_full) {
         KernelEvents kev;
@@ -744,9 +756,10 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         // (a batch with few mid tasks -- 2x150 bp reads: the flanks of 128-131 bases -- defers next to nothing: one workgroup, whose
         // four persistent waves take whatever the list holds, gets its wave slots sooner than a grid sized for a quarter of them, and
         // the call holds its stream for that long)
-        const bool few_mid = 16 * (size_t)n_mid <= (size_t)n;
-        const bool may_defer = any_mid && !inline_wide;
-        const int grid_tasks = !use_short ? n : n_long + (may_defer ? (few_mid ? 0 : (n_mid + 3) / 4) + 4 : 0);
+        // (this is the launch that is NOT late -- the classify entry, BPSW_EXT_LAZY_FULL=0, or tasks the host listed itself: a quarter of
+        // the mid tasks sizes it, at least one workgroup; the late launch below is sized by the posted length of the list)
+        const bool may_defer = use_short && !inline_wide;
+        const int grid_tasks = !use_short ? n : n_long + (may_defer ? std::max(4, (n_mid + 3) / 4) : 0);
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, grid_tasks, k_out, sc, mq, mr, c->num_cu, d_queue, nullptr, s,
                                   nullptr, false, kev, false, use_short ? d_list : nullptr));
       }

@@ -181,8 +181,12 @@ for i, name in enumerate(["a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_unp
 orc_opt.mask_level_redun = mlr.value
 for k in range(25):
     orc_opt.mat[k] = int(m25[k])
-for tag, allo, n, p in (("fr", False, 48, 0.4), ("all4", True, 24, 0.5)):
-    g = synth.rescue_group(n, seed=4242 + n, p_resc=p, all_orientations=allo)
+# ("250": 2x250 bp mates at 8 % / 2 % error, a quarter of the pairs to rescue -- BASELINE.json configs[4]'s half of boundary 1: l_ms * a >= 250, so the
+# reference leaves KSW_XBYTE off, native/bwamem_pair.c:179 / MemSamPe.scala:1187-1190, and its windows are 250 bases wider)
+for tag, allo, n, p, kw in (("fr", False, 48, 0.4, {}), ("all4", True, 24, 0.5, {}),
+                            ("250", False, 40, 0.4, dict(read_len=250, sub_rate=0.08, indel_rate=0.02, p_decoy_anchor=0.2)),
+                            ("250_all4", True, 24, 0.5, dict(read_len=250, sub_rate=0.08, indel_rate=0.02))):
+    g = synth.rescue_group(n, seed=4242 + n + 7 * len(kw), p_resc=p, all_orientations=allo, **kw)
     cnt, regs = ref.matesw_group(orc_opt, g)
     np.savez_compressed(os.path.join(HERE, f"mem_group_matesw_{tag}.npz"), group_size=g.group_size, l_pac=g.l_pac,
                         pes=np.array(g.pes, np.float64), seq_len=g.seq_len, seq_off=g.seq_off, seq_pool=g.seq_pool, reg_cnt=g.reg_cnt,

@@ -492,3 +492,44 @@ def test_sift_kernel_leaves_what_it_cannot_stage_to_the_extension_kernel(ctx, or
     wl = bpsw_hip.wire_pack(long_soa)
     want_l, _ = orc.wire_extend(wl)
     assert np.array_equal(ctx.extend_batch(wl), want_l)
+
+
+_INJECT = r"""
+import os, sys
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {orc!r})
+import numpy as np
+import bpsw_hip
+from bpsw_hip import synth
+import pyoracle as po
+orc = po.Oracle()
+ctx = bpsw_hip.Context(0)
+for n, seed in ((3000, 1), (9000, 2)):
+    soa = synth.ext_tasks(n, read_len=100, seed=seed)      # 100-base reads: no flank reaches 128 bases, nothing is EXPECTED to defer
+    assert int(max(soa.left_qlen.max(), soa.right_qlen.max())) < 128
+    wire = bpsw_hip.wire_pack(soa)
+    want, _ = orc.wire_extend(wire)
+    before = ctx.stats().ext_full_relaunches
+    got = ctx.extend_batch(wire)
+    assert np.array_equal(got, want), int((got != want).any(axis=1).sum())
+    print("LATE", ctx.stats().ext_full_relaunches - before)
+ctx.close()
+"""
+
+
+@pytest.mark.parametrize("lazy", ["1", "0"])
+def test_an_unexpected_band_overflow_is_deferred_not_trapped(lazy):
+    """Round 4's short kernel had no list to defer to when no flank of the batch reached 128 bases, and trapped -- taking the executor's
+    process down (never abort the JVM) -- if a band outgrew the window all the same.  Now every deferring launch has a list:
+    BPSW_EXT_INJECT_DEFER=7 sends every seventh task of such a batch down that path; the full kernel computes it (late launch, or the
+    unconditional one with BPSW_EXT_LAZY_FULL=0), results bit-exact."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BPSW_EXT_INJECT_DEFER="7", BPSW_EXT_LAZY_FULL=lazy)
+    src = _INJECT.format(pkg=os.path.join(root, "cloud-scale-bwamem_amd"), orc=os.path.join(root, "oracle"))
+    r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    late = [int(ln.split()[1]) for ln in r.stdout.splitlines() if ln.startswith("LATE")]
+    assert len(late) == 2
+    if lazy == "1":
+        assert all(v == 1 for v in late), late     # the list was not empty: the full kernel was launched behind the short one

@@ -64,7 +64,7 @@ def test_sort_dedup_vs_mem_sort_and_dedup_golden(orc):
         region_fields_equal(got, z["regs_out"][oo[i]:oo[i + 1]])
 
 
-@pytest.mark.parametrize("tag", ["fr", "all4"])
+@pytest.mark.parametrize("tag", ["fr", "all4", "250", "250_all4"])
 def test_group_rescue_vs_mem_group_matesw_golden(orc, tag):
     import bpsw_hip
     z = np.load(os.path.join(G, f"mem_group_matesw_{tag}.npz"))

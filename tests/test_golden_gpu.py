@@ -98,7 +98,7 @@ def test_extension_tasks_vs_reference_golden(ctx, mask):
         ctx.set_ext_shortcuts(-1)
 
 
-@pytest.mark.parametrize("tag", ["fr", "all4"])
+@pytest.mark.parametrize("tag", ["fr", "all4", "250", "250_all4"])
 def test_group_rescue_vs_mem_group_matesw_golden(ctx, tag):
     z = np.load(os.path.join(G, f"mem_group_matesw_{tag}.npz"))
     g = bpsw_hip.RescueGroupSoA(group_size=int(z["group_size"]), l_pac=int(z["l_pac"]),

@@ -74,10 +74,15 @@ def test_extend_through_jni_matches_c_abi(fake, ctx):
     assert rc == 1 and "RuntimeException" in msg                        # malformed batch -> exception, not a crash
 
 
+# (read_len 250: BASELINE.json configs[4] -- 8 % / 2 % error, the packed kernel's five-columns-per-lane build, the ring's second class)
+RL_CASES = [dict(), dict(read_len=250, sub_rate=0.08, indel_rate=0.02)]
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("rl", RL_CASES, ids=["150bp", "250bp"])
 @pytest.mark.parametrize("allo", [False, True])
-def test_matesw_through_jni_matches_c_abi(fake, ctx, allo):
-    g = synth.rescue_group(120, seed=404, p_resc=0.4, all_orientations=allo)
+def test_matesw_through_jni_matches_c_abi(fake, ctx, allo, rl):
+    g = synth.rescue_group(120, seed=404, p_resc=0.4, all_orientations=allo, **rl)
     want_cnt, want = ctx.matesw_group(bpsw_hip.default_opt(), g)
     rc, cnt, regs, frames, msg = _matesw(fake, g, partition=3)
     assert rc == 0, msg
@@ -102,10 +107,11 @@ def test_matesw_through_jni_with_reference_on_device(fake, ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rl", RL_CASES, ids=["150bp", "250bp"])
 @pytest.mark.parametrize("allo", [False, True])
-def test_matesw_flat_entry_equals_the_object_array_entry(fake, ctx, allo):
+def test_matesw_flat_entry_equals_the_object_array_entry(fake, ctx, allo, rl):
     """mateSWFlatJNI (round 4: primitive arrays in, one long[] out) against mateSWJNI on the same group, and against the C ABI"""
-    g = synth.rescue_group(160, seed=811, p_resc=0.4, all_orientations=allo)
+    g = synth.rescue_group(160, seed=811, p_resc=0.4, all_orientations=allo, **rl)
     want_cnt, want = ctx.matesw_group(bpsw_hip.default_opt(), g)
     rc, cnt_o, regs_o, frames, msg = _matesw(fake, g, partition=2)
     assert rc == 0, msg

@@ -88,3 +88,37 @@ def test_rank_shards_are_deterministic():
     assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0])) and a[1] == b[1]
     assert all(np.array_equal(x.seq_pool, y.seq_pool) and np.array_equal(x.regs, y.regs) for x, y in zip(a[2], b[2]))
     assert not all(x.size == y.size and np.array_equal(x, y) for x, y in zip(a[0], c[0]))
+
+
+def _run_bench(extra_args, env_extra, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ, BENCH_STUB="1", BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command): bench.py starts the two ranks
+    (torch.distributed.run on 127.0.0.1) before it touches any GPU, rank 0 prints the one line, and the line says two ranks took part.
+    BENCH_STUB=1: the launch / rendezvous / reduction skeleton with a sleep for a workload (no GPU here)."""
+    r, line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["stub"] is True
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1          # ONE line: rank 0's
+    assert line["ms_per_step"] >= 2 * 20.0 - 1.0                                          # MAX over ranks: rank 1 sleeps twice as long
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """under a launcher WORLD_SIZE must equal --gpus: a run that was started as one rank cannot print n_gpus: 2"""
+    r, line = _run_bench(["--gpus", "2", "--steps", "1"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and line is None
+    assert "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_single_rank_stub_line():
+    r, line = _run_bench(["--gpus", "1", "--steps", "1"], {})
+    assert r.returncode == 0 and line["n_gpus"] == 1 and line["ranks_seen"] == 1

@@ -23,6 +23,26 @@ def test_group_rescue_matches_oracle(ctx, orc, mode, allo, n, p):
         assert n_sw > 0 and got.shape[0] > g.regs.shape[0]   # something was rescued
 
 
+# BASELINE.json configs[4]'s half of boundary 1: 2x250 bp mates at 8 % / 2 % error, a quarter (and more) of the pairs to rescue.  l_ms * a >= 250
+# (the reference leaves KSW_XBYTE off there, native/bwamem_pair.c:179 / MemSamPe.scala:1187-1190), five query columns per lane in the
+# packed kernel, the second class of the submission ring, windows 250 bases wider.
+@pytest.mark.parametrize("mode", [po.RESCUE_C, po.RESCUE_SCALA])
+@pytest.mark.parametrize("allo,n,p,decoy", [(False, 300, 0.25, 0.0), (True, 120, 0.5, 0.0), (False, 200, 0.4, 0.5)])
+def test_group_rescue_250bp_matches_oracle(ctx, orc, mode, allo, n, p, decoy):
+    g = synth.rescue_group(n, read_len=250, seed=2500 + n, p_resc=p, all_orientations=allo, sub_rate=0.08, indel_rate=0.02,
+                           p_multi_anchor=0.3, p_decoy_anchor=decoy)
+    assert int(g.seq_len.max()) == 250
+    want_cnt, want, n_sw, _ = orc.matesw_group(orc.default_opt(), g, mode)
+    s0 = ctx.stats()
+    got_cnt, got = ctx.matesw_group(bpsw_hip.default_opt(), g, mode)
+    s1 = ctx.stats()
+    assert np.array_equal(got_cnt, want_cnt)
+    region_fields_equal(got, want)
+    assert n_sw > 0 and got.shape[0] > g.regs.shape[0]
+    if decoy > 0:
+        assert s1.sw_replayed_rounds > s0.sw_replayed_rounds   # a decoy's rescue failed: the true hit's job came in a second round
+
+
 def test_no_rescue_flag_and_empty_group(ctx, orc):
     g = synth.rescue_group(50, seed=1, p_resc=0.5)
     opt = bpsw_hip.default_opt(); opt.flag = 0x20  # MEM_F_NO_RESCUE

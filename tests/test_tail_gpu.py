@@ -122,13 +122,15 @@ def test_reg2aln_jobs_vs_oracle_and_edge_cases(ctx, orc):
         ctx.reg2aln_batch(bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(), rl[:1], ro[:1], g.read_pool, bad)
 
 
+@pytest.mark.parametrize("rl", [dict(sub_rate=0.02, indel_rate=0.004), dict(read_len=250, sub_rate=0.08, indel_rate=0.02)], ids=["150bp", "250bp"])
 @pytest.mark.parametrize("rescue_mode,flavour,zmode", [(bpsw_hip.RESCUE_C, bpsw_hip.TAIL_C, po.ZDROP_BWA),
                                                         (bpsw_hip.RESCUE_SCALA, bpsw_hip.TAIL_SCALA, po.ZDROP_SCALA)])
-def test_worker2_in_one_call_vs_oracle_pipeline(ctx, orc, rescue_mode, flavour, zmode):
+def test_worker2_in_one_call_vs_oracle_pipeline(ctx, orc, rescue_mode, flavour, zmode, rl):
     """bpsw_worker2_batch = prepare + rescue (windows from the resident reference) + tail, against the oracle's own pipeline
-    (windows cut as bytes -> orc_matesw_group -> orc_sam_pe_batch) on pairs of which a fifth have an end without any seed."""
-    pac, bases, g = synthetic_group_with_bases(orc, 500, 8800 + flavour, zdrop_mode=zmode, dedup_mode=rescue_mode, sub_rate=0.02,
-                                               indel_rate=0.004, p_hard=0.2, p_unmappable=0.03)
+    (windows cut as bytes -> orc_matesw_group -> orc_sam_pe_batch) on pairs of which a fifth have an end without any seed.
+    250bp: BASELINE.json configs[4]'s reads (8 % / 2 % error) through the same call."""
+    pac, bases, g = synthetic_group_with_bases(orc, 500 if "read_len" not in rl else 300, 8800 + flavour, zdrop_mode=zmode, dedup_mode=rescue_mode,
+                                               p_hard=0.2, p_unmappable=0.03, **rl)
     _load_ref(ctx, pac, g)
     opt, oopt = bpsw_hip.default_opt(), orc.default_opt()
     rg = rescue_group_of(g, bases, oopt)
