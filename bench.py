@@ -548,6 +548,11 @@ def main():
         wires, ntasks, ext_outs = [], [], []
     items, order = fd.make_items(wires, ext_outs, groups, structs, grp_cnts, grp_regs)
     F = fd.Feeder(n_threads, local_rank, opt, bpsw_hip.RESCUE_C, cpus=share if (numa_cpus or distributed) else None)  # no fallback: raises without a gfx950 device
+    # the extension calls the way the JNI shim makes them (csrc/bpsw_jni.cpp: bpsw_extend_stage, GetByteArrayRegion into the pinned block,
+    # bpsw_extend_commit, SetShortArrayRegion from the pinned result block); BENCH_EXT_ENTRY=batch: bpsw_extend_batch, as rounds 1-4 timed
+    ext_entry = os.environ.get("BENCH_EXT_ENTRY", "stage_commit")
+    if ext_entry == "stage_commit":
+        F.use_stage_commit(True)
 
     def barrier():
         if distributed:
@@ -781,7 +786,9 @@ def main():
                    "ext_tasks_per_step": passes * int(sum(ntasks)), "rescue_groups_per_step": passes * W["groups"], "pairs_per_group": PAIRS_PER_GROUP,
                    "rescue_jobs_per_step": int(st["sw_jobs"] / max(args.steps, 1)),
                    "reads_streamed_in_timed_region": int(reads_per_step * args.steps * world),
-                   "timed_region": "host buffers in, host buffers out: bpsw_extend_batch per wire batch + bpsw_matesw_group per group "
+                   "ext_entry": ext_entry,
+                   "timed_region": "host buffers in, host buffers out: bpsw_extend_stage + memcpy + bpsw_extend_commit + memcpy per wire batch (the JNI shim's sequence; "
+                                   "BENCH_EXT_ENTRY=batch: bpsw_extend_batch) + bpsw_matesw_group per group "
                                    "(H2D, kernels, D2H, speculate/replay, sort/dedup all inside)",
                    "host_threads_per_gpu": n_threads, "numa_node": numa_node, "feeder_cpus": len(share),
                    "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "ranks_seen": ranks_seen, "shrink": shrink,

@@ -38,6 +38,16 @@ class Feeder:
         if not self.h:
             raise BpswError("bpsw_feeder_create failed")
         self.n_threads = n_threads
+        self.stage_commit = False
+
+    def use_stage_commit(self, on: bool = True) -> None:
+        """extension items through bpsw_extend_stage / bpsw_extend_commit, the way the JNI shim's swExtendFPGAJNI makes the call (the wire
+        bytes go straight into the pinned staging block, the results are read where the kernel wrote them)"""
+        self.syn.bpsw_feeder_use_stage_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.syn.bpsw_feeder_use_stage_commit.restype = None
+        self.syn.bpsw_feeder_use_stage_commit(self.h, C.cast(self.lib.bpsw_extend_stage, C.c_void_p) if on else None,
+                                              C.cast(self.lib.bpsw_extend_commit, C.c_void_p) if on else None)
+        self.stage_commit = bool(on)
 
     def run(self, items, repeats: int = 1) -> None:
         """items: a ctypes array of FeedItem (make_items); every item is run `repeats` times -- the threads go round the items

@@ -31,6 +31,10 @@ typedef struct {
 } bpsw_feed_item_t;
 
 typedef int (*extend_fn)(void* ctx, const uint8_t* wire, size_t bytes, int16_t* out, size_t out_len);
+// the two-step form the JNI shim uses (csrc/bpsw_jni.cpp, swExtendFPGAJNI): the wire bytes go straight into the context's pinned staging
+// block -- GetByteArrayRegion there, a memcpy here -- and the results are read where the kernel wrote them
+typedef int (*stage_fn)(void* ctx, size_t bytes, uint8_t** buf);
+typedef int (*commit_fn)(void* ctx, size_t wire_bytes, const int16_t** out, size_t* out_len);
 typedef int (*matesw_fn)(void* ctx, const void* opt, const void* group, int mode, int32_t* out_cnt, void* out_regs, int64_t out_cap,
                          int64_t* out_total);
 
@@ -38,6 +42,8 @@ struct bpsw_feeder {
   std::vector<std::thread> threads;
   std::vector<void*> ctxs;
   extend_fn f_ext = nullptr;
+  stage_fn f_stage = nullptr;    // both set: extension items go through stage / commit like the shim's calls
+  commit_fn f_commit = nullptr;
   matesw_fn f_grp = nullptr;
   const void* opt = nullptr;
   int mode = 0;
@@ -84,7 +90,19 @@ static void feeder_worker(bpsw_feeder* F, int t) {
       unsigned char idle = 0;
       while (!F->busy[(size_t)i].compare_exchange_weak(idle, 1, std::memory_order_acquire)) { idle = 0; sched_yield(); }
       const double t0 = now_ms(), c0 = thread_cpu_ms();
-      if (it.kind == 0) it.rc = F->f_ext(F->ctxs[(size_t)t], (const uint8_t*)it.in, it.in_bytes, (int16_t*)it.out, (size_t)it.out_cap);
+      if (it.kind == 0 && F->f_stage && F->f_commit) {
+        uint8_t* buf = nullptr;
+        const int16_t* res = nullptr;
+        size_t res_len = 0;
+        int rc = F->f_stage(F->ctxs[(size_t)t], it.in_bytes, &buf);
+        if (rc == 0) {
+          memcpy(buf, it.in, it.in_bytes);                                   // GetByteArrayRegion
+          rc = F->f_commit(F->ctxs[(size_t)t], it.in_bytes, &res, &res_len);
+        }
+        if (rc == 0 && res_len > (size_t)it.out_cap) rc = -6;
+        if (rc == 0 && res_len) memcpy(it.out, res, 2 * res_len);            // SetShortArrayRegion
+        it.rc = rc;
+      } else if (it.kind == 0) it.rc = F->f_ext(F->ctxs[(size_t)t], (const uint8_t*)it.in, it.in_bytes, (int16_t*)it.out, (size_t)it.out_cap);
       else it.rc = F->f_grp(F->ctxs[(size_t)t], F->opt, it.in, F->mode, (int32_t*)it.out, it.out2, it.out_cap, &it.out_total);
       it.ms = now_ms() - t0;
       it.cpu_ms = thread_cpu_ms() - c0;
@@ -148,6 +166,13 @@ int bpsw_feeder_run_repeats(bpsw_feeder* F, bpsw_feed_item_t* items, int n_items
   std::unique_lock<std::mutex> lk(F->mu);
   F->cv_done.wait(lk, [&] { return F->running == 0; });
   return F->first_rc.load();
+}
+
+// extension items through bpsw_extend_stage / bpsw_extend_commit from now on (both null: back to bpsw_extend_batch)
+void bpsw_feeder_use_stage_commit(bpsw_feeder* F, void* fn_stage, void* fn_commit) {
+  if (!F) return;
+  F->f_stage = (stage_fn)fn_stage;
+  F->f_commit = (commit_fn)fn_commit;
 }
 
 int bpsw_feeder_run(bpsw_feeder* F, bpsw_feed_item_t* items, int n_items) { return bpsw_feeder_run_repeats(F, items, n_items, 1); }

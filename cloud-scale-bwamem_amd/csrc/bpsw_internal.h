@@ -357,6 +357,13 @@ struct StreamLease {
   StreamLease(const StreamLease&) = delete;
   StreamLease& operator=(const StreamLease&) = delete;
 };
+// the device's lane for bulk copies that are made before a call takes a stream (extend_batch_impl): one at a time
+struct CopyLane {
+  std::mutex mu;
+  hipStream_t s = nullptr;
+  hipEvent_t ev = nullptr;
+};
+CopyLane& copy_lane(int device);
 double wall_ms();
 // rescue launches (sw_stage_run) between their launch and the end of their wait, per device: the extension path shapes its bulk copies
 // by it (extend_batch_impl)

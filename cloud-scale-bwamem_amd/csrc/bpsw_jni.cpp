@@ -28,6 +28,7 @@
 #include <mutex>
 #include <string>
 #include <time.h>
+#include <exception>
 #include <vector>
 
 #include "bpsw.h"
@@ -273,6 +274,7 @@ JNIEXPORT void JNICALL Java_cs_ucla_edu_bwaspark_jni_HelloWorld_helloWorld(JNIEn
 JNIEXPORT jshortArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swExtendFPGAJNI(JNIEnv* env, jobject,
                                                                                             jint retTaskNum,
                                                                                             jbyteArray arrayIn) {
+  try {
   if (!arrayIn || retTaskNum < 0) { throw_runtime(env, "bPSW: swExtendFPGAJNI: bad arguments"); return nullptr; }
   const double t0 = now_us();
   const jsize bytes = jni::GetArrayLength(env, arrayIn);
@@ -296,12 +298,17 @@ JNIEXPORT jshortArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_swEx
   if (res_len > 0) jni::SetShortArrayRegion(env, ret, 0, (jsize)res_len, res);
   t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)(res_len / 10)};
   return ret;
+  } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
+    throw_runtime(env, std::string("bPSW: swExtendFPGAJNI: ") + e.what());
+    return nullptr;
+  }
 }
 
 // ---- boundary 1 ------------------------------------------------------------------------------------
 JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI(
     JNIEnv* env, jobject, jobject optObj, jlong pacLen, jobjectArray pesArr, jint groupSize, jobjectArray seqArr,
     jobjectArray mateArr, jobjectArray refArr, jintArray refSizeArr) {
+  try {
   if (!optObj || !pesArr || !seqArr || !mateArr || !refArr || !refSizeArr || groupSize < 0) {
     throw_runtime(env, "bPSW: mateSWJNI: bad arguments");
     return nullptr;
@@ -495,6 +502,10 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
     }
   t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)total};
   return ret;
+  } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
+    throw_runtime(env, std::string("bPSW: mateSWJNI: ") + e.what());
+    return nullptr;
+  }
 }
 
 // ---- boundary 1 with flat arrays (round 4) -------------------------------------------------------------------------------------
@@ -522,6 +533,8 @@ JNIEXPORT jlongArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWFlatJ
     JNIEnv* env, jobject, jintArray optInts, jfloat maskLevelRedun, jbyteArray matArr, jlong pacLen, jdoubleArray pesArr, jint groupSize,
     jintArray seqLenArr, jbyteArray seqsArr, jintArray regCntArr, jlongArray regLongsArr, jintArray regIntsArr, jintArray refCntArr,
     jlongArray refRbArr, jlongArray refReArr, jlongArray refLenArr, jbyteArray refBytesArr) {
+  try {
+  if (groupSize < 0 || groupSize > 0x3fffffff) { throw_runtime(env, "bPSW: mateSWFlatJNI: groupSize out of range"); return nullptr; }
   const jsize ends_j = 2 * groupSize;
   if (!optInts || !matArr || !pesArr || !seqLenArr || !seqsArr || !regCntArr || !regLongsArr || !regIntsArr || !refCntArr || !refRbArr ||
       !refReArr || groupSize < 0 || (refLenArr == nullptr) != (refBytesArr == nullptr) || jni::GetArrayLength(env, optInts) < 16 ||
@@ -654,12 +667,17 @@ JNIEXPORT jlongArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWFlatJ
   if (n_out) jni::SetLongArrayRegion(env, ret, 0, (jsize)n_out, reinterpret_cast<const jlong*>(res.data()));
   t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)total};
   return ret;
+  } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
+    throw_runtime(env, std::string("bPSW: mateSWFlatJNI: ") + e.what());
+    return nullptr;
+  }
 }
 
 // ---- reference on the device -------------------------------------------------------------
 // Scala side (one line in jni/MateSWJNI.scala):  @native def loadPacJNI(pac: Array[Byte], pacLen: Long): Int
 // Call once per executor JVM before the first mateSWJNI; returns the number of devices that now hold the reference.
 JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI(JNIEnv* env, jobject, jbyteArray pacArr, jlong pacLen) {
+  try {
   if (!pacArr || pacLen < 1) { throw_runtime(env, "bPSW: loadPacJNI: bad arguments"); return 0; }
   const jsize bytes = jni::GetArrayLength(env, pacArr);
   if ((int64_t)bytes < (pacLen + 3) / 4) { throw_runtime(env, "bPSW: loadPacJNI: pac shorter than (pacLen+3)/4 bytes"); return 0; }
@@ -677,6 +695,10 @@ JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI(JNIEnv
     ++loaded;
   }
   return loaded;
+  } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
+    throw_runtime(env, std::string("bPSW: loadPacJNI: ") + e.what());
+    return 0;
+  }
 }
 
 // ---- the whole memChainToAlnBatched round loop in one call -------------------------------------
@@ -691,6 +713,7 @@ JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadPacJNI(JNIEnv
 JNIEXPORT jlongArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI(
     JNIEnv* env, jobject, jintArray optInts, jbyteArray matArr, jintArray readLenArr, jbyteArray readsArr, jintArray chainCntArr,
     jintArray seedCntArr, jlongArray seedRBegArr, jintArray seedQBegArr, jintArray seedLenArr) {
+  try {
   if (!optInts || !matArr || !readLenArr || !readsArr || !chainCntArr || !seedCntArr || !seedRBegArr || !seedQBegArr || !seedLenArr ||
       jni::GetArrayLength(env, optInts) < 10 || jni::GetArrayLength(env, matArr) < 25) {
     throw_runtime(env, "bPSW: chainToAlnJNI: bad arguments");
@@ -759,6 +782,10 @@ JNIEXPORT jlongArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chain
   if (!ret) return nullptr;  // OutOfMemoryError already pending
   if (!flat.empty()) jni::SetLongArrayRegion(env, ret, 0, (jsize)flat.size(), flat.data());
   return ret;
+  } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
+    throw_runtime(env, std::string("bPSW: chainToAlnJNI: ") + e.what());
+    return nullptr;
+  }
 }
 
 // ---- worker2's tail -----------------------------------------------------------------------------
@@ -767,6 +794,7 @@ JNIEXPORT jlongArray JNICALL Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chain
 // Call once per executor JVM after loadPacJNI (bns.anns(i).offset / .len / .name); returns the number of devices loaded.
 JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI(JNIEnv* env, jobject, jlongArray offArr, jintArray lenArr,
                                                                           jbyteArray namesArr) {
+  try {
   if (!offArr || !lenArr) { throw_runtime(env, "bPSW: loadBnsJNI: bad arguments"); return 0; }
   const jsize n = jni::GetArrayLength(env, offArr);
   if (n < 1 || jni::GetArrayLength(env, lenArr) != n) { throw_runtime(env, "bPSW: loadBnsJNI: offset and len must have one entry per contig"); return 0; }
@@ -795,6 +823,10 @@ JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI(JNIEnv
     ++loaded;
   }
   return loaded;
+  } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
+    throw_runtime(env, std::string("bPSW: loadBnsJNI: ") + e.what());
+    return 0;
+  }
 }
 
 // Scala side (jni/MateSWJNI.scala); replaces the body of memSamPeGroupRest (worker2/MemSamPe.scala:1390-1612):
@@ -811,6 +843,7 @@ JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJN
     JNIEnv* env, jobject, jintArray optInts, jdoubleArray realsArr, jbyteArray matArr, jlong id0, jintArray readLenArr, jbyteArray readsArr,
     jbyteArray qualsArr, jintArray nameLenArr, jbyteArray namesArr, jintArray regCntArr, jlongArray regLongsArr, jintArray regIntsArr,
     jlongArray outOffArr) {
+  try {
   if (!optInts || !realsArr || !matArr || !readLenArr || !readsArr || !nameLenArr || !namesArr || !regCntArr || !regLongsArr || !regIntsArr ||
       !outOffArr || jni::GetArrayLength(env, optInts) < 12 || jni::GetArrayLength(env, realsArr) < 22 || jni::GetArrayLength(env, matArr) < 25) {
     throw_runtime(env, "bPSW: samPeTailJNI: bad arguments");
@@ -831,7 +864,11 @@ JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJN
   const char* compat = getenv("BPSW_TAIL_COMPAT");
   topt.flavour = (compat && (compat[0] == 'c' || compat[0] == 'C')) ? BPSW_TAIL_C : BPSW_TAIL_SCALA;
   // the read group of the run (samHeader.bwaReadGroupID, FastMap.scala:109-114: fixed by the -R line before any worker starts)
-  if (const char* rg = getenv("BPSW_READ_GROUP_ID")) strncpy(topt.rg_id, rg, sizeof(topt.rg_id) - 1);
+  if (const char* rg = getenv("BPSW_READ_GROUP_ID")) {
+    // (the reference writes samHeader.bwaReadGroupID whatever its length: a truncated ID would give RG:Z tags that match no @RG line)
+    if (strlen(rg) >= sizeof(topt.rg_id)) { throw_runtime(env, "bPSW: samPeTailJNI: BPSW_READ_GROUP_ID is longer than 63 characters"); return nullptr; }
+    strncpy(topt.rg_id, rg, sizeof(topt.rg_id) - 1);
+  }
   const jsize n2 = jni::GetArrayLength(env, readLenArr);
   const jsize G = n2 / 2;
   if ((n2 & 1) || jni::GetArrayLength(env, regCntArr) != n2 || jni::GetArrayLength(env, nameLenArr) != G ||
@@ -900,6 +937,10 @@ JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJN
   if (need) jni::SetByteArrayRegion(env, ret, 0, (jsize)need, reinterpret_cast<const jbyte*>(text.data()));
   jni::SetLongArrayRegion(env, outOffArr, 0, n2 + 1, reinterpret_cast<const jlong*>(out_off.data()));
   return ret;
+  } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
+    throw_runtime(env, std::string("bPSW: samPeTailJNI: ") + e.what());
+    return nullptr;
+  }
 }
 
 }  // extern "C"

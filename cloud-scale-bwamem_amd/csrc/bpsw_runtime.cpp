@@ -304,6 +304,11 @@ int stream_share() {
 }
 }  // namespace
 
+CopyLane& copy_lane(int device) {
+  static CopyLane table[64];
+  return table[device >= 0 && device < 64 ? device : 0];
+}
+
 StreamLease::StreamLease(bpsw_ctx* c) : device(c->device), s(c->stream), pooled(false), wait_ms(0.) {
   const int cap = stream_pool_cap();
   if (cap == 0) return;
@@ -683,21 +688,41 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   }
   const double t_staged = wall_ms();
   double t_dev0, t_dev1, copy_first_ms = 0.;
-  bool kernel_was_last = false;
+  bool kernel_was_last = false, relaunched = false;
   {
-    // The copy of the wire batch.  While rescue launches are in flight on this device (bpsw_sw_runtime.cpp counts them) it is a
-    // blocking hipMemcpy BEFORE the call takes a pooled stream: the pooled streams are non-blocking, so it waits for nobody's
-    // kernels; the stream is then held for the kernels only (the streams are what the calls queue for: DESIGN.md 5.2), and -- all
-    // such copies going through the legacy stream -- one bulk copy crosses PCIe at a time instead of several beside the rescue
-    // kernels' zero-copy reads.  configs[2]: the device phase of an extension call 1.07 -> 0.93 ms, the step +2.7 % (2.03 -> 2.09 x
+    // The copy of the wire batch.  While rescue batches are in flight on this device (bpsw_sw_runtime.cpp counts them) it is made
+    // and waited for BEFORE the call takes a pooled stream, on the device's copy lane (one such copy at a time): the stream is then
+    // held for the kernels only, and one bulk copy crosses PCIe at a time instead of several beside the rescue path's transfers.  configs[2]: the device phase of an extension call 1.07 -> 0.93 ms, the step +2.7 % (2.03 -> 2.09 x
     // 10^8 reads/s).  With no rescue launch about (an extension-only stream of batches moves 55 GB/s: the link's rate) the copy stays
     // on the call's own stream, where several are in flight: one at a time is 43 GB/s (3.2 instead of 4.0 x 10^8 reads/s on
     // configs[1]).  BPSW_EXT_H2D_FIRST=0 / 1: never / always.
     static const int h2d_first = getenv("BPSW_EXT_H2D_FIRST") ? atoi(getenv("BPSW_EXT_H2D_FIRST")) : -1;
     const bool copy_first = h2d_first == 1 || (h2d_first < 0 && sw_launches_in_flight(c->device) > 0);
     if (copy_first) {
+      // one bulk copy at a time per device, on a stream of the library's own (round 4 used a blocking hipMemcpy on the legacy default
+      // stream for the same effect: that synchronises with every BLOCKING stream of the host process -- torch's, another native
+      // library's -- and busy-waits; here the waiting thread sleeps, and nobody else's stream is involved)
       const double t_c0 = wall_ms();
-      HIP_TRY(hipMemcpy(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice));
+      CopyLane& L = copy_lane(c->device);
+      // BPSW_EXT_COPY_WAIT: 0 (default) the runtime's own wait for the lane's stream, under the lane's lock -- what a blocking hipMemcpy
+      // does, without the legacy stream; 1 the lock covers the enqueue only and every caller sleeps / polls on an event of its own
+      // (wait_event): a fifth less CPU per extension call, but the wake-up comes late -- 1.2-1.4 ms per call's device phase instead of
+      // 0.9, the bench step 5-10 % slower with 32, 40 or 48 threads.
+      static const int copy_wait = getenv("BPSW_EXT_COPY_WAIT") ? atoi(getenv("BPSW_EXT_COPY_WAIT")) : 0;
+      if (copy_wait == 0) {
+        std::lock_guard<std::mutex> lk(L.mu);
+        if (!L.s) HIP_TRY(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+        HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, L.s));
+        HIP_TRY(hipStreamSynchronize(L.s));
+      } else {
+        {
+          std::lock_guard<std::mutex> lk(L.mu);
+          if (!L.s) HIP_TRY(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+          HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, L.s));
+          HIP_TRY(hipEventRecord(c->ev[3], L.s));
+        }
+        HIP_TRY(wait_event(c, c->ev[3], 3));
+      }
       copy_first_ms = wall_ms() - t_c0;  // (booked as the call's H2D time below)
     }
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
@@ -772,14 +797,16 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     if (!kernel_is_last) HIP_TRY(hipEventRecord(c->ev[3], s));
     HIP_TRY(wait_event(c, kernel_is_last ? c->ev[2] : c->ev[3], 0));  // the last operation of the call on this stream
     if (lazy_full && *(volatile int*)((char*)c->h_stage_out.ptr + out_bytes) > 0) {  // the short kernel left a list: the full kernel, now
+      // (events of its own: the call's kernel time is the first launches' span plus this one's, not the host's round trip in between)
       KernelEvents kev;
-      kev.stop = c->ev[2];
+      kev.start = c->ev[4]; kev.stop = c->ev[5];
+      relaunched = true;
       const int listed = *(volatile int*)((char*)c->h_stage_out.ptr + out_bytes);
       HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, listed, k_out, c_sc_full, mq, mr, c->num_cu, (int*)((char*)c->d_pre.ptr + 128), nullptr, s,
                                 nullptr, false, kev, false, (int*)((char*)c->d_wire.ptr + list_off)));
       if (!zc_out) HIP_TRY(hipMemcpyAsync(c->h_stage_out.ptr, c->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s));
       if (!kernel_is_last) HIP_TRY(hipEventRecord(c->ev[3], s));
-      HIP_TRY(wait_event(c, kernel_is_last ? c->ev[2] : c->ev[3], 0));
+      HIP_TRY(wait_event(c, kernel_is_last ? c->ev[5] : c->ev[3], 0));
       c->stats.ext_full_relaunches++;
     }
     t_dev1 = wall_ms();
@@ -801,7 +828,8 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   float a = 0, b = 0, d = 0;
   (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-  if (!kernel_was_last) (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
+  if (relaunched) { float b2 = 0; (void)hipEventElapsedTime(&b2, c->ev[4], c->ev[5]); b += b2; }
+  if (!kernel_was_last) (void)hipEventElapsedTime(&d, relaunched ? c->ev[5] : c->ev[2], c->ev[3]);
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n; c->stats.ext_wire_bytes += wire_bytes;
   c->stats.ext_h2d_ms += a + copy_first_ms; c->stats.ext_kernel_ms += b; c->stats.ext_d2h_ms += d;
   c->stats.ext_host_in_ms += t_staged - t_in; c->stats.ext_dev_ms += t_dev1 - t_dev0 + copy_first_ms; c->stats.ext_host_out_ms += t_out - t_dev1;
