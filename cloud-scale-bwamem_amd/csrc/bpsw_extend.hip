@@ -15,9 +15,10 @@
 // band trimming loops (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
 // Before any DP a flank goes through the exact shortcuts (closed forms, certificates: bpsw_extend_core.h), which resolve most
 // flanks of low-error reads -- for large batches of short flanks in a kernel of their own in front of this one (bpsw_extend_sift.hip:
-// one task per lane), which leaves a flag and a verdict per side here (sift_flag, sift_recs).  Three builds (ext_kernel<COORD, SHORT>): two 48-VGPR ones at eight waves per SIMD for flanks up to
-// 127 / 255 bases, and the full one (slot sweeps for wide-band retries, an LDS-row sweep for flanks above 255 bases) for what
-// the host lists or the short build defers.
+// one task per lane), which leaves a flag and a verdict per side here (sift_flag, sift_recs).  Three builds (ext_kernel<COORD, SHORT>): SHORT = 1, the 64-VGPR short kernel at eight waves per SIMD for flanks up to 255 bases
+// (the adaptive sweep of bpsw_extend_rows.h; a band that outgrows its 128-column window defers the task to a list); SHORT = 2, the same
+// for batches with many flanks of 128-255 bases, sweeping such a band itself with the slot sweep instead of deferring; SHORT = 0, the
+// full kernel (slot sweeps, an LDS-row sweep for flanks above 255 bases) for what the host lists or the short build defers.
 #include <stdlib.h>
 
 #include <atomic>
@@ -368,7 +369,7 @@ __global__ void ext_prepass_kernel(const uint32_t* __restrict__ wire, const unsi
     if (oIns < 0 || eIns < 1 || oDel < 0 || eDel < 1) err = 2;  // the prefix-scan form of F needs oIns >= 0; e = 0 divides by zero in SWUtil.scala:110-115
     if ((int8_t)((wire[1] >> 16) & 0xff) < 0) err = 2;         // band width is a signed byte
     if ((wire[1] >> 24) != 0) err = 5;                          // header byte 7: a coordinate batch (format 2) goes through bpsw_extend_batch
-    pre->reserved = oIns + eIns > 0 ? 1 : 0;                    // quad-task kernels are usable
+    pre->reserved = oIns + eIns > 0 ? 1 : 0;                    // the register sweeps are usable (their prefix-scan form of F needs a positive gap cost)
   }
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {
     const uint32_t* rec = wire + 8 + 8 * (size_t)t;

@@ -229,7 +229,7 @@ __device__ __forceinline__ bool zdrop_stop(const int k, const int X, const int e
 }
 
 // The wave-uniform state of a call in flight, handed from the slot sweep (sw_extend_reg) to the sliding sweep
-// (sw_extend_il2<true>) together with the (H,E) row in LDS: see sw_extend_reg_any.
+// (sw_extend_leanS) together with the (H,E) row in LDS: see sw_extend_reg_any.
 struct ExtCarry {
   int handed;  // 1: the slot sweep stopped before row `row` and left the state here and in eh[]
   int mx, max_i, max_j, max_ie, gscore, max_off, beg, end, h1raw, row;
@@ -340,7 +340,7 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
       int hsh = wave_shr1(hl_prev, H);                             // H(i,j-1)
       if (S > 1) hl_prev = __builtin_amdgcn_readlane(H, 63);
       hsh = rel == 0u ? h1 : hsh;                                  // eh[beg].h = h1, SWUtil.scala:153
-      if (S == 1) {  // one slot: every lane is written (columns outside the band are never read before the band rewrites them, see sw_extend_il2)
+      if (S == 1) {  // one slot: every lane is written (columns outside the band are never read before the band rewrites them, see sw_extend_lean2)
         Hs[s] = hsh;
         Es[s] = En;
       } else {
@@ -427,217 +427,6 @@ __device__ ExtRes sw_extend_reg(const int lane, const int qLen, const int tLen, 
   return r;
 }
 
-// The same row sweep for 64 <= qLen <= 127 with the columns INTERLEAVED: lane l holds columns 2l and 2l+1.  sw_extend_reg<2>
-// sweeps the two 64-column slots one after the other -- two dual scans, the carries of the first slot handed to the second
-// through v_readlane, two cross-lane shifts for H(i,j-1); here the lane folds its two columns first, so a row needs ONE dual
-// scan (the exclusive prefix of the odd column is max(prefix of the lane, the even column's term)), H(i,j-1) of the odd
-// column is the even column of the same lane, and only the even column's comes from lane l-1.  About a third fewer
-// instructions per row than the two-slot sweep, and these rows are three quarters of what the DP still costs on 2x150 bp reads.
-// The control (band, last arg-max, trimming, z-drop) is the one of sw_extend_reg, on bit masks of the even and the odd
-// columns.
-#ifndef BPSW_EXT_INTERLEAVE
-#define BPSW_EXT_INTERLEAVE 1
-#endif
-// SLIDE = true: the same sweep over a WINDOW of 128 columns that follows the band, for flanks of any length.  The band of a
-// row -- the columns with a positive score around the best cell -- is 44 columns wide on average and at most 127 for 99.7 % of
-// the rows of 2x250 bp reads at 8 % / 2 % error, however long the flank; the slot sweep (sw_extend_reg<3>, <4>) pays for its
-// three or four slots mostly in scalar control (measured: 93 VALU + 171 SALU instructions per row for three slots, 96 + 210
-// for four, against 94 + 53 here).  Lane l holds columns base + 2l and base + 2l + 1; the per-lane constants of the prefix
-// scan depend only on the column's position in the window (F(i,j) = max_k (a(k) + k e - oe) - (j-1) e is invariant under a
-// shift of the origin); when the band's right end leaves the window, the window moves up to the band's left end: the (H,E)
-// state shifts down by (new base - base) / 2 lanes (ds_bpermute), the profile of the new columns is reloaded.  Columns that
-// enter the window are never read before they are written (SWUtil.scala:174-175 writes eh[end] before the band can grow over
-// it).  A row whose band does not fit 128 columns ends the sweep with *overflow = 1: the caller runs the call again on the slot
-// sweep.  `in`: continue a call the slot sweep started (its first rows did not fit), state in eh[] and *in.
-template <bool SLIDE, class QC>
-__device__ ExtRes sw_extend_il2(const int lane, const int qLen, const int tLen, const QC& qcode,
-                                const uint8_t* __restrict__ ts, const MatRows& mat, const int oDel,
-                                const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
-                                const int zmode, const int h0, const int amax, const int2* __restrict__ eh = nullptr,
-                                const ExtCarry* __restrict__ in = nullptr, int* __restrict__ overflow = nullptr) {
-  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
-  // register budget (the kernel is compiled for five waves per SIMD): the N-row scores of both columns share a register,
-  // and (j-1)*eIns, j*eIns - oeIns of both columns derive from one per-lane value
-  int Hs[2], Es[2], plo[2], phi2 = 0;
-  int base = (SLIDE && in) ? (max(in->beg, in->row - w) & ~1) : 0;  // first column of the window (even)
-  const auto load_profile = [&]() {
-    phi2 = 0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int j = base + 2 * lane + s;
-      const int code = j < qLen ? qcode(j) : 4;
-      const int sh = 8 * code;
-      plo[s] = (int)(((mat.row[0] >> sh) & 0xff) | (((mat.row[1] >> sh) & 0xff) << 8) | (((mat.row[2] >> sh) & 0xff) << 16) |
-                     (((mat.row[3] >> sh) & 0xff) << 24));
-      phi2 |= (int)((mat.row[4] >> sh) & 0xff) << (8 * s);
-    }
-  };
-  load_profile();
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int j = base + 2 * lane + s;
-    if (SLIDE && in) {
-      const int2 v = j <= qLen ? eh[j] : make_int2(0, 0);
-      Hs[s] = v.x;
-      Es[s] = v.y;
-    } else {
-      Hs[s] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
-      Es[s] = 0;
-    }
-  }
-  const int jE0 = 2 * lane * eIns - oeIns;  // j*eIns - oeIns of the even column, j counted from the window's origin; the odd one adds eIns
-  const int kC = oeIns - eIns;              // (j-1)*eIns = (j*eIns - oeIns) + kC
-  const bool cont = SLIDE && in;
-  int mx = vu(cont ? in->mx : h0), max_i = vu(cont ? in->max_i : -1), max_j = vu(cont ? in->max_j : -1);
-  int max_ie = vu(cont ? in->max_ie : -1), gscore = vu(cont ? in->gscore : -1), max_off = vu(cont ? in->max_off : 0);
-  // The band's right end lives in a vector register between rows and in a scalar register within a row.  It is wave-uniform by
-  // construction (ballots, scalar bit scans), but the compiler takes the loop-carried value for divergent and then computes the
-  // clamp, the span and every test that hangs on it with vector instructions -- on the pipe that is full.
-  int beg = vu(cont ? in->beg : 0), end_v = SLIDE ? vu(cont ? in->end : qLen) : (cont ? in->end : qLen);
-  int h1raw = vu(cont ? in->h1raw : h0 - oDel);
-  const int i0 = cont ? in->row : 0;
-  int iv = vu(i0);
-
-  const int i_tail = amax > 0 ? qLen : 0x7fffffff;  // first row the tail bound applies to (one scalar compare per row)
-  for (int i = i0; i < tLen; ++i, iv += 1) {
-    if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
-      const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
-      if (SLIDE ? any_lane(U <= mx && U < gscore) : (U <= mx && U < gscore)) break;
-    }
-    const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base: one LDS byte, the same in every lane
-    const bool isN = tsv == 32;  // wave-uniform: an N row takes a scalar branch instead of two selects per column on every row
-    h1raw -= eDel;
-    const int h1 = max(0, h1raw);      // SWUtil.scala:137-138
-    beg = max(beg, iv - w);            // SWUtil.scala:140-142
-    int end;  // = min(end, iv + w + 1, qLen)
-    if (SLIDE) {  // (the sliding sweep keeps the plain form: with the scalar form below its row costs 28 scalar instructions more)
-      end = min(min(end_v, iv + (w + 1)), qLen);
-    } else {      // on the scalar pipe: a C expression of these scalars is still selected as v_min3_i32
-      asm("s_min_i32 %0, %1, %2\n\ts_min_i32 %0, %0, %3" : "=&s"(end) : "s"(__builtin_amdgcn_readfirstlane(end_v)), "s"(iv + (w + 1)), "s"(qLen) : "scc");
-    }
-    if (SLIDE && any_lane(end - base > 127)) {  // column `end` (written this row) lies beyond the window: move the window up
-      const int nb = __builtin_amdgcn_readfirstlane(beg) & ~1;
-      if (__builtin_amdgcn_readfirstlane(end) - nb > 127) {  // a band wider than the window: not for this sweep
-        *overflow = 1;
-        return ExtRes{0, 0, 0, 0, 0, 0};
-      }
-      const int from = (lane + ((nb - base) >> 1)) << 2;  // byte address of the source lane; lanes past 63 wrap and fetch
-#pragma unroll                                            // columns the band has not reached yet (never read before written)
-      for (int s = 0; s < 2; ++s) {
-        Hs[s] = __builtin_amdgcn_ds_bpermute(from, Hs[s]);
-        Es[s] = __builtin_amdgcn_ds_bpermute(from, Es[s]);
-      }
-      base = nb;
-      load_profile();
-    }
-    const int rbeg = beg - base;       // the band in window coordinates
-    const int span = end - beg;
-    const unsigned spanA = (unsigned)max(span, 0);
-
-    bool act[2];
-    unsigned rel[2];
-    int a[2], Pg[2], akey[2], scv[2];
-    if (isN) {
-      scv[0] = __builtin_amdgcn_sbfe(phi2, 0u, 8u);
-      scv[1] = __builtin_amdgcn_sbfe(phi2, 8u, 8u);
-    } else {
-      scv[0] = __builtin_amdgcn_sbfe(plo[0], (unsigned)tsv, 8u);
-      scv[1] = __builtin_amdgcn_sbfe(plo[1], (unsigned)tsv, 8u);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      rel[s] = (unsigned)(2 * lane + s - rbeg);
-      act[s] = rel[s] < spanA;
-      const int sc = scv[s];
-      const int araw = max(Hs[s] + sc, Es[s]);  // >= 0: E never goes below 0
-      a[s] = act[s] ? araw : NEG_A;
-      akey[s] = (a[s] << 7) | (2 * lane + s);  // the row maximum and its LAST column in one scan (NEG_A << 7 stays far below 0)
-      Pg[s] = a[s] + jE0 + s * eIns;
-    }
-    int Pl = max(Pg[0], Pg[1]);   // the lane's two columns folded
-    int scan_a = max(akey[0], akey[1]);
-    dual_scan_max(Pl, scan_a);
-    const int Pprev = wave_shr1(NEG, Pl);  // prefix over the columns of the lanes below
-    const int Fe = Pprev - kC - jE0;                         // F(i,j) = Pex - (j-1)*eIns for the even column,
-    const int Fo = max(Pprev, Pg[0]) - kC - jE0 - eIns;      // and for the odd one
-    const int Fs[2] = {Fe, Fo};
-    int H[2], En[2];
-    unsigned long long zm[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      H[s] = max3i(a[s], Fs[s], 0);
-      zm[s] = __builtin_amdgcn_ballot_w64(H[s] < 1) & __builtin_amdgcn_ballot_w64(act[s]);  // H >= 0: the zero cells of the band
-      En[s] = act[s] ? max3i(Es[s] - eDel, H[s] - oeDel, 0) : 0;  // E(i+1,j); eh[end].e = 0
-    }
-    int hsh[2] = {wave_shr1(h1, H[1]), H[0]};  // H(i,j-1)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      hsh[s] = rel[s] == 0u ? h1 : hsh[s];  // eh[beg].h = h1, SWUtil.scala:153
-      // Written in EVERY lane, not only for the columns beg..end the reference writes: a column outside the band is never read
-      // again before the band has written it -- beg never decreases, and a column that enters on the right was eh[end] of the row
-      // before (SWUtil.scala:174-175, 202-214: the new end is at most the old end + 1) -- so what the other lanes hold is free.
-      Hs[s] = hsh[s];
-      Es[s] = En[s];
-    }
-    const int mkey = max(0, __builtin_amdgcn_readlane(scan_a, 63));  // scalar
-    const int m = mkey >> 7;
-
-    // SWUtil.scala:177-182: j after the column loop is end (or beg for an empty band); h1 there is eh[end].h
-    if (SLIDE ? any_lane((span > 0 ? end : beg) == qLen) : (span > 0 ? end : beg) == qLen) {
-      int hlast = h1;
-      if (SLIDE ? any_lane(span > 0) : span > 0) {
-        const int e = __builtin_amdgcn_readfirstlane(end) - __builtin_amdgcn_readfirstlane(base);
-        const int he = __builtin_amdgcn_readlane(Hs[0], e >> 1), ho = __builtin_amdgcn_readlane(Hs[1], e >> 1);
-        hlast = (e & 1) ? ho : he;
-      }
-      const bool better = gscore <= hlast;
-      max_ie = better ? iv : max_ie;
-      gscore = better ? hlast : gscore;
-    }
-    if (m == 0) break;  // SWUtil.scala:184-185
-
-    const int mjr = mkey & 127;    // the LAST column whose a == m (SWUtil.scala:158-161), in window coordinates
-    const int mj = base + mjr;
-    const bool improved = m > mx;
-    if (!any_lane(improved) && zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
-      if (any_lane(zdrop_stop((iv - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode))) break;
-    }
-    {  // SWUtil.scala:187-193
-      const int d = mj - iv;
-      const int off = max3i(max_off, d, -d);
-      mx = improved ? m : mx;
-      max_i = improved ? iv : max_i;
-      max_j = improved ? mj : max_j;
-      max_off = improved ? off : max_off;
-    }
-    // band trimming, SWUtil.scala:202-214: last zero of H left of mj, first zero right of mj
-    const int nb0 = beg + (h1 == 0 ? 1 : 0);
-    if ((zm[0] | zm[1]) == 0ull) {  // no zero in the band at all -- most rows while the score is high
-      beg = nb0;
-      end = end + 1;
-    } else {
-      const int ze_l = s_lead_zeros(zm[0] & s_below_mask((mjr + 1) >> 1));  // even columns 2l < mj
-      const int zo_l = s_lead_zeros(zm[1] & s_below_mask(mjr >> 1));        // odd columns 2l+1 < mj
-      const int cl = max(ze_l >= 0 ? 2 * (63 - ze_l) : -1, zo_l >= 0 ? 2 * (63 - zo_l) + 1 : -1);
-      const int se = (mjr + 2) >> 1, so = (mjr + 1) >> 1;                   // first even / odd lane with a column > mj
-      const int fe = s_first_one((zm[0] >> ((mjr + 1) >> 1)) >> ((mjr + 1) & 1));
-      const int fo = s_first_one(zm[1] >> so);
-      const int cr = min(fe >= 0 ? 2 * (se + fe) : 1 << 20, fo >= 0 ? 2 * (so + fo) + 1 : 1 << 20);
-      beg = cl >= 0 ? vu(base + cl + 2) : nb0;
-      end = cr < (1 << 20) ? vu(base + cr + 1) : end + 1;
-    }
-    if (SLIDE) end_v = end;
-    else asm volatile("v_mov_b32 %0, %1" : "=v"(end_v) : "s"(end));
-  }
-  ExtRes r;
-  r.max = __builtin_amdgcn_readfirstlane(mx);
-  r.qle = __builtin_amdgcn_readfirstlane(max_j) + 1;
-  r.tle = __builtin_amdgcn_readfirstlane(max_i) + 1;
-  r.gtle = __builtin_amdgcn_readfirstlane(max_ie) + 1;
-  r.gscore = __builtin_amdgcn_readfirstlane(gscore);
-  r.max_off = __builtin_amdgcn_readfirstlane(max_off);
-  return r;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Closed form for near-exact flanks.  Let a = the match score (every other matrix entry < a), s_j = S(t_j, q_j) the score
@@ -932,18 +721,29 @@ struct LdsShiftT {  // a target already staged as 8*code bytes
   __device__ __forceinline__ int operator()(int i) const { return (int)(ts[i] >> 3); }
 };
 
-#ifndef BPSW_EXT_LEAN
-#define BPSW_EXT_LEAN 1  // 0: the sweeps of round 1 / early round 2 (sw_extend_reg<1>, sw_extend_il2) everywhere
-#endif
-// ---- the two-columns-per-lane sweep once more, written for its instruction count ---------------------------------------------
+// ---- the two-columns-per-lane sweeps ----------------------------------------------------------------------------------------
+// 64 <= qLen <= 127 with the columns INTERLEAVED: lane l holds columns 2l and 2l+1.  The lane folds its two columns first, so a row
+// needs ONE dual scan (the exclusive prefix of the odd column is max(prefix of the lane, the even column's term)), H(i,j-1) of the
+// odd column is the even column of the same lane, and only the even column's comes from lane l-1.  The control (band, last arg-max,
+// trimming, z-drop) works on bit masks of the even and the odd columns.  Every lane's (H,E) is WRITTEN every row, inside the band or
+// not: a column outside the band is never read before the band has rewritten it (SWUtil.scala:174-175 writes eh[end] before the band
+// can grow over it) -- which is also why a column that enters a sliding window needs no initial value.
+// The sliding form (sw_extend_leanS): the same sweep over a WINDOW of 128 columns that follows the band, for flanks of any length.
+// The band of a row is 44 columns wide on average and at most 127 for 99.7 % of the rows of 2x250 bp reads at 8 % / 2 % error, however
+// long the flank.  Lane l holds columns base + 2l and base + 2l + 1; the per-lane constants of the prefix scan depend only on the
+// column's position in the window (F(i,j) = max_k (a(k) + k e - oe) - (j-1) e is invariant under a shift of the origin); when the
+// band's right end leaves the window, the window moves up to the band's left end: the (H,E) state shifts down by (new base - base) / 2
+// lanes (ds_bpermute), the profile of the new columns is reloaded.  A row whose band does not fit 128 columns ends the sweep with
+// *overflow = 1: the caller runs the call on the slot sweep.  `in`: continue a call the slot sweep started, state in eh[] and *in.
+// ---- written for their instruction count ---------------------------------------------
 // A SIMD issues about one instruction per 2.6 cycles whatever pipe it goes to: a row costs what its vector AND
 // scalar AND branch instructions add up to.  sw_extend_il2 spends 69 scalar instructions and 15 branches per row on a control
 // flow the compiler derives from nested breaks and from conditions it cannot prove uniform (boolean phis materialised as
 // s_cselect_b64 / s_and_b64 exec pairs, v_cmp + s_cmp for a compare of two scalars).  Here every loop-carried scalar is pinned to a
 // scalar register (see smax2 / smin2 below for what was dragging them onto the vector pipe), every
 // break sits at the top level of the loop body, and the rare parts (N rows, the rows past the query end, z-drop) are out of line.
-// Same arithmetic, same order of evaluation as sw_extend_il2<false> (which stays, for the sliding sweep and as the reference the
-// tests compare this one with: BPSW_EXT_LEAN=0 at build time).
+// (Rounds 1-2 had an earlier form of this sweep, sw_extend_il2, built in by -DBPSW_EXT_LEAN=0 as the reference these were compared with;
+// it was removed in round 5: rows_cpp in bpsw_extend_rows.h is the C++ reference of the assembly rows, the oracle is everybody's.)
 // min / max of two SCALARS whose result stays scalar: the DAG combiner folds max(max(a, b), c) into a three-operand node that exists
 // only as a vector instruction (v_max3_i32), and the vector result then drags every user -- the band ends, the whole row control --
 // onto the vector pipe.  The readfirstlane hides the inner result from that combine and folds away when its operand is scalar.
@@ -1012,7 +812,7 @@ __device__ ExtRes sw_extend_lean2(const int lane, const int qLen, const int tLen
     const int En0 = act0 ? max3i(Es[0] - eDel, H0 - oeDel, 0) : 0;
     const int En1 = act1 ? max3i(Es[1] - eDel, H1 - oeDel, 0) : 0;
     const int hs0 = wave_shr1(h1, H1), hs1 = H0;  // H(i,j-1)
-    Hs[0] = rel0 == 0u ? h1 : hs0;               // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_il2)
+    Hs[0] = rel0 == 0u ? h1 : hs0;               // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_lean2)
     Hs[1] = rel1 == 0u ? h1 : hs1;
     Es[0] = En0;
     Es[1] = En1;
@@ -1062,7 +862,7 @@ __device__ ExtRes sw_extend_lean2(const int lane, const int qLen, const int tLen
   return r;
 }
 
-// The sliding 128-column window (sw_extend_il2<true>: flanks of any length, continuation of a call the slot sweep started) in the
+// The sliding 128-column window (sw_extend_leanS: flanks of any length, continuation of a call the slot sweep started) in the
 // same style.  `in` / `eh` / `overflow` as there.
 template <class QC>
 __device__ ExtRes sw_extend_leanS(const int lane, const int qLen, const int tLen, const QC& qcode,
@@ -1162,7 +962,7 @@ __device__ ExtRes sw_extend_leanS(const int lane, const int qLen, const int tLen
     const int En0 = act0 ? max3i(Es[0] - eDel, H0 - oeDel, 0) : 0;
     const int En1 = act1 ? max3i(Es[1] - eDel, H1 - oeDel, 0) : 0;
     const int hs0 = wave_shr1(h1, H1), hs1 = H0;  // H(i,j-1)
-    Hs[0] = rel0 == 0u ? h1 : hs0;               // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_il2)
+    Hs[0] = rel0 == 0u ? h1 : hs0;               // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_lean2)
     Hs[1] = rel1 == 0u ? h1 : hs1;
     Es[0] = En0;
     Es[1] = En1;
@@ -1264,7 +1064,7 @@ __device__ ExtRes sw_extend_lean1(const int lane, const int qLen, const int tLen
     const unsigned long long z = __builtin_amdgcn_ballot_w64(H < 1) & __builtin_amdgcn_ballot_w64(act);
     const int En = act ? max3i(Es - eDel, H - oeDel, 0) : 0;
     const int hs = wave_shr1(h1, H);  // H(i,j-1)
-    Hs = rel == 0u ? h1 : hs;         // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_il2)
+    Hs = rel == 0u ? h1 : hs;         // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_lean2)
     Es = En;
     const int mkey = smax2(0, __builtin_amdgcn_readlane(scan_a, 63));
     const int m = mkey >> 7, mj = mkey & 127;
@@ -1303,7 +1103,7 @@ __device__ ExtRes sw_extend_lean1(const int lane, const int qLen, const int tLen
 }
 
 // SWExtend on the register path for any qLen <= 255.  Up to 63 columns: one column per lane; up to 127: two per lane; longer
-// flanks: the sliding 128-column window (sw_extend_il2<true>), started by the slot sweep when the first rows are wider than the
+// flanks: the sliding 128-column window (sw_extend_leanS), started by the slot sweep when the first rows are wider than the
 // window (eh: LDS row for the hand-over, qLen + 2 pairs; without it such calls stay on the slot sweep), and run again on the
 // slot sweep in the rare case that a later row outgrows the window.  BPSW_EXT_SLIDE=0 at compile time: slot sweep only.
 #ifndef BPSW_EXT_SLIDE
@@ -1316,26 +1116,14 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
                                                     const int zdrop, const int zmode, const int h0, const int amax,
                                                     int2* __restrict__ eh = nullptr) {
   const int slots = (qLen + 64) >> 6;
-#if BPSW_EXT_LEAN
   if (slots == 1) return sw_extend_lean1(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
   if (slots == 2) return sw_extend_lean2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#endif
-  if (slots == 1) return sw_extend_reg<1>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#if BPSW_EXT_INTERLEAVE
-  if (slots == 2) return sw_extend_il2<false>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#else
-  if (slots == 2) return sw_extend_reg<2>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#endif
 #if BPSW_EXT_SLIDE
   {
     int overflow = 0;
     ExtRes r;
     if (min(qLen, w + 1) <= 127) {  // row 0's band [0, min(qLen, w+1)] fits the window
-#if BPSW_EXT_LEAN
       r = sw_extend_leanS(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, nullptr, nullptr, &overflow);
-#else
-      r = sw_extend_il2<true>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, nullptr, nullptr, &overflow);
-#endif
       if (!overflow) return r;
     } else if (eh) {
       ExtCarry c;
@@ -1343,11 +1131,7 @@ __device__ __forceinline__ ExtRes sw_extend_reg_any(const int lane, const int qL
       r = slots == 3 ? sw_extend_reg<3>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c)
                      : sw_extend_reg<4>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c);
       if (!c.handed) return r;
-#if BPSW_EXT_LEAN
       r = sw_extend_leanS(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c, &overflow);
-#else
-      r = sw_extend_il2<true>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, eh, &c, &overflow);
-#endif
       if (!overflow) return r;
     }
   }
@@ -1366,7 +1150,6 @@ __device__ __forceinline__ ExtRes sw_extend_reg_short(const int lane, const int 
                                                       const int eDel, const int oIns, const int eIns, const int w,
                                                       const int zdrop, const int zmode, const int h0, const int amax,
                                                       int* __restrict__ overflow) {
-#if BPSW_EXT_LEAN
   if (qLen < 64) return sw_extend_lean1(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
   if (!WINDOW || qLen < 128) return sw_extend_lean2(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
   // longer flanks (the WINDOW build of the kernel admits them up to 255 bases): the sliding window, when row 0's band
@@ -1376,15 +1159,6 @@ __device__ __forceinline__ ExtRes sw_extend_reg_short(const int lane, const int 
     return ExtRes{0, 0, 0, 0, 0, 0};
   }
   return sw_extend_leanS(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, nullptr, nullptr, overflow);
-#else
-  if (qLen < 64) return sw_extend_reg<1>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-  if (qLen >= 128) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
-#if BPSW_EXT_INTERLEAVE
-  return sw_extend_il2<false>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#else
-  return sw_extend_reg<2>(lane, qLen, tLen, qcode, ts, mat, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
-#endif
-#endif
 }
 
 // Wave-level dequeue: lane 0 alone performs one returning atomic add, the result is broadcast.  Written as

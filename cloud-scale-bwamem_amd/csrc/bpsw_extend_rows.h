@@ -8,7 +8,7 @@
 //     positive cells around the best one -- fits 64 columns for three rows in four even of 2x250 bp reads at 8 % / 2 % error.  So the
 //     sweep keeps the (H,E) row in a 64-column window with ONE column per lane while the band fits, switches to a 128-column
 //     window with two columns per lane while it does not, and back (ds_bpermute moves the state between the layouts; a column that
-//     enters a window is never read before the band has written it, see sw_extend_il2).
+//     enters a window is never read before the band has written it, see sw_extend_lean2).
 //   * Half of a row's instructions were scalar control that the compiler builds around a loop with four exits (boolean flags in
 //     SGPR pairs, s_and_b64 vcc / exec before every uniform branch, re-materialised constants).  The one-column loop -- the one that
 //     serves most rows -- is written in GCN assembly here (rows1_asm): every rare case (an N row, a window that has to move, an
@@ -154,7 +154,7 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
     const int En1 = act1 ? max3i(Es1 - eDel, H1 - oeDel, 0) : 0;
     if (COLS == 2) {
       const int hs0 = wave_shr1(h1, H1);  // H(i,j-1)
-      Hs0 = rel0 == 0u ? h1 : hs0;       // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_il2)
+      Hs0 = rel0 == 0u ? h1 : hs0;       // eh[beg].h = h1, SWUtil.scala:153 (written in every lane: see sw_extend_lean2)
       Hs1 = rel1 == 0u ? h1 : H0;
       Es1 = En1;
     } else {

@@ -5,14 +5,17 @@
 // a reverse pass over the reversed prefixes that yields (tBeg, qBeg).  Bit-exact with the Scala text,
 // including the true-DP second best (the SSE2 C differs there).
 //
-// How: one job per 64-lane wavefront, DP state entirely in registers.  The band is static, so the
-// row dependency can be skewed: lane l owns the C consecutive query columns [l*C, l*C+C) and at
-// step t works on target row t-l (a systolic anti-diagonal).  Everything a cell needs from its left
-// neighbour -- F(i,j), the diagonal H(i-1,j-1), the running row maximum and the row's target base --
-// arrives with one DPP wave_shr:1 from the previous step, so there is no in-row scan and no LDS
-// traffic in the inner loop (LDS only holds a 2 KB window of target bases).  Row i leaves the pipe at
-// lane (qLen-1)/C as key = H_max<<10 | (1023 - first argmax); the sequential per-row bookkeeping of
-// SWUtil.scala:517-538 runs on the scalar unit.
+// How.  The band is static, so the row dependency can be skewed: lane l owns C consecutive query columns and at step t works on
+// target row t - l (a systolic anti-diagonal); everything a cell needs from its left neighbour -- F(i,j), the diagonal H(i-1,j-1), the
+// running row key and the row's target selector -- arrives with one DPP wave_shr:1 from the previous step: no in-row scan, no LDS
+// traffic in the inner loop.  Three forms of it live here:
+//   * swp_kernel<C> / swp_resident_kernel<C> (what runs): TWO jobs per wavefront, one in each 16-bit half of every DP register
+//     (v_pk_*_u16; exact because a pass stops at the 255 score cap), the query right-aligned, the row keys booked by the lanes
+//     behind the last column eight rows at a time, the second best rebuilt from the stored row maxima (see "Packed form" below).
+//     The resident kernel is the same job pair taken from the device's submission ring (bpsw_ring.h) instead of one launch's table.
+//   * sw_kernel<C>: one job per wavefront in int32, the per-row bookkeeping of SWUtil.scala:517-538 on the scalar unit -- for
+//     scorings the packed form cannot take (max(mat) > |b| + 1, scores beyond a byte) and mates above 256 bases.
+//   * sw4_kernel: four jobs per wavefront (one per 16-lane DPP row, ten columns per lane) in int32, for such scorings in large batches.
 #include <stdlib.h>
 
 #include "bpsw_internal.h"
