@@ -46,7 +46,7 @@ PAIRS_PER_GROUP = int(os.environ.get("BENCH_GROUP_PAIRS", "4096"))   # boundary-
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT_VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9   # MI355X_MICROARCH.md ("Terms", "Wave scheduling", cycles table): 256 CUs x 4 SIMD-32 x 2.4 GHz --
                                             # a wave64 VALU instruction issues over 2 cycles, 7.86e13 int32 lane-ops/s
-PROFILE_TAG = "r04"              # the committed rocprofv3 summaries this round's line is cross-checked against (profiles/r04_*)
+PROFILE_TAG = "r05"              # the committed rocprofv3 summaries this round's line is cross-checked against (profiles/r04_*)
 PROTOCOL = "r03b"                # what a step IS: changes whenever values stop being comparable with earlier rounds (see `protocol` in the line)
 
 # SURVEY.md 8(d) workloads, keyed by the survey's config number
@@ -564,6 +564,8 @@ def main():
         F.run(items, args.warmup * passes)
     F.reset_stats()
     barrier()
+    # (the device-wide wait in barrier() has let the open epoch of the submission ring close: the epochs of the timed region are whole ones)
+    ring0 = F.ctxs[0].ring_stats() + F.ctxs[0].ring_epoch_times()
     cpu0 = os.times()
     t0 = time.perf_counter()
     # the K steps in one go: the feeder threads go round the passes without waiting for each other, as the task threads of an
@@ -573,6 +575,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     cpu1 = os.times()
+    ring1 = F.ctxs[0].ring_stats() + F.ctxs[0].ring_epoch_times()
     cpu_busy = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / elapsed   # host CPUs busy during the timed region (this rank)
     st = F.stats_sum()
     call_ms = {"extend": [it.ms for it in items if it.kind == 0], "matesw_group": [it.ms for it in items if it.kind == 1]}
@@ -613,17 +616,55 @@ def main():
         pi = {}
     e_cnt = (pi.get("extend_per_call") or pi.get("extend")) if args.config == 3 else None
     w_cnt = pi.get("swalign2") if args.config == 3 else None
-    # The dominant kernel is the one that issues the most wave-instructions in a step (launches x per-launch counts), NOT the one
-    # with the largest summed launch duration: launches of different host threads overlap on the device, so a summed duration is
-    # latency under sharing.  Without counters for this workload: the larger summed wave-time proxy (duration x waves is not known
-    # either, so the summed duration decides, and the line says so).
+    # the committed rocprofv3 --kernel-trace --stats summary of this same command: every kernel's average duration there
+    trace_avg, trace_share = {}, {}
+    try:
+        import csv
+        # `extend`: a call's launches back to back on its stream -- the sift kernel, the short extension kernel, the full kernel (only
+        # behind a launch with listed / deferred tasks) (format-1 batches: the `false` instantiations) -- summed per call, as the library's events see them
+        ext_total_ns, ext_calls = 0.0, 0
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_stats_bench.csv"))):
+            nm = r["Name"]
+            if "ext_sift_kernel<false>" in nm or "ext_kernel<false" in nm:
+                ext_total_ns += float(r["TotalDurationNs"])
+                trace_share["extend"] = trace_share.get("extend", 0.0) + float(r["Percentage"]) * 1e-2
+                if "ext_kernel<false, 1>" in nm or "ext_kernel<false, 2>" in nm:   # the short kernel (2: the build that sweeps wide bands itself)
+                    ext_calls += int(r["Calls"])
+            elif "swp_resident_kernel" in nm and "swalign2_resident" not in trace_avg:
+                trace_avg["swalign2_resident"] = round(float(r["AverageNs"]) * 1e-6, 4)
+                trace_avg["swalign2_resident_share_of_kernel_time"] = round(float(r["Percentage"]) * 1e-2, 4)
+                trace_share["swalign2_resident"] = float(r["Percentage"]) * 1e-2
+            elif per_kernel["swalign2"][3] in nm and "swalign2" not in trace_avg:
+                trace_avg["swalign2"] = round(float(r["AverageNs"]) * 1e-6, 4)
+                trace_share["swalign2"] = float(r["Percentage"]) * 1e-2
+        if ext_calls:
+            trace_avg["extend"] = round(ext_total_ns / ext_calls * 1e-6, 4)
+    except Exception:
+        trace_avg, trace_share = {}, {}
+    # The dominant kernel: the one with the largest share of summed kernel time in the committed kernel trace of this command
+    # (profiles/<tag>_kernel_stats_bench.csv) -- the extension call's kernels together against the rescue path's; without a trace, the one that
+    # issues the most wave-instructions in a step (launches x the committed per-launch counts).  Both kernels' figures are in `kernels`,
+    # their fractions of the HBM peak side by side in `frac_by_kernel`.
     if e_cnt and w_cnt:
         ext_instr = ext_launches * (e_cnt["valu"] + e_cnt["salu"])
         sw_instr = sw_launches * (w_cnt["valu"] + w_cnt["salu"])
-        dominant, dominant_by = ("extend" if ext_instr >= sw_instr else "swalign2"), "issued wave-instructions (profiles/pmc_issue.json x launches)"
     else:
         ext_instr = sw_instr = None
-        dominant, dominant_by = ("extend" if st["ext_kernel_ms"] >= st["sw_kernel_ms"] else "swalign2"), "summed launch durations (no counters committed for this workload)"
+    if trace_share.get("extend") is not None and (trace_share.get("swalign2_resident") is not None or trace_share.get("swalign2") is not None):
+        sw_share = (trace_share.get("swalign2_resident") or 0.0) + (trace_share.get("swalign2") or 0.0)
+        dominant, dominant_by = ("extend" if trace_share["extend"] >= sw_share else "swalign2"), \
+            f"share of summed kernel time in profiles/{PROFILE_TAG}_kernel_stats_bench.csv (extension kernels {trace_share['extend']:.3f}, rescue kernels {sw_share:.3f})"
+    elif ext_instr is not None:
+        dominant, dominant_by = ("extend" if ext_instr >= sw_instr else "swalign2"), "issued wave-instructions (profiles/pmc_issue.json x launches)"
+    else:
+        dominant, dominant_by = ("extend" if st["ext_kernel_ms"] >= st["sw_kernel_ms"] else "swalign2"), "summed launch durations (no trace or counters committed for this workload)"
+    # The rescue batches of the timed region went through the device's submission ring (csrc/bpsw_ring.h): no launch per batch.  `swalign2`
+    # below is a BATCH -- its duration the span first job pair taken -> last one finished on the device's clock -- and `swalign2_resident` is
+    # the resident kernel that served them: launches = epochs, each timed by two HIP events around its launch on the ring's stream.
+    ring_epochs = int(ring1[4] - ring0[4])
+    ring_epoch_ms = (ring1[3] - ring0[3]) / ring_epochs if ring_epochs > 0 else 0.0
+    ring_batches = int(ring1[1] - ring0[1])
+    sw_via_ring = int(st.get("sw_ring_calls", 0))
     per_kernel = {"extend": (ext_bytes, ext_avg_ms, ext_launches, "ext_kernel"), "swalign2": (sw_bytes, sw_avg_ms, sw_launches, "swp_kernel")}
     dom_bytes, dom_ms = per_kernel[dominant][0], per_kernel[dominant][1]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -634,25 +675,6 @@ def main():
         pmc = {}
     traffic = pmc.get(dominant)
     traffic_x2 = pmc.get("detail", {}).get(dominant, {}).get("fetch_size_x2_plus_write_size")
-    # the committed rocprofv3 --kernel-trace --stats summary of this same command: every kernel's average duration there
-    trace_avg = {}
-    try:
-        import csv
-        # `extend`: a call's launches back to back on its stream -- the sift kernel, the short extension kernel, the full kernel (only
-        # behind a launch with listed / deferred tasks) (format-1 batches: the `false` instantiations) -- summed per call, as the library's events see them
-        ext_total_ns, ext_calls = 0.0, 0
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_stats_bench.csv"))):
-            nm = r["Name"]
-            if "ext_sift_kernel<false>" in nm or "ext_kernel<false" in nm:
-                ext_total_ns += float(r["TotalDurationNs"])
-                if "ext_kernel<false, 1>" in nm or "ext_kernel<false, 2>" in nm:   # the short kernel (2: the build that sweeps wide bands itself)
-                    ext_calls += int(r["Calls"])
-            elif per_kernel["swalign2"][3] in nm and "swalign2" not in trace_avg:
-                trace_avg["swalign2"] = round(float(r["AverageNs"]) * 1e-6, 4)
-        if ext_calls:
-            trace_avg["extend"] = round(ext_total_ns / ext_calls * 1e-6, 4)
-    except Exception:
-        trace_avg = {}
     step_s_all = elapsed / args.steps
     # where the dominant kernel's wave-cycles go (committed SQ counters of this command, profiles/<tag>_sq_activity.json)
     sq_activity = None
@@ -668,6 +690,18 @@ def main():
             both[k] = {"achieved_GBps": round(b / (ms * 1e-3) / 1e9, 3) if ms > 0 else 0.0, "frac_of_hbm_peak": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6) if ms > 0 else 0.0,
                        "algorithmic_bytes_per_launch": int(b), "avg_launch_ms": round(ms, 4), "avg_launch_ms_kernel_trace": trace_avg.get(k),
                        "launches_per_step": round(n_l / args.steps, 1), "traffic_per_launch": pmc.get(k)}
+    if sw_via_ring and "swalign2" in both:
+        both["swalign2"]["via"] = f"submission ring: {sw_via_ring} of {sw_launches} batches; avg_launch_ms = a batch's span on the device clock (first job pair taken -> last finished), not a launch"
+        both["swalign2"]["avg_launch_ms_kernel_trace"] = None
+    if ring_epochs > 0:
+        ep_bytes = sw_bytes * ring_batches / ring_epochs
+        both["swalign2_resident"] = {"achieved_GBps": round(ep_bytes / (ring_epoch_ms * 1e-3) / 1e9, 3), "frac_of_hbm_peak": round(ep_bytes / (ring_epoch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                                     "algorithmic_bytes_per_launch": int(ep_bytes), "avg_launch_ms": round(ring_epoch_ms, 3),
+                                     "avg_launch_ms_kernel_trace": trace_avg.get("swalign2_resident"), "launches": ring_epochs,
+                                     "batches_per_launch": round(ring_batches / ring_epochs, 1),
+                                     "share_of_kernel_time_in_trace": trace_avg.get("swalign2_resident_share_of_kernel_time"),
+                                     "note": "swp_resident_kernel: one launch per EPOCH of the device's submission ring (it ends after BPSW_RING_IDLE_US without a batch, or when its "
+                                             "16 384 descriptor slots are used up); launches and durations from HIP events around each launch on the ring's stream"}
     algo_bytes_step = (ext_bytes * ext_launches + sw_bytes * sw_launches) / args.steps
     summed_kernel_s = (st["ext_kernel_ms"] + st["sw_kernel_ms"]) * 1e-3 / args.steps
     # instruction issue: raw rate, the vector pipe's utilisation at the guide's 2 cycles per wave64 instruction, and -- labelled as
@@ -800,7 +834,8 @@ def main():
                                      "WRITE_SIZE; the second figure is the blanket 2*FETCH_SIZE + WRITE_SIZE",
                      "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                      "avg_launch_ms_kernel_trace": trace_avg.get(dominant),
-                     "kernels": both,
+                     "kernels": both, "frac_by_kernel": {k: v.get("frac_of_hbm_peak") for k, v in both.items()},
+                     "share_of_kernel_time_in_trace": {k: round(v, 4) for k, v in trace_share.items()},
                      "aggregate_GBps": round(algo_bytes_step / step_s_all / 1e9, 3),
                      "aggregate_frac_of_hbm_peak": round(algo_bytes_step / step_s_all / 1e9 / HBM_PEAK_GBPS, 6),
                      "launch_overlap": round(summed_kernel_s / step_s_all, 2),
@@ -808,8 +843,10 @@ def main():
                      "note": "launch duration = HIP events attached to the kernel's dispatch on its launch stream inside the library, averaged over "
                              "the timed region; launches of different host threads overlap on the device (launch_overlap = summed launch durations / "
                              "step time), so a launch's duration is the time it spends SHARING the GPU: aggregate_GBps = algorithmic bytes of a step / "
-                             "step time is the figure to cross-check ms_per_step with.  The rescue kernel reads its jobs (table, mates, windows) from pinned "
-                             "HOST memory over PCIe (zero-copy) and writes its results there: its bytes are PCIe reads, not HBM traffic.  The events see "
+                             "step time is the figure to cross-check ms_per_step with.  The rescue batches go through the device's submission ring (one resident "
+                             "kernel per epoch, `swalign2_resident`; `swalign2` is a batch and its duration the batch's span on the device clock): a batch is "
+                             "copied into HBM by the copy engine before its descriptor is published, the workers read HBM and write their results into the "
+                             "caller's pinned block over PCIe.  The events see "
                              "about 0.06 ms of dispatch latency per launch that a kernel trace does not.  `extend` is what an extension call launches back "
                              "to back on its stream -- the sift kernel (shortcuts, one task per lane), the short extension kernel and, only behind a launch that "
                              "deferred a task, the full kernel -- timed from the first dispatch to the end of the last; its avg_launch_ms_kernel_trace is the sum of those "

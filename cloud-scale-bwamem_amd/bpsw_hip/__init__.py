@@ -173,7 +173,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.bpsw_reset_stats.argtypes = [C.c_void_p]
     lib.bpsw_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    lib.bpsw_ring_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.bpsw_ring_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.bpsw_chain2aln_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(Chains), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.POINTER(C.c_int64)]
     lib.bpsw_ref_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -497,8 +497,14 @@ class Context:
     def ring_stats(self):
         """(epochs, submitted, carried) of the device's submission ring (include/bpsw.h: bpsw_ring_stats)"""
         e, s, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-        _chk(self.lib, self.lib.bpsw_ring_stats(self.h, C.byref(e), C.byref(s), C.byref(c)), "bpsw_ring_stats")
+        _chk(self.lib, self.lib.bpsw_ring_stats(self.h, C.byref(e), C.byref(s), C.byref(c), None, None), "bpsw_ring_stats")
         return int(e.value), int(s.value), int(c.value)
+
+    def ring_epoch_times(self):
+        """(summed duration in ms, count) of the device's ring epochs that are over: each the resident kernel's launch as a kernel trace times it"""
+        ms, n = C.c_double(0.0), C.c_uint64(0)
+        _chk(self.lib, self.lib.bpsw_ring_stats(self.h, None, None, None, C.byref(ms), C.byref(n)), "bpsw_ring_stats")
+        return float(ms.value), int(n.value)
 
     def stats(self) -> Stats:
         s = Stats()

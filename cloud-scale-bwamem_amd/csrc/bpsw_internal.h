@@ -157,7 +157,7 @@ int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, dou
 double ring_ticks_per_ms(int device, int c_class);
 void ring_pause(int device);   // close the device's open epochs, wait for their kernels, keep the rings locked ...
 void ring_resume(int device);  // ... until here (bpsw_ref_load / unload: a device-wide synchronisation in between)
-void ring_get_stats(int device, uint64_t* epochs, uint64_t* submitted, uint64_t* carried);
+void ring_get_stats(int device, uint64_t* epochs, uint64_t* submitted, uint64_t* carried, double* epochs_ms = nullptr, uint64_t* epochs_timed = nullptr);
 
 // ---- global alignment + CIGAR -------------------------------------------------
 struct GlobalJobsDev {  // all device pointers
@@ -365,6 +365,7 @@ struct CopyLane {
 };
 CopyLane& copy_lane(int device);
 double wall_ms();
+double stat_ms();  // wall_ms, or the thread CPU clock with BPSW_STATS_CLOCK=cpu (bpsw_runtime.cpp)
 // rescue launches (sw_stage_run) between their launch and the end of their wait, per device: the extension path shapes its bulk copies
 // by it (extend_batch_impl)
 int sw_launches_in_flight(int device);

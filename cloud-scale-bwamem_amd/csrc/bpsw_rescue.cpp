@@ -356,7 +356,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
   if (he != hipSuccess) return fail(BPSW_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
   { const int prc_ = finish_pending(c); if (prc_ != BPSW_OK) return prc_; }
 
-  const double t_begin = wall_ms();
+  const double t_begin = stat_ms();
   double t_pack = 0., t_replay = 0.;
   if (!c->rescue_scratch) c->rescue_scratch = new Scratch();
   Scratch& S = *(Scratch*)c->rescue_scratch;
@@ -424,7 +424,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
   }
   S.job_x.clear(); S.job_round.clear();
   S.results.clear(); S.used.clear();
-  const double t_planned = wall_ms();
+  const double t_planned = stat_ms();
 
   const int xtra_base = BPSW_KSW_XSUBO | BPSW_KSW_XSTART | (opt->min_seed_len * opt->a);  // KSW_XBYTE is ignored by SWAlign
   const size_t nt = S.touched.size();
@@ -438,7 +438,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
   for (;;) {
     // ---- 2. one flat GPU batch, packed in place in the pinned staging block ---------------------------------------------
     if (!S.want.empty()) {
-      const double t_p0 = wall_ms();
+      const double t_p0 = stat_ms();
       if (rounds > 0) {  // later rounds collect their windows out of order and possibly twice
         std::sort(S.want.begin(), S.want.end(), [](const Want& p, const Want& q) { return p.x < q.x; });
         S.want.erase(std::unique(S.want.begin(), S.want.end(), [](const Want& p, const Want& q) { return p.x == q.x; }), S.want.end());
@@ -499,7 +499,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
         memcpy(tpool + at, g->ref_pool + g->ref_off[w.x], (size_t)len);
         at += align16((size_t)len);
       }
-      const double t_p1 = wall_ms();
+      const double t_p1 = stat_ms();
       const int32_t* res = nullptr;
       rc = sw_stage_run(c, opt, xtra_base, st, mq, mt, GR.pac_mode, &res);
       if (rc != BPSW_OK) return rc;
@@ -512,7 +512,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       t_pack += t_p1 - t_p0;
     }
     // ---- 3. replay the pairs that had a job ------------------------------------------------------------------------
-    const double t_r0 = wall_ms();
+    const double t_r0 = stat_ms();
     for (size_t ti = 0; ti < nt; ++ti) {
       if (S.done[ti]) continue;
       const int k = S.touched[ti];
@@ -525,7 +525,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       S.done[ti] = 1;
       ++n_done;
     }
-    t_replay += wall_ms() - t_r0;
+    t_replay += stat_ms() - t_r0;
     if (n_done == nt) break;
     ++rounds;
     if (S.want.empty()) return fail(BPSW_ERR_DEVICE, "matesw_group: replay stalled");  // cannot happen
@@ -536,7 +536,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
 
   // ---- 4. output: the lists of the untouched pairs come out exactly as they went in (every anchor of theirs is skipped or
   // has no usable window, and only an SW result can change a list): one memcpy per run between two touched pairs -----------
-  const double t_o0 = wall_ms();
+  const double t_o0 = stat_ms();
   c->stats.grp_calls++; c->stats.grp_pairs += (uint64_t)G_;
   c->stats.grp_plan_ms += t_planned - t_begin; c->stats.grp_pack_ms += t_pack; c->stats.grp_replay_ms += t_replay;
   int64_t total = nreg;
@@ -564,6 +564,6 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
     }
     src_from = S.reg_base[2 * (size_t)k + 2];
   }
-  c->stats.grp_out_ms += wall_ms() - t_o0;
+  c->stats.grp_out_ms += stat_ms() - t_o0;
   return BPSW_OK;
 }

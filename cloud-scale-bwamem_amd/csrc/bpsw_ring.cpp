@@ -38,6 +38,11 @@ struct RingService {
   unsigned long long ticks_per_us = 100;
   // statistics (under mu)
   uint64_t epochs = 0, submitted = 0, carried = 0;
+  // every epoch's launch is bracketed by two events on the ring's stream: the duration of the resident kernel as a kernel trace sees it
+  hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_end[2] = {nullptr, nullptr};
+  bool ev_pending[2] = {false, false};
+  double epochs_ms = 0.;
+  uint64_t epochs_timed = 0;
 };
 
 // one service per device and ring class (3: mates up to 171 bases, 5: up to 256)
@@ -111,7 +116,20 @@ int start_epoch(RingService& S) {
   A.idle_ticks = (unsigned long long)env_int("BPSW_RING_IDLE_US", 2000) * S.ticks_per_us;
   A.worker_idle_ticks = (unsigned long long)env_int("BPSW_RING_WORKER_IDLE_US", 50000) * S.ticks_per_us;
   hipError_t e = hipMemsetAsync(S.d_block, 0, S.d_zero_bytes, S.stream);  // behind the previous epoch's kernel, in stream order
+  const int slot = (int)(S.epoch & 1u);
+  if (e == hipSuccess && !S.ev_begin[slot]) {
+    e = hipEventCreate(&S.ev_begin[slot]);
+    if (e == hipSuccess) e = hipEventCreate(&S.ev_end[slot]);
+  }
+  if (e == hipSuccess && S.ev_pending[slot]) {  // the epoch before last: long over (this stream has run a whole epoch since)
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, S.ev_begin[slot], S.ev_end[slot]) == hipSuccess) { S.epochs_ms += ms; ++S.epochs_timed; }
+    else (void)hipGetLastError();
+    S.ev_pending[slot] = false;
+  }
+  if (e == hipSuccess) e = hipEventRecord(S.ev_begin[slot], S.stream);
   if (e == hipSuccess) e = launch_swp_resident(S.c_class, A, S.blocks, S.stream);
+  if (e == hipSuccess) { e = hipEventRecord(S.ev_end[slot], S.stream); S.ev_pending[slot] = e == hipSuccess; }
   if (e != hipSuccess) { S.broken = true; return hip_fail_ring(e, "epoch launch"); }
   S.running = true;
   ++S.epochs;
@@ -271,16 +289,27 @@ void ring_resume(int device) {
   }
 }
 
-void ring_get_stats(int device, uint64_t* epochs, uint64_t* submitted, uint64_t* carried) {
-  uint64_t e = 0, s = 0, c = 0;
+void ring_get_stats(int device, uint64_t* epochs, uint64_t* submitted, uint64_t* carried, double* epochs_ms, uint64_t* epochs_timed) {
+  uint64_t e = 0, s = 0, c = 0, t = 0;
+  double ms_sum = 0.;
   for (int k = 0; k < 2; ++k) {
     RingService& S = g_rings[device >= 0 && device < 64 ? device : 0][k];
     std::lock_guard<std::recursive_mutex> lk(S.mu);
-    e += S.epochs; s += S.submitted; c += S.carried;
+    // the durations of the epochs that are over (an epoch that is still open, or has not left the device yet, is not counted)
+    for (int slot = 0; slot < 2; ++slot) {
+      if (!S.ev_pending[slot] || hipEventQuery(S.ev_end[slot]) != hipSuccess) { (void)hipGetLastError(); continue; }
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, S.ev_begin[slot], S.ev_end[slot]) == hipSuccess) { S.epochs_ms += ms; ++S.epochs_timed; }
+      else (void)hipGetLastError();
+      S.ev_pending[slot] = false;
+    }
+    e += S.epochs; s += S.submitted; c += S.carried; ms_sum += S.epochs_ms; t += S.epochs_timed;
   }
   if (epochs) *epochs = e;
   if (submitted) *submitted = s;
   if (carried) *carried = c;
+  if (epochs_ms) *epochs_ms = ms_sum;
+  if (epochs_timed) *epochs_timed = t;
 }
 
 // Process exit / library unload: ask every open epoch to close and give it a moment -- plain memory traffic only, the HIP runtime

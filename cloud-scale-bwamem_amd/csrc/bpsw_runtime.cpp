@@ -247,6 +247,16 @@ hipError_t wait_event(bpsw_ctx* c, hipEvent_t ev, int kind) {
   return e;
 }
 
+// the clock of the per-phase statistics (bpsw_stats_t: *_ms): wall time, or -- BPSW_STATS_CLOCK=cpu, a diagnostic -- the calling thread's
+// CPU time, which says what a phase costs the executor's CPU quota rather than how long it lasts
+double stat_ms() {
+  static const bool cpu = getenv("BPSW_STATS_CLOCK") && getenv("BPSW_STATS_CLOCK")[0] == 'c';
+  if (!cpu) return wall_ms();
+  timespec ts;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+  return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
 double wall_ms() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -679,14 +689,14 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   HIP_TRY(c->h_stage_in.reserve(stage_bytes));
   HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_post_bytes));
   if (lazy_full) *(volatile int*)((char*)c->h_stage_out.ptr + out_bytes) = 0;
-  const double t_in = wall_ms();
+  const double t_in = stat_ms();
   if (!staged) memcpy(c->h_stage_in.ptr, wire, wire_bytes);
   if (with_list) {  // rides on the same copy
     int* hl = (int*)((char*)c->h_stage_in.ptr + list_off);
     hl[0] = n_long;
     if (n_long) memcpy(hl + 1, long_tasks.data(), 4 * (size_t)n_long);
   }
-  const double t_staged = wall_ms();
+  const double t_staged = stat_ms();
   double t_dev0, t_dev1, copy_first_ms = 0.;
   bool kernel_was_last = false, relaunched = false;
   {
@@ -702,7 +712,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       // one bulk copy at a time per device, on a stream of the library's own (round 4 used a blocking hipMemcpy on the legacy default
       // stream for the same effect: that synchronises with every BLOCKING stream of the host process -- torch's, another native
       // library's -- and busy-waits; here the waiting thread sleeps, and nobody else's stream is involved)
-      const double t_c0 = wall_ms();
+      const double t_c0 = stat_ms();
       CopyLane& L = copy_lane(c->device);
       // BPSW_EXT_COPY_WAIT: 0 (default) the runtime's own wait for the lane's stream, under the lane's lock -- what a blocking hipMemcpy
       // does, without the legacy stream; 1 the lock covers the enqueue only and every caller sleeps / polls on an event of its own
@@ -723,11 +733,11 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         }
         HIP_TRY(wait_event(c, c->ev[3], 3));
       }
-      copy_first_ms = wall_ms() - t_c0;  // (booked as the call's H2D time below)
+      copy_first_ms = stat_ms() - t_c0;  // (booked as the call's H2D time below)
     }
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
     hipStream_t s = lease.s;
-    t_dev0 = wall_ms();
+    t_dev0 = stat_ms();
     HIP_TRY(hipEventRecord(c->ev[0], s));
     if (!copy_first) HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, s));
     bool on_dispatch = false;  // ev[1] / ev[2] ride on the kernel's own dispatch (KernelEvents, bpsw_internal.h)
@@ -809,7 +819,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       HIP_TRY(wait_event(c, kernel_is_last ? c->ev[5] : c->ev[3], 0));
       c->stats.ext_full_relaunches++;
     }
-    t_dev1 = wall_ms();
+    t_dev1 = stat_ms();
     c->stats.ext_wait_ms += lease.wait_ms;
   }
   if (zc_slots) {  // gather the 20-byte records out of their 32-byte slots
@@ -824,7 +834,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   } else {
     memcpy(out, c->h_stage_out.ptr, out_bytes);
   }
-  const double t_out = wall_ms();
+  const double t_out = stat_ms();
   float a = 0, b = 0, d = 0;
   (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);

@@ -114,7 +114,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
   const int ring_class = (ring_enabled() && zc_in && zc_out) ? sw_ring_class(sc, mq, mt, &ring_bias) : 0;
   if (ring_class) {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
-    const double t_dev0 = wall_ms();
+    const double t_dev0 = stat_ms();
     // Where the workers read the batch from.  Reading it from the pinned block (zero-copy, what a launch of its own does) costs a job
     // pair about eight dependent round trips over PCIe, and the link does not take thousands of waves doing that at once: with more
     // than ~2 500 job pairs in flight every one of them slows down, with 4 000 the total rate FALLS (32 threads of rescue calls alone:
@@ -129,7 +129,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
       HIP_TRY(hipEventRecord(c->ev[0], c->stream));
       HIP_TRY(wait_event(c, c->ev[0], 2));
       dev.q_pool = dd + st.o_qpool; dev.t_pool = pac_mode ? nullptr : dd + st.o_tpool; dev.packed = (const uint32_t*)(dd + st.o_packed);
-      c->stats.sw_h2d_ms += wall_ms() - t_dev0;  // (wall time of the copy as the caller saw it)
+      c->stats.sw_h2d_ms += stat_ms() - t_dev0;  // (wall time of the copy as the caller saw it)
     }
     RingDesc desc;
     memset(&desc, 0, sizeof desc);
@@ -154,7 +154,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[1]);
     if (rc != BPSW_OK) return rc;
     const float span_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, ring_class));
-    c->stats.grp_dev_ms += wall_ms() - t_dev0;
+    c->stats.grp_dev_ms += stat_ms() - t_dev0;
     c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)n; c->stats.sw_ring_calls++;
     c->stats.sw_kernel_ms += span_ms;  // first unit taken -> last unit finished, on the device's clock
     c->last_sw_ms = span_ms;
@@ -166,7 +166,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
     StreamLease lease(c);  // a device stream for the device phase only (bpsw_internal.h)
     hipStream_t s = lease.s;
-    const double t_dev0 = wall_ms();
+    const double t_dev0 = stat_ms();
     // ev[1] / ev[2] ride on the kernel's own dispatch (KernelEvents): its begin and end as a kernel trace sees them, and two marker
     // packets fewer per call; only copies get markers of their own
     if (!zc_in) {
@@ -182,7 +182,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     }
     HIP_TRY(wait_event(c, zc_out ? c->ev[2] : c->ev[3], 1));  // the last operation of the call on this stream
     c->stats.grp_wait_ms += lease.wait_ms;
-    c->stats.grp_dev_ms += wall_ms() - t_dev0;
+    c->stats.grp_dev_ms += stat_ms() - t_dev0;
   }
   float a = 0, b = 0, e = 0;
   if (!zc_in) (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
@@ -644,9 +644,10 @@ int bpsw_global_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_global_jo
   return BPSW_OK;
 }
 
-int bpsw_ring_stats(bpsw_ctx_t* c, uint64_t* epochs, uint64_t* submitted, uint64_t* carried) {
+int bpsw_ring_stats(bpsw_ctx_t* c, uint64_t* epochs, uint64_t* submitted, uint64_t* carried, double* epochs_ms, uint64_t* epochs_timed) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");
-  ring_get_stats(c->device, epochs, submitted, carried);
+  HIP_TRY(hipSetDevice(c->device));
+  ring_get_stats(c->device, epochs, submitted, carried, epochs_ms, epochs_timed);
   return BPSW_OK;
 }
 

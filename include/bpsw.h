@@ -446,8 +446,10 @@ int bpsw_last_kernel_ms(bpsw_ctx_t *ctx, float *ext_ms, float *sw_ms);
 /* The submission ring of the context's device (round 5; csrc/bpsw_ring.h): the SW batches of bpsw_swalign2_batch / bpsw_matesw_group /
  * mateSWJNI of ALL contexts of a device are descriptors of one resident kernel instead of launches of their own.  epochs = launches of
  * that kernel (it ends by itself BPSW_RING_IDLE_US after its last batch), submitted = batches appended, carried = batches a closing
- * epoch handed to its successor.  Diagnostics; any pointer may be null. */
-int bpsw_ring_stats(bpsw_ctx_t *ctx, uint64_t *epochs, uint64_t *submitted, uint64_t *carried);
+ * epoch handed to its successor; epochs_ms / epochs_timed = summed duration and number of the epochs that are OVER, each timed by two HIP
+ * events around the resident kernel's launch on its stream (what a kernel trace reports as that kernel's duration).  Diagnostics; any
+ * pointer may be null. */
+int bpsw_ring_stats(bpsw_ctx_t *ctx, uint64_t *epochs, uint64_t *submitted, uint64_t *carried, double *epochs_ms, uint64_t *epochs_timed);
 
 #ifdef __cplusplus
 }

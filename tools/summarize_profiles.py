@@ -19,7 +19,7 @@ def short(name):
     m = re.search(r"ext_kernel<\w+, (\d)>", name)   # <COORD, SHORT>: 0 = the full kernel (listed / deferred tasks), 1 = the short kernel
     if m:
         return "extend_full" if m.group(1) == "0" else "extend"
-    for k, v in (("ext_sift", "extend_sift"), ("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("swp_kernel", "swalign2"), ("sw4_kernel", "swalign2"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
+    for k, v in (("swp_resident", "swalign2_resident"), ("ext_sift", "extend_sift"), ("ext_kernel", "extend"), ("ext_prepass", "ext_prepass"), ("swp_kernel", "swalign2"), ("sw4_kernel", "swalign2"), ("sw_kernel", "swalign2"), ("sw_prepass", "sw_prepass"),
                  ("reg2aln", "reg2aln"), ("chain2aln", "chain2aln"), ("global_kernel", "global")):
         if k in name:
             return v
@@ -47,6 +47,18 @@ with open(os.path.join(P, f"{tag}_pmc_counters.csv"), "w") as f:
         for c in sorted(per[k]):
             v = per[k][c]
             f.write(f"{k},{c},{sum(v) / len(v):.4e},{len(v)}\n")
+# The resident rescue kernel (one launch per epoch of the submission ring) serves many batches per launch: what the other kernels have
+# per launch, it has per BATCH -- the epochs' counters summed over the run and divided by the batches the run submitted
+# (PROF_SW_BATCHES: tools/collect_profiles.sh passes what its bench commands submit).  "swalign2" below is that per-batch figure.
+SW_BATCHES = int(os.environ.get("PROF_SW_BATCHES", "0"))
+if "swalign2_resident" in per and SW_BATCHES > 0 and "swalign2" not in per:
+    for c, v in per["swalign2_resident"].items():
+        per["swalign2"][c] = [sum(v) / SW_BATCHES]
+    with open(os.path.join(P, f"{tag}_pmc_counters.csv"), "a") as f:
+        for c in sorted(per["swalign2"]):
+            f.write(f"swalign2 (per batch: swalign2_resident summed over its {len(per['swalign2_resident'][c])} launches / {SW_BATCHES} batches),{c},{per['swalign2'][c][0]:.4e},{SW_BATCHES}\n")
+
+
 def mean(k, c):
     v = per[k].get(c)
     return sum(v) / len(v) if v else None
