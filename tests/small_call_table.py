@@ -58,6 +58,36 @@ def main():
                                     "gpu_ms_per_call": round(gpu, 4), "gpu_us_per_pair": round(1e3 * gpu / pairs, 3),
                                     "reference_c_one_core_ms": round(cpu, 4) if cpu else None,
                                     "gpu_speedup_vs_one_core": round(cpu / gpu, 2) if cpu else None})
+    # Concurrent callers (round 5): T task threads, each making blocking calls of the default group size (-sbatch 10) or 64 pairs, through
+    # the native feeder (csrc/bpsw_feeder.cpp: one context per thread, next free thread takes the next group).  With the submission ring the
+    # calls of all threads are descriptors of one resident kernel; BPSW_RING=0 gives every call a launch of its own.
+    from bpsw_hip import feeder as fd
+    out["matesw_group_concurrent"] = []
+    for pairs in (10, 64):
+        groups = [synth.rescue_group_fast(pairs, seed=synth.CONFIG_SEED_BASE + 5 + 13 * j, p_resc=0.10) for j in range(256)]
+        structs = [g.as_struct() for g in groups]
+        cnts = [np.zeros(2 * g.group_size, np.int32) for g in groups]
+        regs = [np.empty(int(g.regs.shape[0] + g.ref_rb.shape[0] + 16), bpsw_hip.ALNREG_DTYPE) for g in groups]
+        items, _ = fd.make_items([], [], groups, structs, cnts, regs)
+        cpu = timed(lambda g: ref.matesw_group(ropt, g), groups[:64], 2) if ref else None
+        for T in (1, 4, 16):
+            F = fd.Feeder(T, 0, opt, bpsw_hip.RESCUE_C)
+            F.run(items, 2)
+            F.reset_stats()
+            t0 = time.perf_counter()
+            reps = 8
+            F.run(items, reps)
+            dt = time.perf_counter() - t0
+            calls = reps * len(items)
+            st = F.stats_sum()
+            out["matesw_group_concurrent"].append({
+                "pairs_per_call": pairs, "callers": T, "sw_jobs_per_call": round(st["sw_jobs"] / max(st["grp_calls"], 1), 2),
+                "ms_per_call_as_a_caller_sees_it": round(float(np.mean([it.ms for it in items])), 4),
+                "calls_per_s_all_callers": round(calls / dt, 1), "us_per_call_aggregate": round(1e6 * dt / calls, 2),
+                "reference_c_one_core_ms": round(cpu, 4) if cpu else None,
+                "per_caller_rate_vs_reference_core": round(cpu / float(np.mean([it.ms for it in items])), 3) if cpu else None,
+                "ring_batches": int(st.get("sw_ring_calls", 0))})
+            F.close()
     out["note"] = ("one calling thread, distinct inputs per call, host buffers in and out; reference C = oracle/_ref (the reference's own ksw_extend2 / "
                    "mem_group_matesw with SSE2 ksw_align2) on one host core of the GPU box; p_resc = 10 % of the pairs need rescue (configs[2])")
     print(json.dumps(out, indent=1))
@@ -66,6 +96,10 @@ def main():
         print(f"| swExtendFPGAJNI | {r['tasks_per_call']} tasks | {r['gpu_ms_per_call']} | {r['reference_c_one_core_ms']} | {r['gpu_speedup_vs_one_core']}x |")
     for r in out["matesw_group"]:
         print(f"| mateSWJNI | {r['pairs_per_call']} pairs ({r['sw_jobs_per_call']} SW jobs) | {r['gpu_ms_per_call']} | {r['reference_c_one_core_ms']} | {r['gpu_speedup_vs_one_core']}x |")
+    print("\n| callers | pairs per call | ms per call (caller's view) | calls/s, all callers | reference C, one core, ms | per caller vs one core |\n|---|---|---|---|---|---|")
+    for r in out["matesw_group_concurrent"]:
+        print(f"| {r['callers']} | {r['pairs_per_call']} ({r['sw_jobs_per_call']} SW jobs) | {r['ms_per_call_as_a_caller_sees_it']} | {r['calls_per_s_all_callers']} | "
+              f"{r['reference_c_one_core_ms']} | {r['per_caller_rate_vs_reference_core']}x |")
 
 
 if __name__ == "__main__":
