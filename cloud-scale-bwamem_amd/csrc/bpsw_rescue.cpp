@@ -161,7 +161,7 @@ inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* dist) {  //
 // Per-context scratch of bpsw_matesw_group: every vector keeps its capacity between calls, so the steady state allocates nothing.
 struct Want { int64_t x; int32_t mate; };  // window index (anchor row * 4 + orientation) and the end (2k + i) whose read is aligned
 struct Scratch {
-  std::vector<int64_t> reg_base, ref_base;  // per end 2k+i: first region / first anchor row
+  std::vector<int64_t> t_base;              // per TOUCHED pair, four words: first region of end 0 / end 1, first anchor row of end 0 / end 1
   std::vector<int64_t> job_x;               // launched windows, ascending within a round (round boundaries in job_round)
   std::vector<size_t> job_round;            // first job of every round; job_x[job_round[r] .. job_round[r+1]) is sorted
   std::vector<int32_t> results;             // 7 ints per launched job
@@ -183,10 +183,11 @@ struct Group {
   int mode;
   bool pac_mode;
   Scratch* S;
+  int failed_mask;  // bit r: pes[r].failed (an orientation without statistics is skipped for every anchor)
 };
 
 void skip_flags(const Group& G, const Reg& a, const Reg* mates, size_t n_mates, int skip[4]) {
-  for (int r = 0; r < 4; ++r) skip[r] = G.g->pes[r].failed ? 1 : 0;
+  for (int r = 0; r < 4; ++r) skip[r] = (G.failed_mask >> r) & 1;
   for (size_t mi = 0; mi < n_mates; ++mi) {
     const Reg& m = mates[mi];
     int64_t dist;
@@ -312,11 +313,12 @@ bool precompute(Group& G, const Reg& a, int l_ms, int mate_end, std::vector<Reg>
 }
 
 // Replays pair k from its initial state.  Returns false (and fills `missing`) if a result is not available yet.
-bool replay_pair(Group& G, int k, std::vector<Reg> v[2], std::vector<Want>& missing) {
+bool replay_pair(Group& G, int k, size_t ti, std::vector<Reg> v[2], std::vector<Want>& missing) {
   const bpsw_rescue_group_t* g = G.g;
   std::vector<Reg>* tmp = G.S->anchors;
+  const int64_t* tb = G.S->t_base.data() + 4 * ti;
   for (int i = 0; i < 2; ++i) {
-    const Reg* first = g->regs + G.S->reg_base[(size_t)(2 * k + i)];
+    const Reg* first = g->regs + tb[i];
     v[i].assign(first, first + g->reg_cnt[2 * k + i]);
     tmp[i].clear();
     for (const Reg& r : v[i])  // anchors: filtered copy taken before any rescue (native/bwamem_pair.c:126-131)
@@ -325,7 +327,7 @@ bool replay_pair(Group& G, int k, std::vector<Reg> v[2], std::vector<Want>& miss
   for (int i = 0; i < 2; ++i) {
     const int na = std::min<int>((int)tmp[i].size(), std::min<int>(G.opt->max_matesw, g->ref_cnt[2 * k + i]));
     for (int j = 0; j < na; ++j)
-      if (!precompute(G, tmp[i][(size_t)j], g->seq_len[2 * k + !i], 2 * k + !i, v[!i], G.S->ref_base[(size_t)(2 * k + i)] + j, missing))
+      if (!precompute(G, tmp[i][(size_t)j], g->seq_len[2 * k + !i], 2 * k + !i, v[!i], tb[2 + i] + j, missing))
         return false;
   }
   return true;
@@ -369,51 +371,67 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
   static const bool lean = !(getenv("BPSW_RESCUE_LEAN") && atoi(getenv("BPSW_RESCUE_LEAN")) == 0);  // 0: speculate every anchor (A/B)
 
   // ---- 1. one pass: prefix sums, validation, speculation against the initial lists -----------------------------------
-  S.reg_base.resize(2 * (size_t)G_ + 1); S.ref_base.resize(2 * (size_t)G_ + 1);
+  // (a third of a call's CPU time in round 4, and the calls' CPU time is what bounds the bench step since the rescue kernel is
+  // resident: the per-end prefix arrays became four words per TOUCHED pair, the per-pair checks are straight-line on values loaded
+  // once, the region records of the pairs ahead are prefetched -- 64 bytes each, two or three per pair, in input order)
+  GR.failed_mask = 0;
+  for (int r = 0; r < 4; ++r) GR.failed_mask |= (g->pes[r].failed ? 1 : 0) << r;
+  S.t_base.clear();
   S.want.clear(); S.touched.clear();
   int64_t nreg = 0, nref = 0;
-  for (int k = 0; k < G_; ++k) {
-    int64_t base[2], rowb[2];
-    for (int i = 0; i < 2; ++i) {
-      const int e = 2 * k + i;
-      if (g->reg_cnt[e] < 0 || g->ref_cnt[e] < 0 || g->seq_len[e] < 0) return fail(BPSW_ERR_ARG, "matesw_group: negative count");
-      if ((uint64_t)(g->seq_off[e] + g->seq_len[e]) > g->seq_pool_bytes) return fail(BPSW_ERR_ARG, "matesw_group: mate outside seq_pool");
-      S.reg_base[(size_t)e] = base[i] = nreg; S.ref_base[(size_t)e] = rowb[i] = nref;
-      nreg += g->reg_cnt[e]; nref += g->ref_cnt[e];
-    }
-    if (!rescue_on) continue;
-    bool touched = false;
-    for (int i = 0; i < 2; ++i) {
-      const int e = 2 * k + i, mate = e ^ 1;
-      if (g->seq_len[mate] < 1 || g->reg_cnt[e] == 0 || g->ref_cnt[e] == 0) continue;
-      const Reg* init = g->regs + base[i];
-      const Reg* minit = g->regs + base[!i];
-      const int n_init = g->reg_cnt[e], n_mate = g->reg_cnt[mate];
-      const int thr = init[0].score - opt->pen_unpaired;
-      int j = 0;
-      bool emitted = false;  // an earlier anchor of this end has a job: its hit may make the later anchors' jobs unnecessary
-      for (int ai = 0; ai < n_init; ++ai) {
-        const Reg& a = init[ai];
-        if (!(a.score >= thr)) continue;
-        if (j >= opt->max_matesw || j >= g->ref_cnt[e]) break;
-        // lean speculation: only the first anchor of an end that has a job is launched now; what the later ones still need once
-        // its result is in, the replay asks for (a second, small round: only when that first rescue failed or landed elsewhere) --
-        // instead of computing them all and dropping 9 % of the jobs unused (bench step: 467.8 -> 427.3 jobs per group, no
-        // second round at all; tests/test_rescue_gpu.py forces one with decoy anchors)
-        if (lean && emitted) break;
-        int skip[4];
-        skip_flags(GR, a, minit, (size_t)n_mate, skip);
-        if (skip[0] + skip[1] + skip[2] + skip[3] != 4) {
-          const int64_t xrow = rowb[i] + j;
-          for (int r = 0; r < 4; ++r)
-            if (!skip[r] && window_ok(GR, xrow * 4 + r)) { S.want.push_back({xrow * 4 + r, mate}); touched = true; emitted = true; }
+  {
+    const int32_t* reg_cnt = g->reg_cnt;
+    const int32_t* ref_cnt = g->ref_cnt;
+    const int32_t* seq_len = g->seq_len;
+    const int64_t* seq_off = g->seq_off;
+    const uint64_t pool_bytes = g->seq_pool_bytes;
+    const int max_matesw = opt->max_matesw, pen_unpaired = opt->pen_unpaired;
+    for (int k = 0; k < G_; ++k) {
+      const int e0 = 2 * k;
+      const int rc[2] = {reg_cnt[e0], reg_cnt[e0 + 1]}, fc[2] = {ref_cnt[e0], ref_cnt[e0 + 1]}, sl[2] = {seq_len[e0], seq_len[e0 + 1]};
+      if ((rc[0] | rc[1] | fc[0] | fc[1] | sl[0] | sl[1]) < 0) return fail(BPSW_ERR_ARG, "matesw_group: negative count");
+      if ((uint64_t)(seq_off[e0] + sl[0]) > pool_bytes || (uint64_t)(seq_off[e0 + 1] + sl[1]) > pool_bytes)
+        return fail(BPSW_ERR_ARG, "matesw_group: mate outside seq_pool");
+      const int64_t base[2] = {nreg, nreg + rc[0]}, rowb[2] = {nref, nref + fc[0]};
+      nreg += (int64_t)rc[0] + rc[1]; nref += (int64_t)fc[0] + fc[1];
+      if (!rescue_on) continue;
+      __builtin_prefetch(g->regs + nreg + 12);
+      __builtin_prefetch(g->regs + nreg + 13);
+      bool touched = false;
+      for (int i = 0; i < 2; ++i) {
+        const int mate = e0 + (i ^ 1);
+        if (sl[i ^ 1] < 1 || rc[i] == 0 || fc[i] == 0) continue;
+        const Reg* init = g->regs + base[i];
+        const Reg* minit = g->regs + base[i ^ 1];
+        const int n_init = rc[i], n_mate = rc[i ^ 1];
+        const int thr = init[0].score - pen_unpaired;
+        int j = 0;
+        bool emitted = false;  // an earlier anchor of this end has a job: its hit may make the later anchors' jobs unnecessary
+        for (int ai = 0; ai < n_init; ++ai) {
+          const Reg& a = init[ai];
+          if (!(a.score >= thr)) continue;
+          if (j >= max_matesw || j >= fc[i]) break;
+          // lean speculation: only the first anchor of an end that has a job is launched now; what the later ones still need once
+          // its result is in, the replay asks for (a second, small round: only when that first rescue failed or landed elsewhere) --
+          // instead of computing them all and dropping 9 % of the jobs unused (bench step: 467.8 -> 427.3 jobs per group, no
+          // second round at all; tests/test_rescue_gpu.py forces one with decoy anchors)
+          if (lean && emitted) break;
+          int skip[4];
+          skip_flags(GR, a, minit, (size_t)n_mate, skip);
+          if (skip[0] + skip[1] + skip[2] + skip[3] != 4) {
+            const int64_t xrow = rowb[i] + j;
+            for (int r = 0; r < 4; ++r)
+              if (!skip[r] && window_ok(GR, xrow * 4 + r)) { S.want.push_back({xrow * 4 + r, mate}); touched = true; emitted = true; }
+          }
+          ++j;
         }
-        ++j;
+      }
+      if (touched) {
+        S.touched.push_back(k);
+        S.t_base.push_back(base[0]); S.t_base.push_back(base[1]); S.t_base.push_back(rowb[0]); S.t_base.push_back(rowb[1]);
       }
     }
-    if (touched) S.touched.push_back(k);
   }
-  S.reg_base[2 * (size_t)G_] = nreg; S.ref_base[2 * (size_t)G_] = nref;
   RefHold ref_hold;  // coordinate mode: the reference stays put until the last round's kernel has been waited for
   if (GR.pac_mode && nref > 0) {
     const uint8_t* d_pac = nullptr;
@@ -516,7 +534,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
     for (size_t ti = 0; ti < nt; ++ti) {
       if (S.done[ti]) continue;
       const int k = S.touched[ti];
-      if (!replay_pair(GR, k, S.v, S.want)) continue;
+      if (!replay_pair(GR, k, ti, S.v, S.want)) continue;
       for (int i = 0; i < 2; ++i) {
         S.fin_off[2 * ti + (size_t)i] = (int64_t)S.arena.size();
         S.fin_cnt[2 * ti + (size_t)i] = (int32_t)S.v[i].size();
@@ -550,7 +568,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
   int64_t at = 0, src_from = 0;  // output position; first input region not yet copied
   for (size_t ti = 0; ti <= nt; ++ti) {
     const int k = ti < nt ? S.touched[ti] : G_;
-    const int64_t run_end = S.reg_base[2 * (size_t)k];  // regions before pair k
+    const int64_t run_end = ti < nt ? S.t_base[4 * ti] : nreg;  // regions before pair k
     if (run_end > src_from) {
       memcpy(out_regs + at, g->regs + src_from, sizeof(Reg) * (size_t)(run_end - src_from));
       at += run_end - src_from;
@@ -562,7 +580,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       if (cnt) memcpy(out_regs + at, S.arena.data() + S.fin_off[2 * ti + (size_t)i], sizeof(Reg) * (size_t)cnt);
       at += cnt;
     }
-    src_from = S.reg_base[2 * (size_t)k + 2];
+    src_from = S.t_base[4 * ti + 1] + g->reg_cnt[2 * k + 1];  // first region of pair k + 1
   }
   c->stats.grp_out_ms += stat_ms() - t_o0;
   return BPSW_OK;
