@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "bpsw.h"
+#include "bpsw_rescue_skip.h"
 #include "jni_min.h"
 
 namespace {
@@ -113,6 +114,7 @@ double now_us() {
 // wall time of the last JNI call on this thread, split at the C ABI: marshalling in, the bpsw_* call, marshalling out (bpsw_jni_last_times)
 struct ShimTimes { double in_us, call_us, out_us, units; };
 thread_local ShimTimes t_times = {0, 0, 0, 0};
+thread_local int t_mate_path = 0;  // what the last mateSWJNI on this thread did: 1 the lazy path, 2 the eager one (bpsw_jni_last_mate_path, for the tests)
 
 void throw_runtime(JNIEnv* env, const std::string& msg) {
   clear_pending(env);
@@ -248,6 +250,272 @@ void read_bytes(JNIEnv* env, jbyteArray arr, BytePool& pool, int64_t* off, int32
   pool.pad16();
 }
 
+
+// ---- mateSWJNI without the object walk over pairs that need nothing (round 5) -------------------------------------------------------
+// The reference's contract hands over every region, every mate and every rescue window of a group as objects (native/jni_mate_sw.c:
+// 239-518), and 96 % of a 4 096-pair call through this shim was reading and rebuilding them -- while nine pairs in ten are properly
+// paired, need no SW at all and come back exactly as they went in.  So: (1) one light pass over MateSWType[] reads what the skip test
+// needs of a region (its end, rBeg, score: 6 JNI calls instead of 18) and checks that the array is in (pair, end, rank) order with
+// regIdx = rank, as memSamPeGroupJNIPrepare builds it (MemSamPe.scala:1962-1990); (2) the skip test of the library itself
+// (bpsw_rescue_skip.h) selects the pairs that may need a job; (3) only THEIR regions (all fields), mates and windows are unmarshalled,
+// into a group of their own, and bpsw_matesw_group runs on that; (4) the result array holds new objects for those pairs and, for every
+// other end, the caller's own MateSWType objects -- they already carry (readIdx, pairIdx, regIdx = rank) and the unchanged region.
+// The Scala caller rebuilds its lists from the returned array and drops the input arrays (MemSamPe.scala:2010-2044), so sharing the
+// objects is safe.  Anything that does not look like what memSamPeGroupJNIPrepare builds (SeqSWType[] not one per end in order,
+// RefSWType[] not in (pair, end, anchor) order, regIdx != rank, a malformed object) returns 1: the caller takes the eager path below,
+// which accepts any order and raises the errors.  BPSW_JNI_LAZY=0: always the eager path.
+struct LightReg { int64_t rb; int32_t score, e; };
+struct LazyScratch {
+  std::vector<LightReg> light;
+  std::vector<int64_t> reg_at, base;
+  std::vector<int32_t> reg_cnt, ref_cnt, touched;
+  std::vector<uint8_t> is_touched;
+};
+thread_local LazyScratch t_lazy;
+
+void read_region(JNIEnv* env, jobject a, const RegIds& rf, bpsw_alnreg_t* r) {
+  r->rb = jni::GetLongField(env, a, rf.rBeg); r->re = jni::GetLongField(env, a, rf.rEnd);
+  r->qb = jni::GetIntField(env, a, rf.qBeg); r->qe = jni::GetIntField(env, a, rf.qEnd);
+  r->score = jni::GetIntField(env, a, rf.score); r->truesc = jni::GetIntField(env, a, rf.trueScore);
+  r->sub = jni::GetIntField(env, a, rf.sub); r->csub = jni::GetIntField(env, a, rf.csub);
+  r->sub_n = jni::GetIntField(env, a, rf.subNum); r->w = jni::GetIntField(env, a, rf.width);
+  r->seedcov = jni::GetIntField(env, a, rf.seedCov); r->secondary = jni::GetIntField(env, a, rf.secondary);
+  r->hash = (uint64_t)jni::GetLongField(env, a, rf.hash);
+}
+jobject new_mate_object(JNIEnv* env, const MateIds* ids, jint k, jint i, jint rank, const bpsw_alnreg_t& r) {
+  const RegIds& rf = ids->rf;
+  jobject m = jni::AllocObject(env, ids->mateCls), a = jni::AllocObject(env, ids->regCls);
+  if (!m || !a) return nullptr;
+  jni::SetIntField(env, m, ids->mRid, k); jni::SetIntField(env, m, ids->mPid, i); jni::SetIntField(env, m, ids->mReg, rank);
+  jni::SetLongField(env, a, rf.rBeg, r.rb); jni::SetLongField(env, a, rf.rEnd, r.re);
+  jni::SetIntField(env, a, rf.qBeg, r.qb); jni::SetIntField(env, a, rf.qEnd, r.qe);
+  jni::SetIntField(env, a, rf.score, r.score); jni::SetIntField(env, a, rf.trueScore, r.truesc);
+  jni::SetIntField(env, a, rf.sub, r.sub); jni::SetIntField(env, a, rf.csub, r.csub);
+  jni::SetIntField(env, a, rf.subNum, r.sub_n); jni::SetIntField(env, a, rf.width, r.w);
+  jni::SetIntField(env, a, rf.seedCov, r.seedcov); jni::SetIntField(env, a, rf.secondary, r.secondary);
+  jni::SetLongField(env, a, rf.hash, (jlong)r.hash);
+  jni::SetObjectField(env, m, ids->mAln, a);
+  return m;
+}
+
+// 0: done (*ret_out set), 1: take the eager path, -1: a Java exception is pending
+int mate_sw_lazy(JNIEnv* env, const MateIds* ids, const bpsw_opt_t& opt, const bpsw_rescue_group_t& g0, jint groupSize, jobjectArray seqArr,
+                 jobjectArray mateArr, jobjectArray refArr, jintArray refSizeArr, double t0, jobjectArray* ret_out) {
+  constexpr jint FRAME = 512;   // objects per local frame
+  LazyScratch& L = t_lazy;
+  MateScratch& ms = t_ms;
+  const size_t ends = 2 * (size_t)groupSize;
+  const jsize n_mate = jni::GetArrayLength(env, mateArr), n_seq = jni::GetArrayLength(env, seqArr), n_ref = jni::GetArrayLength(env, refArr);
+  if ((size_t)n_seq != ends || (size_t)jni::GetArrayLength(env, refSizeArr) < ends) return 1;
+  L.ref_cnt.assign(ends ? ends : 1, 0);
+  if (ends) jni::GetIntArrayRegion(env, refSizeArr, 0, (jsize)ends, L.ref_cnt.data());
+  L.base.assign(ends + 1, 0);
+  for (size_t e = 0; e < ends; ++e) {
+    if (L.ref_cnt[e] < 0) return 1;
+    L.base[e + 1] = L.base[e] + L.ref_cnt[e];
+  }
+  if (L.base[ends] != (int64_t)n_ref) return 1;
+  // ---- (1) the light pass ----
+  L.light.resize((size_t)n_mate);
+  L.reg_cnt.assign(ends ? ends : 1, 0);
+  {
+    long prev_e = -1;
+    jint rank = 0;
+    for (jsize s0 = 0; s0 < n_mate; s0 += FRAME) {
+      if (jni::PushLocalFrame(env, 2 * FRAME + 8) != JNI_OK) return -1;
+      const jsize s1 = s0 + FRAME < n_mate ? s0 + FRAME : n_mate;
+      for (jsize s = s0; s < s1; ++s) {
+        jobject o = jni::GetObjectArrayElement(env, mateArr, s);
+        if (!o) { jni::PopLocalFrame(env, nullptr); return 1; }
+        const jint k = jni::GetIntField(env, o, ids->mRid), i = jni::GetIntField(env, o, ids->mPid);
+        if (k < 0 || k >= groupSize || i < 0 || i > 1) { jni::PopLocalFrame(env, nullptr); return 1; }
+        const long e = 2l * k + i;
+        rank = e == prev_e ? rank + 1 : 0;
+        if (e < prev_e || jni::GetIntField(env, o, ids->mReg) != rank) { jni::PopLocalFrame(env, nullptr); return 1; }
+        prev_e = e;
+        jobject a = jni::GetObjectField(env, o, ids->mAln);
+        if (!a) { jni::PopLocalFrame(env, nullptr); return 1; }
+        LightReg& lr = L.light[(size_t)s];
+        lr.rb = jni::GetLongField(env, a, ids->rf.rBeg);
+        lr.score = jni::GetIntField(env, a, ids->rf.score);
+        lr.e = (int32_t)e;
+        ++L.reg_cnt[(size_t)e];
+      }
+      jni::PopLocalFrame(env, nullptr);
+    }
+  }
+  L.reg_at.assign(ends + 1, 0);
+  for (size_t e = 0; e < ends; ++e) L.reg_at[e + 1] = L.reg_at[e] + L.reg_cnt[e];
+  // ---- (2) which pairs may need a job: the library's own skip test on (rBeg, score); window validity and empty mates are left to
+  // the library (a superset of the pairs it will really touch) ----
+  L.touched.clear();
+  L.is_touched.assign((size_t)groupSize + 1, 0);
+  if ((opt.flag & 0x20) == 0) {  // MEM_F_NO_RESCUE
+    int32_t low[4], high[4];
+    int failed_mask = 0;
+    for (int r = 0; r < 4; ++r) { low[r] = g0.pes[r].low; high[r] = g0.pes[r].high; failed_mask |= (g0.pes[r].failed ? 1 : 0) << r; }
+    const char* compat = getenv("BPSW_MATESW_COMPAT");
+    const bool scala = compat && strcmp(compat, "scala") == 0;
+    for (jint k = 0; k < groupSize; ++k) {
+      bool touched = false;
+      for (int i = 0; i < 2 && !touched; ++i) {
+        const size_t e = 2 * (size_t)k + (size_t)i, mate = e ^ 1;
+        if (L.reg_cnt[e] == 0 || L.ref_cnt[e] == 0) continue;
+        const LightReg* init = L.light.data() + L.reg_at[e];
+        const LightReg* minit = L.light.data() + L.reg_at[mate];
+        const int thr = init[0].score - opt.pen_unpaired;
+        int j = 0;
+        for (int ai = 0; ai < L.reg_cnt[e] && !touched; ++ai) {
+          if (!(init[ai].score >= thr)) continue;
+          if (j >= opt.max_matesw || j >= L.ref_cnt[e]) break;
+          int skip[4];
+          bpsw::rescue_skip_flags(g0.l_pac, low, high, failed_mask, scala, init[ai].rb, &minit->rb, sizeof(LightReg), (size_t)L.reg_cnt[mate], skip);
+          if (skip[0] + skip[1] + skip[2] + skip[3] != 4) touched = true;
+          ++j;
+        }
+      }
+      if (touched) { L.touched.push_back(k); L.is_touched[(size_t)k] = 1; }
+    }
+  }
+  const size_t nt = L.touched.size();
+  // ---- (3) the touched pairs as a group of their own ----
+  const size_t rends = 2 * nt;
+  std::vector<int32_t>&seq_len = ms.seq_len, &reg_cnt = ms.reg_cnt, &ref_cnt = ms.ref_cnt;
+  std::vector<int64_t>& seq_off = ms.seq_off;
+  seq_len.assign(rends ? rends : 1, 0); reg_cnt.assign(rends ? rends : 1, 0); ref_cnt.assign(rends ? rends : 1, 0); seq_off.assign(rends ? rends : 1, 0);
+  BytePool &seq_pool = ms.seq_pool, &ref_pool = ms.ref_pool;
+  seq_pool.clear(); ref_pool.clear();
+  std::vector<bpsw_alnreg_t>& regs = ms.regs;
+  regs.clear();
+  std::vector<int64_t>&ref_rb = ms.ref_rb, &ref_re = ms.ref_re, &ref_len = ms.ref_len, &ref_off = ms.ref_off;
+  size_t rows = 0;
+  for (size_t ti = 0; ti < nt; ++ti)
+    for (int i = 0; i < 2; ++i) rows += (size_t)L.ref_cnt[2 * (size_t)L.touched[ti] + (size_t)i];
+  ref_rb.assign(4 * rows, -1); ref_re.assign(4 * rows, -1); ref_len.assign(4 * rows, 0); ref_off.assign(4 * rows, 0);
+  size_t coord_windows = 0, byte_windows = 0, row_at = 0;
+  for (size_t ti = 0; ti < nt; ++ti) {
+    const jint k = L.touched[ti];
+    for (int i = 0; i < 2; ++i) {
+      const size_t e = 2 * (size_t)k + (size_t)i, re = 2 * ti + (size_t)i;
+      if (jni::PushLocalFrame(env, 32 + 2 * L.reg_cnt[e] + 16 * L.ref_cnt[e]) != JNI_OK) return -1;
+      {  // the mate (SeqSWType[e] is end e: checked)
+        jobject o = jni::GetObjectArrayElement(env, seqArr, (jsize)e);
+        if (!o || jni::GetIntField(env, o, ids->seq_rid) != k || jni::GetIntField(env, o, ids->seq_pid) != i) { jni::PopLocalFrame(env, nullptr); return 1; }
+        jbyteArray bytes = (jbyteArray)jni::GetObjectField(env, o, ids->seq_trans);
+        int32_t got = 0;
+        read_bytes(env, bytes, seq_pool, &seq_off[re], &got);
+        const jint declared = jni::GetIntField(env, o, ids->seq_len);
+        seq_len[re] = declared < got ? declared : got;
+      }
+      for (int64_t s = L.reg_at[e]; s < L.reg_at[e + 1]; ++s) {  // the regions, all fields
+        jobject o = jni::GetObjectArrayElement(env, mateArr, (jsize)s);
+        jobject a = o ? jni::GetObjectField(env, o, ids->mAln) : nullptr;
+        if (!a) { jni::PopLocalFrame(env, nullptr); return 1; }
+        regs.emplace_back();
+        read_region(env, a, ids->rf, &regs.back());
+      }
+      reg_cnt[re] = L.reg_cnt[e];
+      ref_cnt[re] = L.ref_cnt[e];
+      for (int32_t j = 0; j < L.ref_cnt[e]; ++j, ++row_at) {  // the anchors' windows (RefSWType[base[e] + j] is anchor j of end e: checked)
+        jobject o = jni::GetObjectArrayElement(env, refArr, (jsize)(L.base[e] + j));
+        if (!o || jni::GetIntField(env, o, ids->rRid) != k || jni::GetIntField(env, o, ids->rPid) != i || jni::GetIntField(env, o, ids->rReg) != j) {
+          jni::PopLocalFrame(env, nullptr); return 1;
+        }
+        const size_t x = 4 * row_at;
+        jlongArray ab = (jlongArray)jni::GetObjectField(env, o, ids->rB), ae = (jlongArray)jni::GetObjectField(env, o, ids->rE);
+        jlongArray al = (jlongArray)jni::GetObjectField(env, o, ids->rL);
+        if (!ab || !ae || !al || jni::GetArrayLength(env, ab) < 4 || jni::GetArrayLength(env, ae) < 4 || jni::GetArrayLength(env, al) < 4) {
+          jni::PopLocalFrame(env, nullptr); return 1;
+        }
+        jni::GetLongArrayRegion(env, ab, 0, 4, (jlong*)&ref_rb[x]);
+        jni::GetLongArrayRegion(env, ae, 0, 4, (jlong*)&ref_re[x]);
+        jni::GetLongArrayRegion(env, al, 0, 4, (jlong*)&ref_len[x]);
+        for (int r = 0; r < 4; ++r) {
+          if (ref_rb[x + r] < 0 && ref_re[x + r] < 0) continue;  // failed orientation (MemSamPe.scala:1863-1868)
+          jbyteArray bytes = (jbyteArray)jni::GetObjectField(env, o, ids->rRef[r]);
+          if (!bytes && ref_len[x + r] != 0) { ++coord_windows; continue; }
+          ++byte_windows;
+          if (ref_len[x + r] <= 0) continue;
+          int32_t got = 0;
+          read_bytes(env, bytes, ref_pool, &ref_off[x + r], &got);
+          if (got < ref_len[x + r]) { jni::PopLocalFrame(env, nullptr); return 1; }
+        }
+      }
+      jni::PopLocalFrame(env, nullptr);
+    }
+  }
+  if (coord_windows > 0 && byte_windows > 0) return 1;
+  if (seq_pool.n == 0) memset(seq_pool.grow(16), 0, 16);
+  if (ref_pool.n == 0) memset(ref_pool.grow(16), 0, 16);
+  bpsw_rescue_group_t g = g0;
+  g.group_size = (int32_t)nt;
+  g.seq_len = seq_len.data(); g.seq_off = seq_off.data(); g.seq_pool = seq_pool.p; g.seq_pool_bytes = seq_pool.n;
+  g.reg_cnt = reg_cnt.data(); g.regs = regs.data(); g.ref_cnt = ref_cnt.data();
+  g.ref_rb = ref_rb.data(); g.ref_re = ref_re.data(); g.ref_len = ref_len.data(); g.ref_off = ref_off.data();
+  g.ref_pool = ref_pool.p; g.ref_pool_bytes = ref_pool.n;
+  if (coord_windows > 0) { g.ref_pool = nullptr; g.ref_pool_bytes = 0; g.ref_len = nullptr; g.ref_off = nullptr; }
+  std::vector<int32_t>& out_cnt = ms.out_cnt;
+  std::vector<bpsw_alnreg_t>& out = ms.out;
+  out_cnt.assign(rends ? rends : 1, 0);
+  int64_t total_r = 0;
+  const double t1 = now_us();
+  if (nt) {
+    bpsw_ctx_t* ctx = thread_context(env);
+    if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return -1; }
+    out.resize(regs.size() + rows + 16);
+    const char* compat = getenv("BPSW_MATESW_COMPAT");
+    const int mode = (compat && strcmp(compat, "scala") == 0) ? BPSW_RESCUE_SCALA : BPSW_RESCUE_C;
+    int rc = bpsw_matesw_group(ctx, &opt, &g, mode, out_cnt.data(), out.data(), (int64_t)out.size(), &total_r);
+    if (rc == BPSW_ERR_CAPACITY) {
+      out.resize((size_t)total_r);
+      rc = bpsw_matesw_group(ctx, &opt, &g, mode, out_cnt.data(), out.data(), (int64_t)out.size(), &total_r);
+    }
+    if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: mateSWJNI: ") + bpsw_last_error()); return -1; }
+  } else if (!thread_context(env)) {  // (a call that needs no device still fails without one, like every other: no silent CPU path)
+    throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error());
+    return -1;
+  }
+  // ---- (4) the result: (pair, end, rank) order; untouched ends keep the caller's objects ----
+  const double t2 = now_us();
+  int64_t total = total_r;
+  for (jint k = 0; k < groupSize; ++k)
+    if (!L.is_touched[(size_t)k]) total += L.reg_at[2 * (size_t)k + 2] - L.reg_at[2 * (size_t)k];
+  jobjectArray ret = jni::NewObjectArray(env, (jsize)total, ids->mateCls, nullptr);
+  if (!ret) return -1;
+  int64_t at = 0, rat = 0;
+  size_t ti = 0;
+  jint in_frame = 0;
+  if (jni::PushLocalFrame(env, 2 * FRAME + 8) != JNI_OK) return -1;
+  for (jint k = 0; k < groupSize; ++k) {
+    if (L.is_touched[(size_t)k]) {
+      for (int i = 0; i < 2; ++i)
+        for (int32_t rank = 0; rank < out_cnt[2 * ti + (size_t)i]; ++rank, ++at, ++rat) {
+          jobject m = new_mate_object(env, ids, k, i, rank, out[(size_t)rat]);
+          if (!m) { jni::PopLocalFrame(env, nullptr); return -1; }
+          jni::SetObjectArrayElement(env, ret, (jsize)at, m);
+          in_frame += 2;
+        }
+      ++ti;
+    } else {
+      for (int64_t s = L.reg_at[2 * (size_t)k]; s < L.reg_at[2 * (size_t)k + 2]; ++s, ++at) {
+        jobject o = jni::GetObjectArrayElement(env, mateArr, (jsize)s);
+        jni::SetObjectArrayElement(env, ret, (jsize)at, o);
+        ++in_frame;
+      }
+    }
+    if (in_frame >= FRAME) {
+      jni::PopLocalFrame(env, nullptr);
+      if (jni::PushLocalFrame(env, 2 * FRAME + 8) != JNI_OK) return -1;
+      in_frame = 0;
+    }
+  }
+  jni::PopLocalFrame(env, nullptr);
+  t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)total};
+  t_mate_path = 1;
+  *ret_out = ret;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -262,6 +530,7 @@ JNIEXPORT uint64_t bpsw_jni_thread_info(int32_t out[3]) {
 
 // Wall time of the last swExtendFPGAJNI / mateSWJNI call on the calling thread (for the shim micro-benchmark; not a JNI symbol):
 // out = {marshalling in (us), the C ABI call (us), marshalling out (us), units (tasks / regions returned)}.
+JNIEXPORT int bpsw_jni_last_mate_path(void) { return t_mate_path; }
 JNIEXPORT void bpsw_jni_last_times(double out[4]) {
   if (out) { out[0] = t_times.in_us; out[1] = t_times.call_us; out[2] = t_times.out_us; out[3] = t_times.units; }
 }
@@ -345,6 +614,15 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       g.pes[r].failed = jni::GetIntField(env, o, failed);
       g.pes[r].avg = jni::GetDoubleField(env, o, avg); g.pes[r].std = jni::GetDoubleField(env, o, sd);
       jni::DeleteLocalRef(env, o);
+    }
+  }
+  {  // the lazy path (above): only the pairs that may need a job are unmarshalled; 1 = the arrays are not in the order it relies on
+    static const bool lazy_on = !(getenv("BPSW_JNI_LAZY") && atoi(getenv("BPSW_JNI_LAZY")) == 0);
+    if (lazy_on) {
+      jobjectArray lazy_ret = nullptr;
+      const int st = mate_sw_lazy(env, ids, opt, g, groupSize, seqArr, mateArr, refArr, refSizeArr, t0, &lazy_ret);
+      if (st == 0) return lazy_ret;
+      if (st < 0) return nullptr;
     }
   }
   const size_t ends = 2 * (size_t)groupSize;
@@ -501,6 +779,7 @@ JNIEXPORT jobjectArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWJNI
       jni::PopLocalFrame(env, nullptr);
     }
   t_times = {t1 - t0, t2 - t1, now_us() - t2, (double)total};
+  t_mate_path = 2;
   return ret;
   } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
     throw_runtime(env, std::string("bPSW: mateSWJNI: ") + e.what());

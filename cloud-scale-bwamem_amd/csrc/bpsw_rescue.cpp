@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "bpsw_internal.h"
+#include "bpsw_rescue_skip.h"
 
 using namespace bpsw;
 
@@ -151,12 +152,7 @@ int sort_dedup(std::vector<Reg>& v, float mask, int mode) {
   return m;
 }
 
-inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* dist) {  // native/bwamem_pair.c:27-34
-  const bool r1 = b1 >= l_pac, r2 = b2 >= l_pac;
-  const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
-  *dist = p2 > b1 ? p2 - b1 : b1 - p2;
-  return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
-}
+inline int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* dist) { return rescue_infer_dir(l_pac, b1, b2, dist); }  // bpsw_rescue_skip.h
 
 // Per-context scratch of bpsw_matesw_group: every vector keeps its capacity between calls, so the steady state allocates nothing.
 struct Want { int64_t x; int32_t mate; };  // window index (anchor row * 4 + orientation) and the end (2k + i) whose read is aligned
@@ -184,17 +180,11 @@ struct Group {
   bool pac_mode;
   Scratch* S;
   int failed_mask;  // bit r: pes[r].failed (an orientation without statistics is skipped for every anchor)
+  int32_t pes_low[4], pes_high[4];
 };
 
 void skip_flags(const Group& G, const Reg& a, const Reg* mates, size_t n_mates, int skip[4]) {
-  for (int r = 0; r < 4; ++r) skip[r] = (G.failed_mask >> r) & 1;
-  for (size_t mi = 0; mi < n_mates; ++mi) {
-    const Reg& m = mates[mi];
-    int64_t dist;
-    const int r = infer_dir(G.g->l_pac, a.rb, m.rb, &dist);
-    if (G.mode == BPSW_RESCUE_SCALA) dist = (int64_t)(int32_t)dist;  // MemSamPe.scala:1137-1138 narrows to Int
-    if (dist >= G.g->pes[r].low && dist <= G.g->pes[r].high) skip[r] = 1;
-  }
+  rescue_skip_flags(G.g->l_pac, G.pes_low, G.pes_high, G.failed_mask, G.mode == BPSW_RESCUE_SCALA, a.rb, &mates->rb, sizeof(Reg), n_mates, skip);
 }
 
 // length of window x as the SW sees it: shipped with the bytes, or -- coordinate mode, SURVEY.md 8f.2 -- what bnsGetSeq
@@ -375,7 +365,7 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
   // resident: the per-end prefix arrays became four words per TOUCHED pair, the per-pair checks are straight-line on values loaded
   // once, the region records of the pairs ahead are prefetched -- 64 bytes each, two or three per pair, in input order)
   GR.failed_mask = 0;
-  for (int r = 0; r < 4; ++r) GR.failed_mask |= (g->pes[r].failed ? 1 : 0) << r;
+  for (int r = 0; r < 4; ++r) { GR.failed_mask |= (g->pes[r].failed ? 1 : 0) << r; GR.pes_low[r] = g->pes[r].low; GR.pes_high[r] = g->pes[r].high; }
   S.t_base.clear();
   S.want.clear(); S.touched.clear();
   int64_t nreg = 0, nref = 0;

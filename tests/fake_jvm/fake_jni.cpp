@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -361,6 +362,12 @@ int fake_jvm_matesw(const char* lib, int partition, const int32_t opt_ints[16], 
         mates->elems.push_back(m);
       }
     }
+  // FAKE_JVM_SHUFFLE=1: the arrays in an order memSamPeGroupJNIPrepare never produces (RefSWType[] and SeqSWType[] reversed) -- the contract
+  // keys every object by its own (readIdx, pairIdx, regIdx), so any order is legal; the shim's lazy path must notice and step aside
+  if (getenv("FAKE_JVM_SHUFFLE") && atoi(getenv("FAKE_JVM_SHUFFLE")) != 0) {
+    std::reverse(refs->elems.begin(), refs->elems.end());
+    std::reverse(seqs->elems.begin(), seqs->elems.end());
+  }
   FObj* self = vm.alloc("cs/ucla/edu/bwaspark/jni/MateSWJNI");
   jobjectArray r = fn(&e.env, J(self), J(opt), (jlong)l_pac, J(pes_arr), group_size, J(seqs), J(mates), J(refs), J(ref_sizes));
   if (local_frames) *local_frames = vm.calls[JNI_SLOT_PushLocalFrame] - vm.calls[JNI_SLOT_PopLocalFrame];

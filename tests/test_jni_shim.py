@@ -92,6 +92,33 @@ def test_matesw_through_jni_matches_c_abi(fake, ctx, allo, rl):
 
 
 @pytest.mark.gpu
+def test_matesw_lazy_path_steps_aside_for_arrays_in_another_order(fake, ctx, monkeypatch):
+    """Round 5: mateSWJNI unmarshals only the pairs that may need a job and hands the caller's own objects back for the others -- relying on
+    the order memSamPeGroupJNIPrepare builds its arrays in (MemSamPe.scala:1931-1990).  The contract itself keys every object by its own
+    indices: with RefSWType[] and SeqSWType[] reversed the lazy path must notice and the eager walk (any order) must give the same answer."""
+    lib = bpsw_hip.load_library()
+    lib.bpsw_jni_last_mate_path.restype = C.c_int
+    g = synth.rescue_group(140, seed=407, p_resc=0.4, p_multi_anchor=0.3)
+    want_cnt, want = ctx.matesw_group(bpsw_hip.default_opt(), g)
+    rc, cnt, regs, frames, msg = _matesw(fake, g, partition=2)
+    assert rc == 0 and frames == 0, msg
+    assert lib.bpsw_jni_last_mate_path() == 1                     # the lazy path
+    assert np.array_equal(cnt, want_cnt); region_fields_equal(regs, want); assert np.array_equal(regs["hash"], want["hash"])
+    monkeypatch.setenv("FAKE_JVM_SHUFFLE", "1")
+    rc, cnt, regs, frames, msg = _matesw(fake, g, partition=2)
+    assert rc == 0 and frames == 0, msg
+    assert lib.bpsw_jni_last_mate_path() == 2                     # stepped aside
+    assert np.array_equal(cnt, want_cnt); region_fields_equal(regs, want); assert np.array_equal(regs["hash"], want["hash"])
+    # a group in which nothing needs rescue: no SW job, no new object
+    g0 = synth.rescue_group(60, seed=408, p_resc=0.0)
+    monkeypatch.delenv("FAKE_JVM_SHUFFLE")
+    rc, cnt, regs, frames, msg = _matesw(fake, g0, partition=2)
+    assert rc == 0 and frames == 0, msg
+    assert lib.bpsw_jni_last_mate_path() == 1
+    assert np.array_equal(cnt, g0.reg_cnt) and np.array_equal(regs["rb"], g0.regs["rb"]) and np.array_equal(regs["hash"], g0.regs["hash"])
+
+
+@pytest.mark.gpu
 def test_matesw_through_jni_with_reference_on_device(fake, ctx):
     """SURVEY.md 8f.2 through the JNI surface: loadPacJNI, then RefSWType objects that carry (rBeg, rEnd) only"""
     l_pac = 300_007
