@@ -152,6 +152,7 @@ hipError_t launch_swp_resident(int c_class, const RingArgs& A, int blocks, hipSt
 
 // host side of the ring (bpsw_ring.cpp).  BPSW_RING=0 sends every call through a launch of its own, as before round 5.
 bool ring_enabled();
+bool ring_usable(int device, int c_class);  // false once that ring has failed: its callers take a launch per batch again
 int ring_submit(int device, int c_class, int num_cu, const RingDesc& desc);
 int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, double* est_ms);
 double ring_ticks_per_ms(int device, int c_class);

@@ -189,6 +189,14 @@ bool ring_enabled() {
   return on;
 }
 
+// false once the ring of (device, class) has failed (an epoch that could not be launched, a watchdog): its callers go back to a launch per
+// batch (sw_stage_run) instead of failing for the rest of the process's life
+bool ring_usable(int device, int c_class) {
+  RingService& S = service(device, c_class);
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  return !S.broken;
+}
+
 // Appends one descriptor to the ring of (device, class); starts an epoch when none is open.  The caller then waits on its completion
 // record (ring_wait).  Caller has set the device.
 int ring_submit(int device, int c_class, int num_cu, const RingDesc& desc) {

@@ -1,4 +1,5 @@
 // bpsw_sw_runtime.cpp -- C ABI entry points for the local-SW (mate rescue) jobs.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -111,7 +112,8 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
   // no event; the call waits on a completion record in its own pinned block.  Batches the resident kernel cannot take (a scoring the
   // packed kernel does not cover, mates above 256 bases, windows longer than its key rows) and BPSW_RING=0 go through a launch.
   int ring_bias = 0;
-  const int ring_class = (ring_enabled() && zc_in && zc_out) ? sw_ring_class(sc, mq, mt, &ring_bias) : 0;
+  int ring_class = (ring_enabled() && zc_in && zc_out) ? sw_ring_class(sc, mq, mt, &ring_bias) : 0;
+  if (ring_class && !ring_usable(c->device, ring_class)) ring_class = 0;  // a ring that failed earlier: a launch per batch, as before round 5
   if (ring_class) {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
     const double t_dev0 = stat_ms();
@@ -150,17 +152,25 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     memcpy(desc.w, &head, sizeof head);
     memcpy(desc.w + sizeof(RingDescHead) / 4, &pl, sizeof pl);
     rc = ring_submit(c->device, ring_class, c->num_cu, desc);
-    if (rc != BPSW_OK) return rc;
-    rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[1]);
-    if (rc != BPSW_OK) return rc;
-    const float span_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, ring_class));
-    c->stats.grp_dev_ms += stat_ms() - t_dev0;
-    c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)n; c->stats.sw_ring_calls++;
-    c->stats.sw_kernel_ms += span_ms;  // first unit taken -> last unit finished, on the device's clock
-    c->last_sw_ms = span_ms;
-    c->have_sw_ev = false;
-    *results = (const int32_t*)c->h_stage_out.ptr;
-    return BPSW_OK;
+    if (rc != BPSW_OK && !ring_usable(c->device, ring_class)) {
+      // the epoch could not be started (nothing of this batch has reached the device): this call and the later ones take a launch of their own
+      static std::atomic<bool> said{false};
+      if (!said.exchange(true)) fprintf(stderr, "bPSW: the submission ring of device %d failed (%s); SW batches are launched one by one from here on\n", c->device, bpsw_last_error());
+      ring_class = 0;
+      dev.q_pool = d + st.o_qpool; dev.t_pool = pac_mode ? nullptr : d + st.o_tpool; dev.packed = (const uint32_t*)(d + st.o_packed);
+    } else {
+      if (rc != BPSW_OK) return rc;
+      rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[1]);
+      if (rc != BPSW_OK) return rc;
+      const float span_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, ring_class));
+      c->stats.grp_dev_ms += stat_ms() - t_dev0;
+      c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)n; c->stats.sw_ring_calls++;
+      c->stats.sw_kernel_ms += span_ms;  // first unit taken -> last unit finished, on the device's clock
+      c->last_sw_ms = span_ms;
+      c->have_sw_ev = false;
+      *results = (const int32_t*)c->h_stage_out.ptr;
+      return BPSW_OK;
+    }
   }
   {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
