@@ -387,6 +387,18 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
       if (!rescue_on) continue;
       __builtin_prefetch(g->regs + nreg + 12);
       __builtin_prefetch(g->regs + nreg + 13);
+      // The common pair -- one hit per end, the two properly paired -- in straight-line code: each end's only anchor (it passes its own
+      // score threshold) against the other end's only hit; all four orientations skipped on both sides = nothing to do.  Anything else
+      // takes the general walk below.
+      if (rc[0] == 1 && rc[1] == 1 && fc[0] >= 1 && fc[1] >= 1 && sl[0] >= 1 && sl[1] >= 1 && max_matesw >= 1 && pen_unpaired >= 0) {
+        const int64_t rb0 = g->regs[base[0]].rb, rb1 = g->regs[base[1]].rb;
+        int64_t d01, d10;
+        const int r01 = infer_dir(g->l_pac, rb0, rb1, &d01), r10 = infer_dir(g->l_pac, rb1, rb0, &d10);
+        if (mode == BPSW_RESCUE_SCALA) { d01 = (int64_t)(int32_t)d01; d10 = (int64_t)(int32_t)d10; }
+        const int m0 = GR.failed_mask | ((d01 >= GR.pes_low[r01] && d01 <= GR.pes_high[r01]) ? 1 << r01 : 0);
+        const int m1 = GR.failed_mask | ((d10 >= GR.pes_low[r10] && d10 <= GR.pes_high[r10]) ? 1 << r10 : 0);
+        if (m0 == 15 && m1 == 15) continue;
+      }
       bool touched = false;
       for (int i = 0; i < 2; ++i) {
         const int mate = e0 + (i ^ 1);

@@ -157,8 +157,9 @@ void note_closed(RingService& S, uint64_t s) {
   if (ring_debug())
   {
     const double nu = S.H->diag_units ? (double)S.H->diag_units : 1.0;
-    fprintf(stderr, "bPSW ring[%d/%d]: epoch %u closed: consumed %u of %u published, %u worker waves took a unit, %d workgroups; diag: %llu units, "
-            "taken %.1f us after publication on average, %.1f us per unit\n", S.device, S.c_class, S.epoch, consumed, S.published, (unsigned)S.H->workers_seen,
+    static const char* why[5] = {"?", "asked by the host", "ring used up", "idle", "no progress"};
+    fprintf(stderr, "bPSW ring[%d/%d]: epoch %u closed (%s): consumed %u of %u published, %u worker waves took a unit, %d workgroups; diag: %llu units, "
+            "taken %.1f us after publication on average, %.1f us per unit\n", S.device, S.c_class, S.epoch, why[S.H->close_reason < 5 ? S.H->close_reason : 0], consumed, S.published, (unsigned)S.H->workers_seen,
             S.blocks, (unsigned long long)S.H->diag_units, (double)S.H->diag_claim_ticks / nu / (double)S.ticks_per_us, (double)S.H->diag_unit_ticks / nu / (double)S.ticks_per_us);
   }
   S.running = false;

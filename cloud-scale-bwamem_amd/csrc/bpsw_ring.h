@@ -49,7 +49,7 @@ struct RingHostCtl {
   volatile uint64_t state;      // device (the host initialises it to OPEN before the launch)
   volatile uint64_t heartbeat;  // device: the poller's clock at its last pass (diagnostics)
   volatile uint32_t workers_seen;  // device: worker wavefronts that took at least one unit in this epoch (diagnostics)
-  uint32_t pad1a;
+  volatile uint32_t close_reason;  // device: why the epoch closed -- 1 asked by the host, 2 ring used up, 3 idle, 4 no progress (diagnostics)
   volatile uint64_t diag_claim_ticks, diag_unit_ticks, diag_units;  // copies of RingDevCtl's at the epoch's close
   uint32_t pad1[20];
 };

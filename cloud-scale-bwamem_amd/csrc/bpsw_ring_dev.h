@@ -82,6 +82,7 @@ __device__ inline void ring_poller(const RingArgs& A, const int lane) {
       if (lane == 0) {
         __hip_atomic_store(h_state, state_word(consumed, RING_CLOSED), __ATOMIC_SEQ_CST, RING_SYS);
         __hip_atomic_store((uint32_t*)&A.H->workers_seen, __hip_atomic_load(&A.D->workers, __ATOMIC_RELAXED, RING_DEV), __ATOMIC_RELAXED, RING_SYS);
+        __hip_atomic_store((uint32_t*)&A.H->close_reason, stalled ? 4u : (close_req != 0 && close_req == A.epoch) ? 1u : full ? 2u : 3u, __ATOMIC_RELAXED, RING_SYS);
         __hip_atomic_store((unsigned long long*)&A.H->diag_claim_ticks, __hip_atomic_load(&A.D->diag_claim_ticks, __ATOMIC_RELAXED, RING_DEV), __ATOMIC_RELAXED, RING_SYS);
         __hip_atomic_store((unsigned long long*)&A.H->diag_unit_ticks, __hip_atomic_load(&A.D->diag_unit_ticks, __ATOMIC_RELAXED, RING_DEV), __ATOMIC_RELAXED, RING_SYS);
         __hip_atomic_store((unsigned long long*)&A.H->diag_units, __hip_atomic_load(&A.D->diag_units, __ATOMIC_RELAXED, RING_DEV), __ATOMIC_RELAXED, RING_SYS);
