@@ -39,6 +39,11 @@ struct RowState {
   int H0, E0, H1, E1;  // one column per lane: column base + lane in H0 / E0; two: columns base + 2 lane, base + 2 lane + 1
   int plo0, plo1;      // the lane's profile words: the scores of its column(s) against target A, C, G, T, one byte each
 };
+// four columns per lane (rows_cpp4: bands wider than 127 columns): columns base + 4 lane + 0..3.  Kept apart from RowState so that
+// it is live only inside the wide phase of a call -- RowState rides through the assembly loops in registers
+struct Row4 {
+  int H[4], E[4], plo[4];
+};
 enum { ROWS_DONE = 0, ROWS_MORE = 1, ROWS_OTHER_MODE = 2, ROWS_SLOW = 3, ROWS_OVERFLOW = 4 };
 constexpr int ROWS_NARROW = 52;  // a band of at most this many columns goes (back) to one column per lane; wider than 63 must leave it
 
@@ -213,6 +218,159 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
     }
   }
   save();
+  return ret;
+}
+
+// ---- four columns per lane: a window of 256 columns (round 5) -----------------------------------------------------------------------
+// A band wider than 127 columns used to leave the window sweeps altogether: the short kernel deferred the task to the full kernel or
+// (2x250 bp batches) swept the WHOLE side again with the slot sweep (sw_extend_reg<3>/<4>: ~410 instructions per row, measured).
+// That is not a rare path: the right-hand extension of a 250-base read starts from the score the left-hand one reached, and with
+// h0 = 120-250 the first hundred rows are "live" -- h1 > 0, the band keeps its left end at column 0 and grows by a column per row --
+// so a 130-231-base flank outgrows 128 columns within thirty rows.  On configs[4] a quarter of all rows went through the slot sweep,
+// and they were 70 % of the extension's instructions (tools/pmc_cfg5_instr.sh, tools/pmc_rowcost.sh with H0=120).  Here the same row
+// as rows_cpp, four columns per lane: one dual scan per row whatever the width, the four columns' terms folded before and after it;
+// 256 columns hold every band of a flank the register path takes (qLen <= 255), so this layout never overflows.
+//   ROWS_DONE        the call is over
+//   ROWS_OTHER_MODE  the next row's band fits ROWS4_NARROW columns again (the row has not been touched): back to two columns per lane
+constexpr int ROWS4_NARROW = 100;
+__device__ __forceinline__ void rows_load_profile4(Row4& q, const int base, const ProfLds& pl, const int qLen, const int lane) {
+  const int j0 = base + 4 * lane;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) q.plo[c] = pl.prof[min(j0 + c, qLen)];
+}
+__device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane, const int qLen, const int tLen, const ProfLds& pl, const uint8_t* __restrict__ ts,
+                         const int oDel, const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
+                         const int zmode, const int h0, const int amax) {
+  constexpr int C = 4, WIN = 256;
+  const int oeDel = oDel + eDel, oeIns = oIns + eIns;
+  const int jE0 = C * lane * eIns - oeIns;  // j*eIns - oeIns of the lane's first column, j counted from the window's origin
+  const int kC = oeIns - eIns;
+  int i = st.i, beg = st.beg, end = st.end, h1raw = st.h1raw, mx = st.mx, max_i = st.max_i, max_j = st.max_j, max_ie = st.max_ie;
+  int gscore = st.gscore, max_off = st.max_off, base = st.base;
+  int Hs[C] = {q.H[0], q.H[1], q.H[2], q.H[3]}, Es[C] = {q.E[0], q.E[1], q.E[2], q.E[3]};
+  const int i_tail = amax > 0 ? qLen : 0x7fffffff;
+  const int w1 = w + 1;
+  int ret = ROWS_DONE;
+  for (; i < tLen; ++i) {
+    if (i >= i_tail) {  // nothing past this row can change the result (tail_row_bound)
+      const int U = tail_row_bound(qLen, i, h0, amax, oDel, eDel);
+      const int stop = (U <= mx ? 1 : 0) & (U < gscore ? 1 : 0);
+      if (stop) break;
+    }
+    const int nbeg = smax2(beg, i - w);  // SWUtil.scala:140-142
+    const int nend = smin2(smin2(end, i + w1), qLen);
+    if (nend - nbeg <= ROWS4_NARROW && nend > nbeg) { beg = nbeg; end = nend; ret = ROWS_OTHER_MODE; break; }
+    if (nend - base > WIN - 1) {  // column `end` lies beyond the window: move the window up to the band's left end (always fits: qLen <= 255)
+      const int nb = nbeg & ~3;
+      const int from = (lane + ((nb - base) >> 2)) << 2;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        Hs[c] = __builtin_amdgcn_ds_bpermute(from, Hs[c]);
+        Es[c] = __builtin_amdgcn_ds_bpermute(from, Es[c]);
+      }
+      base = nb;
+      rows_load_profile4(q, base, pl, qLen, lane);
+    }
+    beg = nbeg; end = nend;
+    const int plo[C] = {q.plo[0], q.plo[1], q.plo[2], q.plo[3]};
+    const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base
+    h1raw -= eDel;
+    const int h1 = smax2(0, h1raw);  // SWUtil.scala:137-138
+    const int rbeg = beg - base;
+    const unsigned spanA = (unsigned)smax2(end - beg, 0);
+    const int span = end - beg;
+    int scv[C];
+    if (__builtin_expect(tsv == 32, 0)) {  // an N row
+#pragma unroll
+      for (int c = 0; c < C; ++c) scv[c] = (int)pl.profn[min(base + C * lane + c, qLen)];
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) scv[c] = __builtin_amdgcn_sbfe(plo[c], (unsigned)tsv, 8u);
+    }
+    bool act[C];
+    unsigned rel[C];
+    int a[C], Pg[C];
+    int Pl = NEG, scan_a = NEG_A * 256;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      rel[c] = (unsigned)(C * lane + c - rbeg);
+      act[c] = rel[c] < spanA;
+      a[c] = act[c] ? max(Hs[c] + scv[c], Es[c]) : NEG_A;
+      Pg[c] = a[c] + jE0 + c * eIns;
+      Pl = max(Pl, Pg[c]);
+      scan_a = max(scan_a, (a[c] << 8) | (C * lane + c));  // the row maximum and its LAST column in one scan (columns 0..255)
+    }
+    dual_scan_max(Pl, scan_a);
+    int pre = wave_shr1(NEG, Pl);  // the F prefix of the columns left of this lane
+    int H[C];
+    unsigned long long z[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      H[c] = max3i(a[c], pre - kC - jE0 - c * eIns, 0);
+      pre = max(pre, Pg[c]);
+      z[c] = __builtin_amdgcn_ballot_w64(H[c] < 1) & __builtin_amdgcn_ballot_w64(act[c]);
+      Es[c] = act[c] ? max3i(Es[c] - eDel, H[c] - oeDel, 0) : 0;
+    }
+    {  // the row shifted by one column: Hs(col) = H(i, col - 1); eh[beg].h = h1 (SWUtil.scala:153), written in every lane
+      const int hs = wave_shr1(h1, H[C - 1]);
+      Hs[0] = rel[0] == 0u ? h1 : hs;
+#pragma unroll
+      for (int c = 1; c < C; ++c) Hs[c] = rel[c] == 0u ? h1 : H[c - 1];
+    }
+    const int mkey = smax2(0, __builtin_amdgcn_readlane(scan_a, 63));
+    const int m = mkey >> 8, mjr = mkey & 255, mj = base + mjr;
+
+    const int jlast = span > 0 ? end : beg;  // SWUtil.scala:177-182
+    if (jlast == qLen) {
+      int hlast = h1;
+      if (span > 0) {
+        const int e = end - base;
+        const int v0 = __builtin_amdgcn_readlane(Hs[0], e >> 2), v1 = __builtin_amdgcn_readlane(Hs[1], e >> 2);
+        const int v2 = __builtin_amdgcn_readlane(Hs[2], e >> 2), v3 = __builtin_amdgcn_readlane(Hs[3], e >> 2);
+        hlast = (e & 2) ? ((e & 1) ? v3 : v2) : ((e & 1) ? v1 : v0);
+      }
+      const bool better = gscore <= hlast;
+      max_ie = better ? i : max_ie;
+      gscore = better ? hlast : gscore;
+    }
+    if (m == 0) break;  // SWUtil.scala:184-185
+    if (m > mx) {       // SWUtil.scala:187-193
+      const int d = mj - i;
+      max_off = smax2(max_off, smax2(d, -d));
+      mx = m; max_i = i; max_j = mj;
+    } else if (zdrop > 0) {  // SWUtil.scala:194-199 (Scala parse) / native/ksw.c:455-461 (BWA parse)
+      const int stop = zdrop_stop((i - max_i) - (mj - max_j), mx - m, eDel, eIns, zdrop, zmode) ? 1 : 0;
+      if (stop) break;
+    }
+    // band trimming, SWUtil.scala:202-214: the last zero column left of mj, the first zero column right of mj (columns of class c are
+    // 4 lane + c: the zero masks are four interleaved bit sets)
+    const int nb0 = beg + (h1 == 0 ? 1 : 0);
+    if ((z[0] | z[1] | z[2] | z[3]) == 0ull) {
+      beg = nb0;
+      end = end + 1;
+    } else {
+      int cl = -1, cr = 1 << 20;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        // (plain C, not the s_bfm / s_flbit / s_ff1 helpers of the two-column form: their "s" operands want values the compiler has
+        // PROVEN uniform, and it does not prove it for everything this loop derives them from)
+        const int cnt = (mjr + 3 - c) >> 2;  // lanes whose column of class c lies left of mj: 4 lane + c <= mjr - 1
+        const unsigned long long below = z[c] & (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull));
+        const int top = below ? 63 - (int)__builtin_clzll(below) : -1;  // the highest such lane with a zero cell
+        cl = smax2(cl, top >= 0 ? C * top + c : -1);
+        const int sc = (mjr + 4 - c) >> 2;   // first lane whose column of class c lies right of mj: 4 lane + c >= mjr + 1
+        const unsigned long long above = sc >= 64 ? 0ull : (z[c] >> sc);
+        const int f = above ? (int)__builtin_ctzll(above) : -1;
+        cr = smin2(cr, f >= 0 ? C * (sc + f) + c : 1 << 20);
+      }
+      beg = cl >= 0 ? base + cl + 2 : nb0;
+      end = cr < (1 << 20) ? base + cr + 1 : end + 1;
+    }
+  }
+  st.i = i; st.beg = beg; st.end = end; st.h1raw = h1raw; st.mx = mx; st.max_i = max_i; st.max_j = max_j; st.max_ie = max_ie;
+  st.gscore = gscore; st.max_off = max_off; st.base = base;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { q.H[c] = Hs[c]; q.E[c] = Es[c]; }
   return ret;
 }
 
@@ -1307,8 +1465,32 @@ __device__ __forceinline__ int rows_asm_end(const int i, const int tLen, const i
   return uni(end);
 }
 
-// SWExtend on the adaptive window, for flanks of up to 255 bases.  *overflow = 1: a band wider than 128 columns, the task is not for
-// this build (flanks of at most 127 bases never get there).
+// The wide phase of a call (rows_cpp4): from a band that outgrew the 128-column window -- or a first row that already is wider -- until
+// the call ends or the band fits two columns per lane again.  `q`: the (H,E) row four columns per lane, window origin st.base.
+// (forceinline, like rows_cpp4: a real call would put RowState in memory, and the assembly loops take its fields as scalar operands)
+__device__ __forceinline__ int rows_wide_phase(RowState& st, Row4& q, const int lane, const int qLen, const int tLen, const ProfLds& pl,
+                                               const uint8_t* __restrict__ ts, const int oDel, const int eDel, const int oIns, const int eIns,
+                                               const int w, const int zdrop, const int zmode, const int h0, const int amax) {
+  const int r4 = rows_cpp4(st, q, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax);
+  if (r4 != ROWS_OTHER_MODE) return r4;
+  // back to two columns per lane, window at the band's left end: new column nb + 2 lane + s sits in old lane (D + 2 lane) >> 2, slot
+  // ((D + 2 lane) & 2) + s, with D = nb - base (even)
+  const int nb = st.beg & ~1;
+  const int x = nb - st.base + 2 * lane;
+  const int src = (x >> 2) << 2;
+  const bool hi = (x & 2) != 0;
+  int hv[4], ev[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { hv[c] = __builtin_amdgcn_ds_bpermute(src, q.H[c]); ev[c] = __builtin_amdgcn_ds_bpermute(src, q.E[c]); }
+  st.H0 = hi ? hv[2] : hv[0]; st.H1 = hi ? hv[3] : hv[1];
+  st.E0 = hi ? ev[2] : ev[0]; st.E1 = hi ? ev[3] : ev[1];
+  st.base = nb;
+  rows_load_profile<2>(st, pl, qLen, lane);
+  return ROWS_OTHER_MODE;
+}
+
+// SWExtend on the adaptive window, for flanks of up to 255 bases: one, two or -- bands wider than 127 columns, round 5 -- four columns
+// per lane.  *overflow is never set any more (256 columns hold every band of such a flank); the parameter stays for the callers' sake.
 template <class QC>
 __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int tLen, const QC& qcode, const uint8_t* __restrict__ ts,
                                      const ProfLds& pl, const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w,
@@ -1322,11 +1504,26 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
   st.mx = h0; st.max_i = -1; st.max_j = -1; st.max_ie = -1; st.gscore = -1; st.max_off = 0;  // SWUtil.scala:118-125
   st.base = 0;
   // row 0 spans min(qLen, w + 1) columns (+ the column `end` it writes)
-  int cols = min(qLen, w + 1) <= 63 ? 1 : 2;
-  if (min(qLen, w + 1) > 127) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
+  int cols = min(qLen, w + 1) <= 63 ? 1 : (min(qLen, w + 1) <= 127 ? 2 : 4);
   st.H1 = 0; st.E1 = 0; st.plo1 = 0;
   rows_build_profile(pl, qcode, mat, qLen, lane);
-  if (cols == 1) {
+  if (cols == 4) {  // (w >= 127 and a flank of 128 bases or more: the first row is wider than the two-column window)
+    Row4 q;
+    st.base = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = 4 * lane + c;
+      q.H[c] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
+      q.E[c] = 0;
+    }
+    rows_load_profile4(q, 0, pl, qLen, lane);
+    if (rows_wide_phase(st, q, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax) != ROWS_OTHER_MODE) {
+      ExtRes res0;
+      res0.max = st.mx; res0.qle = st.max_j + 1; res0.tle = st.max_i + 1; res0.gtle = st.max_ie + 1; res0.gscore = st.gscore; res0.max_off = st.max_off;
+      return res0;
+    }
+    cols = 2;
+  } else if (cols == 1) {
     rows_load_profile<1>(st, pl, qLen, lane);
     st.H0 = lane == 0 ? h0 : max(0, h0 - oeIns - (lane - 1) * eIns);  // row -1, SWUtil.scala:97-104
     st.E0 = 0;
@@ -1398,7 +1595,22 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
       if (r == ROWS_SLOW)
 #endif
         r = rows_cpp<2>(st, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax, BPSW_EXT_ROWS_ASM ? 1 : 0x7fffffff);
-      if (r == ROWS_OVERFLOW) { *overflow = 1; return ExtRes{0, 0, 0, 0, 0, 0}; }
+      if (r == ROWS_OVERFLOW) {
+        // the band outgrew 128 columns: four columns per lane (round 4 gave the task up here: *overflow).  New column nb + 4 lane + c
+        // sits in old lane d + 2 lane + (c >> 1), slot c & 1, with d = (nb - base) / 2
+        Row4 q;
+        const int nb = st.beg & ~3;
+        const int srcA = (((nb - st.base) >> 1) + 2 * lane) << 2, srcB = srcA + 4;
+        q.H[0] = __builtin_amdgcn_ds_bpermute(srcA, st.H0); q.H[1] = __builtin_amdgcn_ds_bpermute(srcA, st.H1);
+        q.H[2] = __builtin_amdgcn_ds_bpermute(srcB, st.H0); q.H[3] = __builtin_amdgcn_ds_bpermute(srcB, st.H1);
+        q.E[0] = __builtin_amdgcn_ds_bpermute(srcA, st.E0); q.E[1] = __builtin_amdgcn_ds_bpermute(srcA, st.E1);
+        q.E[2] = __builtin_amdgcn_ds_bpermute(srcB, st.E0); q.E[3] = __builtin_amdgcn_ds_bpermute(srcB, st.E1);
+        st.base = nb;
+        rows_load_profile4(q, nb, pl, qLen, lane);
+        if (rows_wide_phase(st, q, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax) != ROWS_OTHER_MODE) break;
+        ts_chunk = -1;
+        continue;
+      }
       if (r == ROWS_OTHER_MODE) {  // the band fits one column per lane again: window at its left end
         const int nb = st.beg;
         const int col = nb + lane - st.base;  // this lane's new column, in the old window

@@ -631,12 +631,15 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   static const bool split_on = !(getenv("BPSW_EXT_SPLIT") && atoi(getenv("BPSW_EXT_SPLIT")) == 0);
   const int n_long = (int)long_tasks.size();
   const bool use_short = split_on && 2 * (size_t)n_long <= (size_t)n;
-  // Many tasks with a flank of 128-255 bases (2x250 bp reads): the short kernel that sweeps an outgrown band itself (ext_kernel<., 2>,
-  // bpsw_extend.hip) -- nothing is deferred, the full kernel is only launched for what the host listed.  BPSW_EXT_INLINE_WIDE=0: the
-  // deferring build for every batch (A/B).
-  static const bool inline_wide_on = !(getenv("BPSW_EXT_INLINE_WIDE") && atoi(getenv("BPSW_EXT_INLINE_WIDE")) == 0);
+  // Flanks of 128-255 bases (2x250 bp reads) used to meet bands wider than the short kernel's 128-column window: round 3 deferred such a
+  // task to the full kernel, round 4 swept the side again with the slot sweep in a build of its own (ext_kernel<., 2>, "inline wide").
+  // Since round 5 the adaptive sweep has a four-columns-per-lane phase (bpsw_extend_rows.h, rows_cpp4) and no band of a flank up to 255
+  // bases leaves it: nothing is deferred on account of a wide band, one build serves every batch, and the full kernel is for what the
+  // host lists (flanks above 255 bases).  BPSW_EXT_INLINE_WIDE=1 still selects the round-4 build for batches with many such flanks (A/B).
+  static const bool inline_wide_on = getenv("BPSW_EXT_INLINE_WIDE") && atoi(getenv("BPSW_EXT_INLINE_WIDE")) == 1;
   const bool inline_wide = inline_wide_on && use_short && 16 * (size_t)n_mid > (size_t)n;
-  const bool expect_full = !use_short || n_long > 0 || (any_mid && !inline_wide);  // any_mid: the short kernel may defer tasks from the device
+  const bool expect_full = !use_short || n_long > 0;
+  (void)any_mid;
   // behind the wire bytes: the full kernel's list as [count, task indices...]; the host stages its own entries and the count, the
   // 48-VGPR kernel appends (room for every task)
   const size_t list_off = (wire_bytes + 15) & ~(size_t)15;
@@ -657,7 +660,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // launches the full kernel and waits again.  An empty launch held the stream for 0.1-0.18 ms of a 1.6 ms call
   // (profiles/r03_trace_overlap.txt).  BPSW_EXT_LAZY_FULL=0: always launch it.
   static const bool lazy_on = !(getenv("BPSW_EXT_LAZY_FULL") && atoi(getenv("BPSW_EXT_LAZY_FULL")) == 0);
-  const bool lazy_full = lazy_on && !side_how && use_short && with_list && n_long == 0 && 16 * (size_t)n_mid <= (size_t)n;
+  const bool lazy_full = lazy_on && !side_how && use_short && with_list && n_long == 0;
   const bool use_full = expect_full || (with_list && !lazy_full);
   const size_t out_post_bytes = out_bytes + (lazy_full ? 4 : 0);
   // (32-byte result slots in the pinned buffer were tried: the 16 + 4 byte stores of a record then cost two write sectors each,
@@ -794,7 +797,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         // (this is the launch that is NOT late -- the classify entry, BPSW_EXT_LAZY_FULL=0, or tasks the host listed itself: a quarter of
         // the mid tasks sizes it, at least one workgroup; the late launch below is sized by the posted length of the list)
         const bool may_defer = use_short && !inline_wide;
-        const int grid_tasks = !use_short ? n : n_long + (may_defer ? std::max(4, (n_mid + 3) / 4) : 0);
+        const int grid_tasks = !use_short ? n : n_long + (may_defer ? 4 : 0);  // (a wide band defers nothing since round 5: room for the unexpected only)
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, grid_tasks, k_out, sc, mq, mr, c->num_cu, d_queue, nullptr, s,
                                   nullptr, false, kev, false, use_short ? d_list : nullptr));
       }

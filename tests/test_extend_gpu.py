@@ -382,11 +382,13 @@ def test_many_long_flanks_are_swept_where_they_are(ctx, orc, w):
     assert ctx.stats().ext_full_relaunches == before
 
 
-@pytest.mark.parametrize("w,must_defer", [(100, False), (70, True), (127, True)])
-def test_full_kernel_is_launched_late_when_the_short_kernel_deferred(ctx, orc, w, must_defer):
-    """bpsw_runtime.cpp (lazy_full): a batch without flanks above 255 bases and with few of 128-255 gets the full kernel only if
-    the short kernel put something on its list -- the count comes back with the results, the call launches the full kernel behind
-    and waits again.  Same results as the oracle whether the second launch happens or not; bpsw_stats_t counts the second launches."""
+@pytest.mark.parametrize("w,must_defer", [(100, False), (70, False), (127, False)])
+def test_wide_bands_of_mid_flanks_are_swept_in_place(ctx, orc, w, must_defer):
+    """Flanks of 128-255 bases whose band outgrows the 128-column window (w = 70 / 127: the doubled band of a retry; w = 127: the first
+    row) were deferred to the full kernel through round 4 -- a second launch behind the short kernel (bpsw_runtime.cpp, lazy_full).
+    Since round 5 the adaptive sweep goes on four columns per lane (bpsw_extend_rows.h, rows_cpp4): same results as the oracle, and
+    no second launch (bpsw_stats_t::ext_full_relaunches stays where it is).  The late launch itself is still exercised by
+    test_an_unexpected_band_overflow_is_deferred_not_trapped."""
     rng = np.random.default_rng(77 + w)
     tasks = []
     for t in range(2400):
@@ -407,8 +409,7 @@ def test_full_kernel_is_launched_late_when_the_short_kernel_deferred(ctx, orc, w
     for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
         _check(ctx, orc, soa, zmode=zmode)
     late = ctx.stats().ext_full_relaunches - before
-    if must_defer and os.environ.get("BPSW_EXT_LAZY_FULL", "1") != "0":
-        assert late > 0   # w = 70 / 127: the doubled band of a retry outgrows the 128-column window
+    assert late == 0 and not must_defer
     # a batch with nothing between 128 and 255 bases never has a list
     short = _manual_tasks([t for t in tasks if max(len(t[0]), len(t[2])) < 128])
     short.w = w

@@ -41,7 +41,7 @@ for _ in range(n):
     q_off.append(at); pool.append(q); at += L
     t_off.append(at); pool.append(t); at += len(t); t_len.append(len(t))
 z32, z64 = np.zeros(n, np.int32), np.zeros(n, np.int64)
-h0 = np.full(n, 30, np.int32)
+h0 = np.full(n, int(os.environ.get("H0", "30")), np.int32)
 soa = bpsw_hip.ExtTaskSoA(pool=np.concatenate(pool + [np.zeros(16, np.uint8)]), left_qlen=z32, left_rlen=z32, left_q_off=z64, left_r_off=z64,
                           right_qlen=np.full(n, L, np.int32), right_rlen=np.array(t_len, np.int32), right_q_off=np.array(q_off, np.int64),
                           right_r_off=np.array(t_off, np.int64), reg_score=h0, h0=h0, q_beg=z32, idx=np.arange(n, dtype=np.int32))
