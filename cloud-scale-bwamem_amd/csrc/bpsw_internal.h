@@ -366,6 +366,8 @@ struct CopyLane {
 };
 CopyLane& copy_lane(int device);
 double wall_ms();
+void ext_call_mark(int device);      // an extension call of the device begins / ends now (bpsw_runtime.cpp)
+double ext_call_age_ms(int device);  // ms since the last such mark (huge: never)
 double stat_ms();  // wall_ms, or the thread CPU clock with BPSW_STATS_CLOCK=cpu (bpsw_runtime.cpp)
 // rescue launches (sw_stage_run) between their launch and the end of their wait, per device: the extension path shapes its bulk copies
 // by it (extend_batch_impl)

@@ -34,7 +34,7 @@ struct RingService {
   RingCtr* ctr = nullptr;
   size_t d_zero_bytes = 0;  // control block + counters: cleared at every epoch start
   hipStream_t stream = nullptr;
-  int blocks = 0;
+  int blocks = 0, num_cu = 256;
   unsigned long long ticks_per_us = 100;
   // statistics (under mu)
   uint64_t epochs = 0, submitted = 0, carried = 0;
@@ -83,14 +83,7 @@ int init_service(RingService& S, int device, int c_class, int num_cu) {
   }
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) S.ticks_per_us = (unsigned long long)(khz / 1000 > 0 ? khz / 1000 : 1);
-  // Worker workgroups per CU (four wavefronts each).  The resident grid holds its wave slots for as long as the epoch lives, and more
-  // workers are not more throughput: the device is shared with the extension kernels, and what a worker more takes from them costs the
-  // step more than a batch's units waiting a little for a free worker.  Measured on the bench (configs[2], 32 threads): 0.5 / 0.75 / 1 /
-  // 1.25 / 1.5 / 2 / 3 workgroups per CU = 1.63 / 2.34 / 2.35 / 2.26 / 2.20 / 2.05 / 1.70 x 10^8 reads/s; configs[4] (mates of 250
-  // bases, the second class; the step is the extension's): 0.5 / 1 / 2 = 2.28 / 2.12 / 1.96 x 10^7.
-  const double per_cu = getenv("BPSW_RING_WG_PER_CU") ? atof(getenv("BPSW_RING_WG_PER_CU")) : (c_class == 3 ? 1.0 : 0.5);
-  int blocks = (int)(num_cu * (per_cu > 0.0 ? per_cu : 1.0));
-  S.blocks = blocks < 2 ? 2 : blocks;
+  S.num_cu = num_cu;
   S.inited = true;
   return BPSW_OK;
 }
@@ -115,6 +108,23 @@ int start_epoch(RingService& S) {
   A.sleep_ticks_us = S.ticks_per_us;
   A.idle_ticks = (unsigned long long)env_int("BPSW_RING_IDLE_US", 2000) * S.ticks_per_us;
   A.worker_idle_ticks = (unsigned long long)env_int("BPSW_RING_WORKER_IDLE_US", 50000) * S.ticks_per_us;
+  {
+    // Worker workgroups per CU (four wavefronts each).  The resident grid holds its wave slots for as long as the epoch lives, and more
+    // workers are not more throughput: the device is shared with the extension kernels, and what a worker more takes from them costs the
+    // step more than a batch's units waiting a little for a free worker.  Measured on the bench (configs[2], 32 threads): 0.5 / 0.75 / 1 /
+    // 1.25 / 1.5 / 2 / 3 workgroups per CU = 1.63 / 2.34 / 2.35 / 2.26 / 2.20 / 2.05 / 1.70 x 10^8 reads/s; configs[4] (mates of 250
+    // bases, the second class; the step is the extension's): 0.5 / 1 / 2 = 2.28 / 2.12 / 1.96 x 10^7.
+    // ... unless the rescue path has the device to itself (no extension call on it for 20 ms: an executor that runs boundary 1 only, or
+    // a phase of a job): then the wave slots are nobody else's.  Rescue calls alone, 0.5 / 1 / 2 / 3 / 4 workgroups per CU: mates of 250
+    // bases 0.42 / 0.83 / 1.10 / 1.03 / 0.93 x 10^8 reads/s (a launch per batch: 1.18); mates of 150 bases 1 / 2 / 3 / 4 / 5: 3.44 / 2.93 /
+    // 2.98 / 2.24 / 1.96 (3.67; host-bound) -- so only the second class grows, to 2.  The choice holds for the epoch (it ends with its
+    // 16 384 batches or 2 ms after the last one).  BPSW_RING_WG_PER_CU fixes it.
+    const bool alone = ext_call_age_ms(S.device) > 20.0;
+    const double dflt = S.c_class == 3 ? 1.0 : (alone ? 2.0 : 0.5);
+    const double per_cu = getenv("BPSW_RING_WG_PER_CU") ? atof(getenv("BPSW_RING_WG_PER_CU")) : dflt;
+    const int blocks = (int)(S.num_cu * (per_cu > 0.0 ? per_cu : 1.0));
+    S.blocks = blocks < 2 ? 2 : blocks;
+  }
   hipError_t e = hipMemsetAsync(S.d_block, 0, S.d_zero_bytes, S.stream);  // behind the previous epoch's kernel, in stream order
   const int slot = (int)(S.epoch & 1u);
   if (e == hipSuccess && !S.ev_begin[slot]) {

@@ -314,6 +314,15 @@ int stream_share() {
 }
 }  // namespace
 
+// when the last extension call of any context of the device began or ended (wall_ms): the ring sizes an epoch's worker grid by whether
+// the rescue path has the device to itself (bpsw_ring.cpp)
+static std::atomic<long long> g_ext_last_us[64];
+void ext_call_mark(int device) { g_ext_last_us[device >= 0 && device < 64 ? device : 0].store((long long)(wall_ms() * 1e3), std::memory_order_relaxed); }
+double ext_call_age_ms(int device) {
+  const long long t = g_ext_last_us[device >= 0 && device < 64 ? device : 0].load(std::memory_order_relaxed);
+  return t == 0 ? 1e12 : wall_ms() - (double)t * 1e-3;
+}
+
 CopyLane& copy_lane(int device) {
   static CopyLane table[64];
   return table[device >= 0 && device < 64 ? device : 0];
@@ -693,6 +702,8 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   HIP_TRY(c->h_stage_out.reserve(zc_slots ? 32 * (size_t)n : out_post_bytes));
   if (lazy_full) *(volatile int*)((char*)c->h_stage_out.ptr + out_bytes) = 0;
   const double t_in = stat_ms();
+  ext_call_mark(c->device);
+  struct ExtMark { int d; ~ExtMark() { ext_call_mark(d); } } ext_mark{c->device};
   if (!staged) memcpy(c->h_stage_in.ptr, wire, wire_bytes);
   if (with_list) {  // rides on the same copy
     int* hl = (int*)((char*)c->h_stage_in.ptr + list_off);

@@ -117,12 +117,12 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
   if (ring_class) {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
     const double t_dev0 = stat_ms();
-    // Where the workers read the batch from.  Reading it from the pinned block (zero-copy, what a launch of its own does) costs a job
-    // pair about eight dependent round trips over PCIe, and the link does not take thousands of waves doing that at once: with more
-    // than ~2 500 job pairs in flight every one of them slows down, with 4 000 the total rate FALLS (32 threads of rescue calls alone:
-    // 4.2 ms per call instead of 0.5).  The resident kernel keeps every worker busy, so its batches come by copy engine -- one bulk
-    // transfer into the context's device arena, waited for before the descriptor is published -- and the workers read HBM.  Small
-    // batches (BPSW_RING_ZC_BYTES, default 16 KB) stay zero-copy: the copy's latency would be most of their call.
+    // Where the workers read the batch from.  A launch of its own reads it from the pinned block (zero-copy); under the resident kernel a
+    // job pair that does so pays about eight dependent round trips over PCIe and takes 160-190 us instead of 145-155 (BPSW_RING_DIAG
+    // build, one worker wave per SIMD; 390 against 320 with three), and the bench step is a fifth slower (1.73 against 2.05 x 10^8 reads/s at
+    // two worker workgroups per CU).  So a batch is copied into the context's device arena by the copy engine -- one bulk transfer,
+    // waited for before the descriptor is published -- and the workers read HBM.  Small batches (BPSW_RING_ZC_BYTES, default 16 KB) stay
+    // zero-copy: the copy's latency would be most of their call.
     static const size_t ring_zc_bytes = getenv("BPSW_RING_ZC_BYTES") ? (size_t)atoll(getenv("BPSW_RING_ZC_BYTES")) : 16384;
     if (st.total > ring_zc_bytes) {
       HIP_TRY(c->d_sw_in.reserve(st.total));
