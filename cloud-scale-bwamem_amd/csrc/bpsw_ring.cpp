@@ -138,6 +138,10 @@ int start_epoch(RingService& S) {
     S.ev_pending[slot] = false;
   }
   if (e == hipSuccess) e = hipEventRecord(S.ev_begin[slot], S.stream);
+  // (test hook, BPSW_RING_TEST_FAIL_LAUNCH=k: the k-th epoch launch of a ring "fails" -- tests/test_ring_gpu.py checks that its callers
+  // go on with a launch per batch)
+  static const int fail_at = env_int("BPSW_RING_TEST_FAIL_LAUNCH", 0);
+  if (e == hipSuccess && fail_at > 0 && S.epochs + 1 == (uint64_t)fail_at) e = hipErrorLaunchFailure;
   if (e == hipSuccess) e = launch_swp_resident(S.c_class, A, S.blocks, S.stream);
   if (e == hipSuccess) { e = hipEventRecord(S.ev_end[slot], S.stream); S.ev_pending[slot] = e == hipSuccess; }
   if (e != hipSuccess) { S.broken = true; return hip_fail_ring(e, "epoch launch"); }

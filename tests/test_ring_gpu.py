@@ -173,3 +173,48 @@ def test_ring_used_up_rolls_over_to_the_next_epoch():
     r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RING" in r.stdout
+
+
+_FAIL = r"""
+import os, sys, threading
+import numpy as np
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {orc!r})
+import bpsw_hip
+from bpsw_hip import synth
+import pyoracle as po
+XTRA = po.KSW_XSUBO | po.KSW_XSTART | po.KSW_XBYTE | 19
+orc = po.Oracle()
+jobs = synth.sw_jobs(200, seed=580)
+want = orc.sw_align2_jobs(orc.default_opt(), XTRA, **jobs)[0]
+errs = []
+def worker(t):
+    try:
+        c = bpsw_hip.Context(0)
+        for _ in range(20):
+            assert np.array_equal(c.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs), want)
+        c.close()
+    except BaseException as e:
+        errs.append(repr(e))
+ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+[t.start() for t in ts]; [t.join(300) for t in ts]
+assert not errs, errs[:2]
+c = bpsw_hip.Context(0)
+assert np.array_equal(c.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs), want)
+print("RINGCALLS", c.stats().sw_ring_calls, c.ring_stats())
+c.close()
+"""
+
+
+def test_a_ring_that_cannot_launch_sends_its_callers_back_to_launches():
+    """BPSW_RING_TEST_FAIL_LAUNCH=1: the first epoch launch of the ring "fails".  The call that met the failure and every later one take
+    a kernel launch of their own, as before round 5 -- bit-exact, one line on stderr, no error to the caller, nobody left waiting."""
+    if not RING_ON:
+        pytest.skip("BPSW_RING=0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BPSW_RING_TEST_FAIL_LAUNCH="1")
+    src = _FAIL.format(pkg=os.path.join(root, "cloud-scale-bwamem_amd"), orc=os.path.join(root, "oracle"))
+    r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RINGCALLS")][0]
+    assert line.split()[1] == "0", line              # the last context never used the ring
+    assert "submission ring of device 0 failed" in r.stderr
