@@ -628,7 +628,7 @@ def main():
             if "ext_sift_kernel<false>" in nm or "ext_kernel<false" in nm:
                 ext_total_ns += float(r["TotalDurationNs"])
                 trace_share["extend"] = trace_share.get("extend", 0.0) + float(r["Percentage"]) * 1e-2
-                if "ext_kernel<false, 1>" in nm or "ext_kernel<false, 2>" in nm:   # the short kernel (2: the build that sweeps wide bands itself)
+                if "ext_kernel<false, 1>" in nm:   # the short kernel
                     ext_calls += int(r["Calls"])
             elif "swp_resident_kernel" in nm and "swalign2_resident" not in trace_avg:
                 trace_avg["swalign2_resident"] = round(float(r["AverageNs"]) * 1e-6, 4)

@@ -15,10 +15,10 @@
 // band trimming loops (SWUtil.scala:202-214) are evaluated on 64-bit zero masks held in SGPRs, so all row control is scalar.
 // Before any DP a flank goes through the exact shortcuts (closed forms, certificates: bpsw_extend_core.h), which resolve most
 // flanks of low-error reads -- for large batches of short flanks in a kernel of their own in front of this one (bpsw_extend_sift.hip:
-// one task per lane), which leaves a flag and a verdict per side here (sift_flag, sift_recs).  Three builds (ext_kernel<COORD, SHORT>): SHORT = 1, the 64-VGPR short kernel at eight waves per SIMD for flanks up to 255 bases
-// (the adaptive sweep of bpsw_extend_rows.h; a band that outgrows its 128-column window defers the task to a list); SHORT = 2, the same
-// for batches with many flanks of 128-255 bases, sweeping such a band itself with the slot sweep instead of deferring; SHORT = 0, the
-// full kernel (slot sweeps, an LDS-row sweep for flanks above 255 bases) for what the host lists or the short build defers.
+// one task per lane), which leaves a flag and a verdict per side here (sift_flag, sift_recs).  Two builds (ext_kernel<COORD, SHORT>):
+// SHORT = 1, the 64-VGPR short kernel at eight waves per SIMD for flanks up to 255 bases (the adaptive sweep of bpsw_extend_rows.h: one,
+// two or four columns per lane on a window that follows the band); SHORT = 0, the full kernel (slot sweeps, an LDS-row sweep for
+// flanks above 255 bases) for what the host lists.
 #include <stdlib.h>
 
 #include <atomic>
@@ -71,29 +71,17 @@ __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16)
 // reads).  It carries only the adaptive sweep (bpsw_extend_rows.h: one / two columns per lane on a window that follows the band,
 // row loops in assembly) and the shortcuts, needs 64 VGPRs instead of 87 and little LDS (the target bytes and the call's query
 // profile), so eight of its waves share a SIMD.  It skips longer tasks: the host, which has seen every record (scan_wire), lists
-// those for the full kernel.  A task that turns out to need what this kernel lacks -- a band wider than the 128-column window, on
-// its first row (the doubled band of a retry) or later: only possible with a flank of 128 bases or more -- is DEFERRED: appended to
-// the same list (defer[0] = entries so far, defer[1..] = task indices), which the full kernel, launched behind this one on the
-// stream, reads its task count from.  (Rounds 2-3 had two such builds, one for flanks up to 127 bases without the window; since
-// the adaptive sweep of round 3 they were the same code, and round 4 made them one: 2x150 bp batches no longer send their few
-// flanks of 128-131 bases through a full-kernel launch of their own.)
-// SHORT = 2: the short kernel for batches in which MANY tasks may outgrow the window (2x250 bp reads: one task in five has a flank of
-// 128+ bases): a band that does not fit is swept right here, by the full kernel's slot sweep for THIS side and band -- no list, no
-// second launch, and nothing the wave has already computed (the other side, the first band) is computed again.  Round 4: the full
-// kernel's launch behind such a batch was 31 % of the call's kernel time (profiles/r04_cfg5_kernel_stats_before_inline_wide.csv), half of it
-// recomputation, most of the rest a tail of few long tasks.  Built for eight waves per SIMD like SHORT = 1: the slot sweep then
-// spills 34 VGPRs (it is the rare path), and the 2x250 bp step runs 4 % faster than with the 96 VGPRs the sweep would like (2.08 /
-// 2.15 / 2.17 x 10^7 reads/s at 5 / 6 / 8 waves per SIMD: beside the rescue kernel's waves, residency does count).  The extension
-// calls alone: 2.28 -> 2.74 x 10^7; with the rescue launches filling the device meanwhile: 2.14 -> 2.18.
+// those for the full kernel.  Since round 5 no band of such a flank leaves the adaptive sweep (its four-columns-per-lane phase holds 256
+// columns; rounds 3-4 deferred a band wider than 128 columns to the full kernel, or -- a second build, ext_kernel<., 2>, for 2x250 bp
+// batches -- swept the side again with the slot sweep): a task is DEFERRED -- appended to the full kernel's list (defer[0] = entries so
+// far, defer[1..] = task indices), which the full kernel, launched behind this one on the stream, reads its task count from -- only by
+// the asynchronous device entry, where no host has listed the long tasks, and by the test hook below.
 // SHORT = 0: the full kernel (slot sweeps for wide bands, an LDS-row sweep for flanks above 255 bases).
 template <bool COORD, int SHORT>
 #ifndef BPSW_EXT_SHORT_WAVES_PER_SIMD
 #define BPSW_EXT_SHORT_WAVES_PER_SIMD 8
 #endif
-#ifndef BPSW_EXT_WIDE_WAVES_PER_SIMD
-#define BPSW_EXT_WIDE_WAVES_PER_SIMD 8
-#endif
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_WAVES_PER_SIMD : SHORT == 2 ? BPSW_EXT_WIDE_WAVES_PER_SIMD : BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks_arg,
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_PER_SIMD : BPSW_EXT_WAVES_PER_SIMD) void ext_kernel(const uint32_t* __restrict__ wire, const int n_tasks_arg,
                                                                      int16_t* __restrict__ out, const ExtScoring sc,
                                                                      const int qcap, const int rcap,
                                                                      const int lds_per_wave, const int chunk, const int guide_cap,
@@ -125,8 +113,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
   int* prof_w = reinterpret_cast<int*>(base + (((size_t)rcap + 15) & ~(size_t)15));
   const ProfLds pl = {prof_w, reinterpret_cast<int8_t*>(prof_w + qcap + 2),
                       (unsigned)(uintptr_t)((__attribute__((address_space(3))) int*)prof_w)};
-  // (SHORT == 2) the LDS row of the slot sweep's hand-over (sw_extend_reg_any), behind the profile
-  int2* eh_wide = reinterpret_cast<int2*>(base + (((size_t)rcap + 15) & ~(size_t)15) + ((5 * ((size_t)qcap + 2) + 15) & ~(size_t)15));
 
   // header, MemChainToAlignBatched.scala:78-84 (signed bytes)
   const uint32_t hdr0 = wire[0], hdr1 = wire[1];
@@ -208,7 +194,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
     // them itself; short_qmax > 0: the host has listed them for the full kernel
     bool deferred = false;
     // (test hook, BPSW_EXT_INJECT_DEFER=k: every k-th task of a deferring launch takes the way of a band that outgrew the window)
-    if (SHORT == 1 && inject_defer > 0 && task % inject_defer == 0) deferred = true;
+    if (SHORT && inject_defer > 0 && task % inject_defer == 0) deferred = true;
     if (SHORT) {
       const int qm = short_qmax < 0 ? -short_qmax : short_qmax;
       const bool too_long = lq > qm || rq > qm || (short_qmax < 0 && oIns + eIns <= 0);
@@ -301,13 +287,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
 #else
           r = sw_extend_reg_short<true>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
 #endif
-          if (uni(ov)) {
-            if constexpr (SHORT == 2) {  // a band wider than the window: the slot sweep of this side and band, here and now
-              r = sw_extend_reg_any(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, eh_wide);
-            } else {
-              deferred = true;
-              break;
-            }
+          if (uni(ov)) {  // (never since round 5: sw_extend_adaptive holds every band of a flank this kernel takes)
+            deferred = true;
+            break;
           }
         } else if (reg_path) {
           // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
@@ -321,7 +303,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
         regScore = uni(r.max);
         if (regScore == prev || r.max_off < (awSide >> 1) + (awSide >> 2)) break;
       }
-      if (SHORT == 1 && deferred) break;
+      if (SHORT && deferred) break;
       score = regScore;
       awMax = max(awMax, awSide);
       const bool local = r.gscore <= 0 || r.gscore <= regScore - penClip;  // local extension vs reaching the query end
@@ -335,7 +317,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT == 1 ? BPSW_EXT_SHORT_W
         trueScore += (local ? regScore : r.gscore) - sc0;
       }
     }
-    if (SHORT == 1 && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
+    if (SHORT && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
       // (every deferring launch has a list: launch_ext_kernel refuses one without.  A batch whose flanks all have at most 127 bases
       // is not expected to defer anything -- their bands fit the 128-column window -- but if a row loop ever said otherwise, the
       // task goes to the full kernel like any other deferred one instead of trapping the executor's process: round 4 trapped)
@@ -408,28 +390,25 @@ void launch_ext_prepass(const uint32_t* d_wire, size_t wire_words, int n_tasks, 
 hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int qcap,
                              int rcap, int num_cu, int* d_counter, const int* d_task_list, hipStream_t s,
                              const ExtPrepass* d_pre_check, bool counter_zeroed, KernelEvents kev, bool short_kernel, int* d_defer,
-                             int short_qmax, const uint8_t* d_sift_flag, const uint4* d_sift_recs, int* d_defer_post, const int* d_todo_list,
-                             bool inline_wide) {
+                             int short_qmax, const uint8_t* d_sift_flag, const uint4* d_sift_recs, int* d_defer_post, const int* d_todo_list) {
   if (n_tasks <= 0) return hipSuccess;  // (the full kernel behind a SHORT launch: n_tasks = the most its device-side list can hold)
-  if (short_kernel && !inline_wide && !d_defer) return hipErrorInvalidValue;  // the deferring build needs somewhere to defer to
+  if (short_kernel && !d_defer) return hipErrorInvalidValue;  // the deferring build needs somewhere to defer to
   static const int inject_env = getenv("BPSW_EXT_INJECT_DEFER") ? atoi(getenv("BPSW_EXT_INJECT_DEFER")) : 0;  // test hook (tests/test_extend_gpu.py)
-  const int inject_defer = short_kernel && !inline_wide ? inject_env : 0;
+  const int inject_defer = short_kernel ? inject_env : 0;
   const bool coord = sc.pac != nullptr;  // a coordinate batch (the caller sets ExtScoring::pac only for those)
-  const int variant = short_kernel ? (inline_wide ? 2 : 1) : 0;
+  const int variant = short_kernel ? 1 : 0;
   const void* fn = variant == 0 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 0>) : reinterpret_cast<const void*>(ext_kernel<false, 0>))
-                 : variant == 1 ? (coord ? reinterpret_cast<const void*>(ext_kernel<true, 1>) : reinterpret_cast<const void*>(ext_kernel<false, 1>))
-                                : (coord ? reinterpret_cast<const void*>(ext_kernel<true, 2>) : reinterpret_cast<const void*>(ext_kernel<false, 2>));
+                                : (coord ? reinterpret_cast<const void*>(ext_kernel<true, 1>) : reinterpret_cast<const void*>(ext_kernel<false, 1>));
   // round the capacities so that a handful of LDS configurations cover all batches
   qcap = (qcap + 31) & ~31;
   rcap = (rcap + 63) & ~63;
   // short kernels: the target bytes, then the call's query profile (qcap + 2 words and bytes: ProfLds, bpsw_extend_rows.h)
-  const size_t per_wave = short_kernel ? (((size_t)rcap + 15) & ~(size_t)15) + ((5 * ((size_t)qcap + 2) + 15) & ~(size_t)15) +
-                                             (variant == 2 ? ((8 * ((size_t)qcap + 2) + 15) & ~(size_t)15) : 0)   // + the slot sweep's hand-over row
+  const size_t per_wave = short_kernel ? (((size_t)rcap + 15) & ~(size_t)15) + ((5 * ((size_t)qcap + 2) + 15) & ~(size_t)15)
                                        : ext_lds_per_wave(qcap, rcap);
   const size_t lds = per_wave * WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // the opt-in to > 64 KB of dynamic LDS is a property of the function ON A DEVICE: remember the largest size per device
-  static std::atomic<size_t> attr_set_v[6][64];
+  static std::atomic<size_t> attr_set_v[4][64];
   std::atomic<size_t>* attr_set = attr_set_v[(coord ? 1 : 0) + 2 * variant];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -470,8 +449,6 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
               (int)per_wave, chunk, guide_cap, d_counter, d_task_list, d_pre_check, d_defer, short_qmax, d_sift_flag, d_sift_recs, d_defer_post, d_todo_list, inject_defer)
   if (variant == 1) {
     if (coord) BPSW_EXT_GO(true, 1); else BPSW_EXT_GO(false, 1);
-  } else if (variant == 2) {
-    if (coord) BPSW_EXT_GO(true, 2); else BPSW_EXT_GO(false, 2);
   } else {
     if (coord) BPSW_EXT_GO(true, 0); else BPSW_EXT_GO(false, 0);
   }

@@ -41,9 +41,12 @@ struct RowState {
 };
 // four columns per lane (rows_cpp4: bands wider than 127 columns): columns base + 4 lane + 0..3.  Kept apart from RowState so that
 // it is live only inside the wide phase of a call -- RowState rides through the assembly loops in registers
+// (named scalars, not arrays: an int[4] that is copied as a whole becomes a <4 x i32> value -- four CONSECUTIVE, aligned VGPRs -- and the
+// row loop's state in such tuples was part of what round 5's first build of rows_cpp4 spilled)
 struct Row4 {
-  int H[4], E[4], plo[4];
+  int H0, H1, H2, H3, E0, E1, E2, E3, plo0, plo1, plo2, plo3;
 };
+#define ROWS4_EACH(M) M(0) M(1) M(2) M(3)
 enum { ROWS_DONE = 0, ROWS_MORE = 1, ROWS_OTHER_MODE = 2, ROWS_SLOW = 3, ROWS_OVERFLOW = 4 };
 constexpr int ROWS_NARROW = 52;  // a band of at most this many columns goes (back) to one column per lane; wider than 63 must leave it
 
@@ -234,20 +237,26 @@ __device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int 
 //   ROWS_OTHER_MODE  the next row's band fits ROWS4_NARROW columns again (the row has not been touched): back to two columns per lane
 constexpr int ROWS4_NARROW = 100;
 __device__ __forceinline__ void rows_load_profile4(Row4& q, const int base, const ProfLds& pl, const int qLen, const int lane) {
-  const int j0 = base + 4 * lane;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) q.plo[c] = pl.prof[min(j0 + c, qLen)];
+  // (opaque: the four LDS addresses take two instructions each to form; hoisted out of the row loops they were four VGPRs that lived --
+  // in scratch memory -- through the whole side)
+  int l4 = 4 * lane;
+  asm volatile("" : "+v"(l4));
+  const int j0 = base + l4;
+#define ROWS4_M(c) q.plo##c = pl.prof[min(j0 + c, qLen)];
+  ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
 }
 __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane, const int qLen, const int tLen, const ProfLds& pl, const uint8_t* __restrict__ ts,
                          const int oDel, const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
                          const int zmode, const int h0, const int amax) {
   constexpr int C = 4, WIN = 256;
   const int oeDel = oDel + eDel, oeIns = oIns + eIns;
-  const int jE0 = C * lane * eIns - oeIns;  // j*eIns - oeIns of the lane's first column, j counted from the window's origin
+  const int lane4 = C * lane;
+  const int jE0 = lane4 * eIns - oeIns;  // j*eIns - oeIns of the lane's first column, j counted from the window's origin
   const int kC = oeIns - eIns;
   int i = st.i, beg = st.beg, end = st.end, h1raw = st.h1raw, mx = st.mx, max_i = st.max_i, max_j = st.max_j, max_ie = st.max_ie;
   int gscore = st.gscore, max_off = st.max_off, base = st.base;
-  int Hs[C] = {q.H[0], q.H[1], q.H[2], q.H[3]}, Es[C] = {q.E[0], q.E[1], q.E[2], q.E[3]};
+  int Hs0 = q.H0, Hs1 = q.H1, Hs2 = q.H2, Hs3 = q.H3, Es0 = q.E0, Es1 = q.E1, Es2 = q.E2, Es3 = q.E3;
   const int i_tail = amax > 0 ? qLen : 0x7fffffff;
   const int w1 = w + 1;
   int ret = ROWS_DONE;
@@ -263,59 +272,61 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane, 
     if (nend - base > WIN - 1) {  // column `end` lies beyond the window: move the window up to the band's left end (always fits: qLen <= 255)
       const int nb = nbeg & ~3;
       const int from = (lane + ((nb - base) >> 2)) << 2;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        Hs[c] = __builtin_amdgcn_ds_bpermute(from, Hs[c]);
-        Es[c] = __builtin_amdgcn_ds_bpermute(from, Es[c]);
-      }
+#define ROWS4_M(c) Hs##c = __builtin_amdgcn_ds_bpermute(from, Hs##c); Es##c = __builtin_amdgcn_ds_bpermute(from, Es##c);
+      ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
       base = nb;
       rows_load_profile4(q, base, pl, qLen, lane);
     }
     beg = nbeg; end = nend;
-    const int plo[C] = {q.plo[0], q.plo[1], q.plo[2], q.plo[3]};
     const int tsv = __builtin_amdgcn_readfirstlane((int)ts[i]);  // 8 * target base
     h1raw -= eDel;
     const int h1 = smax2(0, h1raw);  // SWUtil.scala:137-138
     const int rbeg = beg - base;
     const unsigned spanA = (unsigned)smax2(end - beg, 0);
     const int span = end - beg;
-    int scv[C];
+    int scv0, scv1, scv2, scv3;
     if (__builtin_expect(tsv == 32, 0)) {  // an N row
-#pragma unroll
-      for (int c = 0; c < C; ++c) scv[c] = (int)pl.profn[min(base + C * lane + c, qLen)];
+      int l4 = C * lane;
+      asm volatile("" : "+v"(l4));  // (as in rows_load_profile4)
+#define ROWS4_M(c) scv##c = (int)pl.profn[min(base + l4 + c, qLen)];
+      ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
     } else {
-#pragma unroll
-      for (int c = 0; c < C; ++c) scv[c] = __builtin_amdgcn_sbfe(plo[c], (unsigned)tsv, 8u);
+#define ROWS4_M(c) scv##c = __builtin_amdgcn_sbfe(q.plo##c, (unsigned)tsv, 8u);
+      ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
     }
-    bool act[C];
-    unsigned rel[C];
-    int a[C], Pg[C];
-    int Pl = NEG, scan_a = NEG_A * 256;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      rel[c] = (unsigned)(C * lane + c - rbeg);
-      act[c] = rel[c] < spanA;
-      a[c] = act[c] ? max(Hs[c] + scv[c], Es[c]) : NEG_A;
-      Pg[c] = a[c] + jE0 + c * eIns;
-      Pl = max(Pl, Pg[c]);
-      scan_a = max(scan_a, (a[c] << 8) | (C * lane + c));  // the row maximum and its LAST column in one scan (columns 0..255)
-    }
+    // Everything per column is kept RELATIVE to the lane's first column (the j*eIns terms as c*eIns, the column number as c): the only
+    // lane-dependent constants of the loop are lane4 and jE0.  (With the absolute forms the compiler kept a dozen of them -- j*eIns -
+    // oeIns, kC + ..., 4 lane + c per c -- in VGPRs it had to spill around every side: 84-104 bytes of scratch per lane, 12 MB of
+    // write-backs per launch, profiles/pmc_traffic.json of round 5's first build.)
+    const int rel0 = lane4 - rbeg;  // the lane's first column, counted from the band's left end
+#define ROWS4_M(c)                                                \
+    const bool act##c = (unsigned)(rel0 + c) < spanA;             \
+    const int a##c = act##c ? max(Hs##c + scv##c, Es##c) : NEG_A; \
+    const int Pg##c = a##c + c * eIns;
+    ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
+    // the lane's maximum and its LAST column
+    const int k4 = max(max3i((a0 << 2) | 0, (a1 << 2) | 1, (a2 << 2) | 2), (a3 << 2) | 3);
+    int Pl = max(max3i(Pg0, Pg1, Pg2), Pg3) + jE0;
+    int scan_a = ((k4 & ~3) << 6) | (k4 & 3) | lane4;  // a << 8 | column: the row maximum and its LAST column in one scan (columns 0..255)
     dual_scan_max(Pl, scan_a);
-    int pre = wave_shr1(NEG, Pl);  // the F prefix of the columns left of this lane
-    int H[C];
-    unsigned long long z[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      H[c] = max3i(a[c], pre - kC - jE0 - c * eIns, 0);
-      pre = max(pre, Pg[c]);
-      z[c] = __builtin_amdgcn_ballot_w64(H[c] < 1) & __builtin_amdgcn_ballot_w64(act[c]);
-      Es[c] = act[c] ? max3i(Es[c] - eDel, H[c] - oeDel, 0) : 0;
-    }
+    int pre = wave_shr1(NEG, Pl) - jE0;  // the F prefix of the columns left of this lane (+ j*eIns - oeIns, j from the lane's first column)
+#define ROWS4_M(c)                                                                                                \
+    const int H##c = max3i(a##c, pre - (kC + c * eIns), 0);                                                       \
+    pre = max(pre, Pg##c);                                                                                        \
+    const unsigned long long z##c = __builtin_amdgcn_ballot_w64(H##c < 1) & __builtin_amdgcn_ballot_w64(act##c); \
+    Es##c = act##c ? max3i(Es##c - eDel, H##c - oeDel, 0) : 0;
+    ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
     {  // the row shifted by one column: Hs(col) = H(i, col - 1); eh[beg].h = h1 (SWUtil.scala:153), written in every lane
-      const int hs = wave_shr1(h1, H[C - 1]);
-      Hs[0] = rel[0] == 0u ? h1 : hs;
-#pragma unroll
-      for (int c = 1; c < C; ++c) Hs[c] = rel[c] == 0u ? h1 : H[c - 1];
+      const int hs = wave_shr1(h1, H3);
+      Hs0 = rel0 == 0 ? h1 : hs;
+      Hs1 = rel0 == -1 ? h1 : H0;
+      Hs2 = rel0 == -2 ? h1 : H1;
+      Hs3 = rel0 == -3 ? h1 : H2;
     }
     const int mkey = smax2(0, __builtin_amdgcn_readlane(scan_a, 63));
     const int m = mkey >> 8, mjr = mkey & 255, mj = base + mjr;
@@ -325,8 +336,8 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane, 
       int hlast = h1;
       if (span > 0) {
         const int e = end - base;
-        const int v0 = __builtin_amdgcn_readlane(Hs[0], e >> 2), v1 = __builtin_amdgcn_readlane(Hs[1], e >> 2);
-        const int v2 = __builtin_amdgcn_readlane(Hs[2], e >> 2), v3 = __builtin_amdgcn_readlane(Hs[3], e >> 2);
+        const int v0 = __builtin_amdgcn_readlane(Hs0, e >> 2), v1 = __builtin_amdgcn_readlane(Hs1, e >> 2);
+        const int v2 = __builtin_amdgcn_readlane(Hs2, e >> 2), v3 = __builtin_amdgcn_readlane(Hs3, e >> 2);
         hlast = (e & 2) ? ((e & 1) ? v3 : v2) : ((e & 1) ? v1 : v0);
       }
       const bool better = gscore <= hlast;
@@ -345,32 +356,33 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane, 
     // band trimming, SWUtil.scala:202-214: the last zero column left of mj, the first zero column right of mj (columns of class c are
     // 4 lane + c: the zero masks are four interleaved bit sets)
     const int nb0 = beg + (h1 == 0 ? 1 : 0);
-    if ((z[0] | z[1] | z[2] | z[3]) == 0ull) {
+    if ((z0 | z1 | z2 | z3) == 0ull) {
       beg = nb0;
       end = end + 1;
     } else {
       int cl = -1, cr = 1 << 20;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        // (plain C, not the s_bfm / s_flbit / s_ff1 helpers of the two-column form: their "s" operands want values the compiler has
-        // PROVEN uniform, and it does not prove it for everything this loop derives them from)
-        const int cnt = (mjr + 3 - c) >> 2;  // lanes whose column of class c lies left of mj: 4 lane + c <= mjr - 1
-        const unsigned long long below = z[c] & (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull));
-        const int top = below ? 63 - (int)__builtin_clzll(below) : -1;  // the highest such lane with a zero cell
-        cl = smax2(cl, top >= 0 ? C * top + c : -1);
-        const int sc = (mjr + 4 - c) >> 2;   // first lane whose column of class c lies right of mj: 4 lane + c >= mjr + 1
-        const unsigned long long above = sc >= 64 ? 0ull : (z[c] >> sc);
-        const int f = above ? (int)__builtin_ctzll(above) : -1;
-        cr = smin2(cr, f >= 0 ? C * (sc + f) + c : 1 << 20);
+      // (plain C, not the s_bfm / s_flbit / s_ff1 helpers of the two-column form: their "s" operands want values the compiler has
+      // PROVEN uniform, and it does not prove it for everything this loop derives them from)
+#define ROWS4_M(c)                                                                                                        \
+      {                                                                                                                     \
+        const int cnt = (mjr + 3 - c) >> 2; /* lanes whose column of class c lies left of mj: 4 lane + c <= mjr - 1 */      \
+        const unsigned long long below = z##c & (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull));                               \
+        const int top = below ? 63 - (int)__builtin_clzll(below) : -1; /* the highest such lane with a zero cell */          \
+        cl = smax2(cl, top >= 0 ? C * top + c : -1);                                                                        \
+        const int sc = (mjr + 4 - c) >> 2; /* first lane whose column of class c lies right of mj: 4 lane + c >= mjr + 1 */ \
+        const unsigned long long above = sc >= 64 ? 0ull : (z##c >> sc);                                                    \
+        const int f = above ? (int)__builtin_ctzll(above) : -1;                                                             \
+        cr = smin2(cr, f >= 0 ? C * (sc + f) + c : 1 << 20);                                                                \
       }
+      ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
       beg = cl >= 0 ? base + cl + 2 : nb0;
       end = cr < (1 << 20) ? base + cr + 1 : end + 1;
     }
   }
   st.i = i; st.beg = beg; st.end = end; st.h1raw = h1raw; st.mx = mx; st.max_i = max_i; st.max_j = max_j; st.max_ie = max_ie;
   st.gscore = gscore; st.max_off = max_off; st.base = base;
-#pragma unroll
-  for (int c = 0; c < C; ++c) { q.H[c] = Hs[c]; q.E[c] = Es[c]; }
+  q.H0 = Hs0; q.H1 = Hs1; q.H2 = Hs2; q.H3 = Hs3; q.E0 = Es0; q.E1 = Es1; q.E2 = Es2; q.E3 = Es3;
   return ret;
 }
 
@@ -1479,11 +1491,11 @@ __device__ __forceinline__ int rows_wide_phase(RowState& st, Row4& q, const int 
   const int x = nb - st.base + 2 * lane;
   const int src = (x >> 2) << 2;
   const bool hi = (x & 2) != 0;
-  int hv[4], ev[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { hv[c] = __builtin_amdgcn_ds_bpermute(src, q.H[c]); ev[c] = __builtin_amdgcn_ds_bpermute(src, q.E[c]); }
-  st.H0 = hi ? hv[2] : hv[0]; st.H1 = hi ? hv[3] : hv[1];
-  st.E0 = hi ? ev[2] : ev[0]; st.E1 = hi ? ev[3] : ev[1];
+#define ROWS4_M(c) const int hv##c = __builtin_amdgcn_ds_bpermute(src, q.H##c), ev##c = __builtin_amdgcn_ds_bpermute(src, q.E##c);
+  ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
+  st.H0 = hi ? hv2 : hv0; st.H1 = hi ? hv3 : hv1;
+  st.E0 = hi ? ev2 : ev0; st.E1 = hi ? ev3 : ev1;
   st.base = nb;
   rows_load_profile<2>(st, pl, qLen, lane);
   return ROWS_OTHER_MODE;
@@ -1510,12 +1522,10 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
   if (cols == 4) {  // (w >= 127 and a flank of 128 bases or more: the first row is wider than the two-column window)
     Row4 q;
     st.base = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int j = 4 * lane + c;
-      q.H[c] = j == 0 ? h0 : max(0, h0 - oeIns - (j - 1) * eIns);  // row -1, SWUtil.scala:97-104
-      q.E[c] = 0;
-    }
+    // row -1, SWUtil.scala:97-104
+#define ROWS4_M(c) q.H##c = 4 * lane + c == 0 ? h0 : max(0, h0 - oeIns - (4 * lane + c - 1) * eIns); q.E##c = 0;
+    ROWS4_EACH(ROWS4_M)
+#undef ROWS4_M
     rows_load_profile4(q, 0, pl, qLen, lane);
     if (rows_wide_phase(st, q, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax) != ROWS_OTHER_MODE) {
       ExtRes res0;
@@ -1601,10 +1611,10 @@ __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int t
         Row4 q;
         const int nb = st.beg & ~3;
         const int srcA = (((nb - st.base) >> 1) + 2 * lane) << 2, srcB = srcA + 4;
-        q.H[0] = __builtin_amdgcn_ds_bpermute(srcA, st.H0); q.H[1] = __builtin_amdgcn_ds_bpermute(srcA, st.H1);
-        q.H[2] = __builtin_amdgcn_ds_bpermute(srcB, st.H0); q.H[3] = __builtin_amdgcn_ds_bpermute(srcB, st.H1);
-        q.E[0] = __builtin_amdgcn_ds_bpermute(srcA, st.E0); q.E[1] = __builtin_amdgcn_ds_bpermute(srcA, st.E1);
-        q.E[2] = __builtin_amdgcn_ds_bpermute(srcB, st.E0); q.E[3] = __builtin_amdgcn_ds_bpermute(srcB, st.E1);
+        q.H0 = __builtin_amdgcn_ds_bpermute(srcA, st.H0); q.H1 = __builtin_amdgcn_ds_bpermute(srcA, st.H1);
+        q.H2 = __builtin_amdgcn_ds_bpermute(srcB, st.H0); q.H3 = __builtin_amdgcn_ds_bpermute(srcB, st.H1);
+        q.E0 = __builtin_amdgcn_ds_bpermute(srcA, st.E0); q.E1 = __builtin_amdgcn_ds_bpermute(srcA, st.E1);
+        q.E2 = __builtin_amdgcn_ds_bpermute(srcB, st.E0); q.E3 = __builtin_amdgcn_ds_bpermute(srcB, st.E1);
         st.base = nb;
         rows_load_profile4(q, nb, pl, qLen, lane);
         if (rows_wide_phase(st, q, lane, qLen, tLen, pl, ts, oDel, eDel, oIns, eIns, w, zdrop, zmode, h0, amax) != ROWS_OTHER_MODE) break;

@@ -88,9 +88,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
                              const ExtPrepass* d_pre_check = nullptr, bool counter_zeroed = false, KernelEvents kev = KernelEvents(),
                              bool short_kernel = false, int* d_defer = nullptr, int short_qmax = 255,
                              const uint8_t* d_sift_flag = nullptr, const uint4* d_sift_recs = nullptr, int* d_defer_post = nullptr,
-                             const int* d_todo_list = nullptr, bool inline_wide = false);
-// (inline_wide: ext_kernel<., 2> -- the short kernel sweeps a band that outgrows its window itself, with the full kernel's slot sweep,
-// instead of deferring the task)
+                             const int* d_todo_list = nullptr);
 // The sift kernel (bpsw_extend_sift.hip): the exact shortcuts of every task of a format-1 batch, one task per lane, in front of
 // the 48-VGPR ext_kernel, which reads d_flag[task] (1: record written, skip; 2: d_recs[2 task + side] holds the verdict per side).
 // dm = a - (the one mismatch score of the matrix), sift_uniform_dm(); qmax = the longest flank the 48-VGPR build takes.

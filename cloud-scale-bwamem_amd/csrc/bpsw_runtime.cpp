@@ -644,9 +644,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // task to the full kernel, round 4 swept the side again with the slot sweep in a build of its own (ext_kernel<., 2>, "inline wide").
   // Since round 5 the adaptive sweep has a four-columns-per-lane phase (bpsw_extend_rows.h, rows_cpp4) and no band of a flank up to 255
   // bases leaves it: nothing is deferred on account of a wide band, one build serves every batch, and the full kernel is for what the
-  // host lists (flanks above 255 bases).  BPSW_EXT_INLINE_WIDE=1 still selects the round-4 build for batches with many such flanks (A/B).
-  static const bool inline_wide_on = getenv("BPSW_EXT_INLINE_WIDE") && atoi(getenv("BPSW_EXT_INLINE_WIDE")) == 1;
-  const bool inline_wide = inline_wide_on && use_short && 16 * (size_t)n_mid > (size_t)n;
+  // host lists (flanks above 255 bases).  (Round 4's second build went with the first profiles that showed it idle.)
   const bool expect_full = !use_short || n_long > 0;
   (void)any_mid;
   // behind the wire bytes: the full kernel's list as [count, task indices...]; the host stages its own entries and the count, the
@@ -655,7 +653,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   // The deferring short kernel ALWAYS has a list to defer to (round 4 gave it none when no task could be expected to defer, and
   // trapped if one did): a batch without mid tasks posts an empty list like any other, and the full kernel is launched behind it
   // only when it is not (lazy_full below) -- or unconditionally where the late launch is off (classify entry, BPSW_EXT_LAZY_FULL=0).
-  const bool with_list = use_short && !inline_wide ? true : (use_short && expect_full);
+  const bool with_list = use_short;
   const size_t stage_bytes = with_list ? list_off + 4 * (1 + (size_t)n_long) : wire_bytes;
   const size_t dev_bytes = with_list ? list_off + 4 * (1 + (size_t)n) : wire_bytes;
   if (!out_view && (!out || out_len < 10 * (size_t)n)) return fail(BPSW_ERR_CAPACITY, "extend: result buffer smaller than 10*n int16");
@@ -793,7 +791,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
                                          use_todo ? d_queue + 2 : nullptr, d_todo, heavy_min));
         }
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, n, k_out, sc, std::min(mq, 255), mr_short, c->num_cu, d_queue, nullptr, s,
-                                  nullptr, false, kev, true, d_list, 255, d_sflag, d_srecs, lazy_full ? (int*)(k_out + 10 * (size_t)n) : nullptr, d_todo, inline_wide));
+                                  nullptr, false, kev, true, d_list, 255, d_sflag, d_srecs, lazy_full ? (int*)(k_out + 10 * (size_t)n) : nullptr, d_todo));
         todo_guard.armed = false;
       }
       if (use_full && !lazy_full) {
@@ -807,7 +805,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         // the call holds its stream for that long)
         // (this is the launch that is NOT late -- the classify entry, BPSW_EXT_LAZY_FULL=0, or tasks the host listed itself: a quarter of
         // the mid tasks sizes it, at least one workgroup; the late launch below is sized by the posted length of the list)
-        const bool may_defer = use_short && !inline_wide;
+        const bool may_defer = use_short;
         const int grid_tasks = !use_short ? n : n_long + (may_defer ? 4 : 0);  // (a wide band defers nothing since round 5: room for the unexpected only)
         HIP_TRY(launch_ext_kernel((const uint32_t*)c->d_wire.ptr, grid_tasks, k_out, sc, mq, mr, c->num_cu, d_queue, nullptr, s,
                                   nullptr, false, kev, false, use_short ? d_list : nullptr));

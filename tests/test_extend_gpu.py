@@ -357,9 +357,10 @@ def test_launch_plans_of_the_split_kernel(ctx, orc, mid_share, w):
 
 @pytest.mark.parametrize("w", [70, 100, 127])
 def test_many_long_flanks_are_swept_where_they_are(ctx, orc, w):
-    """bpsw_extend.hip, ext_kernel<., 2>: a batch in which more than one task in sixteen has a flank of 128-255 bases (2x250 bp reads)
-    runs on the short kernel that sweeps a band wider than its window itself, with the full kernel's slot sweep for that side and
-    band -- no list, no second launch.  Retries that double the band to 140 / 200 / 254 columns, both parses, against the oracle."""
+    """A batch in which more than one task in sixteen has a flank of 128-255 bases (2x250 bp reads): the short kernel sweeps a band
+    wider than 128 columns itself (round 4: with the full kernel's slot sweep, in a build of its own; since round 5 in the
+    four-columns-per-lane phase of the adaptive sweep, bpsw_extend_rows.h rows_cpp4) -- no list entry, no second launch.  Retries
+    that double the band to 140 / 200 / 254 columns, both parses, against the oracle."""
     rng = np.random.default_rng(500 + w)
     tasks = []
     for t in range(1200):
