@@ -408,7 +408,46 @@ def tail_breakdown(ctx, opt, n_pairs: int = 4096):
     return {"pairs": n_pairs, "reg2aln_jobs": int(jobs), "call_ms": round(call_ms, 3), "kernel_ms": round(k_ms / reps, 4),
             "reads_per_s_one_thread": round(2 * n_pairs / (call_ms * 1e-3), 1), "alignments_per_s_kernel": round(jobs / (k_ms / reps * 1e-3), 1),
             "host_ms": {"plan": round(host[0] / reps, 3), "device_roundtrip": round(host[1] / reps, 3), "sam_text": round(host[2] / reps, 3)},
-            "sam_bytes": int(sum(len(t) for t in texts)), "note": "host buffers in, SAM text out; not part of `value`"}
+            "sam_bytes": int(sum(len(t) for t in texts)), "note": "host buffers in, SAM text out; not part of `value`",
+            "pool": tail_pool_rate(ctx, opt, topt, g, sum(len(t) for t in texts))}
+
+
+def tail_pool_rate(ctx, opt, topt, g, text_bytes, workers: int = 8, in_flight: int = 32, rounds: int = 3):
+    """The same group through bpsw_tail_pool_*: THIS thread only enqueues `in_flight` tickets and collects them (tools/tail_pool_rate.py
+    sweeps the number of workers: profiles/r05_tail_pool.json)."""
+    import ctypes as C
+    from bpsw_hip import _pairs_struct, _ptr
+    lib = ctx.lib
+    st, keep, _ = _pairs_struct(g)
+    cap = int(text_bytes) + 4096
+    bufs = [np.empty(cap, np.uint8) for _ in range(in_flight)]
+    offs = [np.zeros(2 * g.group_size + 1, np.int64) for _ in range(in_flight)]
+    pool, need = C.c_void_p(), C.c_size_t(0)
+    rc = lib.bpsw_tail_pool_create(0, workers, C.byref(pool))
+    if rc != 0:
+        return {"error": lib.bpsw_last_error().decode()}
+    tick = [0] * in_flight
+
+    def one_round():
+        for k in range(in_flight):
+            t = C.c_int64(0)
+            if lib.bpsw_tail_pool_submit(pool, C.byref(opt), C.byref(topt), C.byref(st), -1, _ptr(bufs[k]), cap, _ptr(offs[k]), None, None, 0, C.byref(t)) != 0:
+                raise RuntimeError(lib.bpsw_last_error().decode())
+            tick[k] = t.value
+        for k in range(in_flight):
+            if lib.bpsw_tail_pool_wait(pool, tick[k], C.byref(need), None) != 0:
+                raise RuntimeError(lib.bpsw_last_error().decode())
+    try:
+        one_round()
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            one_round()
+        dt = time.perf_counter() - t0
+    finally:
+        lib.bpsw_tail_pool_destroy(pool)
+    return {"workers": workers, "groups_in_flight": in_flight, "reads_per_s_one_calling_thread": round(2 * g.group_size * in_flight * rounds / dt, 1),
+            "ms_per_group": round(1e3 * dt / (in_flight * rounds), 3),
+            "note": "the calling thread enqueues and collects; plan, kernel and text run on the library's tail workers"}
 
 
 def spawn_ranks(n):

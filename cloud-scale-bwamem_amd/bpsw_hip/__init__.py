@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms", "bpsw_ring_stats",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
     "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_worker2_batch", "bpsw_last_tail_times",
+    "bpsw_tail_pool_create", "bpsw_tail_pool_destroy", "bpsw_tail_pool_submit", "bpsw_tail_pool_wait", "bpsw_tail_pool_workers",
     "bpsw_mark_primary_se", "bpsw_approx_mapq_se", "bpsw_mem_pair", "bpsw_sort_dedup", "bpsw_pe_stat",
 ]
 JNI_SYMBOLS = [
@@ -41,6 +42,8 @@ JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_SWExtendFPGAJNI_chainToAlnJNI",   # new entry for SURVEY.md 8f.3
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI",            # new entries for SURVEY.md 8f.1 / 8f.4
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI",
+    "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailSubmitJNI",   # the same call in two halves (bpsw_tail_pool_*, round 5)
+    "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailCollectJNI",
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWFlatJNI",         # boundary 1 with primitive arrays (round 4)
 ]
 
@@ -189,6 +192,13 @@ def load_library(path: str | None = None) -> C.CDLL:
                                       C.POINTER(C.c_size_t), C.c_void_p]
     lib.bpsw_worker2_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.bpsw_tail_pool_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.bpsw_tail_pool_destroy.argtypes = [C.c_void_p]
+    lib.bpsw_tail_pool_destroy.restype = None
+    lib.bpsw_tail_pool_submit.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.bpsw_tail_pool_wait.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
+    lib.bpsw_tail_pool_workers.argtypes = [C.c_void_p]
     lib.bpsw_mark_primary_se.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     lib.bpsw_approx_mapq_se.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_void_p]
     lib.bpsw_mem_pair.argtypes = [C.POINTER(Opt), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
@@ -758,6 +768,79 @@ def _ctx_last_tail_host_ms(self):
     h = (C.c_double * 3)()
     _chk(self.lib, self.lib.bpsw_last_tail_times(self.h, None, None, h), "bpsw_last_tail_times")
     return h[0], h[1], h[2]
+
+
+TAIL_POOL_TAIL_ONLY = -1
+
+
+class TailPool:
+    """bpsw_tail_pool_*: the tail of worker2 on library-owned worker threads.  submit() only enqueues (the arrays of `g` and the output
+    buffers are kept alive by the ticket object until collect()); collect() blocks for that group and returns what the direct call
+    would have: (SAM texts, regions as the tail leaves them) for TAIL_POOL_TAIL_ONLY, (texts, reg_cnt, regs) for a rescue mode."""
+
+    class Ticket:
+        __slots__ = ("id", "mode", "g", "st", "keep", "buf", "off", "cnt", "out_regs", "n_regs_in", "cap", "rcap", "opt", "topt")
+
+    def __init__(self, device: int = 0, workers: int = 8):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _chk(self.lib, self.lib.bpsw_tail_pool_create(int(device), int(workers), C.byref(h)), "bpsw_tail_pool_create")
+        self.h = h
+
+    @property
+    def workers(self) -> int:
+        return int(self.lib.bpsw_tail_pool_workers(self.h))
+
+    def _enqueue(self, t):
+        tid = C.c_int64(0)
+        _chk(self.lib, self.lib.bpsw_tail_pool_submit(self.h, C.byref(t.opt), C.byref(t.topt), C.byref(t.st), t.mode, _ptr(t.buf), t.cap,
+                                                      _ptr(t.off), _ptr(t.cnt), _ptr(t.out_regs), t.rcap, C.byref(tid)),
+             "bpsw_tail_pool_submit")
+        t.id = tid.value
+
+    def submit(self, opt: Opt, topt: "TailOpt", g: "TailGroupSoA", rescue_mode: int = TAIL_POOL_TAIL_ONLY, text_cap: int = 0):
+        t = TailPool.Ticket()
+        t.mode, t.g, t.opt, t.topt = int(rescue_mode), g, opt, topt
+        t.st, t.keep, regs = _pairs_struct(g)
+        t.n_regs_in = int(regs.shape[0])
+        t.off = np.zeros(2 * g.group_size + 1, np.int64)
+        t.cnt = np.zeros(max(2 * g.group_size, 1), np.int32)
+        t.cap = int(text_cap) if text_cap > 0 else 1024 * max(1, 2 * g.group_size)
+        t.rcap = max(t.n_regs_in, 1) if t.mode == TAIL_POOL_TAIL_ONLY else t.n_regs_in + 8 * g.group_size + 64
+        t.buf = np.empty(t.cap, np.uint8)
+        t.out_regs = np.zeros(t.rcap, ALNREG_DTYPE)
+        self._enqueue(t)
+        return t
+
+    def collect(self, t):
+        need, total = C.c_size_t(0), C.c_int64(0)
+        while True:
+            rc = self.lib.bpsw_tail_pool_wait(self.h, t.id, C.byref(need), C.byref(total))
+            if rc == -3 and (need.value > t.cap or total.value > t.rcap):   # BPSW_ERR_CAPACITY: once more with what it asked for
+                t.cap, t.rcap = max(t.cap, int(need.value) + 64), max(t.rcap, int(total.value) + 16)
+                t.buf = np.empty(t.cap, np.uint8)
+                t.out_regs = np.zeros(t.rcap, ALNREG_DTYPE)
+                self._enqueue(t)
+                continue
+            _chk(self.lib, rc, "bpsw_tail_pool_wait")
+            break
+        G = t.g.group_size
+        text = t.buf[: int(t.off[-1])].tobytes()
+        texts = [text[int(t.off[i]):int(t.off[i + 1])] for i in range(2 * G)]
+        if t.mode == TAIL_POOL_TAIL_ONLY:
+            return texts, t.out_regs[: t.n_regs_in]
+        return texts, t.cnt[: 2 * G], t.out_regs[: total.value]
+
+    def close(self):
+        if self.h:
+            self.lib.bpsw_tail_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 Context.bns_load = _ctx_bns_load

@@ -25,6 +25,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <time.h>
@@ -1118,19 +1120,39 @@ JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_loadBnsJNI(JNIEnv
 // regLongs = (rBeg, rEnd) and regInts = (qBeg, qEnd, score, trueScore, sub, csub, subNum, width, seedCov, secondary) per region,
 // in (k, i, j) order as mateSWJNI returns them.  Returns the SAM text of the group; the text of read 2k+i is
 // [outOff(2k+i), outOff(2k+i+1)) (outOff has 2*groupSize + 1 entries).  BPSW_TAIL_COMPAT=c selects the C flavour.
-JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI(
-    JNIEnv* env, jobject, jintArray optInts, jdoubleArray realsArr, jbyteArray matArr, jlong id0, jintArray readLenArr, jbyteArray readsArr,
-    jbyteArray qualsArr, jintArray nameLenArr, jbyteArray namesArr, jintArray regCntArr, jlongArray regLongsArr, jintArray regIntsArr,
-    jlongArray outOffArr) {
-  try {
-  if (!optInts || !realsArr || !matArr || !readLenArr || !readsArr || !nameLenArr || !namesArr || !regCntArr || !regLongsArr || !regIntsArr ||
-      !outOffArr || jni::GetArrayLength(env, optInts) < 12 || jni::GetArrayLength(env, realsArr) < 22 || jni::GetArrayLength(env, matArr) < 25) {
-    throw_runtime(env, "bPSW: samPeTailJNI: bad arguments");
-    return nullptr;
-  }
+}  // extern "C" (the tail's marshalling is shared by three entries: C++ linkage)
+
+namespace {
+
+// one group of samPeTailJNI's arguments in flat native buffers; lives on the stack of the synchronous entry, on the heap behind a ticket
+struct TailCall {
   bpsw_opt_t opt;
-  bpsw_opt_default(&opt);
   bpsw_tail_opt_t topt;
+  bpsw_pairs_t g;
+  std::vector<int32_t> read_len, reg_cnt;
+  std::vector<int64_t> read_off, name_off, out_off;
+  std::vector<uint8_t> reads, quals;
+  std::vector<char> names, text;
+  std::vector<bpsw_alnreg_t> regs;
+  jsize n2 = 0;
+  // (the asynchronous pair) the pool the group went to and its ticket there
+  bpsw_tail_pool_t* pool = nullptr;
+  int64_t ticket = 0;
+};
+
+// false: a RuntimeException is pending
+bool tail_unmarshal(JNIEnv* env, const char* who, jintArray optInts, jdoubleArray realsArr, jbyteArray matArr, jlong id0, jintArray readLenArr,
+                    jbyteArray readsArr, jbyteArray qualsArr, jintArray nameLenArr, jbyteArray namesArr, jintArray regCntArr,
+                    jlongArray regLongsArr, jintArray regIntsArr, TailCall& tc) {
+  const std::string pre = std::string("bPSW: ") + who + ": ";
+  if (!optInts || !realsArr || !matArr || !readLenArr || !readsArr || !nameLenArr || !namesArr || !regCntArr || !regLongsArr || !regIntsArr ||
+      jni::GetArrayLength(env, optInts) < 12 || jni::GetArrayLength(env, realsArr) < 22 || jni::GetArrayLength(env, matArr) < 25) {
+    throw_runtime(env, pre + "bad arguments");
+    return false;
+  }
+  bpsw_opt_t& opt = tc.opt;
+  bpsw_tail_opt_t& topt = tc.topt;
+  bpsw_opt_default(&opt);
   bpsw_tail_opt_default(&topt);
   jint oi[12];
   jni::GetIntArrayRegion(env, optInts, 0, 12, oi);
@@ -1145,79 +1167,180 @@ JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJN
   // the read group of the run (samHeader.bwaReadGroupID, FastMap.scala:109-114: fixed by the -R line before any worker starts)
   if (const char* rg = getenv("BPSW_READ_GROUP_ID")) {
     // (the reference writes samHeader.bwaReadGroupID whatever its length: a truncated ID would give RG:Z tags that match no @RG line)
-    if (strlen(rg) >= sizeof(topt.rg_id)) { throw_runtime(env, "bPSW: samPeTailJNI: BPSW_READ_GROUP_ID is longer than 63 characters"); return nullptr; }
+    if (strlen(rg) >= sizeof(topt.rg_id)) { throw_runtime(env, pre + "BPSW_READ_GROUP_ID is longer than 63 characters"); return false; }
     strncpy(topt.rg_id, rg, sizeof(topt.rg_id) - 1);
   }
   const jsize n2 = jni::GetArrayLength(env, readLenArr);
   const jsize G = n2 / 2;
-  if ((n2 & 1) || jni::GetArrayLength(env, regCntArr) != n2 || jni::GetArrayLength(env, nameLenArr) != G ||
-      jni::GetArrayLength(env, outOffArr) < n2 + 1) {
-    throw_runtime(env, "bPSW: samPeTailJNI: array lengths do not describe groupSize pairs");
-    return nullptr;
+  tc.n2 = n2;
+  if ((n2 & 1) || jni::GetArrayLength(env, regCntArr) != n2 || jni::GetArrayLength(env, nameLenArr) != G) {
+    throw_runtime(env, pre + "array lengths do not describe groupSize pairs");
+    return false;
   }
-  std::vector<int32_t> read_len((size_t)n2), reg_cnt((size_t)n2), name_len((size_t)G);
-  if (n2) { jni::GetIntArrayRegion(env, readLenArr, 0, n2, read_len.data()); jni::GetIntArrayRegion(env, regCntArr, 0, n2, reg_cnt.data()); }
+  std::vector<int32_t> name_len((size_t)G);
+  tc.read_len.resize((size_t)n2); tc.reg_cnt.resize((size_t)n2);
+  if (n2) { jni::GetIntArrayRegion(env, readLenArr, 0, n2, tc.read_len.data()); jni::GetIntArrayRegion(env, regCntArr, 0, n2, tc.reg_cnt.data()); }
   if (G) jni::GetIntArrayRegion(env, nameLenArr, 0, G, name_len.data());
-  std::vector<int64_t> read_off((size_t)n2), name_off((size_t)G + 1, 0);
+  tc.read_off.resize((size_t)n2); tc.name_off.assign((size_t)G + 1, 0);
   int64_t at = 0, n_regs = 0;
   for (jsize r = 0; r < n2; ++r) {
-    if (read_len[(size_t)r] < 0 || reg_cnt[(size_t)r] < 0) { throw_runtime(env, "bPSW: samPeTailJNI: negative length or count"); return nullptr; }
-    read_off[(size_t)r] = at; at += read_len[(size_t)r]; n_regs += reg_cnt[(size_t)r];
+    if (tc.read_len[(size_t)r] < 0 || tc.reg_cnt[(size_t)r] < 0) { throw_runtime(env, pre + "negative length or count"); return false; }
+    tc.read_off[(size_t)r] = at; at += tc.read_len[(size_t)r]; n_regs += tc.reg_cnt[(size_t)r];
   }
   for (jsize k = 0; k < G; ++k) {
-    if (name_len[(size_t)k] < 0) { throw_runtime(env, "bPSW: samPeTailJNI: negative name length"); return nullptr; }
-    name_off[(size_t)k + 1] = name_off[(size_t)k] + name_len[(size_t)k];
+    if (name_len[(size_t)k] < 0) { throw_runtime(env, pre + "negative name length"); return false; }
+    tc.name_off[(size_t)k + 1] = tc.name_off[(size_t)k] + name_len[(size_t)k];
   }
+  const int64_t names_bytes = tc.name_off[(size_t)G];
   if ((int64_t)jni::GetArrayLength(env, readsArr) < at || (qualsArr && (int64_t)jni::GetArrayLength(env, qualsArr) < at) ||
-      (int64_t)jni::GetArrayLength(env, namesArr) < name_off[(size_t)G] || (int64_t)jni::GetArrayLength(env, regLongsArr) < 2 * n_regs ||
+      (int64_t)jni::GetArrayLength(env, namesArr) < names_bytes || (int64_t)jni::GetArrayLength(env, regLongsArr) < 2 * n_regs ||
       (int64_t)jni::GetArrayLength(env, regIntsArr) < 10 * n_regs) {
-    throw_runtime(env, "bPSW: samPeTailJNI: a pool is shorter than its table says");
-    return nullptr;
+    throw_runtime(env, pre + "a pool is shorter than its table says");
+    return false;
   }
-  std::vector<uint8_t> reads((size_t)at + 16), quals;
-  if (at) jni::GetByteArrayRegion(env, readsArr, 0, (jsize)at, reinterpret_cast<jbyte*>(reads.data()));
-  if (qualsArr) { quals.resize((size_t)at + 16); if (at) jni::GetByteArrayRegion(env, qualsArr, 0, (jsize)at, reinterpret_cast<jbyte*>(quals.data())); }
-  std::vector<char> names((size_t)name_off[(size_t)G] + 1);
-  if (name_off[(size_t)G]) jni::GetByteArrayRegion(env, namesArr, 0, (jsize)name_off[(size_t)G], reinterpret_cast<jbyte*>(names.data()));
+  tc.reads.resize((size_t)at + 16);
+  if (at) jni::GetByteArrayRegion(env, readsArr, 0, (jsize)at, reinterpret_cast<jbyte*>(tc.reads.data()));
+  if (qualsArr) { tc.quals.resize((size_t)at + 16); if (at) jni::GetByteArrayRegion(env, qualsArr, 0, (jsize)at, reinterpret_cast<jbyte*>(tc.quals.data())); }
+  tc.names.resize((size_t)names_bytes + 1);
+  if (names_bytes) jni::GetByteArrayRegion(env, namesArr, 0, (jsize)names_bytes, reinterpret_cast<jbyte*>(tc.names.data()));
   std::vector<jlong> rl((size_t)(2 * n_regs) + 1);
   std::vector<jint> ri((size_t)(10 * n_regs) + 1);
   if (n_regs) { jni::GetLongArrayRegion(env, regLongsArr, 0, (jsize)(2 * n_regs), rl.data()); jni::GetIntArrayRegion(env, regIntsArr, 0, (jsize)(10 * n_regs), ri.data()); }
-  std::vector<bpsw_alnreg_t> regs((size_t)n_regs + 1);
+  tc.regs.resize((size_t)n_regs + 1);
   for (int64_t j = 0; j < n_regs; ++j) {
-    bpsw_alnreg_t& a = regs[(size_t)j];
+    bpsw_alnreg_t& a = tc.regs[(size_t)j];
     const jint* v = ri.data() + 10 * j;
     a.rb = rl[(size_t)(2 * j)]; a.re = rl[(size_t)(2 * j + 1)];
     a.qb = v[0]; a.qe = v[1]; a.score = v[2]; a.truesc = v[3]; a.sub = v[4]; a.csub = v[5]; a.sub_n = v[6]; a.w = v[7]; a.seedcov = v[8];
     a.secondary = v[9]; a.hash = 0;
   }
-  bpsw_pairs_t g;
+  bpsw_pairs_t& g = tc.g;
   memset(&g, 0, sizeof g);
   g.group_size = G; g.id0 = id0;
   for (int r = 0; r < 4; ++r) {
     g.pes[r].low = (int32_t)re[2 + 5 * r]; g.pes[r].high = (int32_t)re[3 + 5 * r]; g.pes[r].failed = (int32_t)re[4 + 5 * r];
     g.pes[r].avg = re[5 + 5 * r]; g.pes[r].std = re[6 + 5 * r];
   }
-  g.read_len = read_len.data(); g.read_off = read_off.data(); g.read_pool = reads.data(); g.qual_pool = qualsArr ? quals.data() : nullptr;
-  g.read_pool_bytes = (size_t)at; g.name_off = name_off.data(); g.name_pool = names.data(); g.reg_cnt = reg_cnt.data(); g.regs = regs.data();
-  bpsw_ctx_t* ctx = thread_context(env);
-  if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
-  std::vector<int64_t> out_off((size_t)n2 + 1, 0);
-  std::vector<char> text((size_t)G * 1400 + 1024);
-  size_t need = 0;
-  int rc = bpsw_sam_pe_batch(ctx, &opt, &topt, &g, text.data(), text.size(), out_off.data(), &need, nullptr);
-  if (rc == BPSW_ERR_CAPACITY && need > text.size()) {
-    text.resize(need + 16);
-    rc = bpsw_sam_pe_batch(ctx, &opt, &topt, &g, text.data(), text.size(), out_off.data(), &need, nullptr);
-  }
-  if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: samPeTailJNI: ") + bpsw_last_error()); return nullptr; }
-  if (need > 0x7fffffffULL) { throw_runtime(env, "bPSW: samPeTailJNI: SAM text of the group exceeds 2 GiB; use a smaller group"); return nullptr; }
+  g.read_len = tc.read_len.data(); g.read_off = tc.read_off.data(); g.read_pool = tc.reads.data(); g.qual_pool = qualsArr ? tc.quals.data() : nullptr;
+  g.read_pool_bytes = (size_t)at; g.name_off = tc.name_off.data(); g.name_pool = tc.names.data(); g.reg_cnt = tc.reg_cnt.data(); g.regs = tc.regs.data();
+  tc.out_off.assign((size_t)n2 + 1, 0);
+  tc.text.resize((size_t)G * 1400 + 1024);
+  return true;
+}
+
+// the group's text as a byte[] + outOff filled; nullptr with an exception pending
+jbyteArray tail_result(JNIEnv* env, const char* who, const TailCall& tc, size_t need, jlongArray outOffArr) {
+  if (need > 0x7fffffffULL) { throw_runtime(env, std::string("bPSW: ") + who + ": SAM text of the group exceeds 2 GiB; use a smaller group"); return nullptr; }
   jbyteArray ret = jni::NewByteArray(env, (jsize)need);
   if (!ret) return nullptr;  // OutOfMemoryError already pending
-  if (need) jni::SetByteArrayRegion(env, ret, 0, (jsize)need, reinterpret_cast<const jbyte*>(text.data()));
-  jni::SetLongArrayRegion(env, outOffArr, 0, n2 + 1, reinterpret_cast<const jlong*>(out_off.data()));
+  if (need) jni::SetByteArrayRegion(env, ret, 0, (jsize)need, reinterpret_cast<const jbyte*>(tc.text.data()));
+  jni::SetLongArrayRegion(env, outOffArr, 0, tc.n2 + 1, reinterpret_cast<const jlong*>(tc.out_off.data()));
   return ret;
+}
+
+// The library's tail pools, one per device, made by the first samPeTailSubmitJNI that needs one (BPSW_TAIL_POOL_WORKERS workers, default
+// 8) and kept for the life of the process; the groups in flight, by handle.
+std::mutex g_tail_mu;
+std::map<int, bpsw_tail_pool_t*> g_tail_pools;
+std::map<int64_t, std::unique_ptr<TailCall> > g_tail_calls;
+int64_t g_tail_next = 1;
+
+bpsw_tail_pool_t* tail_pool_of(int device) {
+  std::lock_guard<std::mutex> lk(g_tail_mu);
+  auto it = g_tail_pools.find(device);
+  if (it != g_tail_pools.end()) return it->second;
+  int w = getenv("BPSW_TAIL_POOL_WORKERS") ? atoi(getenv("BPSW_TAIL_POOL_WORKERS")) : 8;
+  w = w < 1 ? 1 : (w > 64 ? 64 : w);
+  bpsw_tail_pool_t* p = nullptr;
+  if (bpsw_tail_pool_create(device, w, &p) != BPSW_OK) return nullptr;
+  g_tail_pools[device] = p;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI(
+    JNIEnv* env, jobject, jintArray optInts, jdoubleArray realsArr, jbyteArray matArr, jlong id0, jintArray readLenArr, jbyteArray readsArr,
+    jbyteArray qualsArr, jintArray nameLenArr, jbyteArray namesArr, jintArray regCntArr, jlongArray regLongsArr, jintArray regIntsArr,
+    jlongArray outOffArr) {
+  try {
+  TailCall tc;
+  if (!tail_unmarshal(env, "samPeTailJNI", optInts, realsArr, matArr, id0, readLenArr, readsArr, qualsArr, nameLenArr, namesArr, regCntArr,
+                      regLongsArr, regIntsArr, tc)) return nullptr;
+  if (!outOffArr || jni::GetArrayLength(env, outOffArr) < tc.n2 + 1) { throw_runtime(env, "bPSW: samPeTailJNI: outOff needs 2*groupSize + 1 entries"); return nullptr; }
+  bpsw_ctx_t* ctx = thread_context(env);
+  if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return nullptr; }
+  size_t need = 0;
+  int rc = bpsw_sam_pe_batch(ctx, &tc.opt, &tc.topt, &tc.g, tc.text.data(), tc.text.size(), tc.out_off.data(), &need, nullptr);
+  if (rc == BPSW_ERR_CAPACITY && need > tc.text.size()) {
+    tc.text.resize(need + 16);
+    rc = bpsw_sam_pe_batch(ctx, &tc.opt, &tc.topt, &tc.g, tc.text.data(), tc.text.size(), tc.out_off.data(), &need, nullptr);
+  }
+  if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: samPeTailJNI: ") + bpsw_last_error()); return nullptr; }
+  return tail_result(env, "samPeTailJNI", tc, need, outOffArr);
   } catch (const std::exception& e) {  // nothing C++ may unwind into the JVM (std::bad_alloc of a scratch vector, ...)
     throw_runtime(env, std::string("bPSW: samPeTailJNI: ") + e.what());
+    return nullptr;
+  }
+}
+
+// The same call in two halves (round 5): the task thread only ENQUEUES its groups -- the arguments are copied into native buffers behind
+// a handle, and one of the library's tail workers of the thread's device (bpsw_tail_pool_*, include/bpsw.h) does the plan, the kernel
+// and the text -- and collects the text later, so that the groups of a partition overlap instead of queueing behind one another on the
+// partition's own thread (worker2/MemSamPe.scala:2099 under FastMap.scala:266-293).
+//   @native def samPeTailSubmitJNI(<the arguments of samPeTailJNI without outOff>): Long
+//   @native def samPeTailCollectJNI(handle: Long, outOff: Array[Long]): Array[Byte]      // blocks for that group; each handle once
+JNIEXPORT jlong JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailSubmitJNI(
+    JNIEnv* env, jobject, jintArray optInts, jdoubleArray realsArr, jbyteArray matArr, jlong id0, jintArray readLenArr, jbyteArray readsArr,
+    jbyteArray qualsArr, jintArray nameLenArr, jbyteArray namesArr, jintArray regCntArr, jlongArray regLongsArr, jintArray regIntsArr) {
+  try {
+  std::unique_ptr<TailCall> tc(new TailCall());
+  if (!tail_unmarshal(env, "samPeTailSubmitJNI", optInts, realsArr, matArr, id0, readLenArr, readsArr, qualsArr, nameLenArr, namesArr, regCntArr,
+                      regLongsArr, regIntsArr, *tc)) return 0;
+  bpsw_ctx_t* ctx = thread_context(env);  // (the partition -> device choice of every other entry)
+  if (!ctx) { throw_runtime(env, std::string("bPSW: no usable HIP device: ") + bpsw_last_error()); return 0; }
+  tc->pool = tail_pool_of(bpsw_device_of(ctx));
+  if (!tc->pool) { throw_runtime(env, std::string("bPSW: samPeTailSubmitJNI: ") + bpsw_last_error()); return 0; }
+  if (bpsw_tail_pool_submit(tc->pool, &tc->opt, &tc->topt, &tc->g, BPSW_TAIL_POOL_TAIL_ONLY, tc->text.data(), tc->text.size(), tc->out_off.data(),
+                            nullptr, nullptr, 0, &tc->ticket) != BPSW_OK) {
+    throw_runtime(env, std::string("bPSW: samPeTailSubmitJNI: ") + bpsw_last_error());
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(g_tail_mu);
+  const int64_t h = g_tail_next++;
+  g_tail_calls[h] = std::move(tc);
+  return (jlong)h;
+  } catch (const std::exception& e) {
+    throw_runtime(env, std::string("bPSW: samPeTailSubmitJNI: ") + e.what());
+    return 0;
+  }
+}
+
+JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailCollectJNI(JNIEnv* env, jobject, jlong handle, jlongArray outOffArr) {
+  try {
+  std::unique_ptr<TailCall> tc;
+  {
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    auto it = g_tail_calls.find((int64_t)handle);
+    if (it == g_tail_calls.end()) { throw_runtime(env, "bPSW: samPeTailCollectJNI: unknown handle (never issued, or collected already)"); return nullptr; }
+    tc = std::move(it->second);
+    g_tail_calls.erase(it);
+  }
+  size_t need = 0;
+  int rc = bpsw_tail_pool_wait(tc->pool, tc->ticket, &need, nullptr);
+  if (rc == BPSW_ERR_CAPACITY && need > tc->text.size()) {  // (a group whose text outgrew the first guess: once more, sized)
+    tc->text.resize(need + 16);
+    rc = bpsw_tail_pool_submit(tc->pool, &tc->opt, &tc->topt, &tc->g, BPSW_TAIL_POOL_TAIL_ONLY, tc->text.data(), tc->text.size(), tc->out_off.data(),
+                               nullptr, nullptr, 0, &tc->ticket);
+    if (rc == BPSW_OK) rc = bpsw_tail_pool_wait(tc->pool, tc->ticket, &need, nullptr);
+  }
+  if (rc != BPSW_OK) { throw_runtime(env, std::string("bPSW: samPeTailCollectJNI: ") + bpsw_last_error()); return nullptr; }
+  if (!outOffArr || jni::GetArrayLength(env, outOffArr) < tc->n2 + 1) { throw_runtime(env, "bPSW: samPeTailCollectJNI: outOff needs 2*groupSize + 1 entries"); return nullptr; }
+  return tail_result(env, "samPeTailCollectJNI", *tc, need, outOffArr);
+  } catch (const std::exception& e) {
+    throw_runtime(env, std::string("bPSW: samPeTailCollectJNI: ") + e.what());
     return nullptr;
   }
 }

@@ -417,6 +417,24 @@ int bpsw_pe_stat(const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, int64_t l_p
 int bpsw_worker2_batch(bpsw_ctx_t *ctx, const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_pairs_t *g, int rescue_mode,
                        char *out_text, size_t text_cap, int64_t *out_off, size_t *out_needed, int32_t *out_reg_cnt,
                        bpsw_alnreg_t *out_regs, int64_t out_regs_cap, int64_t *out_regs_total);
+/* The tail off the calling thread: a library-owned pool of n_workers tail workers on one device (each with a context of its own).
+ * The reference runs memSamPeGroupRest in the partition's task thread (worker2/MemSamPe.scala:1390-1612 under FastMap.scala:266-293);
+ * with the pool that thread only ENQUEUES its groups and collects the text later -- plan, kernel and text of different groups overlap.
+ * bpsw_tail_pool_submit copies opt, topt and *g by value and returns a ticket at once; everything they and the out_* arguments point
+ * to stays the caller's and must stay valid and unchanged until the ticket is collected.  rescue_mode: BPSW_RESCUE_C / BPSW_RESCUE_SCALA
+ * = bpsw_worker2_batch (rescue + tail), BPSW_TAIL_POOL_TAIL_ONLY = bpsw_sam_pe_batch (out_reg_cnt / out_regs_cap unused; out_regs as
+ * there).  bpsw_tail_pool_wait blocks until the ticket's group is done and returns ITS return code (BPSW_ERR_CAPACITY with *out_needed /
+ * *out_regs_total set, exactly as the direct calls; the worker's error text becomes the collecting thread's bpsw_last_error());
+ * tickets may be collected in any order, each once.  bpsw_tail_pool_destroy runs what is still queued, then joins the workers. */
+typedef struct bpsw_tail_pool bpsw_tail_pool_t;
+#define BPSW_TAIL_POOL_TAIL_ONLY (-1)
+int bpsw_tail_pool_create(int device, int n_workers, bpsw_tail_pool_t **out);
+void bpsw_tail_pool_destroy(bpsw_tail_pool_t *pool);
+int bpsw_tail_pool_submit(bpsw_tail_pool_t *pool, const bpsw_opt_t *opt, const bpsw_tail_opt_t *topt, const bpsw_pairs_t *g,
+                          int rescue_mode, char *out_text, size_t text_cap, int64_t *out_off, int32_t *out_reg_cnt,
+                          bpsw_alnreg_t *out_regs, int64_t out_regs_cap, int64_t *ticket);
+int bpsw_tail_pool_wait(bpsw_tail_pool_t *pool, int64_t ticket, size_t *out_needed, int64_t *out_regs_total);
+int bpsw_tail_pool_workers(const bpsw_tail_pool_t *pool);
 /* the most recent tail call on this context: kernel_ms = reg2aln_kernel launches (hipEvents on the launch stream), n_jobs =
  * jobs they carried, host_ms = {plan, device round trip (staging, copies, kernel), emit} of bpsw_sam_pe_batch */
 int bpsw_last_tail_times(bpsw_ctx_t *ctx, float *kernel_ms, int32_t *n_jobs, double host_ms[3]);

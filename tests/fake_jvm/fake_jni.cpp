@@ -508,12 +508,12 @@ int fake_jvm_chain2aln(const char* lib, int partition, const uint8_t* pac, int64
 
 // loadPacJNI + loadBnsJNI, then samPeTailJNI with primitive arrays.  out_text receives the returned
 // byte[], out_off the offsets the native filled in.
-int fake_jvm_sam_pe_tail(const char* lib, int partition, const uint8_t* pac, int64_t l_pac, int n_seqs, const int64_t* ann_off,
+static int sam_pe_tail_impl(const char* lib, int partition, const uint8_t* pac, int64_t l_pac, int n_seqs, const int64_t* ann_off,
                          const int32_t* ann_len, const uint8_t* ann_names, int64_t ann_names_bytes, const int32_t opt_ints[12],
                          const double reals[22], const int8_t mat[25], int64_t id0, int n2, const int32_t* read_len, const uint8_t* reads,
                          const uint8_t* quals, int64_t reads_bytes, const int32_t* name_len, const uint8_t* names, int64_t names_bytes,
                          const int32_t* reg_cnt, const int64_t* reg_longs, const int32_t* reg_ints, int64_t n_regs, uint8_t* out_text,
-                         int64_t out_cap, int64_t* out_bytes, int64_t* out_off, char* err, int errcap) {
+                         int64_t out_cap, int64_t* out_bytes, int64_t* out_off, char* err, int errcap, int async_copies) {
   Jvm vm;
   g_vm = &vm;
   vm.partition = partition;
@@ -536,6 +536,50 @@ int fake_jvm_sam_pe_tail(const char* lib, int partition, const uint8_t* pac, int
   if (!fn) return -1;
   std::vector<int64_t> zero((size_t)n2 + 1, 0);
   FObj* off = long_array(zero.data(), zero.size());
+  if (async_copies > 0) {
+    // the same group `async_copies` times through samPeTailSubmitJNI (fresh Java arrays per call, dropped right after it, as a task
+    // thread's would be), collected in REVERSE order; every copy must come back with the same text and offsets
+    typedef jlong (*SubFn)(JNIEnv*, jobject, jintArray, jdoubleArray, jbyteArray, jlong, jintArray, jbyteArray, jbyteArray, jintArray,
+                           jbyteArray, jintArray, jlongArray, jintArray);
+    typedef jbyteArray (*ColFn)(JNIEnv*, jobject, jlong, jlongArray);
+    SubFn sub = (SubFn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailSubmitJNI", err, (size_t)errcap);
+    ColFn col = (ColFn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailCollectJNI", err, (size_t)errcap);
+    if (!sub || !col) return -1;
+    std::vector<jlong> handles;
+    for (int c = 0; c < async_copies; ++c) {
+      const jlong h = sub(&e.env, J(self), (jintArray)J(int_array(opt_ints, 12)), (jdoubleArray)J(double_array(reals, 22)),
+                          (jbyteArray)J(byte_array(reinterpret_cast<const uint8_t*>(mat), 25)), (jlong)id0, (jintArray)J(int_array(read_len, (size_t)n2)),
+                          (jbyteArray)J(byte_array(reads, (size_t)reads_bytes)), quals ? (jbyteArray)J(byte_array(quals, (size_t)reads_bytes)) : nullptr,
+                          (jintArray)J(int_array(name_len, (size_t)(n2 / 2))), (jbyteArray)J(byte_array(names, (size_t)names_bytes)),
+                          (jintArray)J(int_array(reg_cnt, (size_t)n2)), (jlongArray)J(long_array(reg_longs, (size_t)(2 * n_regs))),
+                          (jintArray)J(int_array(reg_ints, (size_t)(10 * n_regs))));
+      if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+      if (h == 0) { snprintf(err, (size_t)errcap, "null handle"); return -1; }
+      handles.push_back(h);
+    }
+    *out_bytes = -1;
+    for (int c = async_copies - 1; c >= 0; --c) {
+      FObj* offc = long_array(zero.data(), zero.size());
+      jbyteArray r = col(&e.env, J(self), handles[(size_t)c], (jlongArray)J(offc));
+      if (vm.pending) { snprintf(err, (size_t)errcap, "%s", vm.pending_msg.c_str()); return 1; }
+      if (!r) { snprintf(err, (size_t)errcap, "null result"); return -1; }
+      const int64_t nb = (int64_t)O(r)->bytes.size();
+      if (nb > out_cap) { snprintf(err, (size_t)errcap, "out_cap too small"); return -1; }
+      if (*out_bytes < 0) {
+        *out_bytes = nb;
+        memcpy(out_text, O(r)->bytes.data(), (size_t)nb);
+        memcpy(out_off, offc->la.data(), 8 * ((size_t)n2 + 1));
+      } else if (nb != *out_bytes || memcmp(out_text, O(r)->bytes.data(), (size_t)nb) != 0 || memcmp(out_off, offc->la.data(), 8 * ((size_t)n2 + 1)) != 0) {
+        snprintf(err, (size_t)errcap, "copy %d came back with a different text", c);
+        return -1;
+      }
+    }
+    // a handle is good for one collect
+    (void)col(&e.env, J(self), handles[0], (jlongArray)J(off));
+    if (!vm.pending) { snprintf(err, (size_t)errcap, "a second collect of a handle did not throw"); return -1; }
+    vm.pending = false;
+    return 0;
+  }
   jbyteArray r = fn(&e.env, J(self), (jintArray)J(int_array(opt_ints, 12)), (jdoubleArray)J(double_array(reals, 22)),
                     (jbyteArray)J(byte_array(reinterpret_cast<const uint8_t*>(mat), 25)), (jlong)id0, (jintArray)J(int_array(read_len, (size_t)n2)),
                     (jbyteArray)J(byte_array(reads, (size_t)reads_bytes)), quals ? (jbyteArray)J(byte_array(quals, (size_t)reads_bytes)) : nullptr,
@@ -550,6 +594,18 @@ int fake_jvm_sam_pe_tail(const char* lib, int partition, const uint8_t* pac, int
   memcpy(out_off, off->la.data(), 8 * ((size_t)n2 + 1));
   return 0;
 }
+
+#define TAIL_ARGS_DECL const char* lib, int partition, const uint8_t* pac, int64_t l_pac, int n_seqs, const int64_t* ann_off,                      \
+                         const int32_t* ann_len, const uint8_t* ann_names, int64_t ann_names_bytes, const int32_t opt_ints[12],                 \
+                         const double reals[22], const int8_t mat[25], int64_t id0, int n2, const int32_t* read_len, const uint8_t* reads,      \
+                         const uint8_t* quals, int64_t reads_bytes, const int32_t* name_len, const uint8_t* names, int64_t names_bytes,        \
+                         const int32_t* reg_cnt, const int64_t* reg_longs, const int32_t* reg_ints, int64_t n_regs, uint8_t* out_text,          \
+                         int64_t out_cap, int64_t* out_bytes, int64_t* out_off, char* err, int errcap
+#define TAIL_ARGS lib, partition, pac, l_pac, n_seqs, ann_off, ann_len, ann_names, ann_names_bytes, opt_ints, reals, mat, id0, n2, read_len, reads, quals, \
+                  reads_bytes, name_len, names, names_bytes, reg_cnt, reg_longs, reg_ints, n_regs, out_text, out_cap, out_bytes, out_off, err, errcap
+int fake_jvm_sam_pe_tail(TAIL_ARGS_DECL) { return sam_pe_tail_impl(TAIL_ARGS, 0); }
+// ... and through samPeTailSubmitJNI / samPeTailCollectJNI: `copies` groups in flight from this one thread
+int fake_jvm_sam_pe_tail_async(TAIL_ARGS_DECL, int copies) { return sam_pe_tail_impl(TAIL_ARGS, copies); }
 
 // name lookups (FindClass / GetFieldID / GetMethodID) the shim has made in this process so far, and live global references
 long fake_jvm_lookups(void) { return g_world.lookups.load(); }

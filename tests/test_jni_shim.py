@@ -230,6 +230,19 @@ def test_sam_pe_tail_through_jni_matches_c_abi(fake, ctx, orc):
     text = out[:nb.value].tobytes()
     got = [text[int(out_off[i]):int(out_off[i + 1])] for i in range(n2)]
     assert got == want
+    # the same call in two halves (round 5): samPeTailSubmitJNI x 6 from this one thread, samPeTailCollectJNI in reverse order -- the
+    # library's tail workers do the plan, the kernel and the text; every copy gives the text above, a handle is good for one collect
+    out[:] = 0
+    out_off[:] = 0
+    fake.fake_jvm_sam_pe_tail_async.restype = C.c_int
+    rc = fake.fake_jvm_sam_pe_tail_async(bpsw_hip.LIB_PATH.encode(), 3, _vp(pac), C.c_int64(g.l_pac), C.c_int(len(names)), _vp(g.ann_off), _vp(g.ann_len),
+                                         _vp(ann_names), C.c_int64(ann_names.size), _vp(ints), _vp(reals), _vp(mat), C.c_int64(g.id0), C.c_int(n2),
+                                         _vp(np.ascontiguousarray(g.read_len)), _vp(reads), _vp(quals), C.c_int64(reads.size), _vp(name_len), _vp(rnames),
+                                         C.c_int64(rnames.size), _vp(np.ascontiguousarray(g.reg_cnt)), _vp(reg_longs), _vp(reg_ints),
+                                         C.c_int64(g.regs.shape[0]), _vp(out), C.c_int64(out.size), C.byref(nb), _vp(out_off), err, 512, C.c_int(6))
+    assert rc == 0, err.value.decode()
+    text = out[:nb.value].tobytes()
+    assert [text[int(out_off[i]):int(out_off[i + 1])] for i in range(n2)] == want
 
 
 @pytest.mark.gpu

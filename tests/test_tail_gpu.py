@@ -255,3 +255,58 @@ def test_chains_to_sam_end_to_end_vs_reference(ctx, orc, ref):
     for i in diff:
         wl, gl = want[i].splitlines(), got[i].splitlines()
         assert len(wl) == len(gl) and all(strip(a) == strip(b) for a, b in zip(wl, gl)), (want[i], got[i])
+
+
+# ---- the tail off the calling thread: bpsw_tail_pool_* (round 5) ------------------------------------------------------------------------
+def test_tail_pool_gives_the_text_of_the_direct_calls(ctx, orc):
+    """Twelve groups (150 and 250 bp, both flavours, tail-only and rescue + tail) enqueued on a pool of four workers by ONE thread and
+    collected in reverse order: every group's text, counts and regions are byte for byte what the direct call on a context returns, and
+    the golden group of the reference's mem_sam_pe comes back as the reference wrote it."""
+    pac, bases, g150 = synthetic_group_with_bases(orc, 400, 9100, zdrop_mode=po.ZDROP_BWA, dedup_mode=bpsw_hip.RESCUE_C, p_hard=0.2,
+                                                  p_unmappable=0.03, sub_rate=0.02, indel_rate=0.004)
+    _load_ref(ctx, pac, g150)
+    opt = bpsw_hip.default_opt()
+    jobs = []
+    for k in range(6):
+        gk = copy.copy(g150)
+        gk.id0 = 1000 * k       # (the pair ids feed the hash that breaks ties: every group is a different call)
+        jobs.append((gk, bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C if k % 2 else bpsw_hip.TAIL_SCALA),
+                     bpsw_hip.TAIL_POOL_TAIL_ONLY if k % 3 == 0 else (bpsw_hip.RESCUE_C if k % 3 == 1 else bpsw_hip.RESCUE_SCALA)))
+    want = []
+    for gk, topt, mode in jobs:
+        want.append(ctx.sam_pe_batch(opt, topt, gk) if mode == bpsw_hip.TAIL_POOL_TAIL_ONLY else ctx.worker2_batch(opt, topt, gk, mode))
+    pool = bpsw_hip.TailPool(0, workers=4)
+    assert pool.workers == 4
+    tickets = [pool.submit(opt, topt, gk, mode) for gk, topt, mode in jobs] * 1
+    tickets += [pool.submit(opt, topt, gk, mode) for gk, topt, mode in jobs]      # the same groups again: twelve in flight
+    for idx in reversed(range(len(tickets))):
+        got, w = pool.collect(tickets[idx]), want[idx % len(jobs)]
+        assert got[0] == w[0], idx
+        for a, b in zip(got[1:], w[1:]):
+            assert np.asarray(a).tobytes() == np.asarray(b).tobytes(), idx
+    pool.close()
+
+
+def test_tail_pool_golden_text_and_errors(ctx, orc):
+    pac, g, flag, want = load_sam_pe_golden("mem_sam_pe")
+    _load_ref(ctx, pac, g)
+    opt = bpsw_hip.default_opt()
+    opt.flag = flag
+    topt = bpsw_hip.default_tail_opt(bpsw_hip.TAIL_C)
+    pool = bpsw_hip.TailPool(0, workers=2)
+    t_small = pool.submit(opt, topt, g, text_cap=100)     # far too small: the ticket reports BPSW_ERR_CAPACITY and the size, collect() re-submits
+    t_ok = pool.submit(opt, topt, g)
+    assert pool.collect(t_ok)[0] == want                  # the reference's mem_sam_pe output, byte for byte
+    assert pool.collect(t_small)[0] == want
+    assert t_small.cap > 100
+    with pytest.raises(bpsw_hip.BpswError, match="unknown ticket"):
+        pool.collect(t_ok)                                # each ticket is collected once
+    bad = copy.copy(g)
+    bad.read_len = np.asarray(g.read_len).copy()
+    bad.read_len[0] = 10_000_000                          # a read outside its pool: the worker's error reaches the collecting thread
+    t_bad = pool.submit(opt, topt, bad)
+    with pytest.raises(bpsw_hip.BpswError, match="outside its pool"):
+        pool.collect(t_bad)
+    t_after = pool.submit(opt, topt, g)                   # the worker that met the error goes on
+    assert pool.collect(t_after)[0] == want
+    pool.close()
