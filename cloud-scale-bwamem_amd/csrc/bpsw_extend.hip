@@ -218,6 +218,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
     for (int side = 0; side < 2; ++side) {
       const int qLen = side ? rq : lq, rLen = side ? rr : lr;
       if (qLen <= 0) continue;
+      // (SHORT: a side derives its per-lane values from an opaque copy of the lane number -- qStart + lane and the like, computed for
+      // both sides at the top of the task, were VGPRs the 64-register build had to spill: bpsw_extend_rows.h, rows_opaque)
+      const int lane_s = SHORT ? rows_opaque(lane) : lane;
       const int qStart = side ? lq : 0, rStart = side ? lq + rq + lr : lq + rq;
       const int maxIns = side ? rMaxIns : lMaxIns, maxDel = side ? rMaxDel : lMaxDel;
       const int penClip = side ? penClip3 : penClip5;
@@ -231,13 +234,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
       // Row i needs i - w <= qLen, so at most qLen + w + 1 rows of a side are ever swept (the row at i = qLen + w has an empty
       // band and ends the call): a coordinate batch stages only those, before the shortcuts, which then read LDS too.
       const int tstage = COORD ? min(rLen, qLen + (wBand << 1) + 2) : rLen;
-      if (COORD && reg_path) load_target_shifts(lane, tpac, tstage, ts);
+      if (COORD && reg_path) load_target_shifts(lane_s, tpac, tstage, ts);
       // near-exact flank: the DP result is known (flank_closed_form); the retry loop would stop after its first try
       const auto shortcuts = [&](const auto& tsrc, const int tl) {
         return exact_a > 0 &&
-               ((rLen >= qLen && tl >= qLen && flank_closed_form(lane, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
+               ((rLen >= qLen && tl >= qLen && flank_closed_form(lane_s, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
                                                                 hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, sc.certify, &r)) ||
-                (sc.certify >= 3 && flank_start_gap_form(lane, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
+                (sc.certify >= 3 && flank_start_gap_form(lane_s, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
                                                          hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
       };
       bool exact_v;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
         awSide = wBand;
         regScore = uni(r.max);
       } else if (reg_path) {
-        if (!COORD) load_target_shifts(lane, tnib, rLen, ts);
+        if (!COORD) load_target_shifts(lane_s, tnib, rLen, ts);
       } else if constexpr (SHORT) {
         // (never: the host sends a batch whose gap costs rule the register path out to the full kernel)
       } else if constexpr (COORD) {
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
           asm volatile("" : "+s"(oInsT), "+s"(eInsT));
           int ov = 0;
 #if BPSW_EXT_ADAPTIVE
-          r = sw_extend_adaptive(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, pl, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+          r = sw_extend_adaptive(lane_s, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, pl, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
 #else
           r = sw_extend_reg_short<true>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
 #endif

@@ -48,6 +48,10 @@ struct Row4 {
 };
 #define ROWS4_EACH(M) M(0) M(1) M(2) M(3)
 enum { ROWS_DONE = 0, ROWS_MORE = 1, ROWS_OTHER_MODE = 2, ROWS_SLOW = 3, ROWS_OVERFLOW = 4 };
+// The lane number as a value the optimiser cannot see through.  Every piece of the sweep derives its per-lane constants (2 lane,
+// lane * eIns, NEG, ...) from one of these at its own entry: a handful of instructions per piece -- per 64 rows at most -- instead
+// of a dozen VGPRs that, hoisted to the top of the kernel, live (or are spilled) through every piece that does not use them.
+__device__ __forceinline__ int rows_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 constexpr int ROWS_NARROW = 52;  // a band of at most this many columns goes (back) to one column per lane; wider than 63 must leave it
 
 // The query profile of a call lives in LDS (round 4): prof[j] = the scores of query base j against target A, C, G, T (one byte
@@ -86,9 +90,10 @@ __device__ __forceinline__ void rows_load_profile(RowState& st, const ProfLds& p
 //   ROWS_OVERFLOW    COLS == 2: the next row's band does not fit 128 columns (the task goes to the full kernel)
 // In the last two cases the row has not been touched.
 template <int COLS>
-__device__ int rows_cpp(RowState& st, const int lane, const int qLen, const int tLen, const ProfLds& pl, const uint8_t* __restrict__ ts,
+__device__ int rows_cpp(RowState& st, const int lane_arg, const int qLen, const int tLen, const ProfLds& pl, const uint8_t* __restrict__ ts,
                         const int oDel, const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
                         const int zmode, const int h0, const int amax, int max_rows) {
+  const int lane = rows_opaque(lane_arg);
   const int oeDel = oDel + eDel, oeIns = oIns + eIns;
   const int jE0 = COLS * lane * eIns - oeIns;  // j*eIns - oeIns of the lane's first column, j counted from the window's origin
   const int kC = oeIns - eIns;
@@ -246,11 +251,12 @@ __device__ __forceinline__ void rows_load_profile4(Row4& q, const int base, cons
   ROWS4_EACH(ROWS4_M)
 #undef ROWS4_M
 }
-__device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane, const int qLen, const int tLen, const ProfLds& pl, const uint8_t* __restrict__ ts,
+__device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_arg, const int qLen, const int tLen, const ProfLds& pl, const uint8_t* __restrict__ ts,
                          const int oDel, const int eDel, const int oIns, const int eIns, const int w, const int zdrop,
                          const int zmode, const int h0, const int amax) {
   constexpr int C = 4, WIN = 256;
   const int oeDel = oDel + eDel, oeIns = oIns + eIns;
+  const int lane = rows_opaque(lane_arg);
   const int lane4 = C * lane;
   const int jE0 = lane4 * eIns - oeIns;  // j*eIns - oeIns of the lane's first column, j counted from the window's origin
   const int kC = oeIns - eIns;
@@ -840,15 +846,16 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane, 
       : "vcc", "scc", "memory");  /* (M0 is written too: the compiler never keeps a value in it across statements on gfx9) */
 // sel: 0 the general loop over [i, row_end), 1 / 2 the fast loop (LIVE / DEAD phase of h1) over [i, fast_end) under the preconditions
 // listed at ROWS1F_TEXT, which the caller (sw_extend_adaptive) establishes
-__device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int qLen, const int row_end, int& vTS, const int w,
+__device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const int qLen, const int row_end, int& vTS, const int w,
                                          const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
                                          const int i_tail, const int u0, const int qa, const bool tail_rows, const int sel, const int tLen,
                                          const int i_h1z, const unsigned ts_addr, const unsigned prof_addr) {
+  const int lane = rows_opaque(lane_arg);
   int vH = st.H0, vE = st.E0;
   int vP = st.plo0;
   const int vNegC = -(lane * eIns);     // g(k) = a(k) + k*eIns = a - vNegC;  F(j) = Pex(j) + vNegC + (eIns - oeIns)
   int vPp = NEG;                        // the exclusive prefix: lane 0 keeps "nothing to the left"
-  int vNEG = NEG_A;
+  int vNEG = rows_opaque(NEG_A);
   int s_i = st.i, s_beg = st.beg, s_end = st.end, s_h1raw = st.h1raw, s_mx = st.mx, s_maxi = st.max_i, s_maxj = st.max_j;
   int s_maxie = st.max_ie, s_gs = st.gscore, s_moff = st.max_off;
   // the fast loop's forms of max and (gscore, max_ie): mx << 7 | 127 against the scan key; gscore << 16 | max_ie under a signed max
@@ -1421,17 +1428,18 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane, const int
         [nkc1] "s"(s_nkc1), [zdrop] "s"(zdrop), [zpos] "s"(s_zpos), [zneg] "s"(s_zneg), [eins] "s"(eIns), [itail] "s"(i_tail), [tailrows] "s"(s_tailrows), [u0] "s"(u0), \
         [qa] "s"(qa), [narrow1] "s"(ROWS_NARROW + 1), [sel] "s"(s_sel), [profaddr] "s"(s_profaddr), [zc1] "s"(s_zc1), [zlim] "s"(s_zlim) \
       : "vcc", "scc", "memory");  /* (M0 is written too) */
-__device__ __forceinline__ int rows2_asm(RowState& st, const int lane, const int qLen, const int row_end, int& vTS, const int w,
+__device__ __forceinline__ int rows2_asm(RowState& st, const int lane_arg, const int qLen, const int row_end, int& vTS, const int w,
                                          const int eDel, const int oeDel, const int oeIns, const int eIns, const int zdrop, const int zmode,
                                          const int i_tail, const int u0, const int qa, const bool tail_rows, const int sel, const int tLen,
                                          const int i_h1z, const unsigned ts_addr, const unsigned prof_addr) {
+  const int lane = rows_opaque(lane_arg);
   int vH0 = st.H0, vE0 = st.E0, vH1 = st.H1, vE1 = st.E1;
   int vP0 = st.plo0, vP1 = st.plo1;
   const int vL2 = 2 * lane, vL2p1 = 2 * lane + 1;  // the lane's columns, in window coordinates
   const int vNegC = -(2 * lane * eIns);   // g(k) = a(k) + k*eIns;  F(j) = Pex(j) - (j-1)*eIns - oeIns
   const int vNegC1 = vNegC - eIns;
   int vPp = NEG;
-  int vNEG = NEG_A;
+  int vNEG = rows_opaque(NEG_A);
   int s_i = st.i, s_beg = st.beg, s_end = st.end, s_h1raw = st.h1raw, s_mx = st.mx, s_maxi = st.max_i, s_maxj = st.max_j;
   int s_maxie = st.max_ie, s_gs = st.gscore, s_moff = st.max_off;
   int s_mxhi = (st.mx << 7) | 127, s_gskey = (int)(((unsigned)st.gscore << 16) | ((unsigned)st.max_ie & 0xffffu));  // (see rows1_asm)

@@ -40,6 +40,8 @@ def test_no_device_is_an_error_not_a_fallback():
         pytest.skip("a GPU is visible")
     with pytest.raises(bpsw_hip.BpswError):
         bpsw_hip.Context(0)
+    with pytest.raises(bpsw_hip.BpswError):      # the tail pool's workers are contexts too: no device, no pool
+        bpsw_hip.TailPool(0, workers=2)
 
 
 @pytest.mark.parametrize("read_len,n", [(100, 300), (150, 500), (250, 200)])

@@ -21,6 +21,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 d = json.loads([l for l in open(f"{out}/FETCH_SIZE.json") if l.startswith("{")][-1])
 for k, v in per.items():
     fe, wr = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+    if k not in d["kernels"]:   # (the full kernel: launched only for what the host lists)
+        continue
     alg = d["kernels"][k]["bytes_per_launch"]
     print(k, "fetch_KB", round(fe, 1), "write_KB", round(wr, 1), "traffic_B", int((2 * fe + wr) * 1024), "algorithmic_B", alg, "ratio", round((2 * fe + wr) * 1024 / alg, 2), "value", d["value"])
 PY
