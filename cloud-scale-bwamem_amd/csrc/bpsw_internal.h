@@ -371,6 +371,8 @@ double stat_ms();  // wall_ms, or the thread CPU clock with BPSW_STATS_CLOCK=cpu
 // by it (extend_batch_impl)
 int sw_launches_in_flight(int device);
 void sw_launch_in_flight(int device, int delta);
+double wait_est_update(double est, double took_ms, int polls, bool napped);  // the next estimate of a kind of wait
+bool wait_naps(double est_ms);                                       // whether wait_nap sleeps at all for this estimate
 void wait_nap(double est_ms);                                        // the sleep before the first look (BPSW_WAIT_MODE, bpsw_runtime.cpp)
 void wait_poll_pause(int polls, double waited_ms, double est_ms);    // between two looks
 hipError_t wait_event(bpsw_ctx* c, hipEvent_t ev, int kind);  // kind 0: extension call, 1: SW call (separate duration estimates)

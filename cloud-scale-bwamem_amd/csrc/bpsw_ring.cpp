@@ -263,6 +263,7 @@ int ring_poke(int device, int c_class) {
 int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, double* est_ms) {
   const double t0 = wall_ms();
   double est = est_ms ? *est_ms : 0.;
+  const bool napped = !spin_wait() && wait_naps(est);
   if (!spin_wait()) wait_nap(est);
   int polls = 0;
   double next_poke = 2.0;
@@ -283,8 +284,7 @@ int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, dou
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  const double took = wall_ms() - t0;
-  if (est_ms) *est_ms = est <= 0. ? took : 0.75 * est + 0.25 * took;
+  if (est_ms) *est_ms = wait_est_update(est, wall_ms() - t0, polls, napped);
   return BPSW_OK;
 }
 

@@ -10,6 +10,7 @@
 #include <sys/prctl.h>
 #include <time.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 
@@ -212,6 +213,22 @@ void wait_thread_setup() {
   done = true;
   if (wait_mode() == 1) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
 }
+// The running estimate of a kind of wait, from which the next nap is taken (70 % of it): an average of the waits' lengths in which ONE
+// wait cannot raise it beyond 3 x + 0.2 ms.  Without that bound (rounds 4-5) a single wait that a descheduled thread stretched to 48 ms
+// made the estimate 12 ms, and since a wait that ends with its nap is as long as the nap, the estimate then fell by only 7.5 % per
+// call: calls whose kernels take 0.04 ms slept 8.4, 7.8, 7.2 ... ms (seen as ONE 40-50 ms hole in a few hundred 0.1 ms calls:
+// profiles/r05_small_calls.txt of the round's first table, the 61-task row).  With the bound the same outlier costs 0.08 ms of naps.
+// (An estimator that also SHRINKS when a wait ends with its nap was tried: under the bench, where the executor's CPU quota is the
+// limit, it is bistable -- 2.49 or 1.92 x 10^8 reads/s from run to run: shorter naps are more polling, more polling is CPU the other
+// threads do not get.  The averaged lengths err on the side of sleeping, which is the right side there.)
+double wait_est_update(double est, double took_ms, int polls, bool napped) {
+  (void)polls; (void)napped;
+  if (est <= 0.) return took_ms;
+  return 0.75 * est + 0.25 * std::min(took_ms, 3.0 * est + 0.2);
+}
+// (would wait_nap sleep for this estimate?  the same thresholds as below)
+bool wait_naps(double est_ms) { return wait_mode() == 1 ? est_ms * 850.0 - 5.0 > 5.0 : (est_ms > 0.15 && est_ms * 700.0 - 60.0 > 20.0); }
+
 void wait_nap(double est_ms) {
   if (wait_mode() == 1) {
     wait_thread_setup();
@@ -238,12 +255,12 @@ hipError_t wait_event(bpsw_ctx* c, hipEvent_t ev, int kind) {
   if (spin_wait()) return hipEventSynchronize(ev);
   double& est = c->wait_est_ms[kind & 3];
   const double t0 = wall_ms();
+  const bool napped = wait_naps(est);
   wait_nap(est);
   hipError_t e;
   int polls = 0;
   while ((e = hipEventQuery(ev)) == hipErrorNotReady) wait_poll_pause(++polls, wall_ms() - t0, est);
-  const double took = wall_ms() - t0;
-  est = est <= 0. ? took : 0.75 * est + 0.25 * took;
+  est = wait_est_update(est, wall_ms() - t0, polls, napped);
   return e;
 }
 
@@ -374,6 +391,10 @@ using namespace bpsw;
 extern "C" {
 
 const char* bpsw_last_error(void) { return g_err.c_str(); }
+// (diagnostics, not part of include/bpsw.h: the wait estimator's update rule for tests/test_host_logic.py -- no device needed)
+double bpsw_diag_wait_est_update(double est, double took_ms, int polls, int napped) { return bpsw::wait_est_update(est, took_ms, polls, napped != 0); }
+int bpsw_diag_wait_naps(double est_ms) { return bpsw::wait_naps(est_ms) ? 1 : 0; }
+
 const char* bpsw_version(void) {
   return "bPSW-hip 0.5 (gfx950)";  // 0.5 = round 5: bpsw_stats_t grew (sw_ring_calls): rebuild callers against include/bpsw.h
 }

@@ -98,3 +98,35 @@ def test_pe_stat_vs_oracle_and_reference(orc, ref):
         assert got_c == ref.pestat(oopt, otopt, g.l_pac, g.reg_cnt, g.regs)
         if n >= 300:
             assert got_c[1][2] == 0 and 350 < got_c[1][3] < 450 and got_c[0][2] == 1      # FR supported, mean ~ 400; FF not
+
+
+def test_wait_estimate_is_not_poisoned_by_an_outlier():
+    """The estimate the waits nap by (csrc/bpsw_runtime.cpp, wait_est_update): one wait that a descheduled thread stretched to 48 ms must
+    not make calls whose work takes 0.1 ms sleep for milliseconds.  (Rounds 4-5 had no bound on a single measurement: the outlier made
+    the estimate 12 ms, and since a wait that ends with its nap is as long as the nap, some thirty calls slept 8.4, 7.8, 7.2 ... ms.)"""
+    import ctypes as C
+    lib = bpsw_hip.load_library()
+    upd, naps = lib.bpsw_diag_wait_est_update, lib.bpsw_diag_wait_naps
+    upd.restype = C.c_double
+    upd.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    naps.argtypes = [C.c_double]
+    work = 0.1
+    est = 0.0
+    for _ in range(20):                      # steady state: no nap below 0.15 ms, every wait is measured
+        est = upd(est, work, 3, naps(est))
+    assert abs(est - work) < 1e-6 and not naps(est)
+    est = upd(est, 48.0, 500, naps(est))     # the outlier
+    assert est <= 0.75 * work + 0.25 * (3 * work + 0.2) + 1e-9
+    overslept, calls = 0.0, 0
+    while naps(est):
+        nap = 0.7 * est - 0.06               # wait_nap's sleep (BPSW_WAIT_MODE=0)
+        overslept += max(nap - work, 0.0)
+        est = upd(est, max(nap, work), 0 if nap >= work else 2, 1)
+        calls += 1
+        assert calls < 50
+    assert overslept < 0.5, (overslept, calls)
+    # a real change of the work's length is followed within a dozen calls
+    est = 0.1
+    for _ in range(12):
+        est = upd(est, 2.0, 5, naps(est))
+    assert 1.5 < est <= 2.0
