@@ -310,3 +310,38 @@ def test_tail_pool_golden_text_and_errors(ctx, orc):
     t_after = pool.submit(opt, topt, g)                   # the worker that met the error goes on
     assert pool.collect(t_after)[0] == want
     pool.close()
+
+
+def test_tail_pool_shared_by_many_submitting_threads(ctx, orc):
+    """The JNI shim keeps ONE pool per device for all the executor's task threads: six threads submit and collect their own groups on a
+    pool of three workers at once; every thread gets its own groups' text back."""
+    import threading
+    pac, g = synthetic_group(orc, 300, 9300, read_len=150, sub_rate=0.02, indel_rate=0.004, p_span=0.05)
+    _load_ref(ctx, pac, g)
+    opt, topt = bpsw_hip.default_opt(), bpsw_hip.default_tail_opt(bpsw_hip.TAIL_SCALA)
+    groups, want = [], []
+    for k in range(6):
+        gk = copy.copy(g)
+        gk.id0 = 7000 * k
+        groups.append(gk)
+        want.append(ctx.sam_pe_batch(opt, topt, gk)[0])
+    pool = bpsw_hip.TailPool(0, workers=3)
+    errors = []
+
+    def task(k):
+        try:
+            for _ in range(3):
+                tickets = [pool.submit(opt, topt, groups[k]) for _ in range(4)]
+                for t in tickets:
+                    assert pool.collect(t)[0] == want[k]
+        except BaseException as e:   # noqa: BLE001 - reported to the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=task, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not any(t.is_alive() for t in threads)
+    assert not errors, errors[:2]
+    pool.close()
