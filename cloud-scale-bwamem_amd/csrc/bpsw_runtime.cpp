@@ -214,10 +214,10 @@ void wait_thread_setup() {
   if (wait_mode() == 1) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
 }
 // The running estimate of a kind of wait, from which the next nap is taken (70 % of it): an average of the waits' lengths in which ONE
-// wait cannot raise it beyond 3 x + 0.2 ms.  Without that bound (rounds 4-5) a single wait that a descheduled thread stretched to 48 ms
-// made the estimate 12 ms, and since a wait that ends with its nap is as long as the nap, the estimate then fell by only 7.5 % per
-// call: calls whose kernels take 0.04 ms slept 8.4, 7.8, 7.2 ... ms (seen as ONE 40-50 ms hole in a few hundred 0.1 ms calls:
-// profiles/r05_small_calls.txt of the round's first table, the 61-task row).  With the bound the same outlier costs 0.08 ms of naps.
+// wait cannot raise it beyond 3 x + 0.2 ms.  Without that bound (rounds 4-5) a single wait that a descheduled thread stretches to 48 ms
+// would make the estimate 12 ms, and since a wait that ends with its nap is as long as the nap, the estimate then falls by only 7.5 %
+// per call: calls whose kernels take 0.04 ms would sleep 8.4, 7.8, 7.2 ... ms (tests/test_host_logic.py plays it through).  With the
+// bound the same outlier costs 0.08 ms of naps.
 // (An estimator that also SHRINKS when a wait ends with its nap was tried: under the bench, where the executor's CPU quota is the
 // limit, it is bistable -- 2.49 or 1.92 x 10^8 reads/s from run to run: shorter naps are more polling, more polling is CPU the other
 // threads do not get.  The averaged lengths err on the side of sleeping, which is the right side there.)

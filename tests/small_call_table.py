@@ -21,13 +21,22 @@ from bpsw_hip import synth  # noqa: E402
 
 
 def timed(fn, items, reps):
+    """mean ms per call.  (The interpreter's cyclic collector is held off while the clock runs: one collection of the harness's own
+    garbage -- 30-50 ms with the synthetic batches alive -- inside a few hundred 0.1 ms calls doubled the first row of round 5's
+    first tables.)"""
+    import gc
     for it in items:
         fn(it)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        for it in items:
-            fn(it)
-    return 1e3 * (time.perf_counter() - t0) / (reps * len(items))
+    gc.collect()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for it in items:
+                fn(it)
+        return 1e3 * (time.perf_counter() - t0) / (reps * len(items))
+    finally:
+        gc.enable()
 
 
 def main():
