@@ -126,7 +126,7 @@ class Stats(C.Structure):  # bpsw_stats_t
                [(n, C.c_double) for n in ("ext_h2d_ms", "ext_kernel_ms", "ext_d2h_ms", "sw_h2d_ms", "sw_kernel_ms",
                                           "sw_d2h_ms", "sw_host_ms", "ext_host_in_ms", "ext_wait_ms", "ext_dev_ms",
                                           "ext_host_out_ms", "grp_plan_ms", "grp_pack_ms", "grp_wait_ms", "grp_dev_ms",
-                                          "grp_replay_ms", "grp_out_ms")] + [("grp_calls", C.c_uint64), ("grp_pairs", C.c_uint64), ("ext_full_relaunches", C.c_uint64), ("sw_ring_calls", C.c_uint64)]
+                                          "grp_replay_ms", "grp_out_ms")] + [("grp_calls", C.c_uint64), ("grp_pairs", C.c_uint64), ("ext_full_relaunches", C.c_uint64), ("sw_ring_calls", C.c_uint64), ("ext_ring_calls", C.c_uint64)]
 
 
 _lib = None

@@ -25,6 +25,7 @@
 
 #include "bpsw_extend_core.h"
 #include "bpsw_extend_rows.h"
+#include "bpsw_ring_dev.h"
 
 #include "bpsw_diag_waves.h"
 BPSW_DIAG_WAVES_DEFINE(ext)
@@ -59,6 +60,176 @@ __device__ void load_side(const int lane, const uint32_t* __restrict__ words, co
 
 __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
+
+// One task of a batch: both sides' shortcuts and sweeps, the 10-int16 record (extension(), MemChainToAlignBatched.scala:789-883).  Shared
+// by the launched kernels (ext_kernel) and the resident one (ext_resident_kernel: RING, the record is stored for a host that is
+// looking at it while the kernel lives).  eh / qp: the full kernel's LDS rows; ts / pl: the target bytes and the query profile.
+template <bool COORD, int SHORT, bool RING>
+__device__ __forceinline__ void ext_do_task(const int task, const int sifted, const int lane, const uint32_t* __restrict__ wire,
+                                            int16_t* __restrict__ out, const ExtScoring& sc, const MatRows& mat, const int oDel, const int eDel, const int oIns,
+                                            const int eIns, const int penClip5, const int penClip3, const int wBand, const int exact_a,
+                                            const int amax, int2* eh, int8_t* qp, uint8_t* ts, const ProfLds& pl, int* __restrict__ defer,
+                                            const int short_qmax, const uint4* __restrict__ sift_recs, const int inject_defer) {
+  const uint32_t* rec = wire + 8 + (COORD ? 10 : 8) * (size_t)task;  // MemChainToAlignBatched.scala:95-117
+  const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
+  // coordinate batch: the seed's start in the doubled reference and its length (in the slot of the redundant 16-bit idx)
+  const long long seedRb = COORD ? (long long)(((unsigned long long)uni((int)rec[9]) << 32) | (unsigned)uni((int)rec[8])) : 0ll;
+  const int seedLen = COORD ? uni(hi16(r4)) : 0;
+  const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
+  // short_qmax < 0 (the asynchronous device entry, where no host has seen the records): nobody has listed the tasks this build
+  // cannot take -- a flank above -short_qmax bases, or any task when the gap costs rule out the register sweeps -- so it defers
+  // them itself; short_qmax > 0: the host has listed them for the full kernel
+  bool deferred = false;
+  // (test hook, BPSW_EXT_INJECT_DEFER=k: every k-th task of a deferring launch takes the way of a band that outgrew the window)
+  if (SHORT && inject_defer > 0 && task % inject_defer == 0) deferred = true;
+  if (SHORT) {
+    const int qm = short_qmax < 0 ? -short_qmax : short_qmax;
+    const bool too_long = lq > qm || rq > qm || (short_qmax < 0 && oIns + eIns <= 0);
+    if (too_long) {
+      if (short_qmax < 0) {
+        if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
+      }
+      return;
+    }
+  }
+  const uint32_t* words = wire + (size_t)uni((int)rec[2]);
+  const int regScore0 = uni(lo16(r3)), qBeg = uni(hi16(r3)), h0 = uni(lo16(r4));
+  const int lMaxIns = max(1, uni(lo16(r5))), lMaxDel = max(1, uni(hi16(r5)));  // SWUtil.scala:110-115
+  const int rMaxIns = max(1, uni(lo16(r6))), rMaxDel = max(1, uni(hi16(r6)));
+  const int idx = uni((int)rec[7]);
+
+  // extension(), MemChainToAlignBatched.scala:789-883: side 0 = left (penClip5), side 1 = right (penClip3)
+  int awSide = wBand, awMax = wBand;  // the band tried last on this side / the widest over both sides (no array: a dynamically indexed one lives in scratch memory)
+  int regScore = regScore0;
+  int outQBeg = 0, outRBeg = 0, outQEnd = rq, outREnd = 0, trueScore = regScore0, score = -1;
+  for (int side = 0; side < 2; ++side) {
+    const int qLen = side ? rq : lq, rLen = side ? rr : lr;
+    if (qLen <= 0) continue;
+    // (SHORT: a side derives its per-lane values from an opaque copy of the lane number -- qStart + lane and the like, computed for
+    // both sides at the top of the task, were VGPRs the 64-register build had to spill: bpsw_extend_rows.h, rows_opaque)
+    const int lane_s = SHORT ? rows_opaque(lane) : lane;
+    const int qStart = side ? lq : 0, rStart = side ? lq + rq + lr : lq + rq;
+    const int maxIns = side ? rMaxIns : lMaxIns, maxDel = side ? rMaxDel : lMaxDel;
+    const int penClip = side ? penClip3 : penClip5;
+    const int hInit = uni(side ? regScore : h0);  // the right extension starts from the score after the left one (uni: see `exact` below)
+    const int sc0 = regScore;
+    // register path: needs one lane per column 0..qLen and oeIns > 0 (see sw_extend_reg)
+    const bool reg_path = qLen <= 255 && oIns + eIns > 0;
+    ExtRes r = {0, 0, 0, 0, 0, 0};
+    const NibbleT tnib = {words, rStart};
+    const PacT tpac = {sc.pac, sc.l_pac, side ? seedRb + seedLen : seedRb - 1, side ? 1 : -1};
+    // Row i needs i - w <= qLen, so at most qLen + w + 1 rows of a side are ever swept (the row at i = qLen + w has an empty
+    // band and ends the call): a coordinate batch stages only those, before the shortcuts, which then read LDS too.
+    const int tstage = COORD ? min(rLen, qLen + (wBand << 1) + 2) : rLen;
+    if (COORD && reg_path) load_target_shifts(lane_s, tpac, tstage, ts);
+    // near-exact flank: the DP result is known (flank_closed_form); the retry loop would stop after its first try
+    const auto shortcuts = [&](const auto& tsrc, const int tl) {
+      return exact_a > 0 &&
+             ((rLen >= qLen && tl >= qLen && flank_closed_form(lane_s, qLen, tl, NibbleQ{words, qStart}, tsrc, mat,
+                                                              hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, sc.certify, &r)) ||
+              (sc.certify >= 3 && flank_start_gap_form(lane_s, qLen, tl, NibbleQ{words, qStart}, tsrc, mat,
+                                                       hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
+    };
+    bool exact_v;
+    int judged = 0;  // 1: the sift kernel found that no form holds, 2: that one does for this start score
+    if (SHORT && sifted == 2) {
+      const uint4 sr = sift_recs[2 * (size_t)task + side];
+      const int kind = uni((int)(sr.x & 0xffu)), hmin = uni((int)sr.x >> 8);
+      if (kind == 1) judged = 1;
+      else if (kind == 2 && hInit >= hmin) {
+        judged = 2;
+        r.max = hInit + uni(lo16(sr.y)); r.gscore = hInit + uni(hi16(sr.y));
+        r.qle = uni(lo16(sr.z)); r.tle = uni(hi16(sr.z)); r.gtle = uni(lo16(sr.w)); r.max_off = uni(hi16(sr.w));
+      }
+    }
+    if (judged) exact_v = judged == 2;
+    else if constexpr (COORD) exact_v = reg_path && shortcuts(LdsShiftT{ts}, tstage);
+    else exact_v = shortcuts(tnib, rLen);
+    // wave-uniform by construction (the shortcuts decide on wave reductions), but not to the compiler: without this the DP below
+    // sits in what it takes for divergent control flow and its whole scalar state is kept in vector registers
+    const bool exact = uni(exact_v ? 1 : 0) != 0;
+    if (sc.side_how && lane == 0) sc.side_how[2 * (size_t)task + side] = exact ? 1 : 2;  // diagnostics only
+    if (exact) {
+      awSide = wBand;
+      regScore = uni(r.max);
+    } else if (reg_path) {
+      if (!COORD) load_target_shifts(lane_s, tnib, rLen, ts);
+    } else if constexpr (SHORT) {
+      // (never: the host sends a batch whose gap costs rule the register path out to the full kernel)
+    } else if constexpr (COORD) {
+      load_side(lane, words, qStart, qLen, tpac, tstage, mat, qp, ts);
+    } else {
+      load_side(lane, words, qStart, qLen, tnib, rLen, mat, qp, ts);
+    }
+    for (int i = 0; i < 2 && !exact; ++i) {  // MAX_BAND_TRY
+      const int prev = regScore;
+      awSide = wBand << i;
+      const int w = uni(min(min(awSide, maxIns), maxDel));
+      // the retry doubles the band; when the EFFECTIVE band min(w << 1, maxIns, maxDel) is the one just swept, the sweep would
+      // repeat itself row by row (SWUtil.scala:110-115: w is all of the band the call sees): only the reported width changes
+      if (i == 1 && w == uni(min(min(wBand, maxIns), maxDel))) break;
+      if constexpr (SHORT) {
+        int oInsT = oIns, eInsT = eIns;  // opaque copies, as below
+        asm volatile("" : "+s"(oInsT), "+s"(eInsT));
+        int ov = 0;
+#if BPSW_EXT_ADAPTIVE
+        r = sw_extend_adaptive(lane_s, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, pl, mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+#else
+        r = sw_extend_reg_short<true>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
+#endif
+        if (uni(ov)) {  // (never since round 5: sw_extend_adaptive holds every band of a flank this kernel takes)
+          deferred = true;
+          break;
+        }
+      } else if (reg_path) {
+        // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
+        // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
+        int oInsT = oIns, eInsT = eIns;
+        asm volatile("" : "+s"(oInsT), "+s"(eInsT));
+        r = sw_extend_reg_any(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, eh);
+      } else {
+        r = sw_extend_wave(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
+      }
+      regScore = uni(r.max);
+      if (regScore == prev || r.max_off < (awSide >> 1) + (awSide >> 2)) break;
+    }
+    if (SHORT && deferred) break;
+    score = regScore;
+    awMax = max(awMax, awSide);
+    const bool local = r.gscore <= 0 || r.gscore <= regScore - penClip;  // local extension vs reaching the query end
+    if (side == 0) {
+      outQBeg = local ? qBeg - r.qle : 0;
+      outRBeg = local ? -r.tle : -r.gtle;
+      trueScore = local ? regScore : r.gscore;
+    } else {
+      outQEnd = local ? r.qle : rq;
+      outREnd = local ? r.tle : r.gtle;
+      trueScore += (local ? regScore : r.gscore) - sc0;
+    }
+  }
+  if (SHORT && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
+    // (every deferring launch has a list: launch_ext_kernel refuses one without.  A batch whose flanks all have at most 127 bases
+    // is not expected to defer anything -- their bands fit the 128-column window -- but if a row loop ever said otherwise, the
+    // task goes to the full kernel like any other deferred one instead of trapping the executor's process: round 4 trapped)
+    if (!defer) return;
+    if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
+    return;
+  }
+  const int width = awMax;
+  // MemChainToAlignBatched.scala:181-188: 10 int16 per task
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)sc.out_stride * (size_t)task);
+  const uint32_t o1 = ((uint32_t)outQBeg & 0xffffu) | ((uint32_t)outQEnd << 16), o2 = ((uint32_t)outRBeg & 0xffffu) | ((uint32_t)outREnd << 16);
+  const uint32_t o3 = ((uint32_t)score & 0xffffu) | ((uint32_t)trueScore << 16), o4 = (uint32_t)width & 0xffffu;
+  if constexpr (RING) {
+    // under the resident kernel nothing ends with a kernel's end: the record goes out with system-scope (write-through) stores, ONE
+    // wave instruction for its five words (a word per lane; word by word from one lane they are five round trips to the point of
+    // coherence: bpsw_swalign.hip, swp_do_duo, tells what fourteen cost)
+    const uint32_t v = lane == 0 ? (uint32_t)idx : lane == 1 ? o1 : lane == 2 ? o2 : lane == 3 ? o3 : o4;
+    if (lane < 5) __hip_atomic_store(o + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if (lane == 0) {
+    o[0] = (uint32_t)idx; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
+  }
+}
 
 #ifndef BPSW_EXT_WAVES_PER_SIMD
 // register budget.  Five waves per SIMD: 96 VGPRs and no scratch.  Six (80 VGPRs) ran the bench step at the same rate, but three
@@ -183,160 +354,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, SHORT ? BPSW_EXT_SHORT_WAVES_
       if (sifted == 1) continue;
     }
     BPSW_DIAG_TASK_BEGIN(task);
-    const uint32_t* rec = wire + 8 + (COORD ? 10 : 8) * (size_t)task;  // MemChainToAlignBatched.scala:95-117
-    const uint32_t r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
-    // coordinate batch: the seed's start in the doubled reference and its length (in the slot of the redundant 16-bit idx)
-    const long long seedRb = COORD ? (long long)(((unsigned long long)uni((int)rec[9]) << 32) | (unsigned)uni((int)rec[8])) : 0ll;
-    const int seedLen = COORD ? uni(hi16(r4)) : 0;
-    const int lq = uni(lo16(r0)), lr = uni(hi16(r0)), rq = uni(lo16(r1)), rr = uni(hi16(r1));
-    // short_qmax < 0 (the asynchronous device entry, where no host has seen the records): nobody has listed the tasks this build
-    // cannot take -- a flank above -short_qmax bases, or any task when the gap costs rule out the register sweeps -- so it defers
-    // them itself; short_qmax > 0: the host has listed them for the full kernel
-    bool deferred = false;
-    // (test hook, BPSW_EXT_INJECT_DEFER=k: every k-th task of a deferring launch takes the way of a band that outgrew the window)
-    if (SHORT && inject_defer > 0 && task % inject_defer == 0) deferred = true;
-    if (SHORT) {
-      const int qm = short_qmax < 0 ? -short_qmax : short_qmax;
-      const bool too_long = lq > qm || rq > qm || (short_qmax < 0 && oIns + eIns <= 0);
-      if (too_long) {
-        if (short_qmax < 0) {
-          if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
-        }
-        continue;
-      }
-    }
-    const uint32_t* words = wire + (size_t)uni((int)rec[2]);
-    const int regScore0 = uni(lo16(r3)), qBeg = uni(hi16(r3)), h0 = uni(lo16(r4));
-    const int lMaxIns = max(1, uni(lo16(r5))), lMaxDel = max(1, uni(hi16(r5)));  // SWUtil.scala:110-115
-    const int rMaxIns = max(1, uni(lo16(r6))), rMaxDel = max(1, uni(hi16(r6)));
-    const int idx = uni((int)rec[7]);
-
-    // extension(), MemChainToAlignBatched.scala:789-883: side 0 = left (penClip5), side 1 = right (penClip3)
-    int awSide = wBand, awMax = wBand;  // the band tried last on this side / the widest over both sides (no array: a dynamically indexed one lives in scratch memory)
-    int regScore = regScore0;
-    int outQBeg = 0, outRBeg = 0, outQEnd = rq, outREnd = 0, trueScore = regScore0, score = -1;
-    for (int side = 0; side < 2; ++side) {
-      const int qLen = side ? rq : lq, rLen = side ? rr : lr;
-      if (qLen <= 0) continue;
-      // (SHORT: a side derives its per-lane values from an opaque copy of the lane number -- qStart + lane and the like, computed for
-      // both sides at the top of the task, were VGPRs the 64-register build had to spill: bpsw_extend_rows.h, rows_opaque)
-      const int lane_s = SHORT ? rows_opaque(lane) : lane;
-      const int qStart = side ? lq : 0, rStart = side ? lq + rq + lr : lq + rq;
-      const int maxIns = side ? rMaxIns : lMaxIns, maxDel = side ? rMaxDel : lMaxDel;
-      const int penClip = side ? penClip3 : penClip5;
-      const int hInit = uni(side ? regScore : h0);  // the right extension starts from the score after the left one (uni: see `exact` below)
-      const int sc0 = regScore;
-      // register path: needs one lane per column 0..qLen and oeIns > 0 (see sw_extend_reg)
-      const bool reg_path = qLen <= 255 && oIns + eIns > 0;
-      ExtRes r = {0, 0, 0, 0, 0, 0};
-      const NibbleT tnib = {words, rStart};
-      const PacT tpac = {sc.pac, sc.l_pac, side ? seedRb + seedLen : seedRb - 1, side ? 1 : -1};
-      // Row i needs i - w <= qLen, so at most qLen + w + 1 rows of a side are ever swept (the row at i = qLen + w has an empty
-      // band and ends the call): a coordinate batch stages only those, before the shortcuts, which then read LDS too.
-      const int tstage = COORD ? min(rLen, qLen + (wBand << 1) + 2) : rLen;
-      if (COORD && reg_path) load_target_shifts(lane_s, tpac, tstage, ts);
-      // near-exact flank: the DP result is known (flank_closed_form); the retry loop would stop after its first try
-      const auto shortcuts = [&](const auto& tsrc, const int tl) {
-        return exact_a > 0 &&
-               ((rLen >= qLen && tl >= qLen && flank_closed_form(lane_s, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
-                                                                hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, sc.certify, &r)) ||
-                (sc.certify >= 3 && flank_start_gap_form(lane_s, qLen, tl, NibbleQ{words, qStart}, tsrc, sc.mat,
-                                                         hInit, exact_a, oDel, eDel, oIns, eIns, sc.zdrop, wBand, &r)));
-      };
-      bool exact_v;
-      int judged = 0;  // 1: the sift kernel found that no form holds, 2: that one does for this start score
-      if (SHORT && sifted == 2) {
-        const uint4 sr = sift_recs[2 * (size_t)task + side];
-        const int kind = uni((int)(sr.x & 0xffu)), hmin = uni((int)sr.x >> 8);
-        if (kind == 1) judged = 1;
-        else if (kind == 2 && hInit >= hmin) {
-          judged = 2;
-          r.max = hInit + uni(lo16(sr.y)); r.gscore = hInit + uni(hi16(sr.y));
-          r.qle = uni(lo16(sr.z)); r.tle = uni(hi16(sr.z)); r.gtle = uni(lo16(sr.w)); r.max_off = uni(hi16(sr.w));
-        }
-      }
-      if (judged) exact_v = judged == 2;
-      else if constexpr (COORD) exact_v = reg_path && shortcuts(LdsShiftT{ts}, tstage);
-      else exact_v = shortcuts(tnib, rLen);
-      // wave-uniform by construction (the shortcuts decide on wave reductions), but not to the compiler: without this the DP below
-      // sits in what it takes for divergent control flow and its whole scalar state is kept in vector registers
-      const bool exact = uni(exact_v ? 1 : 0) != 0;
-      if (sc.side_how && lane == 0) sc.side_how[2 * (size_t)task + side] = exact ? 1 : 2;  // diagnostics only
-      if (exact) {
-        awSide = wBand;
-        regScore = uni(r.max);
-      } else if (reg_path) {
-        if (!COORD) load_target_shifts(lane_s, tnib, rLen, ts);
-      } else if constexpr (SHORT) {
-        // (never: the host sends a batch whose gap costs rule the register path out to the full kernel)
-      } else if constexpr (COORD) {
-        load_side(lane, words, qStart, qLen, tpac, tstage, sc.mat, qp, ts);
-      } else {
-        load_side(lane, words, qStart, qLen, tnib, rLen, sc.mat, qp, ts);
-      }
-      for (int i = 0; i < 2 && !exact; ++i) {  // MAX_BAND_TRY
-        const int prev = regScore;
-        awSide = wBand << i;
-        const int w = uni(min(min(awSide, maxIns), maxDel));
-        // the retry doubles the band; when the EFFECTIVE band min(w << 1, maxIns, maxDel) is the one just swept, the sweep would
-        // repeat itself row by row (SWUtil.scala:110-115: w is all of the band the call sees): only the reported width changes
-        if (i == 1 && w == uni(min(min(wBand, maxIns), maxDel))) break;
-        if constexpr (SHORT) {
-          int oInsT = oIns, eInsT = eIns;  // opaque copies, as below
-          asm volatile("" : "+s"(oInsT), "+s"(eInsT));
-          int ov = 0;
-#if BPSW_EXT_ADAPTIVE
-          r = sw_extend_adaptive(lane_s, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, pl, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
-#else
-          r = sw_extend_reg_short<true>(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, &ov);
-#endif
-          if (uni(ov)) {  // (never since round 5: sw_extend_adaptive holds every band of a flank this kernel takes)
-            deferred = true;
-            break;
-          }
-        } else if (reg_path) {
-          // opaque copies: otherwise the per-lane column constants of every slot count (j*eIns - oeIns, (j-1)*eIns) are hoisted
-          // out of the task loop and sit in ~20 VGPRs for the whole kernel, which no longer fits five waves per SIMD
-          int oInsT = oIns, eInsT = eIns;
-          asm volatile("" : "+s"(oInsT), "+s"(eInsT));
-          r = sw_extend_reg_any(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, NibbleQ{words, qStart}, ts, sc.mat, oDel, eDel, oInsT, eInsT, w, sc.zdrop, sc.zdrop_mode, hInit, amax, eh);
-        } else {
-          r = sw_extend_wave(lane, qLen, COORD ? min(rLen, qLen + w + 2) : rLen, eh, qp, ts, oDel, eDel, oIns, eIns, w, sc.zdrop, sc.zdrop_mode, hInit, amax);
-        }
-        regScore = uni(r.max);
-        if (regScore == prev || r.max_off < (awSide >> 1) + (awSide >> 2)) break;
-      }
-      if (SHORT && deferred) break;
-      score = regScore;
-      awMax = max(awMax, awSide);
-      const bool local = r.gscore <= 0 || r.gscore <= regScore - penClip;  // local extension vs reaching the query end
-      if (side == 0) {
-        outQBeg = local ? qBeg - r.qle : 0;
-        outRBeg = local ? -r.tle : -r.gtle;
-        trueScore = local ? regScore : r.gscore;
-      } else {
-        outQEnd = local ? r.qle : rq;
-        outREnd = local ? r.tle : r.gtle;
-        trueScore += (local ? regScore : r.gscore) - sc0;
-      }
-    }
-    if (SHORT && deferred) {  // one atomic per deferred task (rare): its slot in the full kernel's list
-      // (every deferring launch has a list: launch_ext_kernel refuses one without.  A batch whose flanks all have at most 127 bases
-      // is not expected to defer anything -- their bands fit the 128-column window -- but if a row loop ever said otherwise, the
-      // task goes to the full kernel like any other deferred one instead of trapping the executor's process: round 4 trapped)
-      if (!defer) continue;
-      if (lane == 0) defer[1 + atomicAdd(defer, 1)] = task;
-      continue;
-    }
-    const int width = awMax;
-    if (lane == 0) {  // MemChainToAlignBatched.scala:181-188: 10 int16 per task
-      uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)sc.out_stride * (size_t)task);
-      o[0] = (uint32_t)idx;
-      o[1] = ((uint32_t)outQBeg & 0xffffu) | ((uint32_t)outQEnd << 16);
-      o[2] = ((uint32_t)outRBeg & 0xffffu) | ((uint32_t)outREnd << 16);
-      o[3] = ((uint32_t)score & 0xffffu) | ((uint32_t)trueScore << 16);
-      o[4] = (uint32_t)width & 0xffffu;
-    }
+    ext_do_task<COORD, SHORT, false>(task, sifted, lane, wire, out, sc, sc.mat, oDel, eDel, oIns, eIns, penClip5, penClip3, wBand, exact_a, amax, eh, qp, ts, pl,
+                                     defer, short_qmax, sift_recs, inject_defer);
     BPSW_DIAG_TASK_END();
   }
   BPSW_DIAG_WAVE_END_TASKS(SHORT ? 1 : 0, next_task, lane);
@@ -375,7 +394,75 @@ __global__ void ext_prepass_kernel(const uint32_t* __restrict__ wire, const unsi
   }
 }
 
+// The resident form of the short kernel (bpsw_ring.h, class RING_CLASS_EXT): the same tasks, taken a unit at a time from the descriptors
+// task threads append to the device's submission ring instead of from one launch's queue.  Wavefront 0 of workgroup 0 is the ring's
+// poller; every other wavefront is a worker.  Only what needs neither the sift kernel nor the full kernel comes here (small batches
+// of flanks up to 255 bases: the host checks), so a descriptor is ONE phase: its units are its tasks.  LDS geometry fixed for the epoch.
+// The batch is read with ordinary (vector) loads from a pointer that arrives in the descriptor -- nothing here is `__restrict__` kernel
+// argument memory the compiler may keep in the scalar cache across batches -- and a unit's first act is ring_next_unit's invalidate of
+// the vector cache: a caller's staging buffer is reused from batch to batch.
+// (register budget: the full kernel's 96 VGPRs.  The epoch's grid is one workgroup per CU -- a wave per SIMD --, so nothing is gained by
+// squeezing it into the short kernel's 64, where the ring's own state and the descriptor's fields cost 160 bytes of scratch per lane)
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void ext_resident_kernel(const RingArgs A, const int qcap, const int rcap,
+                                                                                                        const int lds_per_wave) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ MatRows mat_lds[WAVES_PER_BLOCK];
+  const int lane = threadIdx.x & 63;
+  const int wave = uni((int)(threadIdx.x >> 6));
+  if (blockIdx.x == 0 && wave == 0) {
+    ring_poller(A, lane);
+    return;
+  }
+  unsigned char* base = smem + (size_t)wave * lds_per_wave;
+  uint8_t* ts = base;
+  int* prof_w = reinterpret_cast<int*>(base + (((size_t)rcap + 15) & ~(size_t)15));
+  const ProfLds pl = {prof_w, reinterpret_cast<int8_t*>(prof_w + qcap + 2), (unsigned)(uintptr_t)((__attribute__((address_space(3))) int*)prof_w)};
+  RingWorker W;
+  for (;;) {
+    uint32_t unit = 0, word = 0;
+    if (!ring_next_unit(A, lane, W, unit, word)) break;
+    const auto f32 = [&](const int k) { return (uint32_t)__builtin_amdgcn_readlane((int)word, k); };
+    const auto f64 = [&](const int k) { return ((unsigned long long)f32(k + 1) << 32) | (unsigned long long)f32(k); };
+    // the payload (ExtRingPayload, words 8..) as the arguments a launch would have got
+    const uint32_t* wire = (const uint32_t*)f64(8);
+    int16_t* out = (int16_t*)f64(10);
+    const int n_tasks = (int)f32(12), per_unit = (int)f32(13);
+    ExtScoring sc;
+    sc.out_stride = (int)f32(14); sc.zdrop = (int)f32(15); sc.zdrop_mode = (int)f32(16); sc.mat_max = (int)f32(17);
+    sc.exact_a = (int)f32(18); sc.tail_bound = (int)f32(19); sc.certify = (int)f32(20);
+    sc.side_how = nullptr; sc.pac = nullptr; sc.l_pac = 0;
+    // the matrix rows into this wave's LDS copy (lane r: row r, descriptor words 22 + 2r, 23 + 2r)
+    {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((22 + 2 * lane) << 2, (int)word), hi = (uint32_t)__builtin_amdgcn_ds_bpermute((23 + 2 * lane) << 2, (int)word);
+      if (lane < 5) mat_lds[wave].row[lane] = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+    }
+    // header, MemChainToAlignBatched.scala:78-84 (signed bytes) -- as ext_kernel reads it
+    uint32_t hw = 0;
+    if (lane < 2) hw = __hip_atomic_load(const_cast<uint32_t*>(wire) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t hdr0 = (uint32_t)__builtin_amdgcn_readlane((int)hw, 0), hdr1 = (uint32_t)__builtin_amdgcn_readlane((int)hw, 1);
+    const int oDel = (int8_t)(hdr0 & 0xff), eDel = (int8_t)((hdr0 >> 8) & 0xff);
+    const int oIns = (int8_t)((hdr0 >> 16) & 0xff), eIns = (int8_t)((hdr0 >> 24) & 0xff);
+    const int penClip5 = (int8_t)(hdr1 & 0xff), penClip3 = (int8_t)((hdr1 >> 8) & 0xff);
+    const int wBand = (int8_t)((hdr1 >> 16) & 0xff);
+    const int oe_min = min(oIns + eIns, oDel + eDel);
+    const int exact_a = (oe_min > 0 && wBand >= 2) ? sc.exact_a : 0;
+    const int amax = sc.tail_bound ? sc.mat_max : 0;
+    const int t_end = min(n_tasks, ((int)unit + 1) * per_unit);
+    for (int task = (int)unit * per_unit; task < t_end; ++task)
+      ext_do_task<false, 1, true>(task, 0, lane, wire, out, sc, mat_lds[wave], oDel, eDel, oIns, eIns, penClip5, penClip3, wBand, exact_a, amax, nullptr, nullptr, ts, pl,
+                                  nullptr, 255, nullptr, 0);
+    ring_unit_done(A, lane, W, word);
+  }
+}
+
 }  // namespace
+
+hipError_t launch_ext_resident(const RingArgs& A, int blocks, hipStream_t s) {
+  const size_t per_wave = (((size_t)EXT_RING_RCAP + 15) & ~(size_t)15) + ((5 * ((size_t)EXT_RING_QCAP + 2) + 15) & ~(size_t)15);
+  const size_t lds = per_wave * WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(ext_resident_kernel, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), lds, s, A, (int)EXT_RING_QCAP, (int)EXT_RING_RCAP, (int)per_wave);
+  return hipGetLastError();
+}
 
 size_t ext_lds_per_wave(int qcap, int rcap) {
   size_t b = 8 * (size_t)(qcap + 2) + 5 * (size_t)qcap + (size_t)rcap;

@@ -147,6 +147,7 @@ hipError_t launch_sw_kernel(const SwJobsDev& jobs, const SwScoring& sc, int max_
 // the ring (*bias_out = the packed kernel's score bias), 0 when it needs a launch of its own.
 int sw_ring_class(const SwScoring& sc, int max_qlen, int max_tlen, int* bias_out);
 hipError_t launch_swp_resident(int c_class, const RingArgs& A, int blocks, hipStream_t s);
+hipError_t launch_ext_resident(const RingArgs& A, int blocks, hipStream_t s);  // bpsw_extend.hip: the extension ring's kernel (RING_CLASS_EXT)
 
 // host side of the ring (bpsw_ring.cpp).  BPSW_RING=0 sends every call through a launch of its own, as before round 5.
 bool ring_enabled();

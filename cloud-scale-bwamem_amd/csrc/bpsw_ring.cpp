@@ -45,9 +45,10 @@ struct RingService {
   uint64_t epochs_timed = 0;
 };
 
-// one service per device and ring class (3: mates up to 171 bases, 5: up to 256)
-RingService g_rings[64][2];
-RingService& service(int device, int c_class) { return g_rings[device >= 0 && device < 64 ? device : 0][c_class == 3 ? 0 : 1]; }
+// one service per device and ring class
+constexpr int kRingClasses = 3;  // 3: SW jobs with mates up to 171 bases, 5: up to 256, RING_CLASS_EXT: small extension batches
+RingService g_rings[64][kRingClasses];
+RingService& service(int device, int c_class) { return g_rings[device >= 0 && device < 64 ? device : 0][c_class == 3 ? 0 : c_class == RING_CLASS_EXT ? 2 : 1]; }
 
 int hip_fail_ring(hipError_t e, const char* what) { return fail(BPSW_ERR_DEVICE, std::string("ring: ") + what + ": " + hipGetErrorString(e)); }
 #define RING_TRY(expr)                                      \
@@ -120,7 +121,8 @@ int start_epoch(RingService& S) {
     // 2.98 / 2.24 / 1.96 (3.67; host-bound) -- so only the second class grows, to 2.  The choice holds for the epoch (it ends with its
     // 16 384 batches or 2 ms after the last one).  BPSW_RING_WG_PER_CU fixes it.
     const bool alone = ext_call_age_ms(S.device) > 20.0;
-    const double dflt = S.c_class == 3 ? 1.0 : (alone ? 2.0 : 0.5);
+    // (the extension ring serves small batches only: one workgroup per CU, idle unless such calls are being made)
+    const double dflt = S.c_class == RING_CLASS_EXT ? 1.0 : S.c_class == 3 ? 1.0 : (alone ? 2.0 : 0.5);
     const double per_cu = getenv("BPSW_RING_WG_PER_CU") ? atof(getenv("BPSW_RING_WG_PER_CU")) : dflt;
     const int blocks = (int)(S.num_cu * (per_cu > 0.0 ? per_cu : 1.0));
     S.blocks = blocks < 2 ? 2 : blocks;
@@ -142,7 +144,7 @@ int start_epoch(RingService& S) {
   // go on with a launch per batch)
   static const int fail_at = env_int("BPSW_RING_TEST_FAIL_LAUNCH", 0);
   if (e == hipSuccess && fail_at > 0 && S.epochs + 1 == (uint64_t)fail_at) e = hipErrorLaunchFailure;
-  if (e == hipSuccess) e = launch_swp_resident(S.c_class, A, S.blocks, S.stream);
+  if (e == hipSuccess) e = S.c_class == RING_CLASS_EXT ? launch_ext_resident(A, S.blocks, S.stream) : launch_swp_resident(S.c_class, A, S.blocks, S.stream);
   if (e == hipSuccess) { e = hipEventRecord(S.ev_end[slot], S.stream); S.ev_pending[slot] = e == hipSuccess; }
   if (e != hipSuccess) { S.broken = true; return hip_fail_ring(e, "epoch launch"); }
   S.running = true;
@@ -293,7 +295,7 @@ double ring_ticks_per_ms(int device, int c_class) { return 1000.0 * (double)serv
 // Closes the open epochs of a device and waits for their kernels to end; the rings stay locked until ring_resume, so that a
 // device-wide synchronisation in between (bpsw_ref_load / unload) cannot be held up by an epoch other threads keep feeding.
 void ring_pause(int device) {
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < kRingClasses; ++k) {
     RingService& S = g_rings[device >= 0 && device < 64 ? device : 0][k];
     S.mu.lock();
     ++S.pause_depth;
@@ -305,7 +307,7 @@ void ring_pause(int device) {
   }
 }
 void ring_resume(int device) {
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < kRingClasses; ++k) {
     RingService& S = g_rings[device >= 0 && device < 64 ? device : 0][k];
     if (--S.pause_depth == 0 && S.inited && !S.running && S.carry_n && !S.broken) (void)start_epoch(S);
     S.mu.unlock();
@@ -315,7 +317,7 @@ void ring_resume(int device) {
 void ring_get_stats(int device, uint64_t* epochs, uint64_t* submitted, uint64_t* carried, double* epochs_ms, uint64_t* epochs_timed) {
   uint64_t e = 0, s = 0, c = 0, t = 0;
   double ms_sum = 0.;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < kRingClasses; ++k) {
     RingService& S = g_rings[device >= 0 && device < 64 ? device : 0][k];
     std::lock_guard<std::recursive_mutex> lk(S.mu);
     // the durations of the epochs that are over (an epoch that is still open, or has not left the device yet, is not counted)

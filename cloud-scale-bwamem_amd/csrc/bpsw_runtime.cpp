@@ -396,7 +396,7 @@ double bpsw_diag_wait_est_update(double est, double took_ms, int polls, int napp
 int bpsw_diag_wait_naps(double est_ms) { return bpsw::wait_naps(est_ms) ? 1 : 0; }
 
 const char* bpsw_version(void) {
-  return "bPSW-hip 0.5 (gfx950)";  // 0.5 = round 5: bpsw_stats_t grew (sw_ring_calls): rebuild callers against include/bpsw.h
+  return "bPSW-hip 0.5 (gfx950)";  // 0.5 = round 5: bpsw_stats_t grew (sw_ring_calls, ext_ring_calls): rebuild callers against include/bpsw.h
 }
 
 int bpsw_device_count(void) {
@@ -732,7 +732,75 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   const double t_staged = stat_ms();
   double t_dev0, t_dev1, copy_first_ms = 0.;
   bool kernel_was_last = false, relaunched = false;
+  // The submission ring (bpsw_ring.h, class RING_CLASS_EXT): a SMALL batch -- no task for the full kernel, too few for the sift kernel to
+  // pay, every flank within the resident kernel's fixed LDS geometry -- becomes one descriptor of the device's resident extension kernel:
+  // one bulk copy on the copy lane, no stream, no launch, no event; its tasks are taken by the same wave population as every other
+  // thread's, and the call waits on a completion record in its own pinned block.  These are the calls a launch costs most: the
+  // reference sends everything below -FPGASWExtThreshold tasks... above it, batches of a few dozen tasks in the later rounds of
+  // memChainToAlnBatched (worker1/MemChainToAlignBatched.scala:471-615).  BPSW_EXT_RING=0 (or BPSW_RING=0): a launch per call, as before.
+  bool via_ring = false;
+  float ring_kernel_ms = 0.f;
   {
+    static const bool ext_ring_on = !(getenv("BPSW_EXT_RING") && atoi(getenv("BPSW_EXT_RING")) == 0);
+    // (up to 512 tasks: a lone call of 61 / 253 tasks takes 0.087 / 0.091 ms through the ring against 0.111 / 0.112 with a launch, one of
+    // 1 019 tasks 0.22 against 0.12 -- the epoch's grid is one wave per SIMD, a launch of its own fills the device --, and sixteen
+    // callers make 105 k / 46 k calls/s of 63 / 253 tasks against 32 k / 18 k: tests/small_call_table.py)
+    static const int ext_ring_max = getenv("BPSW_EXT_RING_MAX_TASKS") ? atoi(getenv("BPSW_EXT_RING_MAX_TASKS")) : 512;
+    const bool eligible = ring_enabled() && ext_ring_on && use_short && n_long == 0 && !use_sift && !side_how && !coord && !zc_slots &&
+                          (zerocopy_mask() & 1) != 0 && mq <= 255 && mr_short <= EXT_RING_RCAP && n <= ext_ring_max;
+    if (eligible && ring_usable(c->device, RING_CLASS_EXT)) {
+      t_dev0 = stat_ms();
+      // Where the workers read the batch from: up to BPSW_EXT_RING_ZC_BYTES (64 KB: some 500 tasks of 2x150 bp reads) straight from the
+      // pinned staging block -- a task's record and flanks are a handful of reads, the tasks are spread over a thousand waves, and a
+      // copy's latency would be most of such a call (253 tasks: 0.091 ms zero-copy, 0.127 with a copy on the context's stream; sixteen
+      // callers' copies on the device's ONE copy lane were the bound of the first version, 50 k calls/s) --; above, one bulk copy into
+      // the context's device buffer on the context's own stream, waited for before the descriptor is published.
+      static const size_t ring_zc_bytes = getenv("BPSW_EXT_RING_ZC_BYTES") ? (size_t)atoll(getenv("BPSW_EXT_RING_ZC_BYTES")) : 65536;
+      const void* ring_wire = c->h_stage_in.ptr;
+      if (wire_bytes > ring_zc_bytes) {
+        HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, wire_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        HIP_TRY(wait_event(c, c->ev[0], 2));
+        ring_wire = c->d_wire.ptr;
+        copy_first_ms = stat_ms() - t_dev0;
+      }
+      RingDesc desc;
+      memset(&desc, 0, sizeof desc);
+      RingDescHead head;
+      memset(&head, 0, sizeof head);
+      RingDone* done = (RingDone*)((char*)c->h_pre.ptr + 448);
+      if (++c->ring_seq == 0) ++c->ring_seq;
+      const int per_unit = n <= 2048 ? 1 : 4;  // tasks per ticket: one atomic per task is fine for a few hundred tasks
+      head.n_units = (uint32_t)((n + per_unit - 1) / per_unit);
+      head.done_value = c->ring_seq;
+      head.done_ptr = (uint64_t)(uintptr_t)done;
+      ExtRingPayload pl;
+      memset(&pl, 0, sizeof pl);
+      pl.wire = (uint64_t)(uintptr_t)ring_wire; pl.out = (uint64_t)(uintptr_t)c->h_stage_out.ptr;
+      pl.n_tasks = n; pl.per_unit = per_unit; pl.out_stride = c->ext_sc.out_stride;
+      pl.zdrop = c->ext_sc.zdrop; pl.zdrop_mode = c->ext_sc.zdrop_mode; pl.mat_max = c->ext_sc.mat_max; pl.exact_a = c->ext_sc.exact_a;
+      pl.tail_bound = c->ext_sc.tail_bound; pl.certify = c->ext_sc.certify;
+      for (int r = 0; r < 5; ++r) pl.mat_row[r] = c->ext_sc.mat.row[r];
+      memcpy(desc.w, &head, sizeof head);
+      memcpy(desc.w + sizeof(RingDescHead) / 4, &pl, sizeof pl);
+      int rc = ring_submit(c->device, RING_CLASS_EXT, c->num_cu, desc);
+      if (rc != BPSW_OK && !ring_usable(c->device, RING_CLASS_EXT)) {
+        // the epoch could not be started (nothing of this batch has reached a worker): this call and the later ones take launches of their own
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true)) fprintf(stderr, "bPSW: the extension ring of device %d failed (%s); small extension batches are launched one by one from here on\n", c->device, bpsw_last_error());
+        copy_first_ms = 0.;
+      } else {
+        if (rc != BPSW_OK) return rc;
+        rc = ring_wait(c->device, RING_CLASS_EXT, done, c->ring_seq, &c->wait_est_ms[0]);
+        if (rc != BPSW_OK) return rc;
+        ring_kernel_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, RING_CLASS_EXT));
+        t_dev1 = stat_ms();
+        via_ring = true;
+        c->stats.ext_ring_calls++;
+      }
+    }
+  }
+  if (!via_ring) {
     // The copy of the wire batch.  While rescue batches are in flight on this device (bpsw_sw_runtime.cpp counts them) it is made
     // and waited for BEFORE the call takes a pooled stream, on the device's copy lane (one such copy at a time): the stream is then
     // held for the kernels only, and one bulk copy crosses PCIe at a time instead of several beside the rescue path's transfers.  configs[2]: the device phase of an extension call 1.07 -> 0.93 ms, the step +2.7 % (2.03 -> 2.09 x
@@ -869,10 +937,15 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   }
   const double t_out = stat_ms();
   float a = 0, b = 0, d = 0;
-  (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
-  (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-  if (relaunched) { float b2 = 0; (void)hipEventElapsedTime(&b2, c->ev[4], c->ev[5]); b += b2; }
-  if (!kernel_was_last) (void)hipEventElapsedTime(&d, relaunched ? c->ev[5] : c->ev[2], c->ev[3]);
+  if (via_ring) {
+    b = ring_kernel_ms;  // first task taken -> last task finished, on the device's clock
+    t_dev0 += copy_first_ms;  // (booked once below, with the copy)
+  } else {
+    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+    if (relaunched) { float b2 = 0; (void)hipEventElapsedTime(&b2, c->ev[4], c->ev[5]); b += b2; }
+    if (!kernel_was_last) (void)hipEventElapsedTime(&d, relaunched ? c->ev[5] : c->ev[2], c->ev[3]);
+  }
   c->stats.ext_calls++; c->stats.ext_tasks += (uint64_t)n; c->stats.ext_wire_bytes += wire_bytes;
   c->stats.ext_h2d_ms += a + copy_first_ms; c->stats.ext_kernel_ms += b; c->stats.ext_d2h_ms += d;
   c->stats.ext_host_in_ms += t_staged - t_in; c->stats.ext_dev_ms += t_dev1 - t_dev0 + copy_first_ms; c->stats.ext_host_out_ms += t_out - t_dev1;

@@ -74,7 +74,7 @@ int bpsw_device_slots(void);                  /* number of entries; 0 = no usabl
 int bpsw_device_for_partition(int partition); /* HIP device index of that entry, -1 = no usable device / negative partition */
 const char *bpsw_last_error(void); /* thread-local text of the last failing call */
 const char *bpsw_version(void); /* "bPSW-hip <major.minor> (gfx950)": structs of this header only ever grow at their end, and the minor
-                                   number changes when one does (0.4: bpsw_stats_t::ext_full_relaunches, bpsw_tail_opt_t::rg_id; 0.5: bpsw_stats_t::sw_ring_calls) */
+                                   number changes when one does (0.4: bpsw_stats_t::ext_full_relaunches, bpsw_tail_opt_t::rg_id; 0.5: bpsw_stats_t::sw_ring_calls, ext_ring_calls) */
 
 /* ---- scoring that boundary 2 does not transmit (zdrop, mat) ------------------ */
 /* defaults: MemOptType (datatype/MemOptType.scala:28-73): a=1 b=4 N=-1, zdrop=100, Scala z-drop parse */
@@ -454,6 +454,8 @@ typedef struct {
   uint64_t ext_full_relaunches; /* extension calls whose short kernel deferred tasks, so that the full kernel was launched behind it after all */
   uint64_t sw_ring_calls;       /* SW batches that went through the device's submission ring (resident kernel) instead of a launch of their own;
                                    for those sw_kernel_ms is the batch's span on the device clock: first job pair taken -> last one finished */
+  uint64_t ext_ring_calls;      /* extension batches (small ones: no long flank, too few tasks for the sift kernel) that went through the
+                                   device's extension ring; ext_kernel_ms likewise: first task taken -> last one finished */
 } bpsw_stats_t;
 int bpsw_get_stats(bpsw_ctx_t *ctx, bpsw_stats_t *out);
 int bpsw_reset_stats(bpsw_ctx_t *ctx);

@@ -97,6 +97,32 @@ def main():
                 "per_caller_rate_vs_reference_core": round(cpu / float(np.mean([it.ms for it in items])), 3) if cpu else None,
                 "ring_batches": int(st.get("sw_ring_calls", 0))})
             F.close()
+    # ... and the same for small EXTENSION calls (the extension ring, round 5; BPSW_EXT_RING=0: a launch per call)
+    out["extend_concurrent"] = []
+    for n in (64, 256):
+        soas = [synth.ext_tasks(int(n * 1.08) + 2, read_len=150, seed=synth.CONFIG_SEED_BASE + 9 + 7 * j) for j in range(128)]
+        soas = [s_.subset(np.arange(min(n, s_.n))) for s_ in soas]
+        wires = [bpsw_hip.wire_pack(s_) for s_ in soas]
+        outs = [np.zeros(10 * s_.n, np.int16) for s_ in soas]
+        items, _ = fd.make_items(wires, outs, [], [], [], [])
+        cpu = timed(lambda s_: ref.extend_batch(s_, mat), soas[:32], 1) if ref else None
+        for T in (1, 4, 16):
+            F = fd.Feeder(T, 0, opt, bpsw_hip.RESCUE_C)
+            F.run(items, 2)
+            F.reset_stats()
+            t0 = time.perf_counter()
+            reps = 8
+            F.run(items, reps)
+            dt = time.perf_counter() - t0
+            calls = reps * len(items)
+            st = F.stats_sum()
+            out["extend_concurrent"].append({
+                "tasks_per_call": int(np.mean([s_.n for s_ in soas])), "callers": T,
+                "ms_per_call_as_a_caller_sees_it": round(float(np.mean([it.ms for it in items])), 4),
+                "calls_per_s_all_callers": round(calls / dt, 1), "reference_c_one_core_ms": round(cpu, 4) if cpu else None,
+                "per_caller_rate_vs_reference_core": round(cpu / float(np.mean([it.ms for it in items])), 2) if cpu else None,
+                "ring_batches": int(st.get("ext_ring_calls", 0))})
+            F.close()
     out["note"] = ("one calling thread, distinct inputs per call, host buffers in and out; reference C = oracle/_ref (the reference's own ksw_extend2 / "
                    "mem_group_matesw with SSE2 ksw_align2) on one host core of the GPU box; p_resc = 10 % of the pairs need rescue (configs[2])")
     print(json.dumps(out, indent=1))
@@ -110,6 +136,10 @@ def main():
         print(f"| {r['callers']} | {r['pairs_per_call']} ({r['sw_jobs_per_call']} SW jobs) | {r['ms_per_call_as_a_caller_sees_it']} | {r['calls_per_s_all_callers']} | "
               f"{r['reference_c_one_core_ms']} | {r['per_caller_rate_vs_reference_core']}x |")
 
+    print("\n| callers | tasks per call | ms per call (caller's view) | calls/s, all callers | reference C, one core, ms | per caller vs one core | through the ring |\n|---|---|---|---|---|---|---|")
+    for r in out["extend_concurrent"]:
+        print(f"| {r['callers']} | {r['tasks_per_call']} | {r['ms_per_call_as_a_caller_sees_it']} | {r['calls_per_s_all_callers']} | {r['reference_c_one_core_ms']} | "
+              f"{r['per_caller_rate_vs_reference_core']}x | {r['ring_batches']} |")
 
 if __name__ == "__main__":
     main()
