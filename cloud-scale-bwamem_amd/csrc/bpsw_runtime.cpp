@@ -742,10 +742,11 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   float ring_kernel_ms = 0.f;
   {
     static const bool ext_ring_on = !(getenv("BPSW_EXT_RING") && atoi(getenv("BPSW_EXT_RING")) == 0);
-    // (up to 512 tasks: a lone call of 61 / 253 tasks takes 0.087 / 0.091 ms through the ring against 0.111 / 0.112 with a launch, one of
-    // 1 019 tasks 0.22 against 0.12 -- the epoch's grid is one wave per SIMD, a launch of its own fills the device --, and sixteen
-    // callers make 105 k / 46 k calls/s of 63 / 253 tasks against 32 k / 18 k: tests/small_call_table.py)
-    static const int ext_ring_max = getenv("BPSW_EXT_RING_MAX_TASKS") ? atoi(getenv("BPSW_EXT_RING_MAX_TASKS")) : 512;
+    // (up to 256 tasks.  A lone call of 63 / 126 / 253 tasks takes 0.084 / 0.086 / 0.09-0.15 ms through the ring against 0.108 / 0.105 /
+    // 0.10-0.12 with a launch, one of 1 019 tasks 0.22 against 0.12 -- the epoch's grid is one wave per SIMD, a launch of its own fills
+    // the device --; sixteen callers make 105 k / 68 k / 46 k calls/s against 33 k / 30 k / 26 k, four callers 46 k / 37 k / 22 k against
+    // 32 k / 30 k / 22 k: tests/small_call_table.py, profiles/r05_small_calls*.txt)
+    static const int ext_ring_max = getenv("BPSW_EXT_RING_MAX_TASKS") ? atoi(getenv("BPSW_EXT_RING_MAX_TASKS")) : 256;
     const bool eligible = ring_enabled() && ext_ring_on && use_short && n_long == 0 && !use_sift && !side_how && !coord && !zc_slots &&
                           (zerocopy_mask() & 1) != 0 && mq <= 255 && mr_short <= EXT_RING_RCAP && n <= ext_ring_max;
     if (eligible && ring_usable(c->device, RING_CLASS_EXT)) {

@@ -99,7 +99,7 @@ def main():
             F.close()
     # ... and the same for small EXTENSION calls (the extension ring, round 5; BPSW_EXT_RING=0: a launch per call)
     out["extend_concurrent"] = []
-    for n in (64, 256):
+    for n in (64, 128, 256):
         soas = [synth.ext_tasks(int(n * 1.08) + 2, read_len=150, seed=synth.CONFIG_SEED_BASE + 9 + 7 * j) for j in range(128)]
         soas = [s_.subset(np.arange(min(n, s_.n))) for s_ in soas]
         wires = [bpsw_hip.wire_pack(s_) for s_ in soas]

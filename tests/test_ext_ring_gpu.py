@@ -89,7 +89,7 @@ def test_small_extension_batches_through_the_ring_are_bit_exact():
     if os.environ.get("BPSW_RING", "1") == "0":
         pytest.skip("BPSW_RING=0")
     line = _run({})
-    assert int(line[1]) >= 10      # of the eighteen lone calls: those of up to 512 tasks (BPSW_EXT_RING_MAX_TASKS)
+    assert int(line[1]) >= 10      # of the eighteen lone calls: those of up to 256 tasks (BPSW_EXT_RING_MAX_TASKS)
 
 
 def test_the_same_calls_with_the_extension_ring_switched_off():
