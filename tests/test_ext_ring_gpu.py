@@ -37,6 +37,23 @@ for wire, want in cases:
         assert np.array_equal(got, want), ("lone call", wire.size)
 taken = ctx.stats().ext_ring_calls - before
 assert (taken > 0) == ring_expected and taken <= 2 * len(cases), (taken, ring_expected)   # (a batch without tasks, or with a target flank beyond the resident kernel's LDS, is not the ring's)
+# the reference's own symbol, swExtendFPGAJNI, through the fake JNIEnv: its stage / commit pair takes the same path (the shim's
+# per-thread context: its handle from bpsw_jni_thread_info, its statistics through the C ABI)
+import ctypes as C
+from bpsw_hip import jnishim
+fake, lib = jnishim.load_fake()
+wire_j, want_j = cases[2]
+n_j = int(np.frombuffer(wire_j[8:12].tobytes(), "<i4")[0])
+for _ in range(2):
+    rc, out_j, msg = jnishim.extend(fake, wire_j, n_j)
+    assert rc == 0, msg
+    assert np.array_equal(np.asarray(out_j).reshape(-1), want_j), "swExtendFPGAJNI"
+lib.bpsw_jni_thread_info.restype = C.c_uint64
+three = (C.c_int32 * 3)()
+h = lib.bpsw_jni_thread_info(three)
+st = bpsw_hip.Stats()
+assert h and lib.bpsw_get_stats(C.c_void_p(h), C.byref(st)) == 0
+assert (st.ext_ring_calls >= 2) == ring_expected, (st.ext_ring_calls, ring_expected)
 # a custom matrix and other gap costs ride in the descriptor
 soa = synth.ext_tasks(300, read_len=150, seed=7200)
 for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
