@@ -109,6 +109,13 @@ int start_epoch(RingService& S) {
   A.sleep_ticks_us = S.ticks_per_us;
   A.idle_ticks = (unsigned long long)env_int("BPSW_RING_IDLE_US", 2000) * S.ticks_per_us;
   A.worker_idle_ticks = (unsigned long long)env_int("BPSW_RING_WORKER_IDLE_US", 50000) * S.ticks_per_us;
+  // how long a waiting worker sleeps at most between two looks: 16 rounds, ~55 us, for every class.  (A quarter of that was tried for
+  // the extension ring, whose tasks are 20-40 us each: a lone call is no faster -- 0.083-0.091 ms either way --, and sixteen callers of
+  // 63 / 126-task calls make 85 k / 61 k calls/s instead of 103 k / 71 k: a thousand waiting waves that look four times as often are
+  // in the working waves' way.)
+  A.nap_rounds_max = (uint32_t)env_int("BPSW_RING_NAP_ROUNDS", 16);
+  if (A.nap_rounds_max < 1) A.nap_rounds_max = 1;
+  A.pad = 0;
   {
     // Worker workgroups per CU (four wavefronts each).  The resident grid holds its wave slots for as long as the epoch lives, and more
     // workers are not more throughput: the device is shared with the extension kernels, and what a worker more takes from them costs the

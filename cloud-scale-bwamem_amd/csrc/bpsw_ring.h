@@ -128,6 +128,8 @@ struct RingArgs {
   unsigned long long idle_ticks;         // poller: close after this long without a new descriptor and nothing left to hand out
   unsigned long long worker_idle_ticks;  // worker: leave after this long without work, whatever the poller does
   unsigned long long sleep_ticks_us;     // device clock ticks per microsecond (hipDeviceAttributeWallClockRate / 1000)
+  uint32_t nap_rounds_max;               // a waiting worker's longest nap, in rounds of ~3.4 us (16: ~55 us)
+  uint32_t pad;
 };
 
 }  // namespace bpsw

@@ -137,7 +137,8 @@ __device__ inline bool ring_next_unit(const RingArgs& A, const int lane, RingWor
       // to slow every kernel on the device down several times.
       __builtin_amdgcn_s_sleep(32);
       if (naps >= 6) {
-        const int rounds = naps >= 12 ? 16 : (1 << ((naps - 6) / 2 + 1)) / 2;  // 1, 1, 2, 2, 4, 4, then 16 x 3.4 us
+        int rounds = naps >= 12 ? 16 : (1 << ((naps - 6) / 2 + 1)) / 2;  // 1, 1, 2, 2, 4, 4, then 16 x 3.4 us
+        if (rounds > (int)A.nap_rounds_max) rounds = (int)A.nap_rounds_max;   // (BPSW_RING_NAP_ROUNDS)
         for (int r = 0; r < rounds; ++r) __builtin_amdgcn_s_sleep(127);
       }
       ++naps;
