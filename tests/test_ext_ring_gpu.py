@@ -21,7 +21,7 @@ import bpsw_hip
 from bpsw_hip import synth
 import pyoracle as po
 orc = po.Oracle()
-ring_expected = os.environ.get("BPSW_EXT_RING", "1") != "0" and os.environ.get("BPSW_RING", "1") != "0"
+ring_expected = os.environ.get("BPSW_EXT_RING", "1") != "0" and os.environ.get("BPSW_RING", "1") != "0" and not os.environ.get("BPSW_RING_TEST_FAIL_LAUNCH")
 ctx = bpsw_hip.Context(0)
 cases = []
 for k, (n, rl) in enumerate(((1, 150), (7, 150), (61, 150), (64, 100), (253, 150), (1019, 150), (3000, 150), (200, 250), (2500, 250))):
@@ -96,7 +96,7 @@ def _run(extra_env):
     src = _CHILD.format(pkg=os.path.join(ROOT, "cloud-scale-bwamem_amd"), orc=os.path.join(ROOT, "oracle"), tests=os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
-    return [ln for ln in r.stdout.splitlines() if ln.startswith("EXTRING")][0].split()
+    return [ln for ln in r.stdout.splitlines() if ln.startswith("EXTRING")][0].split() + [r.stderr]
 
 
 def test_small_extension_batches_through_the_ring_are_bit_exact():
@@ -122,3 +122,13 @@ def test_a_tiny_extension_ring_rolls_over():
     line = _run({"BPSW_RING_CAPACITY": "64", "BPSW_EXT_RING_MAX_TASKS": "8192", "BPSW_EXT_RING_ZC_BYTES": "0"})
     assert int(line[1]) == 18
     assert int(line[2]) >= 5   # epochs (both rings)
+
+
+def test_an_extension_ring_that_cannot_launch_sends_its_callers_back_to_launches():
+    """BPSW_RING_TEST_FAIL_LAUNCH=1: the first epoch launch of every ring of the device "fails".  The call that met the failure and every
+    later one take kernel launches of their own -- the same records, one line on stderr per ring, no error to any caller."""
+    if os.environ.get("BPSW_RING", "1") == "0":
+        pytest.skip("BPSW_RING=0")
+    line = _run({"BPSW_RING_TEST_FAIL_LAUNCH": "1"})
+    assert int(line[1]) == 0
+    assert "the extension ring of device 0 failed" in line[-1] and "the submission ring of device 0 failed" in line[-1]
