@@ -114,6 +114,13 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
   int ring_bias = 0;
   int ring_class = (ring_enabled() && zc_in && zc_out) ? sw_ring_class(sc, mq, mt, &ring_bias) : 0;
   if (ring_class && !ring_usable(c->device, ring_class)) ring_class = 0;  // a ring that failed earlier: a launch per batch, as before round 5
+  // A LONE caller with a sizeable batch -- no other SW batch in flight on the device, no extension call on it for 20 ms -- is better off
+  // with a launch of its own: the epoch's grid is one or two waves per SIMD, a launch fills the device (256 / 1 024 / 4 096 pairs per
+  // call, one calling thread: 0.28 / 0.33 / 0.48 ms through the ring, 0.23 / 0.27 / 0.38 with a launch; below sixteen jobs the ring wins:
+  // tests/small_call_table.py).  As soon as callers overlap, or extension launches keep the queues busy, the ring it is.
+  // BPSW_RING_LONE_LAUNCH=0: the ring whenever it can.
+  static const bool lone_launch = !(getenv("BPSW_RING_LONE_LAUNCH") && atoi(getenv("BPSW_RING_LONE_LAUNCH")) == 0);
+  if (ring_class && lone_launch && n >= 16 && sw_launches_in_flight(c->device) == 0 && ext_call_age_ms(c->device) > 20.0) ring_class = 0;
   if (ring_class) {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
     const double t_dev0 = stat_ms();

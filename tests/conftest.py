@@ -12,6 +12,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 # (tests/test_production_defaults_gpu.py runs a slice of the suite once more with the library's own threshold)
 if not os.environ.get("BPSW_TEST_PRODUCTION_DEFAULTS"):
     os.environ.setdefault("BPSW_EXT_SIFT_MIN", "0")
+    # a lone caller's sizeable SW batch takes a launch of its own (csrc/bpsw_sw_runtime.cpp): the tests, mostly lone callers, want the
+    # submission ring whenever it can take the batch (tests/test_ring_gpu.py::test_a_lone_caller_... checks the rule itself)
+    os.environ.setdefault("BPSW_RING_LONE_LAUNCH", "0")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "cloud-scale-bwamem_amd")

@@ -218,3 +218,59 @@ def test_a_ring_that_cannot_launch_sends_its_callers_back_to_launches():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RINGCALLS")][0]
     assert line.split()[1] == "0", line              # the last context never used the ring
     assert "submission ring of device 0 failed" in r.stderr
+
+
+_LONE = r"""
+import os, sys, threading
+import numpy as np
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {orc!r})
+import bpsw_hip
+from bpsw_hip import synth
+import pyoracle as po
+XTRA = po.KSW_XSUBO | po.KSW_XSTART | po.KSW_XBYTE | 19
+orc = po.Oracle()
+small, big = synth.sw_jobs(8, seed=590), synth.sw_jobs(400, seed=591)
+want_s, want_b = (orc.sw_align2_jobs(orc.default_opt(), XTRA, **j)[0] for j in (small, big))
+c = bpsw_hip.Context(0)
+opt = bpsw_hip.default_opt()
+r0 = c.stats().sw_ring_calls
+for _ in range(3):
+    assert np.array_equal(c.swalign2_batch(opt, XTRA, **small), want_s)
+r1 = c.stats().sw_ring_calls
+for _ in range(3):
+    assert np.array_equal(c.swalign2_batch(opt, XTRA, **big), want_b)
+r2 = c.stats().sw_ring_calls
+# ... and with company: four threads of the big batch overlap, most of their calls find another one in flight
+errs, ringed = [], [0]
+def worker(t):
+    try:
+        cc = bpsw_hip.Context(0)
+        for _ in range(25):
+            assert np.array_equal(cc.swalign2_batch(opt, XTRA, **big), want_b)
+        ringed[0] += cc.stats().sw_ring_calls
+        cc.close()
+    except BaseException as e:
+        errs.append(repr(e))
+ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+[t.start() for t in ts]; [t.join(300) for t in ts]
+assert not errs, errs[:2]
+print("LONE", r1 - r0, r2 - r1, ringed[0])
+c.close()
+"""
+
+
+def test_a_lone_caller_with_a_sizeable_batch_takes_a_launch_of_its_own():
+    """The library's default (BPSW_RING_LONE_LAUNCH unset; the suite pins it to 0): with no other SW batch in flight and no extension call
+    about, a batch of sixteen jobs or more is launched -- a lone caller gets the whole device, 0.38 instead of 0.48 ms for 4 096 pairs --,
+    smaller ones and every batch that has company go through the ring.  Bit-exact either way."""
+    if not RING_ON:
+        pytest.skip("BPSW_RING=0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("BPSW_RING_LONE_LAUNCH", None)
+    src = _LONE.format(pkg=os.path.join(root, "cloud-scale-bwamem_amd"), orc=os.path.join(root, "oracle"))
+    r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    small_ringed, big_ringed, company_ringed = (int(x) for x in [ln for ln in r.stdout.splitlines() if ln.startswith("LONE")][0].split()[1:])
+    assert small_ringed == 3 and big_ringed == 0
+    assert company_ringed >= 50      # of 100 overlapping calls
