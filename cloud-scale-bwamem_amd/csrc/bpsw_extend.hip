@@ -397,7 +397,7 @@ __global__ void ext_prepass_kernel(const uint32_t* __restrict__ wire, const unsi
 // The resident form of the short kernel (bpsw_ring.h, class RING_CLASS_EXT): the same tasks, taken a unit at a time from the descriptors
 // task threads append to the device's submission ring instead of from one launch's queue.  Wavefront 0 of workgroup 0 is the ring's
 // poller; every other wavefront is a worker.  Only what needs neither the sift kernel nor the full kernel comes here (small batches
-// of flanks up to 255 bases: the host checks), so a descriptor is ONE phase: its units are its tasks.  LDS geometry fixed for the epoch.
+// of flanks up to 255 bases, of either wire format: the host checks), so a descriptor is ONE phase: its units are its tasks.  LDS geometry fixed for the epoch.
 // The batch is read with ordinary (vector) loads from a pointer that arrives in the descriptor -- nothing here is `__restrict__` kernel
 // argument memory the compiler may keep in the scalar cache across batches -- and a unit's first act is ring_next_unit's invalidate of
 // the vector cache: a caller's staging buffer is reused from batch to batch.
@@ -430,7 +430,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
     ExtScoring sc;
     sc.out_stride = (int)f32(14); sc.zdrop = (int)f32(15); sc.zdrop_mode = (int)f32(16); sc.mat_max = (int)f32(17);
     sc.exact_a = (int)f32(18); sc.tail_bound = (int)f32(19); sc.certify = (int)f32(20);
-    sc.side_how = nullptr; sc.pac = nullptr; sc.l_pac = 0;
+    const bool coord = f32(21) != 0u;  // a coordinate batch (wire format 2): target flanks from the device-resident reference
+    sc.side_how = nullptr; sc.pac = coord ? (const uint8_t*)f64(32) : nullptr; sc.l_pac = coord ? (long long)f64(34) : 0ll;
     // the matrix rows into this wave's LDS copy (lane r: row r, descriptor words 22 + 2r, 23 + 2r)
     {
       const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((22 + 2 * lane) << 2, (int)word), hi = (uint32_t)__builtin_amdgcn_ds_bpermute((23 + 2 * lane) << 2, (int)word);
@@ -448,9 +449,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, BPSW_EXT_WAVES_PER_SIMD) void
     const int exact_a = (oe_min > 0 && wBand >= 2) ? sc.exact_a : 0;
     const int amax = sc.tail_bound ? sc.mat_max : 0;
     const int t_end = min(n_tasks, ((int)unit + 1) * per_unit);
-    for (int task = (int)unit * per_unit; task < t_end; ++task)
-      ext_do_task<false, 1, true>(task, 0, lane, wire, out, sc, mat_lds[wave], oDel, eDel, oIns, eIns, penClip5, penClip3, wBand, exact_a, amax, nullptr, nullptr, ts, pl,
-                                  nullptr, 255, nullptr, 0);
+    if (coord) {
+      for (int task = (int)unit * per_unit; task < t_end; ++task)
+        ext_do_task<true, 1, true>(task, 0, lane, wire, out, sc, mat_lds[wave], oDel, eDel, oIns, eIns, penClip5, penClip3, wBand, exact_a, amax, nullptr, nullptr, ts, pl,
+                                   nullptr, 255, nullptr, 0);
+    } else {
+      for (int task = (int)unit * per_unit; task < t_end; ++task)
+        ext_do_task<false, 1, true>(task, 0, lane, wire, out, sc, mat_lds[wave], oDel, eDel, oIns, eIns, penClip5, penClip3, wBand, exact_a, amax, nullptr, nullptr, ts, pl,
+                                    nullptr, 255, nullptr, 0);
+    }
     ring_unit_done(A, lane, W, word);
   }
 }

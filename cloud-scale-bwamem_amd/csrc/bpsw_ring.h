@@ -104,16 +104,19 @@ struct SwRingPayload {
 };
 static_assert(sizeof(RingDescHead) + sizeof(SwRingPayload) <= sizeof(RingDesc), "rescue payload fits a descriptor");
 
-// payload of the EXTENSION kernel's descriptors (words 8..): a wire batch of format 1 in device-visible memory whose flanks all have at
+// payload of the EXTENSION kernel's descriptors (words 8..): a wire batch (either format) in device-visible memory whose flanks all have at
 // most 255 bases (nothing for the full kernel) and that is too small for the sift kernel to pay -- the calls a launch costs most
 // (-FPGASWExtThreshold 64, the later rounds of memChainToAlnBatched: worker1/MemChainToAlignBatched.scala:471-615).  A unit is
 // `per_unit` consecutive tasks.
 constexpr int RING_CLASS_EXT = 8;
 constexpr int EXT_RING_QCAP = 256, EXT_RING_RCAP = 640;  // LDS geometry of the resident kernel: flanks of <= 255 query, <= 640 target bases
 struct ExtRingPayload {
-  uint64_t wire, out;  // the batch (device memory) and its 10-int16 records (the caller's pinned block)
-  int32_t n_tasks, per_unit, out_stride, zdrop, zdrop_mode, mat_max, exact_a, tail_bound, certify, pad;
+  uint64_t wire, out;  // the batch (device-visible memory) and its 10-int16 records (the caller's pinned block)
+  int32_t n_tasks, per_unit, out_stride, zdrop, zdrop_mode, mat_max, exact_a, tail_bound, certify;
+  int32_t coord;       // != 0: a coordinate batch (wire format 2): the target flanks come from the reference below
   uint64_t mat_row[5];
+  uint64_t pac;        // the device-resident 2-bit reference (bpsw_ref_load) and its length
+  int64_t l_pac;
 };
 static_assert(sizeof(RingDescHead) + sizeof(ExtRingPayload) <= sizeof(RingDesc), "extension payload fits a descriptor");
 

@@ -747,7 +747,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     // the device --; sixteen callers make 105 k / 68 k / 46 k calls/s against 33 k / 30 k / 26 k, four callers 46 k / 37 k / 22 k against
     // 32 k / 30 k / 22 k: tests/small_call_table.py, profiles/r05_small_calls*.txt)
     static const int ext_ring_max = getenv("BPSW_EXT_RING_MAX_TASKS") ? atoi(getenv("BPSW_EXT_RING_MAX_TASKS")) : 256;
-    const bool eligible = ring_enabled() && ext_ring_on && use_short && n_long == 0 && !use_sift && !side_how && !coord && !zc_slots &&
+    const bool eligible = ring_enabled() && ext_ring_on && use_short && n_long == 0 && !use_sift && !side_how && !zc_slots &&
                           (zerocopy_mask() & 1) != 0 && mq <= 255 && mr_short <= EXT_RING_RCAP && n <= ext_ring_max;
     if (eligible && ring_usable(c->device, RING_CLASS_EXT)) {
       t_dev0 = stat_ms();
@@ -781,6 +781,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       pl.n_tasks = n; pl.per_unit = per_unit; pl.out_stride = c->ext_sc.out_stride;
       pl.zdrop = c->ext_sc.zdrop; pl.zdrop_mode = c->ext_sc.zdrop_mode; pl.mat_max = c->ext_sc.mat_max; pl.exact_a = c->ext_sc.exact_a;
       pl.tail_bound = c->ext_sc.tail_bound; pl.certify = c->ext_sc.certify;
+      pl.coord = coord ? 1 : 0; pl.pac = (uint64_t)(uintptr_t)(coord ? d_pac : nullptr); pl.l_pac = coord ? l_pac : 0;  // (ref_hold keeps the reference put)
       for (int r = 0; r < 5; ++r) pl.mat_row[r] = c->ext_sc.mat.row[r];
       memcpy(desc.w, &head, sizeof head);
       memcpy(desc.w + sizeof(RingDescHead) / 4, &pl, sizeof pl);

@@ -54,6 +54,21 @@ h = lib.bpsw_jni_thread_info(three)
 st = bpsw_hip.Stats()
 assert h and lib.bpsw_get_stats(C.c_void_p(h), C.byref(st)) == 0
 assert (st.ext_ring_calls >= 2) == ring_expected, (st.ext_ring_calls, ring_expected)
+# coordinate batches (wire format 2: the target flanks come from the reference on the device) are descriptors like the others
+pac_c, bases_c, off_c, ln_c, names_c, dups_c = synth.contig_reference([60_000, 40_000], seed=7400)
+l_pac_c = int(off_c[-1] + ln_c[-1])
+ctx.ref_load(pac_c, l_pac_c)
+bases_fwd = np.asarray(bases_c[:l_pac_c], np.uint8)
+r_before = ctx.stats().ext_ring_calls
+for k, n_reads in enumerate((20, 64, 200)):
+    chains = synth.read_chains(n_reads, bases_fwd, l_pac_c, read_len=150, seed=7410 + k)
+    co, by = synth.coord_ext_tasks(chains, bases_fwd, seed=7420 + k)
+    want_c = np.asarray(orc.wire_extend(bpsw_hip.wire_pack(by))[0]).reshape(-1)
+    wire_c = bpsw_hip.wire_coords_pack(co)
+    for _ in range(2):
+        assert np.array_equal(np.asarray(ctx.extend_batch(wire_c)).reshape(-1), want_c), ("coordinate batch", n_reads)
+assert (ctx.stats().ext_ring_calls - r_before > 0) == ring_expected
+ctx.ref_unload()
 # a custom matrix and other gap costs ride in the descriptor
 soa = synth.ext_tasks(300, read_len=150, seed=7200)
 for zmode in (po.ZDROP_SCALA, po.ZDROP_BWA):
