@@ -5,7 +5,9 @@
 # the pool requires; rocprofv3 runs one dispatch at a time while it collects counters, and the rescue path's kernel is RESIDENT (one
 # launch per epoch of the submission ring, csrc/bpsw_ring.h) -- under the mixed workload every extension launch would wait for an epoch
 # to idle out -- so the counter passes take the two boundaries one at a time (BENCH_ONLY=ext / grp: the same batches, the same
-# kernels, per-launch and per-batch counts are properties of the kernels and their inputs).
+# kernels, per-launch and per-batch counts are properties of the kernels and their inputs).  BPSW_RING_LONE_LAUNCH=0 in the rescue pass:
+# with the dispatches serialised a batch often finds itself alone, and the library would give it a launch of its own -- the bench's mixed
+# workload, which these counts are for, never does.
 set -e
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -15,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- p
 pmc() {  # name, counters...
   name=$1; shift
   BENCH_ONLY=ext rocprofv3 --pmc "$@" --output-format csv -d $out/$name/ext -o bench -- python bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 > /dev/null 2> $out/$name.ext.err
-  BENCH_ONLY=grp BPSW_RING_CAPACITY=4096 rocprofv3 --pmc "$@" --output-format csv -d $out/$name/grp -o bench -- python bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 > /dev/null 2> $out/$name.grp.err
+  BENCH_ONLY=grp BPSW_RING_CAPACITY=4096 BPSW_RING_LONE_LAUNCH=0 rocprofv3 --pmc "$@" --output-format csv -d $out/$name/grp -o bench -- python bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 > /dev/null 2> $out/$name.grp.err
   echo "pmc pass $name done"
 }
 pmc fetch FETCH_SIZE
