@@ -811,6 +811,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     // configs[1]).  BPSW_EXT_H2D_FIRST=0 / 1: never / always.
     static const int h2d_first = getenv("BPSW_EXT_H2D_FIRST") ? atoi(getenv("BPSW_EXT_H2D_FIRST")) : -1;
     const bool copy_first = h2d_first == 1 || (h2d_first < 0 && sw_launches_in_flight(c->device) > 0);
+    bool copy_on_lane = false;
     if (copy_first) {
       // one bulk copy at a time per device, on a stream of the library's own (round 4 used a blocking hipMemcpy on the legacy default
       // stream for the same effect: that synchronises with every BLOCKING stream of the host process -- torch's, another native
@@ -820,13 +821,23 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       // BPSW_EXT_COPY_WAIT: 0 (default) the runtime's own wait for the lane's stream, under the lane's lock -- what a blocking hipMemcpy
       // does, without the legacy stream; 1 the lock covers the enqueue only and every caller sleeps / polls on an event of its own
       // (wait_event): a fifth less CPU per extension call, but the wake-up comes late -- 1.2-1.4 ms per call's device phase instead of
-      // 0.9, the bench step 5-10 % slower with 32, 40 or 48 threads.
+      // 0.9, the bench step 5-10 % slower with 32, 40 or 48 threads; 2 nobody on the host waits: the call's stream does
+      // (hipStreamWaitEvent) -- the step 2.0 instead of 2.45 x 10^8 reads/s: a dependency between two hardware queues costs the device
+      // more than the spin costs the host.
       static const int copy_wait = getenv("BPSW_EXT_COPY_WAIT") ? atoi(getenv("BPSW_EXT_COPY_WAIT")) : 0;
       if (copy_wait == 0) {
         std::lock_guard<std::mutex> lk(L.mu);
         if (!L.s) HIP_TRY(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
         HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, L.s));
         HIP_TRY(hipStreamSynchronize(L.s));
+      } else if (copy_wait == 2) {
+        // the lane orders the copies (one at a time, in its stream's order); nobody on the host waits for one: the call's own stream
+        // does (hipStreamWaitEvent below), and the kernels are queued behind it at once
+        std::lock_guard<std::mutex> lk(L.mu);
+        if (!L.s) HIP_TRY(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+        HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, L.s));
+        HIP_TRY(hipEventRecord(c->ev[6], L.s));
+        copy_on_lane = true;
       } else {
         {
           std::lock_guard<std::mutex> lk(L.mu);
@@ -842,6 +853,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
     hipStream_t s = lease.s;
     t_dev0 = stat_ms();
     HIP_TRY(hipEventRecord(c->ev[0], s));
+    if (copy_on_lane) HIP_TRY(hipStreamWaitEvent(s, c->ev[6], 0));
     if (!copy_first) HIP_TRY(hipMemcpyAsync(c->d_wire.ptr, c->h_stage_in.ptr, stage_bytes, hipMemcpyHostToDevice, s));
     bool on_dispatch = false;  // ev[1] / ev[2] ride on the kernel's own dispatch (KernelEvents, bpsw_internal.h)
     // results: written by the kernel straight into the pinned staging buffer (20 B per task, posted PCIe writes), or into
