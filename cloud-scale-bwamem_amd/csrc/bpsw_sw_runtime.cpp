@@ -118,9 +118,12 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
   // with a launch of its own: the epoch's grid is one or two waves per SIMD, a launch fills the device (256 / 1 024 / 4 096 pairs per
   // call, one calling thread: 0.28 / 0.33 / 0.48 ms through the ring, 0.23 / 0.27 / 0.38 with a launch; below sixteen jobs the ring wins:
   // tests/small_call_table.py).  As soon as callers overlap, or extension launches keep the queues busy, the ring it is.
-  // BPSW_RING_LONE_LAUNCH=0: the ring whenever it can.
-  static const bool lone_launch = !(getenv("BPSW_RING_LONE_LAUNCH") && atoi(getenv("BPSW_RING_LONE_LAUNCH")) == 0);
-  if (ring_class && lone_launch && n >= 16 && sw_launches_in_flight(c->device) == 0 && ext_call_age_ms(c->device) > 20.0) ring_class = 0;
+  // (For a FEW overlapping callers the two are level -- groups of 1 024 / 4 096 pairs from two to six task threads: 7.2-7.5 / 3.7-4.1 k
+  // groups/s at two, 13.5-14.7 / 7.4-7.6 k at four either way; from eight on the ring wins, 27 k against 17 k, and 48-53 k against 16 k at
+  // sixteen.)  BPSW_RING_LONE_LAUNCH = n: a launch while fewer than n SW batches are in flight (default 1: the lone caller); 0: the ring
+  // whenever it can.
+  static const int lone_launch = getenv("BPSW_RING_LONE_LAUNCH") ? atoi(getenv("BPSW_RING_LONE_LAUNCH")) : 1;
+  if (ring_class && lone_launch > 0 && n >= 16 && sw_launches_in_flight(c->device) < lone_launch && ext_call_age_ms(c->device) > 20.0) ring_class = 0;
   if (ring_class) {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);
     const double t_dev0 = stat_ms();
