@@ -6,8 +6,9 @@
 //
 // How: one task per 64-lane wavefront, four independent waves per workgroup, no workgroup barrier, tasks pulled from a
 // self-resetting work queue by persistent workgroups.  The DP is row-synchronous because the band [beg,end) of row i+1 is
-// derived from the finished row i (SWUtil.scala:201-214).  A row lives in registers, one or two columns per lane
-// (bpsw_extend_core.h: sw_extend_lean1 / lean2, and leanS on a 128-column window that follows the band for longer flanks):
+// derived from the finished row i (SWUtil.scala:201-214).  A row lives in registers, one, two or four columns per lane on a window that
+// follows the band (bpsw_extend_rows.h: sw_extend_adaptive, row loops in GCN assembly; the full kernel: the slot sweeps of
+// bpsw_extend_core.h):
 //   a(j)   = max(H(i-1,j-1) + S(i,j), E(i,j))                      per lane
 //   F(i,j) = max(0, max_{k<j}(a(k) - oeIns - (j-1-k)*eIns))        wave max-plus prefix scan (DPP)
 //   H(i,j) = max(a(j), F(i,j)),  E(i+1,j) = max(E(i,j)-eDel, H(i,j)-oeDel, 0)
@@ -18,7 +19,8 @@
 // one task per lane), which leaves a flag and a verdict per side here (sift_flag, sift_recs).  Two builds (ext_kernel<COORD, SHORT>):
 // SHORT = 1, the 64-VGPR short kernel at eight waves per SIMD for flanks up to 255 bases (the adaptive sweep of bpsw_extend_rows.h: one,
 // two or four columns per lane on a window that follows the band); SHORT = 0, the full kernel (slot sweeps, an LDS-row sweep for
-// flanks above 255 bases) for what the host lists.
+// flanks above 255 bases) for what the host lists.  A task's body is ext_do_task, shared with ext_resident_kernel: the
+// short kernel's resident form behind the device's extension ring (bpsw_ring.h), which takes the small batches without a launch.
 #include <stdlib.h>
 
 #include <atomic>
