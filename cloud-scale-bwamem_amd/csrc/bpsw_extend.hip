@@ -528,7 +528,7 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
   // each with its own tail of long tasks; small grids of several launches (and the rescue kernel of the same step) are
   // resident together and fill each other's tails.
   static const double cap_per_cu = getenv("BPSW_EXT_BLOCKS_PER_CU") ? atof(getenv("BPSW_EXT_BLOCKS_PER_CU")) : 1.0;
-  // the 48-VGPR kernel: 1.25 workgroups per CU.  (Round 2, every pass of the bench behind a barrier: reads/s in millions at 1 / 1.5 / 2 / 3
+  // the short kernel: 1.25 workgroups per CU.  (Round 2, every pass of the bench behind a barrier: reads/s in millions at 1 / 1.5 / 2 / 3
   // per CU 152.5 / 158.1 / 157.5 / 147.2, and two it was.  Round 3, the calls following each other freely and the sift kernel in front:
   // configs[1] 360 / 361 / 326 at 1 / 1.25 / 2, the default workload 165-180 / 179 / 181 at 1 / 0.75 / 2 -- within its noise --,
   // configs[4] 17.9 / 17.7 / 17.7 at 1 / 2 / 3: smaller grids leave wave slots to the one-wave workgroups of the sift kernels.)

@@ -1,4 +1,4 @@
-// bpsw_extend_rows.h -- the SWExtend row sweep of the 48-VGPR extension kernels (ext_kernel<.., SHORT>) in its third form: an
+// bpsw_extend_rows.h -- the SWExtend row sweep of the short extension kernels (ext_kernel<.., SHORT>) in its third form: an
 // ADAPTIVE window, and a hand-written row loop.
 //
 // What a DP row costs is the pipe time of its instructions: ~4.5 cycles of a SIMD for a half-rate vector
@@ -7,15 +7,19 @@
 //   * One column per lane is much cheaper than two (44 against 75 vector instructions per row), and the band of a row -- the
 //     positive cells around the best one -- fits 64 columns for three rows in four even of 2x250 bp reads at 8 % / 2 % error.  So the
 //     sweep keeps the (H,E) row in a 64-column window with ONE column per lane while the band fits, switches to a 128-column
-//     window with two columns per lane while it does not, and back (ds_bpermute moves the state between the layouts; a column that
-//     enters a window is never read before the band has written it, see sw_extend_lean2).
+//     window with two columns per lane while it does not, to a 256-column window with FOUR columns per lane when even that is too
+//     narrow (round 5: rows_cpp4; 256 columns hold every band of a flank of up to 255 bases), and back (ds_bpermute moves the state
+//     between the layouts; a column that enters a window is never read before the band has written it, see sw_extend_lean2).
 //   * Half of a row's instructions were scalar control that the compiler builds around a loop with four exits (boolean flags in
 //     SGPR pairs, s_and_b64 vcc / exec before every uniform branch, re-materialised constants).  The one-column loop -- the one that
 //     serves most rows -- is written in GCN assembly here (rows1_asm): every rare case (an N row, a window that has to move, an
 //     empty band) leaves the loop with the row untouched and is served by the C++ form of the same row (rows_cpp<1>), so the
-//     assembly holds only the common path: 32 vector + ~45 scalar instructions per row against 44 + 65.
+//     assembly holds only the common path: 32 vector + ~45 scalar instructions per row against 44 + 65.  (Round 4 added the
+//     two-column loop in assembly, rows2_asm, and "fast" forms of both for rows whose left band end cannot move: 58 / ~75 per row.)
+//   * Every piece derives its per-lane constants from an opaque copy of the lane number at its own entry (rows_opaque, round 5):
+//     hoisted to the top of the kernel they were a dozen VGPRs more than the short kernel's 64 hold.
 // Same arithmetic, same order of evaluation as sw_extend_lean1 / lean2 / leanS (bpsw_extend_core.h), which stay for the full
-// kernel and chain2aln_kernel; BPSW_EXT_ADAPTIVE=0 at build time puts the 48-VGPR kernels back on them.
+// kernel and chain2aln_kernel; BPSW_EXT_ADAPTIVE=0 at build time puts the short kernels back on them.
 #pragma once
 #include "bpsw_extend_core.h"
 

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void ext_sift_kernel(const uint32_t* __restrict
   item_fail[lane] = 0; item_fail[64 + lane] = 0;
   const bool any_n = __builtin_amdgcn_ballot_w64(n_codes != 0u) != 0ull;
   __syncthreads();
-  const bool mine = live && lq <= qmax && rq <= qmax;  // else not a task the 48-VGPR build of ext_kernel takes
+  const bool mine = live && lq <= qmax && rq <= qmax;  // else not a task the short build of ext_kernel takes
   const int regScore0 = s_lo16(r3), qBeg = s_hi16(r3), h0 = s_lo16(r4);
   const int idx = (int)rec[7];
   const uint32_t* my_raw = raw + (pos - base);

@@ -90,8 +90,8 @@ hipError_t launch_ext_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out
                              const uint8_t* d_sift_flag = nullptr, const uint4* d_sift_recs = nullptr, int* d_defer_post = nullptr,
                              const int* d_todo_list = nullptr);
 // The sift kernel (bpsw_extend_sift.hip): the exact shortcuts of every task of a format-1 batch, one task per lane, in front of
-// the 48-VGPR ext_kernel, which reads d_flag[task] (1: record written, skip; 2: d_recs[2 task + side] holds the verdict per side).
-// dm = a - (the one mismatch score of the matrix), sift_uniform_dm(); qmax = the longest flank the 48-VGPR build takes.
+// the short ext_kernel, which reads d_flag[task] (1: record written, skip; 2: d_recs[2 task + side] holds the verdict per side).
+// dm = a - (the one mismatch score of the matrix), sift_uniform_dm(); qmax = the longest flank the short build takes.
 hipError_t launch_ext_sift_kernel(const uint32_t* d_wire, int n_tasks, int16_t* d_out, const ExtScoring& sc, int dm, int qmax,
                                   uint8_t* d_flag, uint4* d_recs, hipStream_t s, KernelEvents kev = KernelEvents(),
                                   const ExtPrepass* d_pre_check = nullptr, int* d_todo_count = nullptr, int* d_todo_list = nullptr,

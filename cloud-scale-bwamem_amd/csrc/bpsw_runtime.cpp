@@ -544,7 +544,7 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
   int mq = 0, mr = 0, mrs = 0;
   const size_t words = bytes >> 2;
   // tasks for the full kernel (a query flank above 255 bases; every task when the gap costs rule out the register sweeps):
-  // the 48-VGPR kernel serves the others (bpsw_extend.hip, ext_kernel<.., SHORT>); "mid" tasks (a flank of 128-255 bases) run
+  // the short kernel serves the others (bpsw_extend.hip, ext_kernel<.., SHORT>); "mid" tasks (a flank of 128-255 bases) run
   // on its sliding window and may be deferred to the full kernel from the device
   const bool all_long = (int8_t)wire[2] + (int8_t)wire[3] <= 0;
   long_tasks->clear();
@@ -592,7 +592,6 @@ static int scan_wire(const uint8_t* wire, size_t bytes, long long l_pac, int* n_
 
 static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len, uint8_t* side_how,
                              const int16_t** out_view = nullptr);
-static inline bool side_how_blocks_quad(const uint8_t*) { return false; }  // the classify entry runs the same launch plan
 
 int bpsw_extend_batch(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_bytes, int16_t* out, size_t out_len) {
   return extend_batch_impl(c, wire, wire_bytes, out, out_len, nullptr);
@@ -669,7 +668,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   const bool expect_full = !use_short || n_long > 0;
   (void)any_mid;
   // behind the wire bytes: the full kernel's list as [count, task indices...]; the host stages its own entries and the count, the
-  // 48-VGPR kernel appends (room for every task)
+  // short kernel appends (room for every task)
   const size_t list_off = (wire_bytes + 15) & ~(size_t)15;
   // The deferring short kernel ALWAYS has a list to defer to (round 4 gave it none when no task could be expected to defer, and
   // trapped if one did): a batch without mid tasks posts an empty list like any other, and the full kernel is launched behind it
@@ -900,7 +899,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       if (use_full && !lazy_full) {
         KernelEvents kev;
         kev.start = use_short ? nullptr : c->ev[1]; kev.stop = c->ev[2];
-        // behind the 48-VGPR kernel: the list it completed on the device (what it may have deferred is unknown to the host
+        // behind the short kernel: the list it completed on the device (what it may have deferred is unknown to the host
         // -- a subset of the mid tasks, normally a small one: a quarter of them sizes the grid; an empty list costs a launch that
         // returns at once)
         // (a batch with few mid tasks -- 2x150 bp reads: the flanks of 128-131 bases -- defers next to nothing: one workgroup, whose
