@@ -554,7 +554,25 @@ extern "C" int bpsw_matesw_group(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bps
     }
     // ---- 3. replay the pairs that had a job ------------------------------------------------------------------------
     const double t_r0 = stat_ms();
+#ifndef BPSW_REPLAY_NO_PREFETCH
+    // (the thread has slept through the device phase and other threads have had its core: the touched pairs' region records and their
+    // anchors' window rows are cold again.  Ask for the next pairs' lines while one is replayed.)
+    const auto prefetch_pair = [&](const size_t tj) {
+      const int64_t* tb = S.t_base.data() + 4 * tj;
+      const int kk = S.touched[tj];
+      for (int i = 0; i < 2; ++i) {
+        const Reg* r0 = g->regs + tb[i];
+        for (int j = 0; j < g->reg_cnt[2 * kk + i] && j < 4; ++j) __builtin_prefetch(r0 + j);
+        __builtin_prefetch(g->ref_rb + 4 * tb[2 + i]); __builtin_prefetch(g->ref_re + 4 * tb[2 + i]);
+        if (!GR.pac_mode) __builtin_prefetch(g->ref_len + 4 * tb[2 + i]);
+      }
+    };
+    for (size_t tj = 0; tj < nt && tj < 8; ++tj) prefetch_pair(tj);
+#endif
     for (size_t ti = 0; ti < nt; ++ti) {
+#ifndef BPSW_REPLAY_NO_PREFETCH
+      if (ti + 8 < nt) prefetch_pair(ti + 8);
+#endif
       if (S.done[ti]) continue;
       const int k = S.touched[ti];
       if (!replay_pair(GR, k, ti, S.v, S.want)) continue;
