@@ -547,7 +547,7 @@ def main():
     share = numa_cpus if numa_cpus else allowed[(local_rank % ranks_on_node)::ranks_on_node] if distributed else allowed
     # 32: the device phases of the calls share a pool of 20 streams (bpsw_internal.h, StreamLease), and half as many threads
     # again keep it full while the others stage bytes or replay bookkeeping; more change nothing
-    n_threads = args.threads if args.threads > 0 else max(2, min(48, len(share)))
+    n_threads = args.threads if args.threads > 0 else max(2, min(40, len(share)))
     if share and (numa_cpus or distributed):
         try:
             os.sched_setaffinity(0, share)   # before the inputs are generated: first touch puts them on the GPU's node
