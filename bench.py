@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import traceback
 import os
 import sys
 import time
@@ -142,6 +143,65 @@ def reduce_over_ranks(elapsed, device):
 def whole_job_rate(reads_per_step_per_rank, steps, world, elapsed_max):
     """`value`: the reads ALL ranks aligned in the timed region over the slowest rank's time"""
     return reads_per_step_per_rank * steps * world / elapsed_max
+
+
+def load_committed_json(name):
+    """a committed profiles/<name> as a dict; {} only when the file is not there (a fresh workload without counters) -- a file that is
+    there and does not parse is an error of the repository and stops the bench"""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except FileNotFoundError:
+        return {}
+
+
+def trace_figures(csv_path, sw_launch_kernel="swp_kernel"):
+    """Per-kernel averages and shares of summed kernel time from a committed `rocprofv3 --kernel-trace --stats` summary of the bench command.
+
+    Returns (trace_avg, trace_share):
+      trace_avg["extend"]   = a format-1 extension CALL's launches summed (sift kernel + short kernel + the occasional full kernel: the
+                              `false` instantiations, back to back on the call's stream, as the library's events see them) / short-kernel launches, ms
+      trace_avg["swalign2_resident"], ["swalign2"] = AverageNs of the resident rescue kernel / of the launched one, ms
+      trace_share[k]        = k's share of the summed kernel time of the trace
+    ({}, {}) only when the file does not exist; anything else wrong with it raises."""
+    import csv
+    trace_avg, trace_share = {}, {}
+    try:
+        f = open(csv_path, newline="")
+    except FileNotFoundError:
+        return {}, {}
+    with f:
+        ext_total_ns, ext_calls = 0.0, 0
+        for r in csv.DictReader(f):
+            nm = r["Name"]
+            if "ext_sift_kernel<false>" in nm or "ext_kernel<false" in nm:
+                ext_total_ns += float(r["TotalDurationNs"])
+                trace_share["extend"] = trace_share.get("extend", 0.0) + float(r["Percentage"]) * 1e-2
+                if "ext_kernel<false, 1>" in nm:   # the short kernel
+                    ext_calls += int(r["Calls"])
+            elif "swp_resident_kernel" in nm and "swalign2_resident" not in trace_avg:
+                trace_avg["swalign2_resident"] = round(float(r["AverageNs"]) * 1e-6, 4)
+                trace_avg["swalign2_resident_share_of_kernel_time"] = round(float(r["Percentage"]) * 1e-2, 4)
+                trace_share["swalign2_resident"] = float(r["Percentage"]) * 1e-2
+            elif sw_launch_kernel in nm and "swalign2" not in trace_avg:
+                trace_avg["swalign2"] = round(float(r["AverageNs"]) * 1e-6, 4)
+                trace_share["swalign2"] = float(r["Percentage"]) * 1e-2
+        if ext_calls:
+            trace_avg["extend"] = round(ext_total_ns / ext_calls * 1e-6, 4)
+    return trace_avg, trace_share
+
+
+def pick_dominant(trace_share, ext_instr, sw_instr, ext_kernel_ms, sw_kernel_ms, tag):
+    """(dominant, dominant_by): the kernel family with the largest share of summed kernel time in the committed kernel trace of this
+    command -- the extension call's kernels together against the rescue path's; without a trace, the one that issues the most
+    wave-instructions in a step (launches x the committed per-launch counts); without either, the larger sum of launch durations."""
+    if trace_share.get("extend") is not None and (trace_share.get("swalign2_resident") is not None or trace_share.get("swalign2") is not None):
+        sw_share = (trace_share.get("swalign2_resident") or 0.0) + (trace_share.get("swalign2") or 0.0)
+        return ("extend" if trace_share["extend"] >= sw_share else "swalign2"), \
+            f"share of summed kernel time in profiles/{tag}_kernel_stats_bench.csv (extension kernels {trace_share['extend']:.3f}, rescue kernels {sw_share:.3f})"
+    if ext_instr is not None:
+        return ("extend" if ext_instr >= sw_instr else "swalign2"), "issued wave-instructions (profiles/pmc_issue.json x launches)"
+    return ("extend" if ext_kernel_ms >= sw_kernel_ms else "swalign2"), "summed launch durations (no trace or counters committed for this workload)"
 
 
 def cpu_quota():
@@ -648,55 +708,19 @@ def main():
     win_len = float(np.mean([float(g.ref_len[g.ref_len > 0].mean()) for g in groups[:8]])) if groups else 0.0
     sw_bytes = (st["sw_jobs"] / max(sw_launches, 1)) * (W["read_len"] + win_len + 28)           # per launch (B_sw)
     # per-launch instruction counts of this command from the committed rocprofv3 --pmc passes (profiles/pmc_issue.json)
-    pi = {}
-    try:
-        pi = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
-    except Exception:
-        pi = {}
+    pi = load_committed_json("pmc_issue.json")
     e_cnt = (pi.get("extend_per_call") or pi.get("extend")) if args.config == 3 else None
     w_cnt = pi.get("swalign2") if args.config == 3 else None
-    # the committed rocprofv3 --kernel-trace --stats summary of this same command: every kernel's average duration there
-    trace_avg, trace_share = {}, {}
-    try:
-        import csv
-        # `extend`: a call's launches back to back on its stream -- the sift kernel, the short extension kernel, the full kernel (only
-        # behind a launch with listed / deferred tasks) (format-1 batches: the `false` instantiations) -- summed per call, as the library's events see them
-        ext_total_ns, ext_calls = 0.0, 0
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_stats_bench.csv"))):
-            nm = r["Name"]
-            if "ext_sift_kernel<false>" in nm or "ext_kernel<false" in nm:
-                ext_total_ns += float(r["TotalDurationNs"])
-                trace_share["extend"] = trace_share.get("extend", 0.0) + float(r["Percentage"]) * 1e-2
-                if "ext_kernel<false, 1>" in nm:   # the short kernel
-                    ext_calls += int(r["Calls"])
-            elif "swp_resident_kernel" in nm and "swalign2_resident" not in trace_avg:
-                trace_avg["swalign2_resident"] = round(float(r["AverageNs"]) * 1e-6, 4)
-                trace_avg["swalign2_resident_share_of_kernel_time"] = round(float(r["Percentage"]) * 1e-2, 4)
-                trace_share["swalign2_resident"] = float(r["Percentage"]) * 1e-2
-            elif per_kernel["swalign2"][3] in nm and "swalign2" not in trace_avg:
-                trace_avg["swalign2"] = round(float(r["AverageNs"]) * 1e-6, 4)
-                trace_share["swalign2"] = float(r["Percentage"]) * 1e-2
-        if ext_calls:
-            trace_avg["extend"] = round(ext_total_ns / ext_calls * 1e-6, 4)
-    except Exception:
-        trace_avg, trace_share = {}, {}
-    # The dominant kernel: the one with the largest share of summed kernel time in the committed kernel trace of this command
-    # (profiles/<tag>_kernel_stats_bench.csv) -- the extension call's kernels together against the rescue path's; without a trace, the one that
-    # issues the most wave-instructions in a step (launches x the committed per-launch counts).  Both kernels' figures are in `kernels`,
-    # their fractions of the HBM peak side by side in `frac_by_kernel`.
+    # the committed rocprofv3 --kernel-trace --stats summary of this same command: every kernel's average duration there (only for the
+    # workload it was taken on, configs[2])
+    trace_avg, trace_share = trace_figures(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_stats_bench.csv")) if args.config == 3 and not only else ({}, {})
     if e_cnt and w_cnt:
         ext_instr = ext_launches * (e_cnt["valu"] + e_cnt["salu"])
         sw_instr = sw_launches * (w_cnt["valu"] + w_cnt["salu"])
     else:
         ext_instr = sw_instr = None
-    if trace_share.get("extend") is not None and (trace_share.get("swalign2_resident") is not None or trace_share.get("swalign2") is not None):
-        sw_share = (trace_share.get("swalign2_resident") or 0.0) + (trace_share.get("swalign2") or 0.0)
-        dominant, dominant_by = ("extend" if trace_share["extend"] >= sw_share else "swalign2"), \
-            f"share of summed kernel time in profiles/{PROFILE_TAG}_kernel_stats_bench.csv (extension kernels {trace_share['extend']:.3f}, rescue kernels {sw_share:.3f})"
-    elif ext_instr is not None:
-        dominant, dominant_by = ("extend" if ext_instr >= sw_instr else "swalign2"), "issued wave-instructions (profiles/pmc_issue.json x launches)"
-    else:
-        dominant, dominant_by = ("extend" if st["ext_kernel_ms"] >= st["sw_kernel_ms"] else "swalign2"), "summed launch durations (no trace or counters committed for this workload)"
+    # Both kernels' figures are in `kernels`, their fractions of the HBM peak side by side in `frac_by_kernel`.
+    dominant, dominant_by = pick_dominant(trace_share, ext_instr, sw_instr, st["ext_kernel_ms"], st["sw_kernel_ms"], PROFILE_TAG)
     # The rescue batches of the timed region went through the device's submission ring (csrc/bpsw_ring.h): no launch per batch.  `swalign2`
     # below is a BATCH -- its duration the span first job pair taken -> last one finished on the device's clock -- and `swalign2_resident` is
     # the resident kernel that served them: launches = epochs, each timed by two HIP events around its launch on the ring's stream.
@@ -707,22 +731,16 @@ def main():
     per_kernel = {"extend": (ext_bytes, ext_avg_ms, ext_launches, "ext_kernel"), "swalign2": (sw_bytes, sw_avg_ms, sw_launches, "swp_kernel")}
     dom_bytes, dom_ms = per_kernel[dominant][0], per_kernel[dominant][1]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))   # written from rocprofv3 --pmc passes
-    except Exception:
-        pmc = {}
+    pmc = load_committed_json("pmc_traffic.json")   # written from rocprofv3 --pmc passes
     traffic = pmc.get(dominant)
     traffic_x2 = pmc.get("detail", {}).get(dominant, {}).get("fetch_size_x2_plus_write_size")
     step_s_all = elapsed / args.steps
     # where the dominant kernel's wave-cycles go (committed SQ counters of this command, profiles/<tag>_sq_activity.json)
     sq_activity = None
-    try:
-        sa = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_sq_activity.json")))
+    sa = load_committed_json(f"{PROFILE_TAG}_sq_activity.json")
+    if sa:
         sq_activity = {k: {q: sa[k][q] for q in ("active_valu", "active_sca", "wait_inst_any", "wait_any") if q in sa[k]} for k in ("extend", "swalign2") if k in sa}
         sq_activity["note"] = f"fractions of SQ_WAVE_CYCLES, from the committed profiles/{PROFILE_TAG}_sq_activity.json (rocprofv3 --pmc pass of this command)"
-    except Exception:  # noqa: BLE001
-        sq_activity = None
     both = {}
     for k, (b, ms, n_l, _) in per_kernel.items():
         if n_l:
@@ -797,12 +815,14 @@ def main():
         try:
             extras["device_resident"] = device_resident_breakdown(W, args.config, rank, wires, ntasks, dev, local_rank, reps=max(3, min(args.steps, 10)))
         except Exception as e:  # noqa: BLE001 -- a breakdown line must never cost the bench its JSON
+            traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
             extras["device_resident"] = {"error": repr(e)}
         if rank == 0 and world == 1 and wires and only == "":
             try:
                 extras["coordinate_batches"] = coordinate_batches_breakdown(W, args.config, rank, F, fd, wires, groups, structs, grp_cnts, grp_regs,
                                                                             passes, max(2, min(8, len(share))))
             except Exception as e:  # noqa: BLE001
+                traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
                 extras["coordinate_batches"] = {"error": repr(e)}
         if rank == 0 and world == 1 and wires and groups:
             # what the JNI shim adds around the C ABI calls the timed region makes (fake JNIEnv: a JVM exists on neither box)
@@ -816,6 +836,7 @@ def main():
                     g_ref = synth.rescue_group(1024, seed=synth.CONFIG_SEED_BASE + 92, l_pac=l_pac_s, p_resc=W["p_resc"], ref_bases=bases_s)
                     js["mateSWFlatJNI_coordinates"] = jnishim.shim_rate(wires[0], ntasks[0], g_ref, reps=5, pac=pac_s)["mateSWFlatJNI_coordinates"]
                 except Exception as e:  # noqa: BLE001
+                    traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
                     js["mateSWFlatJNI_coordinates"] = {"error": repr(e)}
                 # what a Scala caller could reach THROUGH the shim with the bench's number of task threads: a unit of 32 768 reads is one
                 # extension call and four rescue calls; per thread it takes the calls' loaded latencies (measured in the timed region)
@@ -836,14 +857,17 @@ def main():
                                                               note="min(value, threads x 32768 reads / (loaded call latencies of one extension call and four rescue calls + "
                                                                    "their marshalling through the fake JNIEnv)); mateSWJNI = the reference's object-array contract as it is")
                 except Exception as e:  # noqa: BLE001
+                    traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
                     js["through_shim_reads_per_s_est"] = {"error": repr(e)}
                 extras["jni_shim_fake_env"] = js
             except Exception as e:  # noqa: BLE001
+                traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
                 extras["jni_shim_fake_env"] = {"error": repr(e)}
         if rank == 0 and world == 1 and not args.no_tail and args.config == 3:
             try:
                 extras["worker2_tail"] = tail_breakdown(F.ctxs[0], opt)
             except Exception as e:  # noqa: BLE001
+                traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
                 extras["worker2_tail"] = {"error": repr(e)}
 
     out = {

@@ -440,7 +440,7 @@ struct bpsw_ctx {
   bpsw::PinnedBuffer h_stage_in, h_stage_out, h_pre;
   int shortcut_mask = 63;  // bpsw_set_ext_shortcuts
   std::vector<int> ext_long_tasks, ext_mid_tasks;  // scratch of bpsw_extend_batch: the tasks of the current batch that go to the full kernel / have a flank of 128-255 bases
-  double wait_est_ms[4] = {0., 0., 0., 0.};  // wait_event / ring_wait: running average of the device-phase waits (extension, SW, ring copy-in)
+  double wait_est_ms[6] = {0., 0., 0., 0., 0., 0.};  // wait_event / ring_wait: running average of the device-phase waits ([0] extension launches, [1] SW launches, [2] ring copy-in, [3] spare, [4] extension ring, [5] SW ring: a thread that alternates 1 ms launched batches with 0.085 ms ring batches must not nap through the short ones on the long ones' estimate)
   uint32_t ring_seq = 0;             // completion values of this context's ring submissions (RingDone at h_pre + 448)
   void* rescue_scratch = nullptr;  // bpsw_rescue.cpp: vectors reused across bpsw_matesw_group calls (freed by rescue_scratch_free)
   bpsw_stats_t stats;

@@ -792,7 +792,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
         copy_first_ms = 0.;
       } else {
         if (rc != BPSW_OK) return rc;
-        rc = ring_wait(c->device, RING_CLASS_EXT, done, c->ring_seq, &c->wait_est_ms[0]);
+        rc = ring_wait(c->device, RING_CLASS_EXT, done, c->ring_seq, &c->wait_est_ms[4]);
         if (rc != BPSW_OK) return rc;
         ring_kernel_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, RING_CLASS_EXT));
         t_dev1 = stat_ms();

@@ -170,7 +170,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
       dev.q_pool = d + st.o_qpool; dev.t_pool = pac_mode ? nullptr : d + st.o_tpool; dev.packed = (const uint32_t*)(d + st.o_packed);
     } else {
       if (rc != BPSW_OK) return rc;
-      rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[1]);
+      rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[5]);
       if (rc != BPSW_OK) return rc;
       const float span_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, ring_class));
       c->stats.grp_dev_ms += stat_ms() - t_dev0;
@@ -663,6 +663,8 @@ int bpsw_global_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_global_jo
   memcpy(out_cigar, ho + o_cig, 4 * (size_t)n * (size_t)j->max_cigar);
   return BPSW_OK;
 }
+
+int bpsw_sw_batches_in_flight(int device) { return device >= 0 && device < 64 ? bpsw::sw_launches_in_flight(device) : -1; }
 
 int bpsw_ring_stats(bpsw_ctx_t* c, uint64_t* epochs, uint64_t* submitted, uint64_t* carried, double* epochs_ms, uint64_t* epochs_timed) {
   if (!c) return fail(BPSW_ERR_ARG, "null context");

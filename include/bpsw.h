@@ -470,6 +470,11 @@ int bpsw_last_kernel_ms(bpsw_ctx_t *ctx, float *ext_ms, float *sw_ms);
  * events around the resident kernel's launch on its stream (what a kernel trace reports as that kernel's duration).  Diagnostics; any
  * pointer may be null. */
 int bpsw_ring_stats(bpsw_ctx_t *ctx, uint64_t *epochs, uint64_t *submitted, uint64_t *carried, double *epochs_ms, uint64_t *epochs_timed);
+/* A gauge: the number of SW batches (bpsw_swalign2_batch / bpsw_matesw_group / mateSWJNI rounds, of any context) that are in their device
+ * phase on `device` right now -- what the "lone caller takes a launch of its own" rule of the SW entry points looks at
+ * (BPSW_RING_LONE_LAUNCH).  Diagnostics (an executor's metrics page; tests/test_ring_gpu.py waits on it to make
+ * "a batch that has company" a deterministic state instead of a matter of thread timing).  -1 for a device index outside 0..63. */
+int bpsw_sw_batches_in_flight(int device);
 
 #ifdef __cplusplus
 }

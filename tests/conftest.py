@@ -27,6 +27,36 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The driver runs the GPU suite with -x: whatever comes first is what a failure cannot hide.  So the suite is ordered by evidence value,
+# not by file name: kernels against the reference's own outputs (tests/golden) and against the oracle first, then the boundary (JNI
+# shim, host path, coordinates, large genome), then the policy of the submission rings and the multi-threaded / multi-process tests, and
+# last the production-defaults re-runs, the full-size property runs and the soaks.  Files not listed keep their place between the
+# boundary and the policy tier.
+_ORDER = [
+    # tier 1: parity of every kernel
+    "test_golden_gpu", "test_extend_gpu", "test_swalign_gpu", "test_rescue_gpu", "test_global_gpu", "test_tail_gpu",
+    "test_chain2aln_gpu", "test_ref_gpu", "test_extend_coords_gpu", "test_extend_exhaustive_gpu",
+    # tier 2: the boundary
+    "test_jni_shim", "test_host_path_gpu", "test_large_genome_gpu", "test_async_entries_gpu",
+    # tier 3: ring policy, threads, processes
+    None,
+    "test_concurrency_gpu", "test_ring_gpu", "test_ext_ring_gpu", "test_two_processes_gpu", "test_bench_ranks_gpu",
+    # tier 4: re-runs at other defaults, full-size properties, soaks
+    "test_production_defaults_gpu", "test_scale_properties_gpu", "test_soak_gpu",
+]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    rank = {name: i for i, name in enumerate(_ORDER) if name}
+    unlisted = _ORDER.index(None)
+
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return rank.get(mod, unlisted)
+
+    items.sort(key=key)   # stable: the order inside a file stays
+
+
 def _have(path):
     return os.path.exists(path)
 
