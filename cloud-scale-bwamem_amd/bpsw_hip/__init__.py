@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "bpsw_device_count", "bpsw_create", "bpsw_destroy", "bpsw_device_of", "bpsw_device_slots", "bpsw_device_for_partition", "bpsw_last_error", "bpsw_version",
     "bpsw_set_ext_scoring", "bpsw_set_ext_shortcuts", "bpsw_extend_batch", "bpsw_extend_stage", "bpsw_extend_commit", "bpsw_extend_batch_classify", "bpsw_extend_batch_device", "bpsw_wire_size", "bpsw_wire_pack", "bpsw_wire_coords_size", "bpsw_wire_coords_pack",
     "bpsw_opt_default", "bpsw_swalign2_batch", "bpsw_swalign2_batch_device", "bpsw_matesw_group", "bpsw_global_batch",
-    "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms", "bpsw_ring_stats", "bpsw_sw_batches_in_flight",
+    "bpsw_get_stats", "bpsw_reset_stats", "bpsw_last_kernel_ms", "bpsw_ring_stats", "bpsw_sw_batches_in_flight", "bpsw_ring_integrity",
     "bpsw_ref_load", "bpsw_ref_unload", "bpsw_ref_length", "bpsw_ref_fetch", "bpsw_chain2aln_batch",
     "bpsw_tail_opt_default", "bpsw_bns_load", "bpsw_reg2aln_batch", "bpsw_sam_pe_batch", "bpsw_worker2_batch", "bpsw_last_tail_times",
     "bpsw_tail_pool_create", "bpsw_tail_pool_destroy", "bpsw_tail_pool_submit", "bpsw_tail_pool_wait", "bpsw_tail_pool_workers",
@@ -178,6 +178,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.bpsw_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.bpsw_ring_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.bpsw_sw_batches_in_flight.argtypes = [C.c_int]
+    lib.bpsw_ring_integrity.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.bpsw_chain2aln_batch.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(Chains), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.POINTER(C.c_int64)]
     lib.bpsw_ref_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -510,6 +511,12 @@ class Context:
         e, s, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         _chk(self.lib, self.lib.bpsw_ring_stats(self.h, C.byref(e), C.byref(s), C.byref(c), None, None), "bpsw_ring_stats")
         return int(e.value), int(s.value), int(c.value)
+
+    def ring_integrity(self):
+        """(on, records checked, faults) of the rings' integrity tripwire, process-wide (include/bpsw.h: bpsw_ring_integrity)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        on = self.lib.bpsw_ring_integrity(C.byref(a), C.byref(b))
+        return bool(on), int(a.value), int(b.value)
 
     def sw_batches_in_flight(self):
         """gauge: SW batches of any context in their device phase on this context's device (include/bpsw.h)"""

@@ -155,6 +155,12 @@ bool ring_usable(int device, int c_class);  // false once that ring has failed: 
 int ring_submit(int device, int c_class, int num_cu, const RingDesc& desc);
 int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, double* est_ms);
 double ring_ticks_per_ms(int device, int c_class);
+// the integrity tripwire (bpsw_ring.cpp): poison `n_records` records of `stride_words` words each at their first word (and at
+// `second_word_offset` when not 0) before publishing; afterwards every record must have been overwritten
+bool ring_integrity_on();
+void ring_poison(uint32_t* first_word, size_t stride_words, size_t n_records, size_t second_word_offset);
+int ring_check(const uint32_t* first_word, size_t stride_words, size_t n_records, size_t second_word_offset, const char* what);
+void ring_integrity_stats(uint64_t* checked, uint64_t* faults);
 void ring_pause(int device);   // close the device's open epochs, wait for their kernels, keep the rings locked ...
 void ring_resume(int device);  // ... until here (bpsw_ref_load / unload: a device-wide synchronisation in between)
 void ring_get_stats(int device, uint64_t* epochs, uint64_t* submitted, uint64_t* carried, double* epochs_ms = nullptr, uint64_t* epochs_timed = nullptr);
@@ -441,6 +447,7 @@ struct bpsw_ctx {
   int shortcut_mask = 63;  // bpsw_set_ext_shortcuts
   std::vector<int> ext_long_tasks, ext_mid_tasks;  // scratch of bpsw_extend_batch: the tasks of the current batch that go to the full kernel / have a flank of 128-255 bases
   double wait_est_ms[6] = {0., 0., 0., 0., 0., 0.};  // wait_event / ring_wait: running average of the device-phase waits ([0] extension launches, [1] SW launches, [2] ring copy-in, [3] spare, [4] extension ring, [5] SW ring: a thread that alternates 1 ms launched batches with 0.085 ms ring batches must not nap through the short ones on the long ones' estimate)
+  bool ring_abandoned = false;       // a ring batch of this context ran into the watchdog: a late unit may still write into the pinned blocks, so the context refuses further calls and bpsw_destroy leaks them
   uint32_t ring_seq = 0;             // completion values of this context's ring submissions (RingDone at h_pre + 448)
   void* rescue_scratch = nullptr;  // bpsw_rescue.cpp: vectors reused across bpsw_matesw_group calls (freed by rescue_scratch_free)
   bpsw_stats_t stats;

@@ -98,11 +98,10 @@ int start_epoch(RingService& S) {
   S.carried += S.carry_n;
   S.published = S.carry_n;
   S.carry_from = S.carry_n = 0;
-  S.H->close_req = 0;
-  S.H->state = ring_state(S.epoch, 0, RING_OPEN);
-  std::atomic_thread_fence(std::memory_order_release);
-  S.H->tail = S.published;
-  std::atomic_thread_fence(std::memory_order_seq_cst);
+  // (nobody else looks at the block yet: the epoch's kernel is launched below, and its first loads are ordered behind the launch)
+  S.H->close_req.store(0, std::memory_order_relaxed);
+  S.H->state.store(ring_state(S.epoch, 0, RING_OPEN), std::memory_order_relaxed);
+  S.H->tail.store(S.published, std::memory_order_seq_cst);
   RingArgs A;
   A.H = S.H; A.h_desc = S.h_desc; A.D = S.D; A.d_desc = S.d_desc; A.ctr = S.ctr;
   A.epoch = S.epoch; A.capacity = S.capacity;
@@ -163,7 +162,7 @@ int start_epoch(RingService& S) {
 uint64_t resolved_state(RingService& S) {
   const double t0 = wall_ms();
   for (;;) {
-    const uint64_t s = S.H->state;
+    const uint64_t s = S.H->state.load(std::memory_order_seq_cst);
     if (ring_state_epoch(s) != S.epoch || ring_state_phase(s) != RING_CLOSING) return s;
     if (wall_ms() - t0 > 200.0) return s;  // a device that never resolves: the caller's watchdog reports it
     sched_yield();
@@ -179,11 +178,12 @@ void note_closed(RingService& S, uint64_t s) {
   const uint32_t consumed = ring_state_consumed(s);
   if (ring_debug())
   {
-    const double nu = S.H->diag_units ? (double)S.H->diag_units : 1.0;
+    const uint64_t du = S.H->diag_units.load(std::memory_order_relaxed);
+    const double nu = du ? (double)du : 1.0;
     static const char* why[5] = {"?", "asked by the host", "ring used up", "idle", "no progress"};
     fprintf(stderr, "bPSW ring[%d/%d]: epoch %u closed (%s): consumed %u of %u published, %u worker waves took a unit, %d workgroups; diag: %llu units, "
-            "taken %.1f us after publication on average, %.1f us per unit\n", S.device, S.c_class, S.epoch, why[S.H->close_reason < 5 ? S.H->close_reason : 0], consumed, S.published, (unsigned)S.H->workers_seen,
-            S.blocks, (unsigned long long)S.H->diag_units, (double)S.H->diag_claim_ticks / nu / (double)S.ticks_per_us, (double)S.H->diag_unit_ticks / nu / (double)S.ticks_per_us);
+            "taken %.1f us after publication on average, %.1f us per unit\n", S.device, S.c_class, S.epoch, why[S.H->close_reason.load(std::memory_order_relaxed) < 5 ? S.H->close_reason.load(std::memory_order_relaxed) : 0], consumed, S.published, (unsigned)S.H->workers_seen.load(std::memory_order_relaxed),
+            S.blocks, (unsigned long long)du, (double)S.H->diag_claim_ticks.load(std::memory_order_relaxed) / nu / (double)S.ticks_per_us, (double)S.H->diag_unit_ticks.load(std::memory_order_relaxed) / nu / (double)S.ticks_per_us);
   }
   S.running = false;
   S.carry_from = consumed;
@@ -193,7 +193,7 @@ void note_closed(RingService& S, uint64_t s) {
 int wait_closed(RingService& S, double limit_ms) {
   const double t0 = wall_ms();
   for (;;) {
-    const uint64_t s = S.H->state;
+    const uint64_t s = S.H->state.load(std::memory_order_acquire);
     if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) { note_closed(S, s); return BPSW_OK; }
     if (wall_ms() - t0 > limit_ms) { S.broken = true; return fail(BPSW_ERR_DEVICE, "ring: the resident kernel did not close its epoch"); }
     timespec ts = {0, 20000};
@@ -229,7 +229,7 @@ int ring_submit(int device, int c_class, int num_cu, const RingDesc& desc) {
   if (!S.inited) { const int rc = init_service(S, device, c_class, num_cu); if (rc != BPSW_OK) return rc; }
   for (;;) {
     if (S.running) {  // an epoch that closed by itself (idle) since the last submission
-      const uint64_t s = S.H->state;
+      const uint64_t s = S.H->state.load(std::memory_order_acquire);
       if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) note_closed(S, s);
     }
     if (!S.running) { const int rc = start_epoch(S); if (rc != BPSW_OK) return rc; }
@@ -239,9 +239,9 @@ int ring_submit(int device, int c_class, int num_cu, const RingDesc& desc) {
     if (rc != BPSW_OK) return rc;
   }
   S.h_desc[S.published] = desc;
-  std::atomic_thread_fence(std::memory_order_release);
-  S.H->tail = ++S.published;
-  std::atomic_thread_fence(std::memory_order_seq_cst);  // W(tail) ; fence ; R(state) against the poller's W(state) ; fence ; R(tail)
+  // the descriptor before the count (release), and W(tail) ; R(state) against the poller's W(state) ; R(tail) -- both sequentially
+  // consistent (on x86 the store is an xchg: the full fence round 5 had as a free-standing one), so that at least one side sees the other
+  S.H->tail.store(++S.published, std::memory_order_seq_cst);
   ++S.submitted;
   const uint64_t s = resolved_state(S);
   if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) {
@@ -276,15 +276,19 @@ int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, dou
   if (!spin_wait()) wait_nap(est);
   int polls = 0;
   double next_poke = 2.0;
-  while (done->value != value) {
+  while (done->value.load(std::memory_order_acquire) != value) {
     const double waited = wall_ms() - t0;
     if (spin_wait()) sched_yield();
     else wait_poll_pause(++polls, waited, est);
     if (waited > next_poke) {
       const int rc = ring_poke(device, c_class);
       if (rc != BPSW_OK) return rc;
+      // pokes at 2, 4, 8 ... ms, never further apart than the watchdog's limit (round 5 doubled without bound and tested the limit only at
+      // a poke: BPSW_RING_TIMEOUT_MS=20000 fired after 32.8 s)
       next_poke = waited * 2.0;
-      if (waited > (double)timeout_ms()) {
+      if (next_poke < (double)timeout_ms() && next_poke * 2.0 > (double)timeout_ms()) next_poke = (double)timeout_ms();
+      if (next_poke > waited + (double)timeout_ms()) next_poke = waited + (double)timeout_ms();
+      if (waited >= (double)timeout_ms()) {
         RingService& S = service(device, c_class);
         std::lock_guard<std::recursive_mutex> lk(S.mu);
         S.broken = true;
@@ -292,9 +296,56 @@ int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, dou
       }
     }
   }
-  std::atomic_thread_fence(std::memory_order_acquire);
   if (est_ms) *est_ms = wait_est_update(est, wall_ms() - t0, polls, napped);
   return BPSW_OK;
+}
+
+// The integrity tripwire.  The results of a batch and its completion word travel as separate posted writes over PCIe from up to a
+// thousand wavefronts on eight XCDs (bpsw_ring_dev.h: the argument, and what it assumes of the fabric).  If the completion word ever
+// overtook a result the caller would read stale bytes of an earlier call -- a silent wrong alignment.  So the caller poisons every
+// record of its result block before it publishes the descriptor (a value no kernel writes) and looks at every record again after the
+// completion word: a record that still holds the poison is counted, reported once on stderr, given a moment to arrive, and the call
+// fails with BPSW_ERR_DEVICE if it does not.  Host-side only: the kernels do not know.  BPSW_RING_INTEGRITY=0 switches it off.
+static std::atomic<uint64_t> g_integrity_checked{0}, g_integrity_faults{0};
+bool ring_integrity_on() {
+  static const bool on = env_int("BPSW_RING_INTEGRITY", 1) != 0;
+  return on;
+}
+void ring_poison(uint32_t* first_word, size_t stride_words, size_t n_records, size_t second_word_offset) {
+  if (!ring_integrity_on()) return;
+  for (size_t i = 0; i < n_records; ++i) {
+    first_word[i * stride_words] = RING_POISON;
+    if (second_word_offset) first_word[i * stride_words + second_word_offset] = RING_POISON;
+  }
+  // (the block is the caller's own pinned memory and the descriptor that names it is published behind these stores: ring_submit's
+  // release store of the tail)
+}
+int ring_check(const uint32_t* first_word, size_t stride_words, size_t n_records, size_t second_word_offset, const char* what) {
+  if (!ring_integrity_on()) return BPSW_OK;
+  g_integrity_checked.fetch_add(n_records, std::memory_order_relaxed);
+  const auto scan = [&]() {
+    size_t bad = 0;
+    for (size_t i = 0; i < n_records; ++i) {
+      const volatile uint32_t* r = first_word + i * stride_words;
+      if (r[0] == RING_POISON || (second_word_offset && r[second_word_offset] == RING_POISON)) ++bad;
+    }
+    return bad;
+  };
+  size_t bad = scan();
+  if (!bad) return BPSW_OK;
+  g_integrity_faults.fetch_add(bad, std::memory_order_relaxed);
+  static std::atomic<bool> said{false};
+  if (!said.exchange(true))
+    fprintf(stderr, "bPSW: RING INTEGRITY: %zu of %zu %s records were not in host memory when their batch's completion word was (reported once; "
+            "bpsw_ring_integrity counts them).  Set BPSW_RING=0 and report this.\n", bad, n_records, what);
+  const double t0 = wall_ms();
+  while (bad && wall_ms() - t0 < 5.0) { sched_yield(); bad = scan(); }
+  if (bad) return fail(BPSW_ERR_DEVICE, std::string("ring: integrity: ") + what + " records missing behind the completion word");
+  return BPSW_OK;   // late, but whole: the call's results are what the kernel wrote
+}
+void ring_integrity_stats(uint64_t* checked, uint64_t* faults) {
+  if (checked) *checked = g_integrity_checked.load(std::memory_order_relaxed);
+  if (faults) *faults = g_integrity_faults.load(std::memory_order_relaxed);
 }
 
 double ring_ticks_per_ms(int device, int c_class) { return 1000.0 * (double)service(device, c_class).ticks_per_us; }
@@ -307,8 +358,7 @@ void ring_pause(int device) {
     S.mu.lock();
     ++S.pause_depth;
     if (!S.inited || !S.running) continue;
-    S.H->close_req = S.epoch;
-    std::atomic_thread_fence(std::memory_order_seq_cst);
+    S.H->close_req.store(S.epoch, std::memory_order_seq_cst);
     (void)wait_closed(S, 2000.0);
     (void)hipStreamSynchronize(S.stream);
   }
@@ -350,15 +400,14 @@ __attribute__((destructor)) static void ring_shutdown() {
   bool any = false;
   for (auto& dev : g_rings)
     for (RingService& S : dev)
-      if (S.inited && S.running && S.H) { S.H->close_req = S.epoch; any = true; }
+      if (S.inited && S.running && S.H) { S.H->close_req.store(S.epoch, std::memory_order_seq_cst); any = true; }
   if (!any) return;
-  std::atomic_thread_fence(std::memory_order_seq_cst);
   const double t0 = wall_ms();
   for (auto& dev : g_rings)
     for (RingService& S : dev) {
       if (!(S.inited && S.running && S.H)) continue;
       while (wall_ms() - t0 < 50.0) {
-        const uint64_t s = S.H->state;
+        const uint64_t s = S.H->state.load(std::memory_order_acquire);
         if (ring_state_epoch(s) == S.epoch && ring_state_phase(s) == RING_CLOSED) break;
         sched_yield();
       }

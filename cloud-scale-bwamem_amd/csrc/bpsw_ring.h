@@ -28,6 +28,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
+
 namespace bpsw {
 
 constexpr uint32_t RING_DESC_WORDS = 64;  // 256 bytes: one coalesced wave load
@@ -41,19 +43,23 @@ inline uint32_t ring_state_epoch(uint64_t s) { return (uint32_t)(s >> 40); }
 inline uint32_t ring_state_consumed(uint64_t s) { return (uint32_t)((s >> 8) & 0xffffffffu); }
 inline uint64_t ring_state_phase(uint64_t s) { return s & 0xffu; }
 
-// Control block in pinned host memory: one line the host writes, one the device writes.
+// Control block in pinned host memory: one line the host writes, one the device writes.  The words both sides touch are std::atomic
+// on the host (lock-free, same size and layout as the plain word: the device code addresses them through casts, bpsw_ring_dev.h) --
+// round 5 had `volatile` fields and free-standing fences, which is neither a data-race-free C++ program nor something a thread
+// sanitizer can follow (tests/ring_host builds this file's host half under -fsanitize=thread against a C++ thread that plays the kernel).
 struct RingHostCtl {
-  volatile uint32_t tail;       // host: descriptors published in the current epoch
-  volatile uint32_t close_req;  // host: != 0 -> close the epoch of this number as soon as possible
+  std::atomic<uint32_t> tail;       // host: descriptors published in the current epoch
+  std::atomic<uint32_t> close_req;  // host: != 0 -> close the epoch of this number as soon as possible
   uint32_t pad0[30];
-  volatile uint64_t state;      // device (the host initialises it to OPEN before the launch)
-  volatile uint64_t heartbeat;  // device: the poller's clock at its last pass (diagnostics)
-  volatile uint32_t workers_seen;  // device: worker wavefronts that took at least one unit in this epoch (diagnostics)
-  volatile uint32_t close_reason;  // device: why the epoch closed -- 1 asked by the host, 2 ring used up, 3 idle, 4 no progress (diagnostics)
-  volatile uint64_t diag_claim_ticks, diag_unit_ticks, diag_units;  // copies of RingDevCtl's at the epoch's close
+  std::atomic<uint64_t> state;      // device (the host initialises it to OPEN before the launch)
+  std::atomic<uint64_t> heartbeat;  // device: the poller's clock at its last pass (diagnostics)
+  std::atomic<uint32_t> workers_seen;  // device: worker wavefronts that took at least one unit in this epoch (diagnostics)
+  std::atomic<uint32_t> close_reason;  // device: why the epoch closed -- 1 asked by the host, 2 ring used up, 3 idle, 4 no progress (diagnostics)
+  std::atomic<uint64_t> diag_claim_ticks, diag_unit_ticks, diag_units;  // copies of RingDevCtl's at the epoch's close
   uint32_t pad1[20];
 };
 static_assert(sizeof(RingHostCtl) == 256, "ring control block layout");
+static_assert(sizeof(std::atomic<uint32_t>) == 4 && sizeof(std::atomic<uint64_t>) == 8, "the device side addresses these words through casts");
 
 // Control block in device memory.  The three words a waiting worker looks at share sixteen bytes: ONE load per look.
 struct RingDevCtl {
@@ -87,11 +93,16 @@ struct RingDesc {
   uint32_t w[RING_DESC_WORDS];
 };
 struct RingDone {  // the completion record a caller waits on (pinned host memory, 32 bytes)
-  volatile uint32_t value;
+  std::atomic<uint32_t> value;
   uint32_t pad;
-  volatile uint64_t t_first, t_done;
+  std::atomic<uint64_t> t_first, t_done;
   uint64_t pad2;
 };
+static_assert(sizeof(RingDone) == 32, "completion record layout");
+
+// what a caller writes over every record of its result block before it publishes a descriptor (ring_poison / ring_check, bpsw_ring.cpp):
+// no kernel writes it -- a rescue job's score and an extension record's upper half of the width word are never negative
+constexpr uint32_t RING_POISON = 0x80005a5au;
 
 // payload of the rescue kernel's descriptors (words 8..): what swp_kernel takes as arguments
 struct SwRingPayload {

@@ -482,6 +482,16 @@ void bpsw_destroy(bpsw_ctx_t* c) {
   if (c->pend_ext.active && c->pend_ext.s) (void)hipStreamSynchronize(c->pend_ext.s);  // a caller-provided stream may still run
   if (c->pend_sw.active && c->pend_sw.s) (void)hipStreamSynchronize(c->pend_sw.s);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->ring_abandoned) {
+    // a ring batch of this context ran into the watchdog (or lost records): its descriptor still names these blocks, and a unit that
+    // finishes late would write into whatever they have become -- they stay allocated for the life of the process (a few MB, once)
+    for (int i = 0; i < 8; ++i)
+      if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    rescue_scratch_free(c->rescue_scratch);
+    c->ev[0] = nullptr;  // (the buffers' owners are leaked with the context object itself)
+    return;
+  }
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
   c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release(); c->d_sift.release();
   c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();
@@ -639,6 +649,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
   int n = 0, mq = 0, mr = 0;
   bool coord = false;
   std::lock_guard<std::mutex> g(c->mu);
+  if (c->ring_abandoned) return fail(BPSW_ERR_DEVICE, "this context gave up a ring batch (watchdog / integrity): create a new one");
   HIP_TRY(hipSetDevice(c->device));
   const uint8_t* d_pac = nullptr;
   long long l_pac = 0;
@@ -784,6 +795,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       for (int r = 0; r < 5; ++r) pl.mat_row[r] = c->ext_sc.mat.row[r];
       memcpy(desc.w, &head, sizeof head);
       memcpy(desc.w + sizeof(RingDescHead) / 4, &pl, sizeof pl);
+      ring_poison((uint32_t*)c->h_stage_out.ptr, 5, (size_t)n, 4);  // (idx and the width word of every record: the tripwire of bpsw_ring.cpp)
       int rc = ring_submit(c->device, RING_CLASS_EXT, c->num_cu, desc);
       if (rc != BPSW_OK && !ring_usable(c->device, RING_CLASS_EXT)) {
         // the epoch could not be started (nothing of this batch has reached a worker): this call and the later ones take launches of their own
@@ -793,13 +805,25 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       } else {
         if (rc != BPSW_OK) return rc;
         rc = ring_wait(c->device, RING_CLASS_EXT, done, c->ring_seq, &c->wait_est_ms[4]);
-        if (rc != BPSW_OK) return rc;
-        ring_kernel_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, RING_CLASS_EXT));
+        if (rc != BPSW_OK) { c->ring_abandoned = true; return rc; }
+        // every record written?  (also the net under a task the resident kernel could not finish -- it has no defer list: a record left
+        // as it was would otherwise pass for a result)
+        rc = ring_check((const uint32_t*)c->h_stage_out.ptr, 5, (size_t)n, 4, "extension");
+        if (rc != BPSW_OK) {
+          // still missing after ring_check's grace period: not a late write but a task the resident kernel left alone.  The launch path
+          // below has the full kernel behind it and computes the whole batch again into the same block.
+          static std::atomic<bool> said{false};
+          if (!said.exchange(true)) fprintf(stderr, "bPSW: an extension batch came back from the ring with unwritten records; it is run again through a launch (%s)\n", bpsw_last_error());
+          copy_first_ms = 0.;
+          goto ring_left;
+        }
+        ring_kernel_ms = (float)((double)(done->t_done.load(std::memory_order_relaxed) - done->t_first.load(std::memory_order_relaxed)) / ring_ticks_per_ms(c->device, RING_CLASS_EXT));
         t_dev1 = stat_ms();
         via_ring = true;
         c->stats.ext_ring_calls++;
       }
     }
+  ring_left:;
   }
   if (!via_ring) {
     // The copy of the wire batch.  While rescue batches are in flight on this device (bpsw_sw_runtime.cpp counts them) it is made

@@ -72,6 +72,7 @@ int sw_launches_in_flight(int device) { return g_sw_in_flight[device >= 0 && dev
 void sw_launch_in_flight(int device, int delta) { g_sw_in_flight[device >= 0 && device < 64 ? device : 0].fetch_add(delta, std::memory_order_relaxed); }
 
 int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st, int mq, int mt, bool pac_mode, const int32_t** results) {
+  if (c->ring_abandoned) return fail(BPSW_ERR_DEVICE, "this context gave up a ring batch (watchdog / integrity): create a new one");
   SwScoring sc;
   int rc = make_scoring(opt, xtra, &sc);
   if (rc != BPSW_OK) return rc;
@@ -161,6 +162,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     pl.a = sc.a; pl.b = sc.b; pl.o_del = sc.o_del; pl.e_del = sc.e_del; pl.o_ins = sc.o_ins; pl.e_ins = sc.e_ins; pl.xtra = sc.xtra;
     memcpy(desc.w, &head, sizeof head);
     memcpy(desc.w + sizeof(RingDescHead) / 4, &pl, sizeof pl);
+    ring_poison((uint32_t*)k_out, 7, (size_t)n, 6);  // (score and qb of every record: the tripwire of bpsw_ring.cpp)
     rc = ring_submit(c->device, ring_class, c->num_cu, desc);
     if (rc != BPSW_OK && !ring_usable(c->device, ring_class)) {
       // the epoch could not be started (nothing of this batch has reached the device): this call and the later ones take a launch of their own
@@ -171,8 +173,10 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     } else {
       if (rc != BPSW_OK) return rc;
       rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[5]);
-      if (rc != BPSW_OK) return rc;
-      const float span_ms = (float)((double)(done->t_done - done->t_first) / ring_ticks_per_ms(c->device, ring_class));
+      if (rc != BPSW_OK) { c->ring_abandoned = true; return rc; }  // (the descriptor still names this context's pinned blocks: see bpsw_destroy)
+      rc = ring_check((const uint32_t*)k_out, 7, (size_t)n, 6, "rescue job");
+      if (rc != BPSW_OK) { c->ring_abandoned = true; return rc; }
+      const float span_ms = (float)((double)(done->t_done.load(std::memory_order_relaxed) - done->t_first.load(std::memory_order_relaxed)) / ring_ticks_per_ms(c->device, ring_class));
       c->stats.grp_dev_ms += stat_ms() - t_dev0;
       c->stats.sw_calls++; c->stats.sw_jobs += (uint64_t)n; c->stats.sw_ring_calls++;
       c->stats.sw_kernel_ms += span_ms;  // first unit taken -> last unit finished, on the device's clock
@@ -662,6 +666,11 @@ int bpsw_global_batch(bpsw_ctx_t* c, const bpsw_opt_t* opt, const bpsw_global_jo
   memcpy(out_ncigar, ho + o_nc, 4 * (size_t)n);
   memcpy(out_cigar, ho + o_cig, 4 * (size_t)n * (size_t)j->max_cigar);
   return BPSW_OK;
+}
+
+int bpsw_ring_integrity(uint64_t* checked, uint64_t* faults) {
+  ring_integrity_stats(checked, faults);
+  return ring_integrity_on() ? 1 : 0;
 }
 
 int bpsw_sw_batches_in_flight(int device) { return device >= 0 && device < 64 ? bpsw::sw_launches_in_flight(device) : -1; }

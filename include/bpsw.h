@@ -470,6 +470,13 @@ int bpsw_last_kernel_ms(bpsw_ctx_t *ctx, float *ext_ms, float *sw_ms);
  * events around the resident kernel's launch on its stream (what a kernel trace reports as that kernel's duration).  Diagnostics; any
  * pointer may be null. */
 int bpsw_ring_stats(bpsw_ctx_t *ctx, uint64_t *epochs, uint64_t *submitted, uint64_t *carried, double *epochs_ms, uint64_t *epochs_timed);
+/* The rings' integrity tripwire (csrc/bpsw_ring.cpp).  A batch's results and its completion word reach host memory as separate writes
+ * from many wavefronts; before a caller publishes a batch it poisons every record of its result block with a value no kernel writes, and
+ * after the completion word it looks at every record again.  checked = records looked at, faults = records that still held the poison when
+ * the completion word was visible (process-wide; expected: 0 -- a fault is reported on stderr once, the call waits up to 5 ms for the
+ * records and fails with BPSW_ERR_DEVICE if they do not arrive; an extension batch is run again through a launch instead).  Returns 1
+ * when the check is on (default), 0 when BPSW_RING_INTEGRITY=0 switched it off.  Either pointer may be null. */
+int bpsw_ring_integrity(uint64_t *checked, uint64_t *faults);
 /* A gauge: the number of SW batches (bpsw_swalign2_batch / bpsw_matesw_group / mateSWJNI rounds, of any context) that are in their device
  * phase on `device` right now -- what the "lone caller takes a launch of its own" rule of the SW entry points looks at
  * (BPSW_RING_LONE_LAUNCH).  Diagnostics (an executor's metrics page; tests/test_ring_gpu.py waits on it to make
