@@ -465,7 +465,14 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   // (BPSW_SPIN_WAIT=1 restores the runtime's default busy wait for A/B runs)
   for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreateWithFlags(&c->ev[i], spin_wait() ? hipEventDefault : hipEventBlockingSync);
   if (e == hipSuccess) e = c->d_pre.reserve(512);
-  if (e == hipSuccess) e = hipMemset(c->d_pre.ptr, 0, 512);  // scan records and the self-resetting queue heads of ext_kernel
+  // scan records and the self-resetting queue heads of ext_kernel.  On the context's own stream and WAITED FOR: rounds 1-5 had a plain
+  // hipMemset here, which for device memory is a fill kernel on the legacy stream that the host does not wait for -- and this library's
+  // streams are non-blocking, so nothing ordered it before the context's first kernel.  When the legacy stream's hardware queue was
+  // busy (eight threads creating contexts beside running calls), the fill landed in the middle of the first extension kernel, cleared
+  // its queue heads and `done` count, the kernel's last wave never put them back, and a later call of the context started from stale
+  // heads: records missing from its result (GPU suite, round 6: test_concurrent_contexts_give_identical_results, one run in a few).
+  if (e == hipSuccess) e = hipMemsetAsync(c->d_pre.ptr, 0, 512, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = c->h_pre.reserve(512);
   if (e == hipSuccess) memset(c->h_pre.ptr, 0, 512);  // (+448: the completion record of this context's ring submissions)
   if (e != hipSuccess) {
@@ -492,6 +499,9 @@ void bpsw_destroy(bpsw_ctx_t* c) {
     c->ev[0] = nullptr;  // (the buffers' owners are leaked with the context object itself)
     return;
   }
+  // ONE pause of the device's rings around all the releases (each release pauses them for itself otherwise: a dozen close / synchronise /
+  // relaunch rounds that every ring user of the device sits through whenever a task thread or a tail-pool worker goes away; the pause nests)
+  RingPauseForFree paused_for_all;
   c->d_wire.release(); c->d_out.release(); c->d_pre.release();
   c->d_sw_in.release(); c->d_sw_out.release(); c->d_sw_scratch.release(); c->d_gl_z.release(); c->d_ext_lists.release(); c->d_sift.release();
   c->h_stage_in.release(); c->h_stage_out.release(); c->h_pre.release();

@@ -617,6 +617,9 @@ int bpsw_bns_load(bpsw_ctx_t* c, int32_t n_seqs, const int64_t* offset, const in
     at += len[i];
   }
   if (at != r.l_pac) return fail(BPSW_ERR_ARG, "bns_load: contig lengths do not add up to l_pac");
+  // (as bpsw_ref_load does: an epoch of the extension ring that byte-batch callers keep feeding takes no reference hold and would keep the
+  // device-wide wait below from returning)
+  struct RingPause { int d; explicit RingPause(int dev) : d(dev) { ring_pause(d); } ~RingPause() { ring_resume(d); } } ring_paused(c->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(r.ann.reserve(12 * (size_t)n_seqs + 16));
   HIP_TRY(hipMemcpy(r.ann.ptr, offset, 8 * (size_t)n_seqs, hipMemcpyHostToDevice));

@@ -2,8 +2,9 @@
 tasks for the sift kernel -- are descriptors of one resident kernel per device instead of a launch each.  What the reference has to
 compare with is the call's contract (one blocking call per batch: jni_fpga/sw_extend_fpga.c:116-193) and the sizes it sends
 (-FPGASWExtThreshold 64: run_test.sh:7; the later rounds of memChainToAlnBatched, worker1/MemChainToAlignBatched.scala:471-615, send
-a few dozen tasks): the results must not depend on the path.  The rest of the suite pins BPSW_EXT_SIFT_MIN=0 (the sift kernel in front
-of every batch, which keeps every batch OFF this ring), so these tests run children with the library's production thresholds."""
+a few dozen tasks): the results must not depend on the path.  The switches are read once per process, so these tests run children: at the library's own
+defaults (also when this process is the forced-paths pass, tests/test_forced_paths_gpu.py, whose BPSW_EXT_SIFT_MIN=0 keeps every batch
+OFF this ring), with the ring switched off, with a tiny ring, with a ring that cannot launch."""
 import os
 import subprocess
 import sys
@@ -100,14 +101,17 @@ ts = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
 assert not any(t.is_alive() for t in ts), "a caller is still waiting"
 assert not errors, errors[:2]
 e, s, carried = ctx.ring_stats()
+on, checked, faults = ctx.ring_integrity()   # the tripwire of csrc/bpsw_ring.cpp: every ring record poisoned before, looked at after
+assert on and faults == 0 and (checked > 0) == ring_expected, (on, checked, faults)
 print("EXTRING", taken, e, s, carried)
 ctx.close()
 """
 
 
 def _run(extra_env):
-    env = dict(os.environ, BPSW_TEST_PRODUCTION_DEFAULTS="1", **extra_env)
-    env.pop("BPSW_EXT_SIFT_MIN", None)
+    env = dict(os.environ, **extra_env)
+    for k in ("BPSW_TEST_FORCED_PATHS", "BPSW_EXT_SIFT_MIN", "BPSW_RING_LONE_LAUNCH"):   # the library's own defaults, whatever this process runs with
+        env.pop(k, None)
     src = _CHILD.format(pkg=os.path.join(ROOT, "cloud-scale-bwamem_amd"), orc=os.path.join(ROOT, "oracle"), tests=os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]

@@ -106,6 +106,6 @@ def test_parity_with_the_round_2_mechanisms_switched_off(env):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(HERE, "test_extend_gpu.py"),
                         os.path.join(HERE, "test_swalign_gpu.py"), os.path.join(HERE, "test_rescue_gpu.py"),
-                        os.path.join(HERE, "test_concurrency_gpu.py"), os.path.join(HERE, "test_host_path_gpu.py"), "-k", "not switched_off"],
+                        os.path.join(HERE, "test_concurrency_gpu.py"), os.path.join(HERE, "test_host_path_gpu.py"), "-k", "not switched_off and not large_batch"],   # (test_large_batch: 11 s of oracle time per child, and nothing a switch changes)
                        env=e, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -21,22 +21,36 @@ pytestmark = pytest.mark.gpu
 
 XTRA = po.KSW_XSUBO | po.KSW_XSTART | po.KSW_XBYTE | 19
 RING_ON = os.environ.get("BPSW_RING", "1") != "0"
+# at the library's defaults a LONE caller's batch of sixteen jobs or more takes a launch of its own (BPSW_RING_LONE_LAUNCH,
+# csrc/bpsw_sw_runtime.cpp); the forced-paths pass (tests/test_forced_paths_gpu.py) sends every batch through the ring
+LONE_LAUNCH = os.environ.get("BPSW_RING_LONE_LAUNCH", "1") != "0"
+
+
+def _lone_batch_rings(n_jobs):
+    return RING_ON and (not LONE_LAUNCH or n_jobs < 16)
 
 
 def _want(orc, jobs):
     return orc.sw_align2_jobs(orc.default_opt(), XTRA, **jobs)[0]
 
 
-def test_batches_go_through_the_ring(ctx, orc):
-    jobs = synth.sw_jobs(300, seed=501)
+@pytest.mark.parametrize("n_jobs", [12, 300])
+def test_batches_go_through_the_ring(ctx, orc, n_jobs):
+    """a lone caller: twelve jobs always take the ring; three hundred do when every batch is sent there (the forced-paths pass) and take a
+    launch of their own at the library's defaults -- bit-exact either way, and the counters say which way it went"""
+    jobs = synth.sw_jobs(n_jobs, seed=501 + n_jobs)
+    time.sleep(0.05)   # (no extension call on the device in the last 20 ms: part of the "lone caller" rule)
     before = ctx.stats().sw_ring_calls
     e0, s0, _ = ctx.ring_stats()
     got = ctx.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs)
     assert np.array_equal(got, _want(orc, jobs))
-    if RING_ON:
+    e1, s1, _ = ctx.ring_stats()
+    if _lone_batch_rings(n_jobs):
         assert ctx.stats().sw_ring_calls == before + 1
-        e1, s1, _ = ctx.ring_stats()
         assert s1 == s0 + 1 and e1 >= max(e0, 1)
+    else:
+        assert ctx.stats().sw_ring_calls == before and s1 == s0
+    assert ctx.ring_integrity()[2] == 0
 
 
 @pytest.mark.parametrize("n_jobs", [1, 2, 3, 7, 64, 65])
@@ -93,7 +107,7 @@ def test_32_threads_mixed_sizes_bit_exact(orc):
 def test_idle_epoch_ends_and_the_next_call_restarts_it(ctx, orc):
     if not RING_ON:
         pytest.skip("BPSW_RING=0")
-    jobs = synth.sw_jobs(40, seed=550)
+    jobs = synth.sw_jobs(12, seed=550)   # (fewer than sixteen: the ring's at the library's defaults too)
     want = _want(orc, jobs)
     opt = bpsw_hip.default_opt()
     assert np.array_equal(ctx.swalign2_batch(opt, XTRA, **jobs), want)
@@ -114,7 +128,7 @@ def test_ref_load_between_calls_pauses_the_ring(orc):
     l_pac = 300_007
     c = bpsw_hip.Context(0)
     opt = bpsw_hip.default_opt()
-    jobs = synth.sw_jobs(80, seed=560)
+    jobs = synth.sw_jobs(14, seed=560)   # (the ring's at the library's defaults too)
     want = _want(orc, jobs)
     for seed in (561, 562):
         pac, bases = synth.random_pac(l_pac, seed=seed)
@@ -211,7 +225,7 @@ def test_a_ring_that_cannot_launch_sends_its_callers_back_to_launches():
     if not RING_ON:
         pytest.skip("BPSW_RING=0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BPSW_RING_TEST_FAIL_LAUNCH="1")
+    env = dict(os.environ, BPSW_RING_TEST_FAIL_LAUNCH="1", BPSW_RING_LONE_LAUNCH="0")   # (every batch tries the ring: the first one meets the failure)
     src = _FAIL.format(pkg=os.path.join(root, "cloud-scale-bwamem_amd"), orc=os.path.join(root, "oracle"))
     r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -277,7 +291,7 @@ c.close()
 
 
 def test_a_lone_caller_with_a_sizeable_batch_takes_a_launch_of_its_own():
-    """The library's default (BPSW_RING_LONE_LAUNCH unset; the suite pins it to 0): with no other SW batch in flight and no extension call
+    """The library's default (BPSW_RING_LONE_LAUNCH unset; the forced-paths pass sets it to 0): with no other SW batch in flight and no extension call
     about, a batch of sixteen jobs or more is launched -- a lone caller gets the whole device, 0.38 instead of 0.48 ms for 4 096 pairs --,
     smaller ones and every batch that has company go through the ring.  Bit-exact either way."""
     if not RING_ON:
@@ -293,3 +307,14 @@ def test_a_lone_caller_with_a_sizeable_batch_takes_a_launch_of_its_own():
     # every attempt was submitted while the gauge read >= 1; the helper's batch lasts milliseconds, the submission microseconds, so all
     # ten see the company -- the assertion only asks that the rule fired at all, the deterministic part
     assert attempts == 10 and ringed_with_company >= 1, (attempts, ringed_with_company)
+
+
+def test_the_integrity_tripwire_saw_every_ring_record_and_no_fault(ctx):
+    """Every batch that went through a ring in this process had its result records poisoned before publication and looked at after the
+    completion word (csrc/bpsw_ring.cpp: ring_poison / ring_check): a record that was not in host memory when its completion word was
+    would have been counted.  (Runs after the multi-threaded tests of this file: the order inside a file is kept.)"""
+    on, checked, faults = ctx.ring_integrity()
+    assert on, "BPSW_RING_INTEGRITY=0 in the test environment"
+    assert faults == 0, f"{faults} of {checked} ring records were late behind their completion word"
+    if RING_ON:
+        assert checked > 1000
