@@ -184,7 +184,7 @@ struct Group {
 };
 
 void skip_flags(const Group& G, const Reg& a, const Reg* mates, size_t n_mates, int skip[4]) {
-  rescue_skip_flags(G.g->l_pac, G.pes_low, G.pes_high, G.failed_mask, G.mode == BPSW_RESCUE_SCALA, a.rb, &mates->rb, sizeof(Reg), n_mates, skip);
+  rescue_skip_flags(G.g->l_pac, G.pes_low, G.pes_high, G.failed_mask, G.mode == BPSW_RESCUE_SCALA, a.rb, mates ? &mates->rb : nullptr, sizeof(Reg), n_mates, skip);  // (no mate regions: no address to form -- UBSan, tests/host_san)
 }
 
 // length of window x as the SW sees it: shipped with the bytes, or -- coordinate mode, SURVEY.md 8f.2 -- what bnsGetSeq

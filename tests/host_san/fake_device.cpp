@@ -1,0 +1,314 @@
+// fake_device.cpp -- TEST INFRASTRUCTURE (never shipped, never linked into libbPSW_hip.so): what the HOST layer of the library needs of
+// a GPU, on a box without one, so that csrc/bpsw_runtime.cpp, bpsw_sw_runtime.cpp, bpsw_ring.cpp, bpsw_rescue.cpp, bpsw_pack.cpp,
+// bpsw_tail.cpp, bpsw_tail_pool.cpp and bpsw_jni.cpp -- compiled UNCHANGED by g++ -- can run under -fsanitize=address,undefined / thread
+// (round-5 review, item 6: ~7 k lines of threaded host C++ had only ever been checked by result equality).
+//   * the HIP runtime entry points those files use, over ordinary memory: every "asynchronous" operation completes at once on the calling
+//     thread, events are timestamps, streams carry no state -- except the stream of a submission ring, whose resident kernel is a
+//     group of C++ threads (tests/ring_host/fake_ring_device.h) that stay alive until the epoch closes, as the real one does;
+//   * the kernels behind the launch_* entry points, played by the ORACLE (oracle/bpsw_oracle.c): a rescue job is orc_sw_align2, an
+//     extension batch orc_wire_extend.  The results are therefore the oracle's by construction: what a run of the parity tests against
+//     this build checks is not the kernels (the GPU suite does that) but everything around them -- the JNI marshalling, the rescue
+//     planner's speculation and replay with its hand-placed prefetches, the packers, the staging arithmetic, the rings' host half, the
+//     tail pool's hand-offs -- for out-of-bounds accesses, use after free, undefined behaviour and data races.
+//   * what is not played (coordinate batches, the reference on the device, SWGlobal / reg2aln / chain2aln kernels) fails loudly with
+//     hipErrorNotSupported: the tests that need it are left out of the sanitizer run (tests/test_host_sanitizers.py names them).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "bpsw_internal.h"
+#include "../ring_host/fake_ring_device.h"
+
+extern "C" {
+#include "bpsw_oracle.h"
+}
+
+using namespace bpsw;
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ------------------------------------------------------------------------------------------------ streams, events
+struct FakeKernel {
+  std::thread main;
+  std::atomic<bool> finished{false};
+  std::vector<struct ihipEvent_t*> end_events;
+  std::mutex mu;
+};
+struct ihipStream_t {
+  std::mutex mu;
+  FakeKernel* k = nullptr;  // a resident ring kernel, if this is a ring's stream
+};
+struct ihipEvent_t {
+  std::atomic<double> t_ms{0.};
+  std::atomic<bool> ready{true};
+};
+static void stamp(hipEvent_t e) { if (e) { e->t_ms.store(now_ms()); e->ready.store(true, std::memory_order_release); } }
+static void stream_drain(ihipStream_t* s) {  // (caller holds s->mu)
+  if (!s->k) return;
+  if (s->k->main.joinable()) s->k->main.join();
+  delete s->k;
+  s->k = nullptr;
+}
+
+extern "C" {
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }  // (ring epochs are closed by ring_pause before anybody calls this)
+hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600* p, int) {
+  memset(p, 0, sizeof *p);
+  snprintf(p->gcnArchName, sizeof p->gcnArchName, "gfx950:sramecc+:xnack-");
+  p->multiProcessorCount = 256;
+  return hipSuccess;
+}
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 100000; return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) { return e == hipErrorNotSupported ? "not played by the fake device (tests/host_san)" : "fake device error"; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t s) {
+  if (s) { std::lock_guard<std::mutex> lk(s->mu); stream_drain(s); }  // stream order behind a resident kernel
+  memset(p, v, n);
+  return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new ihipStream_t; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new ihipStream_t; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) {
+  if (s) { { std::lock_guard<std::mutex> lk(s->mu); stream_drain(s); } delete s; }
+  return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) {
+  if (s) { std::lock_guard<std::mutex> lk(s->mu); stream_drain(s); }
+  return hipSuccess;
+}
+hipError_t hipStreamQuery(hipStream_t s) {
+  if (!s) return hipSuccess;
+  std::lock_guard<std::mutex> lk(s->mu);
+  return (!s->k || s->k->finished.load(std::memory_order_acquire)) ? hipSuccess : hipErrorNotReady;
+}
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new ihipEvent_t; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new ihipEvent_t; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t e) { return e->ready.load(std::memory_order_acquire) ? hipSuccess : hipErrorNotReady; }
+hipError_t hipEventSynchronize(hipEvent_t e) {
+  while (!e->ready.load(std::memory_order_acquire)) sched_yield();
+  return hipSuccess;
+}
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  if (!a->ready.load(std::memory_order_acquire) || !b->ready.load(std::memory_order_acquire)) return hipErrorNotReady;
+  *ms = (float)(b->t_ms.load() - a->t_ms.load());
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  if (s) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->k) {
+      std::lock_guard<std::mutex> lk2(s->k->mu);
+      if (!s->k->finished.load(std::memory_order_acquire)) {
+        e->ready.store(false, std::memory_order_relaxed);
+        s->k->end_events.push_back(e);
+        return hipSuccess;
+      }
+    }
+  }
+  stamp(e);
+  return hipSuccess;
+}
+}
+
+// ------------------------------------------------------------------------------------------------ the kernels, played by the oracle
+static void unpack_mat(const MatRows& m, int8_t out[25]) {
+  for (int r = 0; r < 5; ++r)
+    for (int c = 0; c < 5; ++c) out[5 * r + c] = (int8_t)((m.row[r] >> (8 * c)) & 0xff);
+}
+static uint8_t ref_base(const uint8_t* pac, long long l_pac, long long p) {  // the doubled reference (util/BNTSeqUtil.scala:37-79)
+  const auto at = [&](long long x) { return (uint8_t)((pac[x >> 2] >> ((~x & 3) << 1)) & 3); };
+  return p < l_pac ? at(p) : (uint8_t)(3 - at(2 * l_pac - 1 - p));
+}
+static void play_sw_job(const uint8_t* q_pool, const uint8_t* t_pool, const uint8_t* pac, long long l_pac, long long q_off, long long t_off, int q_len,
+                        int t_len, int q_rev, const int8_t mat[25], int a, int b, int o_del, int e_del, int o_ins, int e_ins, int xtra, int32_t out[7]) {
+  std::vector<uint8_t> q((size_t)(q_len > 0 ? q_len : 1)), t((size_t)(t_len > 0 ? t_len : 1));
+  for (int i = 0; i < q_len; ++i) {
+    const uint8_t c = q_pool[q_off + (q_rev ? q_len - 1 - i : i)];
+    q[(size_t)i] = q_rev ? (c < 4 ? (uint8_t)(3 - c) : (uint8_t)4) : c;  // MemSamPe.scala:1175-1184
+  }
+  for (int i = 0; i < t_len; ++i) t[(size_t)i] = t_pool ? t_pool[t_off + i] : ref_base(pac, l_pac, t_off + i);
+  int64_t cells = 0;
+  int32_t o[7];
+  orc_sw_align2(q_len, q.data(), t_len, t.data(), 5, mat, a, b, o_del, e_del, o_ins, e_ins, xtra, o, &cells);
+  for (int k = 0; k < 7; ++k) __atomic_store_n(out + k, o[k], __ATOMIC_RELAXED);  // (a system-scope store on the device)
+}
+
+namespace bpsw {
+
+int sw_ring_class(const SwScoring&, int max_qlen, int max_tlen, int* bias_out) {
+  if (bias_out) *bias_out = 0;
+  if (max_tlen > 4000) return 0;  // (the resident kernel's key rows are fixed for the epoch: longer windows take a launch)
+  return max_qlen <= 171 ? 3 : max_qlen <= 256 ? 5 : 0;
+}
+bool sw_quad_enabled() { return true; }
+int sw_resident_waves(int num_cu) { return 4 * num_cu; }
+size_t sw_scratch_bytes_per_wave(int max_tlen) { return 16 * (size_t)(max_tlen + 64); }
+int global_resident_waves(int, int) { return 1024; }
+int reg2aln_resident_waves(int, int, int, int) { return 1024; }
+size_t reg2aln_lds_per_wave(int, int, int) { return 4096; }
+int chain2aln_resident_waves(int) { return 1024; }
+
+void launch_sw_prepass(const SwJobsDev& j, size_t q_pool_bytes, size_t t_pool_bytes, SwPrepass* pre, hipStream_t) {
+  for (int i = 0; i < j.n; ++i) {
+    const int ql = j.q_len[i], tl = j.t_len[i];
+    const long long qo = j.q_off[i], to = j.t_off[i];
+    const bool t_ok = j.t_pool ? (unsigned long long)(to + tl) <= t_pool_bytes : (to + tl <= (j.l_pac << 1) && (to >= j.l_pac || to + tl <= j.l_pac));
+    if (ql < 1 || tl < 0 || qo < 0 || to < 0 || (unsigned long long)(qo + ql) > q_pool_bytes || !t_ok) pre->error = 1;
+    if (ql > pre->max_qlen) pre->max_qlen = ql;
+    if (tl > pre->max_tlen) pre->max_tlen = tl;
+  }
+}
+hipError_t launch_sw_kernel(const SwJobsDev& j, const SwScoring& sc, int max_qlen, int max_tlen, int32_t* out, uint32_t*, int, hipStream_t,
+                            const SwPrepass* pre, KernelEvents kev) {
+  stamp(kev.start);
+  if (!(pre && (pre->error || pre->max_qlen > max_qlen || pre->max_tlen > max_tlen))) {
+    int8_t mat[25];
+    unpack_mat(sc.mat, mat);
+    for (int i = 0; i < j.n; ++i)
+      play_sw_job(j.q_pool, j.t_pool, j.pac, j.l_pac, j.q_off[i], j.t_off[i], j.q_len[i], j.t_len[i], j.q_rev[i], mat, sc.a, sc.b, sc.o_del, sc.e_del,
+                  sc.o_ins, sc.e_ins, sc.xtra, out + 7 * (size_t)i);
+  }
+  stamp(kev.stop);
+  return hipSuccess;
+}
+
+// a resident kernel: poller + workers until the epoch closes (tests/ring_host/fake_ring_device.h)
+template <class UnitFn>
+static hipError_t launch_resident(const RingArgs& A, hipStream_t s, UnitFn fn) {
+  std::lock_guard<std::mutex> lk(s->mu);
+  stream_drain(s);
+  FakeKernel* k = new FakeKernel;
+  s->k = k;
+  static const int n_workers = getenv("FAKE_RING_WORKERS") ? atoi(getenv("FAKE_RING_WORKERS")) : 4;
+  k->main = std::thread([A, k, fn]() {
+    std::vector<std::thread> ts;
+    ts.emplace_back(fake_ring::play_poller, A);
+    for (int i = 0; i < n_workers; ++i) ts.emplace_back([A, i, fn]() { fake_ring::play_worker(A, i, fn); });
+    for (auto& t : ts) t.join();
+    std::lock_guard<std::mutex> lk2(k->mu);
+    for (ihipEvent_t* e : k->end_events) stamp(e);
+    k->finished.store(true, std::memory_order_release);
+  });
+  return hipSuccess;
+}
+hipError_t launch_swp_resident(int, const RingArgs& A, int, hipStream_t s) {
+  return launch_resident(A, s, [](const uint32_t* word, uint32_t unit) {  // bpsw_swalign.hip: swp_resident_kernel's reading of SwRingPayload
+    SwRingPayload pl;
+    memcpy(&pl, word + sizeof(RingDescHead) / 4, sizeof pl);
+    int8_t mat[25];
+    MatRows m;
+    for (int r = 0; r < 5; ++r) m.row[r] = pl.mat_row[r];
+    unpack_mat(m, mat);
+    const uint32_t* packed = (const uint32_t*)(uintptr_t)pl.packed;
+    for (int job = 2 * (int)unit; job < 2 * (int)unit + 2 && job < pl.n_jobs; ++job) {
+      const uint32_t* rec = packed + 8 * (size_t)job;
+      long long qo, to;
+      memcpy(&qo, rec, 8); memcpy(&to, rec + 2, 8);
+      play_sw_job((const uint8_t*)(uintptr_t)pl.q_pool, (const uint8_t*)(uintptr_t)pl.t_pool, (const uint8_t*)(uintptr_t)pl.pac, pl.l_pac, qo, to, (int)rec[4],
+                  (int)rec[5], (int)rec[6], mat, pl.a, pl.b, pl.o_del, pl.e_del, pl.o_ins, pl.e_ins, pl.xtra, (int32_t*)(uintptr_t)pl.out + 7 * (size_t)job);
+    }
+  });
+}
+
+// ---- extension: a byte batch (wire format 1) through orc_wire_extend; every task, whatever list the launch was given
+static hipError_t play_ext(const uint32_t* wire, int16_t* out, const ExtScoring& sc, int only_from, int only_to) {
+  const uint8_t* w = (const uint8_t*)wire;
+  if (w[7] != 0 && w[7] != 1) return hipErrorNotSupported;  // a coordinate batch
+  int32_t n;
+  memcpy(&n, w + 8, 4);
+  int8_t mat[25];
+  unpack_mat(sc.mat, mat);
+  std::vector<int16_t> tmp(10 * (size_t)(n > 0 ? n : 1));
+  int64_t cells = 0;
+  if (orc_wire_extend(w, (size_t)1 << 40, mat, sc.zdrop, sc.zdrop_mode, tmp.data(), &cells) != n) return hipErrorInvalidValue;
+  for (int t = only_from; t < only_to && t < n; ++t)
+    for (int k = 0; k < 10; ++k) __atomic_store_n(out + (size_t)sc.out_stride * (size_t)t + k, tmp[10 * (size_t)t + k], __ATOMIC_RELAXED);
+  return hipSuccess;
+}
+void launch_ext_prepass(const uint32_t*, size_t, int, ExtPrepass*, hipStream_t) {}  // (the asynchronous device entries are not played)
+hipError_t launch_ext_kernel(const uint32_t* wire, int, int16_t* out, const ExtScoring& sc, int, int, int, int*, const int*, hipStream_t, const ExtPrepass*,
+                             bool, KernelEvents kev, bool, int*, int, const uint8_t*, const uint4*, int* defer_post, const int*) {
+  stamp(kev.start);
+  const hipError_t e = play_ext(wire, out, sc, 0, 1 << 30);
+  if (defer_post) *defer_post = 0;  // nothing deferred: the call launches no full kernel behind this one
+  stamp(kev.stop);
+  return e;
+}
+hipError_t launch_ext_sift_kernel(const uint32_t*, int, int16_t*, const ExtScoring&, int, int, uint8_t*, uint4*, hipStream_t, KernelEvents kev, const ExtPrepass*,
+                                  int*, int*, int) {
+  stamp(kev.start); stamp(kev.stop);  // (launch_ext_kernel above computes every task: the sift kernel has nothing to hand over)
+  return hipSuccess;
+}
+// (the oracle computes a whole batch per call: the first unit of a descriptor to arrive does, the others copy their slice)
+struct ExtBatchPlay {
+  std::once_flag once;
+  std::vector<int16_t> out;  // 10 per task; empty: the oracle refused the batch
+  int units_left = 0;
+};
+static std::mutex g_ext_play_mu;
+static std::map<std::pair<uint64_t, uint32_t>, std::shared_ptr<ExtBatchPlay>> g_ext_play;  // (completion record address, completion value)
+hipError_t launch_ext_resident(const RingArgs& A, int, hipStream_t s) {
+  return launch_resident(A, s, [](const uint32_t* word, uint32_t unit) {  // bpsw_extend.hip: ext_resident_kernel's reading of ExtRingPayload
+    RingDescHead head;
+    ExtRingPayload pl;
+    memcpy(&head, word, sizeof head);
+    memcpy(&pl, word + sizeof(RingDescHead) / 4, sizeof pl);
+    if (pl.coord) return;  // (not played: the record stays poisoned and the call runs the batch again through a launch, which says "not supported")
+    std::shared_ptr<ExtBatchPlay> e;
+    const auto key = std::make_pair(head.done_ptr, head.done_value);
+    {
+      std::lock_guard<std::mutex> lk(g_ext_play_mu);
+      auto& slot = g_ext_play[key];
+      if (!slot) { slot = std::make_shared<ExtBatchPlay>(); slot->units_left = (int)head.n_units; }
+      e = slot;
+      if (--slot->units_left == 0) g_ext_play.erase(key);
+    }
+    std::call_once(e->once, [&]() {
+      int8_t mat[25];
+      MatRows m;
+      for (int r = 0; r < 5; ++r) m.row[r] = pl.mat_row[r];
+      unpack_mat(m, mat);
+      std::vector<int16_t> tmp(10 * (size_t)(pl.n_tasks > 0 ? pl.n_tasks : 1));
+      int64_t cells = 0;
+      if (orc_wire_extend((const uint8_t*)(uintptr_t)pl.wire, (size_t)1 << 40, mat, pl.zdrop, pl.zdrop_mode, tmp.data(), &cells) == pl.n_tasks) e->out.swap(tmp);
+    });
+    if (e->out.empty()) return;
+    int16_t* out = (int16_t*)(uintptr_t)pl.out;
+    for (int t = (int)unit * pl.per_unit; t < ((int)unit + 1) * pl.per_unit && t < pl.n_tasks; ++t)
+      for (int k = 0; k < 10; ++k) __atomic_store_n(out + (size_t)pl.out_stride * (size_t)t + k, e->out[10 * (size_t)t + k], __ATOMIC_RELAXED);
+  });
+}
+
+void launch_ref_fetch(const uint8_t*, long long, int, const long long*, const long long*, uint8_t*, size_t, const long long*, long long*, int* d_error, hipStream_t) {
+  if (d_error) *d_error = 1;
+}
+void launch_global_prepass(const GlobalJobsDev&, size_t, size_t, GlobalPrepass*, hipStream_t) {}
+hipError_t launch_global_kernel(const GlobalJobsDev&, const SwScoring&, int, size_t, int32_t*, int32_t*, uint32_t*, uint8_t*, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_reg2aln_kernel(const Reg2AlnDev&, const SwScoring&, int, int, int, size_t, Reg2AlnOut*, uint32_t*, uint8_t*, uint8_t*, int, hipStream_t) {
+  return hipErrorNotSupported;
+}
+hipError_t launch_chain2aln_kernel(const ChainBatchDev&, const ChainParams&, bpsw_alnreg_t*, int32_t*, int32_t*, int, int, int32_t*, hipStream_t) { return hipErrorNotSupported; }
+
+}  // namespace bpsw

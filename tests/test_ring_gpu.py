@@ -81,7 +81,7 @@ def test_32_threads_mixed_sizes_bit_exact(orc):
         try:
             c = bpsw_hip.Context(0)
             opt = bpsw_hip.default_opt()
-            for it in range(12):
+            for it in range(int(os.environ.get("BPSW_TEST_THREAD_ITERS", "12"))):   # (fewer under the thread sanitizer: tests/test_host_sanitizers.py)
                 k = (tid * 5 + it * 3) % (len(cases) + len(groups))
                 if k < len(cases):
                     jobs, want = cases[k]
