@@ -510,6 +510,33 @@ def tail_pool_rate(ctx, opt, topt, g, text_bytes, workers: int = 8, in_flight: i
             "note": "the calling thread enqueues and collects; plan, kernel and text run on the library's tail workers"}
 
 
+def host_cpu_sweep(fd, items, n_threads, local_rank, opt, mode, stage_commit, cpu_pool, counts, reads_per_step, passes, steps=3):
+    """The timed region once more with the feeder's threads confined to the first c CPUs of `cpu_pool`, c in `counts`: what the step
+    makes of fewer host CPUs per GPU -- the proxy for the 8-GPU node, where eight ranks share the node's cores and memory system and
+    the slope of the scaling curve is set by what a rank needs of them.  The same items, the same number of
+    threads (they block on the device most of the time), `steps` steps after one warm-up pass; the HIP runtime's own helper threads
+    are not confined.  Outside the timed region of `value`."""
+    out = {}
+    for c in counts:
+        if c > len(cpu_pool):
+            continue
+        F2 = fd.Feeder(n_threads, local_rank, opt, mode, cpus=cpu_pool[:c])
+        try:
+            if stage_commit:
+                F2.use_stage_commit(True)
+            F2.run(items, passes)          # warm-up: buffers grown, rings started
+            c0 = os.times()
+            t0 = time.perf_counter()
+            F2.run(items, steps * passes)
+            dt = time.perf_counter() - t0
+            c1 = os.times()
+            out[str(c)] = {"reads_per_s": round(reads_per_step * steps / dt, 1),
+                           "cpus_busy": round(((c1.user - c0.user) + (c1.system - c0.system)) / dt, 2)}
+        finally:
+            F2.close()
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: the N ranks as children of torch.distributed.run on 127.0.0.1 (this process never
     initialises the GPU; the children inherit stdout, so rank 0's JSON line is this command's line).  Returns the exit code."""
@@ -607,7 +634,10 @@ def main():
     share = numa_cpus if numa_cpus else allowed[(local_rank % ranks_on_node)::ranks_on_node] if distributed else allowed
     # 32: the device phases of the calls share a pool of 20 streams (bpsw_internal.h, StreamLease), and half as many threads
     # again keep it full while the others stage bytes or replay bookkeeping; more change nothing
-    n_threads = args.threads if args.threads > 0 else max(2, min(40, len(share)))
+    # (configs[2]: 48 -- forty-eight task threads keep a few more calls in flight while others stage or replay: 2.39-2.52 x 10^8 against 2.19-2.48
+    # with 40 over rounds 5-6, 14.5 of the 16 CPUs busy; 56 is another 1-2 % at 15.5 CPUs busy, too close to the quota.  The other workloads
+    # stay at 40: configs[1]'s forty-eight callers crowd the copy lane and the twenty streams (3.6 -> 2.6 x 10^8), configs[4] loses 6 %.)
+    n_threads = args.threads if args.threads > 0 else max(2, min(48 if args.config == 3 else 40, len(share)))
     if share and (numa_cpus or distributed):
         try:
             os.sched_setaffinity(0, share)   # before the inputs are generated: first touch puts them on the GPU's node
@@ -870,6 +900,19 @@ def main():
                 traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
                 extras["worker2_tail"] = {"error": repr(e)}
 
+    cpu_sweep = None
+    if rank == 0 and world == 1 and not args.no_extras and only == "" and args.config == 3:
+        pool = list(share) if share else sorted(allowed)
+        try:
+            cpu_sweep = host_cpu_sweep(fd, items, n_threads, local_rank, opt, bpsw_hip.RESCUE_C, ext_entry == "stage_commit", pool,
+                                       [c for c in (4, 8, 12, 16) if c <= len(pool)], reads_per_step, passes)
+            cpu_sweep["note"] = ("the timed region's items with the feeder threads confined (affinity) to the first c CPUs of this rank's share, 3 steps each, "
+                                 "outside the timed region of `value`; cpu_s_per_Mreads of the unconfined run says what a read costs, this says what the "
+                                 "step makes of a smaller share -- eight ranks on one node get (node CPUs / 8) each")
+        except Exception as e:  # noqa: BLE001
+            traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
+            cpu_sweep = {"error": repr(e)}
+
     out = {
         "metric": W["metric"],
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -927,7 +970,7 @@ def main():
                     "swalign2": {"avg_ms": round(sw_avg_ms, 4), "launches": sw_launches, "bytes_per_launch": int(sw_bytes),
                                  "jobs": int(st["sw_jobs"]), "replay_rounds": int(st["sw_replayed_rounds"]), "wasted_jobs": int(st["sw_wasted"]),
                                  "h2d_ms_avg": round(st["sw_h2d_ms"] / max(sw_launches, 1), 4), "d2h_ms_avg": round(st["sw_d2h_ms"] / max(sw_launches, 1), 4)}},
-        "host": {"cpus_busy": round(cpu_busy, 2), "cpu_quota": cpu_quota(), "call_ms": host_ms,
+        "host": {"cpus_busy": round(cpu_busy, 2), "cpu_quota": cpu_quota(), "call_ms": host_ms, "reads_per_s_vs_cpus": cpu_sweep,
                  # CPU time of the calling thread inside a call (CLOCK_THREAD_CPUTIME_ID around the last timed call on every item): what a
                  # read costs the executor's CPU quota on this path
                  "call_cpu_ms": {k: round(float(np.mean(v)), 4) if v else None for k, v in call_cpu_ms.items()},
