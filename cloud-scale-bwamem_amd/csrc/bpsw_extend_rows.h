@@ -560,6 +560,248 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
 // the m == 0 test, which only a row that did not improve needs; gscore / max_ie live in one key (H << 16 | i, signed max: a later
 // row wins a tie, SWUtil.scala:178-181); the zero test of the trimming is the SCC of the s_and_b64 that builds the mask.
 // 58 instructions on the common path (a row that improves, no zero cell in the band) against 87.
+
+// ---- how a fast row learns its maximum (round 6) -----------------------------------------------------------------------------
+// Rounds 3-5: a second wave-wide DPP scan beside the one F needs, on the key a << 7 | column (row maximum and its LAST column at lane
+// 63): a v_lshl_or, six half-rate DPP steps and a v_readlane per row.  But a row's maximum is only ever USED when (1) it beats the
+// call's maximum so far (SWUtil.scala:187-193), (2) the row did not and the z-drop has to be looked at (:194-199), or (3) the band has
+// a zero cell and the trimming starts from the maximum's column (:202-214).  And in case (1) the cell that beats the old maximum is
+// nearly always ALONE in its row (the diagonal's): then it IS the row's maximum and its last column -- one compare of the row against
+// the old maximum (a ballot), a population count, s_ff1 and a v_readlane find it without any scan.  In case (2) a stop needs
+// X + k zc1 > zlim with X = max - m and k = (i - max_i) - (mj - max_j) <= kmax = (i - max_i) - (beg - max_j): if ANY cell of the row
+// holds a >= max - zlim + max(kmax, 0) zc1, the row's maximum does too and no form of the test can fire (both parses: the detailed
+// tests only take more off X) -- one more compare instead of the scan; a row with no zero cell then needs nothing else.  Everything
+// else -- two cells beat the old maximum in one row, a zero cell in a row that did not improve, a row that may stop -- computes the key
+// scan after all, out of line (on the row's H, whose maximal cells are the maximal cells of a: F < max a), and goes through the
+// unchanged code of rounds 3-5.  The common one-column row loses eight vector instructions (six of them DPP) for two and gains five
+// scalar ones (58 -> 55 instructions); the two-column row ten vector for four, its new scalar work in the wait states the DPP steps need
+// anyway.  Measured (one MI355X, 24 contexts of 30 k-task batches, kernels alone): 2x250 bp at 8 % / 2 % 28.35 -> 27.42 ms per round
+// (-3.3 %), configs[4] 2.41 -> 2.53 x 10^7 reads/s; 2x150 bp at 1 % unchanged within the noise (2.28 ms) -- a row's time follows its
+// instruction COUNT (about 2.2 cycles each whatever the kind), and that fell by a twentieth, not by the fifth the vector
+// pipe's share of it did.  BPSW_ROWS_UNIQ=0 builds the old form (tools/build_variant.sh old -DBPSW_ROWS_UNIQ=0 for an A/B).
+#ifndef BPSW_ROWS_UNIQ
+#define BPSW_ROWS_UNIQ 1
+#endif
+#define ROWS_GSCAN_(V, NOP) \
+      "v_max_i32_dpp " V ", " V ", " V " row_shr:1 row_mask:0xf bank_mask:0xf\n\t" NOP \
+      "v_max_i32_dpp " V ", " V ", " V " row_shr:2 row_mask:0xf bank_mask:0xf\n\t" NOP \
+      "v_max_i32_dpp " V ", " V ", " V " row_shr:4 row_mask:0xf bank_mask:0xf\n\t" NOP \
+      "v_max_i32_dpp " V ", " V ", " V " row_shr:8 row_mask:0xf bank_mask:0xf\n\t" NOP \
+      "v_max_i32_dpp " V ", " V ", " V " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" NOP \
+      "v_max_i32_dpp " V ", " V ", " V " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+#if BPSW_ROWS_UNIQ
+#define ROWS1F_KEY_INIT \
+      "s_ashr_i32 %[m], %[mxhi], 7\n\t"  /* the call's maximum so far */ \
+      "v_cmp_lt_i32_e64 %[u64], %[m], %[vA]\n\t"  /* the cells that beat it */
+#define ROWS1F_SCANS \
+      ROWS_GSCAN_("%[vG]", "s_nop 1\n\t") \
+      "s_nop 1\n\t" \
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* exclusive prefix of g */
+#define ROWS1F_DECIDE(SFX) \
+      "s_cmp_lg_u64 %[u64], 0\n\t" \
+      "s_cbranch_scc0 L_fni" SFX "_%=\n\t"  /* no cell beats the maximum */ \
+      "s_bcnt1_i32_b64 %[h1], %[u64]\n\t" \
+      "s_cmp_eq_u32 %[h1], 1\n\t" \
+      "s_cbranch_scc0 L_fks" SFX "_%=\n\t"  /* several do: the key scan */ \
+      "s_ff1_i32_b64 %[mj], %[u64]\n\t"  /* the one cell that does: the row's maximum, and its only column */ \
+      "v_readlane_b32 %[h1], %[vA], %[mj]\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
+      "s_lshl_b32 %[h1], %[h1], 7\n\t" \
+      "s_or_b32 %[mxhi], %[h1], 127\n\t" \
+      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t"
+#define ROWS1F_OUTOFLINE(SFX) \
+      "L_fni" SFX "_%=:\n\t"  /* the row did not improve: can it stop, does the trimming need its maximum? */ \
+      "s_and_b64 %[z], vcc, %[act]\n\t" \
+      "s_cbranch_scc1 L_fks" SFX "_%=\n\t"  /* a zero cell: the trimming starts from the maximum's column */ \
+      "s_sub_i32 %[t1], %[i], %[maxi]\n\t" \
+      "s_sub_i32 %[t2], %[beg], %[maxj]\n\t" \
+      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* kmax */ \
+      "s_max_i32 %[t1], %[t1], 0\n\t" \
+      "s_mul_i32 %[t1], %[t1], %[zc1]\n\t" \
+      "s_add_i32 %[t1], %[t1], %[m]\n\t" \
+      "s_sub_i32 %[t1], %[t1], %[zlim]\n\t"  /* a cell this high rules every stop out */ \
+      "v_cmp_le_i32_e64 %[u64], %[t1], %[vA]\n\t" \
+      "s_cmp_lg_u64 %[u64], 0\n\t" \
+      "s_cbranch_scc1 L_fnz" SFX "_%=\n\t"  /* (no zero cell, no stop: the next row's band) */ \
+      "L_fks" SFX "_%=:\n\t"  /* the key scan after all, on H (vcc: its zero cells, as L_ftrim expects them) */ \
+      "v_lshl_or_b32 %[vK], %[vT0], 7, %[vLane]\n\t" \
+      "v_cmp_gt_i32 vcc, 1, %[vT0]\n\t" \
+      "v_cndmask_b32 %[vK], %[vNEG], %[vK], %[act]\n\t"  /* (H of a lane outside the band is whatever F left there) */ \
+      "s_nop 1\n\t" \
+      ROWS_GSCAN_("%[vK]", "s_nop 1\n\t") \
+      "s_nop 1\n\t" \
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
+      "s_cbranch_scc0 L_fnoimp" SFX "_%=\n\t" \
+      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
+      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t" \
+      "s_branch L_ftrim" SFX "_%=\n\t"
+#else
+#define ROWS1F_KEY_INIT \
+      "v_lshl_or_b32 %[vK], %[vA], 7, %[vLane]\n\t"  /* a << 7 | column */
+#define ROWS1F_SCANS \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "s_nop 1\n\t" \
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* exclusive prefix of g */ \
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t"
+#define ROWS1F_DECIDE(SFX) \
+      "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
+      "s_cbranch_scc0 L_fnoimp" SFX "_%=\n\t" \
+      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
+      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t"
+#define ROWS1F_OUTOFLINE(SFX)
+#endif
+
+// ---- the same for the two-column loop (ROWS2F_TEXT): the cells that beat the maximum so far are two ballots (even columns, odd columns);
+// their counts, and the column of the one cell when there is one, are scalar work that fills the wait states between the DPP steps of
+// the one scan that is left
+#if BPSW_ROWS_UNIQ
+#define ROWS2F_KEY_AND_SCANS(H1STEP) \
+      "s_ashr_i32 %[m], %[mxhi], 7\n\t"  /* the call's maximum so far */ \
+      "v_cmp_lt_i32_e64 %[u64], %[m], %[vA0]\n\t"  /* the even / odd cells that beat it */ \
+      "v_cmp_lt_i32 vcc, %[m], %[vA1]\n\t" \
+      "v_max_i32 %[vG], %[vG], %[vG0]\n\t"  /* the lane's two columns folded */ \
+      H1STEP \
+      "s_bcnt1_i32_b64 %[h1], %[u64]\n\t" \
+      "s_bcnt1_i32_b64 %[t], vcc\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_add_i32 %[h1], %[h1], %[t]\n\t"  /* how many */ \
+      "s_ff1_i32_b64 %[mj], %[u64]\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_ff1_i32_b64 %[t], vcc\n\t" \
+      "s_lshl_b32 %[mj], %[mj], 1\n\t"  /* column 2 lane of the first even one (< 0: none) */ \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_lshl_b32 %[t], %[t], 1\n\t" \
+      "s_or_b32 %[t], %[t], 1\n\t"  /* column 2 lane + 1 of the first odd one (< 0: none) */ \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_cmp_lt_i32 %[mj], 0\n\t" \
+      "s_cselect_b32 %[mj], %[t], %[mj]\n\t"  /* where there is exactly one: its column */ \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "s_nop 1\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "s_nop 1\n\t" \
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* prefix over the columns of the lanes below */
+#define ROWS2F_DECIDE(SFX) \
+      "s_cmp_eq_u32 %[h1], 1\n\t" \
+      "s_cbranch_scc0 L_g2nu" SFX "_%=\n\t"  /* none, or several */ \
+      "s_lshr_b32 %[t1], %[mj], 1\n\t" \
+      "v_readlane_b32 %[t2], %[vA0], %[t1]\n\t"  /* (H of that cell is its a: F is below the row's maximum) */ \
+      "v_readlane_b32 %[t4], %[vA1], %[t1]\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
+      "s_bitcmp1_b32 %[mj], 0\n\t" \
+      "s_cselect_b32 %[t2], %[t4], %[t2]\n\t" \
+      "s_lshl_b32 %[t2], %[t2], 7\n\t" \
+      "s_or_b32 %[mxhi], %[t2], 127\n\t" \
+      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t"
+#define ROWS2F_OUTOFLINE(SFX) \
+      "L_g2nu" SFX "_%=:\n\t" \
+      "s_cmp_eq_u32 %[h1], 0\n\t" \
+      "s_cbranch_scc0 L_g2ks" SFX "_%=\n\t"  /* several cells beat the maximum: the key scan */ \
+      "s_or_b64 %[u64], %[z0], %[z1]\n\t" \
+      "s_cbranch_scc1 L_g2ks" SFX "_%=\n\t"  /* not improved and a zero cell: the trimming starts from the maximum's column */ \
+      "s_sub_i32 %[t1], %[i], %[maxi]\n\t" \
+      "s_sub_i32 %[t2], %[beg], %[maxj]\n\t" \
+      "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* kmax */ \
+      "s_max_i32 %[t1], %[t1], 0\n\t" \
+      "s_mul_i32 %[t1], %[t1], %[zc1]\n\t" \
+      "s_add_i32 %[t1], %[t1], %[m]\n\t" \
+      "s_sub_i32 %[t1], %[t1], %[zlim]\n\t"  /* a cell this high rules every stop out (H of a lane outside the band is below the row's maximum) */ \
+      "v_cmp_le_i32_e64 %[u64], %[t1], %[vA0]\n\t" \
+      "v_cmp_le_i32 vcc, %[t1], %[vA1]\n\t" \
+      "s_or_b64 %[u64], %[u64], vcc\n\t" \
+      "s_cbranch_scc1 L_g2nz" SFX "_%=\n\t" \
+      "L_g2ks" SFX "_%=:\n\t"  /* the key scan after all, on H */ \
+      "v_lshl_or_b32 %[vK], %[vA0], 7, %[vL2]\n\t" \
+      "v_lshl_or_b32 %[vS0], %[vA1], 7, %[vL2p1]\n\t" \
+      "v_cndmask_b32 %[vK], %[vNEG], %[vK], %[act0]\n\t" \
+      "v_cndmask_b32 %[vS0], %[vNEG], %[vS0], %[act1]\n\t" \
+      "v_max_i32 %[vK], %[vK], %[vS0]\n\t" \
+      "s_nop 1\n\t" \
+      ROWS_GSCAN_("%[vK]", "s_nop 1\n\t") \
+      "s_nop 1\n\t" \
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
+      "s_cbranch_scc0 L_g2noimp" SFX "_%=\n\t" \
+      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
+      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t" \
+      "s_branch L_g2trim" SFX "_%=\n\t"
+#else
+#define ROWS2F_KEY_AND_SCANS(H1STEP) \
+      "v_lshl_or_b32 %[vK], %[vA0], 7, %[vL2]\n\t" \
+      "v_lshl_or_b32 %[vS0], %[vA1], 7, %[vL2p1]\n\t" \
+      "v_max_i32 %[vG], %[vG], %[vG0]\n\t"  /* the lane's two columns folded */ \
+      "v_max_i32 %[vK], %[vK], %[vS0]\n\t"  /* a << 7 | column: row maximum and its LAST column */ \
+      H1STEP \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+      "s_nop 0\n\t" \
+      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+      "s_nop 1\n\t" \
+      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* prefix over the columns of the lanes below */ \
+      "v_readlane_b32 %[mkey], %[vK], 63\n\t"
+#define ROWS2F_DECIDE(SFX) \
+      "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
+      "s_cbranch_scc0 L_g2noimp" SFX "_%=\n\t" \
+      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
+      "s_mov_b32 %[maxi], %[i]\n\t" \
+      "s_and_b32 %[mj], %[mkey], 127\n\t" \
+      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
+      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
+      "s_abs_i32 %[t1], %[t1]\n\t" \
+      "s_max_i32 %[moff], %[moff], %[t1]\n\t"
+#define ROWS2F_OUTOFLINE(SFX)
+#endif
 #define ROWSF_TAILTEST(SFX) \
       /* a row at or past the query end: tail_row_bound -- U = max(u0 - i eDel, qa); the call is over once U <= max and U < gscore */ \
       /* (in the loop's own forms: U << 7 | 127 <= mxhi; (U + 1) << 16 <= gskey) */ \
@@ -593,28 +835,9 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "v_max_i32 %[vA], %[vA], %[vE]\n\t" \
       "v_cndmask_b32 %[vA], %[vNEG], %[vA], %[act]\n\t"  /* a = max(H(i-1,j-1) + s, E) or "no cell" */ \
       "v_sub_u32 %[vG], %[vA], %[vNegC]\n\t"  /* g = a + j*eIns */ \
-      "v_lshl_or_b32 %[vK], %[vA], 7, %[vLane]\n\t"  /* a << 7 | column */ \
+      ROWS1F_KEY_INIT \
       H1STEP \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
-      "s_nop 1\n\t" \
-      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* exclusive prefix of g */ \
-      "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      ROWS1F_SCANS \
       "v_add3_u32 %[vS], %[vPp], %[vNegC], %[nkc]\n\t"  /* F = Pex - (j-1)*eIns - oeIns */ \
       HMAX  /* H */ \
       "v_cmp_gt_i32 vcc, 1, %[vT0]\n\t"  /* H == 0 */ \
@@ -631,18 +854,11 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "v_readlane_b32 %[t1], %[vS], %[t2]\n\t"  /* lane end - base: H(i, qLen-1) */ \
       "s_max_i32 %[gskey], %[gskey], %[t1]\n\t" \
       "L_fnogs" SFX "_%=:\n\t" \
-      "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
-      "s_cbranch_scc0 L_fnoimp" SFX "_%=\n\t" \
-      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
-      "s_mov_b32 %[maxi], %[i]\n\t" \
-      "s_and_b32 %[mj], %[mkey], 127\n\t" \
-      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
-      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
-      "s_abs_i32 %[t1], %[t1]\n\t" \
-      "s_max_i32 %[moff], %[moff], %[t1]\n\t" \
+      ROWS1F_DECIDE(SFX) \
       "L_ftrim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214 */ \
       "s_and_b64 %[z], vcc, %[act]\n\t"  /* the zero cells of the band; SCC = there are some */ \
       "s_cbranch_scc1 L_fzero" SFX "_%=\n\t" \
+      "L_fnz" SFX "_%=:\n\t" \
       NB0_NOZERO  /* beg, end and the band mask of the next row; falls through when the set-up has to run */ \
       "L_fnext" SFX "_%=:\n\t" \
       "s_add_i32 %[i], %[i], 1\n\t" \
@@ -722,6 +938,7 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "s_cmp_lt_i32 %[t2], 0\n\t" \
       "s_cselect_b32 %[end], %[t1], %[t4]\n\t" \
       "s_branch L_fnext" SFX "_%=\n\t" \
+      ROWS1F_OUTOFLINE(SFX) \
       "L_fnoimp" SFX "_%=:\n\t" \
       "s_cmp_lt_i32 %[mkey], 128\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t"  /* m == 0                                SWUtil.scala:184-185 */ \
@@ -1126,32 +1343,7 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
       "v_cndmask_b32 %[vA1], %[vNEG], %[vA1], %[act1]\n\t" \
       "v_sub_u32 %[vG0], %[vA0], %[vNegC]\n\t"  /* g of the even column */ \
       "v_sub_u32 %[vG], %[vA1], %[vNegC1]\n\t"  /* g of the odd column (vNegC1 = vNegC - eIns) */ \
-      "v_lshl_or_b32 %[vK], %[vA0], 7, %[vL2]\n\t" \
-      "v_lshl_or_b32 %[vS0], %[vA1], 7, %[vL2p1]\n\t" \
-      "v_max_i32 %[vG], %[vG], %[vG0]\n\t"  /* the lane's two columns folded */ \
-      "v_max_i32 %[vK], %[vK], %[vS0]\n\t"  /* a << 7 | column: row maximum and its LAST column */ \
-      H1STEP \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
-      "s_nop 0\n\t" \
-      "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
-      "v_max_i32_dpp %[vK], %[vK], %[vK] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
-      "s_nop 1\n\t" \
-      "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* prefix over the columns of the lanes below */ \
-      "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      ROWS2F_KEY_AND_SCANS(H1STEP) \
       "v_add3_u32 %[vS0], %[vPp], %[vNegC], %[nkc]\n\t"  /* F of the even column */ \
       "v_max_i32 %[vS1], %[vPp], %[vG0]\n\t" \
       "v_add3_u32 %[vS1], %[vS1], %[vNegC], %[nkc1]\n\t"  /* F of the odd column */ \
@@ -1185,18 +1377,11 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
       "v_readlane_b32 %[t1], %[vS0], %[gsl]\n\t" \
       "s_max_i32 %[gskey], %[gskey], %[t1]\n\t" \
       "L_g2nogs" SFX "_%=:\n\t" \
-      "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
-      "s_cbranch_scc0 L_g2noimp" SFX "_%=\n\t" \
-      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
-      "s_mov_b32 %[maxi], %[i]\n\t" \
-      "s_and_b32 %[mj], %[mkey], 127\n\t" \
-      "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
-      "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
-      "s_abs_i32 %[t1], %[t1]\n\t" \
-      "s_max_i32 %[moff], %[moff], %[t1]\n\t" \
+      ROWS2F_DECIDE(SFX) \
       "L_g2trim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214 */ \
       "s_or_b64 %[u64], %[z0], %[z1]\n\t"  /* SCC = the band has a zero cell */ \
       "s_cbranch_scc1 L_g2zero" SFX "_%=\n\t" \
+      "L_g2nz" SFX "_%=:\n\t" \
       NB0_NOZERO \
       SAME_BAND \
       "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
@@ -1316,6 +1501,7 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
       "s_cmp_lt_i32 %[m], 0x100000\n\t" \
       "s_cselect_b32 %[end], %[t1], %[t2]\n\t"  /* end = base + cr + 1, or min(end + 1, qLen) */ \
       "s_branch L_g2next" SFX "_%=\n\t" \
+      ROWS2F_OUTOFLINE(SFX) \
       "L_g2noimp" SFX "_%=:\n\t" \
       "s_cmp_lt_i32 %[mkey], 128\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t"  /* m == 0                                SWUtil.scala:184-185 */ \
