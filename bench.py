@@ -483,7 +483,7 @@ def tail_pool_rate(ctx, opt, topt, g, text_bytes, workers: int = 8, in_flight: i
     bufs = [np.empty(cap, np.uint8) for _ in range(in_flight)]
     offs = [np.zeros(2 * g.group_size + 1, np.int64) for _ in range(in_flight)]
     pool, need = C.c_void_p(), C.c_size_t(0)
-    rc = lib.bpsw_tail_pool_create(0, workers, C.byref(pool))
+    rc = lib.bpsw_tail_pool_create(lib.bpsw_device_of(ctx.h), workers, C.byref(pool))   # (the rank's device, not device 0: advisor, round 5)
     if rc != 0:
         return {"error": lib.bpsw_last_error().decode()}
     tick = [0] * in_flight

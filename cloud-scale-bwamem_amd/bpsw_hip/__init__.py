@@ -44,6 +44,7 @@ JNI_SYMBOLS = [
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailJNI",
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailSubmitJNI",   # the same call in two halves (bpsw_tail_pool_*, round 5)
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailCollectJNI",
+    "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailCancelJNI",    # drop a handle that will not be collected (round 6)
     "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_mateSWFlatJNI",         # boundary 1 with primitive arrays (round 4)
 ]
 

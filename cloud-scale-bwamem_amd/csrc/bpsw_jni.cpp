@@ -1345,4 +1345,28 @@ JNIEXPORT jbyteArray JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailCo
   }
 }
 
+// A handle that will not be collected (the Spark task failed or was killed between submit and collect): wait for the group's ticket -- a
+// tail worker may still be writing into the handle's buffers -- and drop it.  Call it from the `finally` of the code that holds handles;
+// without it the whole TailCall (reads, qualities, names, regions, text: several MB per group) and the pool's job entry stay for the life
+// of the executor JVM (advisor, round 5).  Unknown handles (collected already, never issued) are ignored; returns 1 when one was dropped.
+//   @native def samPeTailCancelJNI(handle: Long): Int
+JNIEXPORT jint JNICALL Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailCancelJNI(JNIEnv* env, jobject, jlong handle) {
+  try {
+  std::unique_ptr<TailCall> tc;
+  {
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    auto it = g_tail_calls.find((int64_t)handle);
+    if (it == g_tail_calls.end()) return 0;
+    tc = std::move(it->second);
+    g_tail_calls.erase(it);
+  }
+  size_t need = 0;
+  (void)bpsw_tail_pool_wait(tc->pool, tc->ticket, &need, nullptr);  // (whatever it returns: the worker is done with the buffers afterwards)
+  return 1;
+  } catch (const std::exception& e) {
+    throw_runtime(env, std::string("bPSW: samPeTailCancelJNI: ") + e.what());
+    return 0;
+  }
+}
+
 }  // extern "C"

@@ -578,6 +578,23 @@ static int sam_pe_tail_impl(const char* lib, int partition, const uint8_t* pac, 
     (void)col(&e.env, J(self), handles[0], (jlongArray)J(off));
     if (!vm.pending) { snprintf(err, (size_t)errcap, "a second collect of a handle did not throw"); return -1; }
     vm.pending = false;
+    // a handle that will never be collected (a failed task): samPeTailCancelJNI waits for its group and drops it -- 1 the first time,
+    // 0 for a handle that is gone (cancelled or collected), and a collect of it throws like any unknown handle
+    typedef jint (*CanFn)(JNIEnv*, jobject, jlong);
+    CanFn can = (CanFn)load_symbol(lib, "Java_cs_ucla_edu_bwaspark_jni_MateSWJNI_samPeTailCancelJNI", err, (size_t)errcap);
+    if (!can) return -1;
+    const jlong hx = sub(&e.env, J(self), (jintArray)J(int_array(opt_ints, 12)), (jdoubleArray)J(double_array(reals, 22)),
+                         (jbyteArray)J(byte_array(reinterpret_cast<const uint8_t*>(mat), 25)), (jlong)id0, (jintArray)J(int_array(read_len, (size_t)n2)),
+                         (jbyteArray)J(byte_array(reads, (size_t)reads_bytes)), quals ? (jbyteArray)J(byte_array(quals, (size_t)reads_bytes)) : nullptr,
+                         (jintArray)J(int_array(name_len, (size_t)(n2 / 2))), (jbyteArray)J(byte_array(names, (size_t)names_bytes)),
+                         (jintArray)J(int_array(reg_cnt, (size_t)n2)), (jlongArray)J(long_array(reg_longs, (size_t)(2 * n_regs))),
+                         (jintArray)J(int_array(reg_ints, (size_t)(10 * n_regs))));
+    if (vm.pending || hx == 0) { snprintf(err, (size_t)errcap, "submit before cancel: %s", vm.pending_msg.c_str()); return 1; }
+    if (can(&e.env, J(self), hx) != 1 || vm.pending) { snprintf(err, (size_t)errcap, "cancel of a live handle did not return 1"); return -1; }
+    if (can(&e.env, J(self), hx) != 0 || can(&e.env, J(self), handles[0]) != 0 || vm.pending) { snprintf(err, (size_t)errcap, "cancel of a gone handle did not return 0"); return -1; }
+    (void)col(&e.env, J(self), hx, (jlongArray)J(off));
+    if (!vm.pending) { snprintf(err, (size_t)errcap, "a collect of a cancelled handle did not throw"); return -1; }
+    vm.pending = false;
     return 0;
   }
   jbyteArray r = fn(&e.env, J(self), (jintArray)J(int_array(opt_ints, 12)), (jdoubleArray)J(double_array(reals, 22)),
