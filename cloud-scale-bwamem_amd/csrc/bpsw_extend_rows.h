@@ -590,25 +590,32 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "v_max_i32_dpp " V ", " V ", " V " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" NOP \
       "v_max_i32_dpp " V ", " V ", " V " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
 #if BPSW_ROWS_UNIQ
+// (the maximum so far lives in its plain form, mx -- one v_readlane gives the new one; its key form mxhi = mx << 7 | 127 is made where the
+// key scan's result is compared with it)
+#define ROWSF_TAIL_CMP_MAX "s_cmp_le_i32 %[t1], %[mx]\n\t"
+#define ROWSF_MX_FROM_KEY
+#define ROWSF_MX_OUT(s_mx, s_mxhi) (s_mx)
+#else
+#define ROWSF_TAIL_CMP_MAX "s_lshl_b32 %[t2], %[t1], 7\n\ts_or_b32 %[t2], %[t2], 127\n\ts_cmp_le_i32 %[t2], %[mxhi]\n\t"
+#define ROWSF_MX_FROM_KEY "s_lshr_b32 %[mx], %[mxhi], 7\n\t"
+#define ROWSF_MX_OUT(s_mx, s_mxhi) ((s_mxhi) >> 7)
+#endif
+#if BPSW_ROWS_UNIQ
 #define ROWS1F_KEY_INIT \
-      "s_ashr_i32 %[m], %[mxhi], 7\n\t"  /* the call's maximum so far */ \
-      "v_cmp_lt_i32_e64 %[u64], %[m], %[vA]\n\t"  /* the cells that beat it */
+      "v_cmp_lt_i32_e64 %[u64], %[mx], %[vA]\n\t"  /* the cells that beat the call's maximum so far (mx: its plain form is the state here) */
 #define ROWS1F_SCANS \
       ROWS_GSCAN_("%[vG]", "s_nop 1\n\t") \
       "s_nop 1\n\t" \
       "v_mov_b32_dpp %[vPp], %[vG] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"  /* exclusive prefix of g */
 #define ROWS1F_DECIDE(SFX) \
-      "s_cmp_lg_u64 %[u64], 0\n\t" \
+      "s_bcnt1_i32_b64 %[h1], %[u64]\n\t"  /* SCC = some cell does */ \
       "s_cbranch_scc0 L_fni" SFX "_%=\n\t"  /* no cell beats the maximum */ \
-      "s_bcnt1_i32_b64 %[h1], %[u64]\n\t" \
       "s_cmp_eq_u32 %[h1], 1\n\t" \
       "s_cbranch_scc0 L_fks" SFX "_%=\n\t"  /* several do: the key scan */ \
       "s_ff1_i32_b64 %[mj], %[u64]\n\t"  /* the one cell that does: the row's maximum, and its only column */ \
-      "v_readlane_b32 %[h1], %[vA], %[mj]\n\t" \
+      "v_readlane_b32 %[mx], %[vA], %[mj]\n\t" \
       "s_mov_b32 %[maxi], %[i]\n\t" \
       "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
-      "s_lshl_b32 %[h1], %[h1], 7\n\t" \
-      "s_or_b32 %[mxhi], %[h1], 127\n\t" \
       "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
       "s_abs_i32 %[t1], %[t1]\n\t" \
       "s_max_i32 %[moff], %[moff], %[t1]\n\t"
@@ -621,7 +628,7 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* kmax */ \
       "s_max_i32 %[t1], %[t1], 0\n\t" \
       "s_mul_i32 %[t1], %[t1], %[zc1]\n\t" \
-      "s_add_i32 %[t1], %[t1], %[m]\n\t" \
+      "s_add_i32 %[t1], %[t1], %[mx]\n\t" \
       "s_sub_i32 %[t1], %[t1], %[zlim]\n\t"  /* a cell this high rules every stop out */ \
       "v_cmp_le_i32_e64 %[u64], %[t1], %[vA]\n\t" \
       "s_cmp_lg_u64 %[u64], 0\n\t" \
@@ -634,9 +641,11 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       ROWS_GSCAN_("%[vK]", "s_nop 1\n\t") \
       "s_nop 1\n\t" \
       "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      "s_lshl_b32 %[mxhi], %[mx], 7\n\t"  /* (the key form of the maximum: only this path and L_fnoimp behind it read it) */ \
+      "s_or_b32 %[mxhi], %[mxhi], 127\n\t" \
       "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
       "s_cbranch_scc0 L_fnoimp" SFX "_%=\n\t" \
-      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
+      "s_lshr_b32 %[mx], %[mkey], 7\n\t" \
       "s_mov_b32 %[maxi], %[i]\n\t" \
       "s_and_b32 %[mj], %[mkey], 127\n\t" \
       "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
@@ -686,25 +695,23 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
 // the one scan that is left
 #if BPSW_ROWS_UNIQ
 #define ROWS2F_KEY_AND_SCANS(H1STEP) \
-      "s_ashr_i32 %[m], %[mxhi], 7\n\t"  /* the call's maximum so far */ \
-      "v_cmp_lt_i32_e64 %[u64], %[m], %[vA0]\n\t"  /* the even / odd cells that beat it */ \
-      "v_cmp_lt_i32 vcc, %[m], %[vA1]\n\t" \
+      "v_cmp_lt_i32_e64 %[u64], %[mx], %[vA0]\n\t"  /* the even / odd cells that beat the call's maximum so far */ \
+      "v_cmp_lt_i32 vcc, %[mx], %[vA1]\n\t" \
       "v_max_i32 %[vG], %[vG], %[vG0]\n\t"  /* the lane's two columns folded */ \
       H1STEP \
-      "s_bcnt1_i32_b64 %[h1], %[u64]\n\t" \
-      "s_bcnt1_i32_b64 %[t], vcc\n\t" \
+      "s_or_b64 %[z0], %[u64], vcc\n\t"  /* (z0, z1: free until the zero masks are taken) */ \
+      "s_bcnt1_i32_b64 %[h1], %[z0]\n\t"  /* lanes with such a cell */ \
       "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_add_i32 %[h1], %[h1], %[t]\n\t"  /* how many */ \
-      "s_ff1_i32_b64 %[mj], %[u64]\n\t" \
+      "s_and_b64 %[z1], %[u64], vcc\n\t"  /* SCC = a lane whose two cells both do */ \
+      "s_addc_u32 %[h1], %[h1], 0\n\t"  /* 1 exactly when ONE cell of the row does */ \
       "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_ff1_i32_b64 %[t], vcc\n\t" \
-      "s_lshl_b32 %[mj], %[mj], 1\n\t"  /* column 2 lane of the first even one (< 0: none) */ \
+      "s_ff1_i32_b64 %[mj], %[z0]\n\t" \
+      "s_lshl_b32 %[mj], %[mj], 1\n\t" \
       "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_lshl_b32 %[t], %[t], 1\n\t" \
-      "s_or_b32 %[t], %[t], 1\n\t"  /* column 2 lane + 1 of the first odd one (< 0: none) */ \
+      "s_cmp_lg_u64 vcc, 0\n\t" \
+      "s_addc_u32 %[mj], %[mj], 0\n\t"  /* then its column: 2 lane, + 1 when it is the odd one */ \
       "v_max_i32_dpp %[vG], %[vG], %[vG] row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
-      "s_cmp_lt_i32 %[mj], 0\n\t" \
-      "s_cselect_b32 %[mj], %[t], %[mj]\n\t"  /* where there is exactly one: its column */ \
+      "s_nop 1\n\t" \
       "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
       "s_nop 1\n\t" \
       "v_max_i32_dpp %[vG], %[vG], %[vG] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
@@ -713,15 +720,11 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
 #define ROWS2F_DECIDE(SFX) \
       "s_cmp_eq_u32 %[h1], 1\n\t" \
       "s_cbranch_scc0 L_g2nu" SFX "_%=\n\t"  /* none, or several */ \
+      "v_max_i32 %[vS0], %[vA0], %[vA1]\n\t"  /* (the one cell is the row's maximum, so also its lane's; H of that cell is its a: F is below the maximum) */ \
       "s_lshr_b32 %[t1], %[mj], 1\n\t" \
-      "v_readlane_b32 %[t2], %[vA0], %[t1]\n\t"  /* (H of that cell is its a: F is below the row's maximum) */ \
-      "v_readlane_b32 %[t4], %[vA1], %[t1]\n\t" \
       "s_mov_b32 %[maxi], %[i]\n\t" \
+      "v_readlane_b32 %[mx], %[vS0], %[t1]\n\t" \
       "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
-      "s_bitcmp1_b32 %[mj], 0\n\t" \
-      "s_cselect_b32 %[t2], %[t4], %[t2]\n\t" \
-      "s_lshl_b32 %[t2], %[t2], 7\n\t" \
-      "s_or_b32 %[mxhi], %[t2], 127\n\t" \
       "s_sub_i32 %[t1], %[maxj], %[i]\n\t" \
       "s_abs_i32 %[t1], %[t1]\n\t" \
       "s_max_i32 %[moff], %[moff], %[t1]\n\t"
@@ -736,7 +739,7 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "s_sub_i32 %[t1], %[t1], %[t2]\n\t"  /* kmax */ \
       "s_max_i32 %[t1], %[t1], 0\n\t" \
       "s_mul_i32 %[t1], %[t1], %[zc1]\n\t" \
-      "s_add_i32 %[t1], %[t1], %[m]\n\t" \
+      "s_add_i32 %[t1], %[t1], %[mx]\n\t" \
       "s_sub_i32 %[t1], %[t1], %[zlim]\n\t"  /* a cell this high rules every stop out (H of a lane outside the band is below the row's maximum) */ \
       "v_cmp_le_i32_e64 %[u64], %[t1], %[vA0]\n\t" \
       "v_cmp_le_i32 vcc, %[t1], %[vA1]\n\t" \
@@ -752,9 +755,11 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       ROWS_GSCAN_("%[vK]", "s_nop 1\n\t") \
       "s_nop 1\n\t" \
       "v_readlane_b32 %[mkey], %[vK], 63\n\t" \
+      "s_lshl_b32 %[mxhi], %[mx], 7\n\t" \
+      "s_or_b32 %[mxhi], %[mxhi], 127\n\t" \
       "s_cmp_gt_i32 %[mkey], %[mxhi]\n\t"  /* m > max                              SWUtil.scala:187-193 */ \
       "s_cbranch_scc0 L_g2noimp" SFX "_%=\n\t" \
-      "s_or_b32 %[mxhi], %[mkey], 127\n\t" \
+      "s_lshr_b32 %[mx], %[mkey], 7\n\t" \
       "s_mov_b32 %[maxi], %[i]\n\t" \
       "s_and_b32 %[mj], %[mkey], 127\n\t" \
       "s_add_i32 %[maxj], %[mj], %[base]\n\t" \
@@ -808,9 +813,7 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "s_mul_i32 %[t1], %[i], %[edel]\n\t" \
       "s_sub_i32 %[t1], %[u0], %[t1]\n\t" \
       "s_max_i32 %[t1], %[t1], %[qa]\n\t" \
-      "s_lshl_b32 %[t2], %[t1], 7\n\t" \
-      "s_or_b32 %[t2], %[t2], 127\n\t" \
-      "s_cmp_le_i32 %[t2], %[mxhi]\n\t" \
+      ROWSF_TAIL_CMP_MAX \
       "s_cbranch_scc0 L_ttgo" SFX "_%=\n\t" \
       "s_add_i32 %[t1], %[t1], 1\n\t" \
       "s_lshl_b32 %[t1], %[t1], 16\n\t" \
@@ -1033,13 +1036,13 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "s_branch L_end_%=\n\t" \
       ROWS1F_ALL \
       "L_ftotail_%=:\n\t"  /* the rows at and past the query end: the general loop with the tail-row test, in its own form of the state */ \
-      "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
+      ROWSF_MX_FROM_KEY \
       "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
       "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
       "s_mov_b32 %[form], 0\n\t" \
       "s_branch L_row_t_%=\n\t" \
       "L_ftogen_%=:\n\t"  /* the left clamp may bind from here on: the general loop */ \
-      "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
+      ROWSF_MX_FROM_KEY \
       "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
       "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
       "s_mov_b32 %[form], 0\n\t" \
@@ -1100,7 +1103,7 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
   st.H0 = vH; st.E0 = vE; st.plo0 = vP; st.base = s_base;
   st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.max_i = s_maxi; st.max_j = s_maxj; st.max_off = s_moff;
   if (s_form) {  // the statement ended in the fast loop: its forms of max and (gscore, max_ie)
-    st.mx = s_mxhi >> 7; st.gscore = s_gskey >> 16; st.max_ie = (int)(short)(s_gskey & 0xffff);
+    st.mx = ROWSF_MX_OUT(s_mx, s_mxhi); st.gscore = s_gskey >> 16; st.max_ie = (int)(short)(s_gskey & 0xffff);
   } else {
     st.mx = s_mx; st.max_ie = s_maxie; st.gscore = s_gs;
   }
@@ -1584,13 +1587,13 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
       "s_branch L_end_%=\n\t" \
       ROWS2F_ALL \
       "L_ftotail_%=:\n\t"  /* the rows at and past the query end: the general loop with the tail-row test, in its own form of the state */ \
-      "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
+      ROWSF_MX_FROM_KEY \
       "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
       "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
       "s_mov_b32 %[form], 0\n\t" \
       "s_branch L_row_t_%=\n\t" \
       "L_ftogen_%=:\n\t"  /* the left clamp may bind from here on: the general loop */ \
-      "s_lshr_b32 %[mx], %[mxhi], 7\n\t" \
+      ROWSF_MX_FROM_KEY \
       "s_ashr_i32 %[gs], %[gskey], 16\n\t" \
       "s_sext_i32_i16 %[maxie], %[gskey]\n\t" \
       "s_mov_b32 %[form], 0\n\t" \
@@ -1649,7 +1652,7 @@ __device__ __forceinline__ int rows2_asm(RowState& st, const int lane_arg, const
   st.H0 = vH0; st.E0 = vE0; st.H1 = vH1; st.E1 = vE1; st.plo0 = vP0; st.plo1 = vP1; st.base = s_base;
   st.i = s_i; st.beg = s_beg; st.end = s_end; st.h1raw = s_h1raw; st.max_i = s_maxi; st.max_j = s_maxj; st.max_off = s_moff;
   if (s_form) {
-    st.mx = s_mxhi >> 7; st.gscore = s_gskey >> 16; st.max_ie = (int)(short)(s_gskey & 0xffff);
+    st.mx = ROWSF_MX_OUT(s_mx, s_mxhi); st.gscore = s_gskey >> 16; st.max_ie = (int)(short)(s_gskey & 0xffff);
   } else {
     st.mx = s_mx; st.max_ie = s_maxie; st.gscore = s_gs;
   }
