@@ -47,7 +47,7 @@ PAIRS_PER_GROUP = int(os.environ.get("BENCH_GROUP_PAIRS", "4096"))   # boundary-
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT_VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9   # MI355X_MICROARCH.md ("Terms", "Wave scheduling", cycles table): 256 CUs x 4 SIMD-32 x 2.4 GHz --
                                             # a wave64 VALU instruction issues over 2 cycles, 7.86e13 int32 lane-ops/s
-PROFILE_TAG = "r05"              # the committed rocprofv3 summaries this round's line is cross-checked against (profiles/r04_*)
+PROFILE_TAG = "r06"              # the committed rocprofv3 summaries this round's line is cross-checked against (profiles/r06_*)
 PROTOCOL = "r03b"                # what a step IS: changes whenever values stop being comparable with earlier rounds (see `protocol` in the line)
 
 # SURVEY.md 8(d) workloads, keyed by the survey's config number
