@@ -67,9 +67,9 @@ void orc_sw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
   int beg = 0, end = qlen;
   int stop = 0;
 
-  ++g_ext_calls;
+  __atomic_fetch_add(&g_ext_calls, 1, __ATOMIC_RELAXED); /* (diagnostic counters: relaxed atomics, the oracle is called from many threads in tests/host_san) */
   for (i = 0; i < tlen && !stop; ++i) { /* SW:129-220 */
-    ++g_ext_rows;
+    __atomic_fetch_add(&g_ext_rows, 1, __ATOMIC_RELAXED);
     int t, f = 0, h1, mm = 0, mj = -1;
     const int8_t *q = qp + (size_t)target[i] * qlen;
     h1 = h0 - (o_del + e_del * (i + 1)); /* SW:137-138 */
@@ -98,7 +98,7 @@ void orc_sw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
     }
     eh_h[end] = h1; /* SW:174-175 */
     eh_e[end] = 0;
-    { const int wd = end - beg + 1; ++g_ext_width_hist[wd < 0 ? 0 : (wd >= 256 ? 32 : wd >> 3)]; }
+    { const int wd = end - beg + 1; __atomic_fetch_add(&g_ext_width_hist[wd < 0 ? 0 : (wd >= 256 ? 32 : wd >> 3)], 1, __ATOMIC_RELAXED); }
     if (j == qlen) { /* SW:177-182; j == max(beg,end) after the loop */
       if (gscore <= h1) { max_ie = i; gscore = h1; }
     }

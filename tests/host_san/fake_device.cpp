@@ -10,8 +10,9 @@
 //     this build checks is not the kernels (the GPU suite does that) but everything around them -- the JNI marshalling, the rescue
 //     planner's speculation and replay with its hand-placed prefetches, the packers, the staging arithmetic, the rings' host half, the
 //     tail pool's hand-offs -- for out-of-bounds accesses, use after free, undefined behaviour and data races.
-//   * what is not played (coordinate batches, the reference on the device, SWGlobal / reg2aln / chain2aln kernels) fails loudly with
-//     hipErrorNotSupported: the tests that need it are left out of the sanitizer run (tests/test_host_sanitizers.py names them).
+//   * memRegToAln jobs are orc_reg2aln, a chain batch orc_chain2aln_batch, a reference fetch orc_bns_get_seq: worker2's tail (plan, emit,
+//     the tail pool's threads) and the round-loop entry run too.  What is not played (coordinate batches of the extension, SWGlobal) fails
+//     loudly with hipErrorNotSupported: the tests that need it are left out of the sanitizer run (tests/test_host_sanitizers.py names them).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -301,14 +302,68 @@ hipError_t launch_ext_resident(const RingArgs& A, int, hipStream_t s) {
   });
 }
 
-void launch_ref_fetch(const uint8_t*, long long, int, const long long*, const long long*, uint8_t*, size_t, const long long*, long long*, int* d_error, hipStream_t) {
-  if (d_error) *d_error = 1;
+void launch_ref_fetch(const uint8_t* pac, long long l_pac, int n, const long long* beg, const long long* end, uint8_t* out_pool, size_t out_pool_bytes, const long long* out_off,
+                      long long* out_len, int* d_error, hipStream_t) {  // bnsGetSeq per window (util/BNTSeqUtil.scala:37-79)
+  for (int i = 0; i < n; ++i) {
+    const long long room = i + 1 < n ? out_off[i + 1] - out_off[i] : (long long)out_pool_bytes - out_off[i];
+    const long long got = orc_bns_get_seq(l_pac, pac, beg[i], end[i], out_pool + out_off[i], room);
+    if (got < 0) { if (d_error) *d_error = 1; out_len[i] = 0; } else out_len[i] = got;
+  }
 }
 void launch_global_prepass(const GlobalJobsDev&, size_t, size_t, GlobalPrepass*, hipStream_t) {}
 hipError_t launch_global_kernel(const GlobalJobsDev&, const SwScoring&, int, size_t, int32_t*, int32_t*, uint32_t*, uint8_t*, int, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_reg2aln_kernel(const Reg2AlnDev&, const SwScoring&, int, int, int, size_t, Reg2AlnOut*, uint32_t*, uint8_t*, uint8_t*, int, hipStream_t) {
-  return hipErrorNotSupported;
+// memRegToAln per job through the oracle (bpsw_reg2aln.hip: what the kernel leaves of a mem_aln_t, its CIGAR and its MD; counts are the
+// true ones also when they outgrow the job's room -- the host resubmits with more)
+hipError_t launch_reg2aln_kernel(const Reg2AlnDev& J, const SwScoring& sc, int, int, int, size_t, Reg2AlnOut* out, uint32_t* out_cigar, uint8_t* out_md, uint8_t*, int,
+                                 hipStream_t) {
+  orc_opt_t o;
+  orc_opt_default(&o);
+  o.a = J.a; o.b = sc.b; o.o_del = sc.o_del; o.e_del = sc.e_del; o.o_ins = sc.o_ins; o.e_ins = sc.e_ins; o.w = J.opt_w;
+  unpack_mat(sc.mat, o.mat);
+  orc_tail_opt_t t;
+  orc_tail_opt_default(&t);
+  std::vector<uint32_t> cig(1 << 14);
+  std::vector<char> md(1 << 17);
+  for (int j = 0; j < J.n; ++j) {
+    orc_alnreg_t ar;
+    static_assert(sizeof(orc_alnreg_t) == sizeof(bpsw_alnreg_t), "region record layouts");
+    memcpy(&ar, J.regs + j, sizeof ar);
+    orc_aln_t a;
+    orc_reg2aln(&o, &t, J.n_seqs, (const int64_t*)J.ann_off, J.ann_len, J.l_pac, J.pac, J.read_len[j], J.read_pool + J.read_off[j], &ar, J.flavour, &a, cig.data(),
+                (int)cig.size(), md.data(), (int)md.size());
+    Reg2AlnOut k;
+    memset(&k, 0, sizeof k);
+    k.pos = a.pos; k.rid = a.rid; k.is_rev = a.is_rev; k.NM = a.NM; k.n_cigar = a.n_cigar; k.md_len = a.md_len; k.status = a.status;
+    if (a.status == 1) { k.pos = -1; k.rid = -1; k.is_rev = 0; k.NM = 0; k.n_cigar = 0; k.md_len = 0; }  // BPSW_ALN_XREF: as the kernel leaves it
+    out[j] = k;
+    if (k.n_cigar <= J.max_cigar) memcpy(out_cigar + (size_t)j * (size_t)J.max_cigar, cig.data(), 4 * (size_t)(k.n_cigar > 0 ? k.n_cigar : 0));
+    memcpy(out_md + (size_t)j * (size_t)J.max_md, md.data(), (size_t)(k.md_len < J.max_md ? (k.md_len > 0 ? k.md_len : 0) : J.max_md));
+  }
+  return hipSuccess;
 }
-hipError_t launch_chain2aln_kernel(const ChainBatchDev&, const ChainParams&, bpsw_alnreg_t*, int32_t*, int32_t*, int, int, int32_t*, hipStream_t) { return hipErrorNotSupported; }
+// memChainToAlnBatched through the oracle: regions of read r in creation order from slot reg_base[r] on
+hipError_t launch_chain2aln_kernel(const ChainBatchDev& B, const ChainParams& P, bpsw_alnreg_t* out_regs, int32_t* out_cnt, int32_t*, int, int, int32_t*, hipStream_t) {
+  orc_opt_t o;
+  orc_opt_default(&o);
+  o.a = P.a; o.o_del = P.o_del; o.e_del = P.e_del; o.o_ins = P.o_ins; o.e_ins = P.e_ins; o.pen_clip5 = P.pen_clip5; o.pen_clip3 = P.pen_clip3;
+  o.w = P.w; o.zdrop = P.zdrop;
+  unpack_mat(P.mat, o.mat);
+  long long seeds = 0, chains = 0;
+  for (int r = 0; r < B.n_reads; ++r) chains += B.chain_cnt[r];
+  for (long long c = 0; c < chains; ++c) seeds += B.seed_cnt[c];
+  std::vector<orc_alnreg_t> regs((size_t)seeds + 16);
+  std::vector<int32_t> cnt((size_t)(B.n_reads > 0 ? B.n_reads : 1));
+  int64_t n_ext = 0, cells = 0;
+  const int64_t tot = orc_chain2aln_batch(&o, P.zmode, B.l_pac, B.pac, B.n_reads, B.read_len, (const int64_t*)B.read_off, B.read_pool, B.chain_cnt, B.seed_cnt,
+                                          (const int64_t*)B.seed_rbeg, B.seed_qbeg, B.seed_len, cnt.data(), regs.data(), (int64_t)regs.size(), &n_ext, &cells);
+  if (tot < 0) return hipErrorInvalidValue;
+  size_t at = 0;
+  for (int r = 0; r < B.n_reads; ++r) {
+    out_cnt[r] = cnt[(size_t)r];
+    memcpy(out_regs + B.reg_base[r], regs.data() + at, sizeof(orc_alnreg_t) * (size_t)cnt[(size_t)r]);
+    at += (size_t)cnt[(size_t)r];
+  }
+  return hipSuccess;
+}
 
 }  // namespace bpsw
