@@ -596,6 +596,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tail", action="store_true", help="skip the worker2-tail breakdown entry")
     ap.add_argument("--no-extras", action="store_true", help="skip every breakdown outside the timed region")
+    ap.add_argument("--cpu-sweep", action="store_true",
+                    help="after the timed region, run its items again with the feeder confined to 4 / 8 / 12 / 16 CPUs (host.reads_per_s_vs_cpus measured live; "
+                         "without it the line carries the committed sweep of profiles/<tag>_cpu_sweep.json, labelled as such)")
     args = ap.parse_args()
     W = dict(WORKLOADS[args.config])
     shrink = max(1, int(os.environ.get("BENCH_SHRINK", "1")))   # rehearsals (tests): 1/k of the batches, groups and passes; the line says so and is not the metric
@@ -900,8 +903,15 @@ def main():
                 traceback.print_exc(file=sys.stderr)   # (recorded in the line as {"error": ...} AND shown: nothing is swallowed)
                 extras["worker2_tail"] = {"error": repr(e)}
 
+    # (not part of the default command: its sixteen thousand extra launches under a lighter load would sit in the kernel trace of the
+    # command beside the timed region's and pull the trace's per-kernel averages away from the line's own)
     cpu_sweep = None
-    if rank == 0 and world == 1 and not args.no_extras and only == "" and args.config == 3:
+    if rank == 0 and world == 1 and args.config == 3 and not args.cpu_sweep:
+        committed = load_committed_json(f"{PROFILE_TAG}_cpu_sweep.json")
+        if committed:
+            cpu_sweep = dict(committed.get("reads_per_s_vs_cpus", {}), unconfined=committed.get("unconfined"),
+                             source=f"COMMITTED profiles/{PROFILE_TAG}_cpu_sweep.json (python bench.py --cpu-sweep), not measured in this run")
+    if rank == 0 and world == 1 and args.cpu_sweep and only == "" and args.config == 3:
         pool = list(share) if share else sorted(allowed)
         try:
             cpu_sweep = host_cpu_sweep(fd, items, n_threads, local_rank, opt, bpsw_hip.RESCUE_C, ext_entry == "stage_commit", pool,

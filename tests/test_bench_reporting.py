@@ -66,3 +66,12 @@ def test_committed_counter_files_parse_and_carry_what_the_line_quotes():
     sa = bench.load_committed_json(f"{bench.PROFILE_TAG}_sq_activity.json")
     assert "extend" in sa and "swalign2" in sa
     json.dumps([issue, traffic, sa])
+
+
+def test_the_committed_cpu_sweep_is_there_and_monotone():
+    """host.reads_per_s_vs_cpus of the default line comes from profiles/<tag>_cpu_sweep.json (python bench.py --cpu-sweep measures it live)"""
+    sw = bench.load_committed_json(f"{bench.PROFILE_TAG}_cpu_sweep.json")
+    pts = sw["reads_per_s_vs_cpus"]
+    rates = [pts[k]["reads_per_s"] for k in sorted(pts, key=int)]
+    assert len(rates) >= 3 and all(b >= a for a, b in zip(rates, rates[1:])), rates
+    assert sw["unconfined"]["reads_per_s"] > 0
