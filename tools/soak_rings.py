@@ -93,5 +93,6 @@ while any(th.is_alive() for th in threads):
         os._exit(3)
 c = bpsw_hip.Context(0)
 print("SOAK_RINGS", {"seconds": round(time.time() - t0, 1), "threads": T, "extend_calls": counts[0], "sw_batches": counts[1], "groups": counts[2],
-                     "contexts_recreated": counts[3], "ext_ring_and_rescue_ring_stats": c.ring_stats(), "errors": errors[:3]})
+                     "contexts_recreated": counts[3], "ext_ring_and_rescue_ring_stats": c.ring_stats(),
+                     "ring_integrity_on_checked_faults": c.ring_integrity(), "errors": errors[:3]})
 sys.exit(1 if errors else 0)
