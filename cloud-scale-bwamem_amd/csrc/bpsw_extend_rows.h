@@ -582,6 +582,17 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
 #ifndef BPSW_ROWS_UNIQ
 #define BPSW_ROWS_UNIQ 1
 #endif
+// ... unless the band already ends at the query end: `end` never exceeds qLen (a zero cell can pull it back, it then grows by one a row up
+// to qLen again) and qLen - base fits the window, so the run is bounded by its other limits only.  Without this a flank whose band
+// sat near the window's top left the loop every few rows for a dispatcher pass that moved nothing (round 6).
+#ifndef BPSW_ROWS_ATQ
+#define BPSW_ROWS_ATQ 1
+#endif
+#if BPSW_ROWS_ATQ
+#define ROWSF_ROOM_ATQ "s_cmp_eq_u32 %[end], %[qlen]\n\ts_cselect_b32 %[fastend], %[hardend], %[fastend]\n\t"
+#else
+#define ROWSF_ROOM_ATQ
+#endif
 #define ROWS_GSCAN_(V, NOP) \
       "v_max_i32_dpp " V ", " V ", " V " row_shr:1 row_mask:0xf bank_mask:0xf\n\t" NOP \
       "v_max_i32_dpp " V ", " V ", " V " row_shr:2 row_mask:0xf bank_mask:0xf\n\t" NOP \
@@ -820,17 +831,8 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "s_cmp_le_i32 %[t1], %[gskey]\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t" \
       "L_ttgo" SFX "_%=:\n\t"
-#define ROWS1F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
-      /* the band's set-up, only when the band is not simply last row's (LIVE: unchanged at the query end) or last row's moved up by */ \
-      /* one lane (DEAD: the mask is shifted in place) */ \
-      "L_frow" SFX "_%=:\n\t" \
-      "s_sub_i32 %[span], %[end], %[beg]\n\t" \
-      "s_cmp_lt_i32 %[span], 1\n\t" \
-      "s_cbranch_scc1 L_fslow_%=\n\t"  /* an empty band */ \
-      "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
-      "s_bfm_b64 %[act], %[span], m0\n\t"  /* the lanes of the band */ \
-      "L_fbody" SFX "_%=:\n\t" \
-      TAILTOP \
+// The row itself (everything between a body's label and its SWUtil.scala:177-182 step), shared by the two bodies of a fast loop
+#define ROWS1F_ROW(H1STEP, HMAX, HSHIFT) \
       "v_readlane_b32 %[t], %[vTS], %[i]\n\t"  /* 8 * target base of row i */ \
       "s_nop 1\n\t" \
       "v_bfe_i32 %[vS], %[vP], %[t], 8\n\t" \
@@ -848,14 +850,41 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "v_subrev_u32 %[vS], %[oedel], %[vT0]\n\t" \
       "v_max3_i32 %[vE], %[vE], %[vS], 0\n\t"  /* E(i+1,j) */ \
       "v_cndmask_b32 %[vE], 0, %[vE], %[act]\n\t"  /* eh[end].e = 0 */ \
-      HSHIFT  /* eh[j].h = H(i,j-1), eh[beg].h = h1 */ \
-      /* SWUtil.scala:177-182 */ \
-      "s_cmp_lg_u32 %[end], %[qlen]\n\t" \
-      "s_cbranch_scc1 L_fnogs" SFX "_%=\n\t" \
+      HSHIFT  /* eh[j].h = H(i,j-1), eh[beg].h = h1 */
+#define ROWS1F_GSCORE \
       "v_lshl_or_b32 %[vS], %[vH], 16, %[i]\n\t"  /* H(i,j-1) << 16 | i */ \
       "s_sub_i32 %[t2], %[end], %[base]\n\t" \
       "v_readlane_b32 %[t1], %[vS], %[t2]\n\t"  /* lane end - base: H(i, qLen-1) */ \
-      "s_max_i32 %[gskey], %[gskey], %[t1]\n\t" \
+      "s_max_i32 %[gskey], %[gskey], %[t1]\n\t"
+// The second body of a fast loop (round 6, BPSW_ROWS_ATQ): rows whose band ENDS AT THE QUERY END and is last row's (LIVE) or last row's
+// moved up by one lane (DEAD) -- three rows in four of a 2x150 bp batch.  Such a row is only ever entered from a row that has just
+// established end == qLen, so it needs neither the test in front of the gscore step nor the one that decides whether `end` grows:
+// four instructions fewer.  Everything out of line (the key scan, the z-drop tests, the trimming on a zero cell) is shared with the
+// first body and returns to IT, which makes no assumption.
+#define ROWS1F_QBODY(SFX, H1STEP, HMAX, HSHIFT, NB0Q) \
+      "L_fbodyq" SFX "_%=:\n\t" \
+      ROWS1F_ROW(H1STEP, HMAX, HSHIFT) \
+      ROWS1F_GSCORE \
+      ROWS1F_DECIDE(SFX) \
+      "s_and_b64 %[z], vcc, %[act]\n\t"  /* the zero cells of the band; SCC = there are some */ \
+      "s_cbranch_scc1 L_fzero" SFX "_%=\n\t" \
+      NB0Q
+#define ROWS1F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH, TAIL_MIN, TAIL_SWITCH, TAILTOP, QBODY) \
+      /* the band's set-up, only when the band is not simply last row's (LIVE: unchanged at the query end) or last row's moved up by */ \
+      /* one lane (DEAD: the mask is shifted in place) */ \
+      "L_frow" SFX "_%=:\n\t" \
+      "s_sub_i32 %[span], %[end], %[beg]\n\t" \
+      "s_cmp_lt_i32 %[span], 1\n\t" \
+      "s_cbranch_scc1 L_fslow_%=\n\t"  /* an empty band */ \
+      "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
+      "s_bfm_b64 %[act], %[span], m0\n\t"  /* the lanes of the band */ \
+      "L_fbody" SFX "_%=:\n\t" \
+      TAILTOP \
+      ROWS1F_ROW(H1STEP, HMAX, HSHIFT) \
+      /* SWUtil.scala:177-182 */ \
+      "s_cmp_lg_u32 %[end], %[qlen]\n\t" \
+      "s_cbranch_scc1 L_fnogs" SFX "_%=\n\t" \
+      ROWS1F_GSCORE \
       "L_fnogs" SFX "_%=:\n\t" \
       ROWS1F_DECIDE(SFX) \
       "L_ftrim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214 */ \
@@ -917,10 +946,11 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "s_mov_b32 %[base], %[beg]\n\t" \
       "s_add_i32 %[b65], %[beg], 65\n\t" \
       "s_waitcnt lgkmcnt(0)\n\t" \
-      "L_froom" SFX "_%=:\n\t"  /* t1 = end - base <= 63: 64 - t1 rows can run before `end` can leave the window */ \
+      "L_froom" SFX "_%=:\n\t"  /* t1 = end - base <= 63: 64 - t1 rows can run before `end` can leave the window ... */ \
       "s_sub_i32 %[t1], 64, %[t1]\n\t" \
       "s_add_i32 %[fastend], %[i], %[t1]\n\t" \
       "s_min_i32 %[fastend], %[fastend], %[hardend]\n\t" \
+      ROWSF_ROOM_ATQ \
       "s_branch L_frow" SFX "_%=\n\t" \
       "L_fzero" SFX "_%=:\n\t" \
       "s_add_i32 %[mja], %[mj], %[base]\n\t" \
@@ -973,24 +1003,37 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
       "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
       "s_cmp_gt_i32 %[t4], %[zlim]\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t" \
-      "s_branch L_ftrim" SFX "_%=\n\t"
-#define ROWS1F_LIVE_(SFX, DEADSFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
-  ROWS1F_TEXT(SFX, "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", "v_max_i32 %[vT0], %[vA], %[vS]\n\t", \
-              "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %[vH], %[h1raw], m0\n\t", \
+      "s_branch L_ftrim" SFX "_%=\n\t" \
+      QBODY
+#define ROWS1F_LIVE_H1STEP "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t"
+#define ROWS1F_LIVE_HMAX "v_max_i32 %[vT0], %[vA], %[vS]\n\t"
+#define ROWS1F_LIVE_HSHIFT "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_writelane_b32 %[vH], %[h1raw], m0\n\t"
+// QT: where a row goes on whose band is this row's and ends at the query end ("L_fbodyq" with the second body, "L_fbody" without)
+#define ROWS1F_LIVE_(SFX, DEADSFX, TAIL_MIN, TAIL_SWITCH, TAILTOP, QT, QBODY) \
+  ROWS1F_TEXT(SFX, ROWS1F_LIVE_H1STEP, ROWS1F_LIVE_HMAX, ROWS1F_LIVE_HSHIFT, \
               /* beg stays; end at the query end: the next row's band is this row's */ \
               "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
               "s_cbranch_scc1 L_fgrow" SFX "_%=\n\t" \
               "s_add_i32 %[i], %[i], 1\n\t" \
               "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
-              "s_cbranch_scc1 L_fbody" SFX "_%=\n\t" \
+              "s_cbranch_scc1 " QT SFX "_%=\n\t" \
               "s_branch L_fbound" SFX "_%=\n\t" \
               "L_fgrow" SFX "_%=:\n\t" \
               "s_add_i32 %[end], %[end], 1\n\t", \
               "s_mov_b32 %[t3], %[beg]\n\t", "s_min_i32 %[hardend], %[hardend], %[ih1z]\n\t", \
-              "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_fbound" DEADSFX "_%=\n\t", TAIL_MIN, TAIL_SWITCH, TAILTOP)
-#define ROWS1F_DEAD_(SFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
-  ROWS1F_TEXT(SFX, "s_nop 0\n\t", "v_max3_i32 %[vT0], %[vA], %[vS], 0\n\t", \
-              "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t", \
+              "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_fbound" DEADSFX "_%=\n\t", TAIL_MIN, TAIL_SWITCH, TAILTOP, QBODY)
+#define ROWS1F_LIVE_QBODY(SFX) \
+  ROWS1F_QBODY(SFX, ROWS1F_LIVE_H1STEP, ROWS1F_LIVE_HMAX, ROWS1F_LIVE_HSHIFT, \
+               "s_add_i32 %[i], %[i], 1\n\t" \
+               "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
+               "s_cbranch_scc1 L_fbodyq" SFX "_%=\n\t" \
+               "s_branch L_fbound" SFX "_%=\n\t")
+#define ROWS1F_DEAD_H1STEP "s_nop 0\n\t"
+#define ROWS1F_DEAD_HMAX "v_max3_i32 %[vT0], %[vA], %[vS], 0\n\t"
+#define ROWS1F_DEAD_HSHIFT "v_mov_b32_dpp %[vH], %[vT0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+// QSH: where a row goes on whose band ends at the query end after its mask has moved up ("L_fshq": the second body's row step; "L_fsh")
+#define ROWS1F_DEAD_(SFX, TAIL_MIN, TAIL_SWITCH, TAILTOP, QSH, QBODY) \
+  ROWS1F_TEXT(SFX, ROWS1F_DEAD_H1STEP, ROWS1F_DEAD_HMAX, ROWS1F_DEAD_HSHIFT, \
               /* beg + 1, and end + 1 below the query end: the band moves up by one lane (or loses its first column) -- the mask follows */ \
               "s_add_i32 %[beg], %[beg], 1\n\t" \
               "s_cmp_lt_i32 %[end], %[qlen]\n\t" \
@@ -1005,14 +1048,36 @@ __device__ __forceinline__ int rows_cpp4(RowState& st, Row4& q, const int lane_a
               "L_fatq" SFX "_%=:\n\t" \
               "s_lshl_b64 %[u64], %[act], 1\n\t" \
               "s_and_b64 %[act], %[act], %[u64]\n\t" \
-              "s_cbranch_scc1 L_fsh" SFX "_%=\n\t",  /* (an empty band: through the set-up, which leaves the loop) */ \
-              "s_add_i32 %[t3], %[beg], 1\n\t", "", "", TAIL_MIN, TAIL_SWITCH, TAILTOP)
+              "s_cbranch_scc1 " QSH SFX "_%=\n\t",  /* (an empty band: through the set-up, which leaves the loop) */ \
+              "s_add_i32 %[t3], %[beg], 1\n\t", "", "", TAIL_MIN, TAIL_SWITCH, TAILTOP, QBODY)
+#define ROWS1F_DEAD_QBODY(SFX) \
+  ROWS1F_QBODY(SFX, ROWS1F_DEAD_H1STEP, ROWS1F_DEAD_HMAX, ROWS1F_DEAD_HSHIFT, \
+               "s_add_i32 %[beg], %[beg], 1\n\t" \
+               "s_lshl_b64 %[u64], %[act], 1\n\t" \
+               "s_and_b64 %[act], %[act], %[u64]\n\t" \
+               "s_cbranch_scc0 L_fnext" SFX "_%=\n\t"  /* (an empty band: through the set-up, which leaves the loop) */ \
+               "L_fshq" SFX "_%=:\n\t" \
+               "s_add_i32 %[i], %[i], 1\n\t" \
+               "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
+               "s_cbranch_scc1 L_fbodyq" SFX "_%=\n\t" \
+               "s_branch L_fbound" SFX "_%=\n\t")
 #define ROWSF_TAILMIN "s_min_i32 %[hardend], %[hardend], %[itail]\n\t"
+#ifndef BPSW_ROWS_ATQ
+#define BPSW_ROWS_ATQ 1
+#endif
+#if BPSW_ROWS_ATQ
 #define ROWS1F_ALL \
-  ROWS1F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_lt_%=\n\t", "") \
-  ROWS1F_DEAD_("_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_dt_%=\n\t", "") \
-  ROWS1F_LIVE_("_lt", "_dt", "", "", ROWSF_TAILTEST("_lt")) \
-  ROWS1F_DEAD_("_dt", "", "", ROWSF_TAILTEST("_dt"))
+  ROWS1F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_lt_%=\n\t", "", "L_fbodyq", ROWS1F_LIVE_QBODY("_l")) \
+  ROWS1F_DEAD_("_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_dt_%=\n\t", "", "L_fshq", ROWS1F_DEAD_QBODY("_d")) \
+  ROWS1F_LIVE_("_lt", "_dt", "", "", ROWSF_TAILTEST("_lt"), "L_fbody", "") \
+  ROWS1F_DEAD_("_dt", "", "", ROWSF_TAILTEST("_dt"), "L_fsh", "")
+#else
+#define ROWS1F_ALL \
+  ROWS1F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_lt_%=\n\t", "", "L_fbody", "") \
+  ROWS1F_DEAD_("_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_fbound_dt_%=\n\t", "", "L_fsh", "") \
+  ROWS1F_LIVE_("_lt", "_dt", "", "", ROWSF_TAILTEST("_lt"), "L_fbody", "") \
+  ROWS1F_DEAD_("_dt", "", "", ROWSF_TAILTEST("_dt"), "L_fsh", "")
+#endif
 // all the instantiations in one statement (two statements under a branch make the compiler route the scalar state through VGPRs):
 // sel 0 = the general loop (ROWS1_TEXT, with or without the tail-row test), 1 = the fast loop in its LIVE phase, 2 = DEAD.
 // Every read-write operand is early-clobber: an input that happens to hold the same value (end and qLen on row 0) must not share
@@ -1319,21 +1384,8 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
 // the column left of the band hands on a 0 by itself -- to an even column through the lane shift (the odd column of the lane
 // below), to an odd column as the even column of its own lane.  gscore reads column qLen - 1 out of the shifted row, whose lane and
 // parity in the window (gsl, gsp) only change when the window moves.
-#define ROWS2F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH, BAND_EXTRA, SAME_BAND, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
-      /* the band's set-up: only when the band has changed (in the LIVE phase a row without a zero cell leaves beg where it is, and */ \
-      /* end as well once it has reached the query end -- most rows of a flank whose score is high) */ \
-      "L_g2row" SFX "_%=:\n\t" \
-      "s_sub_i32 %[span], %[end], %[beg]\n\t" \
-      "s_cmp_lt_i32 %[span], %[narrow1]\n\t" \
-      "s_cbranch_scc1 L_fslow_%=\n\t"  /* an empty band, or one that fits one column per lane again */ \
-      "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
-      "v_subrev_u32 %[vT0], m0, %[vL2]\n\t"  /* rel0 = 2 lane - rbeg */ \
-      "v_add_u32 %[vT1], 1, %[vT0]\n\t"  /* rel1 */ \
-      "v_cmp_gt_u32 %[act0], %[span], %[vT0]\n\t" \
-      "v_cmp_gt_u32 %[act1], %[span], %[vT1]\n\t" \
-      BAND_EXTRA \
-      "L_g2body" SFX "_%=:\n\t" \
-      TAILTOP \
+// the two-column row and its gscore step as texts of their own: a fast loop has two bodies (ROWS1F_QBODY tells why)
+#define ROWS2F_ROW(H1STEP, HMAX, HSHIFT) \
       "v_readlane_b32 %[t], %[vTS], %[i]\n\t" \
       "s_nop 1\n\t" \
       "v_bfe_i32 %[vS0], %[vP0], %[t], 8\n\t" \
@@ -1363,10 +1415,8 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
       "v_subrev_u32 %[vS1], %[oedel], %[vA1]\n\t" \
       "v_max3_i32 %[vE1], %[vE1], %[vS1], 0\n\t" \
       "v_cndmask_b32 %[vE1], 0, %[vE1], %[act1]\n\t" \
-      HSHIFT  /* eh[j].h = H(i,j-1): even column <- odd of the lane below, odd column <- even of the same lane; eh[beg].h = h1 */ \
-      /* SWUtil.scala:177-182 */ \
-      "s_cmp_lg_u32 %[end], %[qlen]\n\t" \
-      "s_cbranch_scc1 L_g2nogs" SFX "_%=\n\t" \
+      HSHIFT  /* eh[j].h = H(i,j-1): even column <- odd of the lane below, odd column <- even of the same lane; eh[beg].h = h1 */
+#define ROWS2F_GSCORE(SFX) \
       "s_cmp_eq_u32 %[gsp], 0\n\t" \
       "s_cbranch_scc0 L_g2gsodd" SFX "_%=\n\t" \
       "v_lshl_or_b32 %[vS0], %[vH0], 16, %[i]\n\t"  /* H(i, qLen-1) << 16 | i */ \
@@ -1379,7 +1429,39 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
       "s_nop 0\n\t" \
       "v_readlane_b32 %[t1], %[vS0], %[gsl]\n\t" \
       "s_max_i32 %[gskey], %[gskey], %[t1]\n\t" \
-      "L_g2nogs" SFX "_%=:\n\t" \
+      "L_g2nogs" SFX "_%=:\n\t"
+// the second body (LIVE phase only: a DEAD row's band moves and goes through the set-up): QS = the body's own label suffix
+#define ROWS2F_QBODY(SFX, QS, H1STEP, HMAX, HSHIFT) \
+      "L_g2bodyq" SFX "_%=:\n\t" \
+      ROWS2F_ROW(H1STEP, HMAX, HSHIFT) \
+      ROWS2F_GSCORE(QS) \
+      ROWS2F_DECIDE(SFX) \
+      "s_or_b64 %[u64], %[z0], %[z1]\n\t"  /* SCC = the band has a zero cell */ \
+      "s_cbranch_scc1 L_g2zero" SFX "_%=\n\t" \
+      "s_add_i32 %[i], %[i], 1\n\t" \
+      "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
+      "s_cbranch_scc1 L_g2bodyq" SFX "_%=\n\t" \
+      "s_branch L_g2bound" SFX "_%=\n\t"
+#define ROWS2F_TEXT(SFX, H1STEP, HMAX, HSHIFT, NB0_NOZERO, NB0_ZERO, PHASE_MIN, PHASE_SWITCH, BAND_EXTRA, SAME_BAND, TAIL_MIN, TAIL_SWITCH, TAILTOP, QBODY) \
+      /* the band's set-up: only when the band has changed (in the LIVE phase a row without a zero cell leaves beg where it is, and */ \
+      /* end as well once it has reached the query end -- most rows of a flank whose score is high) */ \
+      "L_g2row" SFX "_%=:\n\t" \
+      "s_sub_i32 %[span], %[end], %[beg]\n\t" \
+      "s_cmp_lt_i32 %[span], %[narrow1]\n\t" \
+      "s_cbranch_scc1 L_fslow_%=\n\t"  /* an empty band, or one that fits one column per lane again */ \
+      "s_sub_i32 m0, %[beg], %[base]\n\t"  /* rbeg */ \
+      "v_subrev_u32 %[vT0], m0, %[vL2]\n\t"  /* rel0 = 2 lane - rbeg */ \
+      "v_add_u32 %[vT1], 1, %[vT0]\n\t"  /* rel1 */ \
+      "v_cmp_gt_u32 %[act0], %[span], %[vT0]\n\t" \
+      "v_cmp_gt_u32 %[act1], %[span], %[vT1]\n\t" \
+      BAND_EXTRA \
+      "L_g2body" SFX "_%=:\n\t" \
+      TAILTOP \
+      ROWS2F_ROW(H1STEP, HMAX, HSHIFT) \
+      /* SWUtil.scala:177-182 */ \
+      "s_cmp_lg_u32 %[end], %[qlen]\n\t" \
+      "s_cbranch_scc1 L_g2nogs" SFX "_%=\n\t" \
+      ROWS2F_GSCORE(SFX) \
       ROWS2F_DECIDE(SFX) \
       "L_g2trim" SFX "_%=:\n\t"  /* band trimming, SWUtil.scala:202-214 */ \
       "s_or_b64 %[u64], %[z0], %[z1]\n\t"  /* SCC = the band has a zero cell */ \
@@ -1450,10 +1532,11 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
       "s_lshr_b32 %[gsl], %[t2], 1\n\t" \
       "s_and_b32 %[gsp], %[t2], 1\n\t" \
       "s_waitcnt lgkmcnt(0)\n\t" \
-      "L_g2room" SFX "_%=:\n\t"  /* t1 = end - base <= 127: 128 - t1 rows can run before `end` can leave the window */ \
+      "L_g2room" SFX "_%=:\n\t"  /* t1 = end - base <= 127: 128 - t1 rows can run before `end` can leave the window ... */ \
       "s_sub_i32 %[t1], 128, %[t1]\n\t" \
       "s_add_i32 %[fastend], %[i], %[t1]\n\t" \
       "s_min_i32 %[fastend], %[fastend], %[hardend]\n\t" \
+      ROWSF_ROOM_ATQ \
       "s_branch L_g2row" SFX "_%=\n\t" \
       "L_g2zero" SFX "_%=:\n\t"  /* on the even / odd zero masks (as ROWS2_TEXT) */ \
       /* last zero left of mj: even columns 2l < mj <=> l < (mj+1)>>1; odd columns 2l+1 < mj <=> l < mj>>1 */ \
@@ -1536,14 +1619,17 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
       "s_add_i32 %[t4], %[t4], %[t2]\n\t" \
       "s_cmp_gt_i32 %[t4], %[zlim]\n\t" \
       "s_cbranch_scc1 L_fdone_%=\n\t" \
-      "s_branch L_g2trim" SFX "_%=\n\t"
-#define ROWS2F_LIVE_(SFX, DEADSFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
-  ROWS2F_TEXT(SFX, "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t", \
-              "v_max_i32 %[vA0], %[vA0], %[vS0]\n\tv_max_i32 %[vA1], %[vA1], %[vS1]\n\t", \
+      "s_branch L_g2trim" SFX "_%=\n\t" \
+      QBODY
+#define ROWS2F_LIVE_H1STEP "s_sub_i32 %[h1raw], %[h1raw], %[edel]\n\t"
+#define ROWS2F_LIVE_HMAX "v_max_i32 %[vA0], %[vA0], %[vS0]\n\tv_max_i32 %[vA1], %[vA1], %[vS1]\n\t"
+#define ROWS2F_LIVE_HSHIFT \
               "v_mov_b32 %[vh1], %[h1raw]\n\t" \
               "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
               "v_cndmask_b32 %[vH1], %[vA0], %[vh1], %[inj1]\n\t" \
-              "v_cndmask_b32 %[vH0], %[vH0], %[vh1], %[inj0]\n\t", \
+              "v_cndmask_b32 %[vH0], %[vH0], %[vh1], %[inj0]\n\t"
+#define ROWS2F_LIVE_(SFX, DEADSFX, TAIL_MIN, TAIL_SWITCH, TAILTOP, QT, QBODY) \
+  ROWS2F_TEXT(SFX, ROWS2F_LIVE_H1STEP, ROWS2F_LIVE_HMAX, ROWS2F_LIVE_HSHIFT, \
               "", "s_mov_b32 %[t3], %[beg]\n\t", "s_min_i32 %[hardend], %[hardend], %[ih1z]\n\t", \
               "s_cmp_ge_i32 %[i], %[ih1z]\n\ts_cbranch_scc1 L_g2bound" DEADSFX "_%=\n\t", \
               /* the lanes that take eh[beg].h = h1: column beg is an even or an odd one */ \
@@ -1553,20 +1639,29 @@ __device__ __forceinline__ int rows1_asm(RowState& st, const int lane_arg, const
               "s_cbranch_scc1 L_g2grow" SFX "_%=\n\t" \
               "s_add_i32 %[i], %[i], 1\n\t" \
               "s_cmp_lt_i32 %[i], %[fastend]\n\t" \
-              "s_cbranch_scc1 L_g2body" SFX "_%=\n\t" \
+              "s_cbranch_scc1 " QT SFX "_%=\n\t" \
               "s_branch L_g2bound" SFX "_%=\n\t" \
-              "L_g2grow" SFX "_%=:\n\t", TAIL_MIN, TAIL_SWITCH, TAILTOP)
-#define ROWS2F_DEAD_(SFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) \
+              "L_g2grow" SFX "_%=:\n\t", TAIL_MIN, TAIL_SWITCH, TAILTOP, QBODY)
+#define ROWS2F_LIVE_QBODY(SFX, QS) ROWS2F_QBODY(SFX, QS, ROWS2F_LIVE_H1STEP, ROWS2F_LIVE_HMAX, ROWS2F_LIVE_HSHIFT)
+#define ROWS2F_DEAD_(SFX, TAIL_MIN, TAIL_SWITCH, TAILTOP) /* (no second body: a DEAD row's band moves every row) */ \
   ROWS2F_TEXT(SFX, "", \
               "v_max3_i32 %[vA0], %[vA0], %[vS0], 0\n\tv_max3_i32 %[vA1], %[vA1], %[vS1], 0\n\t", \
               "v_mov_b32_dpp %[vH0], %[vA1] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
               "v_mov_b32 %[vH1], %[vA0]\n\t", \
-              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "", "", "", TAIL_MIN, TAIL_SWITCH, TAILTOP)
+              "s_add_i32 %[beg], %[beg], 1\n\t", "s_add_i32 %[t3], %[beg], 1\n\t", "", "", "", "", TAIL_MIN, TAIL_SWITCH, TAILTOP, "")
+#if BPSW_ROWS_ATQ
 #define ROWS2F_ALL \
-  ROWS2F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_g2bound_lt_%=\n\t", "") \
+  ROWS2F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_g2bound_lt_%=\n\t", "", "L_g2bodyq", ROWS2F_LIVE_QBODY("_l", "_lq")) \
   ROWS2F_DEAD_("_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_g2bound_dt_%=\n\t", "") \
-  ROWS2F_LIVE_("_lt", "_dt", "", "", ROWSF_TAILTEST("_lt2")) \
+  ROWS2F_LIVE_("_lt", "_dt", "", "", ROWSF_TAILTEST("_lt2"), "L_g2body", "") \
   ROWS2F_DEAD_("_dt", "", "", ROWSF_TAILTEST("_dt2"))
+#else
+#define ROWS2F_ALL \
+  ROWS2F_LIVE_("_l", "_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_g2bound_lt_%=\n\t", "", "L_g2body", "") \
+  ROWS2F_DEAD_("_d", ROWSF_TAILMIN, "s_cmp_ge_i32 %[i], %[itail]\n\ts_cbranch_scc1 L_g2bound_dt_%=\n\t", "") \
+  ROWS2F_LIVE_("_lt", "_dt", "", "", ROWSF_TAILTEST("_lt2"), "L_g2body", "") \
+  ROWS2F_DEAD_("_dt", "", "", ROWSF_TAILTEST("_dt2"))
+#endif
 // all the instantiations in one statement, as ROWS1_ASM: sel 0 = the general loop, 1 = the fast loop in its LIVE phase, 2 = DEAD
 #define ROWS2_ASM \
   asm volatile( \
