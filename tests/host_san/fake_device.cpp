@@ -223,12 +223,29 @@ hipError_t launch_swp_resident(int, const RingArgs& A, int, hipStream_t s) {
     for (int r = 0; r < 5; ++r) m.row[r] = pl.mat_row[r];
     unpack_mat(m, mat);
     const uint32_t* packed = (const uint32_t*)(uintptr_t)pl.packed;
+    // Fault injection for the integrity tripwire's own test (tests/test_host_sanitizers.py): FAKE_DEVICE_SW_FAULT="drop:n" -- the n-th
+    // job pair this process's resident kernels take never writes its first record; "late:n" -- it writes it 2 ms after the pair was
+    // counted as done (a completion word that overtook a result, as a violated PCIe ordering would look to the host)
+    static const char* fault = getenv("FAKE_DEVICE_SW_FAULT");
+    static std::atomic<long> units_seen{0};
+    const long nth = units_seen.fetch_add(1) + 1;
+    const bool hit = fault && atol(strchr(fault, ':') ? strchr(fault, ':') + 1 : "0") == nth;
     for (int job = 2 * (int)unit; job < 2 * (int)unit + 2 && job < pl.n_jobs; ++job) {
       const uint32_t* rec = packed + 8 * (size_t)job;
       long long qo, to;
       memcpy(&qo, rec, 8); memcpy(&to, rec + 2, 8);
+      int32_t* dst = (int32_t*)(uintptr_t)pl.out + 7 * (size_t)job;
+      int32_t held[7];
+      const bool faulty = hit && job == 2 * (int)unit;
       play_sw_job((const uint8_t*)(uintptr_t)pl.q_pool, (const uint8_t*)(uintptr_t)pl.t_pool, (const uint8_t*)(uintptr_t)pl.pac, pl.l_pac, qo, to, (int)rec[4],
-                  (int)rec[5], (int)rec[6], mat, pl.a, pl.b, pl.o_del, pl.e_del, pl.o_ins, pl.e_ins, pl.xtra, (int32_t*)(uintptr_t)pl.out + 7 * (size_t)job);
+                  (int)rec[5], (int)rec[6], mat, pl.a, pl.b, pl.o_del, pl.e_del, pl.o_ins, pl.e_ins, pl.xtra, faulty ? held : dst);
+      if (faulty && strncmp(fault, "late", 4) == 0) {
+        std::thread([dst, held]() mutable {
+          timespec ts = {0, 2000000};
+          nanosleep(&ts, nullptr);
+          for (int k = 0; k < 7; ++k) __atomic_store_n(dst + k, held[k], __ATOMIC_RELAXED);
+        }).detach();
+      }
     }
   });
 }
@@ -296,6 +313,9 @@ hipError_t launch_ext_resident(const RingArgs& A, int, hipStream_t s) {
       if (orc_wire_extend((const uint8_t*)(uintptr_t)pl.wire, (size_t)1 << 40, mat, pl.zdrop, pl.zdrop_mode, tmp.data(), &cells) == pl.n_tasks) e->out.swap(tmp);
     });
     if (e->out.empty()) return;
+    static const char* xfault = getenv("FAKE_DEVICE_EXT_FAULT");  // "drop:n": the n-th extension-ring unit of the process leaves its records unwritten
+    static std::atomic<long> xunits{0};
+    if (xfault && atol(strchr(xfault, ':') ? strchr(xfault, ':') + 1 : "0") == xunits.fetch_add(1) + 1) return;
     int16_t* out = (int16_t*)(uintptr_t)pl.out;
     for (int t = (int)unit * pl.per_unit; t < ((int)unit + 1) * pl.per_unit && t < pl.n_tasks; ++t)
       for (int k = 0; k < 10; ++k) __atomic_store_n(out + (size_t)pl.out_stride * (size_t)t + k, e->out[10 * (size_t)t + k], __ATOMIC_RELAXED);

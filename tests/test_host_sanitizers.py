@@ -67,3 +67,75 @@ def test_host_layer_under_thread_sanitizer():
     # (no test that starts a child process: a fork from a multi-threaded process under the thread sanitizer does not come back)
     _run("thread", "libtsan.so", ["test_ring_gpu.py", "test_rescue_gpu.py", "test_tail_gpu.py", "test_concurrency_gpu.py"],
          "32_threads or batches_go or (group_rescue and not 250bp) or tail_pool or concurrent", timeout=800)
+
+
+_FAULT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {orc!r})
+import bpsw_hip
+from bpsw_hip import synth
+import pyoracle as po
+XTRA = po.KSW_XSUBO | po.KSW_XSTART | po.KSW_XBYTE | 19
+orc = po.Oracle()
+mode = sys.argv[1]
+c = bpsw_hip.Context(0)
+if mode in ("sw_drop", "sw_late"):
+    jobs = synth.sw_jobs(10, seed=8800)       # ten jobs: the ring's at the library's defaults
+    want = orc.sw_align2_jobs(orc.default_opt(), XTRA, **jobs)[0]
+    assert np.array_equal(c.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs), want)       # five units, none faulty
+    try:
+        got = c.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs)                            # one of its five units is the faulty one
+        raised = None
+    except bpsw_hip.BpswError as e:
+        got, raised = None, str(e)
+    on, checked, faults = c.ring_integrity()
+    assert on and faults == 1, (on, checked, faults)
+    if mode == "sw_drop":
+        assert raised and "integrity" in raised, raised                 # the record never came: the call fails loudly ...
+        try:
+            c.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs)
+            assert False, "an abandoned context took another call"
+        except bpsw_hip.BpswError as e:
+            assert "gave up a ring batch" in str(e)                      # ... and the context takes no further call
+        c2 = bpsw_hip.Context(0)                                         # a new one does
+        assert np.array_equal(c2.swalign2_batch(bpsw_hip.default_opt(), XTRA, **jobs), want)
+    else:
+        assert raised is None and np.array_equal(got, want)             # late but whole: counted, reported once, results intact
+    print("FAULT_OK", mode, checked, faults)
+else:
+    soa = synth.ext_tasks(48, read_len=150, seed=8801)
+    soa = soa.subset(np.arange(40))
+    wire = bpsw_hip.wire_pack(soa)
+    want = np.asarray(orc.wire_extend(wire)[0]).reshape(-1)
+    before = c.stats().ext_ring_calls
+    got = np.asarray(c.extend_batch(wire)).reshape(-1)                   # unit 7 of this batch is left unwritten ...
+    assert np.array_equal(got, want)                                    # ... and the batch is computed again through a launch
+    on, checked, faults = c.ring_integrity()
+    assert on and faults >= 1 and c.stats().ext_ring_calls == before, (faults, c.stats().ext_ring_calls, before)
+    print("FAULT_OK", mode, checked, faults)
+"""
+
+
+@pytest.mark.parametrize("mode,env", [("sw_drop", {"FAKE_DEVICE_SW_FAULT": "drop:8"}), ("sw_late", {"FAKE_DEVICE_SW_FAULT": "late:10", "FAKE_RING_WORKERS": "1"}),   # (one worker: the tenth pair taken is the second batch's last to finish)
+                                      ("ext_drop", {"FAKE_DEVICE_EXT_FAULT": "drop:7"})])
+def test_the_integrity_tripwire_catches_an_injected_fault(mode, env):
+    """The tripwire's evidence on real hardware is "0 faults"; here the fake device MAKES one (tests/host_san/fake_device.cpp): a rescue
+    record that never arrives (the call fails with BPSW_ERR_DEVICE, the context is abandoned, a new one works), one that arrives 2 ms
+    after its batch's completion word (counted and reported, the results intact), an extension-ring unit left unwritten (the batch is
+    computed again through a launch).  ASan / UBSan build."""
+    rt, stdcpp = _gcc_file("libasan.so"), _gcc_file("libstdc++.so")
+    if not rt or not stdcpp:
+        pytest.skip("libasan.so is not installed with this gcc")
+    r = subprocess.run(["make", "-C", SAN_DIR, "-s", "-j8", "SAN=address,undefined"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    root = os.path.dirname(HERE)
+    e = dict(os.environ, LD_PRELOAD=f"{rt}:{stdcpp}", BPSW_LIB=os.path.join(SAN_DIR, "_build", "libbPSW_hostsan_address_undefined.so"),
+             ASAN_OPTIONS="detect_leaks=0", **env)
+    for v in ("BPSW_TEST_FORCED_PATHS", "BPSW_EXT_SIFT_MIN", "BPSW_RING_LONE_LAUNCH", "BPSW_RING", "BPSW_RING_INTEGRITY"):
+        e.pop(v, None)
+    src = _FAULT.format(pkg=os.path.join(root, "cloud-scale-bwamem_amd"), orc=os.path.join(root, "oracle"))
+    r = subprocess.run([sys.executable, "-c", src, mode], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAULT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RING INTEGRITY" in r.stderr or mode == "ext_drop" and "unwritten records" in r.stderr, r.stderr[-1500:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-3000:]
