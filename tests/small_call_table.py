@@ -123,6 +123,32 @@ def main():
                 "per_caller_rate_vs_reference_core": round(cpu / float(np.mean([it.ms for it in items])), 2) if cpu else None,
                 "ring_batches": int(st.get("ext_ring_calls", 0))})
             F.close()
+    # ... and a MIXED stream on one context, as a task thread of memChainToAlnBatched makes it: a first-round batch of thousands of tasks
+    # (a launch, ~1 ms) then later rounds of a few dozen (the extension ring, ~0.085 ms).  Round 5 kept ONE running estimate of the
+    # device-phase wait for both and napped 0.7 x ~1 ms before its first look at a ring call's completion record (advisor, round 5);
+    # since round 6 the ring waits have estimates of their own (bpsw_ctx::wait_est_ms[4..5]).
+    big = bpsw_hip.wire_pack(synth.ext_tasks(4400, read_len=150, seed=synth.CONFIG_SEED_BASE + 77))
+    smalls = []
+    for j in range(24):
+        s_ = synth.ext_tasks(72, read_len=150, seed=synth.CONFIG_SEED_BASE + 78 + j)
+        smalls.append(bpsw_hip.wire_pack(s_.subset(np.arange(min(64, s_.n)))))
+    for w in [big] + smalls:
+        ctx.extend_batch(w)
+    import gc
+    gc.collect(); gc.disable()
+    try:
+        t_small_alone = timed(lambda w: ctx.extend_batch(w), smalls, 10)
+        t_small_mixed, t_big_mixed, n_small = 0.0, 0.0, 0
+        for _ in range(10):
+            t0 = time.perf_counter(); ctx.extend_batch(big); t_big_mixed += time.perf_counter() - t0
+            for w in smalls[:8]:
+                t0 = time.perf_counter(); ctx.extend_batch(w); t_small_mixed += time.perf_counter() - t0; n_small += 1
+    finally:
+        gc.enable()
+    out["extend_mixed_stream"] = {"small_call_tasks": 64, "big_call_tasks": 4400, "small_ms_in_a_stream_of_small_calls": round(t_small_alone, 4),
+                                  "small_ms_behind_a_big_call_on_the_same_context": round(1e3 * t_small_mixed / n_small, 4),
+                                  "big_ms": round(1e3 * t_big_mixed / 10, 4),
+                                  "note": "one context, one thread: ten rounds of one 4 400-task call followed by eight 64-task calls"}
     out["note"] = ("one calling thread, distinct inputs per call, host buffers in and out; reference C = oracle/_ref (the reference's own ksw_extend2 / "
                    "mem_group_matesw with SSE2 ksw_align2) on one host core of the GPU box; p_resc = 10 % of the pairs need rescue (configs[2])")
     print(json.dumps(out, indent=1))
@@ -140,6 +166,11 @@ def main():
     for r in out["extend_concurrent"]:
         print(f"| {r['callers']} | {r['tasks_per_call']} | {r['ms_per_call_as_a_caller_sees_it']} | {r['calls_per_s_all_callers']} | {r['reference_c_one_core_ms']} | "
               f"{r['per_caller_rate_vs_reference_core']}x | {r['ring_batches']} |")
+
+    m = out["extend_mixed_stream"]
+    print(f"\nmixed stream on one context: a 64-task call takes {m['small_ms_behind_a_big_call_on_the_same_context']} ms behind {m['big_call_tasks']}-task calls "
+          f"({m['big_ms']} ms each), {m['small_ms_in_a_stream_of_small_calls']} ms in a stream of its own kind")
+
 
 if __name__ == "__main__":
     main()
