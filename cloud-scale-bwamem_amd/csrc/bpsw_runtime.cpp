@@ -467,10 +467,11 @@ int bpsw_create(int device, bpsw_ctx_t** out) {
   if (e == hipSuccess) e = c->d_pre.reserve(512);
   // scan records and the self-resetting queue heads of ext_kernel.  On the context's own stream and WAITED FOR: rounds 1-5 had a plain
   // hipMemset here, which for device memory is a fill kernel on the legacy stream that the host does not wait for -- and this library's
-  // streams are non-blocking, so nothing ordered it before the context's first kernel.  When the legacy stream's hardware queue was
-  // busy (eight threads creating contexts beside running calls), the fill landed in the middle of the first extension kernel, cleared
-  // its queue heads and `done` count, the kernel's last wave never put them back, and a later call of the context started from stale
-  // heads: records missing from its result (GPU suite, round 6: test_concurrent_contexts_give_identical_results, one run in a few).
+  // streams are non-blocking, so nothing ordered it before the context's first kernel.  When the legacy stream's hardware queue is
+  // busy (eight threads creating contexts beside running calls) the fill can land in the middle of the first extension kernel, clear
+  // its queue heads and `done` count, so that the kernel's last wave never puts them back and a later call of the context starts from
+  // stale heads: records missing from its result.  (The reading of one failure of test_concurrent_contexts_give_identical_results in
+  // round 6's GPU runs -- found in the code, not reproduced on demand)
   if (e == hipSuccess) e = hipMemsetAsync(c->d_pre.ptr, 0, 512, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = c->h_pre.reserve(512);
