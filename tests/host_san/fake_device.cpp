@@ -11,7 +11,7 @@
 //     planner's speculation and replay with its hand-placed prefetches, the packers, the staging arithmetic, the rings' host half, the
 //     tail pool's hand-offs -- for out-of-bounds accesses, use after free, undefined behaviour and data races.
 //   * memRegToAln jobs are orc_reg2aln, a chain batch orc_chain2aln_batch, a reference fetch orc_bns_get_seq: worker2's tail (plan, emit,
-//     the tail pool's threads) and the round-loop entry run too.  What is not played (coordinate batches of the extension, SWGlobal) fails
+//     the tail pool's threads) and the round-loop entry run too.  What is not played (coordinate batches of the extension) fails
 //     loudly with hipErrorNotSupported: the tests that need it are left out of the sanitizer run (tests/test_host_sanitizers.py names them).
 #include <stdio.h>
 #include <stdlib.h>
@@ -331,7 +331,20 @@ void launch_ref_fetch(const uint8_t* pac, long long l_pac, int n, const long lon
   }
 }
 void launch_global_prepass(const GlobalJobsDev&, size_t, size_t, GlobalPrepass*, hipStream_t) {}
-hipError_t launch_global_kernel(const GlobalJobsDev&, const SwScoring&, int, size_t, int32_t*, int32_t*, uint32_t*, uint8_t*, int, hipStream_t) { return hipErrorNotSupported; }
+// SWGlobal + CIGAR per job through the oracle (bpsw_global.hip: score, operation count -- the true one also when it outgrows max_cigar --, operations)
+hipError_t launch_global_kernel(const GlobalJobsDev& J, const SwScoring& sc, int, size_t, int32_t* score, int32_t* ncigar, uint32_t* cigar, uint8_t*, int, hipStream_t) {
+  int8_t mat[25];
+  unpack_mat(sc.mat, mat);
+  std::vector<uint32_t> cg(1 << 14);
+  for (int j = 0; j < J.n; ++j) {
+    int nc = 0;
+    score[j] = orc_sw_global(J.q_len[j], J.q_pool + J.q_off[j], J.t_len[j], J.t_pool + J.t_off[j], 5, mat, sc.o_del, sc.e_del, sc.o_ins, sc.e_ins, J.w[j], &nc, cg.data(),
+                             (int)cg.size());
+    ncigar[j] = nc;
+    if (nc <= J.max_cigar) memcpy(cigar + (size_t)j * (size_t)J.max_cigar, cg.data(), 4 * (size_t)(nc > 0 ? nc : 0));
+  }
+  return hipSuccess;
+}
 // memRegToAln per job through the oracle (bpsw_reg2aln.hip: what the kernel leaves of a mem_aln_t, its CIGAR and its MD; counts are the
 // true ones also when they outgrow the job's room -- the host resubmits with more)
 hipError_t launch_reg2aln_kernel(const Reg2AlnDev& J, const SwScoring& sc, int, int, int, size_t, Reg2AlnOut* out, uint32_t* out_cigar, uint8_t* out_md, uint8_t*, int,
