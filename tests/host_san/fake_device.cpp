@@ -11,8 +11,9 @@
 //     planner's speculation and replay with its hand-placed prefetches, the packers, the staging arithmetic, the rings' host half, the
 //     tail pool's hand-offs -- for out-of-bounds accesses, use after free, undefined behaviour and data races.
 //   * memRegToAln jobs are orc_reg2aln, a chain batch orc_chain2aln_batch, a reference fetch orc_bns_get_seq: worker2's tail (plan, emit,
-//     the tail pool's threads) and the round-loop entry run too.  What is not played (coordinate batches of the extension) fails
-//     loudly with hipErrorNotSupported: the tests that need it are left out of the sanitizer run (tests/test_host_sanitizers.py names them).
+//     the tail pool's threads) and the round-loop entry run too.  Coordinate batches are decoded here (the flanks looked up in the 2-bit
+//     reference) and run through orc_extension.  What is not played -- the sift kernel's classification (side_how), the device-resident entries
+//     -- is left out of the sanitizer run (tests/test_host_sanitizers.py names the tests).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -250,17 +251,58 @@ hipError_t launch_swp_resident(int, const RingArgs& A, int, hipStream_t s) {
   });
 }
 
-// ---- extension: a byte batch (wire format 1) through orc_wire_extend; every task, whatever list the launch was given
+// a coordinate batch (wire format 2, include/bpsw.h): 40-byte records, the query flanks as nibbles, the target flanks looked up in the
+// 2-bit reference around the seed -- one orc_extension per task
+static bool play_ext_coords(const uint8_t* w, int n, const int8_t mat[25], const ExtScoring& sc, int16_t* tmp) {
+  if (!sc.pac || sc.l_pac <= 0) return false;
+  const auto g16 = [&](size_t at) { return (int)(int16_t)(w[at] | (w[at + 1] << 8)); };
+  const auto g32 = [&](size_t at) { uint32_t v; memcpy(&v, w + at, 4); return v; };
+  std::vector<uint8_t> seq;
+  for (int i = 0; i < n; ++i) {
+    const size_t at = 32 + 40 * (size_t)i;
+    orc_ext_param_t p;
+    memset(&p, 0, sizeof p);
+    p.o_del = (int8_t)w[0]; p.e_del = (int8_t)w[1]; p.o_ins = (int8_t)w[2]; p.e_ins = (int8_t)w[3];
+    p.pen_clip5 = (int8_t)w[4]; p.pen_clip3 = (int8_t)w[5]; p.w = (int8_t)w[6];
+    p.left_qlen = g16(at); p.left_rlen = g16(at + 2); p.right_qlen = g16(at + 4); p.right_rlen = g16(at + 6);
+    const size_t pos = (size_t)g32(at + 8) * 4;
+    p.reg_score = g16(at + 12); p.q_beg = g16(at + 14); p.h0 = g16(at + 16);
+    const int seed_len = g16(at + 18);
+    p.idx = (int32_t)g32(at + 28);
+    long long rb;
+    memcpy(&rb, w + at + 32, 8);
+    p.zdrop = sc.zdrop; p.mat = mat;
+    const int nq = p.left_qlen + p.right_qlen;
+    seq.assign((size_t)(nq + p.left_rlen + p.right_rlen + 8), 0);
+    for (int j = 0; j < nq; ++j) seq[(size_t)j] = (uint8_t)((g32(pos + 4 * (size_t)(j >> 3)) >> (28 - 4 * (j & 7))) & 0xF);
+    uint8_t* lr = seq.data() + nq;
+    uint8_t* rr = lr + p.left_rlen;
+    for (int j = 0; j < p.left_rlen; ++j) lr[j] = ref_base(sc.pac, sc.l_pac, rb - 1 - j);
+    for (int j = 0; j < p.right_rlen; ++j) rr[j] = ref_base(sc.pac, sc.l_pac, rb + seed_len + j);
+    p.left_qs = seq.data(); p.right_qs = seq.data() + p.left_qlen; p.left_rs = lr; p.right_rs = rr;
+    orc_ext_ret_t r;
+    int64_t cells = 0;
+    orc_extension(&p, sc.zdrop_mode, &r, &cells);
+    int16_t* o = tmp + 10 * (size_t)i;  // MemChainToAlignBatched.scala:181-188
+    o[0] = (int16_t)(r.idx & 0xffff); o[1] = (int16_t)((r.idx >> 16) & 0xffff);
+    o[2] = (int16_t)r.q_beg; o[3] = (int16_t)r.q_end; o[4] = (int16_t)r.r_beg; o[5] = (int16_t)r.r_end;
+    o[6] = (int16_t)r.score; o[7] = (int16_t)r.true_score; o[8] = (int16_t)r.width; o[9] = 0;
+  }
+  return true;
+}
+// ---- extension: a byte batch (wire format 1) through orc_wire_extend, a coordinate batch through play_ext_coords; every task, whatever
+// list the launch was given
 static hipError_t play_ext(const uint32_t* wire, int16_t* out, const ExtScoring& sc, int only_from, int only_to) {
   const uint8_t* w = (const uint8_t*)wire;
-  if (w[7] != 0 && w[7] != 1) return hipErrorNotSupported;  // a coordinate batch
   int32_t n;
   memcpy(&n, w + 8, 4);
   int8_t mat[25];
   unpack_mat(sc.mat, mat);
   std::vector<int16_t> tmp(10 * (size_t)(n > 0 ? n : 1));
   int64_t cells = 0;
-  if (orc_wire_extend(w, (size_t)1 << 40, mat, sc.zdrop, sc.zdrop_mode, tmp.data(), &cells) != n) return hipErrorInvalidValue;
+  if (w[7] == BPSW_WIRE_COORDS) {
+    if (!play_ext_coords(w, n, mat, sc, tmp.data())) return hipErrorInvalidValue;
+  } else if (orc_wire_extend(w, (size_t)1 << 40, mat, sc.zdrop, sc.zdrop_mode, tmp.data(), &cells) != n) return hipErrorInvalidValue;
   for (int t = only_from; t < only_to && t < n; ++t)
     for (int k = 0; k < 10; ++k) __atomic_store_n(out + (size_t)sc.out_stride * (size_t)t + k, tmp[10 * (size_t)t + k], __ATOMIC_RELAXED);
   return hipSuccess;
@@ -293,7 +335,6 @@ hipError_t launch_ext_resident(const RingArgs& A, int, hipStream_t s) {
     ExtRingPayload pl;
     memcpy(&head, word, sizeof head);
     memcpy(&pl, word + sizeof(RingDescHead) / 4, sizeof pl);
-    if (pl.coord) return;  // (not played: the record stays poisoned and the call runs the batch again through a launch, which says "not supported")
     std::shared_ptr<ExtBatchPlay> e;
     const auto key = std::make_pair(head.done_ptr, head.done_value);
     {
@@ -310,7 +351,12 @@ hipError_t launch_ext_resident(const RingArgs& A, int, hipStream_t s) {
       unpack_mat(m, mat);
       std::vector<int16_t> tmp(10 * (size_t)(pl.n_tasks > 0 ? pl.n_tasks : 1));
       int64_t cells = 0;
-      if (orc_wire_extend((const uint8_t*)(uintptr_t)pl.wire, (size_t)1 << 40, mat, pl.zdrop, pl.zdrop_mode, tmp.data(), &cells) == pl.n_tasks) e->out.swap(tmp);
+      if (pl.coord) {
+        ExtScoring sc;
+        memset(&sc, 0, sizeof sc);
+        sc.zdrop = pl.zdrop; sc.zdrop_mode = pl.zdrop_mode; sc.pac = (const uint8_t*)(uintptr_t)pl.pac; sc.l_pac = pl.l_pac;
+        if (play_ext_coords((const uint8_t*)(uintptr_t)pl.wire, pl.n_tasks, mat, sc, tmp.data())) e->out.swap(tmp);
+      } else if (orc_wire_extend((const uint8_t*)(uintptr_t)pl.wire, (size_t)1 << 40, mat, pl.zdrop, pl.zdrop_mode, tmp.data(), &cells) == pl.n_tasks) e->out.swap(tmp);
     });
     if (e->out.empty()) return;
     static const char* xfault = getenv("FAKE_DEVICE_EXT_FAULT");  // "drop:n": the n-th extension-ring unit of the process leaves its records unwritten
