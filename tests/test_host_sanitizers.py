@@ -59,8 +59,8 @@ def test_host_layer_under_address_and_ub_sanitizers():
     out = _run("address,undefined", "libasan.so",
                ["test_rescue_gpu.py", "test_jni_shim.py", "test_swalign_gpu.py", "test_ring_gpu.py", "test_host_path_gpu.py", "test_extend_gpu.py",
                 "test_tail_gpu.py", "test_chain2aln_gpu.py", "test_concurrency_gpu.py", "test_ref_gpu.py", "test_global_gpu.py",
-                "test_extend_coords_gpu.py", "test_large_genome_gpu.py", "test_ext_ring_gpu.py"],
-               NOT_PLAYED + " and not 32_threads and not sift_kernel_on and not (test_ext_ring_gpu and not tiny_extension_ring)")
+                "test_extend_coords_gpu.py", "test_large_genome_gpu.py"],   # (tests/test_ext_ring_gpu.py passes too: 80 s, left to manual runs)
+               NOT_PLAYED + " and not 32_threads and not sift_kernel_on")
     assert int(out.strip().splitlines()[-1].split()[0]) >= 135    # (tests that ran against the sanitizer build)
 
 
