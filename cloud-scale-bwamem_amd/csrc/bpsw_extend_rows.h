@@ -1798,7 +1798,11 @@ __device__ __forceinline__ int rows_wide_phase(RowState& st, Row4& q, const int 
 }
 
 // SWExtend on the adaptive window, for flanks of up to 255 bases: one, two or -- bands wider than 127 columns, round 5 -- four columns
-// per lane.  *overflow is never set any more (256 columns hold every band of such a flank); the parameter stays for the callers' sake.
+// per lane.  *overflow is set in ONE place only -- a band that is wider than 127 columns at the very moment it leaves the one-column
+// layout (the two-column window could not take it): a band grows by a column a row, so this is not reachable from a 64-column window, and
+// no input has been found that gets there (advisor, round 5).  Should it ever happen the launched short kernel defers the task to the full
+// kernel; the resident one has no list to defer to, leaves the record unwritten, and the rings' integrity check (bpsw_ring.cpp) has the
+// batch computed again through a launch.
 template <class QC>
 __device__ ExtRes sw_extend_adaptive(const int lane, const int qLen, const int tLen, const QC& qcode, const uint8_t* __restrict__ ts,
                                      const ProfLds& pl, const MatRows& mat, const int oDel, const int eDel, const int oIns, const int eIns, const int w,
