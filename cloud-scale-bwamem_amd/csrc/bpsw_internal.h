@@ -154,6 +154,9 @@ bool ring_enabled();
 bool ring_usable(int device, int c_class);  // false once that ring has failed: its callers take a launch per batch again
 int ring_submit(int device, int c_class, int num_cu, const RingDesc& desc);
 int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, double* est_ms);
+// ring_wait's "take a launch of your own": the ring of this class failed to LAUNCH an epoch (no resident kernel exists) and the caller's
+// descriptor is among those nobody consumed -- nothing will ever run it, and nothing of it has reached the device (internal code, > 0)
+constexpr int BPSW_RING_RELAUNCH = 1001;
 double ring_ticks_per_ms(int device, int c_class);
 // the integrity tripwire (bpsw_ring.cpp): poison `n_records` records of `stride_words` words each at their first word (and at
 // `second_word_offset` when not 0) before publishing; afterwards every record must have been overwritten

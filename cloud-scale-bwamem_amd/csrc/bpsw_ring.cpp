@@ -23,6 +23,7 @@ struct RingService {
   int pause_depth = 0;
   int device = 0, c_class = 0;
   bool inited = false, running = false, broken = false;
+  bool launch_failed = false;  // broken because an epoch could not be launched: the descriptors at h_desc[0..published) will never be consumed
   uint32_t epoch = 0, published = 0, capacity = 0;
   uint32_t carry_from = 0, carry_n = 0;  // descriptors of a closed epoch the device did not consume
   RingHostCtl* H = nullptr;
@@ -95,6 +96,7 @@ int start_epoch(RingService& S) {
   ++S.epoch;
   if (S.epoch >= 0xffffffu) S.epoch = 1;
   if (S.carry_n && S.carry_from) memmove(S.h_desc, S.h_desc + S.carry_from, sizeof(RingDesc) * (size_t)S.carry_n);
+  const uint32_t carrying = S.carry_n;
   S.carried += S.carry_n;
   S.published = S.carry_n;
   S.carry_from = S.carry_n = 0;
@@ -150,9 +152,13 @@ int start_epoch(RingService& S) {
   // go on with a launch per batch)
   static const int fail_at = env_int("BPSW_RING_TEST_FAIL_LAUNCH", 0);
   if (e == hipSuccess && fail_at > 0 && S.epochs + 1 == (uint64_t)fail_at) e = hipErrorLaunchFailure;
+  // (... and BPSW_RING_TEST_FAIL_CARRY_LAUNCH=1: the first epoch launch of a ring that CARRIES descriptors over "fails": their waiters --
+  // other threads than the one in here -- must end up with launches of their own too: tests/ring_host)
+  static const int fail_carry = env_int("BPSW_RING_TEST_FAIL_CARRY_LAUNCH", 0);
+  if (e == hipSuccess && fail_carry > 0 && carrying > 0) e = hipErrorLaunchFailure;
   if (e == hipSuccess) e = S.c_class == RING_CLASS_EXT ? launch_ext_resident(A, S.blocks, S.stream) : launch_swp_resident(S.c_class, A, S.blocks, S.stream);
   if (e == hipSuccess) { e = hipEventRecord(S.ev_end[slot], S.stream); S.ev_pending[slot] = e == hipSuccess; }
-  if (e != hipSuccess) { S.broken = true; return hip_fail_ring(e, "epoch launch"); }
+  if (e != hipSuccess) { S.broken = true; S.launch_failed = true; return hip_fail_ring(e, "epoch launch"); }
   S.running = true;
   ++S.epochs;
   return BPSW_OK;
@@ -268,6 +274,22 @@ int ring_poke(int device, int c_class) {
   return BPSW_OK;
 }
 
+// (caller holds nothing)  Is the batch that completes `done` with `value` among the descriptors no kernel will ever consume?  True only for a
+// ring whose epoch LAUNCH failed (no resident kernel exists: start_epoch had moved the closed epoch's unconsumed descriptors to the front
+// of the ring before the launch that failed, and later submitters were turned away).  The waiters of those descriptors used to get
+// BPSW_ERR_DEVICE from ring_poke while only the thread that met the failure fell back to a launch (advisor, round 5).
+static bool ring_unconsumed(int device, int c_class, const RingDone* done, uint32_t value) {
+  RingService& S = service(device, c_class);
+  std::lock_guard<std::recursive_mutex> lk(S.mu);
+  if (!S.inited || !S.launch_failed || S.running) return false;
+  for (uint32_t d = 0; d < S.published && d < S.capacity; ++d) {
+    RingDescHead h;
+    memcpy(&h, S.h_desc[d].w, sizeof h);
+    if (h.done_ptr == (uint64_t)(uintptr_t)done && h.done_value == value) return true;
+  }
+  return false;
+}
+
 // Waits until the completion record shows `value`.  est_ms: running average of this caller's waits of the kind (updated).
 int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, double* est_ms) {
   const double t0 = wall_ms();
@@ -282,7 +304,10 @@ int ring_wait(int device, int c_class, const RingDone* done, uint32_t value, dou
     else wait_poll_pause(++polls, waited, est);
     if (waited > next_poke) {
       const int rc = ring_poke(device, c_class);
-      if (rc != BPSW_OK) return rc;
+      if (rc != BPSW_OK) {
+        if (done->value.load(std::memory_order_acquire) == value) break;  // (it had been consumed before the ring broke, and has finished)
+        return ring_unconsumed(device, c_class, done, value) ? BPSW_RING_RELAUNCH : rc;
+      }
       // pokes at 2, 4, 8 ... ms, never further apart than the watchdog's limit (round 5 doubled without bound and tested the limit only at
       // a poke: BPSW_RING_TIMEOUT_MS=20000 fired after 32.8 s)
       next_poke = waited * 2.0;

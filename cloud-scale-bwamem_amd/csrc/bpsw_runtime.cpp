@@ -816,6 +816,7 @@ static int extend_batch_impl(bpsw_ctx_t* c, const uint8_t* wire, size_t wire_byt
       } else {
         if (rc != BPSW_OK) return rc;
         rc = ring_wait(c->device, RING_CLASS_EXT, done, c->ring_seq, &c->wait_est_ms[4]);
+        if (rc == BPSW_RING_RELAUNCH) { copy_first_ms = 0.; goto ring_left; }  // (another thread's epoch launch failed; nobody will run this batch)
         if (rc != BPSW_OK) { c->ring_abandoned = true; return rc; }
         // every record written?  (also the net under a task the resident kernel could not finish -- it has no defer list: a record left
         // as it was would otherwise pass for a result)

@@ -173,6 +173,11 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
     } else {
       if (rc != BPSW_OK) return rc;
       rc = ring_wait(c->device, ring_class, done, c->ring_seq, &c->wait_est_ms[5]);
+      if (rc == BPSW_RING_RELAUNCH) {  // another thread's epoch launch failed while this batch waited to be carried over: nobody will run it
+        ring_class = 0;
+        dev.q_pool = d + st.o_qpool; dev.t_pool = pac_mode ? nullptr : d + st.o_tpool; dev.packed = (const uint32_t*)(d + st.o_packed);
+        goto launch_instead;
+      }
       if (rc != BPSW_OK) { c->ring_abandoned = true; return rc; }  // (the descriptor still names this context's pinned blocks: see bpsw_destroy)
       rc = ring_check((const uint32_t*)k_out, 7, (size_t)n, 6, "rescue job");
       if (rc != BPSW_OK) { c->ring_abandoned = true; return rc; }
@@ -185,6 +190,7 @@ int sw_stage_run(bpsw_ctx* c, const bpsw_opt_t* opt, int xtra, const SwStage& st
       *results = (const int32_t*)c->h_stage_out.ptr;
       return BPSW_OK;
     }
+  launch_instead:;
   }
   {
     struct InFlight { int d; explicit InFlight(int dev) : d(dev) { sw_launch_in_flight(d, 1); } ~InFlight() { sw_launch_in_flight(d, -1); } } in_flight(c->device);

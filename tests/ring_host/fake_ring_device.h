@@ -9,7 +9,9 @@
 //     the closing handshake's sequentially consistent stores and loads            ->  seq_cst, as on the host side
 #pragma once
 #include <sched.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <chrono>
@@ -35,7 +37,17 @@ static void play_poller(const RingArgs A) {  // bpsw_ring_dev.h: ring_poller
     const uint32_t close_req = A.H->close_req.load(std::memory_order_relaxed);
     if (t > A.capacity) t = A.capacity;
     const unsigned long long now = dev_clock();
-    if (t > consumed) {
+    // FAKE_POLLER_LAG_US (tests): a poller that is slow to pick new descriptors up -- a close request that arrives meanwhile then finds
+    // published descriptors unconsumed, which the next epoch has to carry over (the path a failed carry launch is tested on)
+    static const int lag_us = getenv("FAKE_POLLER_LAG_US") ? atoi(getenv("FAKE_POLLER_LAG_US")) : 0;
+    bool asked_meanwhile = false;
+    if (lag_us > 0 && t > consumed) {
+      timespec ts = {0, (long)lag_us * 1000};
+      nanosleep(&ts, nullptr);
+      const uint32_t cr = A.H->close_req.load(std::memory_order_relaxed);
+      asked_meanwhile = cr != 0 && cr == A.epoch;
+    }
+    if (t > consumed && !asked_meanwhile) {
       for (uint32_t d = consumed; d < t; ++d) {
         for (uint32_t w = 0; w < RING_DESC_WORDS; ++w) st(&A.d_desc[d].w[w], A.h_desc[d].w[w]);  // (ordered behind the acquire of the tail)
         st(&A.ctr[d].n_units, A.h_desc[d].w[0]);
